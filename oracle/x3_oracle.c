@@ -1,0 +1,628 @@
+/*
+ * x3_oracle.c -- CPU restatement of the psiphi75/x3-rust encode/decode hot path.
+ * TEST INFRASTRUCTURE ONLY (see x3_oracle.h).  Deliberately structured like the
+ * reference -- a byte-at-a-time MSB-first packer with a per-byte CRC table update, a
+ * per-frame buffer, table-driven Rice codes, a 32-bit look-ahead bit reader -- so that
+ * it also serves as the timed single-thread CPU baseline ("port").
+ *
+ * Paths in comments are relative to /root/reference.
+ */
+#include "x3_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+x3o_rice_code X3O_RICE[4];
+int16_t X3O_INV_RICE[60];
+uint16_t X3O_CRC_TABLE[256];
+static int g_init_done = 0;
+
+/* src/encoder.rs:228-231 */
+static inline uint32_t count_bits(uint32_t n) { return n ? 32u - (uint32_t)__builtin_clz(n) : 0u; }
+
+/*
+ * Tables.  src/x3.rs:200-252 holds them as literals; here they are generated from the
+ * closed form and tests/test_oracle_golden.py checks every entry
+ * against the literals transcribed into tests/golden/rice_tables.json.
+ *   d -> u = d>=0 ? 2d : -2d-1 ; codeword = (u>>k) zeros then (1<<k | (u & (2^k-1))) in k+1 bits
+ *   (nsubs, offset, len, inv_len) = (0,6,14,16) (1,11,22,26) (2,20,40,44) (3,28,56,60)
+ * CRC table: src/crc.rs:22-42, CRC-16/CCITT-FALSE polynomial 0x1021, MSB first.
+ */
+void x3o_init(void) {
+  if (g_init_done) return;
+  static const uint32_t offs[4] = {6, 11, 20, 28}, lens[4] = {14, 22, 40, 56}, invl[4] = {16, 26, 44, 60};
+  for (uint32_t k = 0; k < 4; k++) {
+    x3o_rice_code* rc = &X3O_RICE[k];
+    rc->nsubs = k;
+    rc->offset = offs[k];
+    rc->len = lens[k];
+    rc->inv_len = invl[k];
+    for (uint32_t i = 0; i < rc->len; i++) {
+      int32_t d = (int32_t)i - (int32_t)rc->offset;
+      uint32_t u = d >= 0 ? (uint32_t)(2 * d) : (uint32_t)(-2 * d - 1);
+      rc->code[i] = (1u << k) | (u & ((1u << k) - 1u));
+      rc->num_bits[i] = (u >> k) + 1u + k;
+    }
+  }
+  for (int i = 0; i < 60; i++) X3O_INV_RICE[i] = (int16_t)((i & 1) ? -((i + 1) / 2) : (i / 2));
+  for (uint32_t b = 0; b < 256; b++) {
+    uint16_t c = (uint16_t)(b << 8);
+    for (int j = 0; j < 8; j++) c = (uint16_t)((c & 0x8000) ? ((c << 1) ^ 0x1021) : (c << 1));
+    X3O_CRC_TABLE[b] = c;
+  }
+  g_init_done = 1;
+}
+
+/* ------------------------------------------------------------------ x3.rs */
+
+/* src/x3.rs:124-134 with the constants of :90-96 */
+void x3o_params_default(x3o_params* p) {
+  p->block_len = 20;
+  p->blocks_per_frame = 500;
+  p->codes[0] = 0; p->codes[1] = 1; p->codes[2] = 3;
+  p->thresholds[0] = 3; p->thresholds[1] = 8; p->thresholds[2] = 20;
+}
+
+/* src/x3.rs:98-122: only the first two thresholds are checked (k in 0..2).
+ * RiceCodes::get indexes CODE[4] with the code numbers -> a code > 3 panics there. */
+int x3o_params_new(const x3o_params* p) {
+  x3o_init();
+  for (int k = 0; k < 3; k++)
+    if (p->codes[k] > 3) return X3O_BAD_ARG;
+  for (int k = 0; k < 2; k++)
+    if (p->thresholds[k] > X3O_RICE[p->codes[k]].offset) return X3O_INVALID_ENCODING_THRESH;
+  return X3O_OK;
+}
+
+/* ----------------------------------------------------------------- crc.rs */
+
+/* src/crc.rs:44-47 */
+uint16_t x3o_update_crc16(uint16_t crc, uint8_t data) {
+  uint8_t lookup = (uint8_t)(data ^ (uint8_t)(crc >> 8));
+  return (uint16_t)((uint16_t)(crc << 8) ^ X3O_CRC_TABLE[lookup]);
+}
+
+/* src/crc.rs:49-58 */
+uint16_t x3o_crc16(const uint8_t* data, size_t n) {
+  x3o_init();
+  uint16_t crc = 0xffff;
+  for (size_t i = 0; i < n; i++) crc = x3o_update_crc16(crc, data[i]);
+  return crc;
+}
+
+/* ---------------------------------------------------------- bytewriter.rs */
+
+/* src/bytewriter.rs:33-41 */
+void x3o_writer_init(x3o_writer* w, uint8_t* slice, size_t cap) {
+  w->slice = slice; w->cap = cap; w->p_byte = 0; w->stream_length = 0;
+}
+
+/* src/bytewriter.rs:86-99 */
+int x3o_writer_write_all(x3o_writer* w, const uint8_t* v, size_t n) {
+  if (n > w->cap - w->p_byte) return X3O_BYTE_WRITER_INSUFFICIENT_MEMORY;
+  memcpy(w->slice + w->p_byte, v, n);
+  w->p_byte += n;
+  if (w->p_byte > w->stream_length) w->stream_length = w->p_byte;
+  return X3O_OK;
+}
+
+/* src/bytewriter.rs:44-54 */
+int x3o_writer_align(x3o_writer* w, size_t n) {
+  size_t residual = w->p_byte % n;
+  if (residual == 0) return X3O_OK;
+  static const uint8_t zeros[16] = {0};
+  return x3o_writer_write_all(w, zeros, n - residual);
+}
+
+/* src/bytewriter.rs:60-80 (SeekFrom::Start) */
+int x3o_writer_seek_start(x3o_writer* w, size_t pos) {
+  if (pos > w->cap) return X3O_BYTE_WRITER_INSUFFICIENT_MEMORY;
+  w->p_byte = pos;
+  if (w->p_byte > w->stream_length) w->stream_length = w->p_byte;
+  return X3O_OK;
+}
+
+/* src/bytewriter.rs:60-80 (SeekFrom::Current) */
+int x3o_writer_seek_current(x3o_writer* w, int64_t off) {
+  return x3o_writer_seek_start(w, (size_t)((int64_t)w->p_byte + off));
+}
+
+/* ----------------------------------------------------------- bitpacker.rs */
+
+/* src/bitpacker.rs:65-73 */
+void x3o_bp_new(x3o_bitpacker* bp, x3o_writer* w) {
+  x3o_init();
+  bp->writer = w; bp->scratch_byte = 0; bp->p_bit = 0; bp->byte_len = 0; bp->crc = 0xffff;
+}
+
+/* src/bitpacker.rs:79-86: CRC and length are updated before the 1-byte write */
+static int bp_flush(x3o_bitpacker* bp) {
+  bp->crc = x3o_update_crc16(bp->crc, bp->scratch_byte);
+  bp->byte_len += 1;
+  int rc = x3o_writer_write_all(bp->writer, &bp->scratch_byte, 1);
+  if (rc) return rc;
+  bp->scratch_byte = 0;
+  bp->p_bit = 0;
+  return X3O_OK;
+}
+
+/* src/bitpacker.rs:143-163 (the reference recurses for the straddling case; so do we) */
+int x3o_bp_write_bits(x3o_bitpacker* bp, uint64_t value, size_t num_bits) {
+  size_t rem_bit = 8 - bp->p_bit;
+  uint64_t mask = (num_bits >= 64) ? ~0ull : ((1ull << num_bits) - 1ull);
+  value &= mask;
+  if (num_bits == rem_bit) {
+    bp->scratch_byte |= (uint8_t)value;
+    return bp_flush(bp);
+  } else if (num_bits < rem_bit) {
+    size_t shift_l = rem_bit - num_bits;
+    bp->scratch_byte |= (uint8_t)(value << shift_l);
+    bp->p_bit += num_bits;
+    return X3O_OK;
+  } else {
+    size_t shift_r = num_bits - rem_bit;
+    bp->scratch_byte |= (uint8_t)(value >> shift_r);
+    int rc = bp_flush(bp);
+    if (rc) return rc;
+    return x3o_bp_write_bits(bp, value, shift_r);
+  }
+}
+
+/* src/bitpacker.rs:174-176 */
+int x3o_bp_write_packed_zeros(x3o_bitpacker* bp, size_t num_zeros) {
+  return x3o_bp_write_bits(bp, 0, num_zeros);
+}
+
+/* src/bitpacker.rs:124-132: pad to a byte, then zero BYTES until the writer's ABSOLUTE
+ * position is even; every pad byte goes through flush() so it is in len() and crc() */
+int x3o_bp_word_align(x3o_bitpacker* bp) {
+  int rc;
+  if (bp->p_bit != 0 && (rc = bp_flush(bp))) return rc;
+  while (bp->writer->p_byte % 2 != 0)
+    if ((rc = bp_flush(bp))) return rc;
+  return X3O_OK;
+}
+
+/* src/bitpacker.rs:56-62 */
+int x3o_bp_drop(x3o_bitpacker* bp) {
+  if (bp->p_bit != 0) return bp_flush(bp);
+  return X3O_OK;
+}
+
+/* ------------------------------------------------------------- encoder.rs */
+
+static inline void be16(uint8_t* p, uint16_t v) { p[0] = (uint8_t)(v >> 8); p[1] = (uint8_t)v; }
+
+/* src/encoder.rs:122-162.  Byte 3 ("num channels") is written with `id` (:135); the
+ * 8 time bytes stay zero (:148-150); samples and payload_len are truncated `as u16`. */
+void x3o_write_frame_header(size_t num_samples, uint8_t id, size_t payload_len, uint16_t payload_crc,
+                            uint8_t out[20]) {
+  memset(out, 0, 20);
+  be16(out + 0, 30771); /* FrameHeader::KEY "x3", src/x3.rs:168 */
+  out[2] = id;
+  out[3] = id;
+  be16(out + 4, (uint16_t)num_samples);
+  be16(out + 6, (uint16_t)payload_len);
+  be16(out + 16, x3o_crc16(out, 16));
+  be16(out + 18, payload_crc);
+}
+
+/* src/encoder.rs:233-267 */
+static int encode_rice_block(const int32_t* wav_diff, size_t n, x3o_bitpacker* bp, const x3o_params* p,
+                             int32_t max_abs, size_t* ftype_out) {
+  size_t ftype = 0;
+  for (int t = 0; t < 3; t++)
+    if (max_abs > (int32_t)p->thresholds[t]) ftype += 1;
+  int rc = x3o_bp_write_bits(bp, ftype + 1, 2);
+  if (rc) return rc;
+  /* ftype <= 2 here because max_abs <= thresholds[2] -- unless the thresholds are not
+   * ascending, in which case rice_codes[3] is an index panic in the reference */
+  if (ftype > 2) return X3O_BAD_ARG;
+  const x3o_rice_code* code = &X3O_RICE[p->codes[ftype]];
+  for (size_t i = 0; i < n; i++) {
+    int64_t ii = (int64_t)wav_diff[i] + (int64_t)code->offset;
+    if (ii < 0 || ii >= (int64_t)code->len) return X3O_BAD_ARG; /* reference: index panic */
+    uint32_t c = code->code[ii];
+    uint32_t rc_num_bits = code->num_bits[ii];
+    uint32_t num_zeros = rc_num_bits - count_bits(c);
+    if ((rc = x3o_bp_write_packed_zeros(bp, num_zeros))) return rc;
+    if ((rc = x3o_bp_write_bits(bp, c, rc_num_bits - num_zeros))) return rc;
+  }
+  *ftype_out = code->nsubs;
+  return X3O_OK;
+}
+
+/* src/encoder.rs:269-276 */
+static int encode_bfp_block(const int32_t* wav_diff, size_t n, x3o_bitpacker* bp, size_t num_bits,
+                            size_t* ftype_out) {
+  int rc = x3o_bp_write_bits(bp, num_bits, 6);
+  if (rc) return rc;
+  for (size_t i = 0; i < n; i++)
+    if ((rc = x3o_bp_write_bits(bp, (uint64_t)(int64_t)wav_diff[i], num_bits + 1))) return rc;
+  *ftype_out = 4;
+  return X3O_OK;
+}
+
+/* src/encoder.rs:278-285: literal blocks carry the raw samples, not the diffs */
+static int encode_literal(const int16_t* wav, size_t n, x3o_bitpacker* bp, size_t* ftype_out) {
+  int rc = x3o_bp_write_bits(bp, 15, 6);
+  if (rc) return rc;
+  for (size_t i = 0; i < n; i++)
+    if ((rc = x3o_bp_write_bits(bp, (uint64_t)(int64_t)wav[i], 16))) return rc;
+  *ftype_out = 5;
+  return X3O_OK;
+}
+
+/* src/encoder.rs:289-315 (+ diff :222-225).  `prev` is the sample before wav[0]. */
+int x3o_encode_block(const int16_t* wav, size_t n, int16_t prev, x3o_bitpacker* bp,
+                     const x3o_params* p, size_t* ftype_out) {
+  int32_t wav_diff[60]; /* Parameters::MAX_BLOCK_LENGTH, src/x3.rs:90 */
+  if (n > 60) return X3O_BAD_ARG; /* reference: index panic at :299 */
+  int32_t max_abs = 0;
+  int32_t last = prev;
+  for (size_t i = 0; i < n; i++) {
+    int32_t wd = (int32_t)wav[i] - last;
+    last = wav[i];
+    wav_diff[i] = wd;
+    int32_t a = wd < 0 ? -wd : wd;
+    if (a > max_abs) max_abs = a;
+  }
+  if (max_abs <= (int32_t)p->thresholds[2]) {
+    return encode_rice_block(wav_diff, n, bp, p, max_abs, ftype_out);
+  } else {
+    size_t num_bits = count_bits((uint32_t)max_abs);
+    if (num_bits >= 15) return encode_literal(wav, n, bp, ftype_out);
+    return encode_bfp_block(wav_diff, n, bp, num_bits, ftype_out);
+  }
+}
+
+/* src/encoder.rs:175-214 */
+int x3o_encode_frame(const int16_t* wav, size_t n, x3o_writer* w, const x3o_params* p, uint64_t stats[6]) {
+  int rc;
+  x3o_init();
+  if (n == 0) return X3O_BAD_ARG; /* reference: wav[0] panics */
+  if ((rc = x3o_writer_align(w, 2))) return rc;
+  size_t frame_header_pos = w->p_byte;
+  if ((rc = x3o_writer_seek_current(w, 20))) return rc;
+
+  x3o_bitpacker bp;
+  x3o_bp_new(&bp, w);
+  if ((rc = x3o_bp_write_bits(&bp, (uint64_t)(int64_t)wav[0], 16))) return rc; /* <Audio State> */
+  if (p->block_len == 0 && n > 1) return X3O_BAD_ARG; /* chunks(0) panics */
+  for (size_t s = 1; s < n; s += p->block_len) {
+    size_t bl = n - s < p->block_len ? n - s : p->block_len;
+    size_t ftype = 0;
+    if ((rc = x3o_encode_block(wav + s, bl, wav[s - 1], &bp, p, &ftype))) return rc;
+    stats[ftype] += bl;
+  }
+  if ((rc = x3o_bp_word_align(&bp))) return rc;
+  size_t payload_len = bp.byte_len;
+  uint16_t payload_crc = bp.crc;
+
+  size_t return_position = w->p_byte;
+  if ((rc = x3o_writer_seek_start(w, frame_header_pos))) return rc;
+  uint8_t hdr[20];
+  x3o_write_frame_header(n, 1, payload_len, payload_crc, hdr);
+  if ((rc = x3o_writer_write_all(w, hdr, 20))) return rc;
+  return x3o_writer_seek_start(w, return_position);
+}
+
+/* src/encoder.rs:51-111, std branch (:65-74): the sample iterator is cut into frames of
+ * block_len*blocks_per_frame samples, each copied into its own frame buffer (the
+ * reference's Vec<i16> per frame) and handed to encode_frame.  The writer is a
+ * SliceByteWriter over out[0..out_cap) positioned at start_pos. */
+int x3o_encode(const int16_t* wav, uint64_t n, uint32_t n_channels, const x3o_params* p,
+               uint8_t* out, uint64_t out_cap, uint64_t start_pos, uint64_t* out_pos, uint64_t stats[6]) {
+  x3o_init();
+  if (n_channels > 1) return X3O_MORE_THAN_ONE_CHANNEL;
+  if (n_channels == 0) return X3O_BAD_ARG; /* channels[0] panics */
+  uint64_t st[6] = {0, 0, 0, 0, 0, 0};
+  x3o_writer w;
+  x3o_writer_init(&w, out, out_cap);
+  if (start_pos > out_cap) return X3O_BYTE_WRITER_INSUFFICIENT_MEMORY;
+  w.p_byte = w.stream_length = start_pos;
+  size_t spf = (size_t)p->block_len * (size_t)p->blocks_per_frame;
+  int16_t* frame_buffer = (int16_t*)malloc((spf ? spf : 1) * sizeof(int16_t));
+  int rc = X3O_OK;
+  uint64_t pos = 0;
+  for (;;) {
+    size_t take = (n - pos) < spf ? (size_t)(n - pos) : spf;
+    if (take == 0) break;
+    memcpy(frame_buffer, wav + pos, take * sizeof(int16_t));
+    pos += take;
+    if ((rc = x3o_encode_frame(frame_buffer, take, &w, p, st))) break;
+  }
+  free(frame_buffer);
+  if (out_pos) *out_pos = w.p_byte;
+  if (stats) memcpy(stats, st, sizeof st);
+  return rc;
+}
+
+/* ----------------------------------------------------------- bitreader.rs */
+
+/* src/bitreader.rs:29-49 */
+static inline uint32_t read_word(const uint8_t* array, size_t len, size_t idx, size_t* nread) {
+  if (len - idx >= 4) {
+    *nread = 4;
+    return ((uint32_t)array[idx] << 24) | ((uint32_t)array[idx + 1] << 16) | ((uint32_t)array[idx + 2] << 8) |
+           (uint32_t)array[idx + 3];
+  }
+  size_t remaining = len - idx;
+  uint32_t word = 0;
+  if (remaining >= 1) word |= (uint32_t)array[idx] << 24;
+  if (remaining >= 2) word |= (uint32_t)array[idx + 1] << 16;
+  if (remaining == 3) word |= (uint32_t)array[idx + 2] << 8;
+  *nread = remaining;
+  return word;
+}
+
+/* src/bitreader.rs:65-74 */
+void x3o_br_new(x3o_bitreader* br, const uint8_t* array, size_t len) {
+  size_t idx;
+  br->array = array;
+  br->len = len;
+  br->leading_word = read_word(array, len, 0, &idx);
+  br->idx = idx;
+  br->rem_bit = idx * 8;
+}
+
+/* src/bitreader.rs:148-175 (peek_next + get_next) */
+static inline void br_get_next(x3o_bitreader* br) {
+  if (br->idx >= br->len) {
+    br->leading_word = 0;
+    br->rem_bit = 0;
+  } else {
+    size_t diff;
+    br->leading_word = read_word(br->array, br->len, br->idx, &diff);
+    br->idx += diff;
+    br->rem_bit = diff * 8;
+  }
+}
+
+/* src/bitreader.rs:76-92.  Release-mode Rust masks an over-wide shift amount to its low
+ * 5 bits (the debug_assert is compiled out); `& 31` reproduces that for n >= 32. */
+static inline void br_inc_bits(x3o_bitreader* br, size_t n) {
+  if (n < br->rem_bit) {
+    br->leading_word <<= (n & 31);
+    br->rem_bit -= n;
+  } else if (n > br->rem_bit) {
+    size_t rem = n - br->rem_bit;
+    br_get_next(br);
+    br->rem_bit = 32 - rem;
+    br->leading_word <<= (rem & 31);
+  } else {
+    br_get_next(br);
+  }
+}
+
+/* src/bitreader.rs:105-119 */
+uint32_t x3o_br_read_nbits(x3o_bitreader* br, size_t n) {
+  if (n <= br->rem_bit) {
+    uint32_t result = br->leading_word >> ((32 - n) & 31);
+    br_inc_bits(br, n);
+    return result;
+  } else {
+    size_t rem = n - br->rem_bit;
+    uint32_t result = br->leading_word >> ((32 - n) & 31);
+    br_inc_bits(br, br->rem_bit);
+    result |= br->leading_word >> ((32 - rem) & 31);
+    br_inc_bits(br, rem);
+    return result;
+  }
+}
+
+/* src/bitreader.rs:128-139: the zero run is extended by at most ONE peeked word */
+size_t x3o_br_count_zero_bits(x3o_bitreader* br) {
+  size_t count = br->leading_word ? (size_t)__builtin_clz(br->leading_word) : 32;
+  if (count > br->rem_bit) {
+    if (br->idx >= br->len) {
+      count = br->rem_bit;
+    } else {
+      size_t d;
+      uint32_t word = read_word(br->array, br->len, br->idx, &d);
+      count = br->rem_bit + (word ? (size_t)__builtin_clz(word) : 32);
+    }
+  }
+  br_inc_bits(br, count);
+  return count;
+}
+
+/* ------------------------------------------------------------- decoder.rs */
+
+static inline uint16_t rd_be16(const uint8_t* p) { return (uint16_t)(((uint16_t)p[0] << 8) | p[1]); }
+
+/* src/decoder.rs:69-118; check order: length, header CRC, key, channels, payload_len */
+int x3o_read_frame_header(const uint8_t* bytes, size_t len, x3o_frame_header* h) {
+  x3o_init();
+  if (len < 20) return X3O_FRAME_DECODE_UNEXPECTED_END;
+  if (rd_be16(bytes + 16) != x3o_crc16(bytes, 16)) return X3O_FRAME_HEADER_INVALID_HEADER_CRC;
+  if (rd_be16(bytes) != 30771) return X3O_FRAME_HEADER_INVALID_KEY;
+  uint8_t channels = bytes[3];
+  if (channels > 1) return X3O_MORE_THAN_ONE_CHANNEL;
+  uint32_t payload_len = rd_be16(bytes + 6);
+  if (payload_len >= 0x7fe0) return X3O_FRAME_LENGTH; /* Frame::MAX_LENGTH src/x3.rs:145 */
+  h->source_id = bytes[2];
+  h->samples = rd_be16(bytes + 4);
+  h->channels = channels;
+  h->payload_len = payload_len;
+  h->payload_crc = rd_be16(bytes + 18);
+  return X3O_OK;
+}
+
+/* src/decoder.rs:147-170; i16 accumulation wraps (release build) */
+static int decode_ricecode_block_r1(x3o_bitreader* br, int16_t* wav, size_t n, int16_t* last_wav,
+                                    const x3o_params* p, size_t ftype) {
+  const x3o_rice_code* code = &X3O_RICE[p->codes[ftype - 1]];
+  int16_t lw = *last_wav;
+  for (size_t b = 0; b < n; b++) {
+    size_t i = x3o_br_count_zero_bits(br);
+    x3o_br_read_nbits(br, 1);
+    if (i >= code->inv_len) return X3O_OUT_OF_BOUNDS_INVERSE;
+    lw = (int16_t)(uint16_t)((uint16_t)lw + (uint16_t)X3O_INV_RICE[i]);
+    wav[b] = lw;
+  }
+  *last_wav = lw;
+  return X3O_OK;
+}
+
+/* src/decoder.rs:172-196; nb is hard-wired: 2 bits for ftype 2, 4 bits for ftype 3 (:180) */
+static int decode_ricecode_block_r2r3(x3o_bitreader* br, int16_t* wav, size_t n, int16_t* last_wav,
+                                      const x3o_params* p, size_t ftype) {
+  const x3o_rice_code* code = &X3O_RICE[p->codes[ftype - 1]];
+  size_t nb = (ftype == 2) ? 2 : 4;
+  int16_t level = (int16_t)(1 << code->nsubs);
+  int16_t lw = *last_wav;
+  for (size_t b = 0; b < n; b++) {
+    int16_t nz = (int16_t)x3o_br_count_zero_bits(br);
+    int16_t r = (int16_t)x3o_br_read_nbits(br, nb);
+    size_t i = (size_t)(int64_t)(int16_t)(r + level * (nz - 1)); /* `as usize` sign-extends */
+    if (i >= code->inv_len) return X3O_OUT_OF_BOUNDS_INVERSE;
+    lw = (int16_t)(uint16_t)((uint16_t)lw + (uint16_t)X3O_INV_RICE[i]);
+    wav[b] = lw;
+  }
+  *last_wav = lw;
+  return X3O_OK;
+}
+
+/* src/decoder.rs:198-207 */
+static inline int16_t unsigned_to_i16(uint16_t a16, size_t num_bits) {
+  int32_t a = a16;
+  int32_t neg_thresh = 1 << (num_bits - 1);
+  int32_t neg = 1 << num_bits;
+  if (a > neg_thresh) a -= neg;
+  return (int16_t)a;
+}
+
+/* src/decoder.rs:209-235 */
+static int decode_bpf_block(x3o_bitreader* br, int16_t* wav, size_t n, int16_t* last_wav) {
+  size_t num_bits = (size_t)x3o_br_read_nbits(br, 4) + 1;
+  if (num_bits <= 5) return X3O_FRAME_DECODE_INVALID_BPF;
+  if (num_bits == 16) {
+    for (size_t i = 0; i < n; i++) wav[i] = (int16_t)x3o_br_read_nbits(br, 16);
+  } else {
+    int16_t value = *last_wav;
+    for (size_t i = 0; i < n; i++) {
+      uint16_t diff = (uint16_t)x3o_br_read_nbits(br, num_bits);
+      value = (int16_t)(uint16_t)((uint16_t)value + (uint16_t)unsigned_to_i16(diff, num_bits));
+      wav[i] = value;
+    }
+  }
+  if (n == 0) return X3O_BAD_ARG; /* wav[wav.len()-1] panics */
+  *last_wav = wav[n - 1];
+  return X3O_OK;
+}
+
+/* src/decoder.rs:132-145 */
+int x3o_decode_block(x3o_bitreader* br, int16_t* wav, size_t n, int16_t* last_wav, const x3o_params* p) {
+  x3o_init();
+  size_t ftype = x3o_br_read_nbits(br, 2);
+  switch (ftype) {
+    case 0: return decode_bpf_block(br, wav, n, last_wav);
+    case 1: return decode_ricecode_block_r1(br, wav, n, last_wav, p, ftype);
+    case 2:
+    case 3: return decode_ricecode_block_r2r3(br, wav, n, last_wav, p, ftype);
+    default: return X3O_FRAME_DECODE_INVALID_FTYPE;
+  }
+}
+
+/* src/decoder.rs:36-58.  CRC is NOT checked here and trailing bits are ignored. */
+int x3o_decode_frame(const uint8_t* x3_bytes, size_t len, int16_t* wav_buf, size_t wav_cap,
+                     const x3o_params* p, size_t samples, size_t* n_out) {
+  x3o_init();
+  if (len < 2 || samples == 0 || wav_cap < 1) return X3O_BAD_ARG; /* reference panics */
+  if (p->block_len == 0 && samples > 1) return X3O_BAD_ARG;      /* reference never returns */
+  int16_t last_wav = (int16_t)rd_be16(x3_bytes);
+  size_t p_wav = 0;
+  wav_buf[p_wav++] = last_wav;
+  x3o_bitreader br;
+  x3o_br_new(&br, x3_bytes + 2, len - 2);
+  size_t remaining = samples - 1;
+  while (remaining > 0) {
+    size_t block_len = remaining < p->block_len ? remaining : p->block_len;
+    if (p_wav + block_len > wav_cap) return X3O_BAD_ARG; /* slice index panic */
+    int rc = x3o_decode_block(&br, wav_buf + p_wav, block_len, &last_wav, p);
+    if (rc) return rc;
+    remaining -= block_len;
+    p_wav += block_len;
+  }
+  if (n_out) *n_out = p_wav;
+  return X3O_OK;
+}
+
+/* ---------------------------------------------------------- decodefile.rs */
+
+/* X3aReader::decode_next_frame (src/decodefile.rs:105-136) + read_bytes (:80-86) +
+ * read_frame_payload (:93-103), looped as x3a_to_wav does (:200-209), over memory. */
+int x3o_decode_stream(const uint8_t* x3, uint64_t len, const x3o_params* p, int16_t* wav,
+                      uint64_t wav_cap, uint64_t* n_out, uint64_t* frames_ok, uint64_t* frame_errors) {
+  x3o_init();
+  uint64_t pos = 0, remaining = len, nsamp = 0, nframes = 0, nerr = 0;
+  int rc = X3O_OK;
+  for (;;) {
+    if (remaining <= 20) break;                                   /* :107-109 */
+    x3o_frame_header h;
+    rc = x3o_read_frame_header(x3 + pos, 20, &h);                 /* :112 */
+    pos += 20; remaining -= 20;
+    if (rc) break;
+    if (remaining < h.payload_len) break;                         /* :114-116, Ok(None) */
+    if (h.payload_len > 1024 * 24) { rc = X3O_FRAME_HEADER_INVALID_PAYLOAD_LEN; break; } /* :118-121 */
+    const uint8_t* payload = x3 + pos;
+    pos += h.payload_len; remaining -= h.payload_len;
+    if (x3o_crc16(payload, h.payload_len) != h.payload_crc) {     /* :96-100 */
+      rc = X3O_FRAME_HEADER_INVALID_PAYLOAD_CRC;
+      break;
+    }
+    size_t got = 0;
+    int drc = x3o_decode_frame(payload, h.payload_len, wav + nsamp, (size_t)(wav_cap - nsamp), p,
+                               h.samples, &got);                  /* :128 */
+    if (drc == X3O_BAD_ARG) { rc = drc; break; }                  /* reference would panic */
+    if (drc) { nerr += 1; break; }                                /* :129-135: counted, Ok(None) */
+    nsamp += got;
+    nframes += 1;
+  }
+  if (n_out) *n_out = nsamp;
+  if (frames_ok) *frames_ok = nframes;
+  if (frame_errors) *frame_errors = nerr;
+  return rc;
+}
+
+/* ------------------------------------------------------------ CPU baseline */
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int x3o_time_roundtrip(const int16_t* wav, uint64_t n, const x3o_params* p, int reps, double* enc_s,
+                       double* dec_s, uint64_t* stream_len) {
+  x3o_init();
+  size_t spf = (size_t)p->block_len * p->blocks_per_frame;
+  if (spf == 0) return X3O_BAD_ARG;
+  uint64_t nframes = (n + spf - 1) / spf;
+  uint64_t cap = nframes * (20 + 2 * (uint64_t)spf + spf / 8 + 64) + 64;
+  uint8_t* out = (uint8_t*)malloc(cap);
+  int16_t* back = (int16_t*)malloc((n ? n : 1) * sizeof(int16_t));
+  if (!out || !back) { free(out); free(back); return X3O_BAD_ARG; }
+  uint64_t stats[6], pos = 0, nout = 0, fok = 0, ferr = 0;
+  int rc = X3O_OK;
+  double te = 0, td = 0;
+  for (int r = 0; r < reps && !rc; r++) {
+    double t0 = now_s();
+    rc = x3o_encode(wav, n, 1, p, out, cap, 0, &pos, stats);
+    double t1 = now_s();
+    if (rc) break;
+    rc = x3o_decode_stream(out, pos, p, back, n, &nout, &fok, &ferr);
+    double t2 = now_s();
+    te += t1 - t0;
+    td += t2 - t1;
+    if (!rc && (nout != n || memcmp(back, wav, n * sizeof(int16_t)) != 0)) rc = X3O_BAD_ARG;
+  }
+  if (enc_s) *enc_s = te;
+  if (dec_s) *dec_s = td;
+  if (stream_len) *stream_len = pos;
+  free(out);
+  free(back);
+  return rc;
+}

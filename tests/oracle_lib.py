@@ -1,0 +1,154 @@
+"""ctypes loader for the CPU oracle (oracle/x3_oracle.c).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ODIR = os.path.join(ROOT, "oracle")
+
+
+class Params(C.Structure):
+    _fields_ = [("block_len", C.c_uint32), ("blocks_per_frame", C.c_uint32),
+                ("codes", C.c_uint32 * 3), ("thresholds", C.c_uint32 * 3)]
+
+    @classmethod
+    def default(cls):
+        return cls(20, 500, (C.c_uint32 * 3)(0, 1, 3), (C.c_uint32 * 3)(3, 8, 20))
+
+    @classmethod
+    def make(cls, block_len=20, blocks_per_frame=500, codes=(0, 1, 3), thresholds=(3, 8, 20)):
+        return cls(block_len, blocks_per_frame, (C.c_uint32 * 3)(*codes), (C.c_uint32 * 3)(*thresholds))
+
+
+class Writer(C.Structure):
+    _fields_ = [("slice", C.c_void_p), ("cap", C.c_size_t), ("p_byte", C.c_size_t), ("stream_length", C.c_size_t)]
+
+
+class BitPacker(C.Structure):
+    _fields_ = [("writer", C.POINTER(Writer)), ("scratch_byte", C.c_uint8), ("p_bit", C.c_size_t),
+                ("byte_len", C.c_size_t), ("crc", C.c_uint16)]
+
+
+class BitReader(C.Structure):
+    _fields_ = [("array", C.c_void_p), ("len", C.c_size_t), ("idx", C.c_size_t),
+                ("leading_word", C.c_uint32), ("rem_bit", C.c_size_t)]
+
+
+class FrameHeader(C.Structure):
+    _fields_ = [("source_id", C.c_uint8), ("samples", C.c_uint16), ("channels", C.c_uint8),
+                ("payload_len", C.c_uint32), ("payload_crc", C.c_uint16)]
+
+
+class RiceCode(C.Structure):
+    _fields_ = [("nsubs", C.c_uint32), ("offset", C.c_uint32), ("len", C.c_uint32), ("inv_len", C.c_uint32),
+                ("code", C.c_uint32 * 56), ("num_bits", C.c_uint32 * 56)]
+
+
+_lib = None
+
+
+def build(native=False):
+    target = "native" if native else "all"
+    subprocess.run(["make", "-s", "-C", ODIR, target], check=True)
+    return os.path.join(ODIR, "libx3oracle_native.so" if native else "libx3oracle.so")
+
+
+def _stale(so):
+    if not os.path.exists(so):
+        return True
+    t = os.path.getmtime(so)
+    return any(os.path.getmtime(os.path.join(ODIR, f)) > t for f in ("x3_oracle.c", "x3_oracle.h"))
+
+
+def lib(native=False):
+    global _lib
+    if _lib is not None and not native:
+        return _lib
+    so = os.path.join(ODIR, "libx3oracle_native.so" if native else "libx3oracle.so")
+    if native or _stale(so):
+        so = build(native)
+    L = C.CDLL(so)
+    L.x3o_crc16.restype = C.c_uint16
+    L.x3o_crc16.argtypes = [C.c_void_p, C.c_size_t]
+    L.x3o_update_crc16.restype = C.c_uint16
+    L.x3o_update_crc16.argtypes = [C.c_uint16, C.c_uint8]
+    L.x3o_bp_write_bits.argtypes = [C.POINTER(BitPacker), C.c_uint64, C.c_size_t]
+    L.x3o_bp_write_packed_zeros.argtypes = [C.POINTER(BitPacker), C.c_size_t]
+    L.x3o_writer_init.argtypes = [C.POINTER(Writer), C.c_void_p, C.c_size_t]
+    L.x3o_br_new.argtypes = [C.POINTER(BitReader), C.c_void_p, C.c_size_t]
+    L.x3o_br_read_nbits.restype = C.c_uint32
+    L.x3o_br_read_nbits.argtypes = [C.POINTER(BitReader), C.c_size_t]
+    L.x3o_br_count_zero_bits.restype = C.c_size_t
+    L.x3o_encode_block.argtypes = [C.c_void_p, C.c_size_t, C.c_int16, C.POINTER(BitPacker), C.POINTER(Params),
+                                   C.POINTER(C.c_size_t)]
+    L.x3o_encode_frame.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(Writer), C.POINTER(Params), C.c_void_p]
+    L.x3o_encode.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(Params), C.c_void_p, C.c_uint64,
+                             C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]
+    L.x3o_write_frame_header.argtypes = [C.c_size_t, C.c_uint8, C.c_size_t, C.c_uint16, C.c_void_p]
+    L.x3o_read_frame_header.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(FrameHeader)]
+    L.x3o_decode_block.argtypes = [C.POINTER(BitReader), C.c_void_p, C.c_size_t, C.POINTER(C.c_int16),
+                                   C.POINTER(Params)]
+    L.x3o_decode_frame.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(Params), C.c_size_t,
+                                   C.POINTER(C.c_size_t)]
+    L.x3o_decode_stream.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Params), C.c_void_p, C.c_uint64,
+                                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.x3o_time_roundtrip.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Params), C.c_int, C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.x3o_init()
+    if not native:
+        _lib = L
+    return L
+
+
+# ------------------------------------------------------------------ numpy-level helpers
+
+def crc16(data):
+    b = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8)) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+    return lib().x3o_crc16(b.ctypes.data, b.size)
+
+
+def encode_bound(n, params):
+    spf = params.block_len * params.blocks_per_frame
+    if spf == 0:
+        return 64
+    nf = (n + spf - 1) // spf
+    return nf * (20 + 2 * spf + spf // 8 + 64) + 64
+
+
+def encode(wav, params=None, start_pos=0, cap=None, n_channels=1):
+    """-> (rc, bytes produced as np.uint8 incl. the start_pos prefix, stats[6])"""
+    params = params or Params.default()
+    wav = np.ascontiguousarray(wav, dtype=np.int16)
+    cap = encode_bound(wav.size, params) + start_pos if cap is None else cap
+    out = np.zeros(max(cap, 1), dtype=np.uint8)
+    pos = C.c_uint64(0)
+    stats = np.zeros(6, dtype=np.uint64)
+    rc = lib().x3o_encode(wav.ctypes.data, wav.size, n_channels, C.byref(params), out.ctypes.data, cap, start_pos,
+                          C.byref(pos), stats.ctypes.data)
+    return rc, out[: pos.value].copy(), stats
+
+
+def decode_stream(x3, params=None, wav_cap=None):
+    """-> (rc, samples np.int16, frames_ok, frame_errors)"""
+    params = params or Params.default()
+    x3 = np.ascontiguousarray(x3, dtype=np.uint8)
+    if wav_cap is None:
+        wav_cap = max(1, x3.size * 16)
+    wav = np.zeros(wav_cap, dtype=np.int16)
+    n = C.c_uint64(0); fok = C.c_uint64(0); ferr = C.c_uint64(0)
+    rc = lib().x3o_decode_stream(x3.ctypes.data, x3.size, C.byref(params), wav.ctypes.data, wav_cap, C.byref(n),
+                                 C.byref(fok), C.byref(ferr))
+    return rc, wav[: n.value].copy(), fok.value, ferr.value
+
+
+def decode_frame(payload, samples, params=None, wav_cap=None):
+    params = params or Params.default()
+    payload = np.ascontiguousarray(payload, dtype=np.uint8)
+    wav_cap = samples if wav_cap is None else wav_cap
+    wav = np.zeros(max(wav_cap, 1), dtype=np.int16)
+    n = C.c_size_t(0)
+    rc = lib().x3o_decode_frame(payload.ctypes.data, payload.size, wav.ctypes.data, wav_cap, C.byref(params), samples,
+                                C.byref(n))
+    return rc, wav[: n.value].copy()
