@@ -1,0 +1,228 @@
+/*
+ * x3hip.h -- C ABI of the MI355X-native X3 encoder/decoder (libx3hip.so).
+ *
+ * This is the drop-in boundary for the encode/decode hot path of the psiphi75/x3-rust crate
+ * (SURVEY.md section 8b).  The reference has no FFI layer of its own: the boundary is its public Rust
+ * API, so every entry point below names the Rust item it replaces (paths relative to the
+ * reference checkout).  INTEGRATION.md shows the `extern "C"` block + safe wrappers a crate
+ * maintainer would add; x3-rust_amd/host/x3.hpp is the same surface for C++ callers and
+ * x3-rust_amd/x3hip/ the ctypes binding used by tests and bench.py.
+ *
+ * Rules of the ABI
+ *   - plain pointers and sizes only; no C++/torch types.
+ *   - every function returns an int status: 0 = OK, otherwise the 1-based variant index of the
+ *     reference's `enum X3Error` (src/error.rs:27-62), or X3_ERR_HIP / X3_ERR_BAD_ARG.
+ *     X3_ERR_BAD_ARG is returned where the reference would panic; the library never aborts.
+ *   - all bulk work (prediction filter, Rice/BFP/literal coding, bit packing, payload CRC,
+ *     stream compaction, decoding) runs in HIP kernels on the context's GPU.  There is no CPU
+ *     fallback: without a usable HIP device x3_ctx_create fails with X3_ERR_HIP.
+ *   - a context is single-threaded; use one per GPU / per host thread.
+ *   - `*_dev` entry points take DEVICE pointers, enqueue on the context's stream and do not
+ *     synchronise; x3_ctx_sync() / x3_*_result() wait.
+ */
+#ifndef X3HIP_H
+#define X3HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status codes */
+/* order = `enum X3Error`, src/error.rs:27-62 */
+enum x3_status {
+  X3_OK = 0,
+  X3_ERR_IO = 1,
+  X3_ERR_HOUND = 2,
+  X3_ERR_BITPACK = 3,
+  X3_ERR_INVALID_ENCODING_THRESH = 4,
+  X3_ERR_OUT_OF_BOUNDS_INVERSE = 5,
+  X3_ERR_MORE_THAN_ONE_CHANNEL = 6,
+  X3_ERR_ARCHIVE_HEADER_XML_INVALID = 7,
+  X3_ERR_ARCHIVE_HEADER_XML_RICE_CODE = 8,
+  X3_ERR_ARCHIVE_HEADER_XML_INVALID_KEY = 9,
+  X3_ERR_FRAME_LENGTH = 10,
+  X3_ERR_FRAME_HEADER_INVALID_KEY = 11,
+  X3_ERR_FRAME_HEADER_INVALID_PAYLOAD_LEN = 12,
+  X3_ERR_FRAME_HEADER_INVALID_HEADER_CRC = 13,
+  X3_ERR_FRAME_HEADER_INVALID_PAYLOAD_CRC = 14,
+  X3_ERR_FRAME_DECODE_INVALID_BLOCK_LENGTH = 15,
+  X3_ERR_FRAME_DECODE_INVALID_INDEX = 16,
+  X3_ERR_FRAME_DECODE_INVALID_NTOGO = 17,
+  X3_ERR_FRAME_DECODE_INVALID_FTYPE = 18,
+  X3_ERR_FRAME_DECODE_INVALID_RICE_CODE = 19,
+  X3_ERR_FRAME_DECODE_INVALID_BPF = 20,
+  X3_ERR_FRAME_DECODE_UNEXPECTED_END = 21,
+  X3_ERR_BYTE_WRITER_INSUFFICIENT_MEMORY = 22,
+  X3_ERR_HIP = 23,    /* a HIP call failed; see x3_last_error() */
+  X3_ERR_BAD_ARG = 24 /* the reference would panic (index out of range, 0 samples, ...) or the
+                         argument is outside what the GPU path supports */
+};
+
+const char* x3_strerror(int status);
+
+/* ------------------------------------------------------------------ types */
+
+/* x3::Parameters (src/x3.rs:81-134); rice_codes[] is derived from codes[]. */
+typedef struct x3_params {
+  uint32_t block_len;        /* DEFAULT_BLOCK_LENGTH 20, MAX_BLOCK_LENGTH 60 */
+  uint32_t blocks_per_frame; /* DEFAULT_BLOCKS_PER_FRAME 500 */
+  uint32_t codes[3];         /* DEFAULT_RICE_CODES {0,1,3} */
+  uint32_t thresholds[3];    /* DEFAULT_THRESHOLDS {3,8,20} */
+} x3_params;
+
+/* x3::FrameHeader (src/x3.rs:148-184) */
+typedef struct x3_frame_header {
+  uint8_t source_id;
+  uint8_t channels;
+  uint16_t samples;
+  uint32_t payload_len;
+  uint16_t payload_crc;
+} x3_frame_header;
+
+#define X3_FRAME_HEADER_LENGTH 20   /* FrameHeader::LENGTH */
+#define X3_FRAME_KEY 0x7833         /* FrameHeader::KEY "x3" */
+#define X3_FRAME_MAX_LENGTH 0x7fe0  /* Frame::MAX_LENGTH */
+#define X3_READ_BUFFER_SIZE 24576   /* decodefile.rs:44 */
+
+typedef struct x3_ctx x3_ctx;
+
+/* ------------------------------------------------------------------ context */
+
+/* Create a context on HIP device `device` with its own non-blocking stream. */
+int x3_ctx_create(int device, x3_ctx** ctx);
+/* Same, but enqueue on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). */
+int x3_ctx_create_on_stream(int device, void* hip_stream, x3_ctx** ctx);
+void x3_ctx_destroy(x3_ctx* ctx);
+int x3_ctx_sync(x3_ctx* ctx);
+/* Text of the last HIP failure seen by this context ("" if none). */
+const char* x3_last_error(const x3_ctx* ctx);
+
+/* HIP-event timing of individual kernels on the context's stream (bench.py's roofline leg).
+ * which: 0 = encode kernel, 1 = decode kernel, 2 = frame-size kernel, 3 = scan kernel. */
+int x3_ctx_enable_kernel_timing(x3_ctx* ctx, int enable);
+int x3_ctx_kernel_time(x3_ctx* ctx, int which, double* total_ms, uint64_t* launches); /* syncs */
+int x3_ctx_reset_kernel_time(x3_ctx* ctx);
+
+/* ------------------------------------------------------------------ x3.rs */
+
+/* `impl Default for Parameters`, src/x3.rs:124-134 */
+void x3_params_default(x3_params* p);
+/* `Parameters::new`, src/x3.rs:98-122: INVALID_ENCODING_THRESH if thresholds[k] > offset of
+ * code k for k = 0,1 (the reference checks only those two); BAD_ARG for a code > 3. */
+int x3_params_validate(const x3_params* p);
+/* number of frames `encode` cuts n samples into (encoder.rs:61-73) */
+uint64_t x3_num_frames(uint64_t n, const x3_params* p);
+/* worst-case bytes `encode` can produce for n samples (all-literal frames) */
+uint64_t x3_encode_bound(uint64_t n, const x3_params* p);
+
+/* ------------------------------------------------------------------ crc.rs */
+
+/* `crc::crc16`, src/crc.rs:49-58 -- computed on the GPU as a segmented reduction. */
+int x3_crc16(x3_ctx* ctx, const uint8_t* data, uint64_t n, uint16_t* crc);
+int x3_crc16_dev(x3_ctx* ctx, const uint8_t* d_data, uint64_t n, uint16_t* crc); /* syncs */
+/* `crc::update_crc16`, src/crc.rs:44-47 -- one byte, host arithmetic. */
+uint16_t x3_crc16_update(uint16_t crc, uint8_t byte);
+
+/* ------------------------------------------------------------------ encoder.rs */
+
+/* `encoder::encode` into a `SliceByteWriter` (src/encoder.rs:51-111, bytewriter.rs:27-100).
+ * wav[0..n) is the single channel's samples (`x3::Channel::wav` / a collected `IterChannel`);
+ * n_channels is `channels.len()` (>1 -> MORE_THAN_ONE_CHANNEL, 0 -> BAD_ARG).  The writer is
+ * out[0..out_cap) positioned at start_pos; frames are appended back to back, each preceded by
+ * zero padding to an even ABSOLUTE position.  *out_pos receives `writer.stream_position()`.
+ * stats[6] (may be NULL) receives the per-sample block-type counts the reference prints
+ * (Rice nsubs 0..3, BFP = 4, literal = 5; encoder.rs:96-108,199).
+ * On BYTE_WRITER_INSUFFICIENT_MEMORY nothing is written and *out_pos = the position that
+ * would have been reached. */
+int x3_encode(x3_ctx* ctx, const int16_t* wav, uint64_t n, uint32_t n_channels, const x3_params* p,
+              uint8_t* out, uint64_t out_cap, uint64_t start_pos, uint64_t* out_pos, uint64_t stats[6]);
+
+/* `encoder::encode_frame` (src/encoder.rs:175-214): exactly one frame from wav[0..n), n >= 1. */
+int x3_encode_frame(x3_ctx* ctx, const int16_t* wav, uint64_t n, const x3_params* p, uint8_t* out,
+                    uint64_t out_cap, uint64_t start_pos, uint64_t* out_pos, uint64_t stats[6]);
+
+/* `encoder::write_frame_header` (src/encoder.rs:122-162); 20 bytes of host arithmetic. */
+void x3_write_frame_header(uint64_t num_samples, uint8_t id, uint64_t payload_len, uint16_t payload_crc,
+                           uint8_t out[X3_FRAME_HEADER_LENGTH]);
+
+/* Batched `encode`: `count` independent clips (BASELINE config 5).  Clip c is wavs[c][0..ns[c]).
+ * The clips' streams are written back to back into out[0..out_cap); clip_offsets[count+1]
+ * receives where each starts/ends (all even).  Equivalent to `count` calls of x3_encode. */
+int x3_encode_batch(x3_ctx* ctx, const int16_t* const* wavs, const uint64_t* ns, uint64_t count,
+                    const x3_params* p, uint8_t* out, uint64_t out_cap, uint64_t* clip_offsets,
+                    uint64_t stats[6]);
+
+/* ------------------------------------------------------------------ decoder.rs / decodefile.rs */
+
+/* `decoder::read_frame_header` (src/decoder.rs:69-118); 20 bytes of host arithmetic.
+ * Check order: length, header CRC, key, channels <= 1, payload_len < Frame::MAX_LENGTH. */
+int x3_read_frame_header(const uint8_t* bytes, uint64_t len, x3_frame_header* h);
+
+/* `decoder::decode_frame` (src/decoder.rs:36-58): payload[0..len) -> wav[0..samples).
+ * Does not check any CRC (the reference does not either). */
+int x3_decode_frame(x3_ctx* ctx, const uint8_t* payload, uint64_t len, int16_t* wav, uint64_t wav_cap,
+                    const x3_params* p, uint64_t samples, uint64_t* n_out);
+
+/* The frame walk of `X3aReader::decode_next_frame` looped as `x3a_to_wav` does
+ * (src/decodefile.rs:93-136,200-209) over an in-memory frame stream x3[0..len) (no archive
+ * header): stop at end of data, at the first hard error (returned), or at the first frame whose
+ * payload fails to decode (counted in *frame_errors, return 0).  wav receives the samples of
+ * the frames before the stop; *n_out their count; *frames_ok the number of good frames. */
+int x3_decode_stream(x3_ctx* ctx, const uint8_t* x3, uint64_t len, const x3_params* p, int16_t* wav,
+                     uint64_t wav_cap, uint64_t* n_out, uint64_t* frames_ok, uint64_t* frame_errors);
+
+/* ------------------------------------------------------------------ device-resident API */
+
+/* Geometry of a uniform batch resident in HBM: n_clips clips of n_per_clip samples, clip c
+ * starting at d_wav + c*clip_stride (samples).  A single stream is n_clips = 1. */
+typedef struct x3_batch {
+  uint64_t n_per_clip;
+  uint64_t clip_stride;
+  uint64_t n_clips;
+} x3_batch;
+
+/* Encode a device-resident batch into d_out[0..out_cap) starting at start_pos (even or odd; an
+ * odd start is zero-padded to even as the reference does).  d_frame_offsets (may be NULL)
+ * receives F+1 byte offsets: frame f occupies [d_frame_offsets[f], d_frame_offsets[f+1]).
+ * Asynchronous; results via x3_encode_result(). */
+int x3_encode_dev(x3_ctx* ctx, const int16_t* d_wav, const x3_batch* batch, const x3_params* p,
+                  uint8_t* d_out, uint64_t out_cap, uint64_t start_pos, uint64_t* d_frame_offsets);
+/* Waits for the last x3_encode_dev; status is X3_OK, BYTE_WRITER_INSUFFICIENT_MEMORY or BAD_ARG. */
+int x3_encode_result(x3_ctx* ctx, uint64_t* out_pos, uint64_t stats[6]);
+
+/* Decode F frames of a device-resident stream.  d_frame_offsets[f] = byte offset of frame f's
+ * header in d_x3 (F entries used).  Frame f's samples go to d_wav + d_wav_offsets[f] when
+ * d_wav_offsets != NULL, else to the position implied by `batch` and p (the layout
+ * x3_encode_dev consumed).  Every frame's header CRC, key, channel count, length and payload CRC
+ * are verified on the GPU; d_status (F int32, may be NULL -> internal) receives a status per frame.
+ * Asynchronous; results via x3_decode_result(). */
+int x3_decode_dev(x3_ctx* ctx, const uint8_t* d_x3, uint64_t x3_len, const uint64_t* d_frame_offsets,
+                  uint64_t n_frames, const x3_batch* batch, const uint64_t* d_wav_offsets,
+                  const x3_params* p, int16_t* d_wav, uint64_t wav_cap, int32_t* d_status);
+/* Waits for the last x3_decode_dev: index and status of the first frame whose status != 0
+ * (first_bad = n_frames, status 0 if all frames are good) and the total samples of good frames
+ * before it. */
+int x3_decode_result(x3_ctx* ctx, uint64_t* first_bad, int* first_bad_status, uint64_t* samples_before);
+
+/* ------------------------------------------------------------------ synthetic inputs (bench/tests) */
+
+/* Seeded, integer-only signal generators.  kind: 0 zeros, 1 white i16 noise,
+ * 2 hydrophone-like noise (coloured noise + swell + sparse clicks), 3 fixed-point sine,
+ * 4 +-2 LSB random walk.  Sample i depends only on (kind, seed, start+i): the host and device
+ * versions are bit-identical and any sub-range can be generated independently. */
+int x3_synth(int kind, uint64_t seed, uint64_t start, uint64_t n, int16_t* out);
+int x3_synth_dev(x3_ctx* ctx, int kind, uint64_t seed, uint64_t start, uint64_t n, int16_t* d_out);
+
+/* device memory helpers so that ctypes/FFI callers need no HIP binding of their own */
+int x3_dev_alloc(x3_ctx* ctx, uint64_t bytes, void** d_ptr);
+int x3_dev_free(x3_ctx* ctx, void* d_ptr);
+int x3_dev_upload(x3_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);   /* syncs */
+int x3_dev_download(x3_ctx* ctx, void* dst, const void* d_src, uint64_t bytes); /* syncs */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

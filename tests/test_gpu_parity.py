@@ -1,0 +1,423 @@
+"""GPU parity tests: the HIP path (through the C ABI, libx3hip.so) against the CPU oracle and the
+reference's golden vectors.  Everything here needs a real MI355X: `pytest -m gpu`.
+Bar: bit-exact (integer/byte work)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return json.load(open(os.path.join(G, name)))
+
+
+@pytest.fixture(scope="module")
+def x3():
+    import x3hip
+    return x3hip
+
+
+@pytest.fixture(scope="module")
+def ctx(x3):
+    c = x3.Context(0)
+    yield c
+    c.close()
+
+
+def oparams(p):
+    return O.Params.make(p.block_len, p.blocks_per_frame, tuple(p.codes), tuple(p.thresholds))
+
+
+def check_encode(ctx, x3, wav, params=None, start_pos=0):
+    params = params or x3.Params.default()
+    rc_o, out_o, st_o = O.encode(wav, oparams(params), start_pos=start_pos)
+    rc_g, out_g, st_g = ctx.encode(wav, params, start_pos=start_pos)
+    assert rc_g == rc_o, (rc_g, rc_o, ctx.last_error())
+    if rc_o == 0:
+        assert out_g.size == out_o.size
+        assert np.array_equal(out_g[start_pos:], out_o[start_pos:])
+        assert st_g.tolist() == st_o.tolist()
+    return out_o
+
+
+def check_decode(ctx, x3, stream, params=None, wav_cap=None):
+    params = params or x3.Params.default()
+    r_o = O.decode_stream(stream, oparams(params), wav_cap=wav_cap)
+    r_g = ctx.decode_stream(stream, params, wav_cap=wav_cap)
+    assert (r_g[0], r_g[2], r_g[3]) == (r_o[0], r_o[2], r_o[3]), (r_g[0], r_g[2:], r_o[0], r_o[2:])
+    assert np.array_equal(r_g[1], r_o[1])
+    return r_o
+
+
+# ------------------------------------------------------------------ golden vectors through the C ABI
+
+def test_golden_encode_frame(ctx, x3):
+    for f in load("encoder_kat.json")["frames"]:
+        wav = np.array(f["wav"], dtype=np.int16)
+        rc, out, stats = ctx.encode_frame(wav)
+        assert rc == 0, ctx.last_error()
+        assert out.tolist() == f["expected"], f["name"]
+        rc, out, _ = ctx.encode(wav)
+        assert rc == 0 and out.tolist() == f["expected"]
+
+
+def test_golden_encode_blocks(ctx, x3):
+    """encode_frame([prev, block...]) = 16 raw bits + the block; compare the block's bits."""
+    for b in load("encoder_kat.json")["blocks"]:
+        wav = np.array(b["wav"], dtype=np.int16)
+        rc, out, _ = ctx.encode_frame(wav)
+        assert rc == 0
+        bits = np.unpackbits(out[20:])[16:]
+        exp = np.unpackbits(np.array(b["expected"], dtype=np.uint8))[b["prepad_zero_bits"]:]
+        n = min(bits.size, exp.size) - 16  # both end with alignment zeros; compare the common prefix
+        assert np.array_equal(bits[:n], exp[:n]), b["name"]
+        assert not bits[n:].any() and not exp[n:].any()
+
+
+def test_golden_decode(ctx, x3):
+    for f in load("encoder_kat.json")["frames"]:
+        rc, wav, fok, ferr = ctx.decode_stream(np.array(f["expected"], dtype=np.uint8))
+        assert (rc, fok, ferr) == (0, 1, 0)
+        assert wav.tolist() == f["wav"]
+
+
+def test_golden_decode_blocks(ctx, x3):
+    for b in load("decoder_kat.json")["blocks"]:
+        x = np.array(b["x3_inp"], dtype=np.uint8)
+        if b["first_sample_in_stream"]:
+            payload = x
+        else:  # re-pack: 16-bit predecessor + the bits after the skipped prefix
+            bits = np.unpackbits(x)[b["skip_bits"]:]
+            first = np.unpackbits(np.array([b["last_wav"]], dtype=">i2").view(np.uint8))
+            payload = np.packbits(np.concatenate([first, bits]))
+        n = len(b["expected_wav"])
+        payload = np.concatenate([payload, np.zeros(8, dtype=np.uint8)])
+        rc, wav = ctx.decode_frame(payload, 1 + n)
+        assert rc == 0, (b["name"], rc)
+        assert wav[1:].tolist() == b["expected_wav"], b["name"]
+        rc_o, wav_o = O.decode_frame(payload, 1 + n)
+        assert rc_o == 0 and np.array_equal(wav, wav_o)
+
+
+def test_golden_crc(ctx, x3):
+    for c in load("crc_kat.json")["cases"]:
+        assert ctx.crc16(bytes(c["bytes"])) == c["crc"]
+
+
+def test_crc_lengths(ctx, x3):
+    rng = np.random.default_rng(7)
+    big = rng.integers(0, 256, size=300001, dtype=np.uint8)
+    for n in [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 16, 17, 255, 256, 257, 4095, 4096, 4097, 32767, 32768, 32769,
+              65535, 65536, 65537, 100000, 300001]:
+        assert ctx.crc16(big[:n]) == O.crc16(big[:n]), n
+    zeros = np.zeros(70000, dtype=np.uint8)
+    assert ctx.crc16(zeros) == O.crc16(zeros)
+
+
+# ------------------------------------------------------------------ encode parity on synthetic signals
+
+SIZES = [1, 2, 3, 20, 21, 22, 41, 9999, 10000, 10001, 10002, 16000, 20000, 123457]
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4])
+def test_encode_parity_kinds(ctx, x3, kind):
+    for n in SIZES:
+        wav = x3.synth(kind, 0x58330000 + kind, 1000, n)
+        check_encode(ctx, x3, wav)
+
+
+def test_encode_start_pos(ctx, x3):
+    wav = x3.synth(2, 11, 0, 25000)
+    for sp in [0, 1, 2, 3, 17, 100, 101]:
+        check_encode(ctx, x3, wav, start_pos=sp)
+
+
+def test_encode_threshold_edges(ctx, x3):
+    """max|diff| exactly at 3/4, 8/9, 20/21, 16383/16384, +-32767 swings."""
+    rng = np.random.default_rng(3)
+    chunks = []
+    for m in [0, 1, 3, 4, 8, 9, 20, 21, 31, 32, 63, 64, 16383, 16384, 16385, 32767, 40000, 65535]:
+        for sign in (1, -1):
+            d = rng.integers(-min(m, 20000), min(m, 20000) + 1, size=40)
+            d[rng.integers(0, 40)] = sign * m
+            chunks.append(d)
+    diffs = np.concatenate(chunks).astype(np.int64)
+    wav = np.zeros(diffs.size, dtype=np.int64)
+    acc = 0
+    for i, d in enumerate(diffs):  # keep the walk inside i16 by reflecting
+        nxt = acc + d
+        if nxt > 32767 or nxt < -32768:
+            nxt = acc - d
+        if nxt > 32767 or nxt < -32768:
+            nxt = acc
+        acc = nxt
+        wav[i] = acc
+    wav = wav.astype(np.int16)
+    check_encode(ctx, x3, wav)
+    alt = np.tile(np.array([32767, -32768], dtype=np.int16), 5000)
+    check_encode(ctx, x3, alt)
+    for p in [x3.Params.make(20, 5), x3.Params.make(20, 1)]:
+        check_encode(ctx, x3, wav, p)
+
+
+@pytest.mark.parametrize("bl,bpf", [(1, 10), (2, 33), (7, 100), (19, 500), (20, 500), (20, 1024), (33, 64),
+                                    (60, 100), (60, 600), (5, 2000)])
+def test_encode_generic_geometry(ctx, x3, bl, bpf):
+    p = x3.Params.make(bl, bpf)
+    for kind in (2, 1, 4):
+        wav = x3.synth(kind, 99 + bl, 0, 3 * bl * bpf + 17)
+        out = check_encode(ctx, x3, wav, p)
+        check_decode(ctx, x3, out, p)
+
+
+@pytest.mark.parametrize("codes,thr", [((0, 1, 3), (3, 8, 20)), ((0, 1, 2), (3, 8, 18)), ((1, 2, 3), (5, 10, 25)),
+                                       ((0, 2, 3), (2, 12, 27)), ((3, 3, 3), (1, 2, 3)), ((0, 0, 0), (1, 2, 5)),
+                                       ((0, 1, 3), (6, 10, 27)), ((0, 1, 3), (0, 0, 0)), ((0, 1, 3), (8, 3, 20))])
+def test_encode_generic_codes(ctx, x3, codes, thr):
+    p = x3.Params.make(20, 500, codes, thr)
+    for kind in (2, 4):
+        wav = x3.synth(kind, 5, 0, 30011)
+        check_encode(ctx, x3, wav, p)
+
+
+def test_encode_out_of_table_is_bad_arg(ctx, x3):
+    """thresholds above a Rice table's range: the reference indexes out of bounds (panics)."""
+    p = x3.Params.make(20, 500, (0, 1, 3), (3, 8, 40))   # Rice3 table covers -28..27 only
+    wav = x3.synth(2, 5, 0, 50000)
+    rc_o, _, _ = O.encode(wav, oparams(p))
+    rc_g, _, _ = ctx.encode(wav, p)
+    assert rc_g == rc_o == x3.ERR_BAD_ARG
+
+
+def test_encode_errors(ctx, x3):
+    wav = x3.synth(2, 1, 0, 30000)
+    rc, _, _ = ctx.encode(wav, n_channels=2)
+    assert rc == x3.ERR_MORE_THAN_ONE_CHANNEL
+    rc, _, _ = ctx.encode(wav, n_channels=0)
+    assert rc == x3.ERR_BAD_ARG
+    full = O.encode(wav)[1]
+    for cap in [0, 10, 20, full.size - 1000, full.size - 2, full.size - 1]:
+        rc, _, _ = ctx.encode(wav, cap=cap)
+        assert rc == x3.ERR_BYTE_WRITER_INSUFFICIENT_MEMORY, cap
+    rc, out, _ = ctx.encode(wav, cap=full.size)
+    assert rc == 0 and np.array_equal(out, full)
+    # empty input / zero-sized frames write nothing
+    rc, out, _ = ctx.encode(np.zeros(0, dtype=np.int16))
+    assert rc == 0 and out.size == 0
+    rc, out, _ = ctx.encode(wav, x3.Params.make(0, 500))
+    assert rc == 0 and out.size == 0
+    assert x3.lib().x3_params_validate(C.byref(x3.Params.make(20, 500, (0, 1, 3), (7, 8, 20)))) == x3.ERR_INVALID_ENCODING_THRESH
+    assert x3.lib().x3_params_validate(C.byref(x3.Params.make(20, 500, (0, 1, 3), (3, 8, 99)))) == 0
+    assert x3.lib().x3_params_validate(C.byref(x3.Params.make(20, 500, (0, 4, 3), (3, 8, 20)))) == x3.ERR_BAD_ARG
+
+
+def test_insufficient_memory_matches_oracle(ctx, x3):
+    wav = x3.synth(2, 1, 0, 30000)
+    full = O.encode(wav)[1]
+    for cap in [0, 19, 20, 21, 5000, full.size - 2]:
+        assert O.encode(wav, cap=cap)[0] == x3.ERR_BYTE_WRITER_INSUFFICIENT_MEMORY
+        assert ctx.encode(wav, cap=cap)[0] == x3.ERR_BYTE_WRITER_INSUFFICIENT_MEMORY
+
+
+# ------------------------------------------------------------------ decode parity incl. corrupt streams
+
+def refresh_crcs(x3, stream, off):
+    """recompute payload CRC + header CRC of the frame at `off` after tampering"""
+    rc, h = x3.read_frame_header(stream[off:off + 20])
+    plen = int(stream[off + 6]) << 8 | int(stream[off + 7])
+    pcrc = O.crc16(stream[off + 20: off + 20 + plen])
+    stream[off + 18] = pcrc >> 8
+    stream[off + 19] = pcrc & 0xFF
+    hcrc = O.crc16(stream[off: off + 16])
+    stream[off + 16] = hcrc >> 8
+    stream[off + 17] = hcrc & 0xFF
+
+
+def frame_offsets(stream):
+    offs, pos = [], 0
+    while pos + 20 < stream.size:
+        offs.append(pos)
+        pos += 20 + (int(stream[pos + 6]) << 8 | int(stream[pos + 7]))
+    return offs
+
+
+def test_decode_roundtrip_kinds(ctx, x3):
+    for kind in range(5):
+        wav = x3.synth(kind, 77, 0, 54321)
+        rc, stream, _ = O.encode(wav)
+        r = check_decode(ctx, x3, stream, wav_cap=wav.size)
+        assert r[0] == 0 and np.array_equal(r[1], wav)
+
+
+def test_decode_corrupt_payload_crc(ctx, x3):
+    wav = x3.synth(2, 78, 0, 60000)
+    stream = O.encode(wav)[1]
+    offs = frame_offsets(stream)
+    for fi in (0, 2, len(offs) - 1):
+        s = stream.copy()
+        s[offs[fi] + 20 + 100] ^= 0x10
+        r = check_decode(ctx, x3, s, wav_cap=wav.size)
+        assert r[0] == x3.ERR_FRAME_HEADER_INVALID_PAYLOAD_CRC and r[2] == fi
+
+
+def test_decode_corrupt_payload_with_valid_crc(ctx, x3):
+    """tamper with payload bits, then fix both CRCs: the block decoders must agree on what they make of it
+    (wrong samples, OutOfBoundsInverse, or InvalidBPF)."""
+    rng = np.random.default_rng(5)
+    wav = x3.synth(2, 79, 0, 40000)
+    stream = O.encode(wav)[1]
+    offs = frame_offsets(stream)
+    seen = set()
+    for trial in range(60):
+        s = stream.copy()
+        fi = int(rng.integers(0, len(offs)))
+        plen = int(s[offs[fi] + 6]) << 8 | int(s[offs[fi] + 7])
+        kind = trial % 3
+        pos = offs[fi] + 22 + int(rng.integers(0, plen - 12))
+        if kind == 0:
+            s[pos] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            s[pos:pos + 8] = 0          # long zero run -> OutOfBoundsInverse or BFP with E <= 5
+        else:
+            s[pos:pos + 6] = rng.integers(0, 256, size=6, dtype=np.uint8)
+        refresh_crcs(x3, s, offs[fi])
+        r = check_decode(ctx, x3, s, wav_cap=wav.size + 70000)
+        seen.add((r[0], r[3]))
+    assert (0, 1) in seen  # at least one counted frame error was exercised
+
+
+def test_decode_header_errors(ctx, x3):
+    wav = x3.synth(2, 80, 0, 35000)
+    stream = O.encode(wav)[1]
+    offs = frame_offsets(stream)
+    o2 = offs[2]
+    # header CRC
+    s = stream.copy(); s[o2 + 5] ^= 1
+    assert check_decode(ctx, x3, s, wav_cap=wav.size)[0] == x3.ERR_FRAME_HEADER_INVALID_HEADER_CRC
+    # key (with a valid header CRC)
+    s = stream.copy(); s[o2] = 0x79; refresh_crcs(x3, s, o2)
+    assert check_decode(ctx, x3, s, wav_cap=wav.size)[0] == x3.ERR_FRAME_HEADER_INVALID_KEY
+    # channels > 1
+    s = stream.copy(); s[o2 + 3] = 2; refresh_crcs(x3, s, o2)
+    assert check_decode(ctx, x3, s, wav_cap=wav.size)[0] == x3.ERR_MORE_THAN_ONE_CHANNEL
+    # payload_len >= Frame::MAX_LENGTH
+    s = stream.copy(); s[o2 + 6] = 0x7F; s[o2 + 7] = 0xE0; refresh_crcs(x3, s, o2)
+    assert check_decode(ctx, x3, s, wav_cap=wav.size)[0] == x3.ERR_FRAME_LENGTH
+    # payload_len beyond the data: quiet end
+    s = stream.copy(); s[o2 + 6] = 0x70; hc = O.crc16(s[o2:o2 + 16]); s[o2 + 16] = hc >> 8; s[o2 + 17] = hc & 0xFF
+    r = check_decode(ctx, x3, s, wav_cap=wav.size)
+    assert r[0] == 0 and r[2] == 2
+    # truncated streams
+    for cut in [0, 1, 19, 20, 21, offs[1] - 1, offs[1], offs[1] + 20, offs[1] + 21, stream.size - 1, stream.size - 2]:
+        check_decode(ctx, x3, stream[:cut].copy(), wav_cap=wav.size)
+    # trailing garbage shorter than a header is ignored
+    check_decode(ctx, x3, np.concatenate([stream, np.zeros(20, dtype=np.uint8)]), wav_cap=wav.size)
+    # samples field larger than what the payload encodes: reads zeros past the end
+    s = stream.copy(); s[offs[-1] + 4] = 0x27; s[offs[-1] + 5] = 0x10; refresh_crcs(x3, s, offs[-1])
+    check_decode(ctx, x3, s, wav_cap=wav.size + 20000)
+
+
+def test_decode_wav_cap_too_small(ctx, x3):
+    wav = x3.synth(2, 81, 0, 35000)
+    stream = O.encode(wav)[1]
+    for cap in [0, 1, 9999, 10000, 10001, 34999]:
+        check_decode(ctx, x3, stream, wav_cap=cap)
+
+
+# ------------------------------------------------------------------ batch + device-resident API
+
+def test_encode_batch(ctx, x3):
+    clips = [x3.synth(2, 1000 + i, 0, 57600) for i in range(7)]
+    rc, out, offs, stats = ctx.encode_batch(clips)
+    assert rc == 0
+    tot = np.zeros(6, dtype=np.uint64)
+    for i, c in enumerate(clips):
+        rc_o, o, st = O.encode(c)
+        assert np.array_equal(out[offs[i]:offs[i + 1]], o)
+        tot += st
+    assert stats.tolist() == tot.tolist()
+    ragged = [x3.synth(4, 2000 + i, 0, n) for i, n in enumerate([1, 10000, 25001, 3])]
+    rc, out, offs, stats = ctx.encode_batch(ragged)
+    assert rc == 0
+    for i, c in enumerate(ragged):
+        assert np.array_equal(out[offs[i]:offs[i + 1]], O.encode(c)[1])
+
+
+def test_synth_host_equals_device(ctx, x3):
+    n = 100000
+    d = ctx.alloc(2 * n)
+    for kind in range(5):
+        ctx.synth_dev(kind, 0x5833, 12345, n, d)
+        ctx.sync()
+        dev = ctx.download(d, 2 * n, np.int16)
+        assert np.array_equal(dev, x3.synth(kind, 0x5833, 12345, n))
+    ctx.free(d)
+
+
+def test_device_api_config2(ctx, x3):
+    """BASELINE config 2: 10 min @ 44.1 kHz hydrophone noise, encode on the GPU, bit-exact vs CPU."""
+    n = 26_460_000
+    p = x3.Params.default()
+    d_wav = ctx.alloc(2 * n)
+    ctx.synth_dev(2, 0x58330002, 0, n, d_wav)
+    cap = x3.lib().x3_encode_bound(n, C.byref(p))
+    d_out = ctx.alloc(cap)
+    F = x3.lib().x3_num_frames(n, C.byref(p))
+    d_off = ctx.alloc(8 * (F + 1))
+    assert ctx.encode_dev(d_wav, n, p, d_out, cap, 0, d_off) == 0
+    rc, pos, stats = ctx.encode_result()
+    assert rc == 0
+    wav = x3.synth(2, 0x58330002, 0, n)
+    rc_o, out_o, st_o = O.encode(wav)
+    assert pos == out_o.size
+    got = ctx.download(d_out, (pos + 3) & ~3)[:pos]
+    assert np.array_equal(got, out_o)
+    assert stats.tolist() == st_o.tolist()
+    offs = ctx.download(d_off, 8 * (F + 1), np.uint64)
+    assert offs[0] == 0 and offs[-1] == pos and frame_offsets(out_o) == offs[:-1].tolist()
+    # decode on the device from the encoder's own frame index
+    d_back = ctx.alloc(2 * n)
+    assert ctx.decode_dev(d_out, pos, d_off, F, p, d_back, n, n_per_clip=n) == 0
+    rc, first_bad, st, before = ctx.decode_result()
+    assert (rc, first_bad, st, before) == (0, F, 0, n)
+    assert np.array_equal(ctx.download(d_back, 2 * n, np.int16), wav)
+    for d in (d_wav, d_out, d_off, d_back):
+        ctx.free(d)
+
+
+def test_full_size_config3_roundtrip(ctx, x3):
+    """BASELINE config 3 at full size (1 h @ 192 kHz = 691.2 M samples): size-independent
+    properties -- encode -> decode is the identity, the frame index is a consistent header chain,
+    and sampled frames equal the CPU oracle's encoding of the same samples."""
+    torch = pytest.importorskip("torch")
+    n = 691_200_000
+    p = x3.Params.default()
+    F = x3.lib().x3_num_frames(n, C.byref(p))
+    dev = torch.device("cuda:0")
+    wav = torch.empty(n, dtype=torch.int16, device=dev)
+    ctx.synth_dev(2, 0x58330003, 0, n, wav.data_ptr())
+    cap = int(n * 1.2)
+    out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    off = torch.empty(F + 1, dtype=torch.int64, device=dev)
+    assert ctx.encode_dev(wav.data_ptr(), n, p, out.data_ptr(), cap, 0, off.data_ptr()) == 0
+    rc, pos, stats = ctx.encode_result()
+    assert rc == 0 and int(stats.sum()) == n - F
+    back = torch.zeros(n, dtype=torch.int16, device=dev)
+    assert ctx.decode_dev(out.data_ptr(), pos, off.data_ptr(), F, p, back.data_ptr(), n, n_per_clip=n) == 0
+    rc, first_bad, st, before = ctx.decode_result()
+    assert (rc, first_bad, st, before) == (0, F, 0, n)
+    assert torch.equal(back, wav)
+    offs = off.cpu().numpy()
+    assert offs[0] == 0 and offs[-1] == pos and np.all(np.diff(offs) >= 22) and np.all(offs % 2 == 0)
+    for f in [0, 1, 12345, F // 2, F - 2, F - 1]:
+        s = wav[f * 10000:(f + 1) * 10000].cpu().numpy()
+        enc = out[int(offs[f]):int(offs[f + 1])].cpu().numpy()
+        assert np.array_equal(enc, O.encode(s)[1]), f

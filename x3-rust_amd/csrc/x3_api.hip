@@ -1,0 +1,850 @@
+// x3_api.hip -- the C ABI of include/x3hip.h on top of the gfx950 kernels.
+//
+// Host logic only: argument checks that mirror the reference's (or its panics), derivation of
+// the kernel parameters from x3::Parameters, scratch-buffer management, the 20-byte frame
+// header helpers, and the host side of the stream walk.  All sample/bit/CRC work over payloads
+// is done by the kernels in x3_encode_kernel.h / x3_decode_kernel.h / x3_util_kernels.h.
+// There is no CPU fallback: every bulk entry point needs a live x3_ctx (a HIP device).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/x3hip.h"
+#include "x3_decode_kernel.h"
+#include "x3_device.h"
+#include "x3_encode_kernel.h"
+#include "x3_synth_core.h"
+#include "x3_util_kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct KernelTimer {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> used, pool;
+};
+
+struct x3_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string last_error;
+  // persistent small device state
+  uint16_t* d_xpow = nullptr;          // X3_XP_SIZE entries
+  int* d_status = nullptr;             // [0] size/scan pass, [1] encode pass
+  unsigned long long* d_stats = nullptr;    // 6
+  unsigned long long* d_end_pos = nullptr;  // 1
+  X3DecodeSummary* d_summary = nullptr;
+  uint16_t* d_crc = nullptr;
+  // pinned mirrors
+  int* h_status = nullptr;
+  unsigned long long* h_stats = nullptr;  // 6 stats + end_pos
+  X3DecodeSummary* h_summary = nullptr;
+  uint16_t* h_crc = nullptr;
+  // growable scratch
+  DevBuf in, out, frame_bytes, frame_off, dec_status, dec_nsamp, wav_off, seg_crc;
+  // bookkeeping of the last async calls
+  bool encode_pending = false, decode_pending = false;
+  uint64_t enc_start_pos = 0;
+  uint64_t dec_frames = 0;
+  // kernel timing
+  bool timing = false;
+  KernelTimer timers[4];
+};
+
+#define HIPCHK(ctx, call)                                                                       \
+  do {                                                                                          \
+    hipError_t e_ = (call);                                                                     \
+    if (e_ != hipSuccess) {                                                                     \
+      if (ctx) (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(e_);           \
+      return X3_ERR_HIP;                                                                        \
+    }                                                                                           \
+  } while (0)
+
+static int ensure(x3_ctx* c, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return X3_OK;
+  if (b.p) HIPCHK(c, hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  size_t want = std::max(bytes, (size_t)4096);
+  want = (want + 255) & ~(size_t)255;
+  HIPCHK(c, hipMalloc(&b.p, want));
+  b.cap = want;
+  return X3_OK;
+}
+
+// ---- GF(2)[x] mod 0x11021 on the host (for the x^n table only)
+static uint32_t gf_mul_host(uint32_t a, uint32_t b) {
+  uint32_t r = 0;
+  for (int i = 0; i < 16; ++i) {
+    if ((a >> i) & 1u) r ^= b;
+    b = (b << 1) ^ ((b & 0x8000u) ? 0x11021u : 0u);
+  }
+  return r & 0xFFFFu;
+}
+static uint32_t gf_xpow_host(uint64_t e) {  // x^e mod P
+  uint32_t result = 1, base = 2;
+  while (e) {
+    if (e & 1) result = gf_mul_host(result, base);
+    base = gf_mul_host(base, base);
+    e >>= 1;
+  }
+  return result;
+}
+
+static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
+  int count = 0;
+  HIPCHK(c, hipGetDeviceCount(&count));
+  if (device < 0 || device >= count) {
+    c->last_error = "no such HIP device";
+    return X3_ERR_HIP;
+  }
+  HIPCHK(c, hipSetDevice(device));
+  c->device = device;
+  if (own) {
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  } else {
+    c->stream = stream;
+  }
+  HIPCHK(c, hipMalloc(&c->d_xpow, X3_XP_SIZE * sizeof(uint16_t)));
+  HIPCHK(c, hipMalloc(&c->d_status, 4 * sizeof(int)));
+  HIPCHK(c, hipMalloc(&c->d_stats, 8 * sizeof(unsigned long long)));
+  c->d_end_pos = c->d_stats + 6;
+  HIPCHK(c, hipMalloc(&c->d_summary, sizeof(X3DecodeSummary)));
+  HIPCHK(c, hipMalloc(&c->d_crc, 16));
+  HIPCHK(c, hipHostMalloc(&c->h_status, 4 * sizeof(int)));
+  HIPCHK(c, hipHostMalloc(&c->h_stats, 8 * sizeof(unsigned long long)));
+  HIPCHK(c, hipHostMalloc(&c->h_summary, sizeof(X3DecodeSummary)));
+  HIPCHK(c, hipHostMalloc(&c->h_crc, 16));
+  std::vector<uint16_t> xp(X3_XP_SIZE);
+  for (int j = 0; j < X3_XP_LEVELS; ++j)
+    for (int m = 0; m <= X3_XP_M; ++m) xp[j * (X3_XP_M + 1) + m] = (uint16_t)gf_xpow_host(32ull * m * (1ull << j));
+  // x^-1 = x^15 + x^11 + x^4 (x * that = x^16 + x^12 + x^5 = P + 1); x^-16 = (x^-1)^16
+  uint32_t xi = 0x8810u;
+  for (int i = 0; i < 4; ++i) xi = gf_mul_host(xi, xi);
+  xp[X3_XINV16_INDEX] = (uint16_t)xi;
+  HIPCHK(c, hipMemcpy(c->d_xpow, xp.data(), X3_XP_SIZE * sizeof(uint16_t), hipMemcpyHostToDevice));
+  return X3_OK;
+}
+
+extern "C" int x3_ctx_create(int device, x3_ctx** ctx) {
+  if (!ctx) return X3_ERR_BAD_ARG;
+  *ctx = nullptr;
+  x3_ctx* c = new x3_ctx();
+  int rc = ctx_init(c, device, nullptr, true);
+  if (rc) {
+    std::fprintf(stderr, "x3hip: cannot create context on device %d: %s\n", device, c->last_error.c_str());
+    delete c;
+    return rc;
+  }
+  *ctx = c;
+  return X3_OK;
+}
+
+extern "C" int x3_ctx_create_on_stream(int device, void* hip_stream, x3_ctx** ctx) {
+  if (!ctx) return X3_ERR_BAD_ARG;
+  *ctx = nullptr;
+  x3_ctx* c = new x3_ctx();
+  int rc = ctx_init(c, device, (hipStream_t)hip_stream, false);
+  if (rc) {
+    std::fprintf(stderr, "x3hip: cannot create context on device %d: %s\n", device, c->last_error.c_str());
+    delete c;
+    return rc;
+  }
+  *ctx = c;
+  return X3_OK;
+}
+
+extern "C" void x3_ctx_destroy(x3_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (DevBuf* b : {&c->in, &c->out, &c->frame_bytes, &c->frame_off, &c->dec_status, &c->dec_nsamp, &c->wav_off,
+                    &c->seg_crc})
+    if (b->p) (void)hipFree(b->p);
+  for (auto& t : c->timers) {
+    for (auto& e : t.used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto& e : t.pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  }
+  (void)hipFree(c->d_xpow);
+  (void)hipFree(c->d_status);
+  (void)hipFree(c->d_stats);
+  (void)hipFree(c->d_summary);
+  (void)hipFree(c->d_crc);
+  (void)hipHostFree(c->h_status);
+  (void)hipHostFree(c->h_stats);
+  (void)hipHostFree(c->h_summary);
+  (void)hipHostFree(c->h_crc);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int x3_ctx_sync(x3_ctx* c) {
+  if (!c) return X3_ERR_BAD_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return X3_OK;
+}
+
+extern "C" const char* x3_last_error(const x3_ctx* c) { return c ? c->last_error.c_str() : ""; }
+
+extern "C" const char* x3_strerror(int s) {
+  static const char* names[] = {"Ok", "Io", "Hound", "BitPack", "InvalidEncodingThresh", "OutOfBoundsInverse",
+                                "MoreThanOneChannel", "ArchiveHeaderXMLInvalid", "ArchiveHeaderXMLRiceCode",
+                                "ArchiveHeaderXMLInvalidKey", "FrameLength", "FrameHeaderInvalidKey",
+                                "FrameHeaderInvalidPayloadLen", "FrameHeaderInvalidHeaderCRC",
+                                "FrameHeaderInvalidPayloadCRC", "FrameDecodeInvalidBlockLength",
+                                "FrameDecodeInvalidIndex", "FrameDecodeInvalidNTOGO", "FrameDecodeInvalidFType",
+                                "FrameDecodeInvalidRiceCode", "FrameDecodeInvalidBPF", "FrameDecodeUnexpectedEnd",
+                                "ByteWriterInsufficientMemory", "Hip", "BadArg"};
+  return (s >= 0 && s <= 24) ? names[s] : "Unknown";
+}
+
+// ---- kernel timing
+struct TimerScope {
+  x3_ctx* c;
+  int which;
+  std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+  TimerScope(x3_ctx* c_, int w) : c(c_), which(w) {
+    if (!c->timing) return;
+    KernelTimer& t = c->timers[which];
+    if (!t.pool.empty()) {
+      ev = t.pool.back();
+      t.pool.pop_back();
+    } else {
+      (void)hipEventCreate(&ev.first);
+      (void)hipEventCreate(&ev.second);
+    }
+    (void)hipEventRecord(ev.first, c->stream);
+  }
+  ~TimerScope() {
+    if (!c->timing) return;
+    (void)hipEventRecord(ev.second, c->stream);
+    c->timers[which].used.push_back(ev);
+  }
+};
+
+extern "C" int x3_ctx_enable_kernel_timing(x3_ctx* c, int enable) {
+  if (!c) return X3_ERR_BAD_ARG;
+  c->timing = enable != 0;
+  return X3_OK;
+}
+
+extern "C" int x3_ctx_reset_kernel_time(x3_ctx* c) {
+  if (!c) return X3_ERR_BAD_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (auto& t : c->timers) {
+    for (auto& e : t.used) t.pool.push_back(e);
+    t.used.clear();
+  }
+  return X3_OK;
+}
+
+extern "C" int x3_ctx_kernel_time(x3_ctx* c, int which, double* total_ms, uint64_t* launches) {
+  if (!c || which < 0 || which > 3) return X3_ERR_BAD_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double tot = 0;
+  for (auto& e : c->timers[which].used) {
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, e.first, e.second));
+    tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = c->timers[which].used.size();
+  return X3_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// x3.rs: parameters
+// ------------------------------------------------------------------------------------------------
+static const uint32_t RICE_OFFSET[4] = {6, 11, 20, 28};   // src/x3.rs:209,216,223,236
+static const uint32_t RICE_LEN[4] = {14, 22, 40, 56};     // table lengths, src/x3.rs:210-249
+static const uint32_t RICE_INV_LEN[4] = {16, 26, 44, 60}; // src/x3.rs:213,220,233,250
+
+extern "C" void x3_params_default(x3_params* p) {
+  if (!p) return;
+  p->block_len = 20;
+  p->blocks_per_frame = 500;
+  p->codes[0] = 0; p->codes[1] = 1; p->codes[2] = 3;
+  p->thresholds[0] = 3; p->thresholds[1] = 8; p->thresholds[2] = 20;
+}
+
+extern "C" int x3_params_validate(const x3_params* p) {
+  if (!p) return X3_ERR_BAD_ARG;
+  for (int k = 0; k < 3; ++k)
+    if (p->codes[k] > 3) return X3_ERR_BAD_ARG;  // RiceCodes::get indexes CODE[4] -> panic
+  for (int k = 0; k < 2; ++k)                    // only k = 0,1 are checked (x3.rs:107-112)
+    if (p->thresholds[k] > RICE_OFFSET[p->codes[k]]) return X3_ERR_INVALID_ENCODING_THRESH;
+  return X3_OK;
+}
+
+static uint64_t spf_of(const x3_params* p) { return (uint64_t)p->block_len * (uint64_t)p->blocks_per_frame; }
+
+// worst-case payload bytes of a frame of n samples: every block literal
+static uint64_t max_payload_bytes(uint64_t n, uint32_t block_len) {
+  if (n == 0) return 0;
+  uint64_t nblocks = block_len ? (n - 1 + block_len - 1) / block_len : 0;
+  uint64_t bits = 16 + nblocks * 6 + 16 * (n - 1);
+  return (((bits + 7) >> 3) + 1) & ~1ull;
+}
+
+extern "C" uint64_t x3_num_frames(uint64_t n, const x3_params* p) {
+  uint64_t spf = p ? spf_of(p) : 0;
+  return spf ? (n + spf - 1) / spf : 0;
+}
+
+extern "C" uint64_t x3_encode_bound(uint64_t n, const x3_params* p) {
+  if (!p) return 0;
+  uint64_t spf = spf_of(p);
+  if (!spf || !n) return 1;
+  uint64_t full = n / spf, tail = n % spf;
+  return full * (20 + max_payload_bytes(spf, p->block_len)) + (tail ? 20 + max_payload_bytes(tail, p->block_len) : 0) + 1;
+}
+
+static int derive(const x3_params* p, uint64_t spf, X3DevParams* d) {
+  int rc = x3_params_validate(p);
+  if (rc == X3_ERR_BAD_ARG) return rc;  // a threshold violation is only an error in Parameters::new
+  for (int k = 0; k < 3; ++k)
+    if (p->thresholds[k] > 0x7FFFFFFFu) return X3_ERR_BAD_ARG;
+  d->block_len = p->block_len;
+  d->blocks_per_frame = p->blocks_per_frame;
+  d->spf = (uint32_t)spf;
+  for (int k = 0; k < 3; ++k) {
+    uint32_t c = p->codes[k];
+    d->thr[k] = p->thresholds[k];
+    d->k[k] = c;
+    d->dmin[k] = -(int32_t)RICE_OFFSET[c];
+    d->dmax[k] = (int32_t)RICE_LEN[c] - (int32_t)RICE_OFFSET[c] - 1;
+    d->inv_len[k] = RICE_INV_LEN[c];
+  }
+  return X3_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// crc.rs / frame header helpers (20-byte host arithmetic)
+// ------------------------------------------------------------------------------------------------
+extern "C" uint16_t x3_crc16_update(uint16_t crc, uint8_t byte) {
+  uint32_t t = ((crc >> 8) ^ byte) & 0xFFu;
+  t ^= t >> 4;
+  return (uint16_t)(((uint32_t)crc << 8) ^ (t << 12) ^ (t << 5) ^ t);
+}
+
+static uint16_t header_crc16_host(const uint8_t* b, size_t n) {  // headers only (16 bytes)
+  uint16_t crc = 0xFFFF;
+  for (size_t i = 0; i < n; ++i) crc = x3_crc16_update(crc, b[i]);
+  return crc;
+}
+
+extern "C" void x3_write_frame_header(uint64_t num_samples, uint8_t id, uint64_t payload_len, uint16_t payload_crc,
+                                      uint8_t out[X3_FRAME_HEADER_LENGTH]) {
+  std::memset(out, 0, 20);
+  out[0] = 0x78; out[1] = 0x33;
+  out[2] = id;
+  out[3] = id;  // the reference writes `id` here too (encoder.rs:135)
+  out[4] = (uint8_t)(num_samples >> 8); out[5] = (uint8_t)num_samples;
+  out[6] = (uint8_t)(payload_len >> 8); out[7] = (uint8_t)payload_len;
+  uint16_t hc = header_crc16_host(out, 16);
+  out[16] = (uint8_t)(hc >> 8); out[17] = (uint8_t)hc;
+  out[18] = (uint8_t)(payload_crc >> 8); out[19] = (uint8_t)payload_crc;
+}
+
+extern "C" int x3_read_frame_header(const uint8_t* b, uint64_t len, x3_frame_header* h) {
+  if (!b || !h) return X3_ERR_BAD_ARG;
+  if (len < 20) return X3_ERR_FRAME_DECODE_UNEXPECTED_END;
+  if ((((uint16_t)b[16] << 8) | b[17]) != header_crc16_host(b, 16)) return X3_ERR_FRAME_HEADER_INVALID_HEADER_CRC;
+  if (b[0] != 0x78 || b[1] != 0x33) return X3_ERR_FRAME_HEADER_INVALID_KEY;
+  if (b[3] > 1) return X3_ERR_MORE_THAN_ONE_CHANNEL;
+  uint32_t plen = ((uint32_t)b[6] << 8) | b[7];
+  if (plen >= X3_FRAME_MAX_LENGTH) return X3_ERR_FRAME_LENGTH;
+  h->source_id = b[2];
+  h->channels = b[3];
+  h->samples = (uint16_t)(((uint16_t)b[4] << 8) | b[5]);
+  h->payload_len = plen;
+  h->payload_crc = (uint16_t)(((uint16_t)b[18] << 8) | b[19]);
+  return X3_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// buffer CRC on the GPU
+// ------------------------------------------------------------------------------------------------
+static int crc_dev_async(x3_ctx* c, const uint8_t* d_data, uint64_t n) {
+  if (reinterpret_cast<uintptr_t>(d_data) & 3u) return X3_ERR_BAD_ARG;
+  const uint64_t n_dw = n >> 2;
+  const uint64_t n_seg = (n_dw + X3_CRC_SEG_DW - 1) / X3_CRC_SEG_DW;
+  if (n_seg > 0x7FFFFFFFull) return X3_ERR_BAD_ARG;
+  int rc = ensure(c, c->seg_crc, (n_seg + 1) * sizeof(uint16_t));
+  if (rc) return rc;
+  if (n_seg)
+    hipLaunchKernelGGL(x3_crc_segments_kernel, dim3((unsigned)n_seg), dim3(64), 0, c->stream,
+                       reinterpret_cast<const uint32_t*>(d_data), n_dw, n_seg, c->d_xpow, (uint16_t*)c->seg_crc.p);
+  hipLaunchKernelGGL(x3_crc_combine_kernel, dim3(1), dim3(64), 0, c->stream, d_data, n, n_seg,
+                     (const uint16_t*)c->seg_crc.p, c->d_xpow, c->d_crc);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->h_crc, c->d_crc, sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
+  return X3_OK;
+}
+
+extern "C" int x3_crc16_dev(x3_ctx* c, const uint8_t* d_data, uint64_t n, uint16_t* crc) {
+  if (!c || !crc || (!d_data && n)) return X3_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = crc_dev_async(c, d_data, n);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *crc = *c->h_crc;
+  return X3_OK;
+}
+
+extern "C" int x3_crc16(x3_ctx* c, const uint8_t* data, uint64_t n, uint16_t* crc) {
+  if (!c || !crc || (!data && n)) return X3_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = ensure(c, c->in, n + 16);
+  if (rc) return rc;
+  if (n) HIPCHK(c, hipMemcpyAsync(c->in.p, data, n, hipMemcpyHostToDevice, c->stream));
+  return x3_crc16_dev(c, (const uint8_t*)c->in.p, n, crc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// encode
+// ------------------------------------------------------------------------------------------------
+struct EncPlan {
+  X3DevParams dp;
+  X3Geom g;
+  uint32_t nthr, lds_in_bytes, img_dwords;
+  size_t smem;
+};
+
+static int plan_encode(x3_ctx* c, const x3_batch* b, const x3_params* p, uint64_t spf, EncPlan* pl) {
+  int rc = derive(p, spf, &pl->dp);
+  if (rc) return rc;
+  if (spf == 0 || spf > 0xFFFFFFFFull || p->block_len == 0) return X3_ERR_BAD_ARG;
+  const uint64_t fpc = (b->n_per_clip + spf - 1) / spf;
+  if (fpc == 0 || fpc > 0xFFFFFFFFull) return X3_ERR_BAD_ARG;
+  const uint64_t F = fpc * b->n_clips;
+  if (F == 0 || F > 0x7FFFFFFFull) return X3_ERR_BAD_ARG;
+  pl->g.n_per_clip = b->n_per_clip;
+  pl->g.clip_stride = b->clip_stride;
+  pl->g.fpc = (uint32_t)fpc;
+  pl->g.n_frames = F;
+  const uint64_t nmax = std::min<uint64_t>(spf, b->n_per_clip);   // samples in the largest frame
+  // a block longer than MAX_BLOCK_LENGTH = 60 samples overruns the reference's diff array (encoder.rs:296-299)
+  if (std::min<uint64_t>(p->block_len, nmax - 1) > 60) return X3_ERR_BAD_ARG;
+  const uint64_t nblocks = (nmax - 1 + p->block_len - 1) / p->block_len;
+  uint32_t nthr = (uint32_t)std::min<uint64_t>(512, std::max<uint64_t>(64, (nblocks + 63) & ~63ull));
+  pl->nthr = nthr;
+  const uint64_t in_bytes = (2 * nmax + 15) & ~15ull;
+  const uint64_t img_dw = ((5 + (max_payload_bytes(nmax, p->block_len) + 3) / 4 + 4) + 3) & ~3ull;
+  const uint64_t smem = X3_ENC_SMEM_HDR + in_bytes + img_dw * 4;
+  if (smem > 160 * 1024) {
+    c->last_error = "frame too large for the LDS-resident encoder (block_len*blocks_per_frame)";
+    return X3_ERR_BAD_ARG;
+  }
+  pl->lds_in_bytes = (uint32_t)in_bytes;
+  pl->img_dwords = (uint32_t)img_dw;
+  pl->smem = (size_t)smem;
+  return X3_OK;
+}
+
+static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3_params* p, uint64_t spf,
+                           uint8_t* d_out, uint64_t out_cap, uint64_t start_pos, uint64_t* d_frame_offsets) {
+  EncPlan pl;
+  int rc = plan_encode(c, b, p, spf, &pl);
+  if (rc) return rc;
+  if (reinterpret_cast<uintptr_t>(d_out) & 1u) return X3_ERR_BAD_ARG;
+  if (reinterpret_cast<uintptr_t>(d_wav) & 1u) return X3_ERR_BAD_ARG;
+  const uint64_t F = pl.g.n_frames;
+  if ((rc = ensure(c, c->frame_bytes, F * sizeof(uint32_t)))) return rc;
+  uint64_t* d_off = d_frame_offsets;
+  if (!d_off) {
+    if ((rc = ensure(c, c->frame_off, (F + 1) * sizeof(uint64_t)))) return rc;
+    d_off = (uint64_t*)c->frame_off.p;
+  }
+  HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4 * sizeof(int), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 8 * sizeof(unsigned long long), c->stream));
+  if (pl.smem > 64 * 1024) {
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_frames_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem));
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_frames_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem));
+  }
+  {
+    TimerScope ts(c, 2);
+    hipLaunchKernelGGL(x3_encode_frames_kernel<true>, dim3((unsigned)F), dim3(pl.nthr),
+                       X3_ENC_SMEM_HDR + pl.lds_in_bytes, c->stream, d_wav, pl.g, pl.dp, (const uint64_t*)nullptr,
+                       (uint32_t*)c->frame_bytes.p, (uint8_t*)nullptr, start_pos, c->d_stats, c->d_status,
+                       (const uint16_t*)c->d_xpow, pl.lds_in_bytes, 0u);
+  }
+  {
+    TimerScope ts(c, 3);
+    hipLaunchKernelGGL(x3_scan_frame_offsets_kernel, dim3(1), dim3(1024), 0, c->stream,
+                       (const uint32_t*)c->frame_bytes.p, F, start_pos, out_cap, d_off, c->d_end_pos, c->d_status);
+  }
+  {
+    TimerScope ts(c, 0);
+    hipLaunchKernelGGL(x3_encode_frames_kernel<false>, dim3((unsigned)F), dim3(pl.nthr), pl.smem, c->stream, d_wav,
+                       pl.g, pl.dp, (const uint64_t*)d_off, (uint32_t*)nullptr, d_out, start_pos, c->d_stats,
+                       c->d_status, (const uint16_t*)c->d_xpow, pl.lds_in_bytes, pl.img_dwords);
+  }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_status, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_stats, c->d_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  c->encode_pending = true;
+  c->enc_start_pos = start_pos;
+  return X3_OK;
+}
+
+extern "C" int x3_encode_dev(x3_ctx* c, const int16_t* d_wav, const x3_batch* batch, const x3_params* p,
+                             uint8_t* d_out, uint64_t out_cap, uint64_t start_pos, uint64_t* d_frame_offsets) {
+  if (!c || !d_wav || !batch || !p || !d_out) return X3_ERR_BAD_ARG;
+  if (batch->n_per_clip == 0 || batch->n_clips == 0) return X3_ERR_BAD_ARG;
+  if (batch->n_clips > 1 && batch->clip_stride < batch->n_per_clip) return X3_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  return encode_dev_impl(c, d_wav, batch, p, spf_of(p), d_out, out_cap, start_pos, d_frame_offsets);
+}
+
+extern "C" int x3_encode_result(x3_ctx* c, uint64_t* out_pos, uint64_t stats[6]) {
+  if (!c) return X3_ERR_BAD_ARG;
+  if (!c->encode_pending) return X3_ERR_BAD_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->encode_pending = false;
+  if (out_pos) *out_pos = c->h_stats[6];
+  if (stats)
+    for (int i = 0; i < 6; ++i) stats[i] = c->h_stats[i];
+  int st = std::max(c->h_status[0], c->h_status[1]);
+  return st;
+}
+
+// host-buffer front end shared by x3_encode / x3_encode_frame / x3_encode_batch
+static int encode_host(x3_ctx* c, const int16_t* const* wavs, uint64_t n_per_clip, uint64_t n_clips,
+                       const x3_params* p, uint64_t spf, uint8_t* out, uint64_t out_cap, uint64_t start_pos,
+                       uint64_t* out_pos, uint64_t* clip_offsets, uint64_t stats[6]) {
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint64_t total = n_per_clip * n_clips;
+  int rc = ensure(c, c->in, total * sizeof(int16_t) + 16);
+  if (rc) return rc;
+  for (uint64_t k = 0; k < n_clips; ++k)
+    HIPCHK(c, hipMemcpyAsync((int16_t*)c->in.p + k * n_per_clip, wavs[k], n_per_clip * sizeof(int16_t),
+                             hipMemcpyHostToDevice, c->stream));
+  x3_params pp = *p;
+  x3_batch b{n_per_clip, n_per_clip, n_clips};
+  uint64_t bound;
+  {
+    uint64_t full = n_per_clip / spf, tail = n_per_clip % spf;
+    bound = n_clips * (full * (20 + max_payload_bytes(spf, p->block_len)) +
+                       (tail ? 20 + max_payload_bytes(tail, p->block_len) : 0));
+  }
+  if (start_pos > out_cap) return X3_ERR_BYTE_WRITER_INSUFFICIENT_MEMORY;
+  const uint64_t dev_cap = std::min<uint64_t>(out_cap, start_pos + 1 + bound);
+  if ((rc = ensure(c, c->out, dev_cap + 16))) return rc;
+  if ((rc = encode_dev_impl(c, (const int16_t*)c->in.p, &b, &pp, spf, (uint8_t*)c->out.p, out_cap, start_pos, nullptr)))
+    return rc;
+  uint64_t pos = 0;
+  rc = x3_encode_result(c, &pos, stats);
+  if (out_pos) *out_pos = pos;
+  if (rc) return rc;
+  if (pos > start_pos)
+    HIPCHK(c, hipMemcpyAsync(out + start_pos, (uint8_t*)c->out.p + start_pos, pos - start_pos, hipMemcpyDeviceToHost,
+                             c->stream));
+  if (clip_offsets) {
+    const uint64_t fpc = (n_per_clip + spf - 1) / spf;
+    std::vector<uint64_t> offs(fpc * n_clips + 1);
+    HIPCHK(c, hipMemcpyAsync(offs.data(), c->frame_off.p, offs.size() * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint64_t k = 0; k <= n_clips; ++k) clip_offsets[k] = offs[k * fpc];
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return X3_OK;
+}
+
+extern "C" int x3_encode(x3_ctx* c, const int16_t* wav, uint64_t n, uint32_t n_channels, const x3_params* p,
+                         uint8_t* out, uint64_t out_cap, uint64_t start_pos, uint64_t* out_pos, uint64_t stats[6]) {
+  if (!c || !p || (!wav && n) || (!out && out_cap)) return X3_ERR_BAD_ARG;
+  if (n_channels > 1) return X3_ERR_MORE_THAN_ONE_CHANNEL;  // encoder.rs:55-57
+  if (n_channels == 0) return X3_ERR_BAD_ARG;                // channels[0] panics
+  if (stats) std::memset(stats, 0, 6 * sizeof(uint64_t));
+  if (out_pos) *out_pos = start_pos;
+  int rc = x3_params_validate(p);
+  if (rc == X3_ERR_BAD_ARG) return rc;
+  const uint64_t spf = spf_of(p);
+  if (spf == 0 || n == 0) return X3_OK;  // take(0) / empty iterator: nothing is written (encoder.rs:67-73)
+  return encode_host(c, &wav, n, 1, p, spf, out, out_cap, start_pos, out_pos, nullptr, stats);
+}
+
+extern "C" int x3_encode_frame(x3_ctx* c, const int16_t* wav, uint64_t n, const x3_params* p, uint8_t* out,
+                               uint64_t out_cap, uint64_t start_pos, uint64_t* out_pos, uint64_t stats[6]) {
+  if (!c || !p || !wav || (!out && out_cap)) return X3_ERR_BAD_ARG;
+  if (stats) std::memset(stats, 0, 6 * sizeof(uint64_t));
+  if (out_pos) *out_pos = start_pos;
+  if (n == 0) return X3_ERR_BAD_ARG;  // wav[0] panics (encoder.rs:189)
+  int rc = x3_params_validate(p);
+  if (rc == X3_ERR_BAD_ARG) return rc;
+  if (p->block_len == 0 && n > 1) return X3_ERR_BAD_ARG;  // chunks(0) panics
+  x3_params pp = *p;
+  if (pp.block_len == 0) pp.block_len = 1;
+  // the whole slice is ONE frame, whatever blocks_per_frame says
+  return encode_host(c, &wav, n, 1, &pp, n, out, out_cap, start_pos, out_pos, nullptr, stats);
+}
+
+extern "C" int x3_encode_batch(x3_ctx* c, const int16_t* const* wavs, const uint64_t* ns, uint64_t count,
+                               const x3_params* p, uint8_t* out, uint64_t out_cap, uint64_t* clip_offsets,
+                               uint64_t stats[6]) {
+  if (!c || !p || !wavs || !ns || !count || !clip_offsets) return X3_ERR_BAD_ARG;
+  if (stats) std::memset(stats, 0, 6 * sizeof(uint64_t));
+  int rc = x3_params_validate(p);
+  if (rc == X3_ERR_BAD_ARG) return rc;
+  const uint64_t spf = spf_of(p);
+  if (spf == 0) return X3_ERR_BAD_ARG;
+  bool uniform = true;
+  for (uint64_t k = 1; k < count; ++k) uniform = uniform && ns[k] == ns[0];
+  if (uniform && ns[0] > 0) {
+    uint64_t pos = 0;
+    return encode_host(c, wavs, ns[0], count, p, spf, out, out_cap, 0, &pos, clip_offsets, stats);
+  }
+  // ragged batch: one launch set per clip, streams appended back to back
+  uint64_t pos = 0;
+  clip_offsets[0] = 0;
+  for (uint64_t k = 0; k < count; ++k) {
+    uint64_t st[6] = {0, 0, 0, 0, 0, 0};
+    if (ns[k]) {
+      rc = encode_host(c, &wavs[k], ns[k], 1, p, spf, out, out_cap, pos, &pos, nullptr, st);
+      if (rc) return rc;
+    }
+    clip_offsets[k + 1] = pos;
+    if (stats)
+      for (int i = 0; i < 6; ++i) stats[i] += st[i];
+  }
+  return X3_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode
+// ------------------------------------------------------------------------------------------------
+static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint64_t* d_frame_offsets,
+                           uint64_t F, const x3_batch* batch, const uint64_t* d_wav_offsets, const x3_params* p,
+                           int16_t* d_wav, uint64_t wav_cap, int32_t* d_status) {
+  if (reinterpret_cast<uintptr_t>(d_x3) & 3u) return X3_ERR_BAD_ARG;
+  if (reinterpret_cast<uintptr_t>(d_wav) & 1u) return X3_ERR_BAD_ARG;
+  if (F == 0 || F > 0x7FFFFFFFull) return X3_ERR_BAD_ARG;
+  const uint64_t spf = spf_of(p);
+  X3DevParams dp;
+  int rc = derive(p, spf > 0xFFFFFFFFull ? 0 : spf, &dp);
+  if (rc) return rc;
+  X3Geom g{0, 0, 1, F};
+  if (!d_wav_offsets) {
+    if (!batch || spf == 0) return X3_ERR_BAD_ARG;
+    const uint64_t fpc = (batch->n_per_clip + spf - 1) / spf;
+    if (fpc == 0 || fpc > 0xFFFFFFFFull) return X3_ERR_BAD_ARG;
+    g.n_per_clip = batch->n_per_clip;
+    g.clip_stride = batch->clip_stride;
+    g.fpc = (uint32_t)fpc;
+  }
+  if ((rc = ensure(c, c->dec_nsamp, F * sizeof(uint32_t)))) return rc;
+  if (!d_status) {
+    if ((rc = ensure(c, c->dec_status, F * sizeof(int32_t)))) return rc;
+    d_status = (int32_t*)c->dec_status.p;
+  }
+  const unsigned nthr = 64;
+  const unsigned grid = (unsigned)((F + nthr - 1) / nthr);
+  {
+    TimerScope ts(c, 1);
+    hipLaunchKernelGGL(x3_decode_frames_kernel, dim3(grid), dim3(nthr), 0, c->stream, d_x3, x3_len, d_frame_offsets,
+                       F, g, d_wav_offsets, dp, d_wav, wav_cap, d_status, (uint32_t*)c->dec_nsamp.p);
+  }
+  hipLaunchKernelGGL(x3_decode_summary_kernel, dim3(1), dim3(1024), 0, c->stream, (const int32_t*)d_status,
+                     (const uint32_t*)c->dec_nsamp.p, F, c->d_summary);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(X3DecodeSummary), hipMemcpyDeviceToHost, c->stream));
+  c->decode_pending = true;
+  c->dec_frames = F;
+  return X3_OK;
+}
+
+extern "C" int x3_decode_dev(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint64_t* d_frame_offsets,
+                             uint64_t n_frames, const x3_batch* batch, const uint64_t* d_wav_offsets,
+                             const x3_params* p, int16_t* d_wav, uint64_t wav_cap, int32_t* d_status) {
+  if (!c || !d_x3 || !d_frame_offsets || !p || !d_wav) return X3_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  return decode_dev_impl(c, d_x3, x3_len, d_frame_offsets, n_frames, batch, d_wav_offsets, p, d_wav, wav_cap, d_status);
+}
+
+extern "C" int x3_decode_result(x3_ctx* c, uint64_t* first_bad, int* first_bad_status, uint64_t* samples_before) {
+  if (!c || !c->decode_pending) return X3_ERR_BAD_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->decode_pending = false;
+  if (first_bad) *first_bad = c->h_summary->first_bad;
+  if (first_bad_status) *first_bad_status = c->h_summary->first_bad_status;
+  if (samples_before) *samples_before = c->h_summary->samples_before;
+  return X3_OK;
+}
+
+extern "C" int x3_decode_stream(x3_ctx* c, const uint8_t* x3, uint64_t len, const x3_params* p, int16_t* wav,
+                                uint64_t wav_cap, uint64_t* n_out, uint64_t* frames_ok, uint64_t* frame_errors) {
+  if (!c || !p || (!x3 && len) || (!wav && wav_cap)) return X3_ERR_BAD_ARG;
+  if (n_out) *n_out = 0;
+  if (frames_ok) *frames_ok = 0;
+  if (frame_errors) *frame_errors = 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  // ---- host side of the walk (decodefile.rs:105-121): header chain, lengths, terminal condition
+  std::vector<uint64_t> offs, woffs;
+  uint64_t pos = 0, remaining = len, nsamp = 0;
+  int terminal = X3_OK;
+  for (;;) {
+    if (remaining <= 20) break;
+    x3_frame_header h;
+    int rc = x3_read_frame_header(x3 + pos, 20, &h);
+    if (rc) { terminal = rc; break; }
+    if (remaining - 20 < h.payload_len) break;
+    if (h.payload_len > X3_READ_BUFFER_SIZE) { terminal = X3_ERR_FRAME_HEADER_INVALID_PAYLOAD_LEN; break; }
+    if (h.samples == 0 || h.payload_len < 2 || nsamp + h.samples > wav_cap || (p->block_len == 0 && h.samples > 1)) {
+      // payload CRC is checked before decode_frame runs, so let the GPU look at this frame too:
+      // it reports the CRC error if there is one, BAD_ARG (reference panic) otherwise
+      offs.push_back(pos);
+      woffs.push_back(nsamp);
+      terminal = X3_ERR_BAD_ARG;
+      break;
+    }
+    offs.push_back(pos);
+    woffs.push_back(nsamp);
+    nsamp += h.samples;
+    pos += 20 + h.payload_len;
+    remaining -= 20 + h.payload_len;
+  }
+  const uint64_t F = offs.size();
+  if (F == 0) return terminal;
+  int rc;
+  if ((rc = ensure(c, c->in, len + 16))) return rc;
+  if ((rc = ensure(c, c->frame_off, (F + 1) * sizeof(uint64_t)))) return rc;
+  if ((rc = ensure(c, c->wav_off, F * sizeof(uint64_t)))) return rc;
+  if ((rc = ensure(c, c->out, (nsamp + 65536) * sizeof(int16_t)))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->in.p, x3, len, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->frame_off.p, offs.data(), F * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->wav_off.p, woffs.data(), F * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  x3_params pp = *p;
+  if (pp.block_len == 0) pp.block_len = 1;  // frames that need block_len were routed to BAD_ARG above
+  const uint64_t dev_wav_cap = std::min<uint64_t>(wav_cap, nsamp + 65535);
+  if ((rc = decode_dev_impl(c, (const uint8_t*)c->in.p, len, (const uint64_t*)c->frame_off.p, F, nullptr,
+                            (const uint64_t*)c->wav_off.p, &pp, (int16_t*)c->out.p, dev_wav_cap, nullptr)))
+    return rc;
+  uint64_t first_bad = 0, before = 0;
+  int bad_status = 0;
+  if ((rc = x3_decode_result(c, &first_bad, &bad_status, &before))) return rc;
+  if (before) HIPCHK(c, hipMemcpyAsync(wav, c->out.p, before * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (n_out) *n_out = before;
+  if (frames_ok) *frames_ok = first_bad;
+  if (first_bad < F) {
+    if (bad_status == X3_ERR_OUT_OF_BOUNDS_INVERSE || bad_status == X3_ERR_FRAME_DECODE_INVALID_BPF) {
+      if (frame_errors) *frame_errors = 1;  // counted, the walk ends quietly (decodefile.rs:129-135)
+      return X3_OK;
+    }
+    return bad_status;  // payload CRC mismatch (hard error) or BAD_ARG (reference panic)
+  }
+  return terminal;
+}
+
+// single bare payload (decoder::decode_frame): wrap it in a frame header so that the one decode
+// kernel serves both paths; decode_frame itself checks no CRC, so a correct one is supplied.
+extern "C" int x3_decode_frame(x3_ctx* c, const uint8_t* payload, uint64_t len, int16_t* wav, uint64_t wav_cap,
+                               const x3_params* p, uint64_t samples, uint64_t* n_out) {
+  if (!c || !p || !payload || !wav) return X3_ERR_BAD_ARG;
+  if (n_out) *n_out = 0;
+  if (len < 2 || samples == 0 || wav_cap < 1) return X3_ERR_BAD_ARG;  // reference panics
+  if (p->block_len == 0 && samples > 1) return X3_ERR_BAD_ARG;         // reference never returns
+  if (samples > wav_cap) return X3_ERR_BAD_ARG;                        // slice index panic
+  if (samples > 0xFFFF || len >= X3_FRAME_MAX_LENGTH || len > X3_READ_BUFFER_SIZE) return X3_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = ensure(c, c->in, 20 + len + 16))) return rc;
+  if ((rc = ensure(c, c->frame_off, 2 * sizeof(uint64_t)))) return rc;
+  if ((rc = ensure(c, c->wav_off, sizeof(uint64_t)))) return rc;
+  if ((rc = ensure(c, c->out, (samples + 16) * sizeof(int16_t)))) return rc;
+  HIPCHK(c, hipMemcpyAsync((uint8_t*)c->in.p + 20, payload, len, hipMemcpyHostToDevice, c->stream));
+  uint16_t pcrc = 0;
+  if ((rc = crc_dev_async(c, (const uint8_t*)c->in.p + 20, len))) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  pcrc = *c->h_crc;
+  uint8_t hdr[20];
+  x3_write_frame_header(samples, 1, len, pcrc, hdr);
+  const uint64_t zero = 0;
+  HIPCHK(c, hipMemcpyAsync(c->in.p, hdr, 20, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->frame_off.p, &zero, sizeof zero, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->wav_off.p, &zero, sizeof zero, hipMemcpyHostToDevice, c->stream));
+  x3_params pp = *p;
+  if (pp.block_len == 0) pp.block_len = 1;
+  if ((rc = decode_dev_impl(c, (const uint8_t*)c->in.p, 20 + len, (const uint64_t*)c->frame_off.p, 1, nullptr,
+                            (const uint64_t*)c->wav_off.p, &pp, (int16_t*)c->out.p, samples, nullptr)))
+    return rc;
+  uint64_t first_bad = 0, before = 0;
+  int bad_status = 0;
+  if ((rc = x3_decode_result(c, &first_bad, &bad_status, &before))) return rc;
+  if (first_bad == 0) return bad_status;
+  HIPCHK(c, hipMemcpyAsync(wav, c->out.p, samples * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (n_out) *n_out = samples;
+  return X3_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// synthetic inputs + device memory helpers
+// ------------------------------------------------------------------------------------------------
+extern "C" int x3_synth(int kind, uint64_t seed, uint64_t start, uint64_t n, int16_t* out) {
+  if (kind < 0 || kind > 4 || (!out && n)) return X3_ERR_BAD_ARG;
+  const uint64_t end = start + n;
+  for (uint64_t seg = start / X3_SYNTH_SEG; seg * X3_SYNTH_SEG < end; ++seg) {
+    const uint64_t seg_lo = seg * X3_SYNTH_SEG, seg_hi = seg_lo + X3_SYNTH_SEG;
+    const uint32_t lo = start > seg_lo ? (uint32_t)(start - seg_lo) : 0u;
+    const uint32_t hi = end < seg_hi ? (uint32_t)(end - seg_lo) : X3_SYNTH_SEG;
+    int16_t* o = out + (seg_lo + lo - start);
+    x3_synth_segment(kind, seed, seg, lo, hi, [o](uint32_t i, int16_t v) { o[i] = v; });
+  }
+  return X3_OK;
+}
+
+extern "C" int x3_synth_dev(x3_ctx* c, int kind, uint64_t seed, uint64_t start, uint64_t n, int16_t* d_out) {
+  if (!c || kind < 0 || kind > 4 || (!d_out && n)) return X3_ERR_BAD_ARG;
+  if (n == 0) return X3_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint64_t first_seg = start / X3_SYNTH_SEG, last_seg = (start + n - 1) / X3_SYNTH_SEG;
+  const uint64_t nseg = last_seg - first_seg + 1;
+  hipLaunchKernelGGL(x3_synth_kernel, dim3((unsigned)((nseg + 63) / 64)), dim3(64), 0, c->stream, kind, seed, start,
+                     n, d_out);
+  HIPCHK(c, hipGetLastError());
+  return X3_OK;
+}
+
+extern "C" int x3_dev_alloc(x3_ctx* c, uint64_t bytes, void** d_ptr) {
+  if (!c || !d_ptr) return X3_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMalloc(d_ptr, bytes ? bytes : 256));
+  return X3_OK;
+}
+extern "C" int x3_dev_free(x3_ctx* c, void* d_ptr) {
+  if (!c) return X3_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipFree(d_ptr));
+  return X3_OK;
+}
+extern "C" int x3_dev_upload(x3_ctx* c, void* d_dst, const void* src, uint64_t bytes) {
+  if (!c) return X3_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return X3_OK;
+}
+extern "C" int x3_dev_download(x3_ctx* c, void* dst, const void* d_src, uint64_t bytes) {
+  if (!c) return X3_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return X3_OK;
+}

@@ -1,0 +1,96 @@
+// x3_device.h -- types and small device helpers shared by the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define X3_WAVE 64
+
+// Codec parameters in the form the kernels want (derived on the host from x3_params).
+// Rice table geometry follows src/x3.rs:207-252: (nsubs, offset, len, inv_len) =
+// (0,6,14,16) (1,11,22,26) (2,20,40,44) (3,28,56,60).
+struct X3DevParams {
+  uint32_t block_len;
+  uint32_t blocks_per_frame;
+  uint32_t spf;          // samples per frame = block_len * blocks_per_frame
+  uint32_t thr[3];       // thresholds
+  uint32_t k[3];         // nsubs of rice_codes[ftype]
+  int32_t dmin[3];       // smallest diff the reference's table for rice_codes[ftype] can index
+  int32_t dmax[3];       // largest  (outside -> the reference panics -> X3_ERR_BAD_ARG)
+  uint32_t inv_len[3];   // decoder bound for rice_codes[ftype]
+};
+
+// Where the frames of a uniform batch live (single stream: n_clips = 1).
+struct X3Geom {
+  uint64_t n_per_clip;   // samples in each clip
+  uint64_t clip_stride;  // samples between clip starts
+  uint32_t fpc;          // frames per clip
+  uint64_t n_frames;     // fpc * n_clips
+};
+
+// status codes used on the device (values of enum x3_status in include/x3hip.h)
+#define X3D_OK 0
+#define X3D_OUT_OF_BOUNDS_INVERSE 5
+#define X3D_MORE_THAN_ONE_CHANNEL 6
+#define X3D_FRAME_LENGTH 10
+#define X3D_FRAME_HEADER_INVALID_KEY 11
+#define X3D_FRAME_HEADER_INVALID_PAYLOAD_LEN 12
+#define X3D_FRAME_HEADER_INVALID_HEADER_CRC 13
+#define X3D_FRAME_HEADER_INVALID_PAYLOAD_CRC 14
+#define X3D_FRAME_DECODE_INVALID_BPF 20
+#define X3D_BYTE_WRITER_INSUFFICIENT_MEMORY 22
+#define X3D_BAD_ARG 24
+
+__device__ __forceinline__ uint32_t x3_bswap32(uint32_t v) { return __builtin_bswap32(v); }
+
+// ---------------------------------------------------------------------------------------------
+// CRC-16/CCITT-FALSE (src/crc.rs): polynomial 0x1021, MSB first, no reflection, no final xor.
+// Table-free byte step: for t = (crc>>8) ^ byte, t ^= t>>4 ; crc' = (crc<<8) ^ (t<<12) ^ (t<<5) ^ t.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t x3_crc_byte(uint32_t crc, uint32_t byte) {
+  uint32_t t = ((crc >> 8) ^ byte) & 0xFFu;
+  t ^= t >> 4;
+  return ((crc << 8) ^ (t << 12) ^ (t << 5) ^ t) & 0xFFFFu;
+}
+
+// four stream bytes held big-endian in `be` (first byte in bits 31..24)
+__device__ __forceinline__ uint32_t x3_crc_be32(uint32_t crc, uint32_t be) {
+  crc = x3_crc_byte(crc, be >> 24);
+  crc = x3_crc_byte(crc, (be >> 16) & 0xFFu);
+  crc = x3_crc_byte(crc, (be >> 8) & 0xFFu);
+  crc = x3_crc_byte(crc, be & 0xFFu);
+  return crc;
+}
+
+// a(x) * k(x) mod 0x11021 for 16-bit a, k.  k is wave-uniform in every caller, so the
+// k*x^b chain runs on the scalar unit and the vector cost is 3 ops per bit.
+__device__ __forceinline__ uint32_t x3_gf_mul(uint32_t a, uint32_t k) {
+  uint32_t r = 0;
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {
+    r ^= (0u - ((a >> b) & 1u)) & k;
+    k = (k << 1) ^ ((k & 0x8000u) ? 0x11021u : 0u);
+  }
+  return r;
+}
+
+// xpow table (built on the host, x3_api): XP[j][m] = x^(32*m*2^j) mod P, j < X3_XP_LEVELS, m <= X3_XP_M
+#define X3_XP_LEVELS 10
+#define X3_XP_M 128
+#define X3_XINV16_INDEX (X3_XP_LEVELS * (X3_XP_M + 1))  // x^(-16) mod P stored after the table
+#define X3_XP_SIZE (X3_XINV16_INDEX + 1)
+
+__device__ __forceinline__ uint32_t x3_xp(const uint16_t* __restrict__ xpow, int level, uint32_t m) {
+  return xpow[level * (X3_XP_M + 1) + m];
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave / workgroup scans
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t x3_wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < X3_WAVE; d <<= 1) {
+    uint32_t t = __shfl_up(v, d, X3_WAVE);
+    if (lane >= d) v += t;
+  }
+  return v;
+}

@@ -1,0 +1,317 @@
+// x3_encode_kernel.h -- frame encoder for gfx950: one workgroup per frame, one block per lane.
+//
+// Replaces, per frame, encoder::encode_frame + x3_encode_block + encode_rice_block /
+// encode_bfp_block / encode_literal (src/encoder.rs:175-315), BitPacker (src/bitpacker.rs:46-177)
+// and the running crc16 (src/crc.rs:44-58) of the reference:
+//
+//   A  the frame's samples are staged in LDS with 16-byte coalesced loads while the LDS frame
+//      image is zeroed;
+//   B  each lane owns one block: first-difference filter, min/max diff, coder selection
+//      (Rice k / BFP / literal) and the block's exact bit length in closed form
+//      (codeword = (u>>k) zeros + (1<<k | u&(2^k-1)) in k+1 bits, u = zigzag(d));
+//   C  a wavefront prefix scan (+ cross-wave partials in LDS) turns bit lengths into bit offsets
+//      (the BitPacker's running p_bit/byte_len become a scan);
+//   D  each lane emits its block MSB-first into the zeroed LDS image with ds_or_b32 on 32-bit
+//      words (words are stored byte-swapped, so LDS memory order == stream byte order);
+//   E  payload CRC-16 as a segmented reduction: every lane CRCs a right-aligned chunk with
+//      init 0 (the 0xFFFF init is folded into the first two payload bytes), chunks are combined
+//      with multiplications by x^(8*len) mod 0x11021 in a log-step tree; the 20-byte frame
+//      header (encoder.rs:122-162) is built by one lane;
+//   F  header+payload are copied to the frame's final byte offset in the stream (offsets come
+//      from the device-wide exclusive scan of frame sizes) with coalesced dword stores.
+//
+// SIZES_ONLY instantiates steps A-C only and writes the frame's byte size (20 + payload_len).
+#pragma once
+#include "x3_device.h"
+
+struct X3BitEmitter {
+  uint32_t* words;  // LDS payload, word w = stream bytes 4w..4w+3 in memory order
+  uint32_t w;
+  uint32_t cnt;     // bits pending in acc (low cnt bits are valid)
+  uint64_t acc;
+  __device__ __forceinline__ void init(uint32_t* payload_words, uint32_t bitpos) {
+    words = payload_words;
+    w = bitpos >> 5;
+    cnt = bitpos & 31u;
+    acc = 0;
+  }
+  // append the low `len` bits of code (len <= 32, code < 2^len)
+  __device__ __forceinline__ void put(uint32_t code, uint32_t len) {
+    acc = (acc << len) | code;
+    cnt += len;
+    if (cnt >= 32u) {
+      uint32_t word = (uint32_t)(acc >> (cnt - 32u));
+      atomicOr(&words[w], x3_bswap32(word));
+      ++w;
+      cnt -= 32u;
+    }
+  }
+  __device__ __forceinline__ void finish() {
+    if (cnt) {
+      uint32_t word = (uint32_t)(acc << (32u - cnt));
+      atomicOr(&words[w], x3_bswap32(word));
+    }
+  }
+};
+
+#define X3_ENC_SMEM_HDR 256u  // bytes of bookkeeping in front of the dynamic LDS carve
+
+template <bool SIZES_ONLY>
+__global__ void __launch_bounds__(1024)
+x3_encode_frames_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p,
+                        const uint64_t* __restrict__ frame_off, uint32_t* __restrict__ frame_bytes,
+                        uint8_t* __restrict__ out, uint64_t start_pos,
+                        unsigned long long* __restrict__ stats, int* __restrict__ status,
+                        const uint16_t* __restrict__ xpow, uint32_t lds_in_bytes, uint32_t img_dwords) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* part = reinterpret_cast<uint32_t*>(smem);  // [0..31] wave partials, [32..37] stats, [40] bad flag
+  int16_t* in_s = reinterpret_cast<int16_t*>(smem + X3_ENC_SMEM_HDR);
+  uint32_t* img = reinterpret_cast<uint32_t*>(smem + X3_ENC_SMEM_HDR + lds_in_bytes);  // 5 header dwords + payload
+
+  const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+  const uint32_t lane = tid & 63u, wid = tid >> 6, nwaves = nthr >> 6;
+  const uint64_t f = blockIdx.x;
+
+  // status[0] is written by the size pass / scan kernel (bad block, output overflow) and only
+  // READ here, so the early exit is uniform; this kernel reports into status[1].
+  if (!SIZES_ONLY) {
+    if (status[0] != 0) return;
+  }
+
+  // ---- frame geometry (encoder.rs:61-73: frames of block_len*blocks_per_frame samples)
+  const uint64_t clip = f / g.fpc;
+  const uint64_t idx = f - clip * g.fpc;
+  const uint64_t s_start = clip * g.clip_stride + idx * (uint64_t)p.spf;
+  const uint64_t left = g.n_per_clip - idx * (uint64_t)p.spf;
+  const uint32_t n = left < p.spf ? (uint32_t)left : p.spf;  // >= 1
+  const int16_t* __restrict__ src = wav + s_start;
+
+  // ---- A: stage samples, zero the frame image
+  if ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
+    const uint32_t nvec = n >> 3;
+    const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(src);
+    uint4* d4 = reinterpret_cast<uint4*>(in_s);
+    for (uint32_t i = tid; i < nvec; i += nthr) d4[i] = s4[i];
+    for (uint32_t i = nvec * 8 + tid; i < n; i += nthr) in_s[i] = src[i];
+  } else {
+    for (uint32_t i = tid; i < n; i += nthr) in_s[i] = src[i];
+  }
+  if (!SIZES_ONLY) {
+    uint4* z4 = reinterpret_cast<uint4*>(img);
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = tid; i < (img_dwords >> 2); i += nthr) z4[i] = zero;
+  }
+  if (tid >= 32 && tid < 48) part[tid] = 0;
+  __syncthreads();
+  // <Audio State>: wav[0] raw in the first 16 payload bits (encoder.rs:189)
+  if (!SIZES_ONLY && tid == 0) atomicOr(&img[5], x3_bswap32(((uint32_t)(uint16_t)in_s[0]) << 16));
+
+  // ---- B..D in rounds of nthr blocks (one round for the default 500 blocks / 512 lanes)
+  const uint32_t bl = p.block_len;
+  const uint32_t nblocks = (n - 1 + bl - 1) / bl;
+  uint32_t base_bits = 16;  // <Audio State>: wav[0] raw (encoder.rs:189)
+  uint32_t bad = 0;
+
+  for (uint32_t b0 = 0; b0 < nblocks; b0 += nthr) {
+    const uint32_t b = b0 + tid;
+    const bool valid = b < nblocks;
+    const uint32_t s0 = 1 + b * bl;  // blocks start at wav[1] (encoder.rs:194)
+    const uint32_t cnt = valid ? (n - s0 < bl ? n - s0 : bl) : 0;
+
+    // B: diff filter + range (encoder.rs:296-302)
+    int32_t dmin = 0, dmax = 0;
+    int32_t prev = valid ? (int32_t)in_s[s0 - 1] : 0;
+    for (uint32_t i = 0; i < cnt; ++i) {
+      int32_t s = in_s[s0 + i];
+      int32_t d = s - prev;
+      prev = s;
+      dmin = d < dmin ? d : dmin;
+      dmax = d > dmax ? d : dmax;
+    }
+    const int32_t maxabs = (-dmin) > dmax ? (-dmin) : dmax;
+
+    // coder selection (encoder.rs:304-314, 241-247)
+    uint32_t type;   // stats index: Rice nsubs 0..3, 4 = BFP, 5 = literal
+    uint32_t k = 0, ft = 0, nb = 0, nbits = 0;
+    if (maxabs <= (int32_t)p.thr[2]) {
+      ft = (maxabs > (int32_t)p.thr[0] ? 1u : 0u) + (maxabs > (int32_t)p.thr[1] ? 1u : 0u);
+      k = ft == 0 ? p.k[0] : (ft == 1 ? p.k[1] : p.k[2]);
+      const int32_t lo = ft == 0 ? p.dmin[0] : (ft == 1 ? p.dmin[1] : p.dmin[2]);
+      const int32_t hi = ft == 0 ? p.dmax[0] : (ft == 1 ? p.dmax[1] : p.dmax[2]);
+      type = k;
+      if (valid && (dmin < lo || dmax > hi)) {
+        bad = 1;  // the reference indexes outside its Rice table here (panic)
+      } else {
+        uint32_t sum = 0;
+        int32_t pv = valid ? (int32_t)in_s[s0 - 1] : 0;
+        for (uint32_t i = 0; i < cnt; ++i) {
+          int32_t s = in_s[s0 + i];
+          int32_t d = s - pv;
+          pv = s;
+          uint32_t u = ((uint32_t)d << 1) ^ (uint32_t)(d >> 31);
+          sum += u >> k;
+        }
+        nbits = 2 + cnt * (k + 1) + sum;
+      }
+    } else {
+      nb = 32u - (uint32_t)__clz(maxabs);
+      if (nb >= 15) {
+        type = 5;
+        nbits = 6 + 16 * cnt;
+      } else {
+        type = 4;
+        nbits = 6 + cnt * (nb + 1);
+      }
+    }
+    if (!valid) nbits = 0;
+
+    // C: workgroup exclusive scan of bit lengths
+    const uint32_t incl = x3_wave_incl_scan(nbits, lane);
+    if (lane == 63) part[wid] = incl;
+    __syncthreads();
+    uint32_t wave_base = 0, total = 0;
+    for (uint32_t w = 0; w < nwaves; ++w) {
+      uint32_t v = part[w];
+      wave_base += (w < wid) ? v : 0u;
+      total += v;
+    }
+    __syncthreads();
+    const uint32_t pos = base_bits + wave_base + incl - nbits;
+    base_bits += total;
+
+    if (!SIZES_ONLY) {
+      // D: emission
+      if (valid && nbits) {
+        X3BitEmitter e;
+        e.init(img + 5, pos);
+        if (type <= 3) {
+          e.put(ft + 1, 2);
+          const uint32_t mask = (1u << k) - 1u;
+          int32_t pv = in_s[s0 - 1];
+          for (uint32_t i = 0; i < cnt; ++i) {
+            int32_t s = in_s[s0 + i];
+            int32_t d = s - pv;
+            pv = s;
+            uint32_t u = ((uint32_t)d << 1) ^ (uint32_t)(d >> 31);
+            e.put((1u << k) | (u & mask), (u >> k) + 1u + k);
+          }
+        } else if (type == 4) {
+          e.put(nb, 6);
+          const uint32_t mask = (1u << (nb + 1)) - 1u;
+          int32_t pv = in_s[s0 - 1];
+          for (uint32_t i = 0; i < cnt; ++i) {
+            int32_t s = in_s[s0 + i];
+            int32_t d = s - pv;
+            pv = s;
+            e.put((uint32_t)d & mask, nb + 1);
+          }
+        } else {
+          e.put(15, 6);
+          for (uint32_t i = 0; i < cnt; ++i) e.put((uint32_t)(uint16_t)in_s[s0 + i], 16);
+        }
+        e.finish();
+      }
+      // statistics (encoder.rs:199): stats[type] += block.len()
+      for (uint32_t t = 0; t < 6; ++t) {
+        unsigned long long m = __ballot(valid && type == t);
+        if (lane == 0 && m) atomicAdd(&part[32 + t], (uint32_t)__popcll(m) * bl);
+      }
+      if (valid && cnt != bl) atomicSub(&part[32 + type], bl - cnt);
+    }
+  }
+
+  if (bad) part[40] = 1;
+  const uint32_t total_bits = base_bits;
+  // word_align (bitpacker.rs:124-132): pad to a byte, then to an even absolute position; the
+  // payload starts at an even position, so payload_len is rounded up to even
+  const uint32_t L = (((total_bits + 7u) >> 3) + 1u) & ~1u;
+
+  if (SIZES_ONLY) {
+    __syncthreads();
+    if (tid == 0) {
+      frame_bytes[f] = 20u + L;
+      if (part[40]) atomicMax(&status[0], X3D_BAD_ARG);
+    }
+    return;
+  }
+
+  __syncthreads();  // emission complete
+  if (part[40] || 5u + ((L + 3u) >> 2) > img_dwords) {
+    if (tid == 0) atomicMax(&status[1], X3D_BAD_ARG);
+    return;
+  }
+
+  // ---- E: payload CRC-16 (bitpacker.rs:79-82 updates it per flushed byte; here: reduction)
+  const uint32_t Lw = (L + 3u) >> 2;                 // payload dwords (last may hold 2 pad-to-4 zero bytes)
+  const uint32_t c_dw = (Lw + nthr - 1) / nthr;      // dwords per lane, uniform
+  const int32_t j0 = (int32_t)(tid * c_dw) - (int32_t)(nthr * c_dw - Lw);  // right-aligned chunks
+  uint32_t crc = 0;
+  for (uint32_t i = 0; i < c_dw; ++i) {
+    const int32_t j = j0 + (int32_t)i;
+    if (j >= 0) {
+      uint32_t be = x3_bswap32(img[5 + j]);
+      if (j == 0) be ^= 0xFFFF0000u;  // CRC init 0xFFFF == xor into the first 16 message bits
+      crc = x3_crc_be32(crc, be);
+    }
+  }
+#pragma unroll
+  for (int lvl = 0; lvl < 6; ++lvl) {
+    const uint32_t kx = x3_xp(xpow, lvl, c_dw);
+    const uint32_t t = __shfl_up(crc, 1 << lvl, X3_WAVE);
+    if (lane >= (1u << lvl)) crc = x3_gf_mul(t, kx) ^ crc;
+  }
+  if (lane == 63) part[wid] = crc;
+  __syncthreads();
+  if (wid == 0) {
+    uint32_t v = lane < nwaves ? part[lane] : 0u;
+    for (uint32_t lvl = 6, d = 1; d < nwaves; ++lvl, d <<= 1) {
+      const uint32_t kx = x3_xp(xpow, lvl, c_dw);
+      const uint32_t t = __shfl_up(v, d, X3_WAVE);
+      if (lane >= d) v = x3_gf_mul(t, kx) ^ v;
+    }
+    if (lane == nwaves - 1) {
+      if (L & 2u) v = x3_gf_mul(v, xpow[X3_XINV16_INDEX]);  // undo the 2 virtual pad-to-4 bytes
+      // frame header (encoder.rs:122-162): "x3", id, id, samples, payload_len, 8 zero time
+      // bytes, header crc over bytes 0..16, payload crc; audio frames use id 1 (encoder.rs:210)
+      const uint32_t h0 = 0x78330101u;
+      const uint32_t h1 = ((n & 0xFFFFu) << 16) | (L & 0xFFFFu);
+      uint32_t hc = 0xFFFFu;
+      hc = x3_crc_be32(hc, h0);
+      hc = x3_crc_be32(hc, h1);
+      hc = x3_crc_be32(hc, 0);
+      hc = x3_crc_be32(hc, 0);
+      img[0] = x3_bswap32(h0);
+      img[1] = x3_bswap32(h1);
+      img[2] = 0;
+      img[3] = 0;
+      img[4] = x3_bswap32((hc << 16) | (v & 0xFFFFu));
+    }
+  }
+  __syncthreads();
+
+  // ---- F: copy header + payload to the final stream position
+  const uint64_t off = frame_off[f];
+  uint8_t* dst = out + off;
+  const uint32_t total_bytes = 20u + L;  // even
+  const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u);
+  if (mis == 0) {
+    const uint32_t ndw = total_bytes >> 2;
+    uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);
+    for (uint32_t i = tid; i < ndw; i += nthr) d32[i] = img[i];
+    if ((total_bytes & 2u) && tid == 0) *reinterpret_cast<uint16_t*>(dst + 4 * ndw) = (uint16_t)img[ndw];
+  } else if (mis == 2) {
+    if (tid == 0) *reinterpret_cast<uint16_t*>(dst) = (uint16_t)img[0];
+    const uint32_t rem = total_bytes - 2u;
+    const uint32_t ndw = rem >> 2;
+    uint32_t* d32 = reinterpret_cast<uint32_t*>(dst + 2);
+    for (uint32_t i = tid; i < ndw; i += nthr) d32[i] = (img[i] >> 16) | (img[i + 1] << 16);
+    if ((rem & 2u) && tid == 0) *reinterpret_cast<uint16_t*>(dst + 2 + 4 * ndw) = (uint16_t)(img[ndw] >> 16);
+  } else {
+    for (uint32_t i = tid; i < total_bytes; i += nthr) dst[i] = (uint8_t)(img[i >> 2] >> (8 * (i & 3u)));
+  }
+  if (f == 0 && tid == 0 && (start_pos & 1ull)) out[start_pos] = 0;  // writer.align::<2>() pad (encoder.rs:182)
+  if (tid < 6) {
+    const uint32_t v = part[32 + tid];
+    if (v) atomicAdd(&stats[tid], (unsigned long long)v);
+  }
+}

@@ -1,0 +1,336 @@
+"""ctypes binding of libx3hip.so (include/x3hip.h): the MI355X-native X3 encoder/decoder.
+
+Thin by design: every call goes straight to the C ABI, which runs the HIP kernels.  There is
+no Python or CPU implementation behind it -- if the library or a GPU is missing, loading or
+context creation raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libx3hip.so")
+
+OK = 0
+ERR_INVALID_ENCODING_THRESH = 4
+ERR_OUT_OF_BOUNDS_INVERSE = 5
+ERR_MORE_THAN_ONE_CHANNEL = 6
+ERR_FRAME_LENGTH = 10
+ERR_FRAME_HEADER_INVALID_KEY = 11
+ERR_FRAME_HEADER_INVALID_PAYLOAD_LEN = 12
+ERR_FRAME_HEADER_INVALID_HEADER_CRC = 13
+ERR_FRAME_HEADER_INVALID_PAYLOAD_CRC = 14
+ERR_FRAME_DECODE_INVALID_BPF = 20
+ERR_FRAME_DECODE_UNEXPECTED_END = 21
+ERR_BYTE_WRITER_INSUFFICIENT_MEMORY = 22
+ERR_HIP = 23
+ERR_BAD_ARG = 24
+
+# every symbol include/x3hip.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "x3_strerror", "x3_ctx_create", "x3_ctx_create_on_stream", "x3_ctx_destroy", "x3_ctx_sync", "x3_last_error",
+    "x3_ctx_enable_kernel_timing", "x3_ctx_kernel_time", "x3_ctx_reset_kernel_time",
+    "x3_params_default", "x3_params_validate", "x3_num_frames", "x3_encode_bound",
+    "x3_crc16", "x3_crc16_dev", "x3_crc16_update",
+    "x3_encode", "x3_encode_frame", "x3_write_frame_header", "x3_encode_batch",
+    "x3_read_frame_header", "x3_decode_frame", "x3_decode_stream",
+    "x3_encode_dev", "x3_encode_result", "x3_decode_dev", "x3_decode_result",
+    "x3_synth", "x3_synth_dev", "x3_dev_alloc", "x3_dev_free", "x3_dev_upload", "x3_dev_download",
+]
+
+
+class Params(C.Structure):
+    """x3::Parameters (src/x3.rs:81-134)"""
+    _fields_ = [("block_len", C.c_uint32), ("blocks_per_frame", C.c_uint32),
+                ("codes", C.c_uint32 * 3), ("thresholds", C.c_uint32 * 3)]
+
+    @classmethod
+    def default(cls):
+        p = cls()
+        lib().x3_params_default(C.byref(p))
+        return p
+
+    @classmethod
+    def make(cls, block_len=20, blocks_per_frame=500, codes=(0, 1, 3), thresholds=(3, 8, 20)):
+        return cls(block_len, blocks_per_frame, (C.c_uint32 * 3)(*codes), (C.c_uint32 * 3)(*thresholds))
+
+    @property
+    def spf(self):
+        return self.block_len * self.blocks_per_frame
+
+
+class FrameHeader(C.Structure):
+    """x3::FrameHeader (src/x3.rs:148-184)"""
+    _fields_ = [("source_id", C.c_uint8), ("channels", C.c_uint8), ("samples", C.c_uint16),
+                ("payload_len", C.c_uint32), ("payload_crc", C.c_uint16)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("n_per_clip", C.c_uint64), ("clip_stride", C.c_uint64), ("n_clips", C.c_uint64)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libx3hip.so; raises if it has not been built (python x3-rust_amd/build.py)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libx3hip.so is missing (%s): run `python x3-rust_amd/build.py`; "
+                           "there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    PP = C.POINTER(Params)
+    L.x3_strerror.restype = C.c_char_p
+    L.x3_strerror.argtypes = [i32]
+    L.x3_ctx_create.argtypes = [i32, C.POINTER(vp)]
+    L.x3_ctx_create_on_stream.argtypes = [i32, vp, C.POINTER(vp)]
+    L.x3_ctx_destroy.restype = None
+    L.x3_ctx_destroy.argtypes = [vp]
+    L.x3_ctx_sync.argtypes = [vp]
+    L.x3_last_error.restype = C.c_char_p
+    L.x3_last_error.argtypes = [vp]
+    L.x3_ctx_enable_kernel_timing.argtypes = [vp, i32]
+    L.x3_ctx_kernel_time.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(u64)]
+    L.x3_ctx_reset_kernel_time.argtypes = [vp]
+    L.x3_params_default.restype = None
+    L.x3_params_default.argtypes = [PP]
+    L.x3_params_validate.argtypes = [PP]
+    L.x3_num_frames.restype = u64
+    L.x3_num_frames.argtypes = [u64, PP]
+    L.x3_encode_bound.restype = u64
+    L.x3_encode_bound.argtypes = [u64, PP]
+    L.x3_crc16.argtypes = [vp, vp, u64, C.POINTER(C.c_uint16)]
+    L.x3_crc16_dev.argtypes = [vp, vp, u64, C.POINTER(C.c_uint16)]
+    L.x3_crc16_update.restype = C.c_uint16
+    L.x3_crc16_update.argtypes = [C.c_uint16, C.c_uint8]
+    L.x3_encode.argtypes = [vp, vp, u64, u32, PP, vp, u64, u64, C.POINTER(u64), vp]
+    L.x3_encode_frame.argtypes = [vp, vp, u64, PP, vp, u64, u64, C.POINTER(u64), vp]
+    L.x3_write_frame_header.restype = None
+    L.x3_write_frame_header.argtypes = [u64, C.c_uint8, u64, C.c_uint16, vp]
+    L.x3_encode_batch.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), u64, PP, vp, u64, C.POINTER(u64), vp]
+    L.x3_read_frame_header.argtypes = [vp, u64, C.POINTER(FrameHeader)]
+    L.x3_decode_frame.argtypes = [vp, vp, u64, vp, u64, PP, u64, C.POINTER(u64)]
+    L.x3_decode_stream.argtypes = [vp, vp, u64, PP, vp, u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+    L.x3_encode_dev.argtypes = [vp, vp, C.POINTER(Batch), PP, vp, u64, u64, vp]
+    L.x3_encode_result.argtypes = [vp, C.POINTER(u64), vp]
+    L.x3_decode_dev.argtypes = [vp, vp, u64, vp, u64, C.POINTER(Batch), vp, PP, vp, u64, vp]
+    L.x3_decode_result.argtypes = [vp, C.POINTER(u64), C.POINTER(i32), C.POINTER(u64)]
+    L.x3_synth.argtypes = [i32, u64, u64, u64, vp]
+    L.x3_synth_dev.argtypes = [vp, i32, u64, u64, u64, vp]
+    L.x3_dev_alloc.argtypes = [vp, u64, C.POINTER(vp)]
+    L.x3_dev_free.argtypes = [vp, vp]
+    L.x3_dev_upload.argtypes = [vp, vp, vp, u64]
+    L.x3_dev_download.argtypes = [vp, vp, vp, u64]
+    _lib = L
+    return L
+
+
+def strerror(rc):
+    return lib().x3_strerror(rc).decode()
+
+
+class X3Error(RuntimeError):
+    def __init__(self, rc, what=""):
+        self.rc = rc
+        super().__init__("%s: %s (%d)" % (what, strerror(rc), rc))
+
+
+SYNTH_ZEROS, SYNTH_WHITE, SYNTH_HYDROPHONE, SYNTH_SINE, SYNTH_WALK = range(5)
+
+
+def synth(kind, seed, start, n):
+    """host-side synthetic samples (bit-identical to Context.synth_dev)"""
+    out = np.empty(n, dtype=np.int16)
+    rc = lib().x3_synth(kind, seed, start, n, out.ctypes.data)
+    if rc:
+        raise X3Error(rc, "x3_synth")
+    return out
+
+
+def write_frame_header(num_samples, ident, payload_len, payload_crc):
+    out = np.zeros(20, dtype=np.uint8)
+    lib().x3_write_frame_header(num_samples, ident, payload_len, payload_crc, out.ctypes.data)
+    return out
+
+
+def read_frame_header(data):
+    b = np.ascontiguousarray(data, dtype=np.uint8)
+    h = FrameHeader()
+    rc = lib().x3_read_frame_header(b.ctypes.data, b.size, C.byref(h))
+    return rc, h
+
+
+class Context:
+    """One x3_ctx: a GPU + stream + scratch.  Not thread-safe."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        L = lib()
+        if stream is None:
+            rc = L.x3_ctx_create(device, C.byref(self._h))
+        else:
+            rc = L.x3_ctx_create_on_stream(device, C.c_void_p(stream), C.byref(self._h))
+        if rc:
+            raise X3Error(rc, "x3_ctx_create (no usable HIP device? there is no CPU fallback)")
+
+    def close(self):
+        if self._h:
+            lib().x3_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def last_error(self):
+        return lib().x3_last_error(self._h).decode()
+
+    def sync(self):
+        rc = lib().x3_ctx_sync(self._h)
+        if rc:
+            raise X3Error(rc, "x3_ctx_sync: " + self.last_error())
+
+    # ---- host-buffer API (returns status codes, like the C ABI) ---------------------------
+    def encode(self, wav, params=None, start_pos=0, cap=None, n_channels=1):
+        """encoder::encode into a slice writer -> (rc, np.uint8 bytes[0:out_pos], stats[6])"""
+        params = params or Params.default()
+        wav = np.ascontiguousarray(wav, dtype=np.int16)
+        if cap is None:
+            cap = start_pos + lib().x3_encode_bound(wav.size, C.byref(params)) + 1
+        out = np.zeros(max(cap, 1), dtype=np.uint8)
+        pos = C.c_uint64(0)
+        stats = np.zeros(6, dtype=np.uint64)
+        rc = lib().x3_encode(self._h, wav.ctypes.data, wav.size, n_channels, C.byref(params), out.ctypes.data, cap,
+                             start_pos, C.byref(pos), stats.ctypes.data)
+        self.out_pos = pos.value
+        return rc, out[: min(pos.value, cap)].copy(), stats
+
+    def encode_frame(self, wav, params=None, start_pos=0, cap=None):
+        params = params or Params.default()
+        wav = np.ascontiguousarray(wav, dtype=np.int16)
+        if cap is None:
+            cap = start_pos + 64 + 3 * wav.size
+        out = np.zeros(max(cap, 1), dtype=np.uint8)
+        pos = C.c_uint64(0)
+        stats = np.zeros(6, dtype=np.uint64)
+        rc = lib().x3_encode_frame(self._h, wav.ctypes.data, wav.size, C.byref(params), out.ctypes.data, cap,
+                                   start_pos, C.byref(pos), stats.ctypes.data)
+        return rc, out[: min(pos.value, cap)].copy(), stats
+
+    def encode_batch(self, clips, params=None, cap=None):
+        params = params or Params.default()
+        clips = [np.ascontiguousarray(c, dtype=np.int16) for c in clips]
+        ptrs = (C.c_void_p * len(clips))(*[c.ctypes.data for c in clips])
+        ns = (C.c_uint64 * len(clips))(*[c.size for c in clips])
+        if cap is None:
+            cap = sum(lib().x3_encode_bound(c.size, C.byref(params)) + 2 for c in clips)
+        out = np.zeros(max(cap, 1), dtype=np.uint8)
+        offs = (C.c_uint64 * (len(clips) + 1))()
+        stats = np.zeros(6, dtype=np.uint64)
+        rc = lib().x3_encode_batch(self._h, ptrs, ns, len(clips), C.byref(params), out.ctypes.data, cap, offs,
+                                   stats.ctypes.data)
+        return rc, out, list(offs), stats
+
+    def decode_stream(self, x3, params=None, wav_cap=None):
+        """-> (rc, samples, frames_ok, frame_errors)"""
+        params = params or Params.default()
+        x3 = np.ascontiguousarray(x3, dtype=np.uint8)
+        if wav_cap is None:
+            wav_cap = max(1, x3.size * 16)
+        wav = np.zeros(wav_cap, dtype=np.int16)
+        n, fok, ferr = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        rc = lib().x3_decode_stream(self._h, x3.ctypes.data, x3.size, C.byref(params), wav.ctypes.data, wav_cap,
+                                    C.byref(n), C.byref(fok), C.byref(ferr))
+        return rc, wav[: n.value].copy(), fok.value, ferr.value
+
+    def decode_frame(self, payload, samples, params=None, wav_cap=None):
+        params = params or Params.default()
+        payload = np.ascontiguousarray(payload, dtype=np.uint8)
+        wav_cap = samples if wav_cap is None else wav_cap
+        wav = np.zeros(max(wav_cap, 1), dtype=np.int16)
+        n = C.c_uint64(0)
+        rc = lib().x3_decode_frame(self._h, payload.ctypes.data, payload.size, wav.ctypes.data, wav_cap,
+                                   C.byref(params), samples, C.byref(n))
+        return rc, wav[: n.value].copy()
+
+    def crc16(self, data):
+        b = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8)) if not isinstance(data, np.ndarray) \
+            else np.ascontiguousarray(data, dtype=np.uint8)
+        crc = C.c_uint16(0)
+        rc = lib().x3_crc16(self._h, b.ctypes.data if b.size else None, b.size, C.byref(crc))
+        if rc:
+            raise X3Error(rc, "x3_crc16: " + self.last_error())
+        return crc.value
+
+    # ---- device-resident API (raw device pointers as ints, e.g. torch.Tensor.data_ptr()) -----
+    def encode_dev(self, d_wav, n_per_clip, params, d_out, out_cap, start_pos=0, d_frame_offsets=None, n_clips=1,
+                   clip_stride=None):
+        b = Batch(n_per_clip, n_per_clip if clip_stride is None else clip_stride, n_clips)
+        return lib().x3_encode_dev(self._h, d_wav, C.byref(b), C.byref(params), d_out, out_cap, start_pos,
+                                   d_frame_offsets)
+
+    def encode_result(self):
+        pos = C.c_uint64(0)
+        stats = np.zeros(6, dtype=np.uint64)
+        rc = lib().x3_encode_result(self._h, C.byref(pos), stats.ctypes.data)
+        return rc, pos.value, stats
+
+    def decode_dev(self, d_x3, x3_len, d_frame_offsets, n_frames, params, d_wav, wav_cap, n_per_clip=None, n_clips=1,
+                   clip_stride=None, d_wav_offsets=None, d_status=None):
+        b = None
+        if n_per_clip is not None:
+            b = C.byref(Batch(n_per_clip, n_per_clip if clip_stride is None else clip_stride, n_clips))
+        return lib().x3_decode_dev(self._h, d_x3, x3_len, d_frame_offsets, n_frames, b, d_wav_offsets,
+                                   C.byref(params), d_wav, wav_cap, d_status)
+
+    def decode_result(self):
+        fb, st, nb = C.c_uint64(0), C.c_int(0), C.c_uint64(0)
+        rc = lib().x3_decode_result(self._h, C.byref(fb), C.byref(st), C.byref(nb))
+        return rc, fb.value, st.value, nb.value
+
+    def synth_dev(self, kind, seed, start, n, d_out):
+        rc = lib().x3_synth_dev(self._h, kind, seed, start, n, d_out)
+        if rc:
+            raise X3Error(rc, "x3_synth_dev: " + self.last_error())
+
+    def enable_kernel_timing(self, on=True):
+        lib().x3_ctx_enable_kernel_timing(self._h, 1 if on else 0)
+
+    def reset_kernel_time(self):
+        lib().x3_ctx_reset_kernel_time(self._h)
+
+    def kernel_time(self, which):
+        ms, cnt = C.c_double(0), C.c_uint64(0)
+        rc = lib().x3_ctx_kernel_time(self._h, which, C.byref(ms), C.byref(cnt))
+        if rc:
+            raise X3Error(rc, "x3_ctx_kernel_time")
+        return ms.value, cnt.value
+
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        rc = lib().x3_dev_alloc(self._h, nbytes, C.byref(p))
+        if rc:
+            raise X3Error(rc, "x3_dev_alloc: " + self.last_error())
+        return p.value
+
+    def free(self, ptr):
+        lib().x3_dev_free(self._h, ptr)
+
+    def upload(self, d_dst, arr):
+        arr = np.ascontiguousarray(arr)
+        rc = lib().x3_dev_upload(self._h, d_dst, arr.ctypes.data, arr.nbytes)
+        if rc:
+            raise X3Error(rc, "x3_dev_upload: " + self.last_error())
+
+    def download(self, d_src, nbytes, dtype=np.uint8):
+        out = np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        rc = lib().x3_dev_download(self._h, out.ctypes.data, d_src, nbytes)
+        if rc:
+            raise X3Error(rc, "x3_dev_download: " + self.last_error())
+        return out
