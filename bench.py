@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- encode+decode round trip of BASELINE config 3 (1 h of 192 kHz mono, 691.2 M samples)
+on N MI355X GPUs, one process per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch of synthetic audio already resident in HBM:
+x3_encode_dev (frame sizes -> scan -> encode+compact into the final stream) followed by
+x3_decode_dev (header + payload CRC check + decode) of the stream just produced.  With N > 1 the
+frames are sharded (weak scaling: every rank owns its own hour of audio = BASELINE config 4 at
+N = 8); the only data-path exchange per step is the RCCL all-gather of the sub-stream lengths that
+places each rank's sub-stream in the global .x3a byte range.  The full reassembly gather to rank 0
+is timed separately and reported under "gather" (DESIGN.md section "Multi-GPU").
+
+Rank 0 prints ONE JSON line (see the contract in the task statement), with
+  roofline     -- the encode kernel: algorithmic bytes (2 B/sample read + stream bytes written)
+                  / mean launch time from HIP events on the launch stream, vs 8 TB/s HBM
+  cpu_baseline -- the CPU oracle (C port of the reference algorithm, 1 thread) on a bounded
+                  sample of the same signal, timed in this run on this box's host cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "x3-rust_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_SAMPLES = 691_200_000  # config 3: 1 h @ 192 kHz mono
+SEED = 0x58330003
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--samples", type=int, default=N_SAMPLES, help="samples per GPU (default: config 3)")
+    ap.add_argument("--kind", type=int, default=2, help="synthetic signal (2 = hydrophone noise)")
+    ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="samples timed on the CPU baseline")
+    ap.add_argument("--cpu-reps", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import x3hip
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n = args.samples
+    p = x3hip.Params.default()
+    L = x3hip.lib()
+    F = L.x3_num_frames(n, C.byref(p))
+    cap = L.x3_encode_bound(n, C.byref(p))
+
+    stream = torch.cuda.current_stream(dev)
+    ctx = x3hip.Context(local_rank, stream=stream.cuda_stream)
+
+    wav = torch.empty(n, dtype=torch.int16, device=dev)
+    out = torch.empty(cap + 16, dtype=torch.uint8, device=dev)
+    off = torch.empty(F + 1, dtype=torch.int64, device=dev)
+    back = torch.empty(n, dtype=torch.int16, device=dev)
+    # every rank owns a different hour of the same seeded signal
+    ctx.synth_dev(args.kind, SEED, rank * n, n, wav.data_ptr())
+    torch.cuda.synchronize(dev)
+
+    lens = torch.zeros(world, dtype=torch.int64, device=dev)
+
+    def step():
+        rc = ctx.encode_dev(wav.data_ptr(), n, p, out.data_ptr(), cap, 0, off.data_ptr())
+        assert rc == 0, (rc, ctx.last_error())
+        if dist is not None:
+            # the exchange step of the sharded path: sub-stream lengths -> global byte offsets
+            dist.all_gather_into_tensor(lens, off[F:F + 1])
+        rc = ctx.decode_dev(out.data_ptr(), cap, off.data_ptr(), F, p, back.data_ptr(), n, n_per_clip=n)
+        assert rc == 0, (rc, ctx.last_error())
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    rc, pos, stats = ctx.encode_result()
+    assert rc == 0, (rc, ctx.last_error())
+    rc, first_bad, st, before = ctx.decode_result()
+    assert (rc, first_bad, st, before) == (0, F, 0, n), (rc, first_bad, st, before)
+
+    ctx.enable_kernel_timing(True)
+    ctx.reset_kernel_time()
+    barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    rc, pos, stats = ctx.encode_result()
+    assert rc == 0, (rc, ctx.last_error())
+    rc, first_bad, st, before = ctx.decode_result()
+    assert (rc, first_bad, st, before) == (0, F, 0, n), (rc, first_bad, st, before)
+    enc_ms, enc_cnt = ctx.kernel_time(0)
+    dec_ms, dec_cnt = ctx.kernel_time(1)
+    size_ms, size_cnt = ctx.kernel_time(2)
+    scan_ms, scan_cnt = ctx.kernel_time(3)
+    ctx.enable_kernel_timing(False)
+
+    # ---- bit-exactness of the timed output
+    assert torch.equal(back, wav), "decode(encode(x)) != x"
+    import oracle_lib as O
+    offs = off.cpu().numpy()
+    assert int(offs[-1]) == pos
+    for f in [0, F // 3, F - 1]:
+        s = wav[f * p.spf:(f + 1) * p.spf].cpu().numpy()
+        enc = out[int(offs[f]):int(offs[f + 1])].cpu().numpy()
+        assert np.array_equal(enc, O.encode(s)[1]), "frame %d differs from the CPU oracle" % f
+
+    # ---- optional: reassembly gather of the sub-streams to rank 0 (timed on its own)
+    gather = None
+    if dist is not None and not args.no_gather:
+        lens_h = lens.cpu().tolist()
+        starts = [0]
+        for v in lens_h:
+            starts.append(starts[-1] + v)
+        whole = torch.empty(starts[-1] if rank == 0 else 1, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)
+        barrier()
+        g0 = time.perf_counter()
+        ops = []
+        if rank == 0:
+            whole[:lens_h[0]].copy_(out[:lens_h[0]])
+            for r in range(1, world):
+                ops.append(dist.P2POp(dist.irecv, whole[starts[r]:starts[r + 1]], r))
+        else:
+            ops.append(dist.P2POp(dist.isend, out[:lens_h[rank]], 0))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        torch.cuda.synchronize(dev)
+        barrier()
+        g1 = time.perf_counter()
+        gather = {"ms": round((g1 - g0) * 1e3, 3), "bytes": int(starts[-1]),
+                  "pattern": "grouped ncclSend/ncclRecv to rank 0 (one xGMI link per peer)"}
+
+    # ---- CPU baseline: the oracle (port of the reference algorithm), 1 thread, bounded sample
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        m = min(args.cpu_sample, n)
+        sample = wav[:m].cpu().numpy()
+        OL = O.lib(native=True)
+        po = O.Params.default()
+        es, ds, sl = C.c_double(0), C.c_double(0), C.c_uint64(0)
+        rc = OL.x3o_time_roundtrip(sample.ctypes.data, m, C.byref(po), args.cpu_reps, C.byref(es), C.byref(ds),
+                                   C.byref(sl))
+        assert rc == 0, rc
+        tot = es.value + ds.value
+        cpu = {"value": round(m * args.cpu_reps / tot / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": "port",
+               "sample": "first %d samples of the same signal, %d reps, encode %.2f s + decode %.2f s; "
+                         "oracle/x3_oracle.c -O3 -march=native -flto" % (m, args.cpu_reps, es.value, ds.value),
+               "encode_msamples_s": round(m * args.cpu_reps / es.value / 1e6, 2),
+               "decode_msamples_s": round(m * args.cpu_reps / ds.value / 1e6, 2)}
+
+    if rank == 0:
+        total_samples = n * world
+        value = total_samples * args.steps / elapsed / 1e6
+        enc_avg_s = enc_ms / max(enc_cnt, 1) / 1e3
+        alg_bytes = 2 * n + pos  # per launch: 2 B/sample read + stream bytes written
+        achieved = alg_bytes / enc_avg_s / 1e9
+        res = {
+            "metric": "Msamples/s encode+decode (bit-exact), 1h 192kHz mono; % HBM-read roofline",
+            "value": round(value, 2),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "i16",
+            "data": "synthetic",
+            "config": {"workload": "config 3: 1 h 192 kHz mono hydrophone-like noise, encode+decode round trip per GPU",
+                       "samples_per_gpu": n, "frames_per_gpu": int(F), "stream_bytes_per_gpu": int(pos),
+                       "bytes_per_sample": round(pos / n, 4), "block_len": 20, "blocks_per_frame": 500,
+                       "sharding": "frames sharded across ranks; all-gather of sub-stream lengths per step"},
+            "roofline": {"bound": "hbm", "kernel": "x3_encode_frames_kernel<false>", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": None, "algorithmic_bytes": int(alg_bytes),
+                         "avg_launch_ms": round(enc_avg_s * 1e3, 4),
+                         "read_frac": round(2 * n / enc_avg_s / 1e9 / HBM_PEAK_GBS, 4)},
+            "kernels_ms": {"encode": round(enc_ms / max(enc_cnt, 1), 4), "decode": round(dec_ms / max(dec_cnt, 1), 4),
+                           "frame_sizes": round(size_ms / max(size_cnt, 1), 4),
+                           "scan": round(scan_ms / max(scan_cnt, 1), 4)},
+            "cpu_baseline": cpu,
+        }
+        if gather is not None:
+            res["gather"] = gather
+        print(json.dumps(res), flush=True)
+
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -73,6 +73,26 @@ class Batch(C.Structure):
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  Two HIP
+    runtimes in one process cannot both own the GPU, so when torch is installed its copy is loaded
+    first and libx3hip.so's DT_NEEDED libamdhip64.so.7 then binds to it -- in either import order
+    bench.py (torch for HBM tensors / streams / RCCL + this library for the kernels) sees one runtime.
+    Without torch the system runtime from /opt/rocm is used."""
+    if os.environ.get("X3HIP_SYSTEM_HIP") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def lib():
     """Load libx3hip.so; raises if it has not been built (python x3-rust_amd/build.py)."""
     global _lib
@@ -81,6 +101,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libx3hip.so is missing (%s): run `python x3-rust_amd/build.py`; "
                            "there is no CPU fallback" % LIB_PATH)
+    _preload_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
     PP = C.POINTER(Params)
