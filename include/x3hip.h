@@ -101,7 +101,8 @@ int x3_ctx_sync(x3_ctx* ctx);
 const char* x3_last_error(const x3_ctx* ctx);
 
 /* HIP-event timing of individual kernels on the context's stream (bench.py's roofline leg).
- * which: 0 = encode kernel, 1 = decode kernel, 2 = frame-size kernel, 3 = scan kernel. */
+ * which: 0 = encode kernel, 1 = decode kernel, 2 = frame-size kernel, 3 = scan kernel,
+ *        4 = frame check (header + payload CRC) kernel. */
 int x3_ctx_enable_kernel_timing(x3_ctx* ctx, int enable);
 int x3_ctx_kernel_time(x3_ctx* ctx, int which, double* total_ms, uint64_t* launches); /* syncs */
 int x3_ctx_reset_kernel_time(x3_ctx* ctx);

@@ -411,6 +411,7 @@ def test_full_size_config3_roundtrip(ctx, x3):
     rc, pos, stats = ctx.encode_result()
     assert rc == 0 and int(stats.sum()) == n - F
     back = torch.zeros(n, dtype=torch.int16, device=dev)
+    torch.cuda.synchronize(dev)  # the fill ran on torch's stream, the decoder runs on the context's
     assert ctx.decode_dev(out.data_ptr(), pos, off.data_ptr(), F, p, back.data_ptr(), n, n_per_clip=n) == 0
     rc, first_bad, st, before = ctx.decode_result()
     assert (rc, first_bad, st, before) == (0, F, 0, n)

@@ -51,14 +51,14 @@ struct x3_ctx {
   X3DecodeSummary* h_summary = nullptr;
   uint16_t* h_crc = nullptr;
   // growable scratch
-  DevBuf in, out, frame_bytes, frame_off, dec_status, dec_nsamp, wav_off, seg_crc;
+  DevBuf in, out, frame_bytes, frame_off, dec_status, dec_meta, wav_off, seg_crc;
   // bookkeeping of the last async calls
   bool encode_pending = false, decode_pending = false;
   uint64_t enc_start_pos = 0;
   uint64_t dec_frames = 0;
   // kernel timing
   bool timing = false;
-  KernelTimer timers[4];
+  KernelTimer timers[5];
 };
 
 #define HIPCHK(ctx, call)                                                                       \
@@ -133,6 +133,15 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
   uint32_t xi = 0x8810u;
   for (int i = 0; i < 4; ++i) xi = gf_mul_host(xi, xi);
   xp[X3_XINV16_INDEX] = (uint16_t)xi;
+  {
+    uint32_t xi8 = 0x8810u;  // x^-1
+    for (int i = 0; i < 3; ++i) xi8 = gf_mul_host(xi8, xi8);  // x^-8
+    uint32_t acc = 1;
+    for (int t = 1; t <= 3; ++t) {
+      acc = gf_mul_host(acc, xi8);
+      xp[X3_XINV8_INDEX(t)] = (uint16_t)acc;
+    }
+  }
   HIPCHK(c, hipMemcpy(c->d_xpow, xp.data(), X3_XP_SIZE * sizeof(uint16_t), hipMemcpyHostToDevice));
   return X3_OK;
 }
@@ -169,7 +178,7 @@ extern "C" void x3_ctx_destroy(x3_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  for (DevBuf* b : {&c->in, &c->out, &c->frame_bytes, &c->frame_off, &c->dec_status, &c->dec_nsamp, &c->wav_off,
+  for (DevBuf* b : {&c->in, &c->out, &c->frame_bytes, &c->frame_off, &c->dec_status, &c->dec_meta, &c->wav_off,
                     &c->seg_crc})
     if (b->p) (void)hipFree(b->p);
   for (auto& t : c->timers) {
@@ -250,7 +259,7 @@ extern "C" int x3_ctx_reset_kernel_time(x3_ctx* c) {
 }
 
 extern "C" int x3_ctx_kernel_time(x3_ctx* c, int which, double* total_ms, uint64_t* launches) {
-  if (!c || which < 0 || which > 3) return X3_ERR_BAD_ARG;
+  if (!c || which < 0 || which > 4) return X3_ERR_BAD_ARG;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   double tot = 0;
   for (auto& e : c->timers[which].used) {
@@ -647,20 +656,25 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
     g.clip_stride = batch->clip_stride;
     g.fpc = (uint32_t)fpc;
   }
-  if ((rc = ensure(c, c->dec_nsamp, F * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(c, c->dec_meta, F * sizeof(X3FrameMeta)))) return rc;
   if (!d_status) {
     if ((rc = ensure(c, c->dec_status, F * sizeof(int32_t)))) return rc;
     d_status = (int32_t*)c->dec_status.p;
   }
-  const unsigned nthr = 64;
-  const unsigned grid = (unsigned)((F + nthr - 1) / nthr);
+  {
+    TimerScope ts(c, 4);
+    hipLaunchKernelGGL(x3_frame_check_kernel, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, c->stream,
+                       reinterpret_cast<const uint32_t*>(d_x3), x3_len, d_frame_offsets, F,
+                       (const uint16_t*)c->d_xpow, d_status, (X3FrameMeta*)c->dec_meta.p);
+  }
   {
     TimerScope ts(c, 1);
-    hipLaunchKernelGGL(x3_decode_frames_kernel, dim3(grid), dim3(nthr), 0, c->stream, d_x3, x3_len, d_frame_offsets,
-                       F, g, d_wav_offsets, dp, d_wav, wav_cap, d_status, (uint32_t*)c->dec_nsamp.p);
+    hipLaunchKernelGGL(x3_decode_lanes_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, c->stream, d_x3, x3_len,
+                       d_frame_offsets, F, g, d_wav_offsets, dp, d_wav, wav_cap, d_status,
+                       (const X3FrameMeta*)c->dec_meta.p);
   }
   hipLaunchKernelGGL(x3_decode_summary_kernel, dim3(1), dim3(1024), 0, c->stream, (const int32_t*)d_status,
-                     (const uint32_t*)c->dec_nsamp.p, F, c->d_summary);
+                     (const X3FrameMeta*)c->dec_meta.p, F, c->d_summary);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(X3DecodeSummary), hipMemcpyDeviceToHost, c->stream));
   c->decode_pending = true;

@@ -77,7 +77,7 @@ __device__ __forceinline__ uint32_t x3_gf_mul(uint32_t a, uint32_t k) {
 #define X3_XP_LEVELS 10
 #define X3_XP_M 128
 #define X3_XINV16_INDEX (X3_XP_LEVELS * (X3_XP_M + 1))  // x^(-16) mod P stored after the table
-#define X3_XP_SIZE (X3_XINV16_INDEX + 1)
+#define X3_XP_SIZE (X3_XINV16_INDEX + 5)               // + x^(-8t), t = 1..3 (x3_decode_kernel.h)
 
 __device__ __forceinline__ uint32_t x3_xp(const uint16_t* __restrict__ xpow, int level, uint32_t m) {
   return xpow[level * (X3_XP_M + 1) + m];
