@@ -138,6 +138,28 @@ __device__ __forceinline__ int32_t x3_inv_rice(uint32_t i) { return (i & 1u) ? -
 #define X3_DEC_OUT_STRIDE 82u    // row stride in dwords (80 + 2: 8-byte aligned rows)
 #define X3_DEC_CHUNK 20u         // samples decoded between two services of the input ring
 
+__device__ __forceinline__ uint32_t x3_wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint32_t t = __shfl_xor(v, d, X3_WAVE);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+
+// LDS traffic between lanes of ONE wave needs no s_barrier: a wave's DS instructions execute in
+// issue order.  This only stops the compiler from moving LDS accesses across the point.
+#define X3_WAVE_LDS_ORDER()                                   \
+  do {                                                        \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+    __builtin_amdgcn_wave_barrier();                          \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
+  } while (0)
+
+// FAST: every valid Rice codeword (zero run + terminator + sub-code) is at most 33 bits, so one
+// window refill per sample suffices and a zero run of >= 32 bits is an error outright.  True for
+// the default parameters; the host picks the general instantiation otherwise.
+template <bool FAST>
 __global__ void __launch_bounds__(64)
 x3_decode_lanes_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uint64_t* __restrict__ frame_off,
                        uint64_t n_frames, X3Geom g, const uint64_t* __restrict__ wav_off, X3DevParams p,
@@ -145,8 +167,8 @@ x3_decode_lanes_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
                        const X3FrameMeta* __restrict__ meta) {
   __shared__ __attribute__((aligned(16))) uint32_t ring[64 * X3_DEC_RING_STRIDE];
   __shared__ __attribute__((aligned(16))) uint32_t outs[64 * X3_DEC_OUT_STRIDE];
-  __shared__ unsigned long long s_base[64];  // output address of each lane's frame (0 = not cooperative)
-  __shared__ uint32_t s_ns[64];              // samples of each lane's frame
+  __shared__ unsigned long long s_wo[64];  // sample offset of each lane's frame in wav
+  __shared__ uint32_t s_ns[64];            // samples of each lane's frame (0 = not flushed cooperatively)
 
   const uint32_t lane = threadIdx.x;
   const uint64_t f = (uint64_t)blockIdx.x * 64 + lane;
@@ -156,9 +178,8 @@ x3_decode_lanes_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   // ---- per-lane frame setup
   bool active = f < n_frames;
   int32_t st = X3D_OK;
-  uint32_t samples = 0, plen = 0;
-  uint64_t p0 = 0;
-  int16_t* o = nullptr;
+  uint32_t samples = 0, plen = 2;
+  uint64_t p0 = 0, wo = 0;
   if (active) {
     st = status[f];
     samples = meta[f].samples;
@@ -170,7 +191,6 @@ x3_decode_lanes_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       st = X3D_BAD_ARG;  // the reference panics (decoder.rs:42,47)
       active = false;
     } else {
-      uint64_t wo;
       if (wav_off) {
         wo = wav_off[f];
       } else {
@@ -181,208 +201,206 @@ x3_decode_lanes_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       if (wo + samples > wav_cap) {
         st = X3D_BAD_ARG;  // slice index panic
         active = false;
-      } else {
-        o = wav + wo;
       }
     }
   }
+  if (!active) { p0 = 0; plen = 2; wo = 0; }  // harmless addresses for idle lanes
+  int16_t* __restrict__ const o = wav + wo;
   // frames whose output is 16-byte aligned are flushed cooperatively, the others store directly
   const bool coop = active && ((reinterpret_cast<uintptr_t>(o) & 15u) == 0);
-  s_base[lane] = coop ? (unsigned long long)reinterpret_cast<uintptr_t>(o) : 0ull;
-  s_ns[lane] = active ? samples : 0u;
+  s_wo[lane] = wo;
+  s_ns[lane] = coop ? samples : 0u;
 
-  // ---- input ring: absolute addresses, 16-byte chunks
-  const uintptr_t pay_addr = reinterpret_cast<uintptr_t>(x3) + p0;
-  const uintptr_t end_addr = pay_addr + plen;          // first byte that must read as zero
-  const uintptr_t bits_addr = pay_addr + 2;            // the bit stream starts behind the raw first sample
-  uintptr_t next_chunk = bits_addr & ~(uintptr_t)15;   // next 16-byte chunk to request
+  // ---- input ring.  Offsets are "virtual": v = byte offset from x3b, the 16-byte-aligned address
+  // at or below x3, so that 16-byte chunks are aligned in memory whatever x3's own alignment is.
+  const uint32_t adj = (uint32_t)(reinterpret_cast<uintptr_t>(x3) & 15u);
+  const uint8_t* __restrict__ const x3b = x3 - adj;
+  const uint64_t v_end = adj + p0 + plen;              // first byte that must read as zero
+  const uint64_t v_bits = adj + p0 + 2;                // the bit stream starts behind the raw first sample
+  const uint64_t v_last = (v_end - 1) & ~15ull;        // last chunk that holds payload bytes
+  uint64_t v_next = v_bits & ~15ull;                   // next 16-byte chunk the ring needs
   uint32_t wr_abs = 0;                                 // dwords written to the ring so far
   uint32_t rd_abs = 0;                                 // dwords taken out of the ring so far
 
-  auto load_chunk = [&](uintptr_t a) -> uint4 {
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (a < end_addr) {
-      v = *reinterpret_cast<const uint4*>(a);
-      if (a + 16 > end_addr) {  // zero the bytes past the payload
-        uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          const uintptr_t ad = a + 4 * d;
-          if (ad >= end_addr) w[d] = 0;
-          else if (ad + 4 > end_addr) w[d] &= (1u << (8u * (uint32_t)(end_addr - ad))) - 1u;
-        }
-        v = make_uint4(w[0], w[1], w[2], w[3]);
-      }
-    }
-    return v;
+  // request a chunk (never touches memory behind the payload's last chunk)
+  auto request = [&](uint64_t v) -> uint4 {
+    const uint64_t a = v < v_last ? v : v_last;
+    return *reinterpret_cast<const uint4*>(x3b + a);
   };
-  auto park = [&](const uint4& v) {
-    *reinterpret_cast<uint4*>(row + (wr_abs & (X3_DEC_RING_DW - 1u))) = v;
+  // park a chunk requested for virtual offset v in the ring, zeroing the bytes past the payload
+  auto park = [&](uint4 c, uint64_t v) {
+    const int64_t left = (int64_t)(v_end - v);  // payload bytes from the chunk start on (may be <= 0)
+    if (left < 16) {
+      uint32_t w[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int64_t r = left - 4 * d;
+        w[d] = r >= 4 ? w[d] : (r <= 0 ? 0u : (w[d] & ((1u << (8u * (uint32_t)r)) - 1u)));
+      }
+      c = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    *reinterpret_cast<uint4*>(row + (wr_abs & (X3_DEC_RING_DW - 1u))) = c;
     wr_abs += 4;
   };
 
-  uint64_t win = 0;
-  uint32_t have = 0, nextw = 0;
+  uint64_t win = 0;          // next bits, MSB first
+  uint32_t have = 0;         // valid bits in win
+  uint32_t nextw_raw = 0;    // ring dword behind the window, in memory byte order (swapped on use)
   int32_t last = 0;
-  uint32_t remaining = 0;  // samples of this lane's frame still to decode
-  if (active) {
-    for (int k = 0; k < 8; ++k) {  // fill the ring: 128 bytes
-      park(load_chunk(next_chunk));
-      next_chunk += 16;
-    }
-    const uint32_t skip = (uint32_t)(bits_addr & 15u);  // bytes of the first chunk in front of the bit stream
+  uint32_t remaining = 0;    // samples of this lane's frame still to decode
+  {
+    uint4 c[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c[k] = request(v_next + 16u * k);  // fill the ring: 128 bytes
+#pragma unroll
+    for (int k = 0; k < 8; ++k) park(c[k], v_next + 16u * k);
+    v_next += 128;
+    const uint32_t skip = (uint32_t)(v_bits & 15u);  // bytes of the first chunk in front of the bit stream
     rd_abs = skip >> 2;
     const uint32_t a = skip & 3u;
     const uint32_t w0 = x3_bswap32(row[rd_abs & (X3_DEC_RING_DW - 1u)]);
     ++rd_abs;
     win = (uint64_t)w0 << (32u + 8u * a);
     have = 32u - 8u * a;
-    nextw = x3_bswap32(row[rd_abs & (X3_DEC_RING_DW - 1u)]);
-    last = (int16_t)(uint16_t)((uint32_t)x3[p0] << 8 | x3[p0 + 1]);  // <Audio State> (decoder.rs:42)
+    nextw_raw = row[rd_abs & (X3_DEC_RING_DW - 1u)];
   }
-  // in-flight chunk requests (issued one service ahead of use)
-  uint4 ld0 = make_uint4(0, 0, 0, 0), ld1 = ld0, ld2 = ld0;
-  uint32_t n_inflight = 0;
+  if (active) {
+    last = (int16_t)(uint16_t)((uint32_t)x3[p0] << 8 | x3[p0 + 1]);  // <Audio State> (decoder.rs:42)
+    remaining = samples - 1u;
+  }
+  // the next three chunks are always requested one service ahead of use; what fits the ring when
+  // they are parked is kept, the rest is simply requested again (it stays in L1/L2)
+  uint4 ld0 = request(v_next), ld1 = request(v_next + 16), ld2 = request(v_next + 32);
+  uint64_t v_req = v_next;
 
   auto refill = [&]() {
     if (have <= 32u) {
-      win |= (uint64_t)nextw << (32u - have);
+      win |= (uint64_t)x3_bswap32(nextw_raw) << (32u - have);
       have += 32u;
       ++rd_abs;
-      nextw = x3_bswap32(row[rd_abs & (X3_DEC_RING_DW - 1u)]);
+      nextw_raw = row[rd_abs & (X3_DEC_RING_DW - 1u)];
     }
   };
-  auto read_bits = [&](uint32_t n) -> uint32_t {  // n in 1..32
-    refill();
-    const uint32_t v = (uint32_t)(win >> (64u - n));
-    win <<= n;
-    have -= n;
-    return v;
-  };
-  auto count_zeros = [&]() -> uint32_t {  // consumes the zero run, not the terminating 1
-    refill();
-    uint32_t top = (uint32_t)(win >> 32);
-    if (top) {
-      const uint32_t z = (uint32_t)__clz(top);
-      win <<= z;
-      have -= z;
-      return z;
-    }
-    uint32_t total = 0;
-    for (;;) {
-      win <<= 32;
-      have -= 32;
-      total += 32;
-      if (total >= 128) return total;  // far beyond every table bound
-      refill();
-      top = (uint32_t)(win >> 32);
-      if (top) {
-        const uint32_t z = (uint32_t)__clz(top);
-        win <<= z;
-        have -= z;
-        return total + z;
-      }
-    }
-  };
-  // keep the ring ahead of the reader: park what was requested one service ago, request up to 3
-  // more chunks (48 B >= the 41 B a 20-sample chunk can consume), top up synchronously if short
+  // keep the ring ahead of the reader (48 B per service >= the 41 B a 20-sample chunk of literals
+  // consumes; the ring starts full, so it never runs dry -- see DESIGN.md)
   auto service = [&]() {
-    if (n_inflight > 0) park(ld0);
-    if (n_inflight > 1) park(ld1);
-    if (n_inflight > 2) park(ld2);
-    n_inflight = 0;
-    if (remaining > 0) {
-      while (wr_abs - rd_abs < 14u) {  // never in steady state; guards ring underflow
-        park(load_chunk(next_chunk));
-        next_chunk += 16;
-      }
-      const uint32_t free_dw = X3_DEC_RING_DW - (wr_abs - rd_abs) - 1u;  // keep nextw's slot
-      const uint32_t want = free_dw >> 2;
-      n_inflight = want > 3u ? 3u : want;
-      if (n_inflight > 0) { ld0 = load_chunk(next_chunk); next_chunk += 16; }
-      if (n_inflight > 1) { ld1 = load_chunk(next_chunk); next_chunk += 16; }
-      if (n_inflight > 2) { ld2 = load_chunk(next_chunk); next_chunk += 16; }
-    }
+    const uint32_t free_dw = X3_DEC_RING_DW - (wr_abs - rd_abs) - 1u;  // keep nextw's slot
+    const uint32_t fit = free_dw >> 2;
+    if (fit > 0) park(ld0, v_req);
+    if (fit > 1) park(ld1, v_req + 16);
+    if (fit > 2) park(ld2, v_req + 32);
+    v_next += 16u * (fit > 3u ? 3u : fit);
+    v_req = v_next;
+    ld0 = request(v_req);
+    ld1 = request(v_req + 16);
+    ld2 = request(v_req + 32);
   };
 
   // ---- output staging
   uint32_t wbase = 0;   // first sample index of the staged window (uniform, multiple of X3_DEC_WIN)
   int32_t carry = 0;    // even-indexed sample waiting for its odd partner
   auto flush = [&](uint32_t upto) {  // stage holds samples [wbase, upto) of every lane's frame
-    __syncthreads();
+    X3_WAVE_LDS_ORDER();
     const uint32_t pieces = (upto - wbase + 7u) >> 3;  // 16-byte pieces per frame in this window
     const uint32_t total = pieces * 64u;
     for (uint32_t t = lane; t < total; t += 64u) {
       const uint32_t r = t / pieces, q = t - r * pieces;
-      const unsigned long long base = s_base[r];
       const uint32_t ns = s_ns[r];
-      if (base && wbase + 8u * q + 8u <= ns) {
+      if (wbase + 8u * q + 8u <= ns) {
         const uint2* src = reinterpret_cast<const uint2*>(outs + r * X3_DEC_OUT_STRIDE + 4u * q);
         const uint2 lo = src[0], hi = src[1];
-        *reinterpret_cast<uint4*>(base + 2ull * wbase + 16ull * q) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        *reinterpret_cast<uint4*>(wav + s_wo[r] + wbase + 8u * q) = make_uint4(lo.x, lo.y, hi.x, hi.y);
       }
     }
-    __syncthreads();
+    X3_WAVE_LDS_ORDER();
   };
 
+  X3_WAVE_LDS_ORDER();  // s_wo / s_ns visible to the wave
   if (active) {
     carry = last;  // sample 0
     if (!coop || samples == 1u) o[0] = (int16_t)last;
   }
 
   // ---- lock-step decode: block index and in-block sample index are wave-uniform
-  remaining = active ? samples - 1u : 0u;
   const uint32_t bl = p.block_len;
   uint32_t i = 1;  // uniform index of the sample being produced
   for (;;) {
-    if (!__any(remaining > 0)) break;
     uint32_t cnt = remaining < bl ? remaining : bl;
-    // block header (decoder.rs:138-144)
-    uint32_t mode_rice = 0, E = 0, nb = 0, bound = 0;
-    int32_t level = 0;
+    const uint32_t maxcnt = __any(cnt == bl) ? bl : x3_wave_max_u32(cnt);
+    if (maxcnt == 0) break;
     service();
+    // block header (decoder.rs:138-144).  Both block families are decoded by one branch-free
+    // body: [z = leading zeros, Rice only] then a fixed-width field of `width` bits.
+    //   Rice: r1 counts zeros and skips the 1 (decoder.rs:156-163) == width 1, level 1;
+    //         r2r3: width hard-wired 2 / 4, level = 1 << nsubs (decoder.rs:180-186)
+    //   BFP / literal: width = E (decoder.rs:209-235)
+    uint32_t zmask = 0, width = 1, bound = 0xFFFFFFFFu, level = 0, lit = 0, neg_thresh = 0xFFFFFFFFu, neg2 = 0;
     if (cnt) {
-      const uint32_t ftype = read_bits(2);
+      refill();
+      const uint32_t hdr = (uint32_t)(win >> 58);  // 6 header bits
+      const uint32_t ftype = hdr >> 4;
       if (ftype == 0) {
-        E = read_bits(4) + 1u;  // decode_bpf_block (decoder.rs:209-235)
+        const uint32_t E = (hdr & 15u) + 1u;
+        win <<= 6;
+        have -= 6;
+        width = E;
+        lit = E == 16u ? 1u : 0u;
+        neg_thresh = 1u << (E - 1u);
+        neg2 = lit ? 0u : (neg_thresh << 1);
         if (E <= 5u) {
           st = X3D_FRAME_DECODE_INVALID_BPF;
           cnt = 0;
           remaining = 0;
         }
       } else {
-        mode_rice = 1;
-        // r1: count zeros, skip the 1 (decoder.rs:156-163)  ==  nb = 1, level = 1 below
-        // r2r3: nb hard-wired 2 / 4, level = 1 << nsubs (decoder.rs:180-186)
-        nb = ftype == 1u ? 1u : (ftype == 2u ? 2u : 4u);
-        level = ftype == 1u ? 1 : (1 << (ftype == 2u ? p.k[1] : p.k[2]));
+        win <<= 2;
+        have -= 2;
+        zmask = 0xFFFFFFFFu;
+        width = ftype == 1u ? 1u : (ftype == 2u ? 2u : 4u);
+        level = ftype == 1u ? 1u : (1u << (ftype == 2u ? p.k[1] : p.k[2]));
         bound = ftype == 1u ? p.inv_len[0] : (ftype == 2u ? p.inv_len[1] : p.inv_len[2]);
       }
     }
-    const uint32_t neg_thresh = E ? (1u << (E - 1u)) : 0u;
-    for (uint32_t j = 0; j < bl; ++j) {
-      if (!__any(j < cnt)) break;
+    const uint32_t rsh = 32u - width;
+    for (uint32_t j = 0; j < maxcnt; ++j) {
       if (j && (j % X3_DEC_CHUNK) == 0) service();
       if (j < cnt) {
-        if (mode_rice) {
-          const int32_t nz = (int32_t)count_zeros();
-          const int32_t r = (int32_t)read_bits(nb);
-          const int32_t ii = (int32_t)(int16_t)(r + level * (nz - 1));
-          if (ii < 0 || (uint32_t)ii >= bound) {
-            st = X3D_OUT_OF_BOUNDS_INVERSE;
-            cnt = 0;
-            remaining = 0;
-          } else {
-            last = (int16_t)(uint16_t)(last + x3_inv_rice((uint32_t)ii));
+        refill();
+        uint32_t top = (uint32_t)(win >> 32);
+        uint32_t z = (uint32_t)__clz(top) & zmask;  // __clz(0) = 32
+        uint32_t zextra = 0;
+        if (!FAST) {
+          if (zmask && top == 0) {  // zero run of >= 32 bits: keep counting (general parameters only)
+            do {
+              win <<= 32;
+              have -= 32;
+              zextra += 32;
+              refill();
+              top = (uint32_t)(win >> 32);
+            } while (top == 0 && zextra < 128);
+            z = top ? (uint32_t)__clz(top) : 0u;
           }
+        }
+        win <<= z;
+        have -= z;
+        if (!FAST) refill();
+        const uint32_t v = (uint32_t)(win >> 32) >> rsh;
+        win <<= width;
+        have -= width;
+        z += zextra;
+        // Rice: i = r + level*(n-1) (decoder.rs:186), inverse table = zigzag (x3.rs:200-204)
+        const uint32_t ii = v + level * z - level;
+        const int32_t d_rice = (int32_t)(ii >> 1) ^ -(int32_t)(ii & 1u);
+        // BFP: unsigned_to_i16 (decoder.rs:198-207)
+        const int32_t d_bfp = (int32_t)v - (int32_t)(v > neg_thresh ? neg2 : 0u);
+        const int32_t d = zmask ? d_rice : d_bfp;
+        const int32_t nl = lit ? (int32_t)v : last + d;
+        if (zmask && ii >= bound) {  // OutOfBoundsInverse (decoder.rs:160,187)
+          st = X3D_OUT_OF_BOUNDS_INVERSE;
+          cnt = 0;
+          remaining = 0;
         } else {
-          int32_t a = (int32_t)read_bits(E);
-          if (E == 16u) {
-            last = (int16_t)(uint16_t)a;  // literal block (decoder.rs:218-222)
-          } else {
-            if ((uint32_t)a > neg_thresh) a -= (int32_t)(neg_thresh << 1);  // unsigned_to_i16 (decoder.rs:198-207)
-            last = (int16_t)(uint16_t)(last + a);
-          }
+          last = (int16_t)(uint16_t)nl;
         }
       }
       if (j < cnt) {  // still alive after this sample
