@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Kernel micro-bench: time the individual kernels of the round trip on config-3-like data.
+usage: kbench.py [--samples N] [--steps K] [--kind 2]     (X3HIP_LIB=/path/to/variant.so to test a build)"""
+import argparse, ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "x3-rust_amd"))
+import x3hip
+if os.environ.get("X3HIP_LIB"):
+    x3hip.LIB_PATH = os.environ["X3HIP_LIB"]
+ap = argparse.ArgumentParser()
+ap.add_argument("--samples", type=int, default=691_200_000)
+ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--kind", type=int, default=2)
+a = ap.parse_args()
+ctx = x3hip.Context(0)
+p = x3hip.Params.default()
+n = a.samples
+L = x3hip.lib()
+F = L.x3_num_frames(n, C.byref(p)); cap = L.x3_encode_bound(n, C.byref(p))
+d_wav = ctx.alloc(2 * n); d_out = ctx.alloc(cap + 16); d_off = ctx.alloc(8 * (F + 1)); d_back = ctx.alloc(2 * n)
+ctx.synth_dev(a.kind, 0x58330003, 0, n, d_wav)
+def step():
+    assert ctx.encode_dev(d_wav, n, p, d_out, cap, 0, d_off) == 0
+    assert ctx.decode_dev(d_out, cap, d_off, F, p, d_back, n, n_per_clip=n) == 0
+step(); rc, pos, st = ctx.encode_result(); assert rc == 0; r = ctx.decode_result(); assert os.environ.get("X3_NOCHECK") or r[:3] == (0, F, 0), r
+ctx.enable_kernel_timing(True); ctx.reset_kernel_time()
+for _ in range(a.steps): step()
+names = ["encode", "decode", "sizes", "scan", "check"]
+print(" ".join("%s=%.3f" % (names[i], ctx.kernel_time(i)[0] / a.steps) for i in range(5)), "ms; stream B/sample=%.4f" % (pos / n))

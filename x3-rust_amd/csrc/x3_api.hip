@@ -668,21 +668,21 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
                        (const uint16_t*)c->d_xpow, d_status, (X3FrameMeta*)c->dec_meta.p);
   }
   {
-    // one window refill per sample is enough when every valid Rice codeword fits 33 bits
+    // the branch-free kernel needs every valid Rice codeword (zeros + terminator + sub-code) to fit 32 bits
     bool fast = true;
     const uint32_t widths[3] = {1, 2, 4};
     for (int k = 0; k < 3; ++k) {
       const uint32_t level = k == 0 ? 1u : (1u << dp.k[k]);
-      fast = fast && (dp.inv_len[k] / level + 1 + widths[k] <= 33);
+      fast = fast && (dp.inv_len[k] / level + 1 + widths[k] <= 32);
     }
     TimerScope ts(c, 1);
     if (fast)
-      hipLaunchKernelGGL(x3_decode_lanes_kernel<true>, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, c->stream, d_x3,
-                         x3_len, d_frame_offsets, F, g, d_wav_offsets, dp, d_wav, wav_cap, d_status,
+      hipLaunchKernelGGL(x3_decode_fast_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, c->stream, d_x3, x3_len,
+                         d_frame_offsets, F, g, d_wav_offsets, dp, d_wav, wav_cap, d_status,
                          (const X3FrameMeta*)c->dec_meta.p);
     else
-      hipLaunchKernelGGL(x3_decode_lanes_kernel<false>, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, c->stream, d_x3,
-                         x3_len, d_frame_offsets, F, g, d_wav_offsets, dp, d_wav, wav_cap, d_status,
+      hipLaunchKernelGGL((x3_decode_lanes_kernel<false, 64>), dim3((unsigned)((F + 63) / 64)), dim3(64), 0, c->stream,
+                         d_x3, x3_len, d_frame_offsets, F, g, d_wav_offsets, dp, d_wav, wav_cap, d_status,
                          (const X3FrameMeta*)c->dec_meta.p);
   }
   hipLaunchKernelGGL(x3_decode_summary_kernel, dim3(1), dim3(1024), 0, c->stream, (const int32_t*)d_status,
@@ -874,3 +874,11 @@ extern "C" int x3_dev_download(x3_ctx* c, void* dst, const void* d_src, uint64_t
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return X3_OK;
 }
+
+#ifdef X3_DBG_STAMPS
+extern "C" int x3_dbg_read(x3_ctx* c, unsigned long long* out, uint64_t n) {
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(x3_dbg), n * sizeof(unsigned long long)));
+  return X3_OK;
+}
+#endif

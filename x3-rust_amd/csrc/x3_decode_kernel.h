@@ -149,6 +149,13 @@ __device__ __forceinline__ uint32_t x3_wave_max_u32(uint32_t v) {
 
 // LDS traffic between lanes of ONE wave needs no s_barrier: a wave's DS instructions execute in
 // issue order.  This only stops the compiler from moving LDS accesses across the point.
+#ifdef X3_DBG_STAMPS
+__device__ unsigned long long x3_dbg[8 * 4096];
+#define X3_STAMP(k) do { unsigned long long t_ = clock64(); dbg_acc[k] += t_ - dbg_t; dbg_t = t_; } while (0)
+#else
+#define X3_STAMP(k) do { } while (0)
+#endif
+
 #define X3_WAVE_LDS_ORDER()                                   \
   do {                                                        \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
@@ -159,24 +166,34 @@ __device__ __forceinline__ uint32_t x3_wave_max_u32(uint32_t v) {
 // FAST: every valid Rice codeword (zero run + terminator + sub-code) is at most 33 bits, so one
 // window refill per sample suffices and a zero run of >= 32 bits is an error outright.  True for
 // the default parameters; the host picks the general instantiation otherwise.
-template <bool FAST>
+// LANES: frames decoded per wave (the first LANES lanes decode, all 64 lanes flush).  The decode
+// loop is one long dependent instruction chain per wave, so with few frames (config 3: 69 120)
+// it is better to spread them over MORE waves than to fill every lane: 16 frames per wave gives
+// ~4 resident waves per SIMD whose chains interleave ("Decode occupancy").
+template <bool FAST, int LANES>
 __global__ void __launch_bounds__(64)
 x3_decode_lanes_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uint64_t* __restrict__ frame_off,
                        uint64_t n_frames, X3Geom g, const uint64_t* __restrict__ wav_off, X3DevParams p,
                        int16_t* __restrict__ wav, uint64_t wav_cap, int32_t* __restrict__ status,
                        const X3FrameMeta* __restrict__ meta) {
-  __shared__ __attribute__((aligned(16))) uint32_t ring[64 * X3_DEC_RING_STRIDE];
-  __shared__ __attribute__((aligned(16))) uint32_t outs[64 * X3_DEC_OUT_STRIDE];
-  __shared__ unsigned long long s_wo[64];  // sample offset of each lane's frame in wav
-  __shared__ uint32_t s_ns[64];            // samples of each lane's frame (0 = not flushed cooperatively)
+  __shared__ __attribute__((aligned(16))) uint32_t ring[LANES * X3_DEC_RING_STRIDE];
+  __shared__ __attribute__((aligned(16))) uint32_t outs[LANES * X3_DEC_OUT_STRIDE];
+  __shared__ unsigned long long s_wo[LANES];  // sample offset of each lane's frame in wav
+  __shared__ uint32_t s_ns[LANES];            // samples of each lane's frame (0 = not flushed cooperatively)
 
   const uint32_t lane = threadIdx.x;
-  const uint64_t f = (uint64_t)blockIdx.x * 64 + lane;
-  uint32_t* const row = ring + lane * X3_DEC_RING_STRIDE;
-  uint32_t* const orow = outs + lane * X3_DEC_OUT_STRIDE;
+  const bool decoder = lane < (uint32_t)LANES;
+  const uint32_t dl = decoder ? lane : 0u;  // row used by this lane (idle lanes alias row 0, never write)
+  const uint64_t f = (uint64_t)blockIdx.x * LANES + lane;
+#ifdef X3_DBG_STAMPS
+  unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long dbg_t = clock64();
+#endif
+  uint32_t* const row = ring + dl * X3_DEC_RING_STRIDE;
+  uint32_t* const orow = outs + dl * X3_DEC_OUT_STRIDE;
 
   // ---- per-lane frame setup
-  bool active = f < n_frames;
+  bool active = decoder && f < n_frames;
   int32_t st = X3D_OK;
   uint32_t samples = 0, plen = 2;
   uint64_t p0 = 0, wo = 0;
@@ -208,8 +225,10 @@ x3_decode_lanes_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   int16_t* __restrict__ const o = wav + wo;
   // frames whose output is 16-byte aligned are flushed cooperatively, the others store directly
   const bool coop = active && ((reinterpret_cast<uintptr_t>(o) & 15u) == 0);
-  s_wo[lane] = wo;
-  s_ns[lane] = coop ? samples : 0u;
+  if (decoder) {
+    s_wo[lane] = wo;
+    s_ns[lane] = coop ? samples : 0u;
+  }
 
   // ---- input ring.  Offsets are "virtual": v = byte offset from x3b, the 16-byte-aligned address
   // at or below x3, so that 16-byte chunks are aligned in memory whatever x3's own alignment is.
@@ -239,7 +258,7 @@ x3_decode_lanes_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       }
       c = make_uint4(w[0], w[1], w[2], w[3]);
     }
-    *reinterpret_cast<uint4*>(row + (wr_abs & (X3_DEC_RING_DW - 1u))) = c;
+    if (decoder) *reinterpret_cast<uint4*>(row + (wr_abs & (X3_DEC_RING_DW - 1u))) = c;
     wr_abs += 4;
   };
 
@@ -291,9 +310,11 @@ x3_decode_lanes_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     if (fit > 2) park(ld2, v_req + 32);
     v_next += 16u * (fit > 3u ? 3u : fit);
     v_req = v_next;
+#ifndef X3_DBG_NOLOAD
     ld0 = request(v_req);
     ld1 = request(v_req + 16);
     ld2 = request(v_req + 32);
+#endif
   };
 
   // ---- output staging
@@ -302,20 +323,25 @@ x3_decode_lanes_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   auto flush = [&](uint32_t upto) {  // stage holds samples [wbase, upto) of every lane's frame
     X3_WAVE_LDS_ORDER();
     const uint32_t pieces = (upto - wbase + 7u) >> 3;  // 16-byte pieces per frame in this window
-    const uint32_t total = pieces * 64u;
+    const uint32_t total = pieces * (uint32_t)LANES;
     for (uint32_t t = lane; t < total; t += 64u) {
       const uint32_t r = t / pieces, q = t - r * pieces;
       const uint32_t ns = s_ns[r];
       if (wbase + 8u * q + 8u <= ns) {
         const uint2* src = reinterpret_cast<const uint2*>(outs + r * X3_DEC_OUT_STRIDE + 4u * q);
         const uint2 lo = src[0], hi = src[1];
+#ifndef X3_DBG_NOSTORE
         *reinterpret_cast<uint4*>(wav + s_wo[r] + wbase + 8u * q) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#else
+        if (lo.x == 0x12345678u && hi.y == 0x9abcdef0u) wav[0] = 1;
+#endif
       }
     }
     X3_WAVE_LDS_ORDER();
   };
 
   X3_WAVE_LDS_ORDER();  // s_wo / s_ns visible to the wave
+  X3_STAMP(0);
   if (active) {
     carry = last;  // sample 0
     if (!coop || samples == 1u) o[0] = (int16_t)last;
@@ -328,7 +354,9 @@ x3_decode_lanes_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     uint32_t cnt = remaining < bl ? remaining : bl;
     const uint32_t maxcnt = __any(cnt == bl) ? bl : x3_wave_max_u32(cnt);
     if (maxcnt == 0) break;
+    X3_STAMP(1);
     service();
+    X3_STAMP(2);
     // block header (decoder.rs:138-144).  Both block families are decoded by one branch-free
     // body: [z = leading zeros, Rice only] then a fixed-width field of `width` bits.
     //   Rice: r1 counts zeros and skips the 1 (decoder.rs:156-163) == width 1, level 1;
@@ -362,6 +390,7 @@ x3_decode_lanes_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       }
     }
     const uint32_t rsh = 32u - width;
+    X3_STAMP(3);
     for (uint32_t j = 0; j < maxcnt; ++j) {
       if (j && (j % X3_DEC_CHUNK) == 0) service();
       if (j < cnt) {
@@ -413,10 +442,13 @@ x3_decode_lanes_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       }
       ++i;
       if (i - wbase == X3_DEC_WIN) {
+        X3_STAMP(4);
         flush(i);
         wbase = i;
+        X3_STAMP(5);
       }
     }
+    X3_STAMP(4);
     if (remaining) {
       remaining -= cnt;
       if (remaining == 0 && coop && st == X3D_OK) {
@@ -431,6 +463,308 @@ x3_decode_lanes_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     }
   }
   if (i > wbase) flush(i);  // the partial last window
+  if (decoder && f < n_frames) status[f] = st;
+#ifdef X3_DBG_STAMPS
+  X3_STAMP(6);
+  if (lane == 0 && blockIdx.x < 4096)
+    for (int k = 0; k < 8; ++k) x3_dbg[blockIdx.x * 8 + k] = dbg_acc[k];
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// x3_decode_fast_kernel -- the same lane-per-frame decoder with a branch-free sample body for
+// parameter sets where every valid codeword is at most 32 bits (the default parameters:
+// Rice0 <= 16, Rice1 <= 15, Rice3 <= 12 bits, BFP/literal <= 16).
+//
+// A wave64 VALU instruction costs a 4-cycle SIMD slot whatever the exec mask holds, and with only
+// 69 120 frames (config 3) there is about one wave per SIMD, so the decoder is bound by the
+// LENGTH of its per-sample instruction chain.  Hence:
+//   * bit window = three big-endian words w0,w1,w2 + s = unconsumed bits of w0 in [0,31];
+//     peek32 = v_alignbit_b32(w0, w1, s); consuming n <= 32 bits is s -= n and, if negative,
+//     one word shift (3 v_cndmask) -- no 64-bit shifts, no refill branch;
+//   * the ring word behind w2 is re-read from LDS every sample (ds_read_b32, branch-free) and
+//     used one sample later, so its latency hides behind the value arithmetic;
+//   * Rice and BFP/literal blocks share one body: z = clz(peek) & zmask, field = next `width`
+//     bits; both deltas are computed and selected with v_bfi;
+//   * ring words are byte-swapped once when parked, not when consumed.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uint64_t* __restrict__ frame_off,
+                      uint64_t n_frames, X3Geom g, const uint64_t* __restrict__ wav_off, X3DevParams p,
+                      int16_t* __restrict__ wav, uint64_t wav_cap, int32_t* __restrict__ status,
+                      const X3FrameMeta* __restrict__ meta) {
+  __shared__ __attribute__((aligned(16))) uint32_t ring[64 * X3_DEC_RING_STRIDE];
+  __shared__ __attribute__((aligned(16))) uint32_t outs[64 * X3_DEC_OUT_STRIDE];
+  __shared__ unsigned long long s_wo[64];
+  __shared__ uint32_t s_ns[64];
+
+  const uint32_t lane = threadIdx.x;
+  const uint64_t f = (uint64_t)blockIdx.x * 64 + lane;
+  uint32_t* const row = ring + lane * X3_DEC_RING_STRIDE;
+  uint32_t* const orow = outs + lane * X3_DEC_OUT_STRIDE;
+
+  // ---- per-lane frame setup (same checks as the general kernel)
+  bool active = f < n_frames;
+  int32_t st = X3D_OK;
+  uint32_t samples = 0, plen = 2;
+  uint64_t p0 = 0, wo = 0;
+  if (active) {
+    st = status[f];
+    samples = meta[f].samples;
+    plen = meta[f].payload_len;
+    p0 = frame_off[f] + 20;
+    if (st != X3D_OK) {
+      active = false;
+    } else if (samples == 0 || plen < 2) {
+      st = X3D_BAD_ARG;
+      active = false;
+    } else {
+      if (wav_off) {
+        wo = wav_off[f];
+      } else {
+        const uint64_t clip = f / g.fpc;
+        const uint64_t idx = f - clip * g.fpc;
+        wo = clip * g.clip_stride + idx * (uint64_t)p.spf;
+      }
+      if (wo + samples > wav_cap) {
+        st = X3D_BAD_ARG;
+        active = false;
+      }
+    }
+  }
+  if (!active) { p0 = 0; plen = 2; wo = 0; }
+  int16_t* __restrict__ const o = wav + wo;
+  const bool coop = active && ((reinterpret_cast<uintptr_t>(o) & 15u) == 0);
+  s_wo[lane] = wo;
+  s_ns[lane] = coop ? samples : 0u;
+
+  // ---- input ring (virtual offsets as in the general kernel); words are parked BIG-ENDIAN
+  const uint32_t adj = (uint32_t)(reinterpret_cast<uintptr_t>(x3) & 15u);
+  const uint8_t* __restrict__ const x3b = x3 - adj;
+  const uint64_t v_end = adj + p0 + plen;
+  const uint64_t v_bits = adj + p0 + 2;
+  const uint64_t v_last = (v_end - 1) & ~15ull;
+  uint64_t v_next = v_bits & ~15ull;
+  uint32_t wr_abs = 0;
+
+  auto request = [&](uint64_t v) -> uint4 {
+    const uint64_t a = v < v_last ? v : v_last;
+    return *reinterpret_cast<const uint4*>(x3b + a);
+  };
+  auto park = [&](uint4 c, uint64_t v) {
+    const int64_t left = (int64_t)(v_end - v);
+    uint32_t w[4] = {c.x, c.y, c.z, c.w};
+    if (left < 16) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int64_t r = left - 4 * d;
+        w[d] = r >= 4 ? w[d] : (r <= 0 ? 0u : (w[d] & ((1u << (8u * (uint32_t)r)) - 1u)));
+      }
+    }
+    *reinterpret_cast<uint4*>(row + (wr_abs & (X3_DEC_RING_DW - 1u))) =
+        make_uint4(x3_bswap32(w[0]), x3_bswap32(w[1]), x3_bswap32(w[2]), x3_bswap32(w[3]));
+    wr_abs += 4;
+  };
+
+  {
+    uint4 c[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c[k] = request(v_next + 16u * k);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) park(c[k], v_next + 16u * k);
+    v_next += 128;
+  }
+  // window: w0 holds `s` unconsumed bits (its low s bits), then w1, w2; widx = ring index of w0
+  const uint32_t skip = (uint32_t)(v_bits & 15u);
+  const uint32_t a0 = skip & 3u;
+  uint32_t widx = (skip >> 2) - (a0 == 0 ? 1u : 0u);   // a0 == 0: start with a fully consumed w0
+  uint32_t s = (32u - 8u * a0) & 31u;
+  uint32_t w0 = row[widx & 31u], w1 = row[(widx + 1) & 31u], w2 = row[(widx + 2) & 31u];
+  uint32_t w3 = row[(widx + 3) & 31u];                 // look-ahead word (re-read every sample)
+  int32_t last = 0;
+  uint32_t remaining = 0;
+  if (active) {
+    last = (int16_t)(uint16_t)((uint32_t)x3[p0] << 8 | x3[p0 + 1]);
+    remaining = samples - 1u;
+  }
+  uint4 ld0 = request(v_next), ld1 = request(v_next + 16), ld2 = request(v_next + 32);
+  uint64_t v_req = v_next;
+
+  // consume n (<= 32) bits
+  auto consume = [&](uint32_t n) {
+    const int32_t s2 = (int32_t)s - (int32_t)n;
+    const bool sh = s2 < 0;
+    s = (uint32_t)s2 & 31u;
+    w0 = sh ? w1 : w0;
+    w1 = sh ? w2 : w1;
+    w2 = sh ? w3 : w2;
+    widx += sh ? 1u : 0u;
+    w3 = row[(widx + 3u) & 31u];
+  };
+  auto service = [&]() {
+    const uint32_t used = wr_abs - widx;                 // dwords from w0 on that the ring still needs
+    const uint32_t fit = used >= X3_DEC_RING_DW ? 0u : (X3_DEC_RING_DW - used) >> 2;  // (widx may be -1)
+    if (fit > 0) park(ld0, v_req);
+    if (fit > 1) park(ld1, v_req + 16);
+    if (fit > 2) park(ld2, v_req + 32);
+    v_next += 16u * (fit > 3u ? 3u : fit);
+    v_req = v_next;
+    ld0 = request(v_req);
+    ld1 = request(v_req + 16);
+    ld2 = request(v_req + 32);
+  };
+
+  uint32_t wbase = 0;
+  int32_t carry = 0;
+  auto flush = [&](uint32_t upto) {
+    X3_WAVE_LDS_ORDER();
+    const uint32_t pieces = (upto - wbase + 7u) >> 3;
+    if (pieces == X3_DEC_WIN / 8u) {
+      uint32_t r = lane / 20u, q = lane - r * 20u;   // 64 = 3*20 + 4
+#pragma unroll 4
+      for (uint32_t it = 0; it < 20u; ++it) {
+        const uint32_t ns = s_ns[r];
+        if (wbase + 8u * q + 8u <= ns) {
+          const uint2* src = reinterpret_cast<const uint2*>(outs + r * X3_DEC_OUT_STRIDE + 4u * q);
+          const uint2 lo = src[0], hi = src[1];
+          *reinterpret_cast<uint4*>(wav + s_wo[r] + wbase + 8u * q) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+        q += 4u;
+        r += 3u;
+        if (q >= 20u) { q -= 20u; r += 1u; }
+      }
+    } else {
+      const uint32_t total = pieces * 64u;
+      for (uint32_t t = lane; t < total; t += 64u) {
+        const uint32_t r = t / pieces, q = t - r * pieces;
+        const uint32_t ns = s_ns[r];
+        if (wbase + 8u * q + 8u <= ns) {
+          const uint2* src = reinterpret_cast<const uint2*>(outs + r * X3_DEC_OUT_STRIDE + 4u * q);
+          const uint2 lo = src[0], hi = src[1];
+          *reinterpret_cast<uint4*>(wav + s_wo[r] + wbase + 8u * q) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+      }
+    }
+    X3_WAVE_LDS_ORDER();
+  };
+
+  X3_WAVE_LDS_ORDER();
+  if (active) {
+    carry = last;
+    if (!coop || samples == 1u) o[0] = (int16_t)last;
+  }
+
+  const uint32_t bl = p.block_len;
+  uint32_t i = 1;  // index of the sample being produced; wave-uniform (kept in an SGPR)
+  for (;;) {
+    uint32_t cnt = remaining < bl ? remaining : bl;
+    uint32_t maxcnt = bl;
+    if (!__any(cnt == bl)) {
+      maxcnt = x3_wave_max_u32(cnt);
+      if (maxcnt == 0) break;
+    }
+    maxcnt = __builtin_amdgcn_readfirstlane(maxcnt);
+    service();
+    // block header: 2 bits ftype; ftype 0 -> 4 more bits E-1 (decoder.rs:138-144, 209-216)
+    uint32_t zmask = 0, width = 1, bound = 0xFFFFFFFFu, level = 0, lit = 0, neg_thresh = 0xFFFFFFFFu, neg2 = 0;
+    {
+      const uint32_t hdr = __builtin_amdgcn_alignbit(w0, w1, s) >> 26;  // 6 header bits
+      const uint32_t ftype = hdr >> 4;
+      const uint32_t E = (hdr & 15u) + 1u;
+      const bool bfp = ftype == 0;
+      if (cnt) {
+        consume(bfp ? 6u : 2u);
+        if (bfp) {
+          width = E;
+          lit = E == 16u ? 1u : 0u;
+          neg_thresh = 1u << (E - 1u);
+          neg2 = lit ? 0u : (neg_thresh << 1);
+          if (E <= 5u) {
+            st = X3D_FRAME_DECODE_INVALID_BPF;
+            cnt = 0;
+            remaining = 0;
+          }
+        } else {
+          zmask = 0xFFFFFFFFu;
+          width = ftype == 1u ? 1u : (ftype == 2u ? 2u : 4u);
+          level = ftype == 1u ? 1u : (1u << (ftype == 2u ? p.k[1] : p.k[2]));
+          bound = ftype == 1u ? p.inv_len[0] : (ftype == 2u ? p.inv_len[1] : p.inv_len[2]);
+        }
+      }
+    }
+    const uint32_t rsh = 32u - width;
+    const uint32_t litmask = lit ? 0xFFFFFFFFu : 0u;
+    const uint32_t nlevel = 0u - level;
+    uint32_t errflag = 0;
+
+    // one sample, branch-free.  A zero run of 32 (t == 0) gives ii >= 31*level, beyond every bound
+    // the fast path admits, so it needs no test of its own.
+    auto sample = [&](uint32_t ii_idx) {
+      const uint32_t t = __builtin_amdgcn_alignbit(w0, w1, s);        // next 32 bits
+      const uint32_t z = (uint32_t)__clz(t) & zmask;                   // __clz(0) = 32
+      const uint32_t v = (t << (z & 31u)) >> rsh;                      // the field behind the zero run
+      const uint32_t n = z + width;
+      consume(n > 32u ? 32u : n);
+      // Rice: i = r + level*(n-1) (decoder.rs:186); inverse table = zigzag (x3.rs:200-204)
+      const uint32_t ii = level * z + (v + nlevel);
+      const uint32_t d_rice = (ii >> 1) ^ (0u - (ii & 1u));
+      // BFP: unsigned_to_i16 (decoder.rs:198-207)
+      const uint32_t d_bfp = v - (v > neg_thresh ? neg2 : 0u);
+      const uint32_t d = (d_rice & zmask) | (d_bfp & ~zmask);
+      const uint32_t nl = (((uint32_t)last + d) & ~litmask) | (v & litmask);  // literal: field = sample
+      errflag |= (zmask && ii >= bound) ? 1u : 0u;
+      last = (int16_t)(uint16_t)nl;
+      if (coop) {
+        if (ii_idx & 1u) orow[(ii_idx - wbase) >> 1] = ((uint32_t)carry & 0xFFFFu) | ((uint32_t)last << 16);
+        else carry = last;
+      } else {
+        o[ii_idx] = (int16_t)last;
+      }
+    };
+
+    uint32_t j = 0;
+    while (j < maxcnt) {  // uniform: segments end at flush points and at ring services
+      uint32_t seg_end = j + (X3_DEC_WIN - (i - wbase));
+      const uint32_t next_service = (j / X3_DEC_CHUNK + 1u) * X3_DEC_CHUNK;
+      seg_end = seg_end < maxcnt ? seg_end : maxcnt;
+      seg_end = seg_end < next_service ? seg_end : next_service;
+      seg_end = __builtin_amdgcn_readfirstlane(seg_end);
+      if (cnt >= seg_end) {
+        // every sample of the segment belongs to this lane's block
+        for (uint32_t jj = j; jj < seg_end; ++jj) {
+          const uint32_t before = errflag;
+          sample(i + (jj - j));
+          (void)before;
+        }
+      } else if (cnt > j) {
+        // tail: the block ends inside the segment
+        for (uint32_t jj = j; jj < cnt; ++jj) sample(i + (jj - j));
+      }
+      i += seg_end - j;
+      j = seg_end;
+      if (i - wbase == X3_DEC_WIN) {
+        flush(i);
+        wbase = i;
+      }
+      if (j < maxcnt && (j % X3_DEC_CHUNK) == 0) service();
+    }
+    if (errflag) {  // OutOfBoundsInverse (decoder.rs:160,187): the frame stops here
+      st = X3D_OUT_OF_BOUNDS_INVERSE;
+      cnt = 0;
+      remaining = 0;
+    }
+    if (remaining) {
+      remaining -= cnt;
+      if (remaining == 0 && coop && st == X3D_OK) {
+        if (samples & 1u) orow[(samples - 1u - wbase) >> 1] = (uint32_t)carry & 0xFFFFu;
+        const uint32_t done = samples & ~7u;
+        const uint32_t from = done > wbase ? done : wbase;
+        const uint16_t* h = reinterpret_cast<const uint16_t*>(orow);
+        for (uint32_t sx = from; sx < samples; ++sx) o[sx] = (int16_t)h[sx - wbase];
+      }
+    }
+  }
+  if (i > wbase) flush(i);
   if (f < n_frames) status[f] = st;
 }
 
