@@ -127,10 +127,10 @@ def main():
     assert rc == 0, (rc, ctx.last_error())
     rc, first_bad, st, before = ctx.decode_result()
     assert (rc, first_bad, st, before) == (0, F, 0, n), (rc, first_bad, st, before)
-    enc_ms, enc_cnt = ctx.kernel_time(0)
-    dec_ms, dec_cnt = ctx.kernel_time(1)
-    size_ms, size_cnt = ctx.kernel_time(2)
-    scan_ms, scan_cnt = ctx.kernel_time(3)
+    ktimes = {}
+    for name, which in (("encode", 0), ("decode", 1), ("frame_sizes", 2), ("scan", 3), ("frame_check", 4)):
+        ms, cnt = ctx.kernel_time(which)
+        ktimes[name] = ms / max(cnt, 1)
     ctx.enable_kernel_timing(False)
 
     # ---- bit-exactness of the timed output
@@ -190,9 +190,25 @@ def main():
     if rank == 0:
         total_samples = n * world
         value = total_samples * args.steps / elapsed / 1e6
-        enc_avg_s = enc_ms / max(enc_cnt, 1) / 1e3
-        alg_bytes = 2 * n + pos  # per launch: 2 B/sample read + stream bytes written
-        achieved = alg_bytes / enc_avg_s / 1e9
+        # algorithmic HBM bytes per launch (DESIGN.md "Kernels"): 2 B per sample + P stream bytes for
+        # the encoder and the decoder; the size pass re-reads the samples; the check pass reads the stream
+        alg = {"encode": 2 * n + pos, "decode": 2 * n + pos, "frame_sizes": 2 * n, "frame_check": pos}
+        kname = {"encode": "x3_encode_frames_kernel<false>", "decode": "x3_decode_fast_kernel",
+                 "frame_sizes": "x3_encode_frames_kernel<true>", "frame_check": "x3_frame_check_kernel"}
+        dominant = max(alg, key=lambda k: ktimes[k])
+        traffic = {}
+        try:  # HBM bytes per launch from rocprofv3 PMC passes (profiles/, see DESIGN.md "Measurement")
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        except Exception:
+            pass
+
+        def roof(k):
+            t = ktimes[k] / 1e3
+            ach = alg[k] / t / 1e9
+            return {"bound": "hbm", "kernel": kname[k], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": traffic.get(kname[k], {}).get("hbm_bytes_per_launch"),
+                    "algorithmic_bytes": int(alg[k]), "avg_launch_ms": round(ktimes[k], 4)}
         res = {
             "metric": "Msamples/s encode+decode (bit-exact), 1h 192kHz mono; % HBM-read roofline",
             "value": round(value, 2),
@@ -210,14 +226,10 @@ def main():
                        "samples_per_gpu": n, "frames_per_gpu": int(F), "stream_bytes_per_gpu": int(pos),
                        "bytes_per_sample": round(pos / n, 4), "block_len": 20, "blocks_per_frame": 500,
                        "sharding": "frames sharded across ranks; all-gather of sub-stream lengths per step"},
-            "roofline": {"bound": "hbm", "kernel": "x3_encode_frames_kernel<false>", "achieved": round(achieved, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None, "algorithmic_bytes": int(alg_bytes),
-                         "avg_launch_ms": round(enc_avg_s * 1e3, 4),
-                         "read_frac": round(2 * n / enc_avg_s / 1e9 / HBM_PEAK_GBS, 4)},
-            "kernels_ms": {"encode": round(enc_ms / max(enc_cnt, 1), 4), "decode": round(dec_ms / max(dec_cnt, 1), 4),
-                           "frame_sizes": round(size_ms / max(size_cnt, 1), 4),
-                           "scan": round(scan_ms / max(scan_cnt, 1), 4)},
+            "roofline": roof(dominant),
+            "roofline_all": {k: roof(k) for k in alg},
+            "encode_read_frac": round(2 * n / (ktimes["encode"] / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
+            "kernels_ms": {k: round(v, 4) for k, v in ktimes.items()},
             "cpu_baseline": cpu,
         }
         if gather is not None:

@@ -25,6 +25,8 @@
 // end of the next 32-bit word (bitreader.rs:129-139), which only differs for runs >= 32 bits -- an
 // OutOfBoundsInverse error either way with the default parameters ("Known divergences").
 #pragma once
+#include <type_traits>
+
 #include "x3_device.h"
 
 #define X3D_STREAM_ENDS_IN_FRAME (-1)  // quiet stop of the walk (decodefile.rs:107-116)
@@ -653,6 +655,8 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
     carry = last;
     if (!coop || samples == 1u) o[0] = (int16_t)last;
   }
+  // true when every decoding lane stages through LDS (the normal case: 16-byte aligned frames)
+  const bool all_coop = !__any(active && !coop);
 
   const uint32_t bl = p.block_len;
   uint32_t i = 1;  // index of the sample being produced; wave-uniform (kept in an SGPR)
@@ -695,30 +699,38 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
     const uint32_t rsh = 32u - width;
     const uint32_t litmask = lit ? 0xFFFFFFFFu : 0u;
     const uint32_t nlevel = 0u - level;
-    uint32_t errflag = 0;
+    const uint32_t lsh = 31u - (uint32_t)__clz(level | 1u);  // level is a power of two (or 0 for BFP)
+    uint32_t maxii = 0;  // largest inverse-table index seen in this block (Rice lanes only)
 
     // one sample, branch-free.  A zero run of 32 (t == 0) gives ii >= 31*level, beyond every bound
-    // the fast path admits, so it needs no test of its own.
-    auto sample = [&](uint32_t ii_idx) {
+    // the fast path admits, so it needs no test of its own; an over-long codeword (z + width > 32)
+    // only happens together with such an error, so `consume` need not clamp it.
+    auto sample = [&](uint32_t idx, auto direct_tag) {
+      constexpr bool DIRECT = decltype(direct_tag)::value;
       const uint32_t t = __builtin_amdgcn_alignbit(w0, w1, s);        // next 32 bits
       const uint32_t z = (uint32_t)__clz(t) & zmask;                   // __clz(0) = 32
       const uint32_t v = (t << (z & 31u)) >> rsh;                      // the field behind the zero run
-      const uint32_t n = z + width;
-      consume(n > 32u ? 32u : n);
+      consume(z + width);
       // Rice: i = r + level*(n-1) (decoder.rs:186); inverse table = zigzag (x3.rs:200-204)
-      const uint32_t ii = level * z + (v + nlevel);
+      const uint32_t ii = (z << lsh) + (v + nlevel);
       const uint32_t d_rice = (ii >> 1) ^ (0u - (ii & 1u));
       // BFP: unsigned_to_i16 (decoder.rs:198-207)
       const uint32_t d_bfp = v - (v > neg_thresh ? neg2 : 0u);
       const uint32_t d = (d_rice & zmask) | (d_bfp & ~zmask);
       const uint32_t nl = (((uint32_t)last + d) & ~litmask) | (v & litmask);  // literal: field = sample
-      errflag |= (zmask && ii >= bound) ? 1u : 0u;
+      const uint32_t iim = ii & zmask;
+      maxii = iim > maxii ? iim : maxii;
       last = (int16_t)(uint16_t)nl;
-      if (coop) {
-        if (ii_idx & 1u) orow[(ii_idx - wbase) >> 1] = ((uint32_t)carry & 0xFFFFu) | ((uint32_t)last << 16);
-        else carry = last;
+      if (DIRECT) {
+        if (coop) {
+          if (idx & 1u) orow[(idx - wbase) >> 1] = ((uint32_t)carry & 0xFFFFu) | ((uint32_t)last << 16);
+          else carry = last;
+        } else {
+          o[idx] = (int16_t)last;
+        }
       } else {
-        o[ii_idx] = (int16_t)last;
+        if (idx & 1u) orow[(idx - wbase) >> 1] = ((uint32_t)carry & 0xFFFFu) | ((uint32_t)last << 16);
+        else carry = last;
       }
     };
 
@@ -729,18 +741,19 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
       seg_end = seg_end < maxcnt ? seg_end : maxcnt;
       seg_end = seg_end < next_service ? seg_end : next_service;
       seg_end = __builtin_amdgcn_readfirstlane(seg_end);
+      const uint32_t i0 = __builtin_amdgcn_readfirstlane(i);
       if (cnt >= seg_end) {
         // every sample of the segment belongs to this lane's block
-        for (uint32_t jj = j; jj < seg_end; ++jj) {
-          const uint32_t before = errflag;
-          sample(i + (jj - j));
-          (void)before;
+        if (all_coop) {
+          for (uint32_t jj = j; jj < seg_end; ++jj) sample(i0 + (jj - j), std::false_type{});
+        } else {
+          for (uint32_t jj = j; jj < seg_end; ++jj) sample(i0 + (jj - j), std::true_type{});
         }
       } else if (cnt > j) {
         // tail: the block ends inside the segment
-        for (uint32_t jj = j; jj < cnt; ++jj) sample(i + (jj - j));
+        for (uint32_t jj = j; jj < cnt; ++jj) sample(i + (jj - j), std::true_type{});
       }
-      i += seg_end - j;
+      i = i0 + (seg_end - j);
       j = seg_end;
       if (i - wbase == X3_DEC_WIN) {
         flush(i);
@@ -748,6 +761,7 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
       }
       if (j < maxcnt && (j % X3_DEC_CHUNK) == 0) service();
     }
+    const uint32_t errflag = maxii >= bound ? 1u : 0u;
     if (errflag) {  // OutOfBoundsInverse (decoder.rs:160,187): the frame stops here
       st = X3D_OUT_OF_BOUNDS_INVERSE;
       cnt = 0;
