@@ -52,6 +52,7 @@ def main():
     import numpy as np
     import torch
     import x3hip
+    from x3hip import shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -92,7 +93,7 @@ def main():
         assert rc == 0, (rc, ctx.last_error())
         if dist is not None:
             # the exchange step of the sharded path: sub-stream lengths -> global byte offsets
-            dist.all_gather_into_tensor(lens, off[F:F + 1])
+            shard.exchange_lengths(off[F:F + 1], out=lens)
         rc = ctx.decode_dev(out.data_ptr(), cap, off.data_ptr(), F, p, back.data_ptr(), n, n_per_clip=n)
         assert rc == 0, (rc, ctx.last_error())
 
@@ -146,26 +147,16 @@ def main():
     # ---- optional: reassembly gather of the sub-streams to rank 0 (timed on its own)
     gather = None
     if dist is not None and not args.no_gather:
-        lens_h = lens.cpu().tolist()
-        starts = [0]
-        for v in lens_h:
-            starts.append(starts[-1] + v)
-        whole = torch.empty(starts[-1] if rank == 0 else 1, dtype=torch.uint8, device=dev)
+        lens_h = lens.cpu()
         torch.cuda.synchronize(dev)
         barrier()
         g0 = time.perf_counter()
-        ops = []
-        if rank == 0:
-            whole[:lens_h[0]].copy_(out[:lens_h[0]])
-            for r in range(1, world):
-                ops.append(dist.P2POp(dist.irecv, whole[starts[r]:starts[r + 1]], r))
-        else:
-            ops.append(dist.P2POp(dist.isend, out[:lens_h[rank]], 0))
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+        whole = shard.gather_stream(out, lens_h, dst=0)
         torch.cuda.synchronize(dev)
         barrier()
         g1 = time.perf_counter()
+        starts = shard.global_offsets(lens_h)
+        del whole
         gather = {"ms": round((g1 - g0) * 1e3, 3), "bytes": int(starts[-1]),
                   "pattern": "grouped ncclSend/ncclRecv to rank 0 (one xGMI link per peer)"}
 

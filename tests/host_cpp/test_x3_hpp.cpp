@@ -1,0 +1,132 @@
+// Exercises x3-rust_amd/host/x3.hpp (the C++ mirror of the reference's Rust API) the way the
+// reference's own unit tests use the crate (src/encoder.rs:462-491, src/crc.rs:78-105), and against
+// the CPU oracle on synthetic signals.   usage: test_x3_hpp [--host-only]
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+#include <vector>
+
+#include "../../oracle/x3_oracle.h"
+#include "../../x3-rust_amd/host/x3.hpp"
+
+#define CHECK(c)                                                              \
+  do {                                                                        \
+    if (!(c)) {                                                               \
+      std::fprintf(stderr, "FAIL %s:%d: %s\n", __FILE__, __LINE__, #c);       \
+      std::exit(1);                                                           \
+    }                                                                         \
+  } while (0)
+
+static void host_only() {
+  // Parameters::new (x3.rs:98-122): only the first two thresholds are validated
+  x3::Parameters p;
+  const size_t codes[3] = {0, 1, 3};
+  const size_t ok[3] = {3, 8, 20}, bad0[3] = {7, 8, 20}, bad2[3] = {3, 8, 99};
+  CHECK(x3::Parameters::create(20, 500, codes, ok, &p) == x3::X3Error::Ok);
+  CHECK(x3::Parameters::create(20, 500, codes, bad0, &p) == x3::X3Error::InvalidEncodingThresh);
+  CHECK(x3::Parameters::create(20, 500, codes, bad2, &p) == x3::X3Error::Ok);
+  // crc.rs:78-98: the 16 header bytes -> 0xADDB, round trip through write/read_frame_header
+  uint8_t h[20];
+  x3::encoder::write_frame_header(0x2710, 1, 0x19d0, 0x6f61, h);
+  CHECK(h[0] == 0x78 && h[1] == 0x33 && h[2] == 1 && h[3] == 1 && h[16] == 0xad && h[17] == 0xdb);
+  x3::FrameHeader fh;
+  CHECK(x3::decoder::read_frame_header(h, 20, &fh) == x3::X3Error::Ok);
+  CHECK(fh.samples == 0x2710 && fh.payload_len == 0x19d0 && fh.payload_crc == 0x6f61 && fh.channels == 1);
+  h[5] ^= 1;
+  CHECK(x3::decoder::read_frame_header(h, 20, &fh) == x3::X3Error::FrameHeaderInvalidHeaderCRC);
+  CHECK(x3::decoder::read_frame_header(h, 19, &fh) == x3::X3Error::FrameDecodeUnexpectedEnd);
+  // SliceByteWriter (bytewriter.rs:27-100)
+  uint8_t buf[8] = {0};
+  x3::bytewriter::SliceByteWriter w(buf, sizeof buf);
+  const uint8_t abc[3] = {1, 2, 3};
+  CHECK(w.write_all(abc, 3) == x3::X3Error::Ok);
+  size_t padded = 0;
+  CHECK(w.align(2, &padded) == x3::X3Error::Ok && padded == 1);
+  uint64_t pos = 0;
+  w.stream_position(&pos);
+  CHECK(pos == 4);
+  CHECK(w.seek(x3::bytewriter::SeekFrom::Current, 5) == x3::X3Error::ByteWriterInsufficientMemory);
+  CHECK(w.write_all(buf, 5) == x3::X3Error::ByteWriterInsufficientMemory);
+  std::printf("host-only checks ok\n");
+}
+
+static std::vector<uint8_t> oracle_encode(const std::vector<int16_t>& wav) {
+  x3o_params p;
+  x3o_params_default(&p);
+  std::vector<uint8_t> out(wav.size() * 3 + 1024);
+  uint64_t pos = 0, stats[6];
+  CHECK(x3o_encode(wav.data(), wav.size(), 1, &p, out.data(), out.size(), 0, &pos, stats) == 0);
+  out.resize(pos);
+  return out;
+}
+
+int main(int argc, char** argv) {
+  host_only();
+  if (argc > 1 && !std::strcmp(argv[1], "--host-only")) return 0;
+
+  x3::Context ctx(0);
+  x3::Parameters params;
+
+  // test_encode_frame_zeros (encoder.rs:462-491)
+  {
+    std::vector<int16_t> wav(20, 0);
+    const uint8_t expected[26] = {'x', '3', 1, 1, 0, 20, 0, 6, 0, 0, 0, 0, 0, 0, 0, 0, 194, 242, 205, 128, 0, 0, 127, 255, 248, 0};
+    std::vector<uint8_t> out(0x0eff * 2);
+    x3::bytewriter::SliceByteWriter w(out.data(), out.size());
+    uint64_t stats[6] = {0};
+    CHECK(x3::encoder::encode_frame(ctx, wav.data(), wav.size(), w, params, stats) == x3::X3Error::Ok);
+    uint64_t pos = 0;
+    w.stream_position(&pos);
+    CHECK(pos == 26 && !std::memcmp(out.data(), expected, 26) && stats[0] == 19);
+  }
+  // README shape: Channel -> encode -> SliceByteWriter; then the iterator shape into a stream
+  std::vector<int16_t> wav(123457);
+  CHECK(x3_synth(2, 0x5833, 0, wav.size(), wav.data()) == 0);
+  const std::vector<uint8_t> ref = oracle_encode(wav);
+  {
+    x3::Channel ch(0, wav.data(), wav.size(), 44100, params);
+    const x3::Channel* chans[1] = {&ch};
+    std::vector<uint8_t> out(wav.size() * 2);
+    x3::bytewriter::SliceByteWriter w(out.data(), out.size());
+    CHECK(x3::encoder::encode(ctx, chans, 1, w) == x3::X3Error::Ok);
+    uint64_t pos = 0;
+    w.stream_position(&pos);
+    CHECK(pos == ref.size() && !std::memcmp(out.data(), ref.data(), ref.size()));
+    const x3::Channel* two[2] = {&ch, &ch};
+    CHECK(x3::encoder::encode(ctx, two, 2, w) == x3::X3Error::MoreThanOneChannel);
+    std::vector<uint8_t> small(1000);
+    x3::bytewriter::SliceByteWriter ws(small.data(), small.size());
+    CHECK(x3::encoder::encode(ctx, chans, 1, ws) == x3::X3Error::ByteWriterInsufficientMemory);
+  }
+  {
+    using It = std::vector<int16_t>::const_iterator;
+    x3::IterChannel<It> ch(0, wav.begin(), wav.end(), 44100, params);
+    x3::IterChannel<It>* chans[1] = {&ch};
+    std::ostringstream os;
+    const char lead = 'L';  // start the stream at an odd position: the encoder must pad to even
+    os.write(&lead, 1);
+    x3::bytewriter::StreamByteWriter w(os);
+    CHECK(x3::encoder::encode(ctx, chans, 1, w) == x3::X3Error::Ok);
+    const std::string s = os.str();
+    CHECK(s.size() == ref.size() + 2 && s[1] == 0 && !std::memcmp(s.data() + 2, ref.data(), ref.size()));
+  }
+  // decode: walk + decode the stream, then one frame through decode_frame
+  {
+    std::vector<int16_t> back(wav.size());
+    x3::decoder::StreamResult r;
+    CHECK(x3::decoder::decode_stream(ctx, ref.data(), ref.size(), params, back.data(), back.size(), &r) == x3::X3Error::Ok);
+    CHECK(r.samples == wav.size() && r.frames_ok == 13 && r.frame_errors == 0 && back == wav);
+    x3::FrameHeader fh;
+    CHECK(x3::decoder::read_frame_header(ref.data(), ref.size(), &fh) == x3::X3Error::Ok);
+    std::vector<int16_t> one(fh.samples);
+    size_t n = 0;
+    CHECK(x3::decoder::decode_frame(ctx, ref.data() + 20, fh.payload_len, one.data(), one.size(), params, fh.samples, &n) ==
+          x3::X3Error::Ok);
+    CHECK(n == fh.samples && !std::memcmp(one.data(), wav.data(), n * 2));
+    uint16_t c = 0;
+    CHECK(x3::crc::crc16(ctx, ref.data() + 20, fh.payload_len, &c) == x3::X3Error::Ok && c == fh.payload_crc);
+  }
+  std::printf("x3.hpp checks ok\n");
+  return 0;
+}

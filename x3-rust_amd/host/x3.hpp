@@ -1,0 +1,353 @@
+// x3.hpp -- host-side mirror of the psiphi75/x3-rust public API on top of the C ABI (include/x3hip.h).
+//
+// The reference is a Rust crate; this image has no Rust toolchain, so the host layer above the
+// C ABI is written in C++ with the reference's module / item names and argument meaning:
+//
+//   reference (Rust)                                   here (C++)
+//   ------------------------------------------------   ---------------------------------------------
+//   x3::Parameters::{default,new}     x3.rs:81-134      x3::Parameters{}, x3::Parameters::create()
+//   x3::Channel / x3::IterChannel     x3.rs:29-69       x3::Channel, x3::IterChannel<It>
+//   x3::FrameHeader / Frame / Archive x3.rs:136-184     x3::FrameHeader, x3::Frame, x3::Archive
+//   error::X3Error                    error.rs:27-62    x3::X3Error (same variant order)
+//   bytewriter::{ByteWriter,SliceByteWriter,StreamByteWriter}  bytewriter.rs:14-165   x3::bytewriter::*
+//   crc::{crc16,update_crc16}         crc.rs:44-58      x3::crc::*
+//   encoder::{encode,encode_frame,write_frame_header}  encoder.rs:51-214   x3::encoder::*
+//   decoder::{read_frame_header,decode_frame}          decoder.rs:36-118   x3::decoder::*
+//   X3aReader::decode_next_frame loop decodefile.rs:105-136,200-209        x3::decoder::decode_stream
+//
+// Every bulk call goes to libx3hip.so (HIP kernels on the MI355X); nothing here computes on the CPU
+// beyond argument marshalling.  BitPacker / BitReader have no host counterpart: on the GPU they are
+// per-block LDS scratch + a wavefront scan (encode) and a per-lane register bit window (decode).
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <iterator>
+#include <stdexcept>
+#include <vector>
+
+#include "../../include/x3hip.h"
+
+namespace x3 {
+
+// error.rs:27-62 (Ok added as 0; Hip / BadArg appended for the C ABI)
+enum class X3Error : int {
+  Ok = 0, Io, Hound, BitPack, InvalidEncodingThresh, OutOfBoundsInverse, MoreThanOneChannel,
+  ArchiveHeaderXMLInvalid, ArchiveHeaderXMLRiceCode, ArchiveHeaderXMLInvalidKey, FrameLength,
+  FrameHeaderInvalidKey, FrameHeaderInvalidPayloadLen, FrameHeaderInvalidHeaderCRC, FrameHeaderInvalidPayloadCRC,
+  FrameDecodeInvalidBlockLength, FrameDecodeInvalidIndex, FrameDecodeInvalidNTOGO, FrameDecodeInvalidFType,
+  FrameDecodeInvalidRiceCode, FrameDecodeInvalidBPF, FrameDecodeUnexpectedEnd, ByteWriterInsufficientMemory,
+  Hip, BadArg
+};
+inline const char* to_string(X3Error e) { return x3_strerror(static_cast<int>(e)); }
+
+// One GPU + stream + scratch (x3_ctx).  Creation throws when no HIP device is usable: there is no CPU path.
+class Context {
+ public:
+  explicit Context(int device = 0) {
+    int rc = x3_ctx_create(device, &ctx_);
+    if (rc) throw std::runtime_error("x3::Context: no usable HIP device (libx3hip has no CPU fallback)");
+  }
+  Context(const Context&) = delete;
+  Context& operator=(const Context&) = delete;
+  ~Context() { x3_ctx_destroy(ctx_); }
+  x3_ctx* raw() const { return ctx_; }
+
+ private:
+  x3_ctx* ctx_ = nullptr;
+};
+
+// x3.rs:81-134
+struct Parameters {
+  static constexpr size_t MAX_BLOCK_LENGTH = 60;
+  static constexpr size_t WAV_BIT_SIZE = 16;
+  static constexpr size_t DEFAULT_BLOCK_LENGTH = 20;
+  static constexpr size_t DEFAULT_BLOCKS_PER_FRAME = 500;
+  size_t block_len = DEFAULT_BLOCK_LENGTH;
+  size_t blocks_per_frame = DEFAULT_BLOCKS_PER_FRAME;
+  size_t codes[3] = {0, 1, 3};
+  size_t thresholds[3] = {3, 8, 20};
+
+  // Parameters::new (x3.rs:98-122)
+  static X3Error create(size_t block_len, size_t blocks_per_frame, const size_t (&codes)[3],
+                        const size_t (&thresholds)[3], Parameters* out) {
+    Parameters p;
+    p.block_len = block_len;
+    p.blocks_per_frame = blocks_per_frame;
+    for (int k = 0; k < 3; ++k) { p.codes[k] = codes[k]; p.thresholds[k] = thresholds[k]; }
+    x3_params c = p.c_params();
+    int rc = x3_params_validate(&c);
+    if (rc) return static_cast<X3Error>(rc);
+    *out = p;
+    return X3Error::Ok;
+  }
+  x3_params c_params() const {
+    x3_params c;
+    c.block_len = (uint32_t)block_len;
+    c.blocks_per_frame = (uint32_t)blocks_per_frame;
+    for (int k = 0; k < 3; ++k) { c.codes[k] = (uint32_t)codes[k]; c.thresholds[k] = (uint32_t)thresholds[k]; }
+    return c;
+  }
+};
+
+// x3.rs:29-45: slice-based channel
+struct Channel {
+  uint16_t id;
+  const int16_t* wav;
+  size_t len;
+  uint32_t sample_rate;
+  Parameters params;
+  Channel(uint16_t id_, const int16_t* wav_, size_t len_, uint32_t rate, Parameters p)
+      : id(id_), wav(wav_), len(len_), sample_rate(rate), params(p) {}
+};
+
+// x3.rs:47-69: iterator-based channel (what encoder::encode takes at this commit)
+template <class It>
+struct IterChannel {
+  uint16_t id;
+  It wav, wav_end;
+  uint32_t sample_rate;
+  Parameters params;
+  IterChannel(uint16_t id_, It b, It e, uint32_t rate, Parameters p)
+      : id(id_), wav(b), wav_end(e), sample_rate(rate), params(p) {}
+};
+
+// x3.rs:70-79
+struct X3aSpec {
+  uint32_t sample_rate;
+  Parameters params;
+  uint8_t channels;
+};
+
+struct Archive {  // x3.rs:136-141
+  static constexpr const char* ID = "X3ARCHIV";
+  static constexpr size_t ID_LEN = 8;
+};
+struct Frame {  // x3.rs:143-146
+  static constexpr size_t MAX_LENGTH = 0x7fe0;
+};
+struct FrameHeader {  // x3.rs:148-184
+  uint8_t source_id = 0;
+  uint16_t samples = 0;
+  uint8_t channels = 0;
+  size_t payload_len = 0;
+  uint16_t payload_crc = 0;
+  static constexpr size_t LENGTH = 20;
+  static constexpr uint16_t KEY = 30771;
+  static constexpr size_t P_KEY = 0, P_SOURCE_ID = 2, P_CHANNELS = 3, P_SAMPLES = 4, P_PAYLOAD_SIZE = 6, P_TIME = 8,
+                          P_HEADER_CRC = 16, P_PAYLOAD_CRC = 18;
+};
+
+namespace bytewriter {
+enum class SeekFrom { Start, Current, End };
+
+// bytewriter.rs:14-22
+struct ByteWriter {
+  virtual ~ByteWriter() = default;
+  virtual X3Error align(size_t n, size_t* written = nullptr) = 0;
+  virtual X3Error write_all(const uint8_t* v, size_t n) = 0;
+  virtual X3Error flush() = 0;
+  virtual X3Error seek(SeekFrom from, int64_t pos, uint64_t* out = nullptr) = 0;
+  virtual X3Error stream_position(uint64_t* pos) = 0;
+};
+
+// bytewriter.rs:27-100
+class SliceByteWriter : public ByteWriter {
+ public:
+  SliceByteWriter(uint8_t* slice, size_t len) : slice_(slice), len_(len) {}
+  X3Error align(size_t n, size_t* written = nullptr) override {
+    size_t residual = p_byte_ % n;
+    if (written) *written = residual ? n - residual : 0;
+    if (!residual) return X3Error::Ok;
+    std::vector<uint8_t> z(n - residual, 0);
+    return write_all(z.data(), z.size());
+  }
+  X3Error write_all(const uint8_t* v, size_t n) override {
+    if (n > len_ - p_byte_) return X3Error::ByteWriterInsufficientMemory;
+    std::memcpy(slice_ + p_byte_, v, n);
+    p_byte_ += n;
+    if (p_byte_ > stream_length_) stream_length_ = p_byte_;
+    return X3Error::Ok;
+  }
+  X3Error flush() override { return X3Error::Ok; }
+  X3Error seek(SeekFrom from, int64_t pos, uint64_t* out = nullptr) override {
+    size_t abs_pos = from == SeekFrom::Start ? (size_t)pos
+                     : from == SeekFrom::Current ? (size_t)((int64_t)p_byte_ + pos)
+                                                 : (size_t)((int64_t)stream_length_ + pos);
+    if (abs_pos > len_) return X3Error::ByteWriterInsufficientMemory;
+    p_byte_ = abs_pos;
+    if (p_byte_ > stream_length_) stream_length_ = p_byte_;
+    if (out) *out = p_byte_;
+    return X3Error::Ok;
+  }
+  X3Error stream_position(uint64_t* pos) override { *pos = p_byte_; return X3Error::Ok; }
+  // direct access for the zero-copy encode path
+  uint8_t* data() { return slice_; }
+  size_t capacity() const { return len_; }
+  size_t position() const { return p_byte_; }
+  void advance_to(size_t pos) { p_byte_ = pos; if (p_byte_ > stream_length_) stream_length_ = p_byte_; }
+
+ private:
+  uint8_t* slice_;
+  size_t len_;
+  size_t p_byte_ = 0, stream_length_ = 0;
+};
+
+// bytewriter.rs:106-165 over any seekable std::ostream
+class StreamByteWriter : public ByteWriter {
+ public:
+  explicit StreamByteWriter(std::ostream& os) : os_(os) {}
+  X3Error align(size_t n, size_t* written = nullptr) override {
+    uint64_t pos = 0;
+    stream_position(&pos);
+    size_t residual = pos % n;
+    if (written) *written = residual ? n - residual : 0;
+    if (!residual) return X3Error::Ok;
+    std::vector<uint8_t> z(n - residual, 0);
+    return write_all(z.data(), z.size());
+  }
+  X3Error write_all(const uint8_t* v, size_t n) override {
+    os_.write(reinterpret_cast<const char*>(v), (std::streamsize)n);
+    return os_ ? X3Error::Ok : X3Error::Io;
+  }
+  X3Error flush() override { os_.flush(); return os_ ? X3Error::Ok : X3Error::Io; }
+  X3Error seek(SeekFrom from, int64_t pos, uint64_t* out = nullptr) override {
+    os_.seekp(pos, from == SeekFrom::Start ? std::ios::beg : from == SeekFrom::Current ? std::ios::cur : std::ios::end);
+    if (!os_) return X3Error::Io;
+    if (out) *out = (uint64_t)os_.tellp();
+    return X3Error::Ok;
+  }
+  X3Error stream_position(uint64_t* pos) override { *pos = (uint64_t)os_.tellp(); return X3Error::Ok; }
+
+ private:
+  std::ostream& os_;
+};
+}  // namespace bytewriter
+
+namespace crc {
+// crc.rs:44-47
+inline uint16_t update_crc16(uint16_t c, uint8_t data) { return x3_crc16_update(c, data); }
+// crc.rs:49-58 (GPU segmented reduction)
+inline X3Error crc16(Context& ctx, const uint8_t* data, size_t n, uint16_t* out) {
+  return static_cast<X3Error>(x3_crc16(ctx.raw(), data, n, out));
+}
+}  // namespace crc
+
+namespace encoder {
+using bytewriter::ByteWriter;
+using bytewriter::SliceByteWriter;
+
+// encoder.rs:122-162
+inline void write_frame_header(size_t num_samples, uint8_t id, size_t payload_len, uint16_t payload_crc,
+                               uint8_t (&out)[FrameHeader::LENGTH]) {
+  x3_write_frame_header(num_samples, id, payload_len, payload_crc, out);
+}
+
+namespace detail {
+// the reference prints this block after encode() when built with std (encoder.rs:96-108)
+inline void print_stats(const uint64_t (&stats)[6]) {
+  float t = (float)(stats[0] + stats[1] + stats[2] + stats[3] + stats[4] + stats[5]);
+  std::printf("\nStatistics:\n  Rice-0: %.4f%%\n  Rice-1: %.4f%%\n  Rice-2: %.4f%%\n  Rice-3: %.4f%%\n  BFP: %.4f%%\n"
+              "  Pass-through %.4f%%\n\n",
+              stats[0] / t * 100.0f, stats[1] / t * 100.0f, stats[2] / t * 100.0f, stats[3] / t * 100.0f,
+              stats[4] / t * 100.0f, stats[5] / t * 100.0f);
+}
+
+inline X3Error encode_samples(Context& ctx, const int16_t* wav, size_t n, size_t n_channels, const Parameters& params,
+                              ByteWriter& writer, bool one_frame, uint64_t (&stats)[6]) {
+  x3_params c = params.c_params();
+  uint64_t pos = 0;
+  if (auto* sw = dynamic_cast<SliceByteWriter*>(&writer)) {  // write straight into the caller's slice
+    int rc = one_frame ? x3_encode_frame(ctx.raw(), wav, n, &c, sw->data(), sw->capacity(), sw->position(), &pos, stats)
+                       : x3_encode(ctx.raw(), wav, n, (uint32_t)n_channels, &c, sw->data(), sw->capacity(),
+                                   sw->position(), &pos, stats);
+    if (rc == 0) sw->advance_to((size_t)pos);
+    return static_cast<X3Error>(rc);
+  }
+  uint64_t start = 0;
+  writer.stream_position(&start);
+  const uint64_t parity = start & 1;  // only the parity of the absolute position matters (encoder.rs:182)
+  std::vector<uint8_t> buf((size_t)(parity + x3_encode_bound(n, &c) + 64 + 3 * (one_frame ? n : 0)));
+  int rc = one_frame ? x3_encode_frame(ctx.raw(), wav, n, &c, buf.data(), buf.size(), parity, &pos, stats)
+                     : x3_encode(ctx.raw(), wav, n, (uint32_t)n_channels, &c, buf.data(), buf.size(), parity, &pos, stats);
+  if (rc) return static_cast<X3Error>(rc);
+  return writer.write_all(buf.data() + parity, (size_t)(pos - parity));
+}
+}  // namespace detail
+
+// encoder::encode over slice channels (README shape): channels.len() > 1 -> MoreThanOneChannel (encoder.rs:55-57)
+inline X3Error encode(Context& ctx, const Channel* const* channels, size_t n_channels, ByteWriter& writer,
+                      bool print_statistics = false) {
+  if (n_channels > 1) return X3Error::MoreThanOneChannel;
+  if (n_channels == 0) return X3Error::BadArg;
+  uint64_t stats[6] = {0, 0, 0, 0, 0, 0};
+  const Channel& ch = *channels[0];
+  X3Error e = detail::encode_samples(ctx, ch.wav, ch.len, n_channels, ch.params, writer, false, stats);
+  if (e == X3Error::Ok && print_statistics) detail::print_stats(stats);
+  return e;
+}
+
+// encoder::encode over iterator channels (encoder.rs:51-54): the iterator is collected, dispatched, written
+template <class It>
+inline X3Error encode(Context& ctx, IterChannel<It>* const* channels, size_t n_channels, ByteWriter& writer,
+                      bool print_statistics = false) {
+  if (n_channels > 1) return X3Error::MoreThanOneChannel;
+  if (n_channels == 0) return X3Error::BadArg;
+  std::vector<int16_t> wav(channels[0]->wav, channels[0]->wav_end);
+  channels[0]->wav = channels[0]->wav_end;  // the reference consumes the iterator
+  uint64_t stats[6] = {0, 0, 0, 0, 0, 0};
+  X3Error e = detail::encode_samples(ctx, wav.data(), wav.size(), n_channels, channels[0]->params, writer, false, stats);
+  if (e == X3Error::Ok && print_statistics) detail::print_stats(stats);
+  return e;
+}
+
+// encoder::encode_frame (encoder.rs:175-214)
+inline X3Error encode_frame(Context& ctx, const int16_t* wav, size_t n, ByteWriter& writer, const Parameters& params,
+                            uint64_t (&stats)[6]) {
+  uint64_t st[6] = {0, 0, 0, 0, 0, 0};
+  X3Error e = detail::encode_samples(ctx, wav, n, 1, params, writer, true, st);
+  if (e == X3Error::Ok)
+    for (int i = 0; i < 6; ++i) stats[i] += st[i];
+  return e;
+}
+}  // namespace encoder
+
+namespace decoder {
+// decoder.rs:69-118
+inline X3Error read_frame_header(const uint8_t* bytes, size_t len, FrameHeader* out) {
+  x3_frame_header h;
+  int rc = x3_read_frame_header(bytes, len, &h);
+  if (rc) return static_cast<X3Error>(rc);
+  out->source_id = h.source_id;
+  out->samples = h.samples;
+  out->channels = h.channels;
+  out->payload_len = h.payload_len;
+  out->payload_crc = h.payload_crc;
+  return X3Error::Ok;
+}
+
+// decoder.rs:36-58: returns the number of samples written in *n_out (the reference's Some(p_wav))
+inline X3Error decode_frame(Context& ctx, const uint8_t* x3_bytes, size_t len, int16_t* wav_buf, size_t wav_cap,
+                            const Parameters& params, size_t samples, size_t* n_out) {
+  x3_params c = params.c_params();
+  uint64_t n = 0;
+  int rc = x3_decode_frame(ctx.raw(), x3_bytes, len, wav_buf, wav_cap, &c, samples, &n);
+  if (n_out) *n_out = (size_t)n;
+  return static_cast<X3Error>(rc);
+}
+
+// the X3aReader::decode_next_frame loop (decodefile.rs:105-136, 200-209) over an in-memory frame stream
+struct StreamResult {
+  uint64_t samples = 0, frames_ok = 0, frame_errors = 0;
+};
+inline X3Error decode_stream(Context& ctx, const uint8_t* x3, size_t len, const Parameters& params, int16_t* wav,
+                             size_t wav_cap, StreamResult* res) {
+  x3_params c = params.c_params();
+  StreamResult r;
+  int rc = x3_decode_stream(ctx.raw(), x3, len, &c, wav, wav_cap, &r.samples, &r.frames_ok, &r.frame_errors);
+  if (res) *res = r;
+  return static_cast<X3Error>(rc);
+}
+}  // namespace decoder
+}  // namespace x3
