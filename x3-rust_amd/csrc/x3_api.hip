@@ -18,6 +18,7 @@
 #include "x3_decode_kernel.h"
 #include "x3_device.h"
 #include "x3_encode_kernel.h"
+#include "x3_encode_stream_kernel.h"
 #include "x3_synth_core.h"
 #include "x3_util_kernels.h"
 
@@ -51,7 +52,9 @@ struct x3_ctx {
   X3DecodeSummary* h_summary = nullptr;
   uint16_t* h_crc = nullptr;
   // growable scratch
-  DevBuf in, out, frame_bytes, frame_off, dec_status, dec_meta, wav_off, seg_crc;
+  DevBuf in, out, frame_bytes, frame_off, dec_status, dec_meta, wav_off, seg_crc, desc;
+  int n_cus = 0;
+  int stream_wg_per_cu = -1;  // co-resident workgroups per CU of x3_encode_stream_kernel (-1 = not queried)
   // bookkeeping of the last async calls
   bool encode_pending = false, decode_pending = false;
   uint64_t enc_start_pos = 0;
@@ -110,6 +113,11 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
   }
   HIPCHK(c, hipSetDevice(device));
   c->device = device;
+  {
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, device));
+    c->n_cus = prop.multiProcessorCount;
+  }
   if (own) {
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;
@@ -179,7 +187,7 @@ extern "C" void x3_ctx_destroy(x3_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf* b : {&c->in, &c->out, &c->frame_bytes, &c->frame_off, &c->dec_status, &c->dec_meta, &c->wav_off,
-                    &c->seg_crc})
+                    &c->seg_crc, &c->desc})
     if (b->p) (void)hipFree(b->p);
   for (auto& t : c->timers) {
     for (auto& e : t.used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -449,7 +457,7 @@ static int plan_encode(x3_ctx* c, const x3_batch* b, const x3_params* p, uint64_
   const uint64_t nblocks = (nmax - 1 + p->block_len - 1) / p->block_len;
   uint32_t nthr = (uint32_t)std::min<uint64_t>(512, std::max<uint64_t>(64, (nblocks + 63) & ~63ull));
   pl->nthr = nthr;
-  const uint64_t in_bytes = (2 * nmax + 15) & ~15ull;
+  const uint64_t in_bytes = (2 * nmax + 4 + 15) & ~15ull;  // + the dword read behind the last sample
   const uint64_t img_dw = ((5 + (max_payload_bytes(nmax, p->block_len) + 3) / 4 + 4) + 3) & ~3ull;
   const uint64_t smem = X3_ENC_SMEM_HDR + in_bytes + img_dw * 4;
   if (smem > 160 * 1024) {
@@ -478,6 +486,36 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
   }
   HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4 * sizeof(int), c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 8 * sizeof(unsigned long long), c->stream));
+  // ---- single-pass path: default block length, 16-byte aligned frames (see x3_encode_stream_kernel.h)
+  const bool stream_path = p->block_len == 20 && pl.nthr == 512 && (spf % 8) == 0 &&
+                           (b->n_clips == 1 || (b->clip_stride % 8) == 0) &&
+                           (reinterpret_cast<uintptr_t>(d_wav) & 15u) == 0 && !std::getenv("X3HIP_TWO_PASS");
+  if (stream_path) {
+    if (c->stream_wg_per_cu < 0) {
+      int nb = 0;
+      HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, x3_encode_stream_kernel, 512, pl.smem));
+      c->stream_wg_per_cu = std::max(0, std::min(nb, 3));
+    }
+    if (c->stream_wg_per_cu >= 1 && pl.smem <= 64 * 1024) {
+      if ((rc = ensure(c, c->desc, F * sizeof(unsigned long long)))) return rc;
+      HIPCHK(c, hipMemsetAsync(c->desc.p, 0, F * sizeof(unsigned long long), c->stream));
+      // persistent grid: every workgroup must be resident (the look-back waits on predecessors)
+      const uint64_t grid = std::min<uint64_t>(F, (uint64_t)c->n_cus * c->stream_wg_per_cu);
+      {
+        TimerScope ts(c, 0);
+        hipLaunchKernelGGL(x3_encode_stream_kernel, dim3((unsigned)grid), dim3(512), pl.smem, c->stream, d_wav, pl.g,
+                           pl.dp, d_off, d_out, out_cap, start_pos, (unsigned long long*)c->desc.p, c->d_stats,
+                           c->d_status, c->d_end_pos, (const uint16_t*)c->d_xpow, pl.lds_in_bytes, pl.img_dwords);
+      }
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_status, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(c->h_stats, c->d_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                               c->stream));
+      c->encode_pending = true;
+      c->enc_start_pos = start_pos;
+      return X3_OK;
+    }
+  }
   if (pl.smem > 64 * 1024) {
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_frames_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem));
