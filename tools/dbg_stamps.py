@@ -11,11 +11,12 @@ for _ in range(2):
     assert ctx.encode_dev(d_wav, n, p, d_out, cap, 0, d_off) == 0
     assert ctx.decode_dev(d_out, cap, d_off, F, p, d_back, n, n_per_clip=n) == 0
     print(ctx.encode_result()[0], ctx.decode_result())
-out = np.zeros(8*1080, dtype=np.uint64)
+NW = int(os.environ.get('X3_STAMP_WGS','1080'))
+out = np.zeros(8*NW, dtype=np.uint64)
 L.x3_dbg_read.argtypes=[C.c_void_p, C.c_void_p, C.c_uint64]
 print(L.x3_dbg_read(ctx._h, out.ctypes.data, out.size))
 a = out.reshape(-1, 8).astype(np.float64)
-names = ["setup","blockhdr-pre","service","header","samples","flush","tail","-"]
+names = os.environ.get("X3_STAMP_NAMES","setup,blockhdr-pre,service,header,samples,flush,tail,-").split(",")
 print("mean cycles per wave (x100MHz clock64 ticks?)")
 for k in range(8): print("%-14s mean %12.0f  min %12.0f max %12.0f" % (names[k], a[:,k].mean(), a[:,k].min(), a[:,k].max()))
 print("total", a.sum(axis=1).mean())

@@ -41,6 +41,7 @@ struct x3_ctx {
   std::string last_error;
   // persistent small device state
   uint16_t* d_xpow = nullptr;          // X3_XP_SIZE entries
+  uint16_t* d_xk = nullptr;            // [10][512]: x^(32*c*(511-t)) mod P (x3_encode_stream_kernel.h)
   int* d_status = nullptr;             // [0] size/scan pass, [1] encode pass
   unsigned long long* d_stats = nullptr;    // 6
   unsigned long long* d_end_pos = nullptr;  // 1
@@ -151,6 +152,13 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
     }
   }
   HIPCHK(c, hipMemcpy(c->d_xpow, xp.data(), X3_XP_SIZE * sizeof(uint16_t), hipMemcpyHostToDevice));
+  {
+    std::vector<uint16_t> xk(10 * 512);
+    for (int cd = 1; cd <= 10; ++cd)
+      for (int t = 0; t < 512; ++t) xk[(cd - 1) * 512 + t] = (uint16_t)gf_xpow_host(32ull * cd * (511 - t));
+    HIPCHK(c, hipMalloc(&c->d_xk, xk.size() * sizeof(uint16_t)));
+    HIPCHK(c, hipMemcpy(c->d_xk, xk.data(), xk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  }
   return X3_OK;
 }
 
@@ -194,6 +202,7 @@ extern "C" void x3_ctx_destroy(x3_ctx* c) {
     for (auto& e : t.pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   }
   (void)hipFree(c->d_xpow);
+  (void)hipFree(c->d_xk);
   (void)hipFree(c->d_status);
   (void)hipFree(c->d_stats);
   (void)hipFree(c->d_summary);
@@ -492,9 +501,19 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
                            (reinterpret_cast<uintptr_t>(d_wav) & 15u) == 0 && !std::getenv("X3HIP_TWO_PASS");
   if (stream_path) {
     if (c->stream_wg_per_cu < 0) {
+      // The look-back waits on predecessors, so EVERY workgroup of the grid must be resident.  The
+      // occupancy API can over-report by one block per CU (MI355X_MICROARCH.md, "Residency"), so it is
+      // capped by a conservative count from the kernel's own register/LDS footprint: 9 waves per
+      // workgroup land unevenly on the 4 SIMDs, hence the slack of 3 waves.
       int nb = 0;
-      HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, x3_encode_stream_kernel, 512, pl.smem));
-      c->stream_wg_per_cu = std::max(0, std::min(nb, 3));
+      HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, x3_encode_stream_kernel, X3_STREAM_THREADS, pl.smem));
+      hipFuncAttributes fa;
+      HIPCHK(c, hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&x3_encode_stream_kernel)));
+      const int alloc = ((fa.numRegs + 7) / 8) * 8;
+      const int wps = std::min(8, 512 / std::max(alloc, 8));
+      const int by_regs = (4 * wps - 3) / 9;
+      const int by_lds = (int)((160 * 1024) / pl.smem);
+      c->stream_wg_per_cu = std::max(0, std::min(std::min(nb, 4), std::min(by_regs, by_lds)));
     }
     if (c->stream_wg_per_cu >= 1 && pl.smem <= 64 * 1024) {
       if ((rc = ensure(c, c->desc, F * sizeof(unsigned long long)))) return rc;
@@ -503,9 +522,10 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
       const uint64_t grid = std::min<uint64_t>(F, (uint64_t)c->n_cus * c->stream_wg_per_cu);
       {
         TimerScope ts(c, 0);
-        hipLaunchKernelGGL(x3_encode_stream_kernel, dim3((unsigned)grid), dim3(512), pl.smem, c->stream, d_wav, pl.g,
+        hipLaunchKernelGGL(x3_encode_stream_kernel, dim3((unsigned)grid), dim3(X3_STREAM_THREADS), pl.smem, c->stream, d_wav, pl.g,
                            pl.dp, d_off, d_out, out_cap, start_pos, (unsigned long long*)c->desc.p, c->d_stats,
-                           c->d_status, c->d_end_pos, (const uint16_t*)c->d_xpow, pl.lds_in_bytes, pl.img_dwords);
+                           c->d_status, c->d_end_pos, (const uint16_t*)c->d_xpow, (const uint16_t*)c->d_xk, pl.lds_in_bytes,
+                           pl.img_dwords);
       }
       HIPCHK(c, hipGetLastError());
       HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_status, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
