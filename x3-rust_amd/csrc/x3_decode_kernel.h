@@ -705,6 +705,7 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
     // one sample, branch-free.  A zero run of 32 (t == 0) gives ii >= 31*level, beyond every bound
     // the fast path admits, so it needs no test of its own; an over-long codeword (z + width > 32)
     // only happens together with such an error, so `consume` need not clamp it.
+    // `last` is kept modulo 2^32 (only its low 16 bits are ever stored or compared).
     auto sample = [&](uint32_t idx, auto direct_tag) {
       constexpr bool DIRECT = decltype(direct_tag)::value;
       const uint32_t t = __builtin_amdgcn_alignbit(w0, w1, s);        // next 32 bits
@@ -720,7 +721,7 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
       const uint32_t nl = (((uint32_t)last + d) & ~litmask) | (v & litmask);  // literal: field = sample
       const uint32_t iim = ii & zmask;
       maxii = iim > maxii ? iim : maxii;
-      last = (int16_t)(uint16_t)nl;
+      last = (int32_t)nl;
       if (DIRECT) {
         if (coop) {
           if (idx & 1u) orow[(idx - wbase) >> 1] = ((uint32_t)carry & 0xFFFFu) | ((uint32_t)last << 16);
@@ -731,6 +732,35 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
       } else {
         if (idx & 1u) orow[(idx - wbase) >> 1] = ((uint32_t)carry & 0xFFFFu) | ((uint32_t)last << 16);
         else carry = last;
+      }
+    };
+    // two samples from ONE 32-bit peek and ONE window update (two valid codewords are <= 32 bits on
+    // this path); staged output only.  ODD: idx is odd, i.e. sample a completes the pending dword.
+    auto sample2 = [&](uint32_t idx, auto odd_tag) {
+      constexpr bool ODD = decltype(odd_tag)::value;
+      const uint32_t t = __builtin_amdgcn_alignbit(w0, w1, s);
+      const uint32_t z1 = (uint32_t)__clz(t) & zmask;
+      const uint32_t v1 = (t << (z1 & 31u)) >> rsh;
+      const uint32_t n1 = z1 + width;
+      const uint32_t t2 = t << (n1 & 31u);
+      const uint32_t z2 = (uint32_t)__clz(t2) & zmask;
+      const uint32_t v2 = (t2 << (z2 & 31u)) >> rsh;
+      consume(n1 + z2 + width);
+      const uint32_t i1 = (z1 << lsh) + (v1 + nlevel), i2 = (z2 << lsh) + (v2 + nlevel);
+      const uint32_t r1 = (i1 >> 1) ^ (0u - (i1 & 1u)), r2 = (i2 >> 1) ^ (0u - (i2 & 1u));
+      const uint32_t b1 = v1 - (v1 > neg_thresh ? neg2 : 0u), b2 = v2 - (v2 > neg_thresh ? neg2 : 0u);
+      const uint32_t d1 = (r1 & zmask) | (b1 & ~zmask), d2 = (r2 & zmask) | (b2 & ~zmask);
+      const uint32_t la = (((uint32_t)last + d1) & ~litmask) | (v1 & litmask);
+      const uint32_t lb = ((la + d2) & ~litmask) | (v2 & litmask);
+      // n1 >= 32 (t2 meaningless) only with i1 beyond every bound: the error is recorded by i1
+      const uint32_t im = (i1 > i2 ? i1 : i2) & zmask;
+      maxii = im > maxii ? im : maxii;
+      last = (int32_t)lb;
+      if (ODD) {
+        orow[(idx - wbase) >> 1] = ((uint32_t)carry & 0xFFFFu) | (la << 16);
+        carry = (int32_t)lb;
+      } else {
+        orow[(idx - wbase) >> 1] = (la & 0xFFFFu) | (lb << 16);
       }
     };
 
@@ -745,7 +775,13 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
       if (cnt >= seg_end) {
         // every sample of the segment belongs to this lane's block
         if (all_coop) {
-          for (uint32_t jj = j; jj < seg_end; ++jj) sample(i0 + (jj - j), std::false_type{});
+          uint32_t jj = j;
+          if (i0 & 1u) {
+            for (; jj + 1 < seg_end; jj += 2) sample2(i0 + (jj - j), std::true_type{});
+          } else {
+            for (; jj + 1 < seg_end; jj += 2) sample2(i0 + (jj - j), std::false_type{});
+          }
+          if (jj < seg_end) sample(i0 + (jj - j), std::false_type{});
         } else {
           for (uint32_t jj = j; jj < seg_end; ++jj) sample(i0 + (jj - j), std::true_type{});
         }
