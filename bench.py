@@ -184,8 +184,10 @@ def main():
         # algorithmic HBM bytes per launch (DESIGN.md "Kernels"): 2 B per sample + P stream bytes for
         # the encoder and the decoder; the size pass re-reads the samples; the check pass reads the stream
         alg = {"encode": 2 * n + pos, "decode": 2 * n + pos, "frame_sizes": 2 * n, "frame_check": pos}
-        kname = {"encode": "x3_encode_frames_kernel<false>", "decode": "x3_decode_fast_kernel",
+        kname = {"encode": "x3_encode_stream_kernel" if ktimes.get("frame_sizes", 0.0) == 0.0 else "x3_encode_frames_kernel<false>",
+                 "decode": "x3_decode_fast_kernel",
                  "frame_sizes": "x3_encode_frames_kernel<true>", "frame_check": "x3_frame_check_kernel"}
+        alg = {k: v for k, v in alg.items() if ktimes.get(k, 0.0) > 0.0}  # the two-pass fallback kernels may not run
         dominant = max(alg, key=lambda k: ktimes[k])
         traffic = {}
         try:  # HBM bytes per launch from rocprofv3 PMC passes (profiles/, see DESIGN.md "Measurement")

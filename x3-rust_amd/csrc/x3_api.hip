@@ -38,6 +38,8 @@ struct x3_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipStream_t stream2 = nullptr;        // side stream: the payload-CRC pass runs beside the decoder
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::string last_error;
   // persistent small device state
   uint16_t* d_xpow = nullptr;          // X3_XP_SIZE entries
@@ -51,9 +53,11 @@ struct x3_ctx {
   int* h_status = nullptr;
   unsigned long long* h_stats = nullptr;  // 6 stats + end_pos
   X3DecodeSummary* h_summary = nullptr;
+  X3DecodeSummary* h_summary_init = nullptr;
+  int32_t* dec_status_ptr = nullptr;
   uint16_t* h_crc = nullptr;
   // growable scratch
-  DevBuf in, out, frame_bytes, frame_off, dec_status, dec_meta, wav_off, seg_crc, desc;
+  DevBuf in, out, frame_bytes, frame_off, dec_status, dec_cstatus, dec_meta, wav_off, seg_crc, desc;
   int n_cus = 0;
   int stream_wg_per_cu = -1;  // co-resident workgroups per CU of x3_encode_stream_kernel (-1 = not queried)
   // bookkeeping of the last async calls
@@ -125,6 +129,9 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
   } else {
     c->stream = stream;
   }
+  HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   HIPCHK(c, hipMalloc(&c->d_xpow, X3_XP_SIZE * sizeof(uint16_t)));
   HIPCHK(c, hipMalloc(&c->d_status, 4 * sizeof(int)));
   HIPCHK(c, hipMalloc(&c->d_stats, 8 * sizeof(unsigned long long)));
@@ -134,6 +141,7 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
   HIPCHK(c, hipHostMalloc(&c->h_status, 4 * sizeof(int)));
   HIPCHK(c, hipHostMalloc(&c->h_stats, 8 * sizeof(unsigned long long)));
   HIPCHK(c, hipHostMalloc(&c->h_summary, sizeof(X3DecodeSummary)));
+  HIPCHK(c, hipHostMalloc(&c->h_summary_init, sizeof(X3DecodeSummary)));
   HIPCHK(c, hipHostMalloc(&c->h_crc, 16));
   std::vector<uint16_t> xp(X3_XP_SIZE);
   for (int j = 0; j < X3_XP_LEVELS; ++j)
@@ -194,7 +202,7 @@ extern "C" void x3_ctx_destroy(x3_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  for (DevBuf* b : {&c->in, &c->out, &c->frame_bytes, &c->frame_off, &c->dec_status, &c->dec_meta, &c->wav_off,
+  for (DevBuf* b : {&c->in, &c->out, &c->frame_bytes, &c->frame_off, &c->dec_status, &c->dec_cstatus, &c->dec_meta, &c->wav_off,
                     &c->seg_crc, &c->desc})
     if (b->p) (void)hipFree(b->p);
   for (auto& t : c->timers) {
@@ -210,7 +218,11 @@ extern "C" void x3_ctx_destroy(x3_ctx* c) {
   (void)hipHostFree(c->h_status);
   (void)hipHostFree(c->h_stats);
   (void)hipHostFree(c->h_summary);
+  (void)hipHostFree(c->h_summary_init);
   (void)hipHostFree(c->h_crc);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -239,8 +251,9 @@ extern "C" const char* x3_strerror(int s) {
 struct TimerScope {
   x3_ctx* c;
   int which;
+  hipStream_t st;
   std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
-  TimerScope(x3_ctx* c_, int w) : c(c_), which(w) {
+  TimerScope(x3_ctx* c_, int w, hipStream_t s_ = nullptr) : c(c_), which(w), st(s_ ? s_ : c_->stream) {
     if (!c->timing) return;
     KernelTimer& t = c->timers[which];
     if (!t.pool.empty()) {
@@ -250,11 +263,11 @@ struct TimerScope {
       (void)hipEventCreate(&ev.first);
       (void)hipEventCreate(&ev.second);
     }
-    (void)hipEventRecord(ev.first, c->stream);
+    (void)hipEventRecord(ev.first, st);
   }
   ~TimerScope() {
     if (!c->timing) return;
-    (void)hipEventRecord(ev.second, c->stream);
+    (void)hipEventRecord(ev.second, st);
     c->timers[which].used.push_back(ev);
   }
 };
@@ -719,12 +732,18 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
     if ((rc = ensure(c, c->dec_status, F * sizeof(int32_t)))) return rc;
     d_status = (int32_t*)c->dec_status.p;
   }
+  if ((rc = ensure(c, c->dec_cstatus, F * sizeof(int32_t)))) return rc;
+  // fork: header + payload-CRC pass on the side stream, decoder on the main stream (independent;
+  // the decoder's one-wave-per-SIMD dependency chains leave the CUs mostly idle)
+  HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
   {
-    TimerScope ts(c, 4);
-    hipLaunchKernelGGL(x3_frame_check_kernel, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, c->stream,
+    TimerScope ts(c, 4, c->stream2);
+    hipLaunchKernelGGL(x3_frame_check_kernel, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, c->stream2,
                        reinterpret_cast<const uint32_t*>(d_x3), x3_len, d_frame_offsets, F,
-                       (const uint16_t*)c->d_xpow, d_status, (X3FrameMeta*)c->dec_meta.p);
+                       (const uint16_t*)c->d_xpow, (int32_t*)c->dec_cstatus.p);
   }
+  HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
   {
     // the branch-free kernel needs every valid Rice codeword (zeros + terminator + sub-code) to fit 32 bits
     bool fast = true;
@@ -737,14 +756,26 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
     if (fast)
       hipLaunchKernelGGL(x3_decode_fast_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, c->stream, d_x3, x3_len,
                          d_frame_offsets, F, g, d_wav_offsets, dp, d_wav, wav_cap, d_status,
-                         (const X3FrameMeta*)c->dec_meta.p);
+                         (X3FrameMeta*)c->dec_meta.p);
     else
       hipLaunchKernelGGL((x3_decode_lanes_kernel<false, 64>), dim3((unsigned)((F + 63) / 64)), dim3(64), 0, c->stream,
                          d_x3, x3_len, d_frame_offsets, F, g, d_wav_offsets, dp, d_wav, wav_cap, d_status,
-                         (const X3FrameMeta*)c->dec_meta.p);
+                         (X3FrameMeta*)c->dec_meta.p);
   }
-  hipLaunchKernelGGL(x3_decode_summary_kernel, dim3(1), dim3(1024), 0, c->stream, (const int32_t*)d_status,
-                     (const X3FrameMeta*)c->dec_meta.p, F, c->d_summary);
+  // join, then merge the two status arrays and summarise
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+  {
+    X3DecodeSummary init;
+    init.first_bad = F;
+    init.samples_before = 0;
+    init.first_bad_status = 0;
+    init.pad = 0;
+    *c->h_summary_init = init;
+    HIPCHK(c, hipMemcpyAsync(c->d_summary, c->h_summary_init, sizeof init, hipMemcpyHostToDevice, c->stream));
+  }
+  hipLaunchKernelGGL(x3_decode_merge_kernel, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, c->stream,
+                     (const int32_t*)c->dec_cstatus.p, d_status, (const X3FrameMeta*)c->dec_meta.p, F, c->d_summary);
+  c->dec_status_ptr = d_status;
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(X3DecodeSummary), hipMemcpyDeviceToHost, c->stream));
   c->decode_pending = true;
@@ -764,6 +795,14 @@ extern "C" int x3_decode_result(x3_ctx* c, uint64_t* first_bad, int* first_bad_s
   if (!c || !c->decode_pending) return X3_ERR_BAD_ARG;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->decode_pending = false;
+  if (c->h_summary->first_bad < c->dec_frames) {
+    // rare: a frame is bad -- its status and the samples of the good frames before it
+    hipLaunchKernelGGL(x3_decode_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, (const int32_t*)c->dec_status_ptr,
+                       (const X3FrameMeta*)c->dec_meta.p, c->dec_frames, c->d_summary);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(X3DecodeSummary), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   if (first_bad) *first_bad = c->h_summary->first_bad;
   if (first_bad_status) *first_bad_status = c->h_summary->first_bad_status;
   if (samples_before) *samples_before = c->h_summary->samples_before;

@@ -50,40 +50,46 @@ __device__ __forceinline__ uint32_t x3_be32_at(const uint32_t* __restrict__ xw, 
 // x^(-8t) mod P for t = 1..3 lives behind the x^n table
 #define X3_XINV8_INDEX(t) (X3_XINV16_INDEX + 1 + (t))
 
+// decoder::read_frame_header (decoder.rs:69-118) + the walk's length checks (decodefile.rs:107-121) for
+// the frame at byte offset `off`; same check order as the reference.
+__device__ __forceinline__ int32_t x3_frame_header_check(const uint32_t* __restrict__ xw, uint64_t n_dw,
+                                                         uint64_t x3_len, uint64_t off, uint32_t& plen,
+                                                         uint32_t& samples, uint32_t& pcrc) {
+  plen = 0;
+  samples = 0;
+  pcrc = 0;
+  if (off + 20 > x3_len) return X3D_STREAM_ENDS_IN_FRAME;
+  const uint32_t h0 = x3_be32_at(xw, n_dw, off), h1 = x3_be32_at(xw, n_dw, off + 4);
+  const uint32_t h2 = x3_be32_at(xw, n_dw, off + 8), h3 = x3_be32_at(xw, n_dw, off + 12);
+  const uint32_t h4 = x3_be32_at(xw, n_dw, off + 16);
+  uint32_t hc = 0xFFFFu;
+  hc = x3_crc_be32(hc, h0);
+  hc = x3_crc_be32(hc, h1);
+  hc = x3_crc_be32(hc, h2);
+  hc = x3_crc_be32(hc, h3);
+  samples = h1 >> 16;
+  plen = h1 & 0xFFFFu;
+  pcrc = h4 & 0xFFFFu;
+  if ((h4 >> 16) != hc) return X3D_FRAME_HEADER_INVALID_HEADER_CRC;
+  if ((h0 >> 16) != 0x7833u) return X3D_FRAME_HEADER_INVALID_KEY;
+  if ((h0 & 0xFFu) > 1u) return X3D_MORE_THAN_ONE_CHANNEL;
+  if (plen >= 0x7fe0u) return X3D_FRAME_LENGTH;
+  if (off + 20 + plen > x3_len) return X3D_STREAM_ENDS_IN_FRAME;   // decodefile.rs:114-116
+  if (plen > 24576u) return X3D_FRAME_HEADER_INVALID_PAYLOAD_LEN;  // decodefile.rs:118-121
+  return X3D_OK;
+}
+
 __global__ void __launch_bounds__(256)
 x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const uint64_t* __restrict__ frame_off,
-                      uint64_t n_frames, const uint16_t* __restrict__ xpow, int32_t* __restrict__ status,
-                      X3FrameMeta* __restrict__ meta) {
+                      uint64_t n_frames, const uint16_t* __restrict__ xpow, int32_t* __restrict__ status) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t f = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (f >= n_frames) return;  // whole wave
   const uint64_t n_dw = (x3_len + 3) >> 2;
   const uint64_t off = frame_off[f];
-  int32_t st = X3D_OK;
+  // ---- header: every lane reads the same 20 bytes (broadcast loads)
   uint32_t plen = 0, samples = 0, pcrc = 0;
-
-  // ---- header (decoder.rs:69-118); every lane reads the same 20 bytes (broadcast loads)
-  if (off + 20 > x3_len) {
-    st = X3D_STREAM_ENDS_IN_FRAME;
-  } else {
-    const uint32_t h0 = x3_be32_at(xw, n_dw, off), h1 = x3_be32_at(xw, n_dw, off + 4);
-    const uint32_t h2 = x3_be32_at(xw, n_dw, off + 8), h3 = x3_be32_at(xw, n_dw, off + 12);
-    const uint32_t h4 = x3_be32_at(xw, n_dw, off + 16);
-    uint32_t hc = 0xFFFFu;
-    hc = x3_crc_be32(hc, h0);
-    hc = x3_crc_be32(hc, h1);
-    hc = x3_crc_be32(hc, h2);
-    hc = x3_crc_be32(hc, h3);
-    samples = h1 >> 16;
-    plen = h1 & 0xFFFFu;
-    pcrc = h4 & 0xFFFFu;
-    if ((h4 >> 16) != hc) st = X3D_FRAME_HEADER_INVALID_HEADER_CRC;
-    else if ((h0 >> 16) != 0x7833u) st = X3D_FRAME_HEADER_INVALID_KEY;
-    else if ((h0 & 0xFFu) > 1u) st = X3D_MORE_THAN_ONE_CHANNEL;
-    else if (plen >= 0x7fe0u) st = X3D_FRAME_LENGTH;
-    else if (off + 20 + plen > x3_len) st = X3D_STREAM_ENDS_IN_FRAME;          // decodefile.rs:114-116
-    else if (plen > 24576u) st = X3D_FRAME_HEADER_INVALID_PAYLOAD_LEN;         // decodefile.rs:118-121
-  }
+  int32_t st = x3_frame_header_check(xw, n_dw, x3_len, off, plen, samples, pcrc);
 
   // ---- payload CRC (decodefile.rs:96-100)
   if (st == X3D_OK) {
@@ -124,11 +130,7 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
     }
     if (crc != pcrc) st = X3D_FRAME_HEADER_INVALID_PAYLOAD_CRC;
   }
-  if (lane == 0) {
-    status[f] = st;
-    meta[f].payload_len = plen;
-    meta[f].samples = samples;
-  }
+  if (lane == 0) status[f] = st;
 }
 
 // inverse Rice map (x3.rs:200-204): 0,-1,1,-2,2,...
@@ -177,7 +179,7 @@ __global__ void __launch_bounds__(64)
 x3_decode_lanes_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uint64_t* __restrict__ frame_off,
                        uint64_t n_frames, X3Geom g, const uint64_t* __restrict__ wav_off, X3DevParams p,
                        int16_t* __restrict__ wav, uint64_t wav_cap, int32_t* __restrict__ status,
-                       const X3FrameMeta* __restrict__ meta) {
+                       X3FrameMeta* __restrict__ meta) {
   __shared__ __attribute__((aligned(16))) uint32_t ring[LANES * X3_DEC_RING_STRIDE];
   __shared__ __attribute__((aligned(16))) uint32_t outs[LANES * X3_DEC_OUT_STRIDE];
   __shared__ unsigned long long s_wo[LANES];  // sample offset of each lane's frame in wav
@@ -200,9 +202,16 @@ x3_decode_lanes_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   uint32_t samples = 0, plen = 2;
   uint64_t p0 = 0, wo = 0;
   if (active) {
-    st = status[f];
-    samples = meta[f].samples;
-    plen = meta[f].payload_len;
+    // header validation is repeated here (cheap, once per frame) so that this kernel does not depend
+    // on x3_frame_check_kernel: the payload-CRC pass runs CONCURRENTLY on a second stream and the
+    // two status arrays are merged afterwards (x3_decode_merge_kernel)
+    uint32_t pcrc_unused;
+    st = x3_frame_header_check(reinterpret_cast<const uint32_t*>(x3 - (reinterpret_cast<uintptr_t>(x3) & 3u)),
+                               (x3_len + (reinterpret_cast<uintptr_t>(x3) & 3u) + 3) >> 2,
+                               x3_len + (reinterpret_cast<uintptr_t>(x3) & 3u),
+                               frame_off[f] + (reinterpret_cast<uintptr_t>(x3) & 3u), plen, samples, pcrc_unused);
+    meta[f].payload_len = plen;
+    meta[f].samples = samples;
     p0 = frame_off[f] + 20;
     if (st != X3D_OK) {
       active = false;
@@ -494,7 +503,7 @@ __global__ void __launch_bounds__(64)
 x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uint64_t* __restrict__ frame_off,
                       uint64_t n_frames, X3Geom g, const uint64_t* __restrict__ wav_off, X3DevParams p,
                       int16_t* __restrict__ wav, uint64_t wav_cap, int32_t* __restrict__ status,
-                      const X3FrameMeta* __restrict__ meta) {
+                      X3FrameMeta* __restrict__ meta) {
   __shared__ __attribute__((aligned(16))) uint32_t ring[64 * X3_DEC_RING_STRIDE];
   __shared__ __attribute__((aligned(16))) uint32_t outs[64 * X3_DEC_OUT_STRIDE];
   __shared__ unsigned long long s_wo[64];
@@ -511,9 +520,16 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
   uint32_t samples = 0, plen = 2;
   uint64_t p0 = 0, wo = 0;
   if (active) {
-    st = status[f];
-    samples = meta[f].samples;
-    plen = meta[f].payload_len;
+    // header validation is repeated here (cheap, once per frame) so that this kernel does not depend
+    // on x3_frame_check_kernel: the payload-CRC pass runs CONCURRENTLY on a second stream and the
+    // two status arrays are merged afterwards (x3_decode_merge_kernel)
+    uint32_t pcrc_unused;
+    st = x3_frame_header_check(reinterpret_cast<const uint32_t*>(x3 - (reinterpret_cast<uintptr_t>(x3) & 3u)),
+                               (x3_len + (reinterpret_cast<uintptr_t>(x3) & 3u) + 3) >> 2,
+                               x3_len + (reinterpret_cast<uintptr_t>(x3) & 3u),
+                               frame_off[f] + (reinterpret_cast<uintptr_t>(x3) & 3u), plen, samples, pcrc_unused);
+    meta[f].payload_len = plen;
+    meta[f].samples = samples;
     p0 = frame_off[f] + 20;
     if (st != X3D_OK) {
       active = false;
@@ -821,32 +837,49 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
 // first frame with a non-zero status, and the samples of the good frames before it
 struct X3DecodeSummary {
   unsigned long long first_bad;
-  unsigned long long samples_before;
+  unsigned long long samples_before;  // valid when first_bad == n_frames (else see x3_decode_prefix_kernel)
   int first_bad_status;
   int pad;
 };
 
+// Merge the two concurrent passes: a frame's status is the check pass's (header, then payload CRC --
+// the reference tests those first, decodefile.rs:112-121,96-100) if that is non-zero, else the
+// decoder's.  Also finds the first bad frame and the total sample count.  summary must be pre-set to
+// {n_frames, 0, 0}.
+__global__ void __launch_bounds__(256)
+x3_decode_merge_kernel(const int32_t* __restrict__ cstatus, int32_t* __restrict__ status,
+                       const X3FrameMeta* __restrict__ meta, uint64_t n_frames, X3DecodeSummary* __restrict__ out) {
+  const uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long ns = 0;
+  if (f < n_frames) {
+    const int32_t cs = cstatus[f];
+    int32_t st = status[f];
+    if (cs != 0) {
+      st = cs;
+      status[f] = cs;
+    }
+    if (st != 0) atomicMin(&out->first_bad, (unsigned long long)f);
+    else ns = meta[f].samples;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) ns += __shfl_xor(ns, o, X3_WAVE);
+  if ((threadIdx.x & 63u) == 0 && ns) atomicAdd(&out->samples_before, ns);
+}
+
+// only when a frame is bad: status of the first bad frame and the samples of the good frames before it
 __global__ void __launch_bounds__(1024)
-x3_decode_summary_kernel(const int32_t* __restrict__ status, const X3FrameMeta* __restrict__ meta,
-                         uint64_t n_frames, X3DecodeSummary* __restrict__ out) {
-  __shared__ unsigned long long s_first;
+x3_decode_prefix_kernel(const int32_t* __restrict__ status, const X3FrameMeta* __restrict__ meta, uint64_t n_frames,
+                        X3DecodeSummary* __restrict__ out) {
   __shared__ unsigned long long s_sum;
-  if (threadIdx.x == 0) { s_first = n_frames; s_sum = 0; }
+  if (threadIdx.x == 0) s_sum = 0;
   __syncthreads();
-  unsigned long long mine = n_frames;
-  for (uint64_t f = threadIdx.x; f < n_frames; f += blockDim.x)
-    if (status[f] != 0) { mine = f; break; }
-  if (mine < n_frames) atomicMin(&s_first, mine);
-  __syncthreads();
-  const unsigned long long first = s_first;
+  const unsigned long long first = out->first_bad;
   unsigned long long sum = 0;
-  for (uint64_t f = threadIdx.x; f < first; f += blockDim.x) sum += meta[f].samples;
+  for (uint64_t f = threadIdx.x; f < first && f < n_frames; f += blockDim.x) sum += meta[f].samples;
   if (sum) atomicAdd(&s_sum, sum);
   __syncthreads();
   if (threadIdx.x == 0) {
-    out->first_bad = first;
     out->samples_before = s_sum;
     out->first_bad_status = first < n_frames ? status[first] : 0;
-    out->pad = 0;
   }
 }
