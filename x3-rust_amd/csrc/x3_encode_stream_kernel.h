@@ -70,6 +70,50 @@ __device__ __forceinline__ uint32_t x3_pk_sar_i16(uint32_t a, uint32_t sh) {  //
 
 #define X3_STREAM_THREADS 576u  // 8 compute waves (one block per lane) + 1 helper wave
 
+// One 16-byte-per-lane direct-to-LDS load, hidden from hipcc (cdna_hip_programming.md section 5.7): the
+// compiler would otherwise wait vmcnt(0) before every later LDS access of the wave.  lds_dst is the
+// wave-uniform LDS byte address; lane l lands at lds_dst + 16*l.  The caller waits (x3_dma_wait)
+// before the barrier that precedes the first read of the staged bytes.
+__device__ __forceinline__ void x3_glds16(const void* gsrc, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+__device__ __forceinline__ void x3_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ uint32_t x3_lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(const char*)p;
+}
+
+// a(x) * C(x) mod 0x11021 for a compile-time constant C: the sixteen C*x^b are immediates
+constexpr uint32_t x3_gf_xtime(uint32_t k) { return ((k << 1) ^ ((k & 0x8000u) ? 0x11021u : 0u)) & 0xFFFFu; }
+constexpr uint32_t x3_gf_mul_c(uint32_t a, uint32_t b) {
+  uint32_t r = 0;
+  for (int i = 0; i < 16; ++i) {
+    if ((a >> i) & 1u) r ^= b;
+    b = x3_gf_xtime(b);
+  }
+  return r;
+}
+constexpr uint32_t x3_gf_pow_c(uint32_t base, int e) {
+  uint32_t r = 1;
+  for (int i = 0; i < e; ++i) r = x3_gf_mul_c(r, base);
+  return r;
+}
+// x^-1 = x^15 + x^11 + x^4 (x * that = x^16 + x^12 + x^5 = P + 1); x^-16 = (x^-1)^16
+constexpr uint32_t X3_XINV16_C = x3_gf_pow_c(0x8810u, 16);
+template <uint32_t C>
+__device__ __forceinline__ uint32_t x3_gf_mul_const(uint32_t a) {
+  uint32_t r = 0, k = C;
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {
+    r ^= (0u - ((a >> b) & 1u)) & k;
+    k = x3_gf_xtime(k);
+  }
+  return r;
+}
+
 // stage frame samples [0, n) of `src` into LDS with direct-to-LDS loads (no VGPRs, all in flight at
 // once); executed by ONE wave.  16-byte pieces; the < 8 samples behind the last full piece by lanes.
 __device__ __forceinline__ void x3_stage_frame_dma(const int16_t* __restrict__ src, uint32_t n, int16_t* in_s,
@@ -78,9 +122,7 @@ __device__ __forceinline__ void x3_stage_frame_dma(const int16_t* __restrict__ s
   const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(src);
   for (uint32_t base = 0; base < npieces; base += 64u) {
     if (base + lane < npieces)
-      __builtin_amdgcn_global_load_lds(s4 + base + lane,
-                                       (__attribute__((address_space(3))) void*)(reinterpret_cast<uint4*>(in_s) + base),
-                                       16, 0, 0);
+      x3_glds16(s4 + base + lane, __builtin_amdgcn_readfirstlane(x3_lds_addr(reinterpret_cast<uint4*>(in_s) + base)));
   }
   const uint32_t done = npieces << 3;
   if (done + lane < n) in_s[done + lane] = src[done + lane];
@@ -126,6 +168,7 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
     uint32_t n;
     frame_geom(blockIdx.x, src, n);
     x3_stage_frame_dma(src, n, in_s, lane);
+    x3_dma_wait();
   }
   __syncthreads();
 
@@ -270,6 +313,13 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
         const unsigned long long d = f == 0 ? ((X3_DESC_PREFIX << X3_DESC_SHIFT) | (base_pos + frame_bytes))
                                             : ((X3_DESC_AGG << X3_DESC_SHIFT) | (unsigned long long)frame_bytes);
         __hip_atomic_store(&desc[f], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // header CRC (encoder.rs:153-154) needs only the frame's sample count and payload length
+        uint32_t hc = 0xFFFFu;
+        hc = x3_crc_be32(hc, 0x78330101u);
+        hc = x3_crc_be32(hc, ((n & 0xFFFFu) << 16) | (L & 0xFFFFu));
+        hc = x3_crc_be32(hc, 0);
+        hc = x3_crc_be32(hc, 0);
+        part[50] = hc;
       }
     } else {
       // zero the image words this frame uses (header + payload, rounded up to 16 bytes)
@@ -351,6 +401,7 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
       }
       if (valid && cnt != 20) atomicSub(&part[32 + type], 20u - cnt);
     }
+    if (helper) x3_dma_wait();  // the next frame's samples have landed in LDS
     __syncthreads();  // B3: emission complete, next frame's samples landed
 
     uint32_t crc = 0;
@@ -436,16 +487,12 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
           uint32_t v = 0;
 #pragma unroll
           for (uint32_t w = 0; w < 8; ++w) v ^= part[16 + w];
-          if (L & 2u) v = x3_gf_mul(v, xpow[X3_XINV16_INDEX]);  // undo the 2 virtual pad-to-4 bytes
+          if (L & 2u) v = x3_gf_mul_const<X3_XINV16_C>(v);  // undo the 2 virtual pad-to-4 bytes
           // frame header (encoder.rs:122-162): "x3", id, id, samples, payload_len, 8 zero time bytes,
-          // header crc over bytes 0..16, payload crc; audio frames use id 1 (encoder.rs:210)
+          // header crc over bytes 0..16 (computed by the helper wave), payload crc; audio frames use id 1
           const uint32_t h0 = 0x78330101u;
           const uint32_t h1 = ((n & 0xFFFFu) << 16) | (L & 0xFFFFu);
-          uint32_t hc = 0xFFFFu;
-          hc = x3_crc_be32(hc, h0);
-          hc = x3_crc_be32(hc, h1);
-          hc = x3_crc_be32(hc, 0);
-          hc = x3_crc_be32(hc, 0);
+          const uint32_t hc = part[50];
           img[0] = x3_bswap32(h0);
           img[1] = x3_bswap32(h1);
           img[2] = 0;
