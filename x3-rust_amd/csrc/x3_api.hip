@@ -43,7 +43,8 @@ struct x3_ctx {
   std::string last_error;
   // persistent small device state
   uint16_t* d_xpow = nullptr;          // X3_XP_SIZE entries
-  uint16_t* d_xk = nullptr;            // [10][512]: x^(32*c*(511-t)) mod P (x3_encode_stream_kernel.h)
+  uint32_t* d_xk16 = nullptr;          // [10][512][16]: x^(32*c*(511-t)) * x^b mod P (x3_encode_stream_kernel.h)
+  uint16_t* d_crctab = nullptr;        // [4][256] slicing-by-4 CRC tables
   int* d_status = nullptr;             // [0] size/scan pass, [1] encode pass
   unsigned long long* d_stats = nullptr;    // 6
   unsigned long long* d_end_pos = nullptr;  // 1
@@ -62,6 +63,10 @@ struct x3_ctx {
   int stream_wg_per_cu = -1;  // co-resident workgroups per CU of x3_encode_stream_kernel (-1 = not queried)
   // bookkeeping of the last async calls
   bool encode_pending = false, decode_pending = false;
+  bool force_two_pass = false;
+  struct {
+    const int16_t* d_wav; x3_batch b; x3_params p; uint64_t spf; uint8_t* d_out; uint64_t out_cap, start_pos; uint64_t* d_off;
+  } last_enc;
   uint64_t enc_start_pos = 0;
   uint64_t dec_frames = 0;
   // kernel timing
@@ -161,11 +166,25 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
   }
   HIPCHK(c, hipMemcpy(c->d_xpow, xp.data(), X3_XP_SIZE * sizeof(uint16_t), hipMemcpyHostToDevice));
   {
-    std::vector<uint16_t> xk(10 * 512);
+    std::vector<uint32_t> xk((size_t)10 * 512 * 16);
     for (int cd = 1; cd <= 10; ++cd)
-      for (int t = 0; t < 512; ++t) xk[(cd - 1) * 512 + t] = (uint16_t)gf_xpow_host(32ull * cd * (511 - t));
-    HIPCHK(c, hipMalloc(&c->d_xk, xk.size() * sizeof(uint16_t)));
-    HIPCHK(c, hipMemcpy(c->d_xk, xk.data(), xk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+      for (int t = 0; t < 512; ++t) {
+        uint32_t k = gf_xpow_host(32ull * cd * (511 - t));
+        for (int b = 0; b < 16; ++b) {
+          xk[((size_t)(cd - 1) * 512 + t) * 16 + b] = k;
+          k = ((k << 1) ^ ((k & 0x8000u) ? 0x11021u : 0u)) & 0xFFFFu;
+        }
+      }
+    HIPCHK(c, hipMalloc(&c->d_xk16, xk.size() * sizeof(uint32_t)));
+    HIPCHK(c, hipMemcpy(c->d_xk16, xk.data(), xk.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    // T[j][v] = crc0 of byte v followed by j zero bytes = v * x^(8j+16) mod P
+    std::vector<uint16_t> tab(4 * 256);
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t sh = gf_xpow_host(8ull * j + 16);
+      for (int v = 0; v < 256; ++v) tab[j * 256 + v] = (uint16_t)gf_mul_host((uint32_t)v, sh);
+    }
+    HIPCHK(c, hipMalloc(&c->d_crctab, tab.size() * sizeof(uint16_t)));
+    HIPCHK(c, hipMemcpy(c->d_crctab, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   }
   return X3_OK;
 }
@@ -210,7 +229,8 @@ extern "C" void x3_ctx_destroy(x3_ctx* c) {
     for (auto& e : t.pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   }
   (void)hipFree(c->d_xpow);
-  (void)hipFree(c->d_xk);
+  (void)hipFree(c->d_xk16);
+  (void)hipFree(c->d_crctab);
   (void)hipFree(c->d_status);
   (void)hipFree(c->d_stats);
   (void)hipFree(c->d_summary);
@@ -511,7 +531,9 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
   // ---- single-pass path: default block length, 16-byte aligned frames (see x3_encode_stream_kernel.h)
   const bool stream_path = p->block_len == 20 && pl.nthr == 512 && (spf % 8) == 0 &&
                            (b->n_clips == 1 || (b->clip_stride % 8) == 0) &&
-                           (reinterpret_cast<uintptr_t>(d_wav) & 15u) == 0 && !std::getenv("X3HIP_TWO_PASS");
+                           (reinterpret_cast<uintptr_t>(d_wav) & 15u) == 0 && !c->force_two_pass &&
+                           !std::getenv("X3HIP_TWO_PASS");
+  c->last_enc = {d_wav, *b, *p, spf, d_out, out_cap, start_pos, d_frame_offsets};
   if (stream_path) {
     if (c->stream_wg_per_cu < 0) {
       // The look-back waits on predecessors, so EVERY workgroup of the grid must be resident.  The
@@ -519,26 +541,27 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
       // capped by a conservative count from the kernel's own register/LDS footprint: 9 waves per
       // workgroup land unevenly on the 4 SIMDs, hence the slack of 3 waves.
       int nb = 0;
-      HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, x3_encode_stream_kernel, X3_STREAM_THREADS, pl.smem));
+      HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, x3_encode_stream_kernel, X3_STREAM_THREADS,
+                                                             pl.smem + 2048));
       hipFuncAttributes fa;
       HIPCHK(c, hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&x3_encode_stream_kernel)));
       const int alloc = ((fa.numRegs + 7) / 8) * 8;
       const int wps = std::min(8, 512 / std::max(alloc, 8));
       const int by_regs = (4 * wps - 3) / 9;
-      const int by_lds = (int)((160 * 1024) / pl.smem);
+      const int by_lds = (int)((160 * 1024) / (pl.smem + 2048));
       c->stream_wg_per_cu = std::max(0, std::min(std::min(nb, 4), std::min(by_regs, by_lds)));
     }
-    if (c->stream_wg_per_cu >= 1 && pl.smem <= 64 * 1024) {
+    if (c->stream_wg_per_cu >= 1 && pl.smem + 2048 <= 64 * 1024) {
       if ((rc = ensure(c, c->desc, F * sizeof(unsigned long long)))) return rc;
       HIPCHK(c, hipMemsetAsync(c->desc.p, 0, F * sizeof(unsigned long long), c->stream));
       // persistent grid: every workgroup must be resident (the look-back waits on predecessors)
       const uint64_t grid = std::min<uint64_t>(F, (uint64_t)c->n_cus * c->stream_wg_per_cu);
       {
         TimerScope ts(c, 0);
-        hipLaunchKernelGGL(x3_encode_stream_kernel, dim3((unsigned)grid), dim3(X3_STREAM_THREADS), pl.smem, c->stream, d_wav, pl.g,
+        hipLaunchKernelGGL(x3_encode_stream_kernel, dim3((unsigned)grid), dim3(X3_STREAM_THREADS), pl.smem + 2048, c->stream, d_wav, pl.g,
                            pl.dp, d_off, d_out, out_cap, start_pos, (unsigned long long*)c->desc.p, c->d_stats,
-                           c->d_status, c->d_end_pos, (const uint16_t*)c->d_xpow, (const uint16_t*)c->d_xk, pl.lds_in_bytes,
-                           pl.img_dwords);
+                           c->d_status, c->d_end_pos, (const uint16_t*)c->d_xpow, (const uint32_t*)c->d_xk16,
+                           (const uint16_t*)c->d_crctab, pl.lds_in_bytes, pl.img_dwords);
       }
       HIPCHK(c, hipGetLastError());
       HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_status, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -590,11 +613,25 @@ extern "C" int x3_encode_dev(x3_ctx* c, const int16_t* d_wav, const x3_batch* ba
   return encode_dev_impl(c, d_wav, batch, p, spf_of(p), d_out, out_cap, start_pos, d_frame_offsets);
 }
 
+static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3_params* p, uint64_t spf,
+                           uint8_t* d_out, uint64_t out_cap, uint64_t start_pos, uint64_t* d_frame_offsets);
+
 extern "C" int x3_encode_result(x3_ctx* c, uint64_t* out_pos, uint64_t stats[6]) {
   if (!c) return X3_ERR_BAD_ARG;
   if (!c->encode_pending) return X3_ERR_BAD_ARG;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->encode_pending = false;
+  if (c->h_status[1] == X3D_LOOKBACK_TIMEOUT) {
+    // the single-pass kernel's workgroups were not all resident (GPU shared with other work): its
+    // bounded look-back spin gave up.  Encode again with the two-pass kernels, which need no residency.
+    c->force_two_pass = true;
+    auto a = c->last_enc;
+    int rc = encode_dev_impl(c, a.d_wav, &a.b, &a.p, a.spf, a.d_out, a.out_cap, a.start_pos, a.d_off);
+    c->force_two_pass = false;
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->encode_pending = false;
+  }
   if (out_pos) *out_pos = c->h_stats[6];
   if (stats)
     for (int i = 0; i < 6; ++i) stats[i] = c->h_stats[i];

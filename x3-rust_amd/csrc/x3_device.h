@@ -86,6 +86,18 @@ __device__ __forceinline__ uint32_t x3_xp(const uint16_t* __restrict__ xpow, int
 // ---------------------------------------------------------------------------------------------
 // wave / workgroup scans
 // ---------------------------------------------------------------------------------------------
+// DPP form (no LDS round trips): Hillis-Steele inside each row of 16 lanes with row_shr, then
+// row_bcast:15 / row_bcast:31 carry the row totals across rows (gfx9 DPP controls).
+__device__ __forceinline__ uint32_t x3_wave_incl_scan_dpp(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);  // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);  // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);  // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);  // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1,3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2,3
+  return v;
+}
+
 __device__ __forceinline__ uint32_t x3_wave_incl_scan(uint32_t v, int lane) {
 #pragma unroll
   for (int d = 1; d < X3_WAVE; d <<= 1) {

@@ -28,6 +28,7 @@
 #define X3_DESC_SHIFT 62
 #define X3_DESC_MASK ((1ull << X3_DESC_SHIFT) - 1ull)
 #define X3_SPIN_LIMIT (1u << 21)  // ~0.1 s of polling: a bounded spin, never a hang
+#define X3D_LOOKBACK_TIMEOUT 100  // internal: the host re-runs the two-pass encoder (x3_encode_result)
 
 typedef short x3_short2 __attribute__((ext_vector_type(2)));
 typedef unsigned short x3_ushort2 __attribute__((ext_vector_type(2)));
@@ -130,7 +131,7 @@ __device__ __forceinline__ void x3_stage_frame_dma(const int16_t* __restrict__ s
 }
 
 #ifndef X3_STREAM_MIN_WAVES
-#define X3_STREAM_MIN_WAVES 5
+#define X3_STREAM_MIN_WAVES 6  // <= 80 VGPRs: two 9-wave workgroups per CU
 #endif
 __global__ void __launch_bounds__(X3_STREAM_THREADS, X3_STREAM_MIN_WAVES)
 x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p,
@@ -138,13 +139,16 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
                         uint64_t start_pos, unsigned long long* __restrict__ desc,
                         unsigned long long* __restrict__ stats, int* __restrict__ status,
                         unsigned long long* __restrict__ end_pos, const uint16_t* __restrict__ xpow,
-                        const uint16_t* __restrict__ xk, uint32_t lds_in_bytes, uint32_t img_dwords) {
+                        const uint32_t* __restrict__ xk16, const uint16_t* __restrict__ crc_tab_g, uint32_t lds_in_bytes,
+                        uint32_t img_dwords) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // part: [0..7] scan partials, [16..23] CRC partials, [32..37] stats, [40] bad, [48..49] frame offset
   uint32_t* part = reinterpret_cast<uint32_t*>(smem);
   int16_t* in_s = reinterpret_cast<int16_t*>(smem + X3_ENC_SMEM_HDR);
   const uint32_t* in_w = reinterpret_cast<const uint32_t*>(smem + X3_ENC_SMEM_HDR);
   uint32_t* img = reinterpret_cast<uint32_t*>(smem + X3_ENC_SMEM_HDR + lds_in_bytes);
+  // slicing-by-4 CRC tables behind the image: T[j][v] = crc0 of byte v followed by j zero bytes
+  uint16_t* crc_tab = reinterpret_cast<uint16_t*>(img + img_dwords);
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u, wid = tid >> 6;
@@ -163,6 +167,7 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
 
   // ---- prologue: the first frame is staged by the helper wave
   if (tid < 64) part[tid] = 0;
+  if (tid < 512) reinterpret_cast<uint32_t*>(crc_tab)[tid] = reinterpret_cast<const uint32_t*>(crc_tab_g)[tid];
   if (helper && blockIdx.x < g.n_frames) {
     const int16_t* src;
     uint32_t n;
@@ -291,7 +296,7 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
     }
 
     // ---- C: workgroup exclusive scan of bit lengths
-    const uint32_t incl = x3_wave_incl_scan(nbits, lane);
+    const uint32_t incl = x3_wave_incl_scan_dpp(nbits);
     if (lane == 63 && !helper) part[wid] = incl;
     if (bad) part[40] = 1;
     __syncthreads();  // B1: partials ready; every compute lane holds its block in registers, in_s is free
@@ -354,8 +359,7 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
             uint32_t la = ((a >> qsh) & qmask) + lbase, lc = ((c >> qsh) & qmask) + lbase;
             uint32_t ca = (a & amask) | orc, cc = (c & amask) | orc;
             if (j == 9) { lc &= last_on; cc &= last_on; }  // a 19-sample block has no sample 20
-            e.acc = (e.acc << la) | ca;
-            e.acc = (e.acc << lc) | cc;
+            e.acc = (e.acc << (la + lc)) | (unsigned long long)((ca << lc) | cc);  // la + lc <= 32
             e.cnt += la + lc;
             if (e.cnt >= 32u) {
               const uint32_t word = (uint32_t)(e.acc >> (e.cnt - 32u));
@@ -393,13 +397,9 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
           e.finish();
         }
       }
-      // statistics (encoder.rs:199): stats[type] += block.len(); accumulated in LDS over all frames
-#pragma unroll
-      for (uint32_t t = 0; t < 6; ++t) {
-        const unsigned long long m = __ballot(valid && type == t);
-        if (lane == 0 && m) atomicAdd(&part[32 + t], (uint32_t)__popcll(m) * 20u);
-      }
-      if (valid && cnt != 20) atomicSub(&part[32 + type], 20u - cnt);
+      // statistics (encoder.rs:199): stats[type] += block.len(); one LDS atomic per lane, summed over
+      // all frames of this workgroup and flushed once at the end
+      if (cnt) atomicAdd(&part[32 + type], cnt);
     }
     if (helper) x3_dma_wait();  // the next frame's samples have landed in LDS
     __syncthreads();  // B3: emission complete, next frame's samples landed
@@ -437,7 +437,7 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
           else look -= 64;
         }
         if (timeout) {
-          if (lane == 0) atomicMax(&status[1], X3D_BAD_ARG);
+          if (lane == 0) atomicMax(&status[1], X3D_LOOKBACK_TIMEOUT);
           run = 0;
         }
         if (lane == 0)
@@ -455,22 +455,28 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
       const uint32_t Lw = (L + 3u) >> 2;
       const uint32_t c_dw = (Lw + nthr - 1) / nthr;  // 1..10 on this path
       const int32_t j0 = (int32_t)(tid * c_dw) - (int32_t)(nthr * c_dw - Lw);
-      uint32_t kt = xk[(c_dw - 1u) * 512u + tid];
+      // this lane's multiplier x^(32*c_dw*(511-tid)), as its sixteen shifts K*x^b (requested now, used below)
+      const uint4* kp = reinterpret_cast<const uint4*>(xk16 + ((size_t)(c_dw - 1u) * 512u + tid) * 16u);
+      const uint4 kq0 = kp[0], kq1 = kp[1], kq2 = kp[2], kq3 = kp[3];
       for (uint32_t i = 0; i < c_dw; ++i) {
         const int32_t j = j0 + (int32_t)i;
         if (j >= 0) {
           uint32_t be = x3_bswap32(img[5 + j]);
           if (j == 0) be ^= 0xFFFF0000u;  // CRC init 0xFFFF folded into the first 16 message bits
-          crc = x3_crc_be32(crc, be);
+          // slicing-by-4: fold the running CRC into the top 16 message bits, one table per byte
+          const uint32_t m = be ^ (crc << 16);
+          crc = (uint32_t)crc_tab[768u + (m >> 24)] ^ (uint32_t)crc_tab[512u + ((m >> 16) & 0xFFu)] ^
+                (uint32_t)crc_tab[256u + ((m >> 8) & 0xFFu)] ^ (uint32_t)crc_tab[m & 0xFFu];
         }
       }
-      uint32_t r = 0;
+      {
+        const uint32_t kk[16] = {kq0.x, kq0.y, kq0.z, kq0.w, kq1.x, kq1.y, kq1.z, kq1.w,
+                                 kq2.x, kq2.y, kq2.z, kq2.w, kq3.x, kq3.y, kq3.z, kq3.w};
+        uint32_t r = 0;
 #pragma unroll
-      for (int bit = 0; bit < 16; ++bit) {
-        r ^= (0u - ((crc >> bit) & 1u)) & kt;
-        kt = (kt << 1) ^ ((0u - ((kt >> 15) & 1u)) & 0x11021u);
+        for (int bit = 0; bit < 16; ++bit) r ^= (0u - ((crc >> bit) & 1u)) & kk[bit];
+        crc = r;
       }
-      crc = r & 0xFFFFu;
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) crc ^= __shfl_xor(crc, o, X3_WAVE);
       if (lane == 0) part[16 + wid] = crc;
@@ -537,7 +543,7 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
   }
   __syncthreads();
   if (tid < 6) {
-    const uint32_t v = part[32 + tid];
+    const uint32_t v = part[32 + tid];  // < 2^32: at most 135 frames x 10 000 samples per workgroup... see host check
     if (v) atomicAdd(&stats[tid], (unsigned long long)v);
   }
 }
