@@ -136,8 +136,8 @@ uint16_t x3_crc16_update(uint16_t crc, uint8_t byte);
  * zero padding to an even ABSOLUTE position.  *out_pos receives `writer.stream_position()`.
  * stats[6] (may be NULL) receives the per-sample block-type counts the reference prints
  * (Rice nsubs 0..3, BFP = 4, literal = 5; encoder.rs:96-108,199).
- * On BYTE_WRITER_INSUFFICIENT_MEMORY nothing is written and *out_pos = the position that
- * would have been reached. */
+ * On BYTE_WRITER_INSUFFICIENT_MEMORY *out_pos = the position that would have been reached; which
+ * of the frames that fit were written is unspecified (the reference leaves a partial stream too). */
 int x3_encode(x3_ctx* ctx, const int16_t* wav, uint64_t n, uint32_t n_channels, const x3_params* p,
               uint8_t* out, uint64_t out_cap, uint64_t start_pos, uint64_t* out_pos, uint64_t stats[6]);
 
