@@ -351,6 +351,46 @@ def test_encode_batch(ctx, x3):
         assert np.array_equal(out[offs[i]:offs[i + 1]], O.encode(c)[1])
 
 
+def test_device_batch_roundtrip(ctx, x3):
+    """BASELINE config 5 in miniature: a uniform batch of clips resident in HBM (with padding between
+    clips), encoded by one launch set and decoded from the encoder's frame index."""
+    n_clips, n_per, stride = 9, 57_603, 57_608
+    p = x3.Params.default()
+    clips = [x3.synth(2 + (i % 3 == 2) * 2, 500 + i, 0, n_per) for i in range(n_clips)]
+    host = np.zeros(n_clips * stride, dtype=np.int16)
+    for i, c in enumerate(clips):
+        host[i * stride:i * stride + n_per] = c
+    d_wav = ctx.alloc(host.nbytes)
+    ctx.upload(d_wav, host)
+    fpc = (n_per + p.spf - 1) // p.spf
+    F = fpc * n_clips
+    cap = sum(x3.lib().x3_encode_bound(n_per, C.byref(p)) for _ in range(n_clips)) + 16
+    d_out = ctx.alloc(cap)
+    d_off = ctx.alloc(8 * (F + 1))
+    assert ctx.encode_dev(d_wav, n_per, p, d_out, cap, 0, d_off, n_clips=n_clips, clip_stride=stride) == 0
+    rc, pos, stats = ctx.encode_result()
+    assert rc == 0
+    offs = ctx.download(d_off, 8 * (F + 1), np.uint64)
+    stream = ctx.download(d_out, (pos + 3) & ~3)[:pos]
+    tot = np.zeros(6, dtype=np.uint64)
+    for i, c in enumerate(clips):
+        rc_o, o, st = O.encode(c)
+        assert np.array_equal(stream[int(offs[i * fpc]):int(offs[(i + 1) * fpc])], o), i
+        tot += st
+    assert stats.tolist() == tot.tolist()
+    d_back = ctx.alloc(host.nbytes)
+    ctx.upload(d_back, np.full(host.size, 12345, dtype=np.int16))
+    assert ctx.decode_dev(d_out, pos, d_off, F, p, d_back, host.size, n_per_clip=n_per, n_clips=n_clips,
+                          clip_stride=stride) == 0
+    assert ctx.decode_result() == (0, F, 0, n_per * n_clips)
+    back = ctx.download(d_back, host.nbytes, np.int16)
+    for i, c in enumerate(clips):
+        assert np.array_equal(back[i * stride:i * stride + n_per], c)
+        assert (back[i * stride + n_per:(i + 1) * stride] == 12345).all()  # the padding is untouched
+    for d in (d_wav, d_out, d_off, d_back):
+        ctx.free(d)
+
+
 def test_synth_host_equals_device(ctx, x3):
     n = 100000
     d = ctx.alloc(2 * n)

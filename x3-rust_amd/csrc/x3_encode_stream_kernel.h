@@ -312,7 +312,72 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
     const uint32_t L = (((total_bits + 7u) >> 3) + 1u) & ~1u;  // word_align (bitpacker.rs:124-132)
     const uint32_t frame_bytes = 20u + L;
     const bool frame_bad = part[40] != 0;
+    auto lookback = [&]() {
+      // ---- F1: decoupled look-back: sum predecessors' sizes back to the nearest inclusive prefix
+      unsigned long long run = base_pos;
+      if (f > 0) {
+        run = 0;
+        uint64_t look = f;  // descriptors [look-64, look) are inspected next
+        uint32_t spins = 0;
+        bool done = false, timeout = false;
+        while (!done) {
+          const bool in_range = look > lane;
+          const uint64_t gi = in_range ? look - 1 - lane : 0;
+          const unsigned long long d =
+              in_range ? __hip_atomic_load(&desc[gi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                       : (X3_DESC_PREFIX << X3_DESC_SHIFT) | base_pos;  // virtual frame -1
+          const uint32_t state = (uint32_t)(d >> X3_DESC_SHIFT);
+          const unsigned long long m_inv = __ballot(state == 0);
+          const unsigned long long m_pre = __ballot(state == (uint32_t)X3_DESC_PREFIX);
+          const int first_pre = m_pre ? __ffsll((long long)m_pre) - 1 : 64;
+          const unsigned long long need = first_pre >= 64 ? ~0ull : ((1ull << first_pre) - 1ull);
+          if (m_inv & need) {  // a nearer predecessor has not published its size yet
+            // wait for the NEAREST missing descriptor with a single lane (64x less polling traffic than
+            // re-reading the whole window: pollers slow everybody's memory traffic), then look again
+            const int miss = __ffsll((long long)(m_inv & need)) - 1;
+            if ((int)lane == miss) {
+              unsigned long long dd = 0;
+              while ((dd >> X3_DESC_SHIFT) == 0 && ++spins <= X3_SPIN_LIMIT) {
+                __builtin_amdgcn_s_sleep(2);
+                dd = __hip_atomic_load(&desc[gi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+            }
+            spins = __shfl(spins, miss, X3_WAVE);
+            if (spins > X3_SPIN_LIMIT) { timeout = true; break; }
+            continue;
+          }
+          unsigned long long v = ((int)lane <= first_pre) ? (d & X3_DESC_MASK) : 0ull;
+#pragma unroll
+          for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, X3_WAVE);
+          run += v;
+          if (first_pre < 64) done = true;
+          else look -= 64;
+        }
+        if (timeout) {
+          if (lane == 0) atomicMax(&status[1], X3D_LOOKBACK_TIMEOUT);
+          run = 0;
+        }
+        if (lane == 0)
+          __hip_atomic_store(&desc[f], (X3_DESC_PREFIX << X3_DESC_SHIFT) | (run + frame_bytes), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (lane == 0) {
+        part[48] = (uint32_t)run;
+        part[49] = (uint32_t)(run >> 32);
+      }
+    };
     if (helper) {
+      // prefetch the next frame of this workgroup straight into LDS (in_s is free: every block is in
+      // registers); the requests are hidden from hipcc and waited for before B3
+      {
+        const uint64_t fn = f + gridDim.x;
+        if (fn < g.n_frames) {
+          const int16_t* nsrc;
+          uint32_t nn;
+          frame_geom(fn, nsrc, nn);
+          x3_stage_frame_dma(nsrc, nn, in_s, lane);
+        }
+      }
       // publish this frame's size as early as possible (successors' look-backs sum these)
       if (lane == 0) {
         const unsigned long long d = f == 0 ? ((X3_DESC_PREFIX << X3_DESC_SHIFT) | (base_pos + frame_bytes))
@@ -336,14 +401,9 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
     __syncthreads();  // B2: image zeroed
 
     if (helper) {
-      // prefetch the next frame of this workgroup straight into LDS while the others emit
-      const uint64_t fn = f + gridDim.x;
-      if (fn < g.n_frames) {
-        const int16_t* nsrc;
-        uint32_t nn;
-        frame_geom(fn, nsrc, nn);
-        x3_stage_frame_dma(nsrc, nn, in_s, lane);
-      }
+#ifdef X3_LB_EARLY
+      lookback();
+#endif
     } else {
       if (tid == 0) atomicOr(&img[5], x3_bswap32(s_first << 16));  // <Audio State> (encoder.rs:189)
       // ---- D: emission
@@ -406,48 +466,9 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
 
     uint32_t crc = 0;
     if (helper) {
-      // ---- F1: decoupled look-back: sum predecessors' sizes back to the nearest inclusive prefix
-      unsigned long long run = base_pos;
-      if (f > 0) {
-        run = 0;
-        uint64_t look = f;  // descriptors [look-64, look) are inspected next
-        uint32_t spins = 0;
-        bool done = false, timeout = false;
-        while (!done) {
-          const bool in_range = look > lane;
-          const uint64_t gi = in_range ? look - 1 - lane : 0;
-          const unsigned long long d =
-              in_range ? __hip_atomic_load(&desc[gi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                       : (X3_DESC_PREFIX << X3_DESC_SHIFT) | base_pos;  // virtual frame -1
-          const uint32_t state = (uint32_t)(d >> X3_DESC_SHIFT);
-          const unsigned long long m_inv = __ballot(state == 0);
-          const unsigned long long m_pre = __ballot(state == (uint32_t)X3_DESC_PREFIX);
-          const int first_pre = m_pre ? __ffsll((long long)m_pre) - 1 : 64;
-          const unsigned long long need = first_pre >= 64 ? ~0ull : ((1ull << first_pre) - 1ull);
-          if (m_inv & need) {  // a nearer predecessor has not published its size yet
-            if (++spins > X3_SPIN_LIMIT) { timeout = true; break; }
-            __builtin_amdgcn_s_sleep(1);
-            continue;
-          }
-          unsigned long long v = ((int)lane <= first_pre) ? (d & X3_DESC_MASK) : 0ull;
-#pragma unroll
-          for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, X3_WAVE);
-          run += v;
-          if (first_pre < 64) done = true;
-          else look -= 64;
-        }
-        if (timeout) {
-          if (lane == 0) atomicMax(&status[1], X3D_LOOKBACK_TIMEOUT);
-          run = 0;
-        }
-        if (lane == 0)
-          __hip_atomic_store(&desc[f], (X3_DESC_PREFIX << X3_DESC_SHIFT) | (run + frame_bytes), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if (lane == 0) {
-        part[48] = (uint32_t)run;
-        part[49] = (uint32_t)(run >> 32);
-      }
+#ifndef X3_LB_EARLY
+      lookback();
+#endif
     } else {
       // ---- E: payload CRC-16 as a segmented reduction:
       // crc0(payload) = XOR over lanes t of crc0(chunk_t) * x^(32*c_dw*(511-t)) mod P; each lane
