@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--samples", type=int, default=N_SAMPLES, help="samples per GPU (default: config 3)")
     ap.add_argument("--kind", type=int, default=2, help="synthetic signal (2 = hydrophone noise)")
     ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="samples timed on the CPU baseline")
-    ap.add_argument("--cpu-reps", type=int, default=2)
+    ap.add_argument("--cpu-reps", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     args = ap.parse_args()

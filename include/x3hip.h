@@ -175,6 +175,26 @@ int x3_decode_frame(x3_ctx* ctx, const uint8_t* payload, uint64_t len, int16_t* 
 int x3_decode_stream(x3_ctx* ctx, const uint8_t* x3, uint64_t len, const x3_params* p, int16_t* wav,
                      uint64_t wav_cap, uint64_t* n_out, uint64_t* frames_ok, uint64_t* frame_errors);
 
+/* ------------------------------------------------------------------ .x3a archive (encodefile.rs / decodefile.rs) */
+
+/* `create_archive_header` (src/encodefile.rs:82-138): "X3ARCHIV" + a frame header with id 0 / 0 samples
+ * + the XML configuration (zero-padded to even length).  Host arithmetic.  *out_len = bytes written. */
+int x3_archive_header_write(uint32_t sample_rate, const x3_params* p, uint8_t* out, uint64_t out_cap,
+                            uint64_t* out_len);
+/* `read_archive_header` + `parse_xml` (src/decodefile.rs:142-176,232-303).  *header_size is what the
+ * reference returns (20 + XML payload, NOT counting the 8-byte id); the audio frames start at
+ * 8 + *header_size.  blocks_per_frame is the default (the XML does not carry it). */
+int x3_archive_header_read(const uint8_t* bytes, uint64_t len, uint32_t* sample_rate, x3_params* p,
+                           uint8_t* channels, uint64_t* header_size);
+/* `wav_to_x3a` without the file I/O (src/encodefile.rs:48-77): archive header + `encode` of one 16-bit
+ * mono channel with default parameters, into out[0..out_cap). */
+int x3_x3a_encode(x3_ctx* ctx, const int16_t* wav, uint64_t n, uint32_t sample_rate, uint8_t* out,
+                  uint64_t out_cap, uint64_t* out_len, uint64_t stats[6]);
+/* `x3a_to_wav` without the file I/O (src/decodefile.rs:189-212 with X3aReader, :59-136): archive header,
+ * then the frame walk with the reader's own byte accounting. */
+int x3_x3a_decode(x3_ctx* ctx, const uint8_t* x3a, uint64_t len, int16_t* wav, uint64_t wav_cap,
+                  uint64_t* n_out, uint32_t* sample_rate, uint64_t* frames_ok, uint64_t* frame_errors);
+
 /* ------------------------------------------------------------------ device-resident API */
 
 /* Geometry of a uniform batch resident in HBM: n_clips clips of n_per_clip samples, clip c

@@ -554,19 +554,34 @@ int x3o_decode_frame(const uint8_t* x3_bytes, size_t len, int16_t* wav_buf, size
 
 /* X3aReader::decode_next_frame (src/decodefile.rs:105-136) + read_bytes (:80-86) +
  * read_frame_payload (:93-103), looped as x3a_to_wav does (:200-209), over memory. */
+static int decode_stream_phantom(const uint8_t* x3, uint64_t len, uint64_t phantom, const x3o_params* p,
+                                 int16_t* wav, uint64_t wav_cap, uint64_t* n_out, uint64_t* frames_ok,
+                                 uint64_t* frame_errors);
+
 int x3o_decode_stream(const uint8_t* x3, uint64_t len, const x3o_params* p, int16_t* wav,
                       uint64_t wav_cap, uint64_t* n_out, uint64_t* frames_ok, uint64_t* frame_errors) {
+  return decode_stream_phantom(x3, len, 0, p, wav, wav_cap, n_out, frames_ok, frame_errors);
+}
+
+/* `phantom` = bytes X3aReader believes remain beyond the real data: open() subtracts the archive
+ * header WITHOUT its 8-byte id from the file length (decodefile.rs:61-66), and read_bytes clamps only
+ * to that count (:80-86), so a read past the real end is a read_exact failure = X3Error::Io. */
+static int decode_stream_phantom(const uint8_t* x3, uint64_t len, uint64_t phantom, const x3o_params* p,
+                                 int16_t* wav, uint64_t wav_cap, uint64_t* n_out, uint64_t* frames_ok,
+                                 uint64_t* frame_errors) {
   x3o_init();
-  uint64_t pos = 0, remaining = len, nsamp = 0, nframes = 0, nerr = 0;
+  uint64_t pos = 0, remaining = len + phantom, nsamp = 0, nframes = 0, nerr = 0;
   int rc = X3O_OK;
   for (;;) {
     if (remaining <= 20) break;                                   /* :107-109 */
+    if (len - pos < 20) { rc = X3O_IO; break; }
     x3o_frame_header h;
     rc = x3o_read_frame_header(x3 + pos, 20, &h);                 /* :112 */
     pos += 20; remaining -= 20;
     if (rc) break;
     if (remaining < h.payload_len) break;                         /* :114-116, Ok(None) */
     if (h.payload_len > 1024 * 24) { rc = X3O_FRAME_HEADER_INVALID_PAYLOAD_LEN; break; } /* :118-121 */
+    if (len - pos < h.payload_len) { rc = X3O_IO; break; }
     const uint8_t* payload = x3 + pos;
     pos += h.payload_len; remaining -= h.payload_len;
     if (x3o_crc16(payload, h.payload_len) != h.payload_crc) {     /* :96-100 */
@@ -585,6 +600,167 @@ int x3o_decode_stream(const uint8_t* x3, uint64_t len, const x3o_params* p, int1
   if (frames_ok) *frames_ok = nframes;
   if (frame_errors) *frame_errors = nerr;
   return rc;
+}
+
+/* ----------------------------------------------- encodefile.rs / decodefile.rs: archive */
+
+#include <stdio.h>
+
+/* src/encodefile.rs:82-138 */
+int x3o_archive_header_write(uint32_t sample_rate, const x3o_params* p, uint8_t* out, uint64_t cap,
+                             uint64_t* out_len) {
+  x3o_init();
+  char xml[600];
+  int n = snprintf(xml, sizeof xml,
+                   "<X3ARCH PROG=\"x3new.m\" VERSION=\"2.0\" />"
+                   "<CFG ID=\"0\" FTYPE=\"XML\" />"
+                   "<CFG ID=\"1\" FTYPE=\"WAV\">"
+                   "<FS UNIT=\"Hz\">%u</FS>"
+                   "<SUFFIX>wav</SUFFIX>"
+                   "<CODEC TYPE=\"X3\" VERS=\"2\">"
+                   "<BLKLEN>%u</BLKLEN>"
+                   "<CODES N=\"4\">RICE%u,RICE%u,RICE%u,BFP</CODES>"
+                   "<FILTER>DIFF</FILTER>"
+                   "<NBITS>16</NBITS>"
+                   "<T N=\"3\">%u,%u,%u</T>"
+                   "</CODEC>"
+                   "</CFG>",
+                   sample_rate, p->block_len, p->codes[0], p->codes[1], p->codes[2], p->thresholds[0],
+                   p->thresholds[1], p->thresholds[2]);
+  size_t payload_len = (size_t)n;
+  uint16_t payload_crc = x3o_crc16((const uint8_t*)xml, payload_len);
+  if (payload_len % 2 == 1) {                     /* :123-128 */
+    xml[payload_len++] = 0;
+    payload_crc = x3o_update_crc16(payload_crc, 0);
+  }
+  uint64_t total = 8 + 20 + payload_len;
+  if (out_len) *out_len = total;
+  if (total > cap) return X3O_BYTE_WRITER_INSUFFICIENT_MEMORY;
+  memcpy(out, "X3ARCHIV", 8);                     /* Archive::ID, src/x3.rs:139 */
+  x3o_write_frame_header(0, 0, payload_len, payload_crc, out + 8);   /* :134 */
+  memcpy(out + 28, xml, payload_len);
+  return X3O_OK;
+}
+
+static int xml_first_text(const char* xml, size_t len, const char* name, char* text, size_t cap) {
+  size_t nl = strlen(name);
+  for (size_t i = 0; i + nl + 1 < len; i++) {
+    if (xml[i] != '<' || memcmp(xml + i + 1, name, nl) != 0) continue;
+    char nx = xml[i + 1 + nl];
+    if (!(nx == '>' || nx == ' ' || nx == '\t' || nx == '\n' || nx == '\r')) continue;
+    size_t gt = i + 1 + nl;
+    while (gt < len && xml[gt] != '>') gt++;
+    if (gt >= len || xml[gt - 1] == '/') return 0;
+    for (size_t c = gt + 1; c + nl + 3 <= len; c++) {
+      if (xml[c] == '<' && xml[c + 1] == '/' && memcmp(xml + c + 2, name, nl) == 0 && xml[c + 2 + nl] == '>') {
+        size_t a = gt + 1, b = c;
+        while (a < b && strchr(" \t\r\n", xml[a])) a++;
+        while (b > a && strchr(" \t\r\n", xml[b - 1])) b--;
+        if (b - a + 1 > cap) return 0;
+        memcpy(text, xml + a, b - a);
+        text[b - a] = 0;
+        return 1;
+      }
+    }
+    return 0;
+  }
+  return 0;
+}
+
+static int parse_u32(const char* s, size_t n, uint32_t* v) {
+  if (n == 0 || n > 10) return 0;
+  size_t i = s[0] == '+' ? 1 : 0;
+  if (i == n) return 0;
+  uint64_t acc = 0;
+  for (; i < n; i++) {
+    if (s[i] < '0' || s[i] > '9') return 0;
+    acc = acc * 10 + (uint64_t)(s[i] - '0');
+  }
+  if (acc > 0xFFFFFFFFull) return 0;
+  *v = (uint32_t)acc;
+  return 1;
+}
+
+/* src/decodefile.rs:142-176 + parse_xml :232-303 */
+int x3o_archive_header_read(const uint8_t* bytes, uint64_t len, uint32_t* sample_rate, x3o_params* p,
+                            uint8_t* channels, uint64_t* header_size) {
+  x3o_init();
+  if (len < 8) return X3O_IO;
+  if (memcmp(bytes, "X3ARCHIV", 8) != 0) return X3O_ARCHIVE_HEADER_XML_INVALID_KEY;
+  if (len < 28) return X3O_IO;
+  x3o_frame_header h;
+  int rc = x3o_read_frame_header(bytes + 8, 20, &h);
+  if (rc) return rc;
+  if (len - 28 < h.payload_len) return X3O_IO;
+  const char* xml = (const char*)bytes + 28;
+  char fs[64], bl[64], codes[128], th[128];
+  if (!xml_first_text(xml, h.payload_len, "FS", fs, sizeof fs) ||
+      !xml_first_text(xml, h.payload_len, "BLKLEN", bl, sizeof bl) ||
+      !xml_first_text(xml, h.payload_len, "CODES", codes, sizeof codes) ||
+      !xml_first_text(xml, h.payload_len, "T", th, sizeof th))
+    return X3O_BAD_ARG; /* fs[0] etc. index panic */
+  uint32_t rate, block_len;
+  if (!parse_u32(fs, strlen(fs), &rate) || !parse_u32(bl, strlen(bl), &block_len)) return X3O_BAD_ARG;
+  uint32_t ids[16], ths[16];
+  size_t nid = 0, nth = 0;
+  for (const char* w = codes;;) {
+    const char* e = strchr(w, ',');
+    size_t wl = e ? (size_t)(e - w) : strlen(w);
+    if (wl == 5 && !memcmp(w, "RICE", 4) && w[4] >= '0' && w[4] <= '3') { if (nid < 16) ids[nid++] = (uint32_t)(w[4] - '0'); }
+    else if (!(wl == 3 && !memcmp(w, "BFP", 3))) return X3O_ARCHIVE_HEADER_XML_RICE_CODE;
+    if (!e) break;
+    w = e + 1;
+  }
+  for (const char* w = th;;) {
+    const char* e = strchr(w, ',');
+    size_t wl = e ? (size_t)(e - w) : strlen(w);
+    uint32_t v;
+    if (!parse_u32(w, wl, &v)) return X3O_BAD_ARG;
+    if (nth < 16) ths[nth++] = v;
+    if (!e) break;
+    w = e + 1;
+  }
+  if (nid < 3 || nth < 3) return X3O_BAD_ARG;
+  x3o_params q;
+  q.block_len = block_len;
+  q.blocks_per_frame = 500;
+  for (int k = 0; k < 3; k++) { q.codes[k] = ids[k]; q.thresholds[k] = ths[k]; }
+  if ((rc = x3o_params_new(&q))) return rc;
+  *p = q;
+  if (sample_rate) *sample_rate = rate;
+  if (channels) *channels = h.channels;
+  if (header_size) *header_size = 20 + (uint64_t)h.payload_len;
+  return X3O_OK;
+}
+
+/* src/encodefile.rs:48-77 without the files */
+int x3o_x3a_encode(const int16_t* wav, uint64_t n, uint32_t sample_rate, uint8_t* out, uint64_t cap,
+                   uint64_t* out_len, uint64_t stats[6]) {
+  x3o_params p;
+  x3o_params_default(&p);
+  uint64_t hlen = 0;
+  int rc = x3o_archive_header_write(sample_rate, &p, out, cap, &hlen);
+  if (out_len) *out_len = hlen;
+  if (rc) return rc;
+  uint64_t pos = hlen;
+  rc = x3o_encode(wav, n, 1, &p, out, cap, hlen, &pos, stats);
+  if (out_len) *out_len = pos;
+  return rc;
+}
+
+/* src/decodefile.rs:59-136,189-212 without the files */
+int x3o_x3a_decode(const uint8_t* x3a, uint64_t len, int16_t* wav, uint64_t wav_cap, uint64_t* n_out,
+                   uint32_t* sample_rate, uint64_t* frames_ok, uint64_t* frame_errors) {
+  if (n_out) *n_out = 0;
+  if (frames_ok) *frames_ok = 0;
+  if (frame_errors) *frame_errors = 0;
+  x3o_params p;
+  uint8_t ch;
+  uint64_t hsize;
+  int rc = x3o_archive_header_read(x3a, len, sample_rate, &p, &ch, &hsize);
+  if (rc) return rc;
+  uint64_t start = 8 + hsize;
+  return decode_stream_phantom(x3a + start, len - start, 8, &p, wav, wav_cap, n_out, frames_ok, frame_errors);
 }
 
 /* ------------------------------------------------------------ CPU baseline */

@@ -28,7 +28,7 @@ extern "C" {
  * then two codes for situations in which the reference panics instead of returning. */
 enum {
   X3O_OK = 0,
-  X3O_IO = 1,
+  X3O_IO = 1, /* std::io::Error, e.g. read_exact past the end of the data */
   X3O_HOUND = 2,
   X3O_BITPACK = 3,
   X3O_INVALID_ENCODING_THRESH = 4,
@@ -158,6 +158,20 @@ int x3o_decode_frame(const uint8_t* x3_bytes, size_t len, int16_t* wav_buf, size
 int x3o_decode_stream(const uint8_t* x3, uint64_t len, const x3o_params* p, int16_t* wav,
                       uint64_t wav_cap, uint64_t* n_out, uint64_t* frames_ok,
                       uint64_t* frame_errors);
+
+/* ---- encodefile.rs / decodefile.rs: the .x3a archive around the frame stream (no file I/O).
+ * Unpinned by any reference test (its file tests are commented out): follows the source.
+ * quick-xml (Cargo.toml: 0.38, not in the reference tree) is restated as "text of the first
+ * <NAME ...>...</NAME> element, trimmed", which is what Event::Start + read_text yield on the
+ * well-formed XML the writer produces. */
+int x3o_archive_header_write(uint32_t sample_rate, const x3o_params* p, uint8_t* out, uint64_t cap,
+                             uint64_t* out_len);                                   /* encodefile.rs:82-138 */
+int x3o_archive_header_read(const uint8_t* bytes, uint64_t len, uint32_t* sample_rate, x3o_params* p,
+                            uint8_t* channels, uint64_t* header_size);             /* decodefile.rs:142-176,232-303 */
+int x3o_x3a_encode(const int16_t* wav, uint64_t n, uint32_t sample_rate, uint8_t* out, uint64_t cap,
+                   uint64_t* out_len, uint64_t stats[6]);                          /* encodefile.rs:48-77 */
+int x3o_x3a_decode(const uint8_t* x3a, uint64_t len, int16_t* wav, uint64_t wav_cap, uint64_t* n_out,
+                   uint32_t* sample_rate, uint64_t* frames_ok, uint64_t* frame_errors); /* decodefile.rs:59-136,189-212 */
 
 /* Timing helper for bench.py's cpu_baseline leg: encode then decode `n` samples `reps` times,
  * single thread; returns seconds for encode and decode separately. */

@@ -48,6 +48,17 @@ static void host_only() {
   CHECK(pos == 4);
   CHECK(w.seek(x3::bytewriter::SeekFrom::Current, 5) == x3::X3Error::ByteWriterInsufficientMemory);
   CHECK(w.write_all(buf, 5) == x3::X3Error::ByteWriterInsufficientMemory);
+  // create_archive_header / read_archive_header (encodefile.rs:82-138, decodefile.rs:142-176)
+  uint8_t arc[512];
+  size_t arc_len = 0, hsize = 0;
+  CHECK(x3::archive::create_archive_header(192000, x3::Parameters{}, arc, sizeof arc, &arc_len) == x3::X3Error::Ok);
+  CHECK(arc_len == 320 && std::memcmp(arc, "X3ARCHIV", 8) == 0);
+  x3::archive::X3aSpec spec;
+  CHECK(x3::archive::read_archive_header(arc, arc_len, &spec, &hsize) == x3::X3Error::Ok);
+  CHECK(spec.sample_rate == 192000 && spec.channels == 0 && hsize == 312 && spec.params.block_len == 20 &&
+        spec.params.codes[2] == 3 && spec.params.thresholds[2] == 20);
+  arc[0] = 'Y';
+  CHECK(x3::archive::read_archive_header(arc, arc_len, &spec, &hsize) == x3::X3Error::ArchiveHeaderXMLInvalidKey);
   std::printf("host-only checks ok\n");
 }
 

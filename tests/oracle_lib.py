@@ -94,6 +94,13 @@ def lib(native=False):
                                    C.POINTER(C.c_size_t)]
     L.x3o_decode_stream.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Params), C.c_void_p, C.c_uint64,
                                     C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.x3o_archive_header_write.argtypes = [C.c_uint32, C.POINTER(Params), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.x3o_archive_header_read.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(Params),
+                                          C.POINTER(C.c_uint8), C.POINTER(C.c_uint64)]
+    L.x3o_x3a_encode.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                 C.c_void_p]
+    L.x3o_x3a_decode.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                 C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.x3o_time_roundtrip.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Params), C.c_int, C.POINTER(C.c_double),
                                      C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.x3o_init()
@@ -152,3 +159,38 @@ def decode_frame(payload, samples, params=None, wav_cap=None):
     rc = lib().x3o_decode_frame(payload.ctypes.data, payload.size, wav.ctypes.data, wav_cap, C.byref(params), samples,
                                 C.byref(n))
     return rc, wav[: n.value].copy()
+
+
+def archive_header_write(sample_rate, params=None, cap=1024):
+    params = params or Params.default()
+    out = np.zeros(cap, dtype=np.uint8)
+    n = C.c_uint64(0)
+    rc = lib().x3o_archive_header_write(sample_rate, C.byref(params), out.ctypes.data, cap, C.byref(n))
+    return rc, out[: min(n.value, cap)].copy()
+
+
+def archive_header_read(data):
+    b = np.ascontiguousarray(data, dtype=np.uint8)
+    rate, p, ch, hs = C.c_uint32(0), Params(), C.c_uint8(0), C.c_uint64(0)
+    rc = lib().x3o_archive_header_read(b.ctypes.data, b.size, C.byref(rate), C.byref(p), C.byref(ch), C.byref(hs))
+    return rc, rate.value, p, ch.value, hs.value
+
+
+def x3a_encode(wav, sample_rate, cap=None):
+    wav = np.ascontiguousarray(wav, dtype=np.int16)
+    cap = 1024 + encode_bound(wav.size, Params.default()) if cap is None else cap
+    out = np.zeros(max(cap, 1), dtype=np.uint8)
+    n = C.c_uint64(0)
+    stats = np.zeros(6, dtype=np.uint64)
+    rc = lib().x3o_x3a_encode(wav.ctypes.data, wav.size, sample_rate, out.ctypes.data, cap, C.byref(n), stats.ctypes.data)
+    return rc, out[: min(n.value, cap)].copy(), stats
+
+
+def x3a_decode(x3a, wav_cap=None):
+    x3a = np.ascontiguousarray(x3a, dtype=np.uint8)
+    wav_cap = max(1, x3a.size * 16) if wav_cap is None else wav_cap
+    wav = np.zeros(wav_cap, dtype=np.int16)
+    n, rate, fok, ferr = C.c_uint64(0), C.c_uint32(0), C.c_uint64(0), C.c_uint64(0)
+    rc = lib().x3o_x3a_decode(x3a.ctypes.data, x3a.size, wav.ctypes.data, wav_cap, C.byref(n), C.byref(rate),
+                              C.byref(fok), C.byref(ferr))
+    return rc, wav[: n.value].copy(), rate.value, fok.value, ferr.value

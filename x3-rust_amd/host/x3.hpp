@@ -89,6 +89,13 @@ struct Parameters {
     for (int k = 0; k < 3; ++k) { c.codes[k] = (uint32_t)codes[k]; c.thresholds[k] = (uint32_t)thresholds[k]; }
     return c;
   }
+  static Parameters from_c(const x3_params& c) {
+    Parameters p;
+    p.block_len = c.block_len;
+    p.blocks_per_frame = c.blocks_per_frame;
+    for (int k = 0; k < 3; ++k) { p.codes[k] = c.codes[k]; p.thresholds[k] = c.thresholds[k]; }
+    return p;
+  }
 };
 
 // x3.rs:29-45: slice-based channel
@@ -350,4 +357,50 @@ inline X3Error decode_stream(Context& ctx, const uint8_t* x3, size_t len, const 
   return static_cast<X3Error>(rc);
 }
 }  // namespace decoder
+
+// encodefile.rs / decodefile.rs without the files: the .x3a archive header and the whole-buffer conversions
+namespace archive {
+struct X3aSpec {  // decodefile.rs:36-43
+  uint32_t sample_rate = 0;
+  Parameters params;
+  uint8_t channels = 0;
+};
+// create_archive_header (encodefile.rs:82-138); returns the header length through *out_len
+inline X3Error create_archive_header(uint32_t sample_rate, const Parameters& params, uint8_t* out, size_t cap,
+                                     size_t* out_len) {
+  x3_params c = params.c_params();
+  uint64_t n = 0;
+  int rc = x3_archive_header_write(sample_rate, &c, out, cap, &n);
+  if (out_len) *out_len = (size_t)n;
+  return static_cast<X3Error>(rc);
+}
+// read_archive_header (decodefile.rs:142-176): header_size = 20 + XML, audio frames start at 8 + header_size
+inline X3Error read_archive_header(const uint8_t* bytes, size_t len, X3aSpec* spec, size_t* header_size) {
+  x3_params c;
+  uint64_t hs = 0;
+  X3aSpec s;
+  int rc = x3_archive_header_read(bytes, len, &s.sample_rate, &c, &s.channels, &hs);
+  if (rc == X3_OK) {
+    s.params = Parameters::from_c(c);
+    if (spec) *spec = s;
+    if (header_size) *header_size = (size_t)hs;
+  }
+  return static_cast<X3Error>(rc);
+}
+// wav_to_x3a (encodefile.rs:48-77) / x3a_to_wav (decodefile.rs:189-212) on buffers
+inline X3Error wav_to_x3a(Context& ctx, const int16_t* wav, size_t n, uint32_t sample_rate, uint8_t* out, size_t cap,
+                          size_t* out_len) {
+  uint64_t len = 0;
+  int rc = x3_x3a_encode(ctx.raw(), wav, n, sample_rate, out, cap, &len, nullptr);
+  if (out_len) *out_len = (size_t)len;
+  return static_cast<X3Error>(rc);
+}
+inline X3Error x3a_to_wav(Context& ctx, const uint8_t* x3a, size_t len, int16_t* wav, size_t wav_cap,
+                          uint32_t* sample_rate, decoder::StreamResult* res) {
+  decoder::StreamResult r;
+  int rc = x3_x3a_decode(ctx.raw(), x3a, len, wav, wav_cap, &r.samples, sample_rate, &r.frames_ok, &r.frame_errors);
+  if (res) *res = r;
+  return static_cast<X3Error>(rc);
+}
+}  // namespace archive
 }  // namespace x3

@@ -50,6 +50,14 @@ pub mod ffi {
                                p: *const x3_params, samples: u64, n_out: *mut u64) -> c_int;
         pub fn x3_decode_stream(ctx: *mut x3_ctx, x3: *const u8, len: u64, p: *const x3_params, wav: *mut i16,
                                 wav_cap: u64, n_out: *mut u64, frames_ok: *mut u64, frame_errors: *mut u64) -> c_int;
+        pub fn x3_archive_header_write(sample_rate: u32, p: *const x3_params, out: *mut u8, out_cap: u64,
+                                       out_len: *mut u64) -> c_int;
+        pub fn x3_archive_header_read(bytes: *const u8, len: u64, sample_rate: *mut u32, p: *mut x3_params,
+                                      channels: *mut u8, header_size: *mut u64) -> c_int;
+        pub fn x3_x3a_encode(ctx: *mut x3_ctx, wav: *const i16, n: u64, sample_rate: u32, out: *mut u8, out_cap: u64,
+                             out_len: *mut u64, stats: *mut u64) -> c_int;
+        pub fn x3_x3a_decode(ctx: *mut x3_ctx, x3a: *const u8, len: u64, wav: *mut i16, wav_cap: u64, n_out: *mut u64,
+                             sample_rate: *mut u32, frames_ok: *mut u64, frame_errors: *mut u64) -> c_int;
     }
 }
 
@@ -299,5 +307,30 @@ pub mod decoder {
                                   wav.len() as u64, &mut n, &mut ok, &mut bad)
         })?;
         Ok((n as usize, ok as usize, bad as usize))
+    }
+}
+
+/// encodefile.rs / decodefile.rs on buffers: what `wav_to_x3a` (encodefile.rs:48-77) and `x3a_to_wav`
+/// (decodefile.rs:189-212) do between their file reads and writes.
+pub mod archive {
+    use super::{error::{self, X3Error}, ffi, Gpu};
+
+    pub fn wav_to_x3a(gpu: &Gpu, wav: &[i16], sample_rate: u32, out: &mut [u8]) -> Result<usize, X3Error> {
+        let mut len = 0u64;
+        error::check(unsafe {
+            ffi::x3_x3a_encode(gpu.raw(), wav.as_ptr(), wav.len() as u64, sample_rate, out.as_mut_ptr(),
+                               out.len() as u64, &mut len, std::ptr::null_mut())
+        })?;
+        Ok(len as usize)
+    }
+
+    /// Returns (samples, sample_rate, frame_errors).
+    pub fn x3a_to_wav(gpu: &Gpu, x3a: &[u8], wav: &mut [i16]) -> Result<(usize, u32, usize), X3Error> {
+        let (mut n, mut ok, mut bad, mut rate) = (0u64, 0u64, 0u64, 0u32);
+        error::check(unsafe {
+            ffi::x3_x3a_decode(gpu.raw(), x3a.as_ptr(), x3a.len() as u64, wav.as_mut_ptr(), wav.len() as u64,
+                               &mut n, &mut rate, &mut ok, &mut bad)
+        })?;
+        Ok((n as usize, rate, bad as usize))
     }
 }

@@ -35,6 +35,7 @@ SYMBOLS = [
     "x3_crc16", "x3_crc16_dev", "x3_crc16_update",
     "x3_encode", "x3_encode_frame", "x3_write_frame_header", "x3_encode_batch",
     "x3_read_frame_header", "x3_decode_frame", "x3_decode_stream",
+    "x3_archive_header_write", "x3_archive_header_read", "x3_x3a_encode", "x3_x3a_decode",
     "x3_encode_dev", "x3_encode_result", "x3_decode_dev", "x3_decode_result",
     "x3_synth", "x3_synth_dev", "x3_dev_alloc", "x3_dev_free", "x3_dev_upload", "x3_dev_download",
 ]
@@ -136,6 +137,10 @@ def lib():
     L.x3_read_frame_header.argtypes = [vp, u64, C.POINTER(FrameHeader)]
     L.x3_decode_frame.argtypes = [vp, vp, u64, vp, u64, PP, u64, C.POINTER(u64)]
     L.x3_decode_stream.argtypes = [vp, vp, u64, PP, vp, u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+    L.x3_archive_header_write.argtypes = [u32, PP, vp, u64, C.POINTER(u64)]
+    L.x3_archive_header_read.argtypes = [vp, u64, C.POINTER(u32), PP, C.POINTER(C.c_uint8), C.POINTER(u64)]
+    L.x3_x3a_encode.argtypes = [vp, vp, u64, u32, vp, u64, C.POINTER(u64), vp]
+    L.x3_x3a_decode.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64), C.POINTER(u32), C.POINTER(u64), C.POINTER(u64)]
     L.x3_encode_dev.argtypes = [vp, vp, C.POINTER(Batch), PP, vp, u64, u64, vp]
     L.x3_encode_result.argtypes = [vp, C.POINTER(u64), vp]
     L.x3_decode_dev.argtypes = [vp, vp, u64, vp, u64, C.POINTER(Batch), vp, PP, vp, u64, vp]
@@ -176,6 +181,23 @@ def write_frame_header(num_samples, ident, payload_len, payload_crc):
     out = np.zeros(20, dtype=np.uint8)
     lib().x3_write_frame_header(num_samples, ident, payload_len, payload_crc, out.ctypes.data)
     return out
+
+
+def archive_header_write(sample_rate, params=None, cap=1024):
+    """-> (rc, header bytes)"""
+    params = params or Params.default()
+    out = np.zeros(cap, dtype=np.uint8)
+    n = C.c_uint64(0)
+    rc = lib().x3_archive_header_write(sample_rate, C.byref(params), out.ctypes.data, cap, C.byref(n))
+    return rc, out[: min(n.value, cap)].copy()
+
+
+def archive_header_read(data):
+    """-> (rc, sample_rate, Params, channels, header_size)"""
+    b = np.ascontiguousarray(data, dtype=np.uint8)
+    rate, p, ch, hs = C.c_uint32(0), Params(), C.c_uint8(0), C.c_uint64(0)
+    rc = lib().x3_archive_header_read(b.ctypes.data, b.size, C.byref(rate), C.byref(p), C.byref(ch), C.byref(hs))
+    return rc, rate.value, p, ch.value, hs.value
 
 
 def read_frame_header(data):
@@ -279,6 +301,30 @@ class Context:
         rc = lib().x3_decode_frame(self._h, payload.ctypes.data, payload.size, wav.ctypes.data, wav_cap,
                                    C.byref(params), samples, C.byref(n))
         return rc, wav[: n.value].copy()
+
+    def x3a_encode(self, wav, sample_rate, cap=None):
+        """wav_to_x3a in memory -> (rc, .x3a bytes, stats)"""
+        wav = np.ascontiguousarray(wav, dtype=np.int16)
+        p = Params.default()
+        if cap is None:
+            cap = 1024 + lib().x3_encode_bound(wav.size, C.byref(p))
+        out = np.zeros(max(cap, 1), dtype=np.uint8)
+        n = C.c_uint64(0)
+        stats = np.zeros(6, dtype=np.uint64)
+        rc = lib().x3_x3a_encode(self._h, wav.ctypes.data, wav.size, sample_rate, out.ctypes.data, cap, C.byref(n),
+                                 stats.ctypes.data)
+        return rc, out[: min(n.value, cap)].copy(), stats
+
+    def x3a_decode(self, x3a, wav_cap=None):
+        """x3a_to_wav in memory -> (rc, samples, sample_rate, frames_ok, frame_errors)"""
+        x3a = np.ascontiguousarray(x3a, dtype=np.uint8)
+        if wav_cap is None:
+            wav_cap = max(1, x3a.size * 16)
+        wav = np.zeros(wav_cap, dtype=np.int16)
+        n, rate, fok, ferr = C.c_uint64(0), C.c_uint32(0), C.c_uint64(0), C.c_uint64(0)
+        rc = lib().x3_x3a_decode(self._h, x3a.ctypes.data, x3a.size, wav.ctypes.data, wav_cap, C.byref(n),
+                                 C.byref(rate), C.byref(fok), C.byref(ferr))
+        return rc, wav[: n.value].copy(), rate.value, fok.value, ferr.value
 
     def crc16(self, data):
         b = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8)) if not isinstance(data, np.ndarray) \
