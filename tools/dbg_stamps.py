@@ -7,6 +7,7 @@ ctx = x3hip.Context(0); p = x3hip.Params.default(); n = 691_200_000; L = x3hip.l
 F = L.x3_num_frames(n, C.byref(p)); cap = L.x3_encode_bound(n, C.byref(p))
 d_wav = ctx.alloc(2*n); d_out = ctx.alloc(cap+16); d_off = ctx.alloc(8*(F+1)); d_back = ctx.alloc(2*n)
 ctx.synth_dev(2, 0x58330003, 0, n, d_wav)
+ctx.enable_kernel_timing(True)
 for _ in range(2):
     assert ctx.encode_dev(d_wav, n, p, d_out, cap, 0, d_off) == 0
     assert ctx.decode_dev(d_out, cap, d_off, F, p, d_back, n, n_per_clip=n) == 0
@@ -20,3 +21,7 @@ names = os.environ.get("X3_STAMP_NAMES","setup,blockhdr-pre,service,header,sampl
 print("mean cycles per wave (x100MHz clock64 ticks?)")
 for k in range(8): print("%-14s mean %12.0f  min %12.0f max %12.0f" % (names[k], a[:,k].mean(), a[:,k].min(), a[:,k].max()))
 print("total", a.sum(axis=1).mean())
+tot = a.sum(axis=1)
+print("total percentiles 0/10/50/90/95/99/100:", np.percentile(tot, [0, 10, 50, 90, 95, 99, 100]).round(0))
+print("waves with total > 1.15 x median:", int((tot > 1.15 * np.median(tot)).sum()), "of", len(tot))
+print("kernel ms/launches (encode, decode, check):", ctx.kernel_time(0), ctx.kernel_time(1), ctx.kernel_time(4))

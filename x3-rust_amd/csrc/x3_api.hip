@@ -60,6 +60,7 @@ struct x3_ctx {
   // growable scratch
   DevBuf in, out, frame_bytes, frame_off, dec_status, dec_cstatus, dec_meta, wav_off, seg_crc, desc;
   int n_cus = 0;
+  uint32_t desc_epoch = 0;    // tag of the current launch's frame-size descriptors (x3_encode_stream_kernel)
   int stream_wg_per_cu = -1;  // co-resident workgroups per CU of x3_encode_stream_kernel (-1 = not queried)
   // bookkeeping of the last async calls
   bool encode_pending = false, decode_pending = false;
@@ -542,25 +543,33 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
       // workgroup land unevenly on the 4 SIMDs, hence the slack of 3 waves.
       int nb = 0;
       HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, x3_encode_stream_kernel, X3_STREAM_THREADS,
-                                                             pl.smem + 2048));
+                                                             pl.smem + (size_t)pl.img_dwords * 4 + 2048));
       hipFuncAttributes fa;
       HIPCHK(c, hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&x3_encode_stream_kernel)));
       const int alloc = ((fa.numRegs + 7) / 8) * 8;
       const int wps = std::min(8, 512 / std::max(alloc, 8));
       const int by_regs = (4 * wps - 3) / 9;
-      const int by_lds = (int)((160 * 1024) / (pl.smem + 2048));
+      const int by_lds = (int)((160 * 1024) / (pl.smem + (size_t)pl.img_dwords * 4 + 2048));
       c->stream_wg_per_cu = std::max(0, std::min(std::min(nb, 4), std::min(by_regs, by_lds)));
     }
-    if (c->stream_wg_per_cu >= 1 && pl.smem + 2048 <= 64 * 1024) {
-      if ((rc = ensure(c, c->desc, F * sizeof(unsigned long long)))) return rc;
-      HIPCHK(c, hipMemsetAsync(c->desc.p, 0, F * sizeof(unsigned long long), c->stream));
-      // persistent grid: every workgroup must be resident (the look-back waits on predecessors)
+    const size_t stream_smem = pl.smem + (size_t)pl.img_dwords * 4 + 2048;  // + second frame image + CRC tables
+    if (c->stream_wg_per_cu >= 1 && stream_smem <= 64 * 1024) {
+      // frame-size descriptors {epoch:12 | bytes:20}: the epoch makes last launch's words "not ready"
+      // without clearing the array (cleared when it is (re)allocated and when the epoch wraps)
+      const size_t desc_bytes = (F + X3_DESC_PAD) * sizeof(uint32_t);
+      const bool fresh = c->desc.cap < desc_bytes;
+      if ((rc = ensure(c, c->desc, desc_bytes))) return rc;
+      if (fresh || ++c->desc_epoch > 0xFFFu) {
+        HIPCHK(c, hipMemsetAsync(c->desc.p, 0, c->desc.cap, c->stream));
+        c->desc_epoch = 1;
+      }
+      // persistent grid: every workgroup must be resident (offsets wait on the other workgroups' sizes)
       const uint64_t grid = std::min<uint64_t>(F, (uint64_t)c->n_cus * c->stream_wg_per_cu);
       {
         TimerScope ts(c, 0);
-        hipLaunchKernelGGL(x3_encode_stream_kernel, dim3((unsigned)grid), dim3(X3_STREAM_THREADS), pl.smem + 2048, c->stream, d_wav, pl.g,
-                           pl.dp, d_off, d_out, out_cap, start_pos, (unsigned long long*)c->desc.p, c->d_stats,
-                           c->d_status, c->d_end_pos, (const uint16_t*)c->d_xpow, (const uint32_t*)c->d_xk16,
+        hipLaunchKernelGGL(x3_encode_stream_kernel, dim3((unsigned)grid), dim3(X3_STREAM_THREADS), stream_smem, c->stream,
+                           d_wav, pl.g, pl.dp, d_off, d_out, out_cap, start_pos, (uint32_t*)c->desc.p + X3_DESC_PAD, c->desc_epoch,
+                           c->d_stats, c->d_status, c->d_end_pos, (const uint32_t*)c->d_xk16,
                            (const uint16_t*)c->d_crctab, pl.lds_in_bytes, pl.img_dwords);
       }
       HIPCHK(c, hipGetLastError());

@@ -511,6 +511,10 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
 
   const uint32_t lane = threadIdx.x;
   const uint64_t f = (uint64_t)blockIdx.x * 64 + lane;
+#ifdef X3_DBG_STAMPS
+  unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long dbg_t = clock64();
+#endif
   uint32_t* const row = ring + lane * X3_DEC_RING_STRIDE;
   uint32_t* const orow = outs + lane * X3_DEC_OUT_STRIDE;
 
@@ -676,6 +680,7 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
 
   const uint32_t bl = p.block_len;
   uint32_t i = 1;  // index of the sample being produced; wave-uniform (kept in an SGPR)
+  X3_STAMP(0);
   for (;;) {
     uint32_t cnt = remaining < bl ? remaining : bl;
     uint32_t maxcnt = bl;
@@ -684,7 +689,9 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
       if (maxcnt == 0) break;
     }
     maxcnt = __builtin_amdgcn_readfirstlane(maxcnt);
+    X3_STAMP(1);
     service();
+    X3_STAMP(2);
     // block header: 2 bits ftype; ftype 0 -> 4 more bits E-1 (decoder.rs:138-144, 209-216)
     uint32_t zmask = 0, width = 1, bound = 0xFFFFFFFFu, level = 0, lit = 0, neg_thresh = 0xFFFFFFFFu, neg2 = 0;
     {
@@ -780,6 +787,7 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
       }
     };
 
+    X3_STAMP(3);
     uint32_t j = 0;
     while (j < maxcnt) {  // uniform: segments end at flush points and at ring services
       uint32_t seg_end = j + (X3_DEC_WIN - (i - wbase));
@@ -807,9 +815,11 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
       }
       i = i0 + (seg_end - j);
       j = seg_end;
+      X3_STAMP(4);
       if (i - wbase == X3_DEC_WIN) {
         flush(i);
         wbase = i;
+        X3_STAMP(5);
       }
       if (j < maxcnt && (j % X3_DEC_CHUNK) == 0) service();
     }
@@ -832,6 +842,11 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
   }
   if (i > wbase) flush(i);
   if (f < n_frames) status[f] = st;
+#ifdef X3_DBG_STAMPS
+  X3_STAMP(6);
+  if (lane == 0 && blockIdx.x < 4096)
+    for (int k = 0; k < 8; ++k) x3_dbg[blockIdx.x * 8 + k] = dbg_acc[k];
+#endif
 }
 
 // first frame with a non-zero status, and the samples of the good frames before it

@@ -23,11 +23,7 @@
 #pragma once
 #include "x3_encode_kernel.h"
 
-#define X3_DESC_AGG 1ull     // value = bytes of this frame
-#define X3_DESC_PREFIX 2ull  // value = stream position behind this frame
-#define X3_DESC_SHIFT 62
-#define X3_DESC_MASK ((1ull << X3_DESC_SHIFT) - 1ull)
-#define X3_SPIN_LIMIT (1u << 21)  // ~0.1 s of polling: a bounded spin, never a hang
+#define X3_SPIN_LIMIT (1u << 16)  // polls of >= 1 memory round trip each (~0.1 s): a bounded spin, never a hang
 #define X3D_LOOKBACK_TIMEOUT 100  // internal: the host re-runs the two-pass encoder (x3_encode_result)
 
 typedef short x3_short2 __attribute__((ext_vector_type(2)));
@@ -82,7 +78,12 @@ __device__ __forceinline__ void x3_glds16(const void* gsrc, uint32_t lds_dst) {
                : "v"(gsrc), "s"(lds_dst)
                : "memory");
 }
-__device__ __forceinline__ void x3_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// vmcnt(0) as the BUILTIN, not as asm text: hipcc's wait-count pass sees it and clears its scoreboard, so it
+// does not add conservative vmcnt(0) waits of its own later (those would also wait for the hidden LDS-DMA).
+__device__ __forceinline__ void x3_dma_wait() {
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
+  asm volatile("" ::: "memory");
+}
 __device__ __forceinline__ uint32_t x3_lds_addr(const void* p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(const char*)p;
 }
@@ -102,6 +103,14 @@ constexpr uint32_t x3_gf_pow_c(uint32_t base, int e) {
   for (int i = 0; i < e; ++i) r = x3_gf_mul_c(r, base);
   return r;
 }
+constexpr uint32_t x3_crc16_step_c(uint32_t crc, uint32_t byte) {
+  uint32_t t = ((crc >> 8) ^ byte) & 0xFFu;
+  t ^= t >> 4;
+  return ((crc << 8) ^ (t << 12) ^ (t << 5) ^ t) & 0xFFFFu;
+}
+constexpr uint32_t x3_crc16_const4(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3) {
+  return x3_crc16_step_c(x3_crc16_step_c(x3_crc16_step_c(x3_crc16_step_c(0xFFFFu, b0), b1), b2), b3);
+}
 // x^-1 = x^15 + x^11 + x^4 (x * that = x^16 + x^12 + x^5 = P + 1); x^-16 = (x^-1)^16
 constexpr uint32_t X3_XINV16_C = x3_gf_pow_c(0x8810u, 16);
 template <uint32_t C>
@@ -115,15 +124,35 @@ __device__ __forceinline__ uint32_t x3_gf_mul_const(uint32_t a) {
   return r;
 }
 
+// Four 16-byte-per-lane direct-to-LDS loads (4 KB) behind ONE M0 write: the instruction offset advances the
+// global address and the LDS address together (LDS address = M0 + inst_offset + 16*lane).
+__device__ __forceinline__ void x3_glds16x4(const void* gsrc, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+      "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+      "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
 // stage frame samples [0, n) of `src` into LDS with direct-to-LDS loads (no VGPRs, all in flight at
-// once); executed by ONE wave.  16-byte pieces; the < 8 samples behind the last full piece by lanes.
+// once); executed by ONE wave.  4 KB groups, then 1 KB pieces, then the < 8 samples behind the last
+// full 16-byte piece by lanes.
 __device__ __forceinline__ void x3_stage_frame_dma(const int16_t* __restrict__ src, uint32_t n, int16_t* in_s,
                                                    uint32_t lane) {
   const uint32_t npieces = n >> 3;  // 16-byte pieces
   const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(src);
-  for (uint32_t base = 0; base < npieces; base += 64u) {
-    if (base + lane < npieces)
-      x3_glds16(s4 + base + lane, __builtin_amdgcn_readfirstlane(x3_lds_addr(reinterpret_cast<uint4*>(in_s) + base)));
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane(x3_lds_addr(in_s));
+  uint32_t base = 0;
+  for (; base + 256u <= npieces; base += 256u)
+    x3_glds16x4(s4 + base + lane, __builtin_amdgcn_readfirstlane(lds0 + 16u * base));
+  for (; base < npieces; base += 64u) {
+    if (base + lane < npieces) x3_glds16(s4 + base + lane, __builtin_amdgcn_readfirstlane(lds0 + 16u * base));
   }
   const uint32_t done = npieces << 3;
   if (done + lane < n) in_s[done + lane] = src[done + lane];
@@ -133,278 +162,425 @@ __device__ __forceinline__ void x3_stage_frame_dma(const int16_t* __restrict__ s
 #ifndef X3_STREAM_MIN_WAVES
 #define X3_STREAM_MIN_WAVES 6  // <= 80 VGPRs: two 9-wave workgroups per CU
 #endif
+#define X3_DESC_BYTES_BITS 20u                       // frame bytes <= 20 + 65535 < 2^20
+#define X3_DESC_BYTES_MASK ((1u << X3_DESC_BYTES_BITS) - 1u)
+#define X3_LB_WINDOWS 8                              // 8 x 64 descriptors requested at once
+#define X3_DESC_PAD 576u                             // words in front of desc[0]: windows may reach below frame 0
+
 __global__ void __launch_bounds__(X3_STREAM_THREADS, X3_STREAM_MIN_WAVES)
 x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p,
                         uint64_t* __restrict__ frame_off, uint8_t* __restrict__ out, uint64_t out_cap,
-                        uint64_t start_pos, unsigned long long* __restrict__ desc,
+                        uint64_t start_pos, uint32_t* __restrict__ desc, uint32_t epoch,
                         unsigned long long* __restrict__ stats, int* __restrict__ status,
-                        unsigned long long* __restrict__ end_pos, const uint16_t* __restrict__ xpow,
-                        const uint32_t* __restrict__ xk16, const uint16_t* __restrict__ crc_tab_g, uint32_t lds_in_bytes,
-                        uint32_t img_dwords) {
+                        unsigned long long* __restrict__ end_pos, const uint32_t* __restrict__ xk16,
+                        const uint16_t* __restrict__ crc_tab_g, uint32_t lds_in_bytes, uint32_t img_dwords) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // part: [0..7] scan partials, [16..23] CRC partials, [32..37] stats, [40] bad, [48..49] frame offset
+  // part: [0..7] scan partials, [16..23] CRC partials, [32..37] stats, [40] bad, [48..49] stream offset of
+  // the frame being copied out, [50] header CRC
   uint32_t* part = reinterpret_cast<uint32_t*>(smem);
   int16_t* in_s = reinterpret_cast<int16_t*>(smem + X3_ENC_SMEM_HDR);
   const uint32_t* in_w = reinterpret_cast<const uint32_t*>(smem + X3_ENC_SMEM_HDR);
-  uint32_t* img = reinterpret_cast<uint32_t*>(smem + X3_ENC_SMEM_HDR + lds_in_bytes);
-  // slicing-by-4 CRC tables behind the image: T[j][v] = crc0 of byte v followed by j zero bytes
-  uint16_t* crc_tab = reinterpret_cast<uint16_t*>(img + img_dwords);
+  // TWO frame images: frame k is copied out while frame k+1 is analysed and emitted (see file header)
+  uint32_t* img0 = reinterpret_cast<uint32_t*>(smem + X3_ENC_SMEM_HDR + lds_in_bytes);
+  // slicing-by-4 CRC tables behind the images: T[j][v] = crc0 of byte v followed by j zero bytes
+  uint16_t* crc_tab = reinterpret_cast<uint16_t*>(img0 + 2u * img_dwords);
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u, wid = tid >> 6;
-  const bool helper = wid == 8;              // wave 8: descriptors, look-back, prefetch of the next frame
+  const bool helper_wave = wid == 8;         // wave 8: descriptors, look-back, prefetch of the next frame
   const uint32_t nthr = 512;                 // compute threads
   const uint64_t base_pos = (start_pos + 1ull) & ~1ull;  // writer.align::<2>() (encoder.rs:182)
   const uint32_t k0 = p.k[0], k1 = p.k[1], k2 = p.k[2];
+  const uint32_t G = gridDim.x;
+  const uint32_t ready_tag = epoch << X3_DESC_BYTES_BITS;
 
-  auto frame_geom = [&](uint64_t f, const int16_t*& src, uint32_t& n) {
-    const uint64_t clip = f / g.fpc;
-    const uint64_t idx = f - clip * g.fpc;
-    const uint64_t left = g.n_per_clip - idx * (uint64_t)p.spf;
+  // frame f = (clip, idx): each role walks its frames f = blockIdx.x + k*G without dividing per frame
+  auto geom_at = [&](uint64_t clip, uint32_t idx, const int16_t*& src, uint32_t& n) __attribute__((always_inline)) {
+    const uint64_t left = g.n_per_clip - (uint64_t)idx * (uint64_t)p.spf;
     n = left < p.spf ? (uint32_t)left : p.spf;
-    src = wav + clip * g.clip_stride + idx * (uint64_t)p.spf;
+    src = wav + clip * g.clip_stride + (uint64_t)idx * (uint64_t)p.spf;
   };
+  auto geom_advance = [&](uint64_t& clip, uint32_t& idx) __attribute__((always_inline)) {
+    if (G < g.fpc) {
+      idx += G;
+      if (idx >= g.fpc) { idx -= g.fpc; ++clip; }
+    } else {  // clips shorter than the grid is wide
+      const uint64_t t = (uint64_t)idx + G;
+      clip += t / g.fpc;
+      idx = (uint32_t)(t % g.fpc);
+    }
+  };
+  uint64_t clip_f = blockIdx.x / g.fpc;
+  uint32_t idx_f = (uint32_t)(blockIdx.x - clip_f * g.fpc);
 
+#ifdef X3_DBG_STAMPS
+  unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long dbg_t = clock64();
+#endif
   // ---- prologue: the first frame is staged by the helper wave
   if (tid < 64) part[tid] = 0;
   if (tid < 512) reinterpret_cast<uint32_t*>(crc_tab)[tid] = reinterpret_cast<const uint32_t*>(crc_tab_g)[tid];
-  if (helper && blockIdx.x < g.n_frames) {
+  if (helper_wave) {
     const int16_t* src;
     uint32_t n;
-    frame_geom(blockIdx.x, src, n);
+    geom_at(clip_f, idx_f, src, n);
     x3_stage_frame_dma(src, n, in_s, lane);
     x3_dma_wait();
   }
   __syncthreads();
 
-  for (uint64_t f = blockIdx.x; f < g.n_frames; f += gridDim.x) {
-    const int16_t* src;
-    uint32_t n;
-    frame_geom(f, src, n);
-    (void)src;
-
-    // ---- B: one block per lane, in registers (blocks of 19 or 20 samples; shorter ones: scalar path)
-    const uint32_t nblocks = (n - 1 + 19) / 20;
-    const uint32_t b = tid;
-    const bool valid = !helper && b < nblocks;
-    const uint32_t s0 = 1 + b * 20;
-    const uint32_t cnt = valid ? (n - s0 < 20 ? n - s0 : 20) : 0;
-    const bool regs = cnt >= 19;
-    const uint32_t s_first = (uint32_t)(uint16_t)in_s[0];
-
-    uint32_t S[10];   // emission source per pair of block samples (r = 2j+1, 2j+2)
-    uint32_t type = 0, ft = 0, nb = 0, nbits = 0, bad = 0;
-    uint32_t amask = 0, orc = 0, qsh = 0, qmask = 0, lbase = 0;  // (code,len) recipe, see file header
-    if (regs) {
-      uint32_t W[11];   // samples 20b .. 20b+21 as (even, odd) pairs
-      const uint2* r2 = reinterpret_cast<const uint2*>(in_w + 10 * b);
+  // The two roles run their own frame loops (the branch is outside the loops so that loop-carried and
+  // hoisted values of one role are not live in the other) and meet at four barriers per frame.
+  if (helper_wave) {
+    // =============================================================== helper wave
+    // Few instructions, all of them on the critical path of the eight compute waves (which wait for this
+    // wave at every barrier): issue them ahead of the compute waves sharing the SIMD.  Measured without it:
+    // ~25 cycles per helper instruction while the compute waves emit.
+    __builtin_amdgcn_s_setprio(3);
+    // Offsets: this workgroup's consecutive frames are f-G and f, so
+    //   off(f) = off(f-G) + bytes(f-G) + SUM bytes(j), j in (f-G, f)      (first frame: base_pos + SUM j < f)
+    // -- at most G-1 sizes of OTHER workgroups, each published as one 4-byte word {epoch:12 | bytes:20} with an
+    // agent-scope relaxed atomic store as soon as the frame's bit lengths are scanned (the word is its own flag:
+    // cdna_hip_programming.md G16, form R2).  No prefix chain.  The loads for frame f are REQUESTED when f's
+    // emission is done and CONSUMED one frame later (a loaded-latency of several microseconds under the
+    // kernel's own streaming traffic, measured, hides behind the next frame's analysis and emission).
+    uint32_t dq[X3_LB_WINDOWS];
+    uint64_t pend_f = 0, my_off = 0;
+    uint32_t pend_bytes = 0, my_bytes = 0;
+    bool pending = false, first = true;
+    // Window w of a frame = the sizes of frames f-1-lane-64w.  Requests are raw loads at constant offsets
+    // from one per-lane pointer (the array has X3_DESC_PAD words in front, so windows reaching below frame
+    // 0 read padding); range and readiness are checked when a word is USED, so that requesting never waits.
+    const uint32_t lane1 = lane + 1u;
+    auto request = [&]() __attribute__((always_inline)) {
+      const uint32_t* p0 = desc + pend_f - lane1;
 #pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        const uint2 v = r2[j];
-        W[2 * j] = v.x;
-        W[2 * j + 1] = v.y;
-      }
-      W[10] = in_w[10 * b + 10];
-      uint32_t mn = 0, mx = 0;
-#pragma unroll
-      for (int j = 0; j < 10; ++j) {
-        const uint32_t Xj = __builtin_amdgcn_alignbit(W[j + 1], W[j], 16);  // (s[2j+1], s[2j+2])
-        S[j] = x3_pk_sub_sat(Xj, W[j]);                                      // (d[2j+1], d[2j+2]), saturated
-        if (j == 9 && cnt == 19) S[9] &= 0xFFFFu;                            // sample 20 does not exist
-        mn = x3_pk_min_i16(mn, S[j]);
-        mx = x3_pk_max_i16(mx, S[j]);
-      }
-      const int32_t dmin = min((int32_t)(int16_t)(mn & 0xFFFFu), (int32_t)mn >> 16);
-      const int32_t dmax = max((int32_t)(int16_t)(mx & 0xFFFFu), (int32_t)mx >> 16);
-      const int32_t maxabs = (-dmin) > dmax ? (-dmin) : dmax;
-      if (maxabs <= (int32_t)p.thr[2]) {
-        ft = (maxabs > (int32_t)p.thr[0] ? 1u : 0u) + (maxabs > (int32_t)p.thr[1] ? 1u : 0u);
-        const uint32_t k = ft == 0 ? k0 : (ft == 1 ? k1 : k2);
-        const int32_t lo = ft == 0 ? p.dmin[0] : (ft == 1 ? p.dmin[1] : p.dmin[2]);
-        const int32_t hi = ft == 0 ? p.dmax[0] : (ft == 1 ? p.dmax[1] : p.dmax[2]);
-        type = k;
-        if (dmin < lo || dmax > hi) bad = 1;  // outside the reference's Rice table (panic there)
-        uint32_t sum = 0;
-#pragma unroll
-        for (int j = 0; j < 10; ++j) {
-          S[j] = x3_pk_shl_b16(S[j], 1) ^ x3_pk_sar_i16(S[j], 15);  // zigzag, per half
-          sum = x3_pk_add_u16(sum, x3_pk_shr_u16(S[j], k));
-        }
-        nbits = bad ? 0u : 2u + cnt * (k + 1u) + (sum & 0xFFFFu) + (sum >> 16);
-        amask = (1u << k) - 1u;
-        orc = 1u << k;
-        qsh = k;
-        qmask = 0xFFFFFFFFu;
-        lbase = k + 1u;
-      } else {
-        nb = 32u - (uint32_t)__clz(maxabs);
-        if (nb >= 15) {
-          type = 5;
-          nbits = 6 + 16 * cnt;
-#pragma unroll
-          for (int j = 0; j < 10; ++j) S[j] = __builtin_amdgcn_alignbit(W[j + 1], W[j], 16);  // raw samples
-          amask = 0xFFFFu;
-          lbase = 16;
-        } else {
-          type = 4;
-          nbits = 6 + cnt * (nb + 1);
-          amask = (1u << (nb + 1)) - 1u;  // S already holds the exact diffs
-          lbase = nb + 1;
-        }
-      }
-    } else if (cnt) {
-      // scalar path for a short block (tail frames only): sizes now, emission below from a private copy
-      int32_t dmin = 0, dmax = 0, prev = in_s[s0 - 1];
-      for (uint32_t i = 0; i < cnt; ++i) {
-        const int32_t s = in_s[s0 + i], d = s - prev;
-        prev = s;
-        dmin = d < dmin ? d : dmin;
-        dmax = d > dmax ? d : dmax;
-      }
-      const int32_t maxabs = (-dmin) > dmax ? (-dmin) : dmax;
-      if (maxabs <= (int32_t)p.thr[2]) {
-        ft = (maxabs > (int32_t)p.thr[0] ? 1u : 0u) + (maxabs > (int32_t)p.thr[1] ? 1u : 0u);
-        const uint32_t k = ft == 0 ? k0 : (ft == 1 ? k1 : k2);
-        const int32_t lo = ft == 0 ? p.dmin[0] : (ft == 1 ? p.dmin[1] : p.dmin[2]);
-        const int32_t hi = ft == 0 ? p.dmax[0] : (ft == 1 ? p.dmax[1] : p.dmax[2]);
-        type = k;
-        if (dmin < lo || dmax > hi) {
-          bad = 1;
-        } else {
-          uint32_t sum = 0;
-          int32_t pv = in_s[s0 - 1];
-          for (uint32_t i = 0; i < cnt; ++i) {
-            const int32_t s = in_s[s0 + i], d = s - pv;
-            pv = s;
-            sum += (((uint32_t)d << 1) ^ (uint32_t)(d >> 31)) >> k;
-          }
-          nbits = 2 + cnt * (k + 1) + sum;
-        }
-      } else {
-        nb = 32u - (uint32_t)__clz(maxabs);
-        type = nb >= 15 ? 5u : 4u;
-        nbits = nb >= 15 ? 6 + 16 * cnt : 6 + cnt * (nb + 1);
-      }
-      // keep the (< 19) samples of a short block in the S registers: in_s is overwritten by the prefetch
-#pragma unroll
-      for (int j = 0; j < 10; ++j) {
-        const uint32_t i0 = 2u * j, i1 = 2u * j + 1u;
-        const uint32_t a = i0 <= cnt ? (uint32_t)(uint16_t)in_s[s0 - 1 + i0] : 0u;   // sample r = i0 (r = 0: predecessor)
-        const uint32_t c = i1 <= cnt ? (uint32_t)(uint16_t)in_s[s0 - 1 + i1] : 0u;
-        S[j] = a | (c << 16);
-      }
-    }
-
-    // ---- C: workgroup exclusive scan of bit lengths
-    const uint32_t incl = x3_wave_incl_scan_dpp(nbits);
-    if (lane == 63 && !helper) part[wid] = incl;
-    if (bad) part[40] = 1;
-    __syncthreads();  // B1: partials ready; every compute lane holds its block in registers, in_s is free
-    uint32_t wave_base = 0, total = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < 8; ++w) {
-      const uint32_t v = part[w];
-      wave_base += (w < wid) ? v : 0u;
-      total += v;
-    }
-    const uint32_t pos = 16u + wave_base + incl - nbits;
-    const uint32_t total_bits = 16u + total;
-    const uint32_t L = (((total_bits + 7u) >> 3) + 1u) & ~1u;  // word_align (bitpacker.rs:124-132)
-    const uint32_t frame_bytes = 20u + L;
-    const bool frame_bad = part[40] != 0;
-    auto lookback = [&]() {
-      // ---- F1: decoupled look-back: sum predecessors' sizes back to the nearest inclusive prefix
-      unsigned long long run = base_pos;
-      if (f > 0) {
-        run = 0;
-        uint64_t look = f;  // descriptors [look-64, look) are inspected next
-        uint32_t spins = 0;
-        bool done = false, timeout = false;
-        while (!done) {
-          const bool in_range = look > lane;
-          const uint64_t gi = in_range ? look - 1 - lane : 0;
-          const unsigned long long d =
-              in_range ? __hip_atomic_load(&desc[gi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                       : (X3_DESC_PREFIX << X3_DESC_SHIFT) | base_pos;  // virtual frame -1
-          const uint32_t state = (uint32_t)(d >> X3_DESC_SHIFT);
-          const unsigned long long m_inv = __ballot(state == 0);
-          const unsigned long long m_pre = __ballot(state == (uint32_t)X3_DESC_PREFIX);
-          const int first_pre = m_pre ? __ffsll((long long)m_pre) - 1 : 64;
-          const unsigned long long need = first_pre >= 64 ? ~0ull : ((1ull << first_pre) - 1ull);
-          if (m_inv & need) {  // a nearer predecessor has not published its size yet
-            // wait for the NEAREST missing descriptor with a single lane (64x less polling traffic than
-            // re-reading the whole window: pollers slow everybody's memory traffic), then look again
-            const int miss = __ffsll((long long)(m_inv & need)) - 1;
-            if ((int)lane == miss) {
-              unsigned long long dd = 0;
-              while ((dd >> X3_DESC_SHIFT) == 0 && ++spins <= X3_SPIN_LIMIT) {
-                __builtin_amdgcn_s_sleep(2);
-                dd = __hip_atomic_load(&desc[gi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              }
-            }
-            spins = __shfl(spins, miss, X3_WAVE);
-            if (spins > X3_SPIN_LIMIT) { timeout = true; break; }
-            continue;
-          }
-          unsigned long long v = ((int)lane <= first_pre) ? (d & X3_DESC_MASK) : 0ull;
-#pragma unroll
-          for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, X3_WAVE);
-          run += v;
-          if (first_pre < 64) done = true;
-          else look -= 64;
-        }
-        if (timeout) {
-          if (lane == 0) atomicMax(&status[1], X3D_LOOKBACK_TIMEOUT);
-          run = 0;
-        }
-        if (lane == 0)
-          __hip_atomic_store(&desc[f], (X3_DESC_PREFIX << X3_DESC_SHIFT) | (run + frame_bytes), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if (lane == 0) {
-        part[48] = (uint32_t)run;
-        part[49] = (uint32_t)(run >> 32);
-      }
+      for (uint32_t w = 0; w < X3_LB_WINDOWS; ++w)
+        dq[w] = __hip_atomic_load(p0 - 64 * (int)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
-    if (helper) {
-      // prefetch the next frame of this workgroup straight into LDS (in_s is free: every block is in
-      // registers); the requests are hidden from hipcc and waited for before B3
-      {
-        const uint64_t fn = f + gridDim.x;
-        if (fn < g.n_frames) {
-          const int16_t* nsrc;
-          uint32_t nn;
-          frame_geom(fn, nsrc, nn);
-          x3_stage_frame_dma(nsrc, nn, in_s, lane);
+    auto resolve = [&]() __attribute__((always_inline)) {
+      // finish the pending frame's offset: all of its predecessors' sizes must have arrived
+      const uint32_t needed = first ? (uint32_t)pend_f : G - 1u;  // sizes in front of pend_f that count
+      const uint32_t nwin = (needed + 63u) >> 6;
+      const uint32_t* p0 = desc + pend_f - lane1;
+      uint32_t sum = 0, spins = 0;
+      bool timeout = false;
+#pragma unroll
+      for (uint32_t w = 0; w < X3_LB_WINDOWS; ++w) {
+        if (w < nwin) {
+          const bool in = (int32_t)lane1 <= (int32_t)needed - 64 * (int32_t)w;
+          uint32_t v = in ? dq[w] : ready_tag;  // "ready, 0 bytes" outside the range
+#ifdef X3_DBG_STAMPS
+          {
+            const unsigned long long miss = __ballot((v >> X3_DESC_BYTES_BITS) != epoch);
+            if (miss) dbg_acc[7] += (1ull << 32) + ((unsigned long long)__popcll(miss) << 48);
+          }
+#endif
+          while (__any((v >> X3_DESC_BYTES_BITS) != epoch)) {
+#ifdef X3_DBG_STAMPS
+            dbg_acc[7] += 1;
+#endif
+            if (++spins > X3_SPIN_LIMIT) { timeout = true; break; }
+            __builtin_amdgcn_s_sleep(8);
+            const uint32_t r = __hip_atomic_load(p0 - 64 * (int)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = in ? r : ready_tag;
+          }
+          sum += v & X3_DESC_BYTES_MASK;
         }
       }
-      // publish this frame's size as early as possible (successors' look-backs sum these)
+      unsigned long long tot = 0;
+      if (nwin > X3_LB_WINDOWS) {  // grids wider than 512 workgroups: the rest synchronously, summed in 64 bits
+        unsigned long long acc = 0;
+        for (uint32_t w = X3_LB_WINDOWS; w < nwin && !timeout; ++w) {
+          const bool in = lane1 + 64u * w <= needed;
+          uint32_t v;
+          for (;;) {
+            const uint32_t r = __hip_atomic_load(p0 - 64 * (int64_t)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = in ? r : ready_tag;
+            if (!__any((v >> X3_DESC_BYTES_BITS) != epoch)) break;
+            if (++spins > X3_SPIN_LIMIT) { timeout = true; break; }
+            __builtin_amdgcn_s_sleep(8);
+          }
+          acc += v & X3_DESC_BYTES_MASK;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, X3_WAVE);
+        tot = acc;
+      }
+      X3_STAMP(1);  // windows examined
+      // 8 windows x 64 lanes x 2^20 < 2^32: a 32-bit DPP scan, total in lane 63
+      tot += (unsigned long long)__builtin_amdgcn_readlane(x3_wave_incl_scan_dpp(sum), 63);
+      uint64_t off = (first ? base_pos : my_off + my_bytes) + tot;
+      if (timeout) {
+        if (lane == 0) atomicMax(&status[1], X3D_LOOKBACK_TIMEOUT);
+        off = 0;
+      }
+      my_off = off;
+      my_bytes = pend_bytes;
+      first = false;
+      X3_STAMP(0);  // reduced
       if (lane == 0) {
-        const unsigned long long d = f == 0 ? ((X3_DESC_PREFIX << X3_DESC_SHIFT) | (base_pos + frame_bytes))
-                                            : ((X3_DESC_AGG << X3_DESC_SHIFT) | (unsigned long long)frame_bytes);
-        __hip_atomic_store(&desc[f], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // header CRC (encoder.rs:153-154) needs only the frame's sample count and payload length
-        uint32_t hc = 0xFFFFu;
-        hc = x3_crc_be32(hc, 0x78330101u);
-        hc = x3_crc_be32(hc, ((n & 0xFFFFu) << 16) | (L & 0xFFFFu));
-        hc = x3_crc_be32(hc, 0);
-        hc = x3_crc_be32(hc, 0);
+        part[48] = (uint32_t)off;
+        part[49] = (uint32_t)(off >> 32);
+        frame_off[pend_f] = off;
+        if (off + pend_bytes > out_cap) atomicMax(&status[0], X3D_BYTE_WRITER_INSUFFICIENT_MEMORY);
+        if (part[40] != 0) atomicMax(&status[0], X3D_BAD_ARG);
+        if (pend_f == g.n_frames - 1) {
+          frame_off[g.n_frames] = off + pend_bytes;
+          *end_pos = off + pend_bytes;
+        }
+        if (pend_f == 0 && (start_pos & 1ull) && start_pos < out_cap) out[start_pos] = 0;  // align pad byte
+      }
+      pending = false;
+    };
+
+    for (uint64_t f = blockIdx.x; f < g.n_frames; f += G) {
+      // nothing of this wave is in flight here except last frame's bookkeeping stores: tell hipcc so, or its
+      // wait-count pass protects registers of the polling loads (maybe pending on the loop's back edge) with
+      // vmcnt(0) waits in the middle of the prefetch below -- which then waits for the prefetch itself
+      x3_dma_wait();
+      const int16_t* src;
+      uint32_t n;
+      geom_at(clip_f, idx_f, src, n);
+      (void)src;
+      geom_advance(clip_f, idx_f);  // now the geometry of f + G
+      X3_STAMP(0);
+      __syncthreads();  // B1: bit-length partials ready; every block is in registers, in_s is free
+      X3_STAMP(2);
+      uint32_t total = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < 8; ++w) total += part[w];
+      const uint32_t L = (((16u + total + 7u) >> 3) + 1u) & ~1u;  // word_align (bitpacker.rs:124-132)
+      const uint32_t frame_bytes = 20u + L;
+      // publish this frame's size as early as possible
+      if (lane == 0)
+        __hip_atomic_store(&desc[f], ready_tag | frame_bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // prefetch the next frame of this workgroup straight into LDS; the requests are hidden from hipcc
+      // and waited for before B3
+      const uint64_t fn = f + G;
+      if (fn < g.n_frames) {
+        const int16_t* nsrc;
+        uint32_t nn;
+        geom_at(clip_f, idx_f, nsrc, nn);
+        x3_stage_frame_dma(nsrc, nn, in_s, lane);
+      }
+      // request the sizes in front of the PREVIOUS frame of this workgroup (published a whole frame time
+      // ago unless a workgroup lags by more than that).  Memory operations retire in order, so these words
+      // arrive behind the prefetch -- which has to be complete before B3 anyway.
+      if (pending) request();
+      X3_STAMP(3);
+      __syncthreads();  // B2: image zeroed
+      X3_STAMP(2);
+      // header CRC (encoder.rs:153-154): it needs only the sample count and the payload length.  The state
+      // behind the constant bytes "x3", id, id is a constant; the (samples, payload_len) word and the
+      // eight zero time bytes go through the slicing tables (a zero word is two look-ups).
+      if (lane == 0) {
+        constexpr uint32_t K4 = x3_crc16_const4(0x78u, 0x33u, 0x01u, 0x01u);
+        const uint32_t m = (((n & 0xFFFFu) << 16) | (L & 0xFFFFu)) ^ (K4 << 16);
+        uint32_t hc = (uint32_t)crc_tab[768u + (m >> 24)] ^ (uint32_t)crc_tab[512u + ((m >> 16) & 0xFFu)] ^
+                      (uint32_t)crc_tab[256u + ((m >> 8) & 0xFFu)] ^ (uint32_t)crc_tab[m & 0xFFu];
+        hc = (uint32_t)crc_tab[768u + (hc >> 8)] ^ (uint32_t)crc_tab[512u + (hc & 0xFFu)];
+        hc = (uint32_t)crc_tab[768u + (hc >> 8)] ^ (uint32_t)crc_tab[512u + (hc & 0xFFu)];
         part[50] = hc;
       }
-    } else {
-      // zero the image words this frame uses (header + payload, rounded up to 16 bytes)
-      uint4* z4 = reinterpret_cast<uint4*>(img);
-      const uint32_t nz = (5u + ((L + 3u) >> 2) + 3u) >> 2;
-      const uint4 zero = make_uint4(0, 0, 0, 0);
-      for (uint32_t i = tid; i < nz; i += nthr) z4[i] = zero;
+      X3_STAMP(4);
+      x3_dma_wait();    // the next frame's samples have landed in LDS (and the requested sizes behind them)
+      X3_STAMP(6);
+      if (pending) resolve();  // the previous frame's offset: consumed by the compute waves behind B3
+      X3_STAMP(5);
+      __syncthreads();  // B3: emission complete, next frame's samples landed, previous frame's offset known
+      X3_STAMP(2);
+      pend_f = f;
+      pend_bytes = frame_bytes;
+      pending = true;
+      __syncthreads();  // B4: CRC partials ready
+      X3_STAMP(2);
     }
-    __syncthreads();  // B2: image zeroed
+    if (pending) {
+      request();
+      resolve();
+    }
+    __syncthreads();  // B5: the last frame's offset
+  } else {
+    // =============================================================== compute waves
+    uint32_t prev_bytes = 0;
+    bool have_prev = false;
+    uint32_t cur = 0;
+    auto copy_out = [&](const uint32_t* img, uint32_t total_bytes) __attribute__((always_inline)) {
+      // header + payload of a finished frame to its final stream position (part[48..49])
+      const uint64_t off = (uint64_t)part[48] | ((uint64_t)part[49] << 32);
+      if (off + total_bytes <= out_cap && part[40] == 0) {
+        uint8_t* dst = out + off;
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u);
+        if (mis == 0) {
+          const uint32_t ndw = total_bytes >> 2;
+          uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);
+          for (uint32_t i = tid; i < ndw; i += nthr) d32[i] = img[i];
+          if ((total_bytes & 2u) && tid == 0) *reinterpret_cast<uint16_t*>(dst + 4 * ndw) = (uint16_t)img[ndw];
+        } else if (mis == 2) {
+          if (tid == 0) *reinterpret_cast<uint16_t*>(dst) = (uint16_t)img[0];
+          const uint32_t rem = total_bytes - 2u;
+          const uint32_t ndw = rem >> 2;
+          uint32_t* d32 = reinterpret_cast<uint32_t*>(dst + 2);
+          for (uint32_t i = tid; i < ndw; i += nthr) d32[i] = (img[i] >> 16) | (img[i + 1] << 16);
+          if ((rem & 2u) && tid == 0) *reinterpret_cast<uint16_t*>(dst + 2 + 4 * ndw) = (uint16_t)(img[ndw] >> 16);
+        } else {
+          for (uint32_t i = tid; i < total_bytes; i += nthr) dst[i] = (uint8_t)(img[i >> 2] >> (8 * (i & 3u)));
+        }
+      }
+    };
 
-    if (helper) {
-#ifdef X3_LB_EARLY
-      lookback();
-#endif
-    } else {
+    for (uint64_t f = blockIdx.x; f < g.n_frames; f += G) {
+      const int16_t* src;
+      uint32_t n;
+      geom_at(clip_f, idx_f, src, n);
+      (void)src;
+      geom_advance(clip_f, idx_f);
+      uint32_t* img = img0 + cur * img_dwords;
+
+      // ---- B: one block per lane, in registers (blocks of 19 or 20 samples; shorter ones: scalar path)
+      const uint32_t nblocks = (n - 1 + 19) / 20;
+      const uint32_t b = tid;
+      const bool valid = b < nblocks;
+      const uint32_t s0 = 1 + b * 20;
+      const uint32_t cnt = valid ? (n - s0 < 20 ? n - s0 : 20) : 0;
+      const bool regs = cnt >= 19;
+      const uint32_t s_first = (uint32_t)(uint16_t)in_s[0];
+
+      uint32_t S[10];   // emission source per pair of block samples (r = 2j+1, 2j+2)
+      uint32_t type = 0, ft = 0, nb = 0, nbits = 0, bad = 0;
+      uint32_t amask = 0, orc = 0, qsh = 0, qmask = 0, lbase = 0;  // (code,len) recipe, see file header
+      if (regs) {
+        uint32_t W[11];   // samples 20b .. 20b+21 as (even, odd) pairs
+        const uint2* r2 = reinterpret_cast<const uint2*>(in_w + 10 * b);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const uint2 v = r2[j];
+          W[2 * j] = v.x;
+          W[2 * j + 1] = v.y;
+        }
+        W[10] = in_w[10 * b + 10];
+        uint32_t mn = 0, mx = 0;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+          const uint32_t Xj = __builtin_amdgcn_alignbit(W[j + 1], W[j], 16);  // (s[2j+1], s[2j+2])
+          S[j] = x3_pk_sub_sat(Xj, W[j]);                                      // (d[2j+1], d[2j+2]), saturated
+          if (j == 9 && cnt == 19) S[9] &= 0xFFFFu;                            // sample 20 does not exist
+          mn = x3_pk_min_i16(mn, S[j]);
+          mx = x3_pk_max_i16(mx, S[j]);
+        }
+        const int32_t dmin = min((int32_t)(int16_t)(mn & 0xFFFFu), (int32_t)mn >> 16);
+        const int32_t dmax = max((int32_t)(int16_t)(mx & 0xFFFFu), (int32_t)mx >> 16);
+        const int32_t maxabs = (-dmin) > dmax ? (-dmin) : dmax;
+        if (maxabs <= (int32_t)p.thr[2]) {
+          ft = (maxabs > (int32_t)p.thr[0] ? 1u : 0u) + (maxabs > (int32_t)p.thr[1] ? 1u : 0u);
+          const uint32_t k = ft == 0 ? k0 : (ft == 1 ? k1 : k2);
+          const int32_t lo = ft == 0 ? p.dmin[0] : (ft == 1 ? p.dmin[1] : p.dmin[2]);
+          const int32_t hi = ft == 0 ? p.dmax[0] : (ft == 1 ? p.dmax[1] : p.dmax[2]);
+          type = k;
+          if (dmin < lo || dmax > hi) bad = 1;  // outside the reference's Rice table (panic there)
+          uint32_t sum = 0;
+#pragma unroll
+          for (int j = 0; j < 10; ++j) {
+            S[j] = x3_pk_shl_b16(S[j], 1) ^ x3_pk_sar_i16(S[j], 15);  // zigzag, per half
+            sum = x3_pk_add_u16(sum, x3_pk_shr_u16(S[j], k));
+          }
+          nbits = bad ? 0u : 2u + cnt * (k + 1u) + (sum & 0xFFFFu) + (sum >> 16);
+          amask = (1u << k) - 1u;
+          orc = 1u << k;
+          qsh = k;
+          qmask = 0xFFFFFFFFu;
+          lbase = k + 1u;
+        } else {
+          nb = 32u - (uint32_t)__clz(maxabs);
+          if (nb >= 15) {
+            type = 5;
+            nbits = 6 + 16 * cnt;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) S[j] = __builtin_amdgcn_alignbit(W[j + 1], W[j], 16);  // raw samples
+            amask = 0xFFFFu;
+            lbase = 16;
+          } else {
+            type = 4;
+            nbits = 6 + cnt * (nb + 1);
+            amask = (1u << (nb + 1)) - 1u;  // S already holds the exact diffs
+            lbase = nb + 1;
+          }
+        }
+      } else if (cnt) {
+        // scalar path for a short block (tail frames only): sizes now, emission below from a private copy
+        int32_t dmin = 0, dmax = 0, prev = in_s[s0 - 1];
+        for (uint32_t i = 0; i < cnt; ++i) {
+          const int32_t s = in_s[s0 + i], d = s - prev;
+          prev = s;
+          dmin = d < dmin ? d : dmin;
+          dmax = d > dmax ? d : dmax;
+        }
+        const int32_t maxabs = (-dmin) > dmax ? (-dmin) : dmax;
+        if (maxabs <= (int32_t)p.thr[2]) {
+          ft = (maxabs > (int32_t)p.thr[0] ? 1u : 0u) + (maxabs > (int32_t)p.thr[1] ? 1u : 0u);
+          const uint32_t k = ft == 0 ? k0 : (ft == 1 ? k1 : k2);
+          const int32_t lo = ft == 0 ? p.dmin[0] : (ft == 1 ? p.dmin[1] : p.dmin[2]);
+          const int32_t hi = ft == 0 ? p.dmax[0] : (ft == 1 ? p.dmax[1] : p.dmax[2]);
+          type = k;
+          if (dmin < lo || dmax > hi) {
+            bad = 1;
+          } else {
+            uint32_t sum = 0;
+            int32_t pv = in_s[s0 - 1];
+            for (uint32_t i = 0; i < cnt; ++i) {
+              const int32_t s = in_s[s0 + i], d = s - pv;
+              pv = s;
+              sum += (((uint32_t)d << 1) ^ (uint32_t)(d >> 31)) >> k;
+            }
+            nbits = 2 + cnt * (k + 1) + sum;
+          }
+        } else {
+          nb = 32u - (uint32_t)__clz(maxabs);
+          type = nb >= 15 ? 5u : 4u;
+          nbits = nb >= 15 ? 6 + 16 * cnt : 6 + cnt * (nb + 1);
+        }
+        // keep the (< 19) samples of a short block in the S registers: in_s is overwritten by the prefetch
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+          const uint32_t i0 = 2u * j, i1 = 2u * j + 1u;
+          const uint32_t a = i0 <= cnt ? (uint32_t)(uint16_t)in_s[s0 - 1 + i0] : 0u;   // sample r = i0 (r = 0: predecessor)
+          const uint32_t c = i1 <= cnt ? (uint32_t)(uint16_t)in_s[s0 - 1 + i1] : 0u;
+          S[j] = a | (c << 16);
+        }
+      }
+
+
+      X3_STAMP(0);
+      // ---- C: workgroup exclusive scan of bit lengths
+      const uint32_t incl = x3_wave_incl_scan_dpp(nbits);
+      if (lane == 63) part[wid] = incl;
+      if (bad) part[40] = 1;
+      X3_STAMP(1);
+      __syncthreads();  // B1: partials ready; every compute lane holds its block in registers, in_s is free
+      X3_STAMP(2);
+      uint32_t wave_base = 0, total = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < 8; ++w) {
+        const uint32_t v = part[w];
+        wave_base += (w < wid) ? v : 0u;
+        total += v;
+      }
+      const uint32_t pos = 16u + wave_base + incl - nbits;
+      const uint32_t total_bits = 16u + total;
+      const uint32_t L = (((total_bits + 7u) >> 3) + 1u) & ~1u;  // word_align (bitpacker.rs:124-132)
+      const uint32_t frame_bytes = 20u + L;
+      {
+        // zero the image words this frame uses (header + payload, rounded up to 16 bytes)
+        uint4* z4 = reinterpret_cast<uint4*>(img);
+        const uint32_t nz = (5u + ((L + 3u) >> 2) + 3u) >> 2;
+        const uint4 zero = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = tid; i < nz; i += nthr) z4[i] = zero;
+      }
+      X3_STAMP(3);
+      __syncthreads();  // B2: image zeroed
+      X3_STAMP(2);
+
       if (tid == 0) atomicOr(&img[5], x3_bswap32(s_first << 16));  // <Audio State> (encoder.rs:189)
       // ---- D: emission
       if (nbits) {
@@ -460,16 +636,17 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
       // statistics (encoder.rs:199): stats[type] += block.len(); one LDS atomic per lane, summed over
       // all frames of this workgroup and flushed once at the end
       if (cnt) atomicAdd(&part[32 + type], cnt);
-    }
-    if (helper) x3_dma_wait();  // the next frame's samples have landed in LDS
-    __syncthreads();  // B3: emission complete, next frame's samples landed
 
-    uint32_t crc = 0;
-    if (helper) {
-#ifndef X3_LB_EARLY
-      lookback();
-#endif
-    } else {
+      X3_STAMP(4);
+      __syncthreads();  // B3: emission complete, next frame's samples landed, previous frame's offset known
+      X3_STAMP(2);
+
+      // ---- F: the PREVIOUS frame goes out now (its offset needed every predecessor's size: that wait
+      // overlapped this frame's analysis and emission)
+      if (have_prev) copy_out(img0 + (cur ^ 1u) * img_dwords, prev_bytes);
+      X3_STAMP(6);
+
+      uint32_t crc = 0;
       // ---- E: payload CRC-16 as a segmented reduction:
       // crc0(payload) = XOR over lanes t of crc0(chunk_t) * x^(32*c_dw*(511-t)) mod P; each lane
       // multiplies by ITS OWN power of x (table xk) and the products are XOR-reduced.
@@ -501,67 +678,37 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) crc ^= __shfl_xor(crc, o, X3_WAVE);
       if (lane == 0) part[16 + wid] = crc;
-    }
-    __syncthreads();  // B4: CRC partials and the frame offset are in LDS
 
-    // ---- F2: header (wave 0) + copy header and payload to the final stream position
-    const uint64_t off = (uint64_t)part[48] | ((uint64_t)part[49] << 32);
-    const uint32_t total_bytes = frame_bytes;
-    const bool fits = off + total_bytes <= out_cap;
-    if (!helper) {
-      if (wid == 0) {
-        if (lane == 0) {
-          uint32_t v = 0;
+      X3_STAMP(5);
+      __syncthreads();  // B4: CRC partials are in LDS
+      X3_STAMP(2);
+      if (tid == 0) {
+        uint32_t v = 0;
 #pragma unroll
-          for (uint32_t w = 0; w < 8; ++w) v ^= part[16 + w];
-          if (L & 2u) v = x3_gf_mul_const<X3_XINV16_C>(v);  // undo the 2 virtual pad-to-4 bytes
-          // frame header (encoder.rs:122-162): "x3", id, id, samples, payload_len, 8 zero time bytes,
-          // header crc over bytes 0..16 (computed by the helper wave), payload crc; audio frames use id 1
-          const uint32_t h0 = 0x78330101u;
-          const uint32_t h1 = ((n & 0xFFFFu) << 16) | (L & 0xFFFFu);
-          const uint32_t hc = part[50];
-          img[0] = x3_bswap32(h0);
-          img[1] = x3_bswap32(h1);
-          img[2] = 0;
-          img[3] = 0;
-          img[4] = x3_bswap32((hc << 16) | (v & 0xFFFFu));
-        }
-        // the header words are consumed by lanes 0..4 of this same wave: LDS order within a wave suffices
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t w = 0; w < 8; ++w) v ^= part[16 + w];
+        if (L & 2u) v = x3_gf_mul_const<X3_XINV16_C>(v);  // undo the 2 virtual pad-to-4 bytes
+        // frame header (encoder.rs:122-162): "x3", id, id, samples, payload_len, 8 zero time bytes,
+        // header crc over bytes 0..16 (computed by the helper wave), payload crc; audio frames use id 1
+        const uint32_t h0 = 0x78330101u;
+        const uint32_t h1 = ((n & 0xFFFFu) << 16) | (L & 0xFFFFu);
+        const uint32_t hc = part[50];
+        img[0] = x3_bswap32(h0);
+        img[1] = x3_bswap32(h1);
+        img[2] = 0;
+        img[3] = 0;
+        img[4] = x3_bswap32((hc << 16) | (v & 0xFFFFu));
       }
-      if (fits && !frame_bad) {
-        uint8_t* dst = out + off;
-        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u);
-        if (mis == 0) {
-          const uint32_t ndw = total_bytes >> 2;
-          uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);
-          for (uint32_t i = tid; i < ndw; i += nthr) d32[i] = img[i];
-          if ((total_bytes & 2u) && tid == 0) *reinterpret_cast<uint16_t*>(dst + 4 * ndw) = (uint16_t)img[ndw];
-        } else if (mis == 2) {
-          if (tid == 0) *reinterpret_cast<uint16_t*>(dst) = (uint16_t)img[0];
-          const uint32_t rem = total_bytes - 2u;
-          const uint32_t ndw = rem >> 2;
-          uint32_t* d32 = reinterpret_cast<uint32_t*>(dst + 2);
-          for (uint32_t i = tid; i < ndw; i += nthr) d32[i] = (img[i] >> 16) | (img[i + 1] << 16);
-          if ((rem & 2u) && tid == 0) *reinterpret_cast<uint16_t*>(dst + 2 + 4 * ndw) = (uint16_t)(img[ndw] >> 16);
-        } else {
-          for (uint32_t i = tid; i < total_bytes; i += nthr) dst[i] = (uint8_t)(img[i >> 2] >> (8 * (i & 3u)));
-        }
-      }
-    } else if (lane == 0) {
-      frame_off[f] = off;
-      if (!fits) atomicMax(&status[0], X3D_BYTE_WRITER_INSUFFICIENT_MEMORY);
-      if (frame_bad) atomicMax(&status[0], X3D_BAD_ARG);
-      if (f == g.n_frames - 1) {
-        frame_off[g.n_frames] = off + total_bytes;
-        *end_pos = off + total_bytes;
-      }
-      if (f == 0 && (start_pos & 1ull) && start_pos < out_cap) out[start_pos] = 0;  // align pad byte
+      prev_bytes = frame_bytes;
+      have_prev = true;
+      cur ^= 1u;
     }
-    // no barrier here: the next iteration's B1 orders this copy-out before the image is zeroed again
+    __syncthreads();  // B5: the last frame's header and offset
+    copy_out(img0 + (cur ^ 1u) * img_dwords, prev_bytes);
   }
+#ifdef X3_DBG_STAMPS
+  if (lane == 0 && (wid == 0 || wid == 8) && blockIdx.x < 2048)
+    for (int k = 0; k < 8; ++k) x3_dbg[(blockIdx.x * 2 + (wid == 8)) * 8 + k] = dbg_acc[k];
+#endif
   __syncthreads();
   if (tid < 6) {
     const uint32_t v = part[32 + tid];  // < 2^32: at most 135 frames x 10 000 samples per workgroup... see host check
