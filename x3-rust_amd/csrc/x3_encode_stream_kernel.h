@@ -219,6 +219,8 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
 #endif
   // ---- prologue: the first frame is staged by the helper wave
   if (tid < 64) part[tid] = 0;
+  for (uint32_t i = tid; i < (2u * img_dwords) >> 2; i += X3_STREAM_THREADS)
+    reinterpret_cast<uint4*>(img0)[i] = make_uint4(0, 0, 0, 0);  // both frame images start clear
   if (tid < 512) reinterpret_cast<uint32_t*>(crc_tab)[tid] = reinterpret_cast<const uint32_t*>(crc_tab_g)[tid];
   if (helper_wave) {
     const int16_t* src;
@@ -369,8 +371,6 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
       // arrive behind the prefetch -- which has to be complete before B3 anyway.
       if (pending) request();
       X3_STAMP(3);
-      __syncthreads();  // B2: image zeroed
-      X3_STAMP(2);
       // header CRC (encoder.rs:153-154): it needs only the sample count and the payload length.  The state
       // behind the constant bytes "x3", id, id is a constant; the (samples, payload_len) word and the
       // eight zero time bytes go through the slicing tables (a zero word is two look-ups).
@@ -570,16 +570,6 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
       const uint32_t total_bits = 16u + total;
       const uint32_t L = (((total_bits + 7u) >> 3) + 1u) & ~1u;  // word_align (bitpacker.rs:124-132)
       const uint32_t frame_bytes = 20u + L;
-      {
-        // zero the image words this frame uses (header + payload, rounded up to 16 bytes)
-        uint4* z4 = reinterpret_cast<uint4*>(img);
-        const uint32_t nz = (5u + ((L + 3u) >> 2) + 3u) >> 2;
-        const uint4 zero = make_uint4(0, 0, 0, 0);
-        for (uint32_t i = tid; i < nz; i += nthr) z4[i] = zero;
-      }
-      X3_STAMP(3);
-      __syncthreads();  // B2: image zeroed
-      X3_STAMP(2);
 
       if (tid == 0) atomicOr(&img[5], x3_bswap32(s_first << 16));  // <Audio State> (encoder.rs:189)
       // ---- D: emission
@@ -697,6 +687,14 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
         img[2] = 0;
         img[3] = 0;
         img[4] = x3_bswap32((hc << 16) | (v & 0xFFFFu));
+      }
+      // the image of the PREVIOUS frame went out behind B3 (every wave is past B4 now): clear what it used,
+      // ready for the frame after this one.  No barrier of its own: the next B1 separates it from emission.
+      if (have_prev) {
+        uint4* z4 = reinterpret_cast<uint4*>(img0 + (cur ^ 1u) * img_dwords);
+        const uint32_t nz = (((prev_bytes + 3u) >> 2) + 3u) >> 2;
+        const uint4 zero = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = tid; i < nz; i += nthr) z4[i] = zero;
       }
       prev_bytes = frame_bytes;
       have_prev = true;
