@@ -1,0 +1,24 @@
+#!/bin/bash
+# Collect everything profiles/rN/ holds, on the GPU box, from the repo root:
+#   tools/profile_round.sh gpurun_out/r1
+# 1. the default bench line; 2. rocprofv3 --kernel-trace --stats of the same command; 3. separate PMC
+# passes (FETCH_SIZE, WRITE_SIZE, SQ counters) as MI355X_MICROARCH.md prescribes (no other trace domains).
+out=$1
+mkdir -p $out
+export TMPDIR=/tmp
+root=$PWD
+python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $root/$out/stats -o bench --output-format csv -- python3 $root/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $root/$out/stats.log 2>&1)
+cp $out/stats/bench_kernel_stats.csv $out/bench_kernel_stats.csv 2>/dev/null
+cp $out/stats/bench_domain_stats.csv $out/bench_domain_stats.csv 2>/dev/null
+i=0
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"; do
+  i=$((i+1))
+  (cd /tmp && rocprofv3 --kernel-trace --pmc $grp -d $root/$out/pmc$i -o pmc --output-format csv -- python3 $root/tools/kbench.py --steps 3 > $root/$out/pmc$i.log 2>&1)
+done
+python3 tools/pmc_summary.py $out/pmc1 x3_ > $out/pmc_fetch_size.txt
+python3 tools/pmc_summary.py $out/pmc2 x3_ > $out/pmc_write_size.txt
+python3 tools/pmc_summary.py $out/pmc3 x3_ > $out/pmc_sq.txt
+python3 tools/make_traffic.py $out/pmc1 $out/pmc2 > $out/traffic.json
+rm -rf $out/stats/*.db $out/pmc*/*.db
+cat $out/bench_default.json
