@@ -106,3 +106,46 @@ __device__ __forceinline__ uint32_t x3_wave_incl_scan(uint32_t v, int lane) {
   }
   return v;
 }
+
+// packed 16-bit helpers (VOP3P: both halves of a dword at once)
+__device__ __forceinline__ uint32_t x3_pk_add_u16(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ uint32_t x3_pk_sub_u16(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_sub_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ uint32_t x3_pk_max_u16(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ uint32_t x3_pk_lshr_b16_1(uint32_t a) {
+  uint32_t r;
+  asm("v_pk_lshrrev_b16 %0, 1, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a));
+  return r;
+}
+__device__ __forceinline__ uint32_t x3_pk_ashr_i16_15(uint32_t a) {
+  uint32_t r;
+  asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a));
+  return r;
+}
+// (a & 0xFFFF) | (b << 16)
+__device__ __forceinline__ uint32_t x3_pack_lo16(uint32_t a, uint32_t b) {
+  return __builtin_amdgcn_perm(b, a, 0x05040100u);
+}
+// (m & a) | (~m & b)
+__device__ __forceinline__ uint32_t x3_bfi(uint32_t m, uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+  return r;
+}
+// v_ffbh_u32 without __clz's clamp: -1 (not 32) for 0
+__device__ __forceinline__ uint32_t x3_ffbh(uint32_t a) {
+  uint32_t r;
+  asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(a));
+  return r;
+}

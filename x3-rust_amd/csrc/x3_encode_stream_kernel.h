@@ -44,11 +44,6 @@ __device__ __forceinline__ uint32_t x3_pk_max_i16(uint32_t a, uint32_t b) {
   asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
-__device__ __forceinline__ uint32_t x3_pk_add_u16(uint32_t a, uint32_t b) {
-  uint32_t r;
-  asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
 __device__ __forceinline__ uint32_t x3_pk_shl_b16(uint32_t a, uint32_t sh) {  // a << sh, per half
   uint32_t r;
   asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(r) : "v"(sh * 0x10001u), "v"(a));
