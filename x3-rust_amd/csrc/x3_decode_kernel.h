@@ -560,26 +560,27 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
   s_wo[lane] = wo;
   s_ns[lane] = coop ? samples : 0u;
 
-  // ---- input ring (virtual offsets as in the general kernel); words are parked BIG-ENDIAN
+  // ---- input ring; words are parked BIG-ENDIAN.  Offsets are 32-bit (the host selects this kernel only
+  // for streams below 4 GiB): a chunk is x3b + (uint32) offset, i.e. one scalar base + a VGPR offset.
   const uint32_t adj = (uint32_t)(reinterpret_cast<uintptr_t>(x3) & 15u);
   const uint8_t* __restrict__ const x3b = x3 - adj;
-  const uint64_t v_end = adj + p0 + plen;
-  const uint64_t v_bits = adj + p0 + 2;
-  const uint64_t v_last = (v_end - 1) & ~15ull;
-  uint64_t v_next = v_bits & ~15ull;
+  const uint32_t v_end = adj + (uint32_t)p0 + plen;      // end of the payload
+  const uint32_t v_bits = adj + (uint32_t)p0 + 2u;       // first block header
+  const uint32_t v_last = (v_end - 1u) & ~15u;           // last 16-byte chunk that holds payload
+  uint32_t v_next = v_bits & ~15u;
   uint32_t wr_abs = 0;
 
-  auto request = [&](uint64_t v) -> uint4 {
-    const uint64_t a = v < v_last ? v : v_last;
+  auto request = [&](uint32_t v) -> uint4 {
+    const uint32_t a = v < v_last ? v : v_last;
     return *reinterpret_cast<const uint4*>(x3b + a);
   };
-  auto park = [&](uint4 c, uint64_t v) {
-    const int64_t left = (int64_t)(v_end - v);
+  auto park = [&](uint4 c, uint32_t v) {
+    const int32_t left = (int32_t)(v_end - v);
     uint32_t w[4] = {c.x, c.y, c.z, c.w};
-    if (left < 16) {
+    if (__any(left < 16)) {  // some lane is at (or past) the end of its payload: rare until the last blocks
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
-        const int64_t r = left - 4 * d;
+        const int32_t r = left - 4 * d;
         w[d] = r >= 4 ? w[d] : (r <= 0 ? 0u : (w[d] & ((1u << (8u * (uint32_t)r)) - 1u)));
       }
     }
@@ -610,7 +611,7 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
     remaining = samples - 1u;
   }
   uint4 ld0 = request(v_next), ld1 = request(v_next + 16), ld2 = request(v_next + 32);
-  uint64_t v_req = v_next;
+  uint32_t v_req = v_next;
 
   // consume n (<= 32) bits
   // The word shift is a v_bfi_b32 with a VGPR mask, NOT a compare + v_cndmask: on gfx950 a VOP2
