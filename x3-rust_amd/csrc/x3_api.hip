@@ -16,6 +16,7 @@
 
 #include "../../include/x3hip.h"
 #include "x3_decode_kernel.h"
+#include "x3_decode_split_kernel.h"
 #include "x3_device.h"
 #include "x3_encode_kernel.h"
 #include "x3_encode_stream_kernel.h"
@@ -60,6 +61,7 @@ struct x3_ctx {
   // growable scratch
   DevBuf in, out, frame_bytes, frame_off, dec_status, dec_cstatus, dec_meta, wav_off, seg_crc, desc;
   int n_cus = 0;
+  bool force_single_wave_decode = false;
   uint32_t desc_epoch = 0;    // tag of the current launch's frame-size descriptors (x3_encode_stream_kernel)
   int stream_wg_per_cu = -1;  // co-resident workgroups per CU of x3_encode_stream_kernel (-1 = not queried)
   // bookkeeping of the last async calls
@@ -798,8 +800,15 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
       const uint32_t level = k == 0 ? 1u : (1u << dp.k[k]);
       fast = fast && (dp.inv_len[k] / level + 1 + widths[k] <= 32);
     }
+    // two waves per group of 64 frames (parser + valuer) when the geometry is the plain one
+    const bool split = fast && dp.block_len == X3S_BL && !d_wav_offsets && !c->force_single_wave_decode &&
+                       !std::getenv("X3HIP_DECODE_SINGLE") && (reinterpret_cast<uintptr_t>(d_wav) & 15u) == 0 &&
+                       (dp.spf % 8u) == 0 && (g.fpc * (uint64_t)1 >= g.n_frames || (g.clip_stride % 8u) == 0);
     TimerScope ts(c, 1);
-    if (fast)
+    if (split)
+      hipLaunchKernelGGL(x3_decode_split_kernel, dim3((unsigned)((F + 63) / 64)), dim3(128), 0, c->stream, d_x3, x3_len,
+                         d_frame_offsets, F, g, dp, d_wav, wav_cap, d_status, (X3FrameMeta*)c->dec_meta.p);
+    else if (fast)
       hipLaunchKernelGGL(x3_decode_fast_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, c->stream, d_x3, x3_len,
                          d_frame_offsets, F, g, d_wav_offsets, dp, d_wav, wav_cap, d_status,
                          (X3FrameMeta*)c->dec_meta.p);

@@ -1,0 +1,346 @@
+// x3_decode_split_kernel.h -- the lane-per-frame decoder of x3_decode_fast_kernel split over TWO waves.
+//
+// Why: a frame is one serial bit stream, so decode parallelism is frames (69 120 in config 3 = 1 080
+// waves, about one per SIMD), and ONE wave can issue a VALU instruction only every ~5-8 cycles however
+// idle its SIMD is (tools/ubench/issue_cost.hip: 8.5 cycles dependent, 5.3 with four independent
+// chains; the SIMD itself sustains one every ~3).  The time of x3_decode_fast_kernel is therefore
+// (instructions per sample) x (that latency), with more than half of every SIMD unused.  Here each group
+// of 64 frames gets a workgroup of two waves on two SIMDs:
+//
+//   wave 0, the PARSER: owns the input ring and the bit window.  Per block it reads the 6 header bits and
+//     walks the codewords: for every sample the zero run z and the field v behind it, two samples per
+//     32-bit peek.  It does not compute a single sample value; it hands over i = (z << lsh) + v (the index
+//     into the reference's inverse Rice table, or simply the field for BFP/literal blocks, where z = 0),
+//     two 16-bit values per dword, through a double-buffered LDS block buffer, and the header bits.
+//   wave 1, the VALUER: turns indices into differences (zigzag / unsigned_to_i16) and samples (running sum,
+//     in packed 16-bit arithmetic), checks the table bounds, stages the samples in LDS and flushes them to
+//     HBM as 16-byte pieces of contiguous runs, and owns status and metadata.
+//
+// One s_barrier per 20-sample block: behind barrier k the parser works on block k+1 while the valuer
+// consumes block k.  Both waves derive the per-lane block sizes from the frame header alone, so their
+// loop trip counts agree whatever the payload holds; a lane whose frame fails (BFP exponent, table
+// bound) is only marked dead in the valuer -- the parser keeps walking its bits (lanes are independent,
+// and every read is bounded by the ring), the valuer stops storing for it.
+//
+// Geometry: block_len = 20 (ten pairs per block), staging window = 4 blocks = 80 samples, output frames
+// 16-byte aligned (the host launches x3_decode_fast_kernel otherwise).  Same results as the fast kernel.
+#pragma once
+#include "x3_decode_kernel.h"
+
+#define X3S_BL 20u             // block length served by this kernel
+#define X3S_PAIRS 10u
+#define X3S_WIN 80u            // samples staged per lane between flushes (4 blocks)
+#define X3S_OUT_STRIDE 42u     // dwords per staging row: 40 + 2 (8-byte aligned rows)
+#define X3S_XROWS 11u          // transfer rows per block buffer: 10 pair dwords + the header word
+
+// LDS barrier of the two waves: LDS operations retired, nothing else waited for
+#define X3S_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+__global__ void __launch_bounds__(128)
+x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uint64_t* __restrict__ frame_off,
+                       uint64_t n_frames, X3Geom g, X3DevParams p, int16_t* __restrict__ wav, uint64_t wav_cap,
+                       int32_t* __restrict__ status, X3FrameMeta* __restrict__ meta) {
+  __shared__ __attribute__((aligned(16))) uint32_t ring[64 * X3_DEC_RING_STRIDE];
+  __shared__ __attribute__((aligned(16))) uint32_t outs[64 * X3S_OUT_STRIDE];
+  __shared__ __attribute__((aligned(16))) uint32_t xfer[2 * X3S_XROWS * 64];
+  __shared__ unsigned long long s_wo[64];
+  __shared__ uint32_t s_ns[64];
+
+  const uint32_t lane = threadIdx.x & 63u;
+  const bool parser = threadIdx.x < 64u;
+  const uint64_t f = (uint64_t)blockIdx.x * 64 + lane;
+
+  // ---- per-lane frame setup, done by both waves (same checks as the fast kernel)
+  bool active = f < n_frames;
+  int32_t st = X3D_OK;
+  uint32_t samples = 0, plen = 2;
+  uint64_t p0 = 0, wo = 0;
+  if (active) {
+    uint32_t pcrc_unused;
+    st = x3_frame_header_check(reinterpret_cast<const uint32_t*>(x3 - (reinterpret_cast<uintptr_t>(x3) & 3u)),
+                               (x3_len + (reinterpret_cast<uintptr_t>(x3) & 3u) + 3) >> 2,
+                               x3_len + (reinterpret_cast<uintptr_t>(x3) & 3u),
+                               frame_off[f] + (reinterpret_cast<uintptr_t>(x3) & 3u), plen, samples, pcrc_unused);
+    if (!parser) {
+      meta[f].payload_len = plen;
+      meta[f].samples = samples;
+    }
+    p0 = frame_off[f] + 20;
+    if (st != X3D_OK) {
+      active = false;
+    } else if (samples == 0 || plen < 2) {
+      st = X3D_BAD_ARG;
+      active = false;
+    } else {
+      const uint64_t clip = f / g.fpc;
+      const uint64_t idx = f - clip * g.fpc;
+      wo = clip * g.clip_stride + idx * (uint64_t)p.spf;
+      if (wo + samples > wav_cap) {
+        st = X3D_BAD_ARG;
+        active = false;
+      }
+    }
+  }
+  if (!active) { p0 = 0; plen = 2; wo = 0; samples = 0; }
+  // blocks of this lane's frame and of the longest frame of the group: the loop both waves run
+  const uint32_t nblk = samples ? (samples - 1u + X3S_BL - 1u) / X3S_BL : 0u;
+  const uint32_t nblk_max = __builtin_amdgcn_readfirstlane(x3_wave_max_u32(nblk));
+  uint32_t remaining = samples ? samples - 1u : 0u;
+
+  if (parser) {
+    // ================================================================= wave 0: parser
+    uint32_t* const row = ring + lane * X3_DEC_RING_STRIDE;
+    // input ring; words are parked BIG-ENDIAN; 32-bit stream offsets (streams below 4 GiB)
+    const uint32_t adj = (uint32_t)(reinterpret_cast<uintptr_t>(x3) & 15u);
+    const uint8_t* __restrict__ const x3b = x3 - adj;
+    const uint32_t v_end = adj + (uint32_t)p0 + plen;
+    const uint32_t v_bits = adj + (uint32_t)p0 + 2u;
+    const uint32_t v_last = (v_end - 1u) & ~15u;
+    uint32_t v_next = v_bits & ~15u;
+    uint32_t wr_abs = 0;
+    auto request = [&](uint32_t v) -> uint4 {
+      const uint32_t a = v < v_last ? v : v_last;
+      return *reinterpret_cast<const uint4*>(x3b + a);
+    };
+    auto park = [&](uint4 c, uint32_t v) {
+      const int32_t left = (int32_t)(v_end - v);
+      uint32_t w[4] = {c.x, c.y, c.z, c.w};
+      if (__any(left < 16)) {  // some lane is at (or past) the end of its payload
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const int32_t r = left - 4 * d;
+          w[d] = r >= 4 ? w[d] : (r <= 0 ? 0u : (w[d] & ((1u << (8u * (uint32_t)r)) - 1u)));
+        }
+      }
+      *reinterpret_cast<uint4*>(row + (wr_abs & (X3_DEC_RING_DW - 1u))) =
+          make_uint4(x3_bswap32(w[0]), x3_bswap32(w[1]), x3_bswap32(w[2]), x3_bswap32(w[3]));
+      wr_abs += 4;
+    };
+    {
+      uint4 c[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) c[k] = request(v_next + 16u * k);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) park(c[k], v_next + 16u * k);
+      v_next += 128;
+    }
+    // window: w0 holds `s` unconsumed bits (its low s bits), then w1, w2; widx = ring index of w0
+    const uint32_t skip = v_bits & 15u;
+    const uint32_t a0 = skip & 3u;
+    uint32_t widx = (skip >> 2) - (a0 == 0 ? 1u : 0u);  // a0 == 0: start with a fully consumed w0
+    uint32_t s = (32u - 8u * a0) & 31u;
+    uint32_t w0 = row[widx & 31u], w1 = row[(widx + 1) & 31u], w2 = row[(widx + 2) & 31u];
+    uint32_t w3 = row[(widx + 3) & 31u];                // look-ahead word (re-read at every consume)
+    uint4 ld0 = request(v_next), ld1 = request(v_next + 16), ld2 = request(v_next + 32);
+    uint32_t v_req = v_next;
+    // consume n (<= 32) bits; the word shift is v_bfi with a VGPR mask (see x3_decode_fast_kernel)
+    auto consume = [&](uint32_t n) {
+      const int32_t s2 = (int32_t)s - (int32_t)n;
+      const uint32_t m = (uint32_t)(s2 >> 31);
+      s = (uint32_t)s2 & 31u;
+      w0 = x3_bfi(m, w1, w0);
+      w1 = x3_bfi(m, w2, w1);
+      w2 = x3_bfi(m, w3, w2);
+      widx -= m;
+      w3 = row[(widx + 3u) & 31u];
+    };
+    auto service = [&]() {
+      const uint32_t used = wr_abs - widx;  // dwords from w0 on that the ring still needs
+      const uint32_t fit = used >= X3_DEC_RING_DW ? 0u : (X3_DEC_RING_DW - used) >> 2;  // (widx may be -1)
+      if (fit > 0) park(ld0, v_req);
+      if (fit > 1) park(ld1, v_req + 16);
+      if (fit > 2) park(ld2, v_req + 32);
+      v_next += 16u * (fit > 3u ? 3u : fit);
+      v_req = v_next;
+      ld0 = request(v_req);
+      ld1 = request(v_req + 16);
+      ld2 = request(v_req + 32);
+    };
+
+    for (uint32_t b = 0; b < nblk_max; ++b) {
+      const uint32_t cnt = remaining < X3S_BL ? remaining : X3S_BL;
+      remaining -= cnt;
+      service();
+      // block header: 2 bits ftype; ftype 0 -> 4 more bits E-1 (decoder.rs:138-144, 209-216)
+      const uint32_t hdr = __builtin_amdgcn_alignbit(w0, w1, s) >> 26;
+      const uint32_t ftype = hdr >> 4;
+      const bool bfp = ftype == 0;
+      consume(cnt ? (bfp ? 6u : 2u) : 0u);
+      const uint32_t zmask = bfp ? 0u : 0xFFFFFFFFu;
+      const uint32_t width = bfp ? (hdr & 15u) + 1u : (ftype == 1u ? 1u : (ftype == 2u ? 2u : 4u));
+      const uint32_t lsh = bfp || ftype == 1u ? 0u : (ftype == 2u ? p.k[1] : p.k[2]);
+      const uint32_t rsh = 32u - width;
+      uint32_t* const buf = xfer + (b & 1u) * (X3S_XROWS * 64u) + lane;
+      buf[X3S_PAIRS * 64u] = hdr;
+      if (__all(cnt == X3S_BL || cnt == 0u)) {
+        // two samples per 32-bit peek and per window update (two valid codewords are <= 32 bits)
+#pragma unroll 2
+        for (uint32_t j = 0; j < X3S_PAIRS; ++j) {
+          const uint32_t t = __builtin_amdgcn_alignbit(w0, w1, s);
+          const uint32_t z1 = x3_ffbh(t) & zmask;
+          const uint32_t v1 = (t << (z1 & 31u)) >> rsh;
+          const uint32_t n1 = z1 + width;
+          const uint32_t t2 = t << (n1 & 31u);
+          const uint32_t z2 = x3_ffbh(t2) & zmask;
+          const uint32_t v2 = (t2 << (z2 & 31u)) >> rsh;
+          consume(n1 + z2 + width);
+          buf[j * 64u] = x3_pack_lo16((z1 << lsh) + v1, (z2 << lsh) + v2);
+        }
+      } else {
+        // a block that is short in some lane (the last block of a frame): one sample at a time
+        uint16_t* const h = reinterpret_cast<uint16_t*>(buf);
+        for (uint32_t j = 0; j < X3S_BL; ++j) {
+          const uint32_t t = __builtin_amdgcn_alignbit(w0, w1, s);
+          const uint32_t z = x3_ffbh(t) & zmask;
+          const uint32_t v = (t << (z & 31u)) >> rsh;
+          consume(j < cnt ? z + width : 0u);
+          h[(j >> 1) * 128u + (j & 1u)] = (uint16_t)((z << lsh) + v);
+        }
+      }
+      X3S_BARRIER();
+    }
+  } else {
+    // ================================================================= wave 1: valuer
+    uint32_t* const orow = outs + lane * X3S_OUT_STRIDE;
+    int16_t* __restrict__ const o = wav + wo;
+    s_wo[lane] = wo;
+    s_ns[lane] = samples;
+    bool alive = active;
+    uint32_t prevP = 0;  // the previous pair; its high half is the pending (even-index) sample
+    uint32_t LL = 0;     // (last, last)
+    if (active) {
+      const uint32_t first = ((uint32_t)x3[p0] << 8) | x3[p0 + 1];
+      prevP = first << 16;
+      LL = first * 0x10001u;
+      if (samples == 1u) o[0] = (int16_t)first;
+    }
+    // the usual group: 64 frames of the same size, one behind the other in wav
+    const uint32_t S0 = __builtin_amdgcn_readfirstlane(samples);
+    const uint64_t wo0 = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(wo >> 32)) << 32) |
+                         __builtin_amdgcn_readfirstlane((uint32_t)wo);
+    bool regular = __all(active && samples == S0 && wo == wo0 + (uint64_t)lane * S0) && (S0 & 7u) == 0;
+    uint32_t wbase = 0;  // first sample index of the staging window (a multiple of X3S_WIN)
+    X3_WAVE_LDS_ORDER();
+
+    // window [wbase, wbase + X3S_WIN): 10 pieces of 16 bytes per row, 640 pieces per group
+    auto flush = [&]() {
+      X3_WAVE_LDS_ORDER();
+#pragma unroll 5
+      for (uint32_t it = 0; it < 10u; ++it) {
+        const uint32_t t = it * 64u + lane;
+        const uint32_t r = t / 10u, q = t - r * 10u;
+        const uint2* src = reinterpret_cast<const uint2*>(outs + r * X3S_OUT_STRIDE + 4u * q);
+        if (regular) {
+          if (wbase + 8u * q + 8u <= S0) {
+            const uint2 lo = src[0], hi = src[1];
+            *reinterpret_cast<uint4*>(wav + wo0 + (uint64_t)r * S0 + wbase + 8u * q) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          }
+        } else {
+          const uint32_t ns = s_ns[r];
+          if (wbase + 8u * q + 8u <= ns) {
+            const uint2 lo = src[0], hi = src[1];
+            *reinterpret_cast<uint4*>(wav + s_wo[r] + wbase + 8u * q) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          }
+        }
+      }
+      X3_WAVE_LDS_ORDER();
+    };
+
+    for (uint32_t b = 0; b < nblk_max; ++b) {
+      X3S_BARRIER();
+      const uint32_t cnt = remaining < X3S_BL ? remaining : X3S_BL;
+      remaining -= cnt;
+      const uint32_t* const buf = xfer + (b & 1u) * (X3S_XROWS * 64u) + lane;
+      const uint32_t hdr = buf[X3S_PAIRS * 64u];
+      // block parameters from the header bits
+      const uint32_t ftype = hdr >> 4;
+      const uint32_t E = (hdr & 15u) + 1u;
+      const bool bfp = ftype == 0;
+      uint32_t zmask = 0, litmask = 0, level = 0, bound = 0xFFFFFFFFu, neg_thresh = 0, neg2 = 0;
+      if (bfp) {
+        litmask = E == 16u ? 0xFFFFFFFFu : 0u;
+        neg_thresh = 1u << (E - 1u);
+        neg2 = E == 16u ? 0u : (neg_thresh << 1);
+        if (cnt && alive && E <= 5u) {  // decoder.rs:209-216
+          st = X3D_FRAME_DECODE_INVALID_BPF;
+          alive = false;
+        }
+      } else {
+        zmask = 0xFFFFFFFFu;
+        level = ftype == 1u ? 1u : (1u << (ftype == 2u ? p.k[1] : p.k[2]));
+        bound = ftype == 1u ? p.inv_len[0] : (ftype == 2u ? p.inv_len[1] : p.inv_len[2]);
+      }
+      const uint32_t nlevel2 = ((0u - level) & 0xFFFFu) * 0x10001u;
+      const uint32_t nt2 = neg_thresh * 0x10001u;   // <= 0x8000 in each half
+      const uint32_t neg22 = neg2 * 0x10001u;       // <= 0x8000 in each half
+      uint32_t maxii2 = 0;
+      uint32_t* const dst = orow + X3S_PAIRS * (b & 3u);
+
+      if (__all(cnt == X3S_BL || cnt == 0u)) {
+#pragma unroll 2
+        for (uint32_t j = 0; j < X3S_PAIRS; ++j) {
+          const uint32_t X = buf[j * 64u];
+          // Rice: i = r + level*(n-1) (decoder.rs:186); inverse table = zigzag (x3.rs:200-204)
+          const uint32_t I = x3_pk_add_u16(X, nlevel2);
+          maxii2 = x3_pk_max_u16(maxii2, I);
+          const uint32_t R = x3_pk_lshr_b16_1(I) ^ x3_pk_sub_u16(0u, I & 0x00010001u);
+          // BFP: unsigned_to_i16 (decoder.rs:198-207): v - (v > thresh ? 2*thresh : 0), strict compare
+          const uint32_t M = x3_pk_ashr_i16_15(x3_pk_sub_u16(nt2, X));  // 0xFFFF where v > thresh
+          const uint32_t B = x3_pk_sub_u16(X, M & neg22);
+          const uint32_t D = x3_bfi(zmask, R, B);                        // (d1, d2)
+          const uint32_t Q = x3_pk_add_u16(D, D << 16);                  // (d1, d1 + d2)
+          uint32_t P = x3_pk_add_u16(Q, LL);                             // (last + d1, last + d1 + d2)
+          P = x3_bfi(litmask, X, P);                                     // literal: field = sample
+          LL = __builtin_amdgcn_perm(P, P, 0x07060706u);                 // (lb, lb)
+          dst[j] = __builtin_amdgcn_alignbit(P, prevP, 16);              // (pending sample, la)
+          prevP = P;
+        }
+      } else {
+        // short block somewhere in the group: one sample at a time, staged as halfwords
+        const uint16_t* const h = reinterpret_cast<const uint16_t*>(buf);
+        uint16_t* const oh = reinterpret_cast<uint16_t*>(orow);
+        const uint32_t idx0 = 1u + X3S_BL * b - wbase;  // window-relative index of the block's first sample
+        if (cnt) oh[idx0 - 1u] = (uint16_t)(prevP >> 16);
+        uint32_t last = LL & 0xFFFFu, maxii = 0;
+        for (uint32_t j = 0; j < X3S_BL; ++j) {
+          if (j < cnt) {
+            const uint32_t x = h[(j >> 1) * 128u + (j & 1u)];
+            const uint32_t ii = (x + (0u - level)) & 0xFFFFu;
+            const uint32_t d_rice = (ii >> 1) ^ (0u - (ii & 1u));
+            const uint32_t d_bfp = x - (x > neg_thresh ? neg2 : 0u);
+            const uint32_t d = bfp ? d_bfp : d_rice;
+            last = litmask ? x : ((last + d) & 0xFFFFu);
+            maxii = bfp ? maxii : (ii > maxii ? ii : maxii);
+            oh[idx0 + j] = (uint16_t)last;
+          }
+        }
+        maxii2 = maxii;
+        LL = last * 0x10001u;
+        prevP = last << 16;
+      }
+      // OutOfBoundsInverse (decoder.rs:160,187): the frame stops here
+      if (cnt && alive && max(maxii2 & 0xFFFFu, maxii2 >> 16) >= bound) {
+        st = X3D_OUT_OF_BOUNDS_INVERSE;
+        alive = false;
+      }
+      if (__any(active && !alive)) {  // a frame of the group failed: no more stores for it
+        regular = false;
+        if (!alive) s_ns[lane] = 0;
+      }
+      if (cnt && remaining == 0 && alive) {
+        // this lane's frame is complete: the flush stores only 16-byte pieces that lie inside the frame
+        if (samples & 1u) orow[(samples - 1u - wbase) >> 1] = prevP >> 16;
+        const uint32_t done = samples & ~7u;
+        const uint32_t from = done > wbase ? done : wbase;
+        const uint16_t* h = reinterpret_cast<const uint16_t*>(orow);
+        for (uint32_t sx = from; sx < samples; ++sx) o[sx] = (int16_t)h[sx - wbase];
+      }
+      if ((b & 3u) == 3u) {
+        flush();
+        wbase += X3S_WIN;
+      }
+    }
+    if (nblk_max & 3u) flush();
+    if (f < n_frames) status[f] = st;
+  }
+}
