@@ -45,7 +45,8 @@ struct x3_ctx {
   // persistent small device state
   uint16_t* d_xpow = nullptr;          // X3_XP_SIZE entries
   uint32_t* d_xk16 = nullptr;          // [10][512][16]: x^(32*c*(511-t)) * x^b mod P (x3_encode_stream_kernel.h)
-  uint16_t* d_crctab = nullptr;        // [4][256] slicing-by-4 CRC tables
+  uint16_t* d_crctab = nullptr;        // [6][256]: slicing-by-4 CRC tables + the two x^2048 rows
+  uint32_t* d_kx64 = nullptr;          // [64][16] (x3_frame_check_kernel)
   int* d_status = nullptr;             // [0] size/scan pass, [1] encode pass
   unsigned long long* d_stats = nullptr;    // 6
   unsigned long long* d_end_pos = nullptr;  // 1
@@ -181,10 +182,28 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
     HIPCHK(c, hipMalloc(&c->d_xk16, xk.size() * sizeof(uint32_t)));
     HIPCHK(c, hipMemcpy(c->d_xk16, xk.data(), xk.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     // T[j][v] = crc0 of byte v followed by j zero bytes = v * x^(8j+16) mod P
-    std::vector<uint16_t> tab(4 * 256);
+    // rows 4 and 5 (x3_frame_check_kernel): (v << 8) * x^2048 and v * x^2048
+    std::vector<uint16_t> tab(6 * 256);
     for (int j = 0; j < 4; ++j) {
       const uint32_t sh = gf_xpow_host(8ull * j + 16);
       for (int v = 0; v < 256; ++v) tab[j * 256 + v] = (uint16_t)gf_mul_host((uint32_t)v, sh);
+    }
+    for (int v = 0; v < 256; ++v) {
+      tab[4 * 256 + v] = (uint16_t)gf_mul_host((uint32_t)v, gf_xpow_host(2048 + 8));
+      tab[5 * 256 + v] = (uint16_t)gf_mul_host((uint32_t)v, gf_xpow_host(2048));
+    }
+    {
+      // per-lane constants of x3_frame_check_kernel: x^(32*(63-t)) * x^b, b = 0..15
+      std::vector<uint32_t> kx((size_t)64 * 16);
+      for (int t = 0; t < 64; ++t) {
+        uint32_t k = gf_xpow_host(32ull * (63 - t));
+        for (int b = 0; b < 16; ++b) {
+          kx[(size_t)t * 16 + b] = k;
+          k = ((k << 1) ^ ((k & 0x8000u) ? 0x11021u : 0u)) & 0xFFFFu;
+        }
+      }
+      HIPCHK(c, hipMalloc(&c->d_kx64, kx.size() * sizeof(uint32_t)));
+      HIPCHK(c, hipMemcpy(c->d_kx64, kx.data(), kx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     HIPCHK(c, hipMalloc(&c->d_crctab, tab.size() * sizeof(uint16_t)));
     HIPCHK(c, hipMemcpy(c->d_crctab, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
@@ -234,6 +253,7 @@ extern "C" void x3_ctx_destroy(x3_ctx* c) {
   (void)hipFree(c->d_xpow);
   (void)hipFree(c->d_xk16);
   (void)hipFree(c->d_crctab);
+  (void)hipFree(c->d_kx64);
   (void)hipFree(c->d_status);
   (void)hipFree(c->d_stats);
   (void)hipFree(c->d_summary);
@@ -785,11 +805,16 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
   // the decoder's one-wave-per-SIMD dependency chains leave the CUs mostly idle)
   HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
   HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-  {
+  if (std::getenv("X3HIP_PROFILE_NO_CHECK")) {
+    // profiling aid only: time the decoder without the check pass beside it (payload CRCs are NOT verified)
+    HIPCHK(c, hipMemsetAsync(c->dec_cstatus.p, 0, F * sizeof(int32_t), c->stream2));
+  } else {
     TimerScope ts(c, 4, c->stream2);
-    hipLaunchKernelGGL(x3_frame_check_kernel, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, c->stream2,
+    const uint64_t check_grid = std::min<uint64_t>((F + 3) / 4, (uint64_t)c->n_cus * 8);
+    hipLaunchKernelGGL(x3_frame_check_kernel, dim3((unsigned)check_grid), dim3(256), 0, c->stream2,
                        reinterpret_cast<const uint32_t*>(d_x3), x3_len, d_frame_offsets, F,
-                       (const uint16_t*)c->d_xpow, (int32_t*)c->dec_cstatus.p);
+                       (const uint16_t*)c->d_xpow, (const uint16_t*)c->d_crctab, (const uint32_t*)c->d_kx64,
+                       (int32_t*)c->dec_cstatus.p);
   }
   HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
   {

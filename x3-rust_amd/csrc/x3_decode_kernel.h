@@ -79,58 +79,85 @@ __device__ __forceinline__ int32_t x3_frame_header_check(const uint32_t* __restr
   return X3D_OK;
 }
 
+// Payload-CRC tables in LDS: T[0..3][v] = crc0 of byte v followed by 0..3 zero bytes (slicing by 4),
+// T[4][v] = (v << 8) * x^2048, T[5][v] = v * x^2048 (a 16-bit state times x^(32*64) is T[4][hi] ^ T[5][lo]).
+#define X3_CHECK_TAB_DW 768u  // 6 * 256 uint16
+
+// One WAVE per frame, waves walk the frames grid-stride (the tables are loaded once per workgroup).
+// Lane t takes the payload dwords nd - 64*(c - i) + t, i = 0..c-1 (RIGHT-aligned and interleaved: every
+// load is one contiguous 256-byte run of the wave), folds them Horner-style with x^2048 between
+// consecutive ones, and multiplies its partial by its own FIXED constant x^(32*(63 - t)) (sixteen
+// pre-shifted words per lane, held in registers for the whole kernel); the products are XOR-reduced.
 __global__ void __launch_bounds__(256)
 x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const uint64_t* __restrict__ frame_off,
-                      uint64_t n_frames, const uint16_t* __restrict__ xpow, int32_t* __restrict__ status) {
+                      uint64_t n_frames, const uint16_t* __restrict__ xpow, const uint16_t* __restrict__ tab_g,
+                      const uint32_t* __restrict__ kx64, int32_t* __restrict__ status) {
+  __shared__ __attribute__((aligned(16))) uint16_t tab[6 * 256];
+  for (uint32_t i = threadIdx.x; i < X3_CHECK_TAB_DW; i += blockDim.x)
+    reinterpret_cast<uint32_t*>(tab)[i] = reinterpret_cast<const uint32_t*>(tab_g)[i];
   const uint32_t lane = threadIdx.x & 63u;
-  const uint64_t f = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (f >= n_frames) return;  // whole wave
-  const uint64_t n_dw = (x3_len + 3) >> 2;
-  const uint64_t off = frame_off[f];
-  // ---- header: every lane reads the same 20 bytes (broadcast loads)
-  uint32_t plen = 0, samples = 0, pcrc = 0;
-  int32_t st = x3_frame_header_check(xw, n_dw, x3_len, off, plen, samples, pcrc);
-
-  // ---- payload CRC (decodefile.rs:96-100)
-  if (st == X3D_OK) {
-    const uint64_t p0 = off + 20;
-    uint32_t crc;
-    if (plen < 4) {
-      crc = 0xFFFFu;
-      for (uint32_t i = 0; i < plen; ++i) crc = x3_crc_byte(crc, x3_be32_at(xw, n_dw, p0 + i) >> 24);
-    } else {
-      const uint32_t lead = (uint32_t)(p0 & 3u);                 // header bytes in front, inside dword 0
-      const uint64_t a_dw = p0 >> 2;
-      const uint32_t nd = (lead + plen + 3u) >> 2;               // aligned dwords covering the payload
-      const uint32_t tpad = 4u * nd - lead - plen;               // bytes behind the payload in the last dword
-      const uint32_t c_dw = (nd + 63u) >> 6;
-      const int32_t j0 = (int32_t)(lane * c_dw) - (int32_t)(64u * c_dw - nd);
-      crc = 0;
-      for (uint32_t i = 0; i < c_dw; ++i) {
-        const int32_t j = j0 + (int32_t)i;
-        if (j >= 0) {
-          uint32_t be = x3_bswap32(xw[a_dw + (uint32_t)j]);
-          if (j == 0) {
-            be &= 0xFFFFFFFFu >> (8u * lead);
-            be ^= lead <= 2 ? (0xFFFF0000u >> (8u * lead)) : 0x000000FFu;   // CRC init folded into bytes 0,1
-          }
-          if (j == 1 && lead == 3) be ^= 0xFF000000u;
-          if ((uint32_t)j == nd - 1) be &= 0xFFFFFFFFu << (8u * tpad);
-          crc = x3_crc_be32(crc, be);
-        }
-      }
-#pragma unroll
-      for (int lvl = 0; lvl < 6; ++lvl) {
-        const uint32_t kx = x3_xp(xpow, lvl, c_dw);
-        const uint32_t t = __shfl_up(crc, 1 << lvl, X3_WAVE);
-        if (lane >= (1u << lvl)) crc = x3_gf_mul(t, kx) ^ crc;
-      }
-      crc = __shfl(crc, 63, X3_WAVE);
-      if (tpad) crc = x3_gf_mul(crc, xpow[X3_XINV8_INDEX(tpad)]);  // undo the virtual trailing zero bytes
-    }
-    if (crc != pcrc) st = X3D_FRAME_HEADER_INVALID_PAYLOAD_CRC;
+  uint32_t kk[16];
+  {
+    const uint4* kp = reinterpret_cast<const uint4*>(kx64 + lane * 16u);
+    const uint4 k0 = kp[0], k1 = kp[1], k2 = kp[2], k3 = kp[3];
+    kk[0] = k0.x; kk[1] = k0.y; kk[2] = k0.z; kk[3] = k0.w; kk[4] = k1.x; kk[5] = k1.y; kk[6] = k1.z; kk[7] = k1.w;
+    kk[8] = k2.x; kk[9] = k2.y; kk[10] = k2.z; kk[11] = k2.w; kk[12] = k3.x; kk[13] = k3.y; kk[14] = k3.z; kk[15] = k3.w;
   }
-  if (lane == 0) status[f] = st;
+  __syncthreads();
+  auto crc0_be32 = [&](uint32_t m) -> uint32_t {  // crc0 of four bytes held big-endian
+    return (uint32_t)tab[768u + (m >> 24)] ^ (uint32_t)tab[512u + ((m >> 16) & 0xFFu)] ^
+           (uint32_t)tab[256u + ((m >> 8) & 0xFFu)] ^ (uint32_t)tab[m & 0xFFu];
+  };
+  const uint64_t n_dw = (x3_len + 3) >> 2;
+  const uint64_t waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+  for (uint64_t f = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); f < n_frames; f += waves) {
+    const uint64_t off = frame_off[f];
+    // ---- header: every lane reads the same 20 bytes (broadcast loads)
+    uint32_t plen = 0, samples = 0, pcrc = 0;
+    int32_t st = x3_frame_header_check(xw, n_dw, x3_len, off, plen, samples, pcrc);
+
+    // ---- payload CRC (decodefile.rs:96-100)
+    if (st == X3D_OK) {
+      const uint64_t p0 = off + 20;
+      uint32_t crc;
+      if (plen < 4) {
+        crc = 0xFFFFu;
+        for (uint32_t i = 0; i < plen; ++i) crc = x3_crc_byte(crc, x3_be32_at(xw, n_dw, p0 + i) >> 24);
+      } else {
+        const uint32_t lead = (uint32_t)(p0 & 3u);       // header bytes in front, inside dword 0
+        const uint32_t* __restrict__ const pw = xw + (p0 >> 2);
+        const uint32_t nd = (lead + plen + 3u) >> 2;     // aligned dwords covering the payload
+        const uint32_t tpad = 4u * nd - lead - plen;     // bytes behind the payload in the last dword
+        const uint32_t c = (nd + 63u) >> 6;
+        int32_t j = (int32_t)(nd + lane) - (int32_t)(64u * c);
+        crc = 0;
+        for (uint32_t i = 0; i < c; ++i, j += 64) {
+          uint32_t be = j >= 0 ? x3_bswap32(pw[j]) : 0u;
+          if (i < 2u || i + 1u == c) {  // only the first two dwords and the last one need fixing up
+            if (j == 0) {
+              be &= 0xFFFFFFFFu >> (8u * lead);
+              be ^= lead <= 2 ? (0xFFFF0000u >> (8u * lead)) : 0x000000FFu;  // CRC init folded into bytes 0,1
+            }
+            if (j == 1 && lead == 3) be ^= 0xFF000000u;
+            if ((uint32_t)j == nd - 1) be &= 0xFFFFFFFFu << (8u * tpad);
+          }
+          // partial = partial * x^2048 + crc0(dword)
+          crc = (uint32_t)tab[1024u + (crc >> 8)] ^ (uint32_t)tab[1280u + (crc & 0xFFu)] ^ crc0_be32(be);
+        }
+        {
+          uint32_t r = 0;
+#pragma unroll
+          for (int bit = 0; bit < 16; ++bit) r ^= (0u - ((crc >> bit) & 1u)) & kk[bit];
+          crc = r;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) crc ^= __shfl_xor(crc, o, X3_WAVE);
+        if (tpad) crc = x3_gf_mul(crc, xpow[X3_XINV8_INDEX(tpad)]);  // undo the virtual trailing zero bytes
+      }
+      if (crc != pcrc) st = X3D_FRAME_HEADER_INVALID_PAYLOAD_CRC;
+    }
+    if (lane == 0) status[f] = st;
+  }
 }
 
 // inverse Rice map (x3.rs:200-204): 0,-1,1,-2,2,...
