@@ -30,7 +30,7 @@
 #define X3S_BL 20u             // block length served by this kernel
 #define X3S_PAIRS 10u
 #define X3S_WIN 80u            // samples staged per lane between flushes (4 blocks)
-#define X3S_OUT_STRIDE 42u     // dwords per staging row: 40 + 2 (8-byte aligned rows)
+#define X3S_OUT_STRIDE 44u     // dwords per staging row: 40 + 4 (16-byte aligned rows, spread over the banks)
 #define X3S_XROWS 11u          // transfer rows per block buffer: 10 pair dwords + the header word
 
 // LDS barrier of the two waves: LDS operations retired, nothing else waited for
@@ -49,6 +49,10 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   const uint32_t lane = threadIdx.x & 63u;
   const bool parser = threadIdx.x < 64u;
   const uint64_t f = (uint64_t)blockIdx.x * 64 + lane;
+#ifdef X3_DBG_STAMPS
+  unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long dbg_t = clock64();
+#endif
 
   // ---- per-lane frame setup, done by both waves (same checks as the fast kernel)
   bool active = f < n_frames;
@@ -131,7 +135,12 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     uint32_t s = (32u - 8u * a0) & 31u;
     uint32_t w0 = row[widx & 31u], w1 = row[(widx + 1) & 31u], w2 = row[(widx + 2) & 31u];
     uint32_t w3 = row[(widx + 3) & 31u];                // look-ahead word (re-read at every consume)
-    uint4 ld0 = request(v_next), ld1 = request(v_next + 16), ld2 = request(v_next + 32);
+    // the ring is topped up every SECOND block: up to 6 chunks (96 bytes >= the 80 bytes two blocks can
+    // consume: at most one word per pair), requested one service ahead.  Most lanes need one or two chunks
+    // (0.53 bytes per sample), so the later parks are skipped by the whole wave.
+    uint4 ld[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ld[k] = request(v_next + 16u * k);
     uint32_t v_req = v_next;
     // consume n (<= 32) bits; the word shift is v_bfi with a VGPR mask (see x3_decode_fast_kernel)
     auto consume = [&](uint32_t n) {
@@ -147,20 +156,24 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     auto service = [&]() {
       const uint32_t used = wr_abs - widx;  // dwords from w0 on that the ring still needs
       const uint32_t fit = used >= X3_DEC_RING_DW ? 0u : (X3_DEC_RING_DW - used) >> 2;  // (widx may be -1)
-      if (fit > 0) park(ld0, v_req);
-      if (fit > 1) park(ld1, v_req + 16);
-      if (fit > 2) park(ld2, v_req + 32);
-      v_next += 16u * (fit > 3u ? 3u : fit);
+#pragma unroll
+      for (uint32_t k = 0; k < 6; ++k) {
+        if (__any(fit > k)) {
+          if (fit > k) park(ld[k], v_req + 16u * k);
+        }
+      }
+      v_next += 16u * (fit > 6u ? 6u : fit);
       v_req = v_next;
-      ld0 = request(v_req);
-      ld1 = request(v_req + 16);
-      ld2 = request(v_req + 32);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ld[k] = request(v_req + 16u * k);
     };
 
     for (uint32_t b = 0; b < nblk_max; ++b) {
       const uint32_t cnt = remaining < X3S_BL ? remaining : X3S_BL;
       remaining -= cnt;
-      service();
+      X3_STAMP(0);
+      if ((b & 1u) == 0) service();
+      X3_STAMP(1);
       // block header: 2 bits ftype; ftype 0 -> 4 more bits E-1 (decoder.rs:138-144, 209-216)
       const uint32_t hdr = __builtin_amdgcn_alignbit(w0, w1, s) >> 26;
       const uint32_t ftype = hdr >> 4;
@@ -172,6 +185,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       const uint32_t rsh = 32u - width;
       uint32_t* const buf = xfer + (b & 1u) * (X3S_XROWS * 64u) + lane;
       buf[X3S_PAIRS * 64u] = hdr;
+      X3_STAMP(2);
       if (__all(cnt == X3S_BL || cnt == 0u)) {
         // two samples per 32-bit peek and per window update (two valid codewords are <= 32 bits)
 #pragma unroll 2
@@ -197,7 +211,9 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
           h[(j >> 1) * 128u + (j & 1u)] = (uint16_t)((z << lsh) + v);
         }
       }
+      X3_STAMP(3);
       X3S_BARRIER();
+      X3_STAMP(4);
     }
   } else {
     // ================================================================= wave 1: valuer
@@ -222,32 +238,42 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     uint32_t wbase = 0;  // first sample index of the staging window (a multiple of X3S_WIN)
     X3_WAVE_LDS_ORDER();
 
-    // window [wbase, wbase + X3S_WIN): 10 pieces of 16 bytes per row, 640 pieces per group
+    // window [wbase, wbase + X3S_WIN): 10 pieces of 16 bytes per row, 640 pieces per group, ten per lane.
+    // Which pieces a lane moves never changes: piece t = 64*it + lane of row r = t / 10.  For the regular
+    // group the LDS offset and the offset in wav (relative to the window) are computed once.
+    uint32_t f_src[10], f_dst[10];
+#pragma unroll
+    for (uint32_t it = 0; it < 10u; ++it) {
+      const uint32_t t = it * 64u + lane;
+      const uint32_t r = t / 10u, q = t - r * 10u;
+      f_src[it] = r * X3S_OUT_STRIDE + 4u * q;   // dwords into outs
+      f_dst[it] = r * S0 + 8u * q;               // samples behind wav + wo0 + wbase (< 2^32: 64 frames)
+    }
     auto flush = [&]() {
       X3_WAVE_LDS_ORDER();
-#pragma unroll 5
-      for (uint32_t it = 0; it < 10u; ++it) {
-        const uint32_t t = it * 64u + lane;
-        const uint32_t r = t / 10u, q = t - r * 10u;
-        const uint2* src = reinterpret_cast<const uint2*>(outs + r * X3S_OUT_STRIDE + 4u * q);
-        if (regular) {
-          if (wbase + 8u * q + 8u <= S0) {
-            const uint2 lo = src[0], hi = src[1];
-            *reinterpret_cast<uint4*>(wav + wo0 + (uint64_t)r * S0 + wbase + 8u * q) = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          }
-        } else {
+      if (regular && wbase + X3S_WIN <= S0) {
+        int16_t* const base = wav + wo0 + wbase;
+#pragma unroll
+        for (uint32_t it = 0; it < 10u; ++it)
+          *reinterpret_cast<uint4*>(base + f_dst[it]) = *reinterpret_cast<const uint4*>(outs + f_src[it]);
+      } else {
+#pragma unroll 2
+        for (uint32_t it = 0; it < 10u; ++it) {
+          const uint32_t t = it * 64u + lane;
+          const uint32_t r = t / 10u, q = t - r * 10u;
           const uint32_t ns = s_ns[r];
-          if (wbase + 8u * q + 8u <= ns) {
-            const uint2 lo = src[0], hi = src[1];
-            *reinterpret_cast<uint4*>(wav + s_wo[r] + wbase + 8u * q) = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          }
+          if (wbase + 8u * q + 8u <= ns)
+            *reinterpret_cast<uint4*>(wav + s_wo[r] + wbase + 8u * q) =
+                *reinterpret_cast<const uint4*>(outs + r * X3S_OUT_STRIDE + 4u * q);
         }
       }
       X3_WAVE_LDS_ORDER();
     };
 
     for (uint32_t b = 0; b < nblk_max; ++b) {
+      X3_STAMP(0);
       X3S_BARRIER();
+      X3_STAMP(4);
       const uint32_t cnt = remaining < X3S_BL ? remaining : X3S_BL;
       remaining -= cnt;
       const uint32_t* const buf = xfer + (b & 1u) * (X3S_XROWS * 64u) + lane;
@@ -275,6 +301,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       const uint32_t neg22 = neg2 * 0x10001u;       // <= 0x8000 in each half
       uint32_t maxii2 = 0;
       uint32_t* const dst = orow + X3S_PAIRS * (b & 3u);
+      X3_STAMP(2);
 
       if (__all(cnt == X3S_BL || cnt == 0u)) {
 #pragma unroll 2
@@ -318,6 +345,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
         LL = last * 0x10001u;
         prevP = last << 16;
       }
+      X3_STAMP(3);
       // OutOfBoundsInverse (decoder.rs:160,187): the frame stops here
       if (cnt && alive && max(maxii2 & 0xFFFFu, maxii2 >> 16) >= bound) {
         st = X3D_OUT_OF_BOUNDS_INVERSE;
@@ -335,12 +363,18 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
         const uint16_t* h = reinterpret_cast<const uint16_t*>(orow);
         for (uint32_t sx = from; sx < samples; ++sx) o[sx] = (int16_t)h[sx - wbase];
       }
+      X3_STAMP(1);
       if ((b & 3u) == 3u) {
         flush();
         wbase += X3S_WIN;
+        X3_STAMP(5);
       }
     }
     if (nblk_max & 3u) flush();
     if (f < n_frames) status[f] = st;
   }
+#ifdef X3_DBG_STAMPS
+  if (lane == 0 && blockIdx.x < 2048)
+    for (int k = 0; k < 8; ++k) x3_dbg[(blockIdx.x * 2 + (parser ? 0 : 1)) * 8 + k] = dbg_acc[k];
+#endif
 }
