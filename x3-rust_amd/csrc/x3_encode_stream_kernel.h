@@ -2,14 +2,15 @@
 //
 // Same steps A-F as x3_encode_kernel.h, with three changes that matter on MI355X:
 //
-//  1. ONE pass over the samples.  Frame offsets in the stream come from a decoupled look-back over
-//     per-frame descriptors instead of a size pass + scan: the grid is persistent (<= 3 workgroups
-//     per CU, all co-resident, each looping over frames f = blockIdx.x + k*gridDim.x), a frame's
-//     byte size is published as soon as its bit lengths are scanned, and after emission + CRC one
-//     wave sums the predecessors' descriptors back to the nearest inclusive prefix.  A descriptor
-//     is ONE 8-byte word {state:2 | value:62} written with an agent-scope relaxed atomic store and
-//     polled with agent-scope relaxed atomic loads (write-through / L1-bypassing on gfx950; the
-//     granule is its own flag, so no fence is needed -- cdna_hip_programming.md G16, form R2).
+//  1. ONE pass over the samples.  The grid is persistent (2 workgroups per CU, all co-resident, each looping
+//     over frames f = blockIdx.x + k*G) and frame offsets in the stream come from the frames' sizes, which
+//     every workgroup publishes as soon as the bit lengths are scanned -- one 4-byte word
+//     {epoch:12 | bytes:20}, agent-scope relaxed atomic store, polled with agent-scope relaxed atomic loads
+//     (write-through / L1-bypassing on gfx950; the word is its own flag, so no fence is needed --
+//     cdna_hip_programming.md G16, form R2).  A workgroup's consecutive frames are f-G and f, hence
+//         off(f) = off(f-G) + bytes(f-G) + SUM bytes(j), j in (f-G, f):
+//     G-1 words of the OTHER workgroups, no prefix chain.  The words are requested while frame f+G is
+//     analysed and emitted, and frame f is copied out one frame late from the second of two frame images.
 //     HBM traffic = 2 B/sample in + stream bytes out, nothing else.
 //  2. The block lives in REGISTERS: 11 dwords (22 samples) per lane from LDS by ds_read_b64, the
 //     20 first differences as ten v_pk_sub_i16 (saturating: |d| >= 16384 means a literal block
