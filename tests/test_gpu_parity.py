@@ -462,3 +462,62 @@ def test_full_size_config3_roundtrip(ctx, x3):
         s = wav[f * 10000:(f + 1) * 10000].cpu().numpy()
         enc = out[int(offs[f]):int(offs[f + 1])].cpu().numpy()
         assert np.array_equal(enc, O.encode(s)[1]), f
+
+
+class _env:
+    """set an environment switch of libx3hip.so (read by the library at every call) for a with-block"""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_decoder_kernels_agree(ctx, x3):
+    """the two-wave decoder (default for the plain geometry) and the single-wave kernel it falls back to
+    must make the same of good and of tampered streams: status, frame counts, samples"""
+    rng = np.random.default_rng(11)
+    wav = np.concatenate([x3.synth(k, 90 + k, 0, 30011 + 977 * k) for k in range(5)])
+    stream = O.encode(wav)[1]
+    offs = frame_offsets(stream)
+    cases = [stream]
+    for trial in range(24):
+        s = stream.copy()
+        fi = int(rng.integers(0, len(offs)))
+        plen = int(s[offs[fi] + 6]) << 8 | int(s[offs[fi] + 7])
+        pos = offs[fi] + 22 + int(rng.integers(0, plen - 12))
+        if trial % 3 == 0:
+            s[pos] ^= 1 << int(rng.integers(0, 8))
+        elif trial % 3 == 1:
+            s[pos:pos + 8] = 0
+        else:
+            s[pos:pos + 6] = rng.integers(0, 256, size=6, dtype=np.uint8)
+        refresh_crcs(x3, s, offs[fi])
+        cases.append(s)
+    for s in cases:
+        a = ctx.decode_stream(s, x3.Params.default(), wav_cap=wav.size + 70000)
+        with _env(X3HIP_DECODE_SINGLE="1"):
+            b = ctx.decode_stream(s, x3.Params.default(), wav_cap=wav.size + 70000)
+        assert a[0] == b[0] and a[2:] == b[2:] and np.array_equal(a[1], b[1])
+        o = O.decode_stream(s, O.Params.default(), wav_cap=wav.size + 70000)
+        assert a[0] == o[0] and a[2:] == o[2:] and np.array_equal(a[1], o[1])
+
+
+def test_encoder_kernels_agree(ctx, x3):
+    """single-pass persistent encoder (default) vs the two-pass kernels it falls back to"""
+    p = x3.Params.default()
+    for kind, n in ((2, 1_234_567), (4, 10_000 * 700 + 1), (0, 20_001)):
+        wav = x3.synth(kind, 120 + kind, 0, n)
+        a = ctx.encode(wav, p)
+        with _env(X3HIP_TWO_PASS="1"):
+            b = ctx.encode(wav, p)
+        assert a[0] == b[0] == 0 and np.array_equal(a[1], b[1]) and a[2].tolist() == b[2].tolist()
