@@ -177,6 +177,32 @@ def main():
                          "oracle/x3_oracle.c -O3 -march=native -flto" % (m, args.cpu_reps, es.value, ds.value),
                "encode_msamples_s": round(m * args.cpu_reps / es.value / 1e6, 2),
                "decode_msamples_s": round(m * args.cpu_reps / ds.value / 1e6, 2)}
+        # the generous baseline: the same port, frame-parallel over all host cores -- every
+        # thread round-trips its own slice of whole frames (ctypes releases the GIL)
+        import threading
+        ncores = os.cpu_count() or 1
+        if ncores > 1 and args.cpu_reps > 0:
+            spf = 10000
+            per = max(spf, (m // ncores) // spf * spf)
+            parts = [sample[i * per:(i + 1) * per] for i in range(ncores) if (i + 1) * per <= m]
+            rcs = [0] * len(parts)
+            reps_mt = max(1, args.cpu_reps // 2)
+
+            def work(i):
+                e, d, l = C.c_double(0), C.c_double(0), C.c_uint64(0)
+                rcs[i] = OL.x3o_time_roundtrip(parts[i].ctypes.data, parts[i].size, C.byref(po), reps_mt,
+                                               C.byref(e), C.byref(d), C.byref(l))
+            th = [threading.Thread(target=work, args=(i,)) for i in range(len(parts))]
+            t0 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            wall = time.perf_counter() - t0
+            assert not any(rcs), rcs
+            cpu["all_cores"] = {"value": round(sum(q.size for q in parts) * reps_mt / wall / 1e6, 2),
+                                "unit": "Msamples/s", "cores": len(parts),
+                                "sample": "%d slices of %d samples, %d reps, %.2f s wall" % (len(parts), per, reps_mt, wall)}
 
     if rank == 0:
         total_samples = n * world

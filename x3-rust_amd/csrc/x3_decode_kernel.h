@@ -150,8 +150,7 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
           for (int bit = 0; bit < 16; ++bit) r ^= (0u - ((crc >> bit) & 1u)) & kk[bit];
           crc = r;
         }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) crc ^= __shfl_xor(crc, o, X3_WAVE);
+        crc = (uint32_t)__builtin_amdgcn_readlane((int)x3_wave_xor_to_lane63_dpp(crc), 63);
         if (tpad) crc = x3_gf_mul(crc, xpow[X3_XINV8_INDEX(tpad)]);  // undo the virtual trailing zero bytes
       }
       if (crc != pcrc) st = X3D_FRAME_HEADER_INVALID_PAYLOAD_CRC;

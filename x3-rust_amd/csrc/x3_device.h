@@ -98,6 +98,18 @@ __device__ __forceinline__ uint32_t x3_wave_incl_scan_dpp(uint32_t v) {
   return v;
 }
 
+// XOR of all 64 lanes, valid in lane 63 (same DPP ladder; a __shfl_xor butterfly costs six ds_bpermute
+// round trips and ~36 VALU)
+__device__ __forceinline__ uint32_t x3_wave_xor_to_lane63_dpp(uint32_t v) {
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);  // row_shr:1
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);  // row_shr:2
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);  // row_shr:4
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);  // row_shr:8
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1,3
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2,3
+  return v;
+}
+
 __device__ __forceinline__ uint32_t x3_wave_incl_scan(uint32_t v, int lane) {
 #pragma unroll
   for (int d = 1; d < X3_WAVE; d <<= 1) {

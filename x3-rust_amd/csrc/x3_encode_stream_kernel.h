@@ -661,9 +661,8 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
         for (int bit = 0; bit < 16; ++bit) r ^= (0u - ((crc >> bit) & 1u)) & kk[bit];
         crc = r;
       }
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) crc ^= __shfl_xor(crc, o, X3_WAVE);
-      if (lane == 0) part[16 + wid] = crc;
+      crc = x3_wave_xor_to_lane63_dpp(crc);
+      if (lane == 63) part[16 + wid] = crc;
 
       X3_STAMP(5);
       __syncthreads();  // B4: CRC partials are in LDS
