@@ -161,3 +161,9 @@ __device__ __forceinline__ uint32_t x3_ffbh(uint32_t a) {
   asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(a));
   return r;
 }
+// all ones when j == 0 (j >= 0), else 0 -- two VALU, no compare
+__device__ __forceinline__ uint32_t x3_mask_if_zero(int32_t j) {
+  uint32_t r;
+  asm("v_add_u32 %0, -1, %1\n\tv_ashrrev_i32 %0, 31, %0" : "=&v"(r) : "v"(j));
+  return r;
+}

@@ -61,6 +61,36 @@ __device__ __forceinline__ uint32_t x3_pk_sar_i16(uint32_t a, uint32_t sh) {  //
   return r;
 }
 
+// packed 16-bit logical shift right, per-half amounts in sh2
+__device__ __forceinline__ uint32_t x3_pk_lshr_b16(uint32_t a, uint32_t sh2) {
+  uint32_t r;
+  asm("v_pk_lshrrev_b16 %0, %1, %2" : "=v"(r) : "v"(sh2), "v"(a));
+  return r;
+}
+// SDWA operand selects (gfx9 encoding, available on gfx950): halves of a dword as operands of a 32-bit op
+__device__ __forceinline__ uint32_t x3_sdwa_add_w0_w1(uint32_t a) {  // a.lo16 + a.hi16
+  uint32_t r;
+  asm("v_add_u32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(r) : "v"(a));
+  return r;
+}
+__device__ __forceinline__ uint32_t x3_sdwa_shl_w0_by_w1(uint32_t v, uint32_t sh) {  // v.lo16 << sh.hi16
+  uint32_t r;
+  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0"
+      : "=v"(r) : "v"(sh), "v"(v));
+  return r;
+}
+__device__ __forceinline__ uint32_t x3_sdwa_or_w1(uint32_t a, uint32_t b) {  // a | b.hi16
+  uint32_t r;
+  asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+      : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// ds_or_b32 on an LDS byte address (no return value)
+__device__ __forceinline__ void x3_lds_or_b32(uint32_t addr, uint32_t v) {
+  __hip_atomic_fetch_or(reinterpret_cast<__attribute__((address_space(3))) uint32_t*>((uintptr_t)addr), v,
+                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 #define X3_STREAM_THREADS 576u  // 8 compute waves (one block per lane) + 1 helper wave
 
 // One 16-byte-per-lane direct-to-LDS load, hidden from hipcc (cdna_hip_programming.md section 5.7): the
@@ -574,23 +604,30 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
         e.init(img + 5, pos);
         if (regs) {
           e.put(type <= 3 ? ft + 1u : (type == 4 ? nb : 15u), type <= 3 ? 2u : 6u);
-          const uint32_t last_on = cnt == 20 ? 0xFFFFFFFFu : 0u;
+          // (code, len) for BOTH samples of a pair in packed 16-bit arithmetic, the halves combined with
+          // SDWA operand selects: 11 VALU per pair in front of the flush test
+          const uint32_t qsh2 = qsh * 0x10001u, lbase2 = lbase * 0x10001u;
+          const uint32_t amask2 = amask * 0x10001u, orc2 = orc * 0x10001u;
+          const uint32_t last_on = cnt == 20 ? 0xFFFFFFFFu : 0x0000FFFFu;  // a 19-sample block has no sample 20
+          uint32_t waddr = x3_lds_addr(e.words + e.w);  // byte address of the word the accumulator flushes to
+          uint64_t acc = e.acc;
+          uint32_t pend = e.cnt;
 #pragma unroll
           for (int j = 0; j < 10; ++j) {
-            const uint32_t a = S[j] & 0xFFFFu, c = S[j] >> 16;
-            uint32_t la = ((a >> qsh) & qmask) + lbase, lc = ((c >> qsh) & qmask) + lbase;
-            uint32_t ca = (a & amask) | orc, cc = (c & amask) | orc;
-            if (j == 9) { lc &= last_on; cc &= last_on; }  // a 19-sample block has no sample 20
-            e.acc = (e.acc << (la + lc)) | (unsigned long long)((ca << lc) | cc);  // la + lc <= 32
-            e.cnt += la + lc;
-            if (e.cnt >= 32u) {
-              const uint32_t word = (uint32_t)(e.acc >> (e.cnt - 32u));
-              atomicOr(&e.words[e.w], x3_bswap32(word));
-              ++e.w;
-              e.cnt -= 32u;
+            uint32_t Lp = x3_pk_add_u16(x3_pk_lshr_b16(S[j], qsh2) & qmask, lbase2);  // (la, lc)
+            uint32_t Cp = (S[j] & amask2) | orc2;                                        // (ca, cc)
+            if (j == 9) { Lp &= last_on; Cp &= last_on; }
+            const uint32_t tot = x3_sdwa_add_w0_w1(Lp);                                  // la + lc <= 32
+            const uint32_t pair = x3_sdwa_or_w1(x3_sdwa_shl_w0_by_w1(Cp, Lp), Cp);       // (ca << lc) | cc
+            acc = (acc << tot) | (unsigned long long)pair;
+            pend += tot;
+            if (pend >= 32u) {
+              pend -= 32u;
+              x3_lds_or_b32(waddr, x3_bswap32((uint32_t)(acc >> pend)));
+              waddr += 4u;
             }
           }
-          e.finish();
+          if (pend) x3_lds_or_b32(waddr, x3_bswap32((uint32_t)(acc << (32u - pend))));
         } else {
           // short block: samples r = 0..cnt are in S as raw 16-bit values (r = 0 is the predecessor)
           auto smp = [&](uint32_t r) -> int32_t {
@@ -646,7 +683,9 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
         const int32_t j = j0 + (int32_t)i;
         if (j >= 0) {
           uint32_t be = x3_bswap32(img[5 + j]);
-          if (j == 0) be ^= 0xFFFF0000u;  // CRC init 0xFFFF folded into the first 16 message bits
+          // CRC init 0xFFFF folded into the first 16 message bits (dword 0 only); as arithmetic, not a select:
+          // a v_cndmask on a stale VCC is a SIMD-wide bottleneck on gfx950 (tools/ubench/issue_cost.hip)
+          be ^= x3_mask_if_zero(j) & 0xFFFF0000u;
           // slicing-by-4: fold the running CRC into the top 16 message bits, one table per byte
           const uint32_t m = be ^ (crc << 16);
           crc = (uint32_t)crc_tab[768u + (m >> 24)] ^ (uint32_t)crc_tab[512u + ((m >> 16) & 0xFFu)] ^
