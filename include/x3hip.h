@@ -228,6 +228,20 @@ int x3_decode_dev(x3_ctx* ctx, const uint8_t* d_x3, uint64_t x3_len, const uint6
  * before it. */
 int x3_decode_result(x3_ctx* ctx, uint64_t* first_bad, int* first_bad_status, uint64_t* samples_before);
 
+/* GPU-side frame walk of a device-resident stream whose frame offsets are not known (SURVEY 8f.2;
+ * X3aReader::decode_next_frame, src/decodefile.rs:105-121 + decoder::read_frame_header, src/decoder.rs:69-118):
+ * every even offset is tested for a valid frame header in parallel, the chain off -> off + 20 + payload_len is
+ * resolved by pointer doubling.  d_frame_offsets[0..*n_frames) receives the byte offsets of the frames the walk
+ * pushes, d_wav_offsets their exclusive sample offsets (both need room for max_frames entries); *terminal is
+ * how the walk ends behind them: X3_OK (data exhausted / payload runs past the end), a header error, or
+ * X3_ERR_FRAME_HEADER_INVALID_PAYLOAD_LEN.  Synchronous. */
+int x3_index_dev(x3_ctx* ctx, const uint8_t* d_x3, uint64_t len, uint64_t max_frames, uint64_t* d_frame_offsets,
+                 uint64_t* d_wav_offsets, uint64_t* n_frames, uint64_t* n_samples, int* terminal);
+/* x3_decode_stream for device buffers: index (above) + decode, nothing crosses PCIe but the summary.  Same
+ * results and status as x3_decode_stream on the same bytes; samples go to d_wav[0..*n_out). */
+int x3_decode_stream_dev(x3_ctx* ctx, const uint8_t* d_x3, uint64_t len, const x3_params* p, int16_t* d_wav,
+                         uint64_t wav_cap, uint64_t* n_out, uint64_t* frames_ok, uint64_t* frame_errors);
+
 /* ------------------------------------------------------------------ synthetic inputs (bench/tests) */
 
 /* Seeded, integer-only signal generators.  kind: 0 zeros, 1 white i16 noise,

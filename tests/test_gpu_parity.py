@@ -462,6 +462,21 @@ def test_full_size_config3_roundtrip(ctx, x3):
         s = wav[f * 10000:(f + 1) * 10000].cpu().numpy()
         enc = out[int(offs[f]):int(offs[f + 1])].cpu().numpy()
         assert np.array_equal(enc, O.encode(s)[1]), f
+    # the GPU-side frame walk finds the same 69 120 frames in the bare byte stream
+    import time
+    fo = torch.empty(F + 8, dtype=torch.int64, device=dev)
+    wo = torch.empty(F + 8, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    rc, nf, ns, term = ctx.index_dev(out.data_ptr(), pos, F + 8, fo.data_ptr(), wo.data_ptr())
+    dt = time.perf_counter() - t0
+    assert (rc, nf, ns, term) == (0, F, n, 0)
+    assert torch.equal(fo[:F], off[:F]) and torch.equal(wo[:F], torch.arange(F, device=dev, dtype=torch.int64) * 10000)
+    print("x3_index_dev: %d frames in %.0f MB indexed in %.2f ms" % (F, pos / 1e6, dt * 1e3))
+    back.zero_()
+    torch.cuda.synchronize(dev)
+    assert ctx.decode_stream_dev(out.data_ptr(), pos, p, back.data_ptr(), n) == (0, n, F, 0)
+    assert torch.equal(back, wav)
 
 
 class _env:
@@ -521,3 +536,77 @@ def test_encoder_kernels_agree(ctx, x3):
         with _env(X3HIP_TWO_PASS="1"):
             b = ctx.encode(wav, p)
         assert a[0] == b[0] == 0 and np.array_equal(a[1], b[1]) and a[2].tolist() == b[2].tolist()
+
+
+# ------------------------------------------------------------------ GPU-side frame index
+
+def _dev_stream(ctx, stream):
+    d = ctx.alloc(stream.size + 64)
+    ctx.upload(d, np.concatenate([stream, np.zeros(64, dtype=np.uint8)]))
+    return d
+
+
+def test_index_dev_matches_host_walk(ctx, x3):
+    wav = np.concatenate([x3.synth(k, 300 + k, 0, 20000 + 1111 * k) for k in range(5)])
+    stream = O.encode(wav)[1]
+    offs = frame_offsets(stream)
+    # a few short frames in front: many frames per kilobyte, sample offsets that are not multiples of anything
+    small = np.concatenate([O.encode(x3.synth(4, 400 + i, 0, 1 + 7 * i))[1] for i in range(40)])
+    for s in (stream, np.concatenate([small, stream]), small[:-1], stream[:offs[3] + 7], stream[:offs[3] + 21]):
+        d = _dev_stream(ctx, s)
+        d_fo = ctx.alloc(8 * 4096)
+        d_wo = ctx.alloc(8 * 4096)
+        rc, nf, ns, term = ctx.index_dev(d, s.size, 4000, d_fo, d_wo)
+        assert rc == 0
+        # the host walk on the same bytes
+        exp_off, exp_wo, pos, nsamp = [], [], 0, 0
+        while s.size - pos > 20:
+            rch, h = x3.read_frame_header(s[pos:pos + 20])
+            if rch or s.size - pos - 20 < h.payload_len:
+                break
+            exp_off.append(pos); exp_wo.append(nsamp)
+            nsamp += h.samples
+            pos += 20 + h.payload_len
+        assert nf == len(exp_off) and ns == nsamp
+        assert ctx.download(d_fo, 8 * nf, np.uint64).tolist() == exp_off
+        assert ctx.download(d_wo, 8 * nf, np.uint64).tolist() == exp_wo
+        for x in (d, d_fo, d_wo):
+            ctx.free(x)
+
+
+def test_decode_stream_dev_matches_host_api(ctx, x3):
+    """x3_decode_stream_dev (GPU index + decode, device buffers) == x3_decode_stream == oracle on good streams,
+    truncations, trailing bytes, broken headers and tampered payloads"""
+    rng = np.random.default_rng(21)
+    wav = np.concatenate([x3.synth(k, 500 + k, 0, 30011 + 977 * k) for k in range(5)])
+    stream = O.encode(wav)[1]
+    offs = frame_offsets(stream)
+    cases = [stream, stream[:-1], stream[:-13], stream[:offs[5] + 20], stream[:offs[5] + 19], stream[:19],
+             np.concatenate([stream, np.zeros(12, dtype=np.uint8)]), np.concatenate([stream, np.zeros(40, dtype=np.uint8)]),
+             np.concatenate([stream, stream[:offs[2]]])]
+    for fi, byte in ((0, 0), (3, 1), (7, 2), (9, 5), (11, 16), (len(offs) - 1, 18)):
+        s = stream.copy(); s[offs[fi] + byte] ^= 0x41; cases.append(s)
+    for trial in range(9):
+        s = stream.copy()
+        fi = int(rng.integers(0, len(offs)))
+        plen = int(s[offs[fi] + 6]) << 8 | int(s[offs[fi] + 7])
+        pos = offs[fi] + 22 + int(rng.integers(0, plen - 12))
+        if trial % 3 == 0:
+            s[pos] ^= 1 << int(rng.integers(0, 8))
+        elif trial % 3 == 1:
+            s[pos:pos + 8] = 0
+        else:
+            s[pos:pos + 6] = rng.integers(0, 256, size=6, dtype=np.uint8)
+        refresh_crcs(x3, s, offs[fi])
+        cases.append(s)
+    p = x3.Params.default()
+    for cap in (wav.size + 70000, 55555):
+        d_wav = ctx.alloc(2 * (wav.size + 70000))
+        for s in cases:
+            d = _dev_stream(ctx, s)
+            a = ctx.decode_stream(s, p, wav_cap=cap)
+            b = ctx.decode_stream_dev(d, s.size, p, d_wav, cap)
+            assert (a[0], a[1].size, a[2], a[3]) == b, (a[0], a[1].size, a[2:], b, s.size)
+            assert np.array_equal(ctx.download(d_wav, 2 * b[1], np.int16), a[1])
+            ctx.free(d)
+        ctx.free(d_wav)

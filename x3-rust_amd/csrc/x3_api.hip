@@ -17,6 +17,7 @@
 #include "../../include/x3hip.h"
 #include "x3_decode_kernel.h"
 #include "x3_decode_split_kernel.h"
+#include "x3_index_kernels.h"
 #include "x3_device.h"
 #include "x3_encode_kernel.h"
 #include "x3_encode_stream_kernel.h"
@@ -61,6 +62,7 @@ struct x3_ctx {
   uint16_t* h_crc = nullptr;
   // growable scratch
   DevBuf in, out, frame_bytes, frame_off, dec_status, dec_cstatus, dec_meta, wav_off, seg_crc, desc;
+  DevBuf idx_cand, idx_keys, idx_vals, idx_J, idx_S, idx_L, idx_sum;  // x3_index_dev scratch
   int n_cus = 0;
   bool force_single_wave_decode = false;
   uint32_t desc_epoch = 0;    // tag of the current launch's frame-size descriptors (x3_encode_stream_kernel)
@@ -244,7 +246,8 @@ extern "C" void x3_ctx_destroy(x3_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf* b : {&c->in, &c->out, &c->frame_bytes, &c->frame_off, &c->dec_status, &c->dec_cstatus, &c->dec_meta, &c->wav_off,
-                    &c->seg_crc, &c->desc})
+                    &c->seg_crc, &c->desc, &c->idx_cand, &c->idx_keys, &c->idx_vals, &c->idx_J, &c->idx_S,
+                    &c->idx_L, &c->idx_sum})
     if (b->p) (void)hipFree(b->p);
   for (auto& t : c->timers) {
     for (auto& e : t.used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -890,6 +893,158 @@ extern "C" int x3_decode_result(x3_ctx* c, uint64_t* first_bad, int* first_bad_s
   if (first_bad_status) *first_bad_status = c->h_summary->first_bad_status;
   if (samples_before) *samples_before = c->h_summary->samples_before;
   return X3_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GPU-side frame index of a device-resident stream (x3_index_kernels.h)
+// ------------------------------------------------------------------------------------------------
+static int index_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t len, uint32_t bl0, uint64_t wav_cap,
+                          uint64_t max_frames, uint64_t* d_frame_offsets, uint64_t* d_wav_offsets,
+                          X3IndexSummary* result) {
+  if (reinterpret_cast<uintptr_t>(d_x3) & 3u) return X3_ERR_BAD_ARG;
+  const uint32_t* xw = reinterpret_cast<const uint32_t*>(d_x3);
+  int rc;
+  if ((rc = ensure(c, c->idx_sum, 256))) return rc;
+  unsigned int* d_count = reinterpret_cast<unsigned int*>((char*)c->idx_sum.p + 128);
+  X3IndexSummary* d_sum = reinterpret_cast<X3IndexSummary*>(c->idx_sum.p);
+  X3IndexSummary init{0, 0, 0, X3I_NONE, ~0ull, 0, X3I_NONE, 0};
+  HIPCHK(c, hipMemcpyAsync(d_sum, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(d_count, 0, sizeof(unsigned int), c->stream));
+  const uint64_t chunks = (len + 15) >> 4;
+  const unsigned grid = (unsigned)std::min<uint64_t>((chunks + 255) / 256, (uint64_t)c->n_cus * 16);
+  // pass 1: how many candidates (the buffers are sized from the answer)
+  unsigned int n_cand = 0;
+  if (grid) {
+    hipLaunchKernelGGL(x3_index_candidates_kernel, dim3(grid), dim3(256), 0, c->stream, xw, len, bl0,
+                       (X3Cand*)nullptr, 0u, d_count);
+    HIPCHK(c, hipMemcpyAsync(&n_cand, d_count, sizeof n_cand, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  uint32_t start = X3I_NONE;
+  unsigned long long n_chain = 0;
+  if (n_cand) {
+    uint32_t tsize = 1024;
+    while (tsize < 2u * n_cand && tsize < 0x80000000u) tsize <<= 1;
+    uint32_t levels = 1;
+    while ((1ull << (levels - 1)) < n_cand) ++levels;  // the top level spans 2^(levels-1) >= n_cand >= any chain
+    if ((rc = ensure(c, c->idx_cand, (size_t)n_cand * sizeof(X3Cand)))) return rc;
+    if ((rc = ensure(c, c->idx_keys, (size_t)tsize * sizeof(unsigned long long)))) return rc;
+    if ((rc = ensure(c, c->idx_vals, (size_t)tsize * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(c, c->idx_J, (size_t)levels * n_cand * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(c, c->idx_S, (size_t)levels * n_cand * sizeof(unsigned long long)))) return rc;
+    if ((rc = ensure(c, c->idx_L, (size_t)levels * n_cand * sizeof(uint32_t)))) return rc;
+    X3Cand* cand = (X3Cand*)c->idx_cand.p;
+    unsigned long long* keys = (unsigned long long*)c->idx_keys.p;
+    uint32_t* vals = (uint32_t*)c->idx_vals.p;
+    uint32_t* J = (uint32_t*)c->idx_J.p;
+    unsigned long long* S = (unsigned long long*)c->idx_S.p;
+    uint32_t* L = (uint32_t*)c->idx_L.p;
+    HIPCHK(c, hipMemsetAsync(d_count, 0, sizeof(unsigned int), c->stream));
+    HIPCHK(c, hipMemsetAsync(keys, 0, (size_t)tsize * sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(x3_index_candidates_kernel, dim3(grid), dim3(256), 0, c->stream, xw, len, bl0, cand, n_cand,
+                       d_count);
+    const unsigned cg = (n_cand + 255) / 256;
+    hipLaunchKernelGGL(x3_index_hash_insert_kernel, dim3(cg), dim3(256), 0, c->stream, (const X3Cand*)cand, n_cand,
+                       keys, vals, tsize - 1);
+    hipLaunchKernelGGL(x3_index_succ_kernel, dim3(cg), dim3(256), 0, c->stream, (const X3Cand*)cand, n_cand,
+                       (const unsigned long long*)keys, (const uint32_t*)vals, tsize - 1, J, S, L);
+    for (uint32_t r = 1; r < levels; ++r)
+      hipLaunchKernelGGL(x3_index_double_kernel, dim3(cg), dim3(256), 0, c->stream, n_cand,
+                         (const uint32_t*)(J + (size_t)(r - 1) * n_cand),
+                         (const unsigned long long*)(S + (size_t)(r - 1) * n_cand),
+                         (const uint32_t*)(L + (size_t)(r - 1) * n_cand), J + (size_t)r * n_cand,
+                         S + (size_t)r * n_cand, L + (size_t)r * n_cand);
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(x3_index_start_kernel, dim3(1), dim3(64), 0, c->stream, (const X3Cand*)cand,
+                       (const unsigned long long*)keys, (const uint32_t*)vals, tsize - 1,
+                       (const uint32_t*)(L + (size_t)(levels - 1) * n_cand), d_sum);
+    {
+      X3IndexSummary mid;
+      HIPCHK(c, hipMemcpyAsync(&mid, d_sum, sizeof mid, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      start = mid.start;
+      n_chain = mid.n_chain;
+    }
+    if (start != X3I_NONE) {
+      if (n_chain > max_frames) {
+        c->last_error = "x3_index_dev: more frames in the stream than max_frames";
+        return X3_ERR_BAD_ARG;
+      }
+      hipLaunchKernelGGL(x3_index_emit_kernel, dim3((unsigned)((n_chain + 255) / 256)), dim3(256), 0, c->stream,
+                         (const X3Cand*)cand, n_cand, levels, (const uint32_t*)J, (const unsigned long long*)S, start,
+                         n_chain, (unsigned long long)wav_cap, (unsigned long long*)d_frame_offsets,
+                         (unsigned long long*)d_wav_offsets, d_sum);
+    }
+    hipLaunchKernelGGL(x3_index_finalize_kernel, dim3(1), dim3(64), 0, c->stream, xw, len, bl0, (const X3Cand*)cand,
+                       start, n_chain, (const unsigned long long*)d_wav_offsets, d_sum);
+  } else {
+    hipLaunchKernelGGL(x3_index_finalize_kernel, dim3(1), dim3(64), 0, c->stream, xw, len, bl0, (const X3Cand*)nullptr,
+                       X3I_NONE, 0ull, (const unsigned long long*)nullptr, d_sum);
+  }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(result, d_sum, sizeof *result, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return X3_OK;
+}
+
+extern "C" int x3_index_dev(x3_ctx* c, const uint8_t* d_x3, uint64_t len, uint64_t max_frames,
+                            uint64_t* d_frame_offsets, uint64_t* d_wav_offsets, uint64_t* n_frames,
+                            uint64_t* n_samples, int* terminal) {
+  if (!c || (!d_x3 && len) || !d_frame_offsets || !d_wav_offsets) return X3_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  X3IndexSummary r;
+  int rc = index_dev_impl(c, d_x3, len, 0, ~0ull, max_frames, d_frame_offsets, d_wav_offsets, &r);
+  if (rc) return rc;
+  if (n_frames) *n_frames = r.n_frames;
+  if (n_samples) *n_samples = r.n_samples;
+  if (terminal) *terminal = r.terminal;
+  return X3_OK;
+}
+
+extern "C" int x3_decode_stream_dev(x3_ctx* c, const uint8_t* d_x3, uint64_t len, const x3_params* p, int16_t* d_wav,
+                                    uint64_t wav_cap, uint64_t* n_out, uint64_t* frames_ok, uint64_t* frame_errors) {
+  if (!c || !p || (!d_x3 && len) || (!d_wav && wav_cap)) return X3_ERR_BAD_ARG;
+  if (n_out) *n_out = 0;
+  if (frames_ok) *frames_ok = 0;
+  if (frame_errors) *frame_errors = 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  // every frame is at least 22 bytes; index into internal buffers sized for the real count
+  const uint64_t max_frames = len / 22 + 1;
+  int rc;
+  X3IndexSummary r;
+  // sizes are not known before the candidate count: index_dev_impl sizes its own scratch, the two output arrays
+  // are sized here from an upper bound that is refined by a first call when it is large
+  uint64_t cap_frames = std::min<uint64_t>(max_frames, 1u << 20);
+  for (;;) {
+    if ((rc = ensure(c, c->frame_off, (cap_frames + 1) * sizeof(uint64_t)))) return rc;
+    if ((rc = ensure(c, c->wav_off, cap_frames * sizeof(uint64_t)))) return rc;
+    rc = index_dev_impl(c, d_x3, len, p->block_len == 0 ? 1u : 0u, wav_cap, cap_frames, (uint64_t*)c->frame_off.p,
+                        (uint64_t*)c->wav_off.p, &r);
+    if (rc == X3_ERR_BAD_ARG && cap_frames < max_frames) { cap_frames = max_frames; continue; }
+    break;
+  }
+  if (rc) return rc;
+  const uint64_t F = r.n_frames;
+  const int terminal = r.terminal;
+  if (F == 0) return terminal;
+  x3_params pp = *p;
+  if (pp.block_len == 0) pp.block_len = 1;  // frames that need block_len are BAD_ARG frames of the index
+  if ((rc = decode_dev_impl(c, d_x3, len, (const uint64_t*)c->frame_off.p, F, nullptr, (const uint64_t*)c->wav_off.p,
+                            &pp, d_wav, wav_cap, nullptr)))
+    return rc;
+  uint64_t first_bad = 0, before = 0;
+  int bad_status = 0;
+  if ((rc = x3_decode_result(c, &first_bad, &bad_status, &before))) return rc;
+  if (n_out) *n_out = before;
+  if (frames_ok) *frames_ok = first_bad;
+  if (first_bad < F) {
+    if (bad_status == X3_ERR_OUT_OF_BOUNDS_INVERSE || bad_status == X3_ERR_FRAME_DECODE_INVALID_BPF) {
+      if (frame_errors) *frame_errors = 1;  // counted, the walk ends quietly (decodefile.rs:129-135)
+      return X3_OK;
+    }
+    return bad_status;
+  }
+  return terminal;
 }
 
 static int decode_stream_impl(x3_ctx* c, const uint8_t* x3, uint64_t len, uint64_t phantom, const x3_params* p,

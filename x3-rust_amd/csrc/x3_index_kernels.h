@@ -1,0 +1,242 @@
+// x3_index_kernels.h -- the frame walk of X3aReader::decode_next_frame (src/decodefile.rs:105-121) on the
+// GPU, for streams that are already in HBM and whose frame offsets are not known.
+//
+// The walk is a linked list threaded through the stream: frame i+1 starts at off_i + 20 + payload_len_i.
+// Followed serially that is one dependent memory access per frame; here
+//   1. every even byte offset is tested IN PARALLEL for the key bytes "x3" and, on a hit, for a valid header
+//      (decoder::read_frame_header, decoder.rs:69-118: header CRC, key, channels, length) -> candidates
+//      {offset, payload_len, samples, kind}; a random pair of bytes is the key once in 65 536 and then still
+//      has to pass a 16-bit CRC, so candidates ~ frames;
+//   2. candidates go into an open-addressing hash table keyed by offset, and every candidate that the walk
+//      would step over looks up its successor;
+//   3. pointer doubling builds, per level r, the 2^r-th successor together with the sample count and node
+//      count of the span, and
+//   4. frame k of the stream is found from the start node by the binary digits of k -- all k in parallel --
+//      which also yields its sample offset (an exclusive prefix sum along the list for free).
+// A single thread then states how the walk ends, with the reference's rules: <= 20 bytes left, a header
+// that does not validate (its error), a payload that runs past the end (quiet stop), a payload longer than
+// the reader's buffer (FrameHeaderInvalidPayloadLen), a frame the decoder cannot take (BAD_ARG, included).
+#pragma once
+#include "x3_decode_kernel.h"
+
+#define X3I_CONT 0u     // the walk steps over this frame
+#define X3I_LAST_BAD 1u // pushed, then the walk stops with BAD_ARG (samples == 0, payload < 2 bytes, ...)
+#define X3I_QUIET 2u    // header fine, payload runs past the end of the data: quiet stop, not a frame
+#define X3I_PLEN 3u     // header fine, payload longer than X3_READ_BUFFER_SIZE: hard error, not a frame
+#define X3I_NONE 0xFFFFFFFFu
+#define X3I_READ_BUFFER 24576u
+
+struct X3Cand {
+  unsigned long long off;
+  uint32_t plen_kind;  // payload_len | kind << 16
+  uint32_t samples;
+};
+
+struct X3IndexSummary {
+  unsigned long long n_frames;
+  unsigned long long n_samples;
+  int terminal;
+  uint32_t last_node;   // scratch: candidate index of the last frame of the chain
+  unsigned long long first_over;  // scratch: first frame that does not fit wav_cap
+  unsigned long long n_chain;     // scratch: frames reachable from the start node
+  uint32_t start;                 // scratch: candidate at offset 0 (X3I_NONE: the walk cannot step onto it)
+  uint32_t pad;
+};
+
+// decoder::read_frame_header only (no walk checks): status, payload_len, samples
+__device__ __forceinline__ int32_t x3i_read_header(const uint32_t* __restrict__ xw, uint64_t n_dw, uint64_t off,
+                                                   uint32_t& plen, uint32_t& samples) {
+  const uint32_t h0 = x3_be32_at(xw, n_dw, off), h1 = x3_be32_at(xw, n_dw, off + 4);
+  const uint32_t h2 = x3_be32_at(xw, n_dw, off + 8), h3 = x3_be32_at(xw, n_dw, off + 12);
+  const uint32_t h4 = x3_be32_at(xw, n_dw, off + 16);
+  uint32_t hc = 0xFFFFu;
+  hc = x3_crc_be32(hc, h0);
+  hc = x3_crc_be32(hc, h1);
+  hc = x3_crc_be32(hc, h2);
+  hc = x3_crc_be32(hc, h3);
+  samples = h1 >> 16;
+  plen = h1 & 0xFFFFu;
+  if ((h4 >> 16) != hc) return X3D_FRAME_HEADER_INVALID_HEADER_CRC;
+  if ((h0 >> 16) != 0x7833u) return X3D_FRAME_HEADER_INVALID_KEY;
+  if ((h0 & 0xFFu) > 1u) return X3D_MORE_THAN_ONE_CHANNEL;
+  if (plen >= 0x7fe0u) return X3D_FRAME_LENGTH;
+  return X3D_OK;
+}
+
+// what the walk does with a VALID header at `off` (decodefile.rs:114-121 and the decoder's preconditions)
+__device__ __forceinline__ uint32_t x3i_kind(uint64_t len, uint64_t off, uint32_t plen, uint32_t samples, uint32_t bl0) {
+  if (len - off - 20 < plen) return X3I_QUIET;
+  if (plen > X3I_READ_BUFFER) return X3I_PLEN;
+  if (samples == 0 || plen < 2 || (bl0 && samples > 1)) return X3I_LAST_BAD;
+  return X3I_CONT;
+}
+
+// 1. candidates: thread t looks at the 8 even offsets of 16-byte chunk t.  cand == nullptr: count only.
+__global__ void __launch_bounds__(256)
+x3_index_candidates_kernel(const uint32_t* __restrict__ xw, uint64_t len, uint32_t bl0, X3Cand* __restrict__ cand,
+                           uint32_t cap, unsigned int* __restrict__ count) {
+  const uint64_t n_dw = (len + 3) >> 2;
+  const uint64_t chunks = (len + 15) >> 4;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < chunks; t += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t w[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) w[d] = 4 * t + d < n_dw ? xw[4 * t + d] : 0u;
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      const uint32_t hw = (w[h >> 1] >> (16 * (h & 1))) & 0xFFFFu;
+      if (hw != 0x3378u) continue;  // bytes 0x78 0x33 in memory order
+      const uint64_t off = 16 * t + 2 * h;
+      if (off + 20 > len) continue;
+      uint32_t plen, samples;
+      if (x3i_read_header(xw, n_dw, off, plen, samples) != X3D_OK) continue;
+      const unsigned int slot = atomicAdd(count, 1u);
+      if (cand && slot < cap) {
+        cand[slot].off = off;
+        cand[slot].plen_kind = plen | (x3i_kind(len, off, plen, samples, bl0) << 16);
+        cand[slot].samples = samples;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t x3i_hash(unsigned long long off, uint32_t mask) {
+  unsigned long long x = off * 0x9E3779B97F4A7C15ull;
+  return (uint32_t)(x >> 32) & mask;
+}
+
+// 2a. hash table: keys[] = offset + 1 (0 = empty), vals[] = candidate index
+__global__ void __launch_bounds__(256)
+x3_index_hash_insert_kernel(const X3Cand* __restrict__ cand, uint32_t n, unsigned long long* __restrict__ keys,
+                            uint32_t* __restrict__ vals, uint32_t mask) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long key = cand[i].off + 1ull;
+  uint32_t h = x3i_hash(cand[i].off, mask);
+  for (;;) {
+    const unsigned long long prev = atomicCAS(&keys[h], 0ull, key);
+    if (prev == 0ull) { vals[h] = i; return; }
+    h = (h + 1u) & mask;
+  }
+}
+
+__device__ __forceinline__ uint32_t x3i_lookup(unsigned long long off, const unsigned long long* __restrict__ keys,
+                                               const uint32_t* __restrict__ vals, uint32_t mask) {
+  uint32_t h = x3i_hash(off, mask);
+  for (;;) {
+    const unsigned long long k = keys[h];
+    if (k == 0ull) return X3I_NONE;
+    if (k == off + 1ull) return vals[h];
+    h = (h + 1u) & mask;
+  }
+}
+
+// 2b. level 0: successor, samples and node count of every candidate
+__global__ void __launch_bounds__(256)
+x3_index_succ_kernel(const X3Cand* __restrict__ cand, uint32_t n, const unsigned long long* __restrict__ keys,
+                     const uint32_t* __restrict__ vals, uint32_t mask, uint32_t* __restrict__ J0,
+                     unsigned long long* __restrict__ S0, uint32_t* __restrict__ L0) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t kind = cand[i].plen_kind >> 16;
+  uint32_t succ = X3I_NONE;
+  if (kind == X3I_CONT) {
+    const uint32_t j = x3i_lookup(cand[i].off + 20ull + (cand[i].plen_kind & 0xFFFFu), keys, vals, mask);
+    if (j != X3I_NONE && (cand[j].plen_kind >> 16) <= X3I_LAST_BAD) succ = j;
+  }
+  J0[i] = succ;
+  S0[i] = kind == X3I_CONT ? cand[i].samples : 0ull;  // a LAST_BAD frame is pushed but its samples are not counted
+  L0[i] = 1u;
+}
+
+// 3. one doubling step: level r from level r-1
+__global__ void __launch_bounds__(256)
+x3_index_double_kernel(uint32_t n, const uint32_t* __restrict__ Jp, const unsigned long long* __restrict__ Sp,
+                       const uint32_t* __restrict__ Lp, uint32_t* __restrict__ J, unsigned long long* __restrict__ S,
+                       uint32_t* __restrict__ L) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t j = Jp[i];
+  if (j == X3I_NONE) {
+    J[i] = X3I_NONE;
+    S[i] = Sp[i];
+    L[i] = Lp[i];
+  } else {
+    J[i] = Jp[j];
+    S[i] = Sp[i] + Sp[j];
+    L[i] = Lp[i] + Lp[j];
+  }
+}
+
+// the start node = the candidate at offset 0, if the walk can step onto it, and the length of its chain
+__global__ void x3_index_start_kernel(const X3Cand* __restrict__ cand, const unsigned long long* __restrict__ keys,
+                                      const uint32_t* __restrict__ vals, uint32_t mask,
+                                      const uint32_t* __restrict__ L_top, X3IndexSummary* __restrict__ sum) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint32_t s = x3i_lookup(0ull, keys, vals, mask);
+  if (s != X3I_NONE && (cand[s].plen_kind >> 16) > X3I_LAST_BAD) s = X3I_NONE;
+  sum->start = s;
+  sum->n_chain = s == X3I_NONE ? 0ull : (unsigned long long)L_top[s];
+}
+
+// 4. frame k = the k-th successor of the start node; its sample offset = the samples of the k nodes before it.
+// levels: J/S arrays of level r start at r*n.
+__global__ void __launch_bounds__(256)
+x3_index_emit_kernel(const X3Cand* __restrict__ cand, uint32_t n, uint32_t levels, const uint32_t* __restrict__ J,
+                     const unsigned long long* __restrict__ S, uint32_t start, unsigned long long n_chain,
+                     unsigned long long wav_cap, unsigned long long* __restrict__ frame_off,
+                     unsigned long long* __restrict__ wav_off, X3IndexSummary* __restrict__ sum) {
+  const unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_chain) return;
+  uint32_t node = start;
+  unsigned long long acc = 0;
+  for (uint32_t r = 0; r < levels; ++r) {
+    if ((k >> r) & 1ull) {
+      acc += S[(size_t)r * n + node];
+      node = J[(size_t)r * n + node];
+    }
+  }
+  frame_off[k] = cand[node].off;
+  wav_off[k] = acc;
+  // decodefile walk as the host runs it: a frame that does not fit the output is pushed and ends the walk
+  if ((cand[node].plen_kind >> 16) == X3I_CONT && acc + cand[node].samples > wav_cap) atomicMin(&sum->first_over, k);
+  if (k == n_chain - 1) sum->last_node = node;
+}
+
+// 5. how the walk ends (one thread)
+__global__ void x3_index_finalize_kernel(const uint32_t* __restrict__ xw, uint64_t len, uint32_t bl0,
+                                         const X3Cand* __restrict__ cand, uint32_t start, unsigned long long n_chain,
+                                         const unsigned long long* __restrict__ wav_off, X3IndexSummary* __restrict__ sum) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const uint64_t n_dw = (len + 3) >> 2;
+  auto ending_at = [&](uint64_t pos) -> int {  // the walk arrives at `pos` and finds no frame to push
+    if (len - pos <= 20) return X3D_OK;
+    uint32_t plen, samples;
+    const int32_t st = x3i_read_header(xw, n_dw, pos, plen, samples);
+    if (st != X3D_OK) return st;
+    const uint32_t kind = x3i_kind(len, pos, plen, samples, bl0);
+    if (kind == X3I_QUIET) return X3D_OK;
+    if (kind == X3I_PLEN) return X3D_FRAME_HEADER_INVALID_PAYLOAD_LEN;
+    return X3D_BAD_ARG;  // unreachable: such a header is a candidate and would be part of the chain
+  };
+  if (start == X3I_NONE) {
+    sum->n_frames = 0;
+    sum->n_samples = 0;
+    sum->terminal = ending_at(0);
+    return;
+  }
+  if (sum->first_over < n_chain) {  // the first frame that does not fit the output: pushed, BAD_ARG
+    sum->n_frames = sum->first_over + 1;
+    sum->n_samples = wav_off[sum->first_over];
+    sum->terminal = X3D_BAD_ARG;
+    return;
+  }
+  const X3Cand last = cand[sum->last_node];
+  sum->n_frames = n_chain;
+  if ((last.plen_kind >> 16) == X3I_LAST_BAD) {
+    sum->n_samples = wav_off[n_chain - 1];
+    sum->terminal = X3D_BAD_ARG;
+  } else {
+    sum->n_samples = wav_off[n_chain - 1] + last.samples;
+    sum->terminal = ending_at(last.off + 20ull + (last.plen_kind & 0xFFFFu));
+  }
+}

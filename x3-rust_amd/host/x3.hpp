@@ -356,6 +356,15 @@ inline X3Error decode_stream(Context& ctx, const uint8_t* x3, size_t len, const 
   if (res) *res = r;
   return static_cast<X3Error>(rc);
 }
+// the same walk for a stream that is already in HBM: frame index and decode on the device (x3_index_dev)
+inline X3Error decode_stream_dev(Context& ctx, const uint8_t* d_x3, size_t len, const Parameters& params, int16_t* d_wav,
+                                 size_t wav_cap, StreamResult* res) {
+  x3_params c = params.c_params();
+  StreamResult r;
+  int rc = x3_decode_stream_dev(ctx.raw(), d_x3, len, &c, d_wav, wav_cap, &r.samples, &r.frames_ok, &r.frame_errors);
+  if (res) *res = r;
+  return static_cast<X3Error>(rc);
+}
 }  // namespace decoder
 
 // encodefile.rs / decodefile.rs without the files: the .x3a archive header and the whole-buffer conversions

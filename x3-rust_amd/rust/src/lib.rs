@@ -50,6 +50,10 @@ pub mod ffi {
                                p: *const x3_params, samples: u64, n_out: *mut u64) -> c_int;
         pub fn x3_decode_stream(ctx: *mut x3_ctx, x3: *const u8, len: u64, p: *const x3_params, wav: *mut i16,
                                 wav_cap: u64, n_out: *mut u64, frames_ok: *mut u64, frame_errors: *mut u64) -> c_int;
+        pub fn x3_index_dev(ctx: *mut x3_ctx, d_x3: *const u8, len: u64, max_frames: u64, d_frame_offsets: *mut u64,
+                            d_wav_offsets: *mut u64, n_frames: *mut u64, n_samples: *mut u64, terminal: *mut c_int) -> c_int;
+        pub fn x3_decode_stream_dev(ctx: *mut x3_ctx, d_x3: *const u8, len: u64, p: *const x3_params, d_wav: *mut i16,
+                                    wav_cap: u64, n_out: *mut u64, frames_ok: *mut u64, frame_errors: *mut u64) -> c_int;
         pub fn x3_archive_header_write(sample_rate: u32, p: *const x3_params, out: *mut u8, out_cap: u64,
                                        out_len: *mut u64) -> c_int;
         pub fn x3_archive_header_read(bytes: *const u8, len: u64, sample_rate: *mut u32, p: *mut x3_params,

@@ -36,7 +36,7 @@ SYMBOLS = [
     "x3_encode", "x3_encode_frame", "x3_write_frame_header", "x3_encode_batch",
     "x3_read_frame_header", "x3_decode_frame", "x3_decode_stream",
     "x3_archive_header_write", "x3_archive_header_read", "x3_x3a_encode", "x3_x3a_decode",
-    "x3_encode_dev", "x3_encode_result", "x3_decode_dev", "x3_decode_result",
+    "x3_encode_dev", "x3_encode_result", "x3_decode_dev", "x3_decode_result", "x3_index_dev", "x3_decode_stream_dev",
     "x3_synth", "x3_synth_dev", "x3_dev_alloc", "x3_dev_free", "x3_dev_upload", "x3_dev_download",
 ]
 
@@ -145,6 +145,8 @@ def lib():
     L.x3_encode_result.argtypes = [vp, C.POINTER(u64), vp]
     L.x3_decode_dev.argtypes = [vp, vp, u64, vp, u64, C.POINTER(Batch), vp, PP, vp, u64, vp]
     L.x3_decode_result.argtypes = [vp, C.POINTER(u64), C.POINTER(i32), C.POINTER(u64)]
+    L.x3_index_dev.argtypes = [vp, vp, u64, u64, vp, vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(i32)]
+    L.x3_decode_stream_dev.argtypes = [vp, vp, u64, PP, vp, u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.x3_synth.argtypes = [i32, u64, u64, u64, vp]
     L.x3_synth_dev.argtypes = [vp, i32, u64, u64, u64, vp]
     L.x3_dev_alloc.argtypes = [vp, u64, C.POINTER(vp)]
@@ -360,6 +362,20 @@ class Context:
         fb, st, nb = C.c_uint64(0), C.c_int(0), C.c_uint64(0)
         rc = lib().x3_decode_result(self._h, C.byref(fb), C.byref(st), C.byref(nb))
         return rc, fb.value, st.value, nb.value
+
+    def index_dev(self, d_x3, x3_len, max_frames, d_frame_offsets, d_wav_offsets):
+        """GPU-side frame walk -> (rc, n_frames, n_samples, terminal)"""
+        nf, ns, term = C.c_uint64(0), C.c_uint64(0), C.c_int(0)
+        rc = lib().x3_index_dev(self._h, d_x3, x3_len, max_frames, d_frame_offsets, d_wav_offsets, C.byref(nf),
+                                C.byref(ns), C.byref(term))
+        return rc, nf.value, ns.value, term.value
+
+    def decode_stream_dev(self, d_x3, x3_len, params, d_wav, wav_cap):
+        """x3_decode_stream on device buffers -> (rc, n_samples, frames_ok, frame_errors)"""
+        n, fok, ferr = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        rc = lib().x3_decode_stream_dev(self._h, d_x3, x3_len, C.byref(params), d_wav, wav_cap, C.byref(n),
+                                        C.byref(fok), C.byref(ferr))
+        return rc, n.value, fok.value, ferr.value
 
     def synth_dev(self, kind, seed, start, n, d_out):
         rc = lib().x3_synth_dev(self._h, kind, seed, start, n, d_out)
