@@ -33,6 +33,12 @@
 #define X3S_OUT_STRIDE 44u     // dwords per staging row: 40 + 4 (16-byte aligned rows, spread over the banks)
 #define X3S_XROWS 11u          // transfer rows per block buffer: 10 pair dwords + the header word
 
+// halfword index of sample j (0..19) of a block in its transfer buffer: pair j/2 is dword (j/2 & 1) of the
+// 8-byte slot of this lane in row j/4
+__device__ __forceinline__ uint32_t x3s_half_index(uint32_t j, uint32_t lane) {
+  return 2u * (((j >> 2) * 64u + lane) * 2u + ((j >> 1) & 1u)) + (j & 1u);
+}
+
 // LDS barrier of the two waves: LDS operations retired, nothing else waited for
 #define X3S_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -183,22 +189,29 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       const uint32_t width = bfp ? (hdr & 15u) + 1u : (ftype == 1u ? 1u : (ftype == 2u ? 2u : 4u));
       const uint32_t lsh = bfp || ftype == 1u ? 0u : (ftype == 2u ? p.k[1] : p.k[2]);
       const uint32_t rsh = 32u - width;
-      uint32_t* const buf = xfer + (b & 1u) * (X3S_XROWS * 64u) + lane;
-      buf[X3S_PAIRS * 64u] = hdr;
+      // block buffer: five rows of 64 x 8 bytes (two pair dwords per lane per row), then the 64 header words
+      uint32_t* const buf = xfer + (b & 1u) * (X3S_XROWS * 64u);
+      buf[X3S_PAIRS * 64u + lane] = hdr;
       X3_STAMP(2);
       if (__all(cnt == X3S_BL || cnt == 0u)) {
         // two samples per 32-bit peek and per window update (two valid codewords are <= 32 bits)
-#pragma unroll 2
-        for (uint32_t j = 0; j < X3S_PAIRS; ++j) {
-          const uint32_t t = __builtin_amdgcn_alignbit(w0, w1, s);
-          const uint32_t z1 = x3_ffbh(t) & zmask;
-          const uint32_t v1 = (t << (z1 & 31u)) >> rsh;
-          const uint32_t n1 = z1 + width;
-          const uint32_t t2 = t << (n1 & 31u);
-          const uint32_t z2 = x3_ffbh(t2) & zmask;
-          const uint32_t v2 = (t2 << (z2 & 31u)) >> rsh;
-          consume(n1 + z2 + width);
-          buf[j * 64u] = x3_pack_lo16((z1 << lsh) + v1, (z2 << lsh) + v2);
+        uint2* const b2 = reinterpret_cast<uint2*>(buf) + lane;
+#pragma unroll
+        for (uint32_t j = 0; j < X3S_PAIRS; j += 2) {
+          uint32_t X[2];
+#pragma unroll
+          for (uint32_t e = 0; e < 2; ++e) {
+            const uint32_t t = __builtin_amdgcn_alignbit(w0, w1, s);
+            const uint32_t z1 = x3_ffbh(t) & zmask;
+            const uint32_t v1 = (t << (z1 & 31u)) >> rsh;
+            const uint32_t n1 = z1 + width;
+            const uint32_t t2 = t << (n1 & 31u);
+            const uint32_t z2 = x3_ffbh(t2) & zmask;
+            const uint32_t v2 = (t2 << (z2 & 31u)) >> rsh;
+            consume(n1 + z2 + width);
+            X[e] = x3_pack_lo16((z1 << lsh) + v1, (z2 << lsh) + v2);
+          }
+          b2[(j >> 1) * 64u] = make_uint2(X[0], X[1]);
         }
       } else {
         // a block that is short in some lane (the last block of a frame): one sample at a time
@@ -208,7 +221,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
           const uint32_t z = x3_ffbh(t) & zmask;
           const uint32_t v = (t << (z & 31u)) >> rsh;
           consume(j < cnt ? z + width : 0u);
-          h[(j >> 1) * 128u + (j & 1u)] = (uint16_t)((z << lsh) + v);
+          h[x3s_half_index(j, lane)] = (uint16_t)((z << lsh) + v);
         }
       }
       X3_STAMP(3);
@@ -276,8 +289,8 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       X3_STAMP(4);
       const uint32_t cnt = remaining < X3S_BL ? remaining : X3S_BL;
       remaining -= cnt;
-      const uint32_t* const buf = xfer + (b & 1u) * (X3S_XROWS * 64u) + lane;
-      const uint32_t hdr = buf[X3S_PAIRS * 64u];
+      const uint32_t* const buf = xfer + (b & 1u) * (X3S_XROWS * 64u);
+      const uint32_t hdr = buf[X3S_PAIRS * 64u + lane];
       // block parameters from the header bits
       const uint32_t ftype = hdr >> 4;
       const uint32_t E = (hdr & 15u) + 1u;
@@ -304,23 +317,33 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       X3_STAMP(2);
 
       if (__all(cnt == X3S_BL || cnt == 0u)) {
-#pragma unroll 2
-        for (uint32_t j = 0; j < X3S_PAIRS; ++j) {
-          const uint32_t X = buf[j * 64u];
-          // Rice: i = r + level*(n-1) (decoder.rs:186); inverse table = zigzag (x3.rs:200-204)
-          const uint32_t I = x3_pk_add_u16(X, nlevel2);
-          maxii2 = x3_pk_max_u16(maxii2, I);
-          const uint32_t R = x3_pk_lshr_b16_1(I) ^ x3_pk_sub_u16(0u, I & 0x00010001u);
-          // BFP: unsigned_to_i16 (decoder.rs:198-207): v - (v > thresh ? 2*thresh : 0), strict compare
-          const uint32_t M = x3_pk_ashr_i16_15(x3_pk_sub_u16(nt2, X));  // 0xFFFF where v > thresh
-          const uint32_t B = x3_pk_sub_u16(X, M & neg22);
-          const uint32_t D = x3_bfi(zmask, R, B);                        // (d1, d2)
-          const uint32_t Q = x3_pk_add_u16(D, D << 16);                  // (d1, d1 + d2)
-          uint32_t P = x3_pk_add_u16(Q, LL);                             // (last + d1, last + d1 + d2)
-          P = x3_bfi(litmask, X, P);                                     // literal: field = sample
-          LL = __builtin_amdgcn_perm(P, P, 0x07060706u);                 // (lb, lb)
-          dst[j] = __builtin_amdgcn_alignbit(P, prevP, 16);              // (pending sample, la)
-          prevP = P;
+        // the whole block's indices at once (five 8-byte reads in flight), then ten pairs from registers
+        const uint2* const b2 = reinterpret_cast<const uint2*>(buf) + lane;
+        uint2 XX[5];
+#pragma unroll
+        for (uint32_t r = 0; r < 5u; ++r) XX[r] = b2[r * 64u];
+#pragma unroll
+        for (uint32_t r = 0; r < 5u; ++r) {
+          uint32_t W[2];
+#pragma unroll
+          for (uint32_t e = 0; e < 2; ++e) {
+            const uint32_t X = e ? XX[r].y : XX[r].x;
+            // Rice: i = r + level*(n-1) (decoder.rs:186); inverse table = zigzag (x3.rs:200-204)
+            const uint32_t I = x3_pk_add_u16(X, nlevel2);
+            maxii2 = x3_pk_max_u16(maxii2, I);
+            const uint32_t R = x3_pk_lshr_b16_1(I) ^ x3_pk_sub_u16(0u, I & 0x00010001u);
+            // BFP: unsigned_to_i16 (decoder.rs:198-207): v - (v > thresh ? 2*thresh : 0), strict compare
+            const uint32_t M = x3_pk_ashr_i16_15(x3_pk_sub_u16(nt2, X));  // 0xFFFF where v > thresh
+            const uint32_t B = x3_pk_sub_u16(X, M & neg22);
+            const uint32_t D = x3_bfi(zmask, R, B);                        // (d1, d2)
+            const uint32_t Q = x3_pk_add_u16(D, D << 16);                  // (d1, d1 + d2)
+            uint32_t P = x3_pk_add_u16(Q, LL);                             // (last + d1, last + d1 + d2)
+            P = x3_bfi(litmask, X, P);                                     // literal: field = sample
+            LL = __builtin_amdgcn_perm(P, P, 0x07060706u);                 // (lb, lb)
+            W[e] = __builtin_amdgcn_alignbit(P, prevP, 16);                // (pending sample, la)
+            prevP = P;
+          }
+          *reinterpret_cast<uint2*>(dst + 2u * r) = make_uint2(W[0], W[1]);
         }
       } else {
         // short block somewhere in the group: one sample at a time, staged as halfwords
@@ -331,7 +354,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
         uint32_t last = LL & 0xFFFFu, maxii = 0;
         for (uint32_t j = 0; j < X3S_BL; ++j) {
           if (j < cnt) {
-            const uint32_t x = h[(j >> 1) * 128u + (j & 1u)];
+            const uint32_t x = h[x3s_half_index(j, lane)];
             const uint32_t ii = (x + (0u - level)) & 0xFFFFu;
             const uint32_t d_rice = (ii >> 1) ^ (0u - (ii & 1u));
             const uint32_t d_bfp = x - (x > neg_thresh ? neg2 : 0u);
