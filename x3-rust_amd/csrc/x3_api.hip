@@ -809,20 +809,24 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
   if ((rc = ensure(c, c->dec_cstatus, F * sizeof(int32_t)))) return rc;
   // fork: header + payload-CRC pass on the side stream, decoder on the main stream (independent;
   // the decoder's one-wave-per-SIMD dependency chains leave the CUs mostly idle)
+  // X3HIP_CHECK_SERIAL (experiments): the check pass in front of the decoder on the same stream
+  hipStream_t check_stream = std::getenv("X3HIP_CHECK_SERIAL") ? c->stream : c->stream2;
   HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-  HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+  HIPCHK(c, hipStreamWaitEvent(check_stream, c->ev_fork, 0));
   if (std::getenv("X3HIP_PROFILE_NO_CHECK")) {
     // profiling aid only: time the decoder without the check pass beside it (payload CRCs are NOT verified)
     HIPCHK(c, hipMemsetAsync(c->dec_cstatus.p, 0, F * sizeof(int32_t), c->stream2));
   } else {
-    TimerScope ts(c, 4, c->stream2);
-    const uint64_t check_grid = std::min<uint64_t>((F + 3) / 4, (uint64_t)c->n_cus * 8);
-    hipLaunchKernelGGL(x3_frame_check_kernel, dim3((unsigned)check_grid), dim3(256), 0, c->stream2,
+    TimerScope ts(c, 4, check_stream);
+    uint64_t check_wgs_per_cu = 8;
+    if (const char* e = std::getenv("X3HIP_CHECK_WGS")) check_wgs_per_cu = std::max(1, std::atoi(e));
+    const uint64_t check_grid = std::min<uint64_t>((F + 3) / 4, (uint64_t)c->n_cus * check_wgs_per_cu);
+    hipLaunchKernelGGL(x3_frame_check_kernel, dim3((unsigned)check_grid), dim3(256), 0, check_stream,
                        reinterpret_cast<const uint32_t*>(d_x3), x3_len, d_frame_offsets, F,
                        (const uint16_t*)c->d_xpow, (const uint16_t*)c->d_crctab, (const uint32_t*)c->d_kx64,
                        (int32_t*)c->dec_cstatus.p);
   }
-  HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
+  HIPCHK(c, hipEventRecord(c->ev_join, check_stream));
   {
     // the branch-free kernel needs every valid Rice codeword (zeros + terminator + sub-code) to fit 32 bits
     bool fast = x3_len + 64 < (1ull << 32);  // the fast kernel addresses the stream with 32-bit offsets

@@ -131,18 +131,34 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
         const uint32_t c = (nd + 63u) >> 6;
         int32_t j = (int32_t)(nd + lane) - (int32_t)(64u * c);
         crc = 0;
-        for (uint32_t i = 0; i < c; ++i, j += 64) {
-          uint32_t be = j >= 0 ? x3_bswap32(pw[j]) : 0u;
-          if (i < 2u || i + 1u == c) {  // only the first two dwords and the last one need fixing up
-            if (j == 0) {
-              be &= 0xFFFFFFFFu >> (8u * lead);
-              be ^= lead <= 2 ? (0xFFFF0000u >> (8u * lead)) : 0x000000FFu;  // CRC init folded into bytes 0,1
-            }
-            if (j == 1 && lead == 3) be ^= 0xFF000000u;
-            if ((uint32_t)j == nd - 1) be &= 0xFFFFFFFFu << (8u * tpad);
+        // the dwords do not depend on the CRC state: eight loads in flight per batch (one load per step would
+        // make every step a memory round trip -- the kernel is latency-bound per wave, not bandwidth-bound)
+        for (uint32_t i0 = 0; i0 < c; i0 += 8u) {
+          uint32_t raw[8];
+#pragma unroll
+          for (uint32_t u = 0; u < 8u; ++u) {
+            const int32_t ju = j + 64 * (int32_t)u;
+            raw[u] = (i0 + u < c && ju >= 0) ? pw[ju] : 0u;
           }
-          // partial = partial * x^2048 + crc0(dword)
-          crc = (uint32_t)tab[1024u + (crc >> 8)] ^ (uint32_t)tab[1280u + (crc & 0xFFu)] ^ crc0_be32(be);
+#pragma unroll
+          for (uint32_t u = 0; u < 8u; ++u) {
+            const uint32_t i = i0 + u;
+            if (i < c) {
+              const int32_t ju = j + 64 * (int32_t)u;
+              uint32_t be = x3_bswap32(raw[u]);
+              if (i < 2u || i + 1u == c) {  // only the first two dwords and the last one need fixing up
+                if (ju == 0) {
+                  be &= 0xFFFFFFFFu >> (8u * lead);
+                  be ^= lead <= 2 ? (0xFFFF0000u >> (8u * lead)) : 0x000000FFu;  // CRC init folded into bytes 0,1
+                }
+                if (ju == 1 && lead == 3) be ^= 0xFF000000u;
+                if ((uint32_t)ju == nd - 1) be &= 0xFFFFFFFFu << (8u * tpad);
+              }
+              // partial = partial * x^2048 + crc0(dword)
+              crc = (uint32_t)tab[1024u + (crc >> 8)] ^ (uint32_t)tab[1280u + (crc & 0xFFu)] ^ crc0_be32(be);
+            }
+          }
+          j += 512;
         }
         {
           uint32_t r = 0;
