@@ -11,17 +11,20 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--samples", type=int, default=691_200_000)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--kind", type=int, default=2)
+ap.add_argument("--clips", type=int, default=1, help="config-5 style batch: CLIPS clips of SAMPLES/CLIPS samples")
 a = ap.parse_args()
 ctx = x3hip.Context(0)
 p = x3hip.Params.default()
 n = a.samples
 L = x3hip.lib()
-F = L.x3_num_frames(n, C.byref(p)); cap = L.x3_encode_bound(n, C.byref(p))
+npc = n // a.clips
+n = npc * a.clips
+F = L.x3_num_frames(npc, C.byref(p)) * a.clips; cap = L.x3_encode_bound(npc, C.byref(p)) * a.clips
 d_wav = ctx.alloc(2 * n); d_out = ctx.alloc(cap + 16); d_off = ctx.alloc(8 * (F + 1)); d_back = ctx.alloc(2 * n)
 ctx.synth_dev(a.kind, 0x58330003, 0, n, d_wav)
 def step():
-    assert ctx.encode_dev(d_wav, n, p, d_out, cap, 0, d_off) == 0
-    assert ctx.decode_dev(d_out, cap, d_off, F, p, d_back, n, n_per_clip=n) == 0
+    assert ctx.encode_dev(d_wav, npc, p, d_out, cap, 0, d_off, n_clips=a.clips, clip_stride=npc) == 0
+    assert ctx.decode_dev(d_out, cap, d_off, F, p, d_back, n, n_per_clip=npc, n_clips=a.clips, clip_stride=npc) == 0
 step(); rc, pos, st = ctx.encode_result(); assert rc == 0; r = ctx.decode_result(); assert os.environ.get("X3_NOCHECK") or r[:3] == (0, F, 0), r
 ctx.enable_kernel_timing(True); ctx.reset_kernel_time()
 for _ in range(a.steps): step()
