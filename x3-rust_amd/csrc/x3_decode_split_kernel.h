@@ -174,6 +174,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       for (int k = 0; k < 6; ++k) ld[k] = request(v_req + 16u * k);
     };
 
+    const uint32_t lsh_tab = (p.k[1] << 16) | (p.k[2] << 24);  // log2(level) by ftype
     for (uint32_t b = 0; b < nblk_max; ++b) {
       const uint32_t cnt = remaining < X3S_BL ? remaining : X3S_BL;
       remaining -= cnt;
@@ -182,12 +183,12 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       X3_STAMP(1);
       // block header: 2 bits ftype; ftype 0 -> 4 more bits E-1 (decoder.rs:138-144, 209-216)
       const uint32_t hdr = __builtin_amdgcn_alignbit(w0, w1, s) >> 26;
+      // all of it as arithmetic on the 6 bits (no compares: selects on a stale VCC are slow on gfx950)
       const uint32_t ftype = hdr >> 4;
-      const bool bfp = ftype == 0;
-      consume(cnt ? (bfp ? 6u : 2u) : 0u);
-      const uint32_t zmask = bfp ? 0u : 0xFFFFFFFFu;
-      const uint32_t width = bfp ? (hdr & 15u) + 1u : (ftype == 1u ? 1u : (ftype == 2u ? 2u : 4u));
-      const uint32_t lsh = bfp || ftype == 1u ? 0u : (ftype == 2u ? p.k[1] : p.k[2]);
+      const uint32_t zmask = (uint32_t)((int32_t)(15u - hdr) >> 31);     // all ones for Rice (hdr >= 16)
+      consume((cnt ? 0xFFFFFFFFu : 0u) & (6u - (zmask & 4u)));           // 6 header bits for BFP, 2 for Rice
+      const uint32_t width = x3_bfi(zmask, (1u << ftype) >> 1, (hdr & 15u) + 1u);  // Rice 1,2,4; BFP E
+      const uint32_t lsh = (lsh_tab >> (8u * ftype)) & 0xFFu;            // 0, 0, k1, k2
       const uint32_t rsh = 32u - width;
       // block buffer: five rows of 64 x 8 bytes (two pair dwords per lane per row), then the 64 header words
       uint32_t* const buf = xfer + (b & 1u) * (X3S_XROWS * 64u);
@@ -283,6 +284,8 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       X3_WAVE_LDS_ORDER();
     };
 
+    const uint32_t lsh_tab = (p.k[1] << 16) | (p.k[2] << 24);                                   // by ftype
+    const uint32_t bound_tab = (p.inv_len[0] << 8) | (p.inv_len[1] << 16) | (p.inv_len[2] << 24);  // by ftype (< 256)
     for (uint32_t b = 0; b < nblk_max; ++b) {
       X3_STAMP(0);
       X3S_BARRIER();
@@ -291,23 +294,19 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       remaining -= cnt;
       const uint32_t* const buf = xfer + (b & 1u) * (X3S_XROWS * 64u);
       const uint32_t hdr = buf[X3S_PAIRS * 64u + lane];
-      // block parameters from the header bits
+      // block parameters from the header bits, as arithmetic (see the parser)
       const uint32_t ftype = hdr >> 4;
       const uint32_t E = (hdr & 15u) + 1u;
-      const bool bfp = ftype == 0;
-      uint32_t zmask = 0, litmask = 0, level = 0, bound = 0xFFFFFFFFu, neg_thresh = 0, neg2 = 0;
-      if (bfp) {
-        litmask = E == 16u ? 0xFFFFFFFFu : 0u;
-        neg_thresh = 1u << (E - 1u);
-        neg2 = E == 16u ? 0u : (neg_thresh << 1);
-        if (cnt && alive && E <= 5u) {  // decoder.rs:209-216
-          st = X3D_FRAME_DECODE_INVALID_BPF;
-          alive = false;
-        }
-      } else {
-        zmask = 0xFFFFFFFFu;
-        level = ftype == 1u ? 1u : (1u << (ftype == 2u ? p.k[1] : p.k[2]));
-        bound = ftype == 1u ? p.inv_len[0] : (ftype == 2u ? p.inv_len[1] : p.inv_len[2]);
+      const uint32_t zmask = (uint32_t)((int32_t)(15u - hdr) >> 31);      // all ones for Rice
+      const bool bfp = zmask == 0u;
+      const uint32_t litmask = ~zmask & (uint32_t)((int32_t)(14u - (hdr & 15u)) >> 31);  // BFP with E == 16
+      const uint32_t neg_thresh = ~zmask & (1u << (E - 1u));
+      const uint32_t neg2 = (neg_thresh << 1) & ~litmask;
+      const uint32_t level = zmask & (1u << ((lsh_tab >> (8u * ftype)) & 0xFFu));
+      const uint32_t bound = x3_bfi(zmask, (bound_tab >> (8u * ftype)) & 0xFFu, 0xFFFFFFFFu);
+      if (cnt && alive && bfp && E <= 5u) {  // decoder.rs:209-216
+        st = X3D_FRAME_DECODE_INVALID_BPF;
+        alive = false;
       }
       const uint32_t nlevel2 = ((0u - level) & 0xFFFFu) * 0x10001u;
       const uint32_t nt2 = neg_thresh * 0x10001u;   // <= 0x8000 in each half
