@@ -144,13 +144,14 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
   HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   HIPCHK(c, hipMalloc(&c->d_xpow, X3_XP_SIZE * sizeof(uint16_t)));
-  HIPCHK(c, hipMalloc(&c->d_status, 4 * sizeof(int)));
-  HIPCHK(c, hipMalloc(&c->d_stats, 8 * sizeof(unsigned long long)));
+  // status (4 ints) and stats (6 + end_pos) share one 128-byte block: one memset, one copy back
+  HIPCHK(c, hipMalloc(&c->d_status, 128));
+  c->d_stats = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->d_status) + 32);
   c->d_end_pos = c->d_stats + 6;
   HIPCHK(c, hipMalloc(&c->d_summary, sizeof(X3DecodeSummary)));
   HIPCHK(c, hipMalloc(&c->d_crc, 16));
-  HIPCHK(c, hipHostMalloc(&c->h_status, 4 * sizeof(int)));
-  HIPCHK(c, hipHostMalloc(&c->h_stats, 8 * sizeof(unsigned long long)));
+  HIPCHK(c, hipHostMalloc(&c->h_status, 128));
+  c->h_stats = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_status) + 32);
   HIPCHK(c, hipHostMalloc(&c->h_summary, sizeof(X3DecodeSummary)));
   HIPCHK(c, hipHostMalloc(&c->h_summary_init, sizeof(X3DecodeSummary)));
   HIPCHK(c, hipHostMalloc(&c->h_crc, 16));
@@ -258,11 +259,9 @@ extern "C" void x3_ctx_destroy(x3_ctx* c) {
   (void)hipFree(c->d_crctab);
   (void)hipFree(c->d_kx64);
   (void)hipFree(c->d_status);
-  (void)hipFree(c->d_stats);
   (void)hipFree(c->d_summary);
   (void)hipFree(c->d_crc);
   (void)hipHostFree(c->h_status);
-  (void)hipHostFree(c->h_stats);
   (void)hipHostFree(c->h_summary);
   (void)hipHostFree(c->h_summary_init);
   (void)hipHostFree(c->h_crc);
@@ -552,8 +551,7 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
     if ((rc = ensure(c, c->frame_off, (F + 1) * sizeof(uint64_t)))) return rc;
     d_off = (uint64_t*)c->frame_off.p;
   }
-  HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4 * sizeof(int), c->stream));
-  HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 8 * sizeof(unsigned long long), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_status, 0, 128, c->stream));
   // ---- single-pass path: default block length, 16-byte aligned frames (see x3_encode_stream_kernel.h)
   const bool stream_path = p->block_len == 20 && pl.nthr == 512 && (spf % 8) == 0 &&
                            (b->n_clips == 1 || (b->clip_stride % 8) == 0) &&
@@ -601,9 +599,6 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
                            (const uint16_t*)c->d_crctab, pl.lds_in_bytes, pl.img_dwords);
       }
       HIPCHK(c, hipGetLastError());
-      HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_status, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipMemcpyAsync(c->h_stats, c->d_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                               c->stream));
       c->encode_pending = true;
       c->enc_start_pos = start_pos;
       return X3_OK;
@@ -634,8 +629,6 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
                        c->d_status, (const uint16_t*)c->d_xpow, pl.lds_in_bytes, pl.img_dwords);
   }
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_status, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_stats, c->d_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   c->encode_pending = true;
   c->enc_start_pos = start_pos;
   return X3_OK;
@@ -656,6 +649,9 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
 extern "C" int x3_encode_result(x3_ctx* c, uint64_t* out_pos, uint64_t stats[6]) {
   if (!c) return X3_ERR_BAD_ARG;
   if (!c->encode_pending) return X3_ERR_BAD_ARG;
+  // status and statistics are fetched here, not behind every launch: a small copy is a packet of its own in
+  // the queue (~8 us), and a pipeline that launches encode and decode back to back asks once per batch
+  HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_status, 128, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->encode_pending = false;
   if (c->h_status[1] == X3D_LOOKBACK_TIMEOUT) {
@@ -666,6 +662,7 @@ extern "C" int x3_encode_result(x3_ctx* c, uint64_t* out_pos, uint64_t stats[6])
     int rc = encode_dev_impl(c, a.d_wav, &a.b, &a.p, a.spf, a.d_out, a.out_cap, a.start_pos, a.d_off);
     c->force_two_pass = false;
     if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_status, 128, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->encode_pending = false;
   }
@@ -824,7 +821,7 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
     hipLaunchKernelGGL(x3_frame_check_kernel, dim3((unsigned)check_grid), dim3(256), 0, check_stream,
                        reinterpret_cast<const uint32_t*>(d_x3), x3_len, d_frame_offsets, F,
                        (const uint16_t*)c->d_xpow, (const uint16_t*)c->d_crctab, (const uint32_t*)c->d_kx64,
-                       (int32_t*)c->dec_cstatus.p);
+                       (int32_t*)c->dec_cstatus.p, reinterpret_cast<unsigned long long*>(c->d_summary));
   }
   HIPCHK(c, hipEventRecord(c->ev_join, check_stream));
   {
@@ -854,7 +851,7 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
   }
   // join, then merge the two status arrays and summarise
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-  {
+  if (std::getenv("X3HIP_PROFILE_NO_CHECK")) {  // otherwise the check kernel's first thread does this
     X3DecodeSummary init;
     init.first_bad = F;
     init.samples_before = 0;
@@ -867,7 +864,6 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
                      (const int32_t*)c->dec_cstatus.p, d_status, (const X3FrameMeta*)c->dec_meta.p, F, c->d_summary);
   c->dec_status_ptr = d_status;
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(X3DecodeSummary), hipMemcpyDeviceToHost, c->stream));
   c->decode_pending = true;
   c->dec_frames = F;
   return X3_OK;
@@ -883,6 +879,7 @@ extern "C" int x3_decode_dev(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, co
 
 extern "C" int x3_decode_result(x3_ctx* c, uint64_t* first_bad, int* first_bad_status, uint64_t* samples_before) {
   if (!c || !c->decode_pending) return X3_ERR_BAD_ARG;
+  HIPCHK(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(X3DecodeSummary), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->decode_pending = false;
   if (c->h_summary->first_bad < c->dec_frames) {

@@ -91,8 +91,16 @@ __device__ __forceinline__ int32_t x3_frame_header_check(const uint32_t* __restr
 __global__ void __launch_bounds__(256)
 x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const uint64_t* __restrict__ frame_off,
                       uint64_t n_frames, const uint16_t* __restrict__ xpow, const uint16_t* __restrict__ tab_g,
-                      const uint32_t* __restrict__ kx64, int32_t* __restrict__ status) {
+                      const uint32_t* __restrict__ kx64, int32_t* __restrict__ status,
+                      unsigned long long* __restrict__ summary) {
   __shared__ __attribute__((aligned(16))) uint16_t tab[6 * 256];
+  // the summary x3_decode_merge_kernel reduces into starts as {first_bad = n_frames, samples_before = 0,
+  // status 0} (X3DecodeSummary, 24 bytes); this kernel is joined in front of the merge, so it can set that up
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    summary[0] = n_frames;
+    summary[1] = 0;
+    summary[2] = 0;
+  }
   for (uint32_t i = threadIdx.x; i < X3_CHECK_TAB_DW; i += blockDim.x)
     reinterpret_cast<uint32_t*>(tab)[i] = reinterpret_cast<const uint32_t*>(tab_g)[i];
   const uint32_t lane = threadIdx.x & 63u;
