@@ -94,6 +94,9 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
                       const uint32_t* __restrict__ kx64, int32_t* __restrict__ status,
                       unsigned long long* __restrict__ summary) {
   __shared__ __attribute__((aligned(16))) uint16_t tab[6 * 256];
+  // short and latency-bound: ahead of the decoder's waves it shares the SIMDs with, so that it is out of the way
+  // early instead of being stretched to the decoder's whole duration
+  __builtin_amdgcn_s_setprio(3);
   // the summary x3_decode_merge_kernel reduces into starts as {first_bad = n_frames, samples_before = 0,
   // status 0} (X3DecodeSummary, 24 bytes); this kernel is joined in front of the merge, so it can set that up
   if (blockIdx.x == 0 && threadIdx.x == 0) {
