@@ -52,16 +52,10 @@ __device__ __forceinline__ uint32_t x3_be32_at(const uint32_t* __restrict__ xw, 
 
 // decoder::read_frame_header (decoder.rs:69-118) + the walk's length checks (decodefile.rs:107-121) for
 // the frame at byte offset `off`; same check order as the reference.
-__device__ __forceinline__ int32_t x3_frame_header_check(const uint32_t* __restrict__ xw, uint64_t n_dw,
-                                                         uint64_t x3_len, uint64_t off, uint32_t& plen,
-                                                         uint32_t& samples, uint32_t& pcrc) {
-  plen = 0;
-  samples = 0;
-  pcrc = 0;
-  if (off + 20 > x3_len) return X3D_STREAM_ENDS_IN_FRAME;
-  const uint32_t h0 = x3_be32_at(xw, n_dw, off), h1 = x3_be32_at(xw, n_dw, off + 4);
-  const uint32_t h2 = x3_be32_at(xw, n_dw, off + 8), h3 = x3_be32_at(xw, n_dw, off + 12);
-  const uint32_t h4 = x3_be32_at(xw, n_dw, off + 16);
+// ... on the five big-endian words of the header
+__device__ __forceinline__ int32_t x3_frame_header_check_words(uint32_t h0, uint32_t h1, uint32_t h2, uint32_t h3,
+                                                               uint32_t h4, uint64_t x3_len, uint64_t off,
+                                                               uint32_t& plen, uint32_t& samples, uint32_t& pcrc) {
   uint32_t hc = 0xFFFFu;
   hc = x3_crc_be32(hc, h0);
   hc = x3_crc_be32(hc, h1);
@@ -79,21 +73,40 @@ __device__ __forceinline__ int32_t x3_frame_header_check(const uint32_t* __restr
   return X3D_OK;
 }
 
+__device__ __forceinline__ int32_t x3_frame_header_check(const uint32_t* __restrict__ xw, uint64_t n_dw,
+                                                         uint64_t x3_len, uint64_t off, uint32_t& plen,
+                                                         uint32_t& samples, uint32_t& pcrc) {
+  plen = 0;
+  samples = 0;
+  pcrc = 0;
+  if (off + 20 > x3_len) return X3D_STREAM_ENDS_IN_FRAME;
+  const uint32_t h0 = x3_be32_at(xw, n_dw, off), h1 = x3_be32_at(xw, n_dw, off + 4);
+  const uint32_t h2 = x3_be32_at(xw, n_dw, off + 8), h3 = x3_be32_at(xw, n_dw, off + 12);
+  const uint32_t h4 = x3_be32_at(xw, n_dw, off + 16);
+  return x3_frame_header_check_words(h0, h1, h2, h3, h4, x3_len, off, plen, samples, pcrc);
+}
+
 // Payload-CRC tables in LDS: T[0..3][v] = crc0 of byte v followed by 0..3 zero bytes (slicing by 4),
 // T[4][v] = (v << 8) * x^2048, T[5][v] = v * x^2048 (a 16-bit state times x^(32*64) is T[4][hi] ^ T[5][lo]).
 #define X3_CHECK_TAB_DW 768u  // 6 * 256 uint16
 
 // One WAVE per frame, waves walk the frames grid-stride (the tables are loaded once per workgroup).
-// Lane t takes the payload dwords nd - 64*(c - i) + t, i = 0..c-1 (RIGHT-aligned and interleaved: every
-// load is one contiguous 256-byte run of the wave), folds them Horner-style with x^2048 between
-// consecutive ones, and multiplies its partial by its own FIXED constant x^(32*(63 - t)) (sixteen
-// pre-shifted words per lane, held in registers for the whole kernel); the products are XOR-reduced.
+// Lane t takes the payload dwords t, t + 64, t + 128, ... (every load is one contiguous 256-byte run of the
+// wave), folds them Horner-style with x^2048 between consecutive ones, and multiplies its partial by
+// x^(32*m), m = the number of dwords behind its last one (0..63; sixteen pre-shifted words per m in LDS); the
+// products are XOR-reduced.  The kernel is LATENCY-bound per wave (frame offset -> header -> payload are
+// dependent loads), so everything a frame needs is requested one frame ahead: its offset two frames ahead,
+// its header words and -- speculatively, the mapping does not depend on the payload length -- its first
+// X3_CHECK_AHEAD x 64 payload dwords one frame ahead.
+#define X3_CHECK_AHEAD 24u  // dwords per lane requested ahead: 6 KB of payload (a default frame is ~5.3 KB)
+
 __global__ void __launch_bounds__(256)
 x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const uint64_t* __restrict__ frame_off,
                       uint64_t n_frames, const uint16_t* __restrict__ xpow, const uint16_t* __restrict__ tab_g,
                       const uint32_t* __restrict__ kx64, int32_t* __restrict__ status,
                       unsigned long long* __restrict__ summary) {
   __shared__ __attribute__((aligned(16))) uint16_t tab[6 * 256];
+  __shared__ __attribute__((aligned(16))) uint32_t kxs[64 * 16];  // [m][b] = x^(32*m) * x^b
   // short and latency-bound: ahead of the decoder's waves it shares the SIMDs with, so that it is out of the way
   // early instead of being stretched to the decoder's whole duration
   __builtin_amdgcn_s_setprio(3);
@@ -106,14 +119,9 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
   }
   for (uint32_t i = threadIdx.x; i < X3_CHECK_TAB_DW; i += blockDim.x)
     reinterpret_cast<uint32_t*>(tab)[i] = reinterpret_cast<const uint32_t*>(tab_g)[i];
+  // kx64 is indexed by lane t = 63 - m
+  for (uint32_t i = threadIdx.x; i < 64u * 16u; i += blockDim.x) kxs[i] = kx64[(63u - (i >> 4)) * 16u + (i & 15u)];
   const uint32_t lane = threadIdx.x & 63u;
-  uint32_t kk[16];
-  {
-    const uint4* kp = reinterpret_cast<const uint4*>(kx64 + lane * 16u);
-    const uint4 k0 = kp[0], k1 = kp[1], k2 = kp[2], k3 = kp[3];
-    kk[0] = k0.x; kk[1] = k0.y; kk[2] = k0.z; kk[3] = k0.w; kk[4] = k1.x; kk[5] = k1.y; kk[6] = k1.z; kk[7] = k1.w;
-    kk[8] = k2.x; kk[9] = k2.y; kk[10] = k2.z; kk[11] = k2.w; kk[12] = k3.x; kk[13] = k3.y; kk[14] = k3.z; kk[15] = k3.w;
-  }
   __syncthreads();
   auto crc0_be32 = [&](uint32_t m) -> uint32_t {  // crc0 of four bytes held big-endian
     return (uint32_t)tab[768u + (m >> 24)] ^ (uint32_t)tab[512u + ((m >> 16) & 0xFFu)] ^
@@ -121,12 +129,48 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
   };
   const uint64_t n_dw = (x3_len + 3) >> 2;
   const uint64_t waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
-  for (uint64_t f = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); f < n_frames; f += waves) {
-    const uint64_t off = frame_off[f];
-    // ---- header: every lane reads the same 20 bytes (broadcast loads)
-    uint32_t plen = 0, samples = 0, pcrc = 0;
-    int32_t st = x3_frame_header_check(xw, n_dw, x3_len, off, plen, samples, pcrc);
+  const uint64_t f0 = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (f0 >= n_frames) return;  // whole wave
 
+  // what is in flight for a frame: header dwords (6 aligned dwords cover 20 bytes at an even offset) and the
+  // first X3_CHECK_AHEAD payload dwords of this lane
+  auto request = [&](uint64_t off, uint32_t (&hd)[6], uint32_t (&pd)[X3_CHECK_AHEAD]) {
+    const uint64_t a = off >> 2;
+#pragma unroll
+    for (uint32_t i = 0; i < 6u; ++i) hd[i] = a + i < n_dw ? xw[a + i] : 0u;
+    const uint64_t pa = (off + 20) >> 2;
+#pragma unroll
+    for (uint32_t u = 0; u < X3_CHECK_AHEAD; ++u) {
+      const uint64_t j = pa + lane + 64u * u;
+      pd[u] = j < n_dw ? xw[j] : 0u;
+    }
+  };
+  uint64_t off_cur = frame_off[f0];
+  uint64_t off_next = f0 + waves < n_frames ? frame_off[f0 + waves] : 0;
+  uint32_t hd[6], pd[X3_CHECK_AHEAD];
+  request(off_cur, hd, pd);
+
+  for (uint64_t f = f0; f < n_frames; f += waves) {
+    // ---- requests for the frames behind this one
+    const uint64_t off_next2 = f + 2 * waves < n_frames ? frame_off[f + 2 * waves] : 0;
+    uint32_t hn[6], pn[X3_CHECK_AHEAD];
+    if (f + waves < n_frames) request(off_next, hn, pn);
+    // ---- this frame: header (decoder.rs:69-118 + the walk's checks)
+    const uint64_t off = off_cur;
+    uint32_t plen = 0, samples = 0, pcrc = 0;
+    int32_t st;
+    if (off + 20 > x3_len) {
+      st = X3D_STREAM_ENDS_IN_FRAME;
+    } else {
+      uint32_t h[5];
+      const uint32_t sh = 8u * (uint32_t)(off & 3u);
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const uint32_t x = x3_bswap32(hd[i]), y = x3_bswap32(hd[i + 1]);
+        h[i] = sh ? (x << sh) | (y >> (32u - sh)) : x;
+      }
+      st = x3_frame_header_check_words(h[0], h[1], h[2], h[3], h[4], x3_len, off, plen, samples, pcrc);
+    }
     // ---- payload CRC (decodefile.rs:96-100)
     if (st == X3D_OK) {
       const uint64_t p0 = off + 20;
@@ -139,43 +183,41 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
         const uint32_t* __restrict__ const pw = xw + (p0 >> 2);
         const uint32_t nd = (lead + plen + 3u) >> 2;     // aligned dwords covering the payload
         const uint32_t tpad = 4u * nd - lead - plen;     // bytes behind the payload in the last dword
-        const uint32_t c = (nd + 63u) >> 6;
-        int32_t j = (int32_t)(nd + lane) - (int32_t)(64u * c);
         crc = 0;
-        // the dwords do not depend on the CRC state: eight loads in flight per batch (one load per step would
-        // make every step a memory round trip -- the kernel is latency-bound per wave, not bandwidth-bound)
-        for (uint32_t i0 = 0; i0 < c; i0 += 8u) {
+        auto fold = [&](uint32_t raw, uint32_t j) {      // dword j of the payload
+          if (j < nd) {
+            uint32_t be = x3_bswap32(raw);
+            if (j < 2u || j == nd - 1u) {  // only the first two dwords and the last one need fixing up
+              if (j == 0) {
+                be &= 0xFFFFFFFFu >> (8u * lead);
+                be ^= lead <= 2 ? (0xFFFF0000u >> (8u * lead)) : 0x000000FFu;  // CRC init folded into bytes 0,1
+              }
+              if (j == 1 && lead == 3) be ^= 0xFF000000u;
+              if (j == nd - 1u) be &= 0xFFFFFFFFu << (8u * tpad);
+            }
+            // partial = partial * x^2048 + crc0(dword)
+            crc = (uint32_t)tab[1024u + (crc >> 8)] ^ (uint32_t)tab[1280u + (crc & 0xFFu)] ^ crc0_be32(be);
+          }
+        };
+#pragma unroll
+        for (uint32_t u = 0; u < X3_CHECK_AHEAD; ++u) fold(pd[u], lane + 64u * u);
+        for (uint32_t j0 = 64u * X3_CHECK_AHEAD; j0 < nd; j0 += 512u) {  // payloads longer than the look-ahead
           uint32_t raw[8];
 #pragma unroll
-          for (uint32_t u = 0; u < 8u; ++u) {
-            const int32_t ju = j + 64 * (int32_t)u;
-            raw[u] = (i0 + u < c && ju >= 0) ? pw[ju] : 0u;
-          }
+          for (uint32_t u = 0; u < 8u; ++u) raw[u] = j0 + lane + 64u * u < nd ? pw[j0 + lane + 64u * u] : 0u;
 #pragma unroll
-          for (uint32_t u = 0; u < 8u; ++u) {
-            const uint32_t i = i0 + u;
-            if (i < c) {
-              const int32_t ju = j + 64 * (int32_t)u;
-              uint32_t be = x3_bswap32(raw[u]);
-              if (i < 2u || i + 1u == c) {  // only the first two dwords and the last one need fixing up
-                if (ju == 0) {
-                  be &= 0xFFFFFFFFu >> (8u * lead);
-                  be ^= lead <= 2 ? (0xFFFF0000u >> (8u * lead)) : 0x000000FFu;  // CRC init folded into bytes 0,1
-                }
-                if (ju == 1 && lead == 3) be ^= 0xFF000000u;
-                if ((uint32_t)ju == nd - 1) be &= 0xFFFFFFFFu << (8u * tpad);
-              }
-              // partial = partial * x^2048 + crc0(dword)
-              crc = (uint32_t)tab[1024u + (crc >> 8)] ^ (uint32_t)tab[1280u + (crc & 0xFFu)] ^ crc0_be32(be);
-            }
-          }
-          j += 512;
+          for (uint32_t u = 0; u < 8u; ++u) fold(raw[u], j0 + lane + 64u * u);
         }
+        // this lane's last dword is followed by m = (nd - 1 - lane) mod 64 dwords: times x^(32*m)
         {
+          const uint4* kp = reinterpret_cast<const uint4*>(kxs + ((nd - 1u - lane) & 63u) * 16u);
+          const uint4 k0 = kp[0], k1 = kp[1], k2 = kp[2], k3 = kp[3];
+          const uint32_t kk[16] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w,
+                                   k2.x, k2.y, k2.z, k2.w, k3.x, k3.y, k3.z, k3.w};
           uint32_t r = 0;
 #pragma unroll
           for (int bit = 0; bit < 16; ++bit) r ^= (0u - ((crc >> bit) & 1u)) & kk[bit];
-          crc = r;
+          crc = lane < nd ? r : 0u;
         }
         crc = (uint32_t)__builtin_amdgcn_readlane((int)x3_wave_xor_to_lane63_dpp(crc), 63);
         if (tpad) crc = x3_gf_mul(crc, xpow[X3_XINV8_INDEX(tpad)]);  // undo the virtual trailing zero bytes
@@ -183,6 +225,13 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
       if (crc != pcrc) st = X3D_FRAME_HEADER_INVALID_PAYLOAD_CRC;
     }
     if (lane == 0) status[f] = st;
+    // ---- rotate
+    off_cur = off_next;
+    off_next = off_next2;
+#pragma unroll
+    for (uint32_t i = 0; i < 6u; ++i) hd[i] = hn[i];
+#pragma unroll
+    for (uint32_t u = 0; u < X3_CHECK_AHEAD; ++u) pd[u] = pn[u];
   }
 }
 
