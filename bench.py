@@ -91,11 +91,15 @@ def main():
     def step():
         rc = ctx.encode_dev(wav.data_ptr(), n, p, out.data_ptr(), cap, 0, off.data_ptr())
         assert rc == 0, (rc, ctx.last_error())
+        work = None
         if dist is not None:
-            # the exchange step of the sharded path: sub-stream lengths -> global byte offsets
-            shard.exchange_lengths(off[F:F + 1], out=lens)
+            # the exchange step of the sharded path: sub-stream lengths -> global byte offsets.  Every rank decodes
+            # its own frames, so the 8-byte all-gather runs beside the decoder and is waited for at the end of the step
+            _, work = shard.exchange_lengths(off[F:F + 1], out=lens, async_op=True)
         rc = ctx.decode_dev(out.data_ptr(), cap, off.data_ptr(), F, p, back.data_ptr(), n, n_per_clip=n)
         assert rc == 0, (rc, ctx.last_error())
+        if work is not None:
+            work.wait()
 
     def barrier():
         if dist is not None:

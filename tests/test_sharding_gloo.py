@@ -41,6 +41,10 @@ def _worker(rank, world, port, n, result_path):
         local = torch.from_numpy(np.ascontiguousarray(sub))
         lens = shard.exchange_lengths(local.numel())
         assert lens.tolist()[rank] == local.numel()
+        # the overlapped form bench.py uses: same result once the work handle has been waited for
+        lens2, work = shard.exchange_lengths(local.numel(), async_op=True)
+        work.wait()
+        assert lens2.tolist() == lens.tolist()
         starts = shard.global_offsets(lens)
         assert all(s % 2 == 0 for s in starts)  # sub-streams concatenate without padding
         whole = shard.gather_stream(local, lens, dst=0)

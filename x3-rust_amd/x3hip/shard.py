@@ -30,16 +30,18 @@ def sample_range(n_samples, samples_per_frame, rank, world):
     return s_lo, max(0, s_hi - s_lo)
 
 
-def exchange_lengths(local_len, device=None, group=None, out=None):
+def exchange_lengths(local_len, device=None, group=None, out=None, async_op=False):
     """all-gather of the sub-stream lengths -> tensor[world] (int64) on `device`.
-    `local_len` may be a 1-element int64 tensor already on the device (no host sync)."""
+    `local_len` may be a 1-element int64 tensor already on the device (no host sync).
+    async_op=True returns (out, work): the collective runs beside whatever is enqueued next (nothing on the
+    decode path needs the other ranks' lengths); call work.wait() before `out` is used."""
     world = dist.get_world_size(group)
     if not torch.is_tensor(local_len):
         local_len = torch.tensor([int(local_len)], dtype=torch.int64, device=device)
     if out is None:
         out = torch.empty(world, dtype=torch.int64, device=local_len.device)
-    dist.all_gather_into_tensor(out, local_len.reshape(1), group=group)
-    return out
+    work = dist.all_gather_into_tensor(out, local_len.reshape(1), group=group, async_op=async_op)
+    return (out, work) if async_op else out
 
 
 def global_offsets(lens):
