@@ -28,5 +28,7 @@ def step():
 step(); rc, pos, st = ctx.encode_result(); assert rc == 0; r = ctx.decode_result(); assert os.environ.get("X3_NOCHECK") or r[:3] == (0, F, 0), r
 ctx.enable_kernel_timing(True); ctx.reset_kernel_time()
 for _ in range(a.steps): step()
+rc, pos2, st2 = ctx.encode_result(); r2 = ctx.decode_result()
+assert rc == 0 and pos2 == pos and (os.environ.get("X3_NOCHECK") or r2[:3] == (0, F, 0)), (rc, pos2, r2)
 names = ["encode", "decode", "sizes", "scan", "check"]
 print(" ".join("%s=%.3f" % (names[i], ctx.kernel_time(i)[0] / a.steps) for i in range(5)), "ms; stream B/sample=%.4f" % (pos / n))
