@@ -577,6 +577,9 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
       if (const char* e = std::getenv("X3HIP_STREAM_WGS")) by_regs = std::max(1, std::atoi(e));
       const int by_lds = (int)((160 * 1024) / (pl.smem + (size_t)pl.img_dwords * 4 + 2048));
       c->stream_wg_per_cu = std::max(0, std::min(std::min(nb, 4), std::min(by_regs, by_lds)));
+      if (std::getenv("X3HIP_VERBOSE"))
+        std::fprintf(stderr, "x3hip: stream encoder %d VGPRs, occupancy API %d, by_regs %d, by_lds %d -> %d workgroups/CU\n",
+                     fa.numRegs, nb, by_regs, by_lds, c->stream_wg_per_cu);
     }
     const size_t stream_smem = pl.smem + (size_t)pl.img_dwords * 4 + 2048;  // + second frame image + CRC tables
     if (c->stream_wg_per_cu >= 1 && stream_smem <= 64 * 1024) {
