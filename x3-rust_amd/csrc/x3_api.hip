@@ -571,8 +571,8 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
       HIPCHK(c, hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&x3_encode_stream_kernel)));
       const int alloc = ((fa.numRegs + 7) / 8) * 8;
       const int wps = std::min(8, 512 / std::max(alloc, 8));
-      // 9-wave workgroups on 4 SIMDs of wps slots each, with slack for their uneven placement (measured: three
-      // workgroups per CU at <= 72 VGPRs are no faster than two).  X3HIP_STREAM_WGS overrides (experiments).
+      // 9-wave workgroups on 4 SIMDs of wps slots each, with slack for their uneven placement.  (LDS is the
+      // binding limit: two frame images sized for an all-literal frame.)  X3HIP_STREAM_WGS overrides (experiments).
       int by_regs = (4 * wps - 3) / 9;
       if (const char* e = std::getenv("X3HIP_STREAM_WGS")) by_regs = std::max(1, std::atoi(e));
       const int by_lds = (int)((160 * 1024) / (pl.smem + (size_t)pl.img_dwords * 4 + 2048));
