@@ -208,7 +208,12 @@ typedef struct x3_batch {
 /* Encode a device-resident batch into d_out[0..out_cap) starting at start_pos (even or odd; an
  * odd start is zero-padded to even as the reference does).  d_frame_offsets (may be NULL)
  * receives F+1 byte offsets: frame f occupies [d_frame_offsets[f], d_frame_offsets[f+1]).
- * Asynchronous; results via x3_encode_result(). */
+ * Asynchronous; results via x3_encode_result().  The default-geometry encoder is a persistent grid whose
+ * workgroups wait for each other's frame sizes; on a GPU that this context does not have to itself a launch
+ * can find them not all resident, gives up after a bounded wait, and x3_encode_result() then re-encodes with
+ * the general kernels: take the status from x3_encode_result() before the stream is trusted (launching
+ * x3_decode_dev on the same context in between is fine -- same stream -- as long as its result is only used
+ * after x3_encode_result() returned X3_OK). */
 int x3_encode_dev(x3_ctx* ctx, const int16_t* d_wav, const x3_batch* batch, const x3_params* p,
                   uint8_t* d_out, uint64_t out_cap, uint64_t start_pos, uint64_t* d_frame_offsets);
 /* Waits for the last x3_encode_dev; status is X3_OK, BYTE_WRITER_INSUFFICIENT_MEMORY or BAD_ARG. */
