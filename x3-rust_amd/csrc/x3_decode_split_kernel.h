@@ -141,12 +141,13 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     uint32_t s = (32u - 8u * a0) & 31u;
     uint32_t w0 = row[widx & 31u], w1 = row[(widx + 1) & 31u], w2 = row[(widx + 2) & 31u];
     uint32_t w3 = row[(widx + 3) & 31u];                // look-ahead word (re-read at every consume)
-    // the ring is topped up every SECOND block: up to 6 chunks (96 bytes >= the 80 bytes two blocks can
-    // consume: at most one word per pair), requested one service ahead.  Most lanes need one or two chunks
-    // (0.53 bytes per sample), so the later parks are skipped by the whole wave.
-    uint4 ld[6];
+    // the ring is topped up every SECOND block with up to 6 chunks (96 bytes >= the 80 bytes two blocks can
+    // consume: at most one word per pair).  Three of them are requested one service ahead -- most lanes need
+    // one or two (0.53 bytes per sample), and a scattered 16-byte-per-lane load costs ~64 cycles of issue --
+    // the other three only when some lane does need them.
+    uint4 ld[3];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) ld[k] = request(v_next + 16u * k);
+    for (int k = 0; k < 3; ++k) ld[k] = request(v_next + 16u * k);
     uint32_t v_req = v_next;
     // consume n (<= 32) bits; the word shift is v_bfi with a VGPR mask (see x3_decode_fast_kernel)
     auto consume = [&](uint32_t n) {
@@ -163,15 +164,24 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       const uint32_t used = wr_abs - widx;  // dwords from w0 on that the ring still needs
       const uint32_t fit = used >= X3_DEC_RING_DW ? 0u : (X3_DEC_RING_DW - used) >> 2;  // (widx may be -1)
 #pragma unroll
-      for (uint32_t k = 0; k < 6; ++k) {
+      for (uint32_t k = 0; k < 3; ++k) {
         if (__any(fit > k)) {
           if (fit > k) park(ld[k], v_req + 16u * k);
+        }
+      }
+      if (__any(fit > 3u)) {  // a lane went through more than 48 bytes in two blocks (BFP / literal blocks)
+        uint4 more[3];
+#pragma unroll
+        for (uint32_t k = 0; k < 3; ++k) more[k] = request(v_req + 16u * (3u + k));
+#pragma unroll
+        for (uint32_t k = 0; k < 3; ++k) {
+          if (fit > 3u + k) park(more[k], v_req + 16u * (3u + k));
         }
       }
       v_next += 16u * (fit > 6u ? 6u : fit);
       v_req = v_next;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) ld[k] = request(v_req + 16u * k);
+      for (int k = 0; k < 3; ++k) ld[k] = request(v_req + 16u * k);
     };
 
     const uint32_t lsh_tab = (p.k[1] << 16) | (p.k[2] << 24);  // log2(level) by ftype
