@@ -31,6 +31,9 @@
 #define X3S_PAIRS 10u
 #define X3S_WIN 80u            // samples staged per lane between flushes (4 blocks)
 #define X3S_OUT_STRIDE 44u     // dwords per staging row: 40 + 4 (16-byte aligned rows, spread over the banks)
+#ifndef X3S_AHEAD
+#define X3S_AHEAD 3u          // 16-byte chunks per lane requested one service ahead (of up to 6 per service)
+#endif
 #define X3S_XROWS 11u          // transfer rows per block buffer: 10 pair dwords + the header word
 
 // halfword index of sample j (0..19) of a block in its transfer buffer: pair j/2 is dword (j/2 & 1) of the
@@ -145,9 +148,9 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     // consume: at most one word per pair).  Three of them are requested one service ahead -- most lanes need
     // one or two (0.53 bytes per sample), and a scattered 16-byte-per-lane load costs ~64 cycles of issue --
     // the other three only when some lane does need them.
-    uint4 ld[3];
+    uint4 ld[X3S_AHEAD];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) ld[k] = request(v_next + 16u * k);
+    for (int k = 0; k < (int)X3S_AHEAD; ++k) ld[k] = request(v_next + 16u * k);
     uint32_t v_req = v_next;
     // consume n (<= 32) bits; the word shift is v_bfi with a VGPR mask (see x3_decode_fast_kernel)
     auto consume = [&](uint32_t n) {
@@ -164,24 +167,24 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       const uint32_t used = wr_abs - widx;  // dwords from w0 on that the ring still needs
       const uint32_t fit = used >= X3_DEC_RING_DW ? 0u : (X3_DEC_RING_DW - used) >> 2;  // (widx may be -1)
 #pragma unroll
-      for (uint32_t k = 0; k < 3; ++k) {
+      for (uint32_t k = 0; k < X3S_AHEAD; ++k) {
         if (__any(fit > k)) {
           if (fit > k) park(ld[k], v_req + 16u * k);
         }
       }
-      if (__any(fit > 3u)) {  // a lane went through more than 48 bytes in two blocks (BFP / literal blocks)
-        uint4 more[3];
+      if (__any(fit > X3S_AHEAD)) {  // a lane went through more than that in two blocks (BFP / literal blocks)
+        uint4 more[6u - X3S_AHEAD];
 #pragma unroll
-        for (uint32_t k = 0; k < 3; ++k) more[k] = request(v_req + 16u * (3u + k));
+        for (uint32_t k = 0; k < 6u - X3S_AHEAD; ++k) more[k] = request(v_req + 16u * (X3S_AHEAD + k));
 #pragma unroll
-        for (uint32_t k = 0; k < 3; ++k) {
-          if (fit > 3u + k) park(more[k], v_req + 16u * (3u + k));
+        for (uint32_t k = 0; k < 6u - X3S_AHEAD; ++k) {
+          if (fit > X3S_AHEAD + k) park(more[k], v_req + 16u * (X3S_AHEAD + k));
         }
       }
       v_next += 16u * (fit > 6u ? 6u : fit);
       v_req = v_next;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) ld[k] = request(v_req + 16u * k);
+      for (int k = 0; k < (int)X3S_AHEAD; ++k) ld[k] = request(v_req + 16u * k);
     };
 
     const uint32_t lsh_tab = (p.k[1] << 16) | (p.k[2] << 24);  // log2(level) by ftype
