@@ -31,6 +31,9 @@
 #define X3S_PAIRS 10u
 #define X3S_WIN 80u            // samples staged per lane between flushes (4 blocks)
 #define X3S_OUT_STRIDE 44u     // dwords per staging row: 40 + 4 (16-byte aligned rows, spread over the banks)
+#ifndef X3S_PERIOD
+#define X3S_PERIOD 2u         // the ring is topped up every X3S_PERIOD blocks (1 or 2)
+#endif
 #ifndef X3S_AHEAD
 #define X3S_AHEAD 3u          // 16-byte chunks per lane requested one service ahead (of up to 6 per service)
 #endif
@@ -173,15 +176,15 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
         }
       }
       if (__any(fit > X3S_AHEAD)) {  // a lane went through more than that in two blocks (BFP / literal blocks)
-        uint4 more[6u - X3S_AHEAD];
+        uint4 more[3u * X3S_PERIOD - X3S_AHEAD];
 #pragma unroll
-        for (uint32_t k = 0; k < 6u - X3S_AHEAD; ++k) more[k] = request(v_req + 16u * (X3S_AHEAD + k));
+        for (uint32_t k = 0; k < 3u * X3S_PERIOD - X3S_AHEAD; ++k) more[k] = request(v_req + 16u * (X3S_AHEAD + k));
 #pragma unroll
-        for (uint32_t k = 0; k < 6u - X3S_AHEAD; ++k) {
+        for (uint32_t k = 0; k < 3u * X3S_PERIOD - X3S_AHEAD; ++k) {
           if (fit > X3S_AHEAD + k) park(more[k], v_req + 16u * (X3S_AHEAD + k));
         }
       }
-      v_next += 16u * (fit > 6u ? 6u : fit);
+      v_next += 16u * (fit > 3u * X3S_PERIOD ? 3u * X3S_PERIOD : fit);
       v_req = v_next;
 #pragma unroll
       for (int k = 0; k < (int)X3S_AHEAD; ++k) ld[k] = request(v_req + 16u * k);
@@ -192,7 +195,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       const uint32_t cnt = remaining < X3S_BL ? remaining : X3S_BL;
       remaining -= cnt;
       X3_STAMP(0);
-      if ((b & 1u) == 0) service();
+      if ((b % X3S_PERIOD) == 0) service();
       X3_STAMP(1);
       // block header: 2 bits ftype; ftype 0 -> 4 more bits E-1 (decoder.rs:138-144, 209-216)
       const uint32_t hdr = __builtin_amdgcn_alignbit(w0, w1, s) >> 26;
