@@ -201,12 +201,13 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
         };
 #pragma unroll
         for (uint32_t u = 0; u < X3_CHECK_AHEAD; ++u) fold(pd[u], lane + 64u * u);
-        for (uint32_t j0 = 64u * X3_CHECK_AHEAD; j0 < nd; j0 += 512u) {  // payloads longer than the look-ahead
-          uint32_t raw[8];
+        // payloads longer than the look-ahead (high-entropy data: up to 20 KB per frame): the same registers,
+        // X3_CHECK_AHEAD dwords per lane per round trip
+        for (uint32_t j0 = 64u * X3_CHECK_AHEAD; j0 < nd; j0 += 64u * X3_CHECK_AHEAD) {
 #pragma unroll
-          for (uint32_t u = 0; u < 8u; ++u) raw[u] = j0 + lane + 64u * u < nd ? pw[j0 + lane + 64u * u] : 0u;
+          for (uint32_t u = 0; u < X3_CHECK_AHEAD; ++u) pd[u] = j0 + lane + 64u * u < nd ? pw[j0 + lane + 64u * u] : 0u;
 #pragma unroll
-          for (uint32_t u = 0; u < 8u; ++u) fold(raw[u], j0 + lane + 64u * u);
+          for (uint32_t u = 0; u < X3_CHECK_AHEAD; ++u) fold(pd[u], j0 + lane + 64u * u);
         }
         // this lane's last dword is followed by m = (nd - 1 - lane) mod 64 dwords: times x^(32*m)
         {
