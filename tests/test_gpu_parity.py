@@ -610,3 +610,22 @@ def test_decode_stream_dev_matches_host_api(ctx, x3):
             assert np.array_equal(ctx.download(d_wav, 2 * b[1], np.int16), a[1])
             ctx.free(d)
         ctx.free(d_wav)
+
+
+def test_encoder_falls_back_when_grid_not_resident(x3):
+    """the single-pass encoder's workgroups wait for each other's frame sizes; a grid that cannot be co-resident
+    (forced here: 3 workgroups per CU where 2 fit) must time out in bounded time and x3_encode_result must hand
+    back the two-pass kernels' bit-exact result"""
+    import time
+    with _env(X3HIP_STREAM_WGS="3"):
+        c = x3.Context(0)
+        try:
+            wav = x3.synth(2, 321, 0, 10000 * 1500 + 17)
+            t0 = time.perf_counter()
+            rc, out, stats = c.encode(wav, x3.Params.default())
+            dt = time.perf_counter() - t0
+        finally:
+            c.close()
+    rco, oo, so = O.encode(wav)
+    assert rc == rco == 0 and np.array_equal(out, oo) and stats.tolist() == so.tolist()
+    assert dt < 20.0, dt

@@ -572,11 +572,13 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
       const int alloc = ((fa.numRegs + 7) / 8) * 8;
       const int wps = std::min(8, 512 / std::max(alloc, 8));
       // 9-wave workgroups on 4 SIMDs of wps slots each, with slack for their uneven placement.  (LDS is the
-      // binding limit: two frame images sized for an all-literal frame.)  X3HIP_STREAM_WGS overrides (experiments).
-      int by_regs = (4 * wps - 3) / 9;
-      if (const char* e = std::getenv("X3HIP_STREAM_WGS")) by_regs = std::max(1, std::atoi(e));
+      // binding limit: two frame images sized for an all-literal frame.)
+      const int by_regs = (4 * wps - 3) / 9;
       const int by_lds = (int)((160 * 1024) / (pl.smem + (size_t)pl.img_dwords * 4 + 2048));
       c->stream_wg_per_cu = std::max(0, std::min(std::min(nb, 4), std::min(by_regs, by_lds)));
+      // experiments and the fallback test: force a grid (one that is too large cannot be resident: the size
+      // waits time out and x3_encode_result re-encodes with the two-pass kernels)
+      if (const char* e = std::getenv("X3HIP_STREAM_WGS")) c->stream_wg_per_cu = std::max(1, std::atoi(e));
       if (std::getenv("X3HIP_VERBOSE"))
         std::fprintf(stderr, "x3hip: stream encoder %d VGPRs, occupancy API %d, by_regs %d, by_lds %d -> %d workgroups/CU\n",
                      fa.numRegs, nb, by_regs, by_lds, c->stream_wg_per_cu);

@@ -308,7 +308,13 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
 #ifdef X3_DBG_STAMPS
             dbg_acc[7] += 1;
 #endif
-            if (++spins > X3_SPIN_LIMIT) { timeout = true; break; }
+            // give up after the bounded spin -- or as soon as ANY workgroup has (then the launch is lost anyway and
+            // every further wait would only add its own 0.1 s): the host re-encodes with the two-pass kernels
+            if (++spins > X3_SPIN_LIMIT ||
+                __hip_atomic_load(&status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == X3D_LOOKBACK_TIMEOUT) {
+              timeout = true;
+              break;
+            }
             __builtin_amdgcn_s_sleep(8);
             const uint32_t r = __hip_atomic_load(p0 - 64 * (int)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             v = in ? r : ready_tag;
@@ -326,7 +332,11 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
             const uint32_t r = __hip_atomic_load(p0 - 64 * (int64_t)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             v = in ? r : ready_tag;
             if (!__any((v >> X3_DESC_BYTES_BITS) != epoch)) break;
-            if (++spins > X3_SPIN_LIMIT) { timeout = true; break; }
+            if (++spins > X3_SPIN_LIMIT ||
+                __hip_atomic_load(&status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == X3D_LOOKBACK_TIMEOUT) {
+              timeout = true;
+              break;
+            }
             __builtin_amdgcn_s_sleep(8);
           }
           acc += v & X3_DESC_BYTES_MASK;
