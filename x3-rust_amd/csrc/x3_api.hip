@@ -560,7 +560,7 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
   c->last_enc = {d_wav, *b, *p, spf, d_out, out_cap, start_pos, d_frame_offsets};
   if (stream_path) {
     if (c->stream_wg_per_cu < 0) {
-      // The look-back waits on predecessors, so EVERY workgroup of the grid must be resident.  The
+      // Offsets wait on the other workgroups' frame sizes, so EVERY workgroup of the grid must be resident.  The
       // occupancy API can over-report by one block per CU (MI355X_MICROARCH.md, "Residency"), so it is
       // capped by a conservative count from the kernel's own register/LDS footprint: 9 waves per
       // workgroup land unevenly on the 4 SIMDs, hence the slack of 3 waves.
@@ -659,9 +659,9 @@ extern "C" int x3_encode_result(x3_ctx* c, uint64_t* out_pos, uint64_t stats[6])
   HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_status, 128, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->encode_pending = false;
-  if (c->h_status[1] == X3D_LOOKBACK_TIMEOUT) {
+  if (c->h_status[1] == X3D_SIZE_WAIT_TIMEOUT) {
     // the single-pass kernel's workgroups were not all resident (GPU shared with other work): its
-    // bounded look-back spin gave up.  Encode again with the two-pass kernels, which need no residency.
+    // bounded wait for frame sizes gave up.  Encode again with the two-pass kernels, which need no residency.
     c->force_two_pass = true;
     auto a = c->last_enc;
     int rc = encode_dev_impl(c, a.d_wav, &a.b, &a.p, a.spf, a.d_out, a.out_cap, a.start_pos, a.d_off);

@@ -25,7 +25,7 @@
 #include "x3_encode_kernel.h"
 
 #define X3_SPIN_LIMIT (1u << 16)  // polls of >= 1 memory round trip each (~0.1 s): a bounded spin, never a hang
-#define X3D_LOOKBACK_TIMEOUT 100  // internal: the host re-runs the two-pass encoder (x3_encode_result)
+#define X3D_SIZE_WAIT_TIMEOUT 100  // internal: the host re-runs the two-pass encoder (x3_encode_result)
 
 typedef short x3_short2 __attribute__((ext_vector_type(2)));
 typedef unsigned short x3_ushort2 __attribute__((ext_vector_type(2)));
@@ -213,7 +213,7 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u, wid = tid >> 6;
-  const bool helper_wave = wid == 8;         // wave 8: descriptors, look-back, prefetch of the next frame
+  const bool helper_wave = wid == 8;         // wave 8: frame sizes and offsets, prefetch of the next frame
   const uint32_t nthr = 512;                 // compute threads
   const uint64_t base_pos = (start_pos + 1ull) & ~1ull;  // writer.align::<2>() (encoder.rs:182)
   const uint32_t k0 = p.k[0], k1 = p.k[1], k2 = p.k[2];
@@ -311,7 +311,7 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
             // give up after the bounded spin -- or as soon as ANY workgroup has (then the launch is lost anyway and
             // every further wait would only add its own 0.1 s): the host re-encodes with the two-pass kernels
             if (++spins > X3_SPIN_LIMIT ||
-                __hip_atomic_load(&status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == X3D_LOOKBACK_TIMEOUT) {
+                __hip_atomic_load(&status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == X3D_SIZE_WAIT_TIMEOUT) {
               timeout = true;
               break;
             }
@@ -333,7 +333,7 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
             v = in ? r : ready_tag;
             if (!__any((v >> X3_DESC_BYTES_BITS) != epoch)) break;
             if (++spins > X3_SPIN_LIMIT ||
-                __hip_atomic_load(&status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == X3D_LOOKBACK_TIMEOUT) {
+                __hip_atomic_load(&status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == X3D_SIZE_WAIT_TIMEOUT) {
               timeout = true;
               break;
             }
@@ -350,7 +350,7 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
       tot += (unsigned long long)__builtin_amdgcn_readlane(x3_wave_incl_scan_dpp(sum), 63);
       uint64_t off = (first ? base_pos : my_off + my_bytes) + tot;
       if (timeout) {
-        if (lane == 0) atomicMax(&status[1], X3D_LOOKBACK_TIMEOUT);
+        if (lane == 0) atomicMax(&status[1], X3D_SIZE_WAIT_TIMEOUT);
         off = 0;
       }
       my_off = off;
