@@ -587,19 +587,22 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
     if (c->stream_wg_per_cu >= 1 && stream_smem <= 64 * 1024) {
       // frame-size descriptors {epoch:12 | bytes:20}: the epoch makes last launch's words "not ready"
       // without clearing the array (cleared when it is (re)allocated and when the epoch wraps)
-      const size_t desc_bytes = (F + X3_DESC_PAD) * sizeof(uint32_t);
+      // persistent grid: every workgroup must be resident (offsets wait on the other workgroups' sizes)
+      const uint64_t grid = std::min<uint64_t>(F, (uint64_t)c->n_cus * c->stream_wg_per_cu);
+      // words in front of desc[0]: the windows of the first frames reach below frame 0 -- eight windows (512)
+      // always, and (grid - 1) rounded up to whole windows when the grid is wider than that
+      const size_t desc_pad = std::max<size_t>(X3_DESC_PAD, (size_t)grid + 64);
+      const size_t desc_bytes = (F + desc_pad) * sizeof(uint32_t);
       const bool fresh = c->desc.cap < desc_bytes;
       if ((rc = ensure(c, c->desc, desc_bytes))) return rc;
       if (fresh || ++c->desc_epoch > 0xFFFu) {
         HIPCHK(c, hipMemsetAsync(c->desc.p, 0, c->desc.cap, c->stream));
         c->desc_epoch = 1;
       }
-      // persistent grid: every workgroup must be resident (offsets wait on the other workgroups' sizes)
-      const uint64_t grid = std::min<uint64_t>(F, (uint64_t)c->n_cus * c->stream_wg_per_cu);
       {
         TimerScope ts(c, 0);
         hipLaunchKernelGGL(x3_encode_stream_kernel, dim3((unsigned)grid), dim3(X3_STREAM_THREADS), stream_smem, c->stream,
-                           d_wav, pl.g, pl.dp, d_off, d_out, out_cap, start_pos, (uint32_t*)c->desc.p + X3_DESC_PAD, c->desc_epoch,
+                           d_wav, pl.g, pl.dp, d_off, d_out, out_cap, start_pos, (uint32_t*)c->desc.p + desc_pad, c->desc_epoch,
                            c->d_stats, c->d_status, c->d_end_pos, (const uint32_t*)c->d_xk16,
                            (const uint16_t*)c->d_crctab, pl.lds_in_bytes, pl.img_dwords);
       }
