@@ -834,7 +834,7 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
   HIPCHK(c, hipEventRecord(c->ev_join, check_stream));
   {
     // the branch-free kernel needs every valid Rice codeword (zeros + terminator + sub-code) to fit 32 bits
-    bool fast = x3_len + 64 < (1ull << 32);  // the fast kernel addresses the stream with 32-bit offsets
+    bool fast = true;
     const uint32_t widths[3] = {1, 2, 4};
     for (int k = 0; k < 3; ++k) {
       const uint32_t level = k == 0 ? 1u : (1u << dp.k[k]);

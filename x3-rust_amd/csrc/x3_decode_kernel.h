@@ -663,14 +663,16 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
   s_wo[lane] = wo;
   s_ns[lane] = coop ? samples : 0u;
 
-  // ---- input ring; words are parked BIG-ENDIAN.  Offsets are 32-bit (the host selects this kernel only
-  // for streams below 4 GiB): a chunk is x3b + (uint32) offset, i.e. one scalar base + a VGPR offset.
+  // ---- input ring; words are parked BIG-ENDIAN
   const uint32_t adj = (uint32_t)(reinterpret_cast<uintptr_t>(x3) & 15u);
-  const uint8_t* __restrict__ const x3b = x3 - adj;
-  const uint32_t v_end = adj + (uint32_t)p0 + plen;      // end of the payload
-  const uint32_t v_bits = adj + (uint32_t)p0 + 2u;       // first block header
-  const uint32_t v_last = (v_end - 1u) & ~15u;           // last 16-byte chunk that holds payload
-  uint32_t v_next = v_bits & ~15u;
+  // offsets are relative to this lane's first 16-byte chunk (a frame is < 64 KB): a 64-bit pointer per lane,
+  // 32-bit arithmetic on everything else, streams of any length
+  const uint64_t abs_bits = (uint64_t)adj + p0 + 2u;
+  const uint8_t* __restrict__ const x3b = (x3 - adj) + (abs_bits & ~15ull);
+  const uint32_t v_bits = (uint32_t)(abs_bits & 15u);    // first block header
+  const uint32_t v_end = v_bits - 2u + plen;               // end of the payload
+  const uint32_t v_last = (v_end - 1u) & ~15u;             // last 16-byte chunk that holds payload
+  uint32_t v_next = 0;
   uint32_t wr_abs = 0;
 
   auto request = [&](uint32_t v) -> uint4 {
