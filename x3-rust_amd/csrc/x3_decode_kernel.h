@@ -53,14 +53,10 @@ __device__ __forceinline__ uint32_t x3_be32_at(const uint32_t* __restrict__ xw, 
 // decoder::read_frame_header (decoder.rs:69-118) + the walk's length checks (decodefile.rs:107-121) for
 // the frame at byte offset `off`; same check order as the reference.
 // ... on the five big-endian words of the header
-__device__ __forceinline__ int32_t x3_frame_header_check_words(uint32_t h0, uint32_t h1, uint32_t h2, uint32_t h3,
-                                                               uint32_t h4, uint64_t x3_len, uint64_t off,
-                                                               uint32_t& plen, uint32_t& samples, uint32_t& pcrc) {
-  uint32_t hc = 0xFFFFu;
-  hc = x3_crc_be32(hc, h0);
-  hc = x3_crc_be32(hc, h1);
-  hc = x3_crc_be32(hc, h2);
-  hc = x3_crc_be32(hc, h3);
+// hc = CRC-16 of the first 16 header bytes, computed by the caller (table-free or from LDS tables)
+__device__ __forceinline__ int32_t x3_frame_header_check_words(uint32_t h0, uint32_t h1, uint32_t h4, uint32_t hc,
+                                                               uint64_t x3_len, uint64_t off, uint32_t& plen,
+                                                               uint32_t& samples, uint32_t& pcrc) {
   samples = h1 >> 16;
   plen = h1 & 0xFFFFu;
   pcrc = h4 & 0xFFFFu;
@@ -83,7 +79,12 @@ __device__ __forceinline__ int32_t x3_frame_header_check(const uint32_t* __restr
   const uint32_t h0 = x3_be32_at(xw, n_dw, off), h1 = x3_be32_at(xw, n_dw, off + 4);
   const uint32_t h2 = x3_be32_at(xw, n_dw, off + 8), h3 = x3_be32_at(xw, n_dw, off + 12);
   const uint32_t h4 = x3_be32_at(xw, n_dw, off + 16);
-  return x3_frame_header_check_words(h0, h1, h2, h3, h4, x3_len, off, plen, samples, pcrc);
+  uint32_t hc = 0xFFFFu;
+  hc = x3_crc_be32(hc, h0);
+  hc = x3_crc_be32(hc, h1);
+  hc = x3_crc_be32(hc, h2);
+  hc = x3_crc_be32(hc, h3);
+  return x3_frame_header_check_words(h0, h1, h4, hc, x3_len, off, plen, samples, pcrc);
 }
 
 // Payload-CRC tables in LDS: T[0..3][v] = crc0 of byte v followed by 0..3 zero bytes (slicing by 4),
@@ -169,7 +170,12 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
         const uint32_t x = x3_bswap32(hd[i]), y = x3_bswap32(hd[i + 1]);
         h[i] = sh ? (x << sh) | (y >> (32u - sh)) : x;
       }
-      st = x3_frame_header_check_words(h[0], h[1], h[2], h[3], h[4], x3_len, off, plen, samples, pcrc);
+      // header CRC from the LDS tables (init 0xFFFF folded into the first word)
+      uint32_t hc = crc0_be32(h[0] ^ 0xFFFF0000u);
+      hc = crc0_be32(h[1] ^ (hc << 16));
+      hc = crc0_be32(h[2] ^ (hc << 16));
+      hc = crc0_be32(h[3] ^ (hc << 16));
+      st = x3_frame_header_check_words(h[0], h[1], h[4], hc, x3_len, off, plen, samples, pcrc);
     }
     // ---- payload CRC (decodefile.rs:96-100)
     if (st == X3D_OK) {
