@@ -629,3 +629,42 @@ def test_encoder_falls_back_when_grid_not_resident(x3):
     rco, oo, so = O.encode(wav)
     assert rc == rco == 0 and np.array_equal(out, oo) and stats.tolist() == so.tolist()
     assert dt < 20.0, dt
+
+
+def test_random_parameter_sweep(ctx, x3):
+    """seeded sweep over geometry x codes x thresholds x signal scale x start position: encode equals the oracle
+    byte for byte (or fails with the same status), and streams of the default codes decode back (GPU == oracle)"""
+    rng = np.random.default_rng(20261003)
+    offsets = [6, 11, 20, 28]  # Rice table offsets by code (x3.rs:200-252): thresholds 0,1 must not exceed them
+    done = 0
+    for trial in range(48):
+        bl = int(rng.choice([1, 2, 3, 5, 8, 13, 19, 20, 21, 32, 47, 60]))
+        bpf = int(rng.integers(1, 40)) if trial % 3 else int(rng.choice([100, 500, 777]))
+        codes = (0, 1, 3) if trial % 2 else tuple(int(c) for c in rng.integers(0, 4, size=3))
+        thr = tuple(int(rng.integers(0, offsets[c] + 1)) for c in codes)
+        p = x3.Params.make(bl, bpf, codes, thr)
+        assert x3.lib().x3_params_validate(C.byref(p)) == 0
+        n = int(rng.integers(1, 4 * bl * bpf + 40))
+        base = x3.synth(int(rng.choice([1, 2, 4])), 700 + trial, 0, n).astype(np.int32)
+        scale = int(rng.choice([1, 1, 2, 7, 64, 4096]))   # widen the differences: Rice -> BFP -> literal
+        if rng.random() < 0.5:
+            wav = np.clip(base // max(1, 4096 // scale), -32768, 32767).astype(np.int16)
+        else:
+            wav = np.clip(base * scale // 64, -32768, 32767).astype(np.int16)
+        sp = int(rng.integers(0, 3))
+        rc_o, out_o, st_o = O.encode(wav, oparams(p), start_pos=sp)
+        rc_g, out_g, st_g = ctx.encode(wav, p, start_pos=sp)
+        assert rc_g == rc_o, (trial, bl, bpf, codes, thr, rc_g, rc_o)
+        if rc_o == 0:
+            assert np.array_equal(out_g, out_o) and st_g.tolist() == st_o.tolist(), (trial, bl, bpf, codes, thr)
+            body = out_o[(sp + 1) & ~1:]
+            if codes == (0, 1, 3):
+                # the reference DECODER is hard-wired to codes 0,1,3 (decoder.rs:180): only such streams round-trip,
+                # in the reference as here
+                r = check_decode(ctx, x3, body, p, wav_cap=n)
+                # ... and only when BFP blocks have nb >= 5: the reference decoder rejects E = nb + 1 <= 5
+                # (decoder.rs:213), which its own encoder emits for a third threshold below 16
+                if thr[2] >= 16:
+                    assert r[0] == 0 and np.array_equal(r[1], wav), (trial, bl, bpf, codes, thr)
+            done += 1
+    assert done >= 24
