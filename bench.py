@@ -190,7 +190,8 @@ def main():
             per = max(spf, (m // ncores) // spf * spf)
             parts = [sample[i * per:(i + 1) * per] for i in range(ncores) if (i + 1) * per <= m]
             rcs = [0] * len(parts)
-            reps_mt = max(1, args.cpu_reps // 2)
+            # about 4 s of work per thread (from the single-thread rate just measured)
+            reps_mt = max(1, int(4.0 * cpu["value"] * 1e6 / per + 0.5))
 
             def work(i):
                 e, d, l = C.c_double(0), C.c_double(0), C.c_uint64(0)
