@@ -29,8 +29,12 @@
 
 #define X3S_BL 20u             // block length served by this kernel
 #define X3S_PAIRS 10u
-#define X3S_WIN 80u            // samples staged per lane between flushes (4 blocks)
-#define X3S_OUT_STRIDE 44u     // dwords per staging row: 40 + 4 (16-byte aligned rows, spread over the banks)
+#ifndef X3S_WBLK
+#define X3S_WBLK 4u            // blocks staged per lane between flushes (a power of two)
+#endif
+#define X3S_WIN (X3S_BL * X3S_WBLK)   // samples per staging window
+#define X3S_WPIECES (X3S_WIN / 8u)     // 16-byte pieces per row and window
+#define X3S_OUT_STRIDE (X3S_WIN / 2u + 4u)  // dwords per staging row: 16-byte aligned rows, spread over the banks
 #ifndef X3S_PERIOD
 #define X3S_PERIOD 2u         // the ring is topped up every X3S_PERIOD blocks (1 or 2)
 #endif
@@ -271,14 +275,14 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     uint32_t wbase = 0;  // first sample index of the staging window (a multiple of X3S_WIN)
     X3_WAVE_LDS_ORDER();
 
-    // window [wbase, wbase + X3S_WIN): 10 pieces of 16 bytes per row, 640 pieces per group, ten per lane.
+    // window [wbase, wbase + X3S_WIN): X3S_WPIECES pieces of 16 bytes per row, as many per lane.
     // Which pieces a lane moves never changes: piece t = 64*it + lane of row r = t / 10.  For the regular
     // group the LDS offset and the offset in wav (relative to the window) are computed once.
-    uint32_t f_src[10], f_dst[10];
+    uint32_t f_src[X3S_WPIECES], f_dst[X3S_WPIECES];
 #pragma unroll
-    for (uint32_t it = 0; it < 10u; ++it) {
+    for (uint32_t it = 0; it < X3S_WPIECES; ++it) {
       const uint32_t t = it * 64u + lane;
-      const uint32_t r = t / 10u, q = t - r * 10u;
+      const uint32_t r = t / X3S_WPIECES, q = t - r * X3S_WPIECES;
       f_src[it] = r * X3S_OUT_STRIDE + 4u * q;   // dwords into outs
       f_dst[it] = r * S0 + 8u * q;               // samples behind wav + wo0 + wbase (< 2^32: 64 frames)
     }
@@ -287,13 +291,13 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       if (regular && wbase + X3S_WIN <= S0) {
         int16_t* const base = wav + wo0 + wbase;
 #pragma unroll
-        for (uint32_t it = 0; it < 10u; ++it)
+        for (uint32_t it = 0; it < X3S_WPIECES; ++it)
           *reinterpret_cast<uint4*>(base + f_dst[it]) = *reinterpret_cast<const uint4*>(outs + f_src[it]);
       } else {
 #pragma unroll 2
-        for (uint32_t it = 0; it < 10u; ++it) {
+        for (uint32_t it = 0; it < X3S_WPIECES; ++it) {
           const uint32_t t = it * 64u + lane;
-          const uint32_t r = t / 10u, q = t - r * 10u;
+          const uint32_t r = t / X3S_WPIECES, q = t - r * X3S_WPIECES;
           const uint32_t ns = s_ns[r];
           if (wbase + 8u * q + 8u <= ns)
             *reinterpret_cast<uint4*>(wav + s_wo[r] + wbase + 8u * q) =
@@ -331,7 +335,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       const uint32_t nt2 = neg_thresh * 0x10001u;   // <= 0x8000 in each half
       const uint32_t neg22 = neg2 * 0x10001u;       // <= 0x8000 in each half
       uint32_t maxii2 = 0;
-      uint32_t* const dst = orow + X3S_PAIRS * (b & 3u);
+      uint32_t* const dst = orow + X3S_PAIRS * (b & (X3S_WBLK - 1u));
       X3_STAMP(2);
 
       if (__all(cnt == X3S_BL || cnt == 0u)) {
@@ -405,13 +409,13 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
         for (uint32_t sx = from; sx < samples; ++sx) o[sx] = (int16_t)h[sx - wbase];
       }
       X3_STAMP(1);
-      if ((b & 3u) == 3u) {
+      if ((b & (X3S_WBLK - 1u)) == X3S_WBLK - 1u) {
         flush();
         wbase += X3S_WIN;
         X3_STAMP(5);
       }
     }
-    if (nblk_max & 3u) flush();
+    if (nblk_max & (X3S_WBLK - 1u)) flush();
     if (f < n_frames) status[f] = st;
   }
 #ifdef X3_DBG_STAMPS
