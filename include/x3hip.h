@@ -195,6 +195,23 @@ int x3_x3a_encode(x3_ctx* ctx, const int16_t* wav, uint64_t n, uint32_t sample_r
 int x3_x3a_decode(x3_ctx* ctx, const uint8_t* x3a, uint64_t len, int16_t* wav, uint64_t wav_cap,
                   uint64_t* n_out, uint32_t* sample_rate, uint64_t* frames_ok, uint64_t* frame_errors);
 
+/* The file level: `encodefile::wav_to_x3a` (src/encodefile.rs:48-77) and `decodefile::x3a_to_wav`
+ * (src/decodefile.rs:189-227) -- what the reference's CLI calls (src/bin/x3.rs:79-80).  Streaming: the file
+ * moves through the GPU in chunks of whole frames (pread -> pinned staging -> H2D -> kernels -> D2H ->
+ * pwrite, neighbouring chunks overlapped on a few worker contexts), so memory is bounded whatever the
+ * file size; the bytes written are those of x3_x3a_encode / x3_x3a_decode on the whole file.
+ * WAV container as `hound` 3.4.0 handles it for the only format the reference accepts: 16-bit integer PCM,
+ * one channel (anything else: X3_ERR_BAD_ARG, where the reference asserts); output is hound's canonical
+ * 44-byte header + samples.  A file that cannot be opened or read: X3_ERR_IO (the reference unwraps);
+ * an output .wav that cannot be created: X3_ERR_HOUND (`WavWriter::create(..)?`).
+ * x3_x3a_to_wav leaves, like the reference's dropped WavWriter, a valid WAV of the samples in front of the
+ * frame that ended the walk, also when it returns an error.
+ * Tuning (environment): X3HIP_FILE_CHUNK_FRAMES (default 3200 frames = 64 MB of samples),
+ * X3HIP_FILE_WORKERS (default 3). */
+int x3_wav_to_x3a(x3_ctx* ctx, const char* wav_path, const char* x3a_path, uint64_t stats[6]);
+int x3_x3a_to_wav(x3_ctx* ctx, const char* x3a_path, const char* wav_path, uint64_t* n_samples,
+                  uint64_t* frame_errors);
+
 /* ------------------------------------------------------------------ device-resident API */
 
 /* Geometry of a uniform batch resident in HBM: n_clips clips of n_per_clip samples, clip c

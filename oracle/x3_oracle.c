@@ -763,6 +763,162 @@ int x3o_x3a_decode(const uint8_t* x3a, uint64_t len, int16_t* wav, uint64_t wav_
   return decode_stream_phantom(x3a + start, len - start, 8, &p, wav, wav_cap, n_out, frames_ok, frame_errors);
 }
 
+/* ------------------------------------------------------------ files (hound restated, see x3_oracle.h) */
+
+static uint32_t le32(const uint8_t* b) { return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24); }
+static uint16_t le16(const uint8_t* b) { return (uint16_t)(b[0] | (b[1] << 8)); }
+static void put_le32(uint8_t* b, uint32_t v) { b[0] = (uint8_t)v; b[1] = (uint8_t)(v >> 8); b[2] = (uint8_t)(v >> 16); b[3] = (uint8_t)(v >> 24); }
+static void put_le16(uint8_t* b, uint16_t v) { b[0] = (uint8_t)v; b[1] = (uint8_t)(v >> 8); }
+
+/* hound::WavReader::new: "RIFF" size "WAVE", then chunks until "data"; fmt must come first */
+int x3o_wav_parse(const uint8_t* bytes, uint64_t len, uint32_t* sample_rate, uint16_t* channels, uint16_t* bits,
+                  uint64_t* data_off, uint64_t* data_len) {
+  if (len < 12) return X3O_IO;
+  if (memcmp(bytes, "RIFF", 4) != 0 || memcmp(bytes + 8, "WAVE", 4) != 0) return X3O_BAD_ARG;
+  uint64_t pos = 12;
+  int have_fmt = 0;
+  for (;;) {
+    if (len - pos < 8) return X3O_IO; /* end of file without a data chunk */
+    const uint8_t* h = bytes + pos;
+    uint32_t clen = le32(h + 4);
+    pos += 8;
+    if (memcmp(h, "fmt ", 4) == 0) {
+      if (clen < 16) return X3O_BAD_ARG;
+      if (len - pos < clen) return X3O_IO;
+      uint16_t tag = le16(bytes + pos);
+      *channels = le16(bytes + pos + 2);
+      *sample_rate = le32(bytes + pos + 4);
+      *bits = le16(bytes + pos + 14);
+      if (tag == 0xFFFE) { /* WAVE_FORMAT_EXTENSIBLE: the sub-format GUID starts with the real tag */
+        if (clen < 40) return X3O_BAD_ARG;
+        tag = le16(bytes + pos + 24);
+      }
+      if (tag != 1) return X3O_BAD_ARG; /* integer PCM only (the reference reads i16 samples) */
+      have_fmt = 1;
+    } else if (memcmp(h, "data", 4) == 0) {
+      if (!have_fmt) return X3O_BAD_ARG;
+      *data_off = pos;
+      *data_len = clen;
+      return X3O_OK;
+    }
+    uint64_t skip = (uint64_t)clen + (clen & 1u); /* chunks are word aligned */
+    if (len - pos < skip) return X3O_IO;
+    pos += skip;
+  }
+}
+
+/* hound::WavWriter for {channels 1, 16 bit, Int}: PCMWAVEFORMAT header, sizes as finalize() leaves them */
+void x3o_wav_header_write(uint32_t sample_rate, uint64_t n_samples, uint8_t out[44]) {
+  uint32_t data_len = (uint32_t)(n_samples * 2);
+  memcpy(out, "RIFF", 4);
+  put_le32(out + 4, 36 + data_len);
+  memcpy(out + 8, "WAVEfmt ", 8);
+  put_le32(out + 16, 16);
+  put_le16(out + 20, 1);
+  put_le16(out + 22, 1);
+  put_le32(out + 24, sample_rate);
+  put_le32(out + 28, sample_rate * 2);
+  put_le16(out + 32, 2);
+  put_le16(out + 34, 16);
+  memcpy(out + 36, "data", 4);
+  put_le32(out + 40, data_len);
+}
+
+static uint8_t* read_whole_file(const char* path, uint64_t* len) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return NULL;
+  fseek(f, 0, SEEK_END);
+  long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  uint8_t* b = (uint8_t*)malloc(n > 0 ? (size_t)n : 1);
+  if (b && n > 0 && fread(b, 1, (size_t)n, f) != (size_t)n) { free(b); b = NULL; }
+  fclose(f);
+  *len = n > 0 ? (uint64_t)n : 0;
+  return b;
+}
+
+/* src/encodefile.rs:48-77 */
+int x3o_wav_to_x3a(const char* wav_path, const char* x3a_path, uint64_t stats[6]) {
+  uint64_t st_local[6];
+  if (!stats) stats = st_local;
+  memset(stats, 0, 6 * sizeof(uint64_t));
+  uint64_t len = 0;
+  uint8_t* file = read_whole_file(wav_path, &len);
+  if (!file) return X3O_IO; /* WavReader::open(..).unwrap() */
+  uint32_t rate = 0;
+  uint16_t ch = 0, bits = 0;
+  uint64_t off = 0, dlen = 0;
+  int rc = x3o_wav_parse(file, len, &rate, &ch, &bits, &off, &dlen);
+  if (rc) { free(file); return rc; }
+  if (bits != 16 || ch != 1) { free(file); return X3O_BAD_ARG; } /* assert_eq!, :53,56 */
+  if (dlen & 1u) { free(file); return X3O_BAD_ARG; }               /* hound: not a multiple of the sample size */
+  FILE* out = fopen(x3a_path, "wb");                               /* File::create(..)?, :66 */
+  if (!out) { free(file); return X3O_IO; }
+  uint64_t n = dlen / 2, avail = (len - off) / 2;
+  int truncated = avail < n; /* samples().map(|x| x.unwrap()) panics at the first missing sample */
+  if (truncated) n = avail;
+  x3o_params p;
+  x3o_params_default(&p);
+  uint64_t spf = (uint64_t)p.block_len * p.blocks_per_frame, nf = (n + spf - 1) / spf;
+  uint64_t cap = 1024 + nf * (20 + 2 * spf + spf / 8 + 64);
+  uint8_t* buf = (uint8_t*)malloc(cap);
+  int16_t* wav = (int16_t*)malloc((n ? n : 1) * sizeof(int16_t));
+  if (!buf || !wav) { free(buf); free(wav); free(file); fclose(out); return X3O_BAD_ARG; }
+  for (uint64_t i = 0; i < n; i++) wav[i] = (int16_t)le16(file + off + 2 * i);
+  uint64_t olen = 0;
+  rc = x3o_x3a_encode(wav, n, rate, buf, cap, &olen, stats);
+  if (!rc && fwrite(buf, 1, olen, out) != olen) rc = X3O_IO;
+  if (fclose(out) != 0 && !rc) rc = X3O_IO;
+  free(buf); free(wav); free(file);
+  if (!rc && truncated) rc = X3O_IO;
+  return rc;
+}
+
+/* src/decodefile.rs:189-227 */
+int x3o_x3a_to_wav(const char* x3a_path, const char* wav_path, uint64_t* n_samples, uint64_t* frame_errors) {
+  if (n_samples) *n_samples = 0;
+  if (frame_errors) *frame_errors = 0;
+  uint64_t len = 0;
+  uint8_t* file = read_whole_file(x3a_path, &len);
+  if (!file) return X3O_IO; /* File::open(..).unwrap(), :60 */
+  x3o_params p;
+  uint32_t rate = 0;
+  uint8_t ch;
+  uint64_t hsize;
+  int rc = x3o_archive_header_read(file, len, &rate, &p, &ch, &hsize); /* X3aReader::open before the writer exists */
+  if (rc) { free(file); return rc; }
+  FILE* out = fopen(wav_path, "wb"); /* WavWriter::create(..)?, :201 */
+  if (!out) { free(file); return X3O_HOUND; }
+  uint64_t cap = 0; /* samples the headers of the stream promise (an upper bound of what the walk yields) */
+  for (uint64_t pos = 8 + hsize; len - pos >= 20;) {
+    x3o_frame_header h;
+    if (x3o_read_frame_header(file + pos, 20, &h)) break;
+    cap += h.samples;
+    if (len - pos - 20 < h.payload_len) break;
+    pos += 20 + (uint64_t)h.payload_len;
+  }
+  int16_t* wav = (int16_t*)malloc((cap ? cap : 1) * sizeof(int16_t));
+  if (!wav) { free(file); fclose(out); return X3O_BAD_ARG; }
+  uint64_t n = 0, fok = 0, ferr = 0;
+  uint32_t rate2;
+  rc = x3o_x3a_decode(file, len, wav, cap, &n, &rate2, &fok, &ferr);
+  /* whatever ended the walk, the writer is dropped and finalised with what it got */
+  uint8_t hdr[44];
+  x3o_wav_header_write(rate, n, hdr);
+  int wrc = X3O_OK;
+  if (fwrite(hdr, 1, 44, out) != 44) wrc = X3O_IO;
+  for (uint64_t i = 0; i < n && !wrc; i++) {
+    uint8_t s[2];
+    put_le16(s, (uint16_t)wav[i]);
+    if (fwrite(s, 1, 2, out) != 2) wrc = X3O_IO;
+  }
+  if (fclose(out) != 0 && !wrc) wrc = X3O_IO;
+  free(wav); free(file);
+  if (n_samples) *n_samples = n;
+  if (frame_errors) *frame_errors = ferr;
+  return rc ? rc : wrc;
+}
+
 /* ------------------------------------------------------------ CPU baseline */
 
 static double now_s(void) {

@@ -173,6 +173,23 @@ int x3o_x3a_encode(const int16_t* wav, uint64_t n, uint32_t sample_rate, uint8_t
 int x3o_x3a_decode(const uint8_t* x3a, uint64_t len, int16_t* wav, uint64_t wav_cap, uint64_t* n_out,
                    uint32_t* sample_rate, uint64_t* frames_ok, uint64_t* frame_errors); /* decodefile.rs:59-136,189-212 */
 
+/* ---- the file level: encodefile::wav_to_x3a (encodefile.rs:48-77), decodefile::x3a_to_wav
+ * (decodefile.rs:189-227).  WAV files go through `hound` 3.4.0 in the reference (Cargo.toml:24; not in
+ * the reference tree, no Cargo.lock).  Restated here from its documented behaviour for the only case the
+ * reference accepts, 16-bit integer PCM, one channel: the reader walks the RIFF chunks up to "data"
+ * (fmt tag 1, or 0xFFFE with the PCM sub-format) and yields data_len/2 little-endian samples; the writer
+ * emits the canonical 44-byte header (RIFF size, "WAVE", a 16-byte PCMWAVEFORMAT "fmt " chunk, "data")
+ * followed by the samples, and fixes both sizes when it is dropped -- also on the error path, so a walk
+ * that ends with a hard error leaves a valid WAV of the samples decoded before it.  PARITY UNPINNED: no
+ * reference test touches files (they are commented out, encodefile.rs:140-148, decodefile.rs:317-325).
+ * Where the reference panics (unwrap / assert_eq: input missing, not 16 bit, not mono, malformed WAV)
+ * these return X3O_IO for a file that cannot be opened or read and X3O_BAD_ARG for a format it rejects. */
+int x3o_wav_parse(const uint8_t* bytes, uint64_t len, uint32_t* sample_rate, uint16_t* channels,
+                  uint16_t* bits, uint64_t* data_off, uint64_t* data_len);
+void x3o_wav_header_write(uint32_t sample_rate, uint64_t n_samples, uint8_t out[44]);
+int x3o_wav_to_x3a(const char* wav_path, const char* x3a_path, uint64_t stats[6]);
+int x3o_x3a_to_wav(const char* x3a_path, const char* wav_path, uint64_t* n_samples, uint64_t* frame_errors);
+
 /* Timing helper for bench.py's cpu_baseline leg: encode then decode `n` samples `reps` times,
  * single thread; returns seconds for encode and decode separately. */
 int x3o_time_roundtrip(const int16_t* wav, uint64_t n, const x3o_params* p, int reps,

@@ -101,6 +101,12 @@ def lib(native=False):
                                  C.c_void_p]
     L.x3o_x3a_decode.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                                  C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.x3o_wav_parse.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint16),
+                                C.POINTER(C.c_uint16), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.x3o_wav_header_write.argtypes = [C.c_uint32, C.c_uint64, C.c_void_p]
+    L.x3o_wav_header_write.restype = None
+    L.x3o_wav_to_x3a.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p]
+    L.x3o_x3a_to_wav.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.x3o_time_roundtrip.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Params), C.c_int, C.POINTER(C.c_double),
                                      C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.x3o_init()
@@ -194,3 +200,29 @@ def x3a_decode(x3a, wav_cap=None):
     rc = lib().x3o_x3a_decode(x3a.ctypes.data, x3a.size, wav.ctypes.data, wav_cap, C.byref(n), C.byref(rate),
                               C.byref(fok), C.byref(ferr))
     return rc, wav[: n.value].copy(), rate.value, fok.value, ferr.value
+
+
+def wav_header(sample_rate, n_samples):
+    out = np.zeros(44, dtype=np.uint8)
+    lib().x3o_wav_header_write(sample_rate, n_samples, out.ctypes.data)
+    return out
+
+
+def wav_parse(data):
+    """-> (rc, sample_rate, channels, bits, data_off, data_len)"""
+    b = np.ascontiguousarray(data, dtype=np.uint8)
+    rate, ch, bits, off, dlen = C.c_uint32(0), C.c_uint16(0), C.c_uint16(0), C.c_uint64(0), C.c_uint64(0)
+    rc = lib().x3o_wav_parse(b.ctypes.data, b.size, C.byref(rate), C.byref(ch), C.byref(bits), C.byref(off), C.byref(dlen))
+    return rc, rate.value, ch.value, bits.value, off.value, dlen.value
+
+
+def wav_to_x3a(wav_path, x3a_path):
+    stats = np.zeros(6, dtype=np.uint64)
+    rc = lib().x3o_wav_to_x3a(os.fsencode(wav_path), os.fsencode(x3a_path), stats.ctypes.data)
+    return rc, stats
+
+
+def x3a_to_wav(x3a_path, wav_path):
+    n, ferr = C.c_uint64(0), C.c_uint64(0)
+    rc = lib().x3o_x3a_to_wav(os.fsencode(x3a_path), os.fsencode(wav_path), C.byref(n), C.byref(ferr))
+    return rc, n.value, ferr.value

@@ -1065,66 +1065,84 @@ extern "C" int x3_decode_stream(x3_ctx* c, const uint8_t* x3, uint64_t len, cons
   return decode_stream_impl(c, x3, len, 0, p, wav, wav_cap, n_out, frames_ok, frame_errors);
 }
 
-// `phantom`: bytes the reader BELIEVES remain beyond the real data (X3aReader::open subtracts the archive
-// header without its 8-byte id, decodefile.rs:62-66); a read that runs past the real end is X3Error::Io.
-static int decode_stream_impl(x3_ctx* c, const uint8_t* x3, uint64_t len, uint64_t phantom, const x3_params* p,
-                              int16_t* wav, uint64_t wav_cap, uint64_t* n_out, uint64_t* frames_ok,
-                              uint64_t* frame_errors) {
-  if (!c || !p || (!x3 && len) || (!wav && wav_cap)) return X3_ERR_BAD_ARG;
-  if (n_out) *n_out = 0;
-  if (frames_ok) *frames_ok = 0;
-  if (frame_errors) *frame_errors = 0;
-  HIPCHK(c, hipSetDevice(c->device));
-  // ---- host side of the walk (decodefile.rs:105-121): header chain, lengths, terminal condition
+// The host side of X3aReader::decode_next_frame's walk (decodefile.rs:105-121) over `buf`, a window of
+// `buf_len` bytes at the head of `real_total` bytes that really exist (a file read in pieces; the same for
+// an in-memory stream) of which the reader BELIEVES `believed_total` remain (X3aReader::open subtracts the
+// archive header without its 8-byte id, decodefile.rs:62-66: 8 phantom bytes).  Collects the frames the walk
+// steps over -- and the one frame the decoder will refuse, where there is one -- and says how it ends:
+// `need_more`: the window ran out (or `max_samples` were collected) at *end_pos, the walk goes on from there;
+// otherwise *terminal is what the reference's walk returns if every frame before decodes.
+struct HostWalk {
   std::vector<uint64_t> offs, woffs;
-  uint64_t pos = 0, remaining = len + phantom, nsamp = 0;
+  uint64_t nsamp = 0, end_pos = 0;
   int terminal = X3_OK;
+  bool need_more = false;
+};
+static void walk_host(const uint8_t* buf, uint64_t buf_len, uint64_t real_total, uint64_t believed_total,
+                      const x3_params* p, uint64_t wav_cap, uint64_t max_samples, HostWalk* w) {
+  uint64_t pos = 0, remaining = believed_total, nsamp = 0;
   for (;;) {
     if (remaining <= 20) break;
-    if (len - pos < 20) { terminal = X3_ERR_IO; break; }  // read_exact past the real end of the data
+    if (real_total - pos < 20) { w->terminal = X3_ERR_IO; break; }  // read_exact past the real end of the data
+    if (buf_len - pos < 20) { w->need_more = true; break; }
     x3_frame_header h;
-    int rc = x3_read_frame_header(x3 + pos, 20, &h);
-    if (rc) { terminal = rc; break; }
+    int rc = x3_read_frame_header(buf + pos, 20, &h);
+    if (rc) { w->terminal = rc; break; }
     if (remaining - 20 < h.payload_len) break;
-    if (len - pos - 20 < h.payload_len) { terminal = X3_ERR_IO; break; }
-    if (h.payload_len > X3_READ_BUFFER_SIZE) { terminal = X3_ERR_FRAME_HEADER_INVALID_PAYLOAD_LEN; break; }
+    if (real_total - pos - 20 < h.payload_len) { w->terminal = X3_ERR_IO; break; }
+    if (buf_len - pos - 20 < h.payload_len) { w->need_more = true; break; }
+    if (h.payload_len > X3_READ_BUFFER_SIZE) { w->terminal = X3_ERR_FRAME_HEADER_INVALID_PAYLOAD_LEN; break; }
     if (h.samples == 0 || h.payload_len < 2 || nsamp + h.samples > wav_cap || (p->block_len == 0 && h.samples > 1)) {
       // payload CRC is checked before decode_frame runs, so let the GPU look at this frame too:
       // it reports the CRC error if there is one, BAD_ARG (reference panic) otherwise
-      offs.push_back(pos);
-      woffs.push_back(nsamp);
-      terminal = X3_ERR_BAD_ARG;
+      w->offs.push_back(pos);
+      w->woffs.push_back(nsamp);
+      w->terminal = X3_ERR_BAD_ARG;
+      pos += 20 + (uint64_t)h.payload_len;
       break;
     }
-    offs.push_back(pos);
-    woffs.push_back(nsamp);
+    if (nsamp + h.samples > max_samples && !w->offs.empty()) { w->need_more = true; break; }
+    w->offs.push_back(pos);
+    w->woffs.push_back(nsamp);
     nsamp += h.samples;
     pos += 20 + h.payload_len;
     remaining -= 20 + h.payload_len;
   }
-  const uint64_t F = offs.size();
-  if (F == 0) return terminal;
+  w->nsamp = nsamp;
+  w->end_pos = pos;
+}
+
+// decode the frames a walk collected from host memory into host memory: H2D, one decode launch, D2H of the
+// samples in front of the first frame that fails.  *first_bad == F: all of them decoded.
+static int decode_frames_host(x3_ctx* c, const uint8_t* x3, uint64_t len, const HostWalk& w, const x3_params* p,
+                              int16_t* wav, uint64_t wav_cap, uint64_t* before, uint64_t* first_bad, int* bad_status) {
+  const uint64_t F = w.offs.size();
+  *before = 0;
+  *first_bad = 0;
+  *bad_status = 0;
+  if (F == 0) return X3_OK;
   int rc;
   if ((rc = ensure(c, c->in, len + 16))) return rc;
   if ((rc = ensure(c, c->frame_off, (F + 1) * sizeof(uint64_t)))) return rc;
   if ((rc = ensure(c, c->wav_off, F * sizeof(uint64_t)))) return rc;
-  if ((rc = ensure(c, c->out, (nsamp + 65536) * sizeof(int16_t)))) return rc;
+  if ((rc = ensure(c, c->out, (w.nsamp + 65536) * sizeof(int16_t)))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->in.p, x3, len, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->frame_off.p, offs.data(), F * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->wav_off.p, woffs.data(), F * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->frame_off.p, w.offs.data(), F * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->wav_off.p, w.woffs.data(), F * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
   x3_params pp = *p;
-  if (pp.block_len == 0) pp.block_len = 1;  // frames that need block_len were routed to BAD_ARG above
-  const uint64_t dev_wav_cap = std::min<uint64_t>(wav_cap, nsamp + 65535);
+  if (pp.block_len == 0) pp.block_len = 1;  // frames that need block_len were routed to BAD_ARG by the walk
+  const uint64_t dev_wav_cap = std::min<uint64_t>(wav_cap, w.nsamp + 65535);
   if ((rc = decode_dev_impl(c, (const uint8_t*)c->in.p, len, (const uint64_t*)c->frame_off.p, F, nullptr,
                             (const uint64_t*)c->wav_off.p, &pp, (int16_t*)c->out.p, dev_wav_cap, nullptr)))
     return rc;
-  uint64_t first_bad = 0, before = 0;
-  int bad_status = 0;
-  if ((rc = x3_decode_result(c, &first_bad, &bad_status, &before))) return rc;
-  if (before) HIPCHK(c, hipMemcpyAsync(wav, c->out.p, before * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
+  if ((rc = x3_decode_result(c, first_bad, bad_status, before))) return rc;
+  if (*before) HIPCHK(c, hipMemcpyAsync(wav, c->out.p, *before * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (n_out) *n_out = before;
-  if (frames_ok) *frames_ok = first_bad;
+  return X3_OK;
+}
+
+// how the walk ends when frame `first_bad` of F failed with `bad_status` (decodefile.rs:96-100, 128-135)
+static int walk_result(uint64_t F, uint64_t first_bad, int bad_status, int terminal, uint64_t* frame_errors) {
   if (first_bad < F) {
     if (bad_status == X3_ERR_OUT_OF_BOUNDS_INVERSE || bad_status == X3_ERR_FRAME_DECODE_INVALID_BPF) {
       if (frame_errors) *frame_errors = 1;  // counted, the walk ends quietly (decodefile.rs:129-135)
@@ -1133,6 +1151,29 @@ static int decode_stream_impl(x3_ctx* c, const uint8_t* x3, uint64_t len, uint64
     return bad_status;  // payload CRC mismatch (hard error) or BAD_ARG (reference panic)
   }
   return terminal;
+}
+
+// `phantom`: bytes the reader BELIEVES remain beyond the real data; a read that runs past the real end is
+// X3Error::Io.
+static int decode_stream_impl(x3_ctx* c, const uint8_t* x3, uint64_t len, uint64_t phantom, const x3_params* p,
+                              int16_t* wav, uint64_t wav_cap, uint64_t* n_out, uint64_t* frames_ok,
+                              uint64_t* frame_errors) {
+  if (!c || !p || (!x3 && len) || (!wav && wav_cap)) return X3_ERR_BAD_ARG;
+  if (n_out) *n_out = 0;
+  if (frames_ok) *frames_ok = 0;
+  if (frame_errors) *frame_errors = 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  HostWalk w;
+  walk_host(x3, len, len, len + phantom, p, wav_cap, ~0ull, &w);
+  const uint64_t F = w.offs.size();
+  if (F == 0) return w.terminal;
+  uint64_t first_bad = 0, before = 0;
+  int bad_status = 0;
+  int rc = decode_frames_host(c, x3, len, w, p, wav, wav_cap, &before, &first_bad, &bad_status);
+  if (rc) return rc;
+  if (n_out) *n_out = before;
+  if (frames_ok) *frames_ok = first_bad;
+  return walk_result(F, first_bad, bad_status, w.terminal, frame_errors);
 }
 
 // single bare payload (decoder::decode_frame): wrap it in a frame header so that the one decode
@@ -1400,3 +1441,5 @@ extern "C" int x3_x3a_decode(x3_ctx* c, const uint8_t* x3a, uint64_t len, int16_
   const uint64_t start = 8 + hsize;
   return decode_stream_impl(c, x3a + start, len - start, 8, &p, wav, wav_cap, n_out, frames_ok, frame_errors);
 }
+
+#include "x3_file_pipeline.h"

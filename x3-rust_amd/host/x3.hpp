@@ -412,4 +412,21 @@ inline X3Error x3a_to_wav(Context& ctx, const uint8_t* x3a, size_t len, int16_t*
   return static_cast<X3Error>(rc);
 }
 }  // namespace archive
+
+// the file level, under the reference's module names (encodefile.rs:48-77, decodefile.rs:189-227): what
+// src/bin/x3.rs:79-80 calls.  Streamed through the GPU in chunks (x3hip.h).
+namespace encodefile {
+inline X3Error wav_to_x3a(Context& ctx, const char* wav_filename, const char* x3a_filename, bool print_statistics = true) {
+  uint64_t stats[6] = {0, 0, 0, 0, 0, 0};
+  const int rc = x3_wav_to_x3a(ctx.raw(), wav_filename, x3a_filename, stats);
+  if (rc == X3_OK && print_statistics) encoder::detail::print_stats(stats);
+  return static_cast<X3Error>(rc);
+}
+}  // namespace encodefile
+namespace decodefile {
+inline X3Error x3a_to_wav(Context& ctx, const char* x3a_filename, const char* wav_filename, uint64_t* samples = nullptr,
+                          uint64_t* frame_errors = nullptr) {
+  return static_cast<X3Error>(x3_x3a_to_wav(ctx.raw(), x3a_filename, wav_filename, samples, frame_errors));
+}
+}  // namespace decodefile
 }  // namespace x3

@@ -62,6 +62,9 @@ pub mod ffi {
                              out_len: *mut u64, stats: *mut u64) -> c_int;
         pub fn x3_x3a_decode(ctx: *mut x3_ctx, x3a: *const u8, len: u64, wav: *mut i16, wav_cap: u64, n_out: *mut u64,
                              sample_rate: *mut u32, frames_ok: *mut u64, frame_errors: *mut u64) -> c_int;
+        pub fn x3_wav_to_x3a(ctx: *mut x3_ctx, wav_path: *const c_char, x3a_path: *const c_char, stats: *mut u64) -> c_int;
+        pub fn x3_x3a_to_wav(ctx: *mut x3_ctx, x3a_path: *const c_char, wav_path: *const c_char, n_samples: *mut u64,
+                             frame_errors: *mut u64) -> c_int;
     }
 }
 
@@ -336,5 +339,38 @@ pub mod archive {
                                &mut n, &mut rate, &mut ok, &mut bad)
         })?;
         Ok((n as usize, rate, bad as usize))
+    }
+}
+
+/// src/encodefile.rs:48-77 on files, streamed through the GPU in chunks (same name, same arguments plus
+/// the device handle).
+pub mod encodefile {
+    use super::{error::{self, X3Error}, ffi, Gpu};
+    use std::{ffi::CString, path::Path};
+
+    pub fn wav_to_x3a<P: AsRef<Path>>(gpu: &Gpu, wav_filename: P, x3a_filename: P) -> Result<(), X3Error> {
+        let a = CString::new(wav_filename.as_ref().to_str().ok_or(X3Error::Io)?).map_err(|_| X3Error::Io)?;
+        let b = CString::new(x3a_filename.as_ref().to_str().ok_or(X3Error::Io)?).map_err(|_| X3Error::Io)?;
+        let mut stats = [0u64; 6];
+        error::check(unsafe { ffi::x3_wav_to_x3a(gpu.raw(), a.as_ptr(), b.as_ptr(), stats.as_mut_ptr()) })?;
+        // the block `encoder::encode` prints under `std` (src/encoder.rs:96-108)
+        let t = stats.iter().sum::<u64>() as f32;
+        let pc = |k: usize| (stats[k] as f32 / t) * 100.0;
+        println!("\nStatistics:\n  Rice-0: {:.4}%\n  Rice-1: {:.4}%\n  Rice-2: {:.4}%\n  Rice-3: {:.4}%\n  BFP: {:.4}%\n  Pass-through {:.4}%\n",
+                 pc(0), pc(1), pc(2), pc(3), pc(4), pc(5));
+        Ok(())
+    }
+}
+
+/// src/decodefile.rs:189-227 on files.
+pub mod decodefile {
+    use super::{error::{self, X3Error}, ffi, Gpu};
+    use std::{ffi::CString, path::Path};
+
+    pub fn x3a_to_wav<P: AsRef<Path>>(gpu: &Gpu, x3a_filename: P, wav_filename: P) -> Result<(), X3Error> {
+        let a = CString::new(x3a_filename.as_ref().to_str().ok_or(X3Error::Io)?).map_err(|_| X3Error::Io)?;
+        let b = CString::new(wav_filename.as_ref().to_str().ok_or(X3Error::Io)?).map_err(|_| X3Error::Io)?;
+        let (mut n, mut bad) = (0u64, 0u64);
+        error::check(unsafe { ffi::x3_x3a_to_wav(gpu.raw(), a.as_ptr(), b.as_ptr(), &mut n, &mut bad) })
     }
 }

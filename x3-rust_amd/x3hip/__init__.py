@@ -36,6 +36,7 @@ SYMBOLS = [
     "x3_encode", "x3_encode_frame", "x3_write_frame_header", "x3_encode_batch",
     "x3_read_frame_header", "x3_decode_frame", "x3_decode_stream",
     "x3_archive_header_write", "x3_archive_header_read", "x3_x3a_encode", "x3_x3a_decode",
+    "x3_wav_to_x3a", "x3_x3a_to_wav",
     "x3_encode_dev", "x3_encode_result", "x3_decode_dev", "x3_decode_result", "x3_index_dev", "x3_decode_stream_dev",
     "x3_synth", "x3_synth_dev", "x3_dev_alloc", "x3_dev_free", "x3_dev_upload", "x3_dev_download",
 ]
@@ -141,6 +142,8 @@ def lib():
     L.x3_archive_header_read.argtypes = [vp, u64, C.POINTER(u32), PP, C.POINTER(C.c_uint8), C.POINTER(u64)]
     L.x3_x3a_encode.argtypes = [vp, vp, u64, u32, vp, u64, C.POINTER(u64), vp]
     L.x3_x3a_decode.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64), C.POINTER(u32), C.POINTER(u64), C.POINTER(u64)]
+    L.x3_wav_to_x3a.argtypes = [vp, C.c_char_p, C.c_char_p, vp]
+    L.x3_x3a_to_wav.argtypes = [vp, C.c_char_p, C.c_char_p, C.POINTER(u64), C.POINTER(u64)]
     L.x3_encode_dev.argtypes = [vp, vp, C.POINTER(Batch), PP, vp, u64, u64, vp]
     L.x3_encode_result.argtypes = [vp, C.POINTER(u64), vp]
     L.x3_decode_dev.argtypes = [vp, vp, u64, vp, u64, C.POINTER(Batch), vp, PP, vp, u64, vp]
@@ -327,6 +330,19 @@ class Context:
         rc = lib().x3_x3a_decode(self._h, x3a.ctypes.data, x3a.size, wav.ctypes.data, wav_cap, C.byref(n),
                                  C.byref(rate), C.byref(fok), C.byref(ferr))
         return rc, wav[: n.value].copy(), rate.value, fok.value, ferr.value
+
+
+    def wav_to_x3a(self, wav_path, x3a_path):
+        """encodefile::wav_to_x3a on files (streamed through the GPU) -> (rc, stats[6])"""
+        stats = np.zeros(6, dtype=np.uint64)
+        rc = lib().x3_wav_to_x3a(self._h, os.fsencode(wav_path), os.fsencode(x3a_path), stats.ctypes.data)
+        return rc, stats
+
+    def x3a_to_wav(self, x3a_path, wav_path):
+        """decodefile::x3a_to_wav on files -> (rc, samples written, frame_errors)"""
+        n, ferr = C.c_uint64(0), C.c_uint64(0)
+        rc = lib().x3_x3a_to_wav(self._h, os.fsencode(x3a_path), os.fsencode(wav_path), C.byref(n), C.byref(ferr))
+        return rc, n.value, ferr.value
 
     def crc16(self, data):
         b = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8)) if not isinstance(data, np.ndarray) \
