@@ -215,18 +215,37 @@ def main():
     # internal staging; reported beside the headline, never as `value`
     host_api = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        m2 = min(50_000_000, n)
-        hwav = wav[:m2].cpu().numpy()
-        t0 = time.perf_counter()
-        rc, hout, _ = ctx.encode(hwav, p)
-        t1 = time.perf_counter()
-        r = ctx.decode_stream(hout, p, wav_cap=m2)
-        t2 = time.perf_counter()
-        assert rc == 0 and r[0] == 0 and np.array_equal(r[1], hwav)
-        host_api = {"samples": m2, "encode_ms": round((t1 - t0) * 1e3, 2), "decode_ms": round((t2 - t1) * 1e3, 2),
-                    "msamples_s": round(m2 / (t2 - t0) / 1e6, 1),
-                    "note": "x3_encode + x3_decode_stream on host buffers (H2D/D2H, allocation and the host-side "
-                            "frame walk included)"}
+        # caller-owned pageable buffers, allocated and touched beforehand (a caller that streams audio has
+        # them already); first call = cold (device scratch is allocated), second = steady state
+        import ctypes as C
+        L = x3hip.lib()
+        hwav = wav.cpu().numpy()
+        hcap = L.x3_encode_bound(n, C.byref(p))
+        hout = np.zeros(hcap, dtype=np.uint8); hout[::4096] = 1
+        hback = np.zeros(n, dtype=np.int16); hback[::2048] = 1
+        hpos, hn, hok, herr = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        hstats = np.zeros(6, dtype=np.uint64)
+        times = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            rc = L.x3_encode(ctx._h, hwav.ctypes.data, n, 1, C.byref(p), hout.ctypes.data, hcap, 0, C.byref(hpos),
+                             hstats.ctypes.data)
+            t1 = time.perf_counter()
+            rc2 = L.x3_decode_stream(ctx._h, hout.ctypes.data, hpos.value, C.byref(p), hback.ctypes.data, n, C.byref(hn),
+                                     C.byref(hok), C.byref(herr))
+            t2 = time.perf_counter()
+            assert rc == 0 and rc2 == 0 and hn.value == n, (rc, rc2, hn.value)
+            times.append((t1 - t0, t2 - t1))
+        assert np.array_equal(hback, hwav)
+        te, td = times[-1]
+        host_api = {"samples": n, "encode_ms": round(te * 1e3, 2), "decode_ms": round(td * 1e3, 2),
+                    "encode_msamples_s": round(n / te / 1e6, 1), "decode_msamples_s": round(n / td / 1e6, 1),
+                    "msamples_s": round(n / (te + td) / 1e6, 1),
+                    "cold_call_ms": [round(times[0][0] * 1e3, 2), round(times[0][1] * 1e3, 2)],
+                    "pcie_gb_s": round((2 * n + hpos.value) / te / 1e9, 1),
+                    "note": "x3_encode + x3_decode_stream on caller-owned pageable host buffers: H2D, kernels, D2H "
+                            "and the host-side frame walk, second call (the first also allocates device scratch)"}
+        del hwav, hout, hback
 
     if rank == 0:
         total_samples = n * world

@@ -206,8 +206,8 @@ int x3_x3a_decode(x3_ctx* ctx, const uint8_t* x3a, uint64_t len, int16_t* wav, u
  * an output .wav that cannot be created: X3_ERR_HOUND (`WavWriter::create(..)?`).
  * x3_x3a_to_wav leaves, like the reference's dropped WavWriter, a valid WAV of the samples in front of the
  * frame that ended the walk, also when it returns an error.
- * Tuning (environment): X3HIP_FILE_CHUNK_FRAMES (default 3200 frames = 64 MB of samples),
- * X3HIP_FILE_WORKERS (default 3). */
+ * Tuning (environment): X3HIP_FILE_CHUNK_FRAMES (default 800 frames = 16 MB of samples),
+ * X3HIP_FILE_WORKERS (default 4). */
 int x3_wav_to_x3a(x3_ctx* ctx, const char* wav_path, const char* x3a_path, uint64_t stats[6]);
 int x3_x3a_to_wav(x3_ctx* ctx, const char* x3a_path, const char* wav_path, uint64_t* n_samples,
                   uint64_t* frame_errors);

@@ -52,7 +52,9 @@ def test_archive_header_errors_match_oracle():
 
 
 @pytest.mark.gpu
-def test_x3a_roundtrip_matches_oracle():
+@pytest.mark.parametrize("host_walk", ["1", "0"])
+def test_x3a_roundtrip_matches_oracle(host_walk, monkeypatch):
+    monkeypatch.setenv("X3HIP_HOST_WALK", host_walk)  # the frame walk on the host / on the GPU (x3_index_kernels.h)
     ctx = x3hip.Context(0)
     try:
         for kind, n, rate in ((2, 123457, 192000), (4, 10000, 44100), (1, 25001, 8000), (0, 1, 96000)):

@@ -89,5 +89,33 @@ int main(int argc, char** argv) {
       std::printf("c) chunked 16 MiB staging H2D, %2d threads  %7.2f GB/s\n", thr, gbs(t1 - t0));
     }
   }
+  {  // d) is hipMemcpyAsync on pageable memory asynchronous to the host, and do H2D and D2H overlap?
+    hipStream_t s2; CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    void* dev2; CK(hipMalloc(&dev2, n));
+    for (int rep = 0; rep < 2; ++rep) {
+      double t0 = now(); CK(hipMemcpyAsync(dev, host, n, hipMemcpyHostToDevice, s)); double t1 = now();
+      CK(hipStreamSynchronize(s)); double t2 = now();
+      std::printf("d) pageable H2D async: call returns after %7.2f ms, done after %7.2f ms\n", (t1 - t0) * 1e3, (t2 - t0) * 1e3);
+      t0 = now(); CK(hipMemcpyAsync(back, dev2, n, hipMemcpyDeviceToHost, s2)); t1 = now();
+      CK(hipStreamSynchronize(s2)); t2 = now();
+      std::printf("d) pageable D2H async: call returns after %7.2f ms, done after %7.2f ms\n", (t1 - t0) * 1e3, (t2 - t0) * 1e3);
+      t0 = now();
+      CK(hipMemcpyAsync(dev, host, n, hipMemcpyHostToDevice, s)); t1 = now();
+      CK(hipMemcpyAsync(back, dev2, n, hipMemcpyDeviceToHost, s2)); t2 = now();
+      CK(hipStreamSynchronize(s)); CK(hipStreamSynchronize(s2)); double t3 = now();
+      std::printf("d) pageable H2D + D2H on two streams, one thread: issued after %7.2f / %7.2f ms, both done after %7.2f ms (%.1f GB/s each way)\n",
+                  (t1 - t0) * 1e3, (t2 - t0) * 1e3, (t3 - t0) * 1e3, gbs(t3 - t0));
+      t0 = now();
+      std::thread th([&] { (void)hipMemcpy(back, dev2, n, hipMemcpyDeviceToHost); });
+      CK(hipMemcpy(dev, host, n, hipMemcpyHostToDevice));
+      th.join(); t3 = now();
+      std::printf("d) pageable H2D + D2H from two threads: both done after %7.2f ms (%.1f GB/s each way)\n", (t3 - t0) * 1e3, gbs(t3 - t0));
+      t0 = now();
+      CK(hipMemcpyAsync(dev, pin, n, hipMemcpyHostToDevice, s));
+      CK(hipMemcpyAsync(pin, dev2, n, hipMemcpyDeviceToHost, s2));   // (overwrites pin while it is read: bandwidth only)
+      CK(hipStreamSynchronize(s)); CK(hipStreamSynchronize(s2)); t3 = now();
+      std::printf("d) pinned H2D + D2H on two streams: both done after %7.2f ms (%.1f GB/s each way)\n", (t3 - t0) * 1e3, gbs(t3 - t0));
+    }
+  }
   return 0;
 }

@@ -907,7 +907,7 @@ extern "C" int x3_decode_result(x3_ctx* c, uint64_t* first_bad, int* first_bad_s
 // ------------------------------------------------------------------------------------------------
 // GPU-side frame index of a device-resident stream (x3_index_kernels.h)
 // ------------------------------------------------------------------------------------------------
-static int index_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t len, uint32_t bl0, uint64_t wav_cap,
+static int index_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t len, uint64_t phantom, uint32_t bl0, uint64_t wav_cap,
                           uint64_t max_frames, uint64_t* d_frame_offsets, uint64_t* d_wav_offsets,
                           X3IndexSummary* result) {
   if (reinterpret_cast<uintptr_t>(d_x3) & 3u) return X3_ERR_BAD_ARG;
@@ -924,7 +924,7 @@ static int index_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t len, uint32_t
   // pass 1: how many candidates (the buffers are sized from the answer)
   unsigned int n_cand = 0;
   if (grid) {
-    hipLaunchKernelGGL(x3_index_candidates_kernel, dim3(grid), dim3(256), 0, c->stream, xw, len, bl0,
+    hipLaunchKernelGGL(x3_index_candidates_kernel, dim3(grid), dim3(256), 0, c->stream, xw, len, len + phantom, bl0,
                        (X3Cand*)nullptr, 0u, d_count);
     HIPCHK(c, hipMemcpyAsync(&n_cand, d_count, sizeof n_cand, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -950,8 +950,8 @@ static int index_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t len, uint32_t
     uint32_t* L = (uint32_t*)c->idx_L.p;
     HIPCHK(c, hipMemsetAsync(d_count, 0, sizeof(unsigned int), c->stream));
     HIPCHK(c, hipMemsetAsync(keys, 0, (size_t)tsize * sizeof(unsigned long long), c->stream));
-    hipLaunchKernelGGL(x3_index_candidates_kernel, dim3(grid), dim3(256), 0, c->stream, xw, len, bl0, cand, n_cand,
-                       d_count);
+    hipLaunchKernelGGL(x3_index_candidates_kernel, dim3(grid), dim3(256), 0, c->stream, xw, len, len + phantom, bl0,
+                       cand, n_cand, d_count);
     const unsigned cg = (n_cand + 255) / 256;
     hipLaunchKernelGGL(x3_index_hash_insert_kernel, dim3(cg), dim3(256), 0, c->stream, (const X3Cand*)cand, n_cand,
                        keys, vals, tsize - 1);
@@ -984,11 +984,11 @@ static int index_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t len, uint32_t
                          n_chain, (unsigned long long)wav_cap, (unsigned long long*)d_frame_offsets,
                          (unsigned long long*)d_wav_offsets, d_sum);
     }
-    hipLaunchKernelGGL(x3_index_finalize_kernel, dim3(1), dim3(64), 0, c->stream, xw, len, bl0, (const X3Cand*)cand,
-                       start, n_chain, (const unsigned long long*)d_wav_offsets, d_sum);
+    hipLaunchKernelGGL(x3_index_finalize_kernel, dim3(1), dim3(64), 0, c->stream, xw, len, len + phantom, bl0,
+                       (const X3Cand*)cand, start, n_chain, (const unsigned long long*)d_wav_offsets, d_sum);
   } else {
-    hipLaunchKernelGGL(x3_index_finalize_kernel, dim3(1), dim3(64), 0, c->stream, xw, len, bl0, (const X3Cand*)nullptr,
-                       X3I_NONE, 0ull, (const unsigned long long*)nullptr, d_sum);
+    hipLaunchKernelGGL(x3_index_finalize_kernel, dim3(1), dim3(64), 0, c->stream, xw, len, len + phantom, bl0,
+                       (const X3Cand*)nullptr, X3I_NONE, 0ull, (const unsigned long long*)nullptr, d_sum);
   }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(result, d_sum, sizeof *result, hipMemcpyDeviceToHost, c->stream));
@@ -1002,13 +1002,17 @@ extern "C" int x3_index_dev(x3_ctx* c, const uint8_t* d_x3, uint64_t len, uint64
   if (!c || (!d_x3 && len) || !d_frame_offsets || !d_wav_offsets) return X3_ERR_BAD_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   X3IndexSummary r;
-  int rc = index_dev_impl(c, d_x3, len, 0, ~0ull, max_frames, d_frame_offsets, d_wav_offsets, &r);
+  int rc = index_dev_impl(c, d_x3, len, 0, 0, ~0ull, max_frames, d_frame_offsets, d_wav_offsets, &r);
   if (rc) return rc;
   if (n_frames) *n_frames = r.n_frames;
   if (n_samples) *n_samples = r.n_samples;
   if (terminal) *terminal = r.terminal;
   return X3_OK;
 }
+
+static int decode_stream_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t len, uint64_t phantom, const x3_params* p,
+                                  int16_t* d_wav, uint64_t wav_cap, DevBuf* own_out, uint64_t* n_out,
+                                  uint64_t* frames_ok, uint64_t* frame_errors);
 
 extern "C" int x3_decode_stream_dev(x3_ctx* c, const uint8_t* d_x3, uint64_t len, const x3_params* p, int16_t* d_wav,
                                     uint64_t wav_cap, uint64_t* n_out, uint64_t* frames_ok, uint64_t* frame_errors) {
@@ -1017,6 +1021,14 @@ extern "C" int x3_decode_stream_dev(x3_ctx* c, const uint8_t* d_x3, uint64_t len
   if (frames_ok) *frames_ok = 0;
   if (frame_errors) *frame_errors = 0;
   HIPCHK(c, hipSetDevice(c->device));
+  return decode_stream_dev_impl(c, d_x3, len, 0, p, d_wav, wav_cap, nullptr, n_out, frames_ok, frame_errors);
+}
+
+// the walk on the GPU (x3_index_kernels.h), then one decode launch; `phantom` as in walk_host.  own_out: decode
+// into this scratch buffer, sized once the index knows the sample count, instead of d_wav.
+static int decode_stream_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t len, uint64_t phantom, const x3_params* p,
+                                  int16_t* d_wav, uint64_t wav_cap, DevBuf* own_out, uint64_t* n_out,
+                                  uint64_t* frames_ok, uint64_t* frame_errors) {
   // every frame is at least 22 bytes; index into internal buffers sized for the real count
   const uint64_t max_frames = len / 22 + 1;
   int rc;
@@ -1027,7 +1039,7 @@ extern "C" int x3_decode_stream_dev(x3_ctx* c, const uint8_t* d_x3, uint64_t len
   for (;;) {
     if ((rc = ensure(c, c->frame_off, (cap_frames + 1) * sizeof(uint64_t)))) return rc;
     if ((rc = ensure(c, c->wav_off, cap_frames * sizeof(uint64_t)))) return rc;
-    rc = index_dev_impl(c, d_x3, len, p->block_len == 0 ? 1u : 0u, wav_cap, cap_frames, (uint64_t*)c->frame_off.p,
+    rc = index_dev_impl(c, d_x3, len, phantom, p->block_len == 0 ? 1u : 0u, wav_cap, cap_frames, (uint64_t*)c->frame_off.p,
                         (uint64_t*)c->wav_off.p, &r);
     if (rc == X3_ERR_BAD_ARG && cap_frames < max_frames) { cap_frames = max_frames; continue; }
     break;
@@ -1038,6 +1050,11 @@ extern "C" int x3_decode_stream_dev(x3_ctx* c, const uint8_t* d_x3, uint64_t len
   if (F == 0) return terminal;
   x3_params pp = *p;
   if (pp.block_len == 0) pp.block_len = 1;  // frames that need block_len are BAD_ARG frames of the index
+  if (own_out) {
+    if ((rc = ensure(c, *own_out, (r.n_samples + 65536) * sizeof(int16_t)))) return rc;
+    d_wav = (int16_t*)own_out->p;
+    wav_cap = std::min<uint64_t>(wav_cap, r.n_samples + 65535);
+  }
   if ((rc = decode_dev_impl(c, d_x3, len, (const uint64_t*)c->frame_off.p, F, nullptr, (const uint64_t*)c->wav_off.p,
                             &pp, d_wav, wav_cap, nullptr)))
     return rc;
@@ -1163,6 +1180,23 @@ static int decode_stream_impl(x3_ctx* c, const uint8_t* x3, uint64_t len, uint64
   if (frames_ok) *frames_ok = 0;
   if (frame_errors) *frame_errors = 0;
   HIPCHK(c, hipSetDevice(c->device));
+  // Long streams: the header chain is one dependent cache miss per frame on the host (10 ms for the 69 120
+  // frames of config 3), and a few launches on the GPU once the bytes are there anyway.  Short ones: the
+  // other way round.  X3HIP_HOST_WALK=0/1 forces one or the other (tests run both).
+  bool gpu_walk = len >= (4u << 20);
+  if (const char* e = std::getenv("X3HIP_HOST_WALK")) gpu_walk = e[0] == '0';
+  if (gpu_walk && len > 0) {
+    int rc = ensure(c, c->in, len + 16);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->in.p, x3, len, hipMemcpyHostToDevice, c->stream));
+    uint64_t before = 0;
+    rc = decode_stream_dev_impl(c, (const uint8_t*)c->in.p, len, phantom, p, nullptr, wav_cap, &c->out, &before,
+                                frames_ok, frame_errors);
+    if (before) HIPCHK(c, hipMemcpyAsync(wav, c->out.p, before * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n_out) *n_out = before;
+    return rc;
+  }
   HostWalk w;
   walk_host(x3, len, len, len + phantom, p, wav_cap, ~0ull, &w);
   const uint64_t F = w.offs.size();

@@ -29,6 +29,7 @@ struct X3Geom {
 
 // status codes used on the device (values of enum x3_status in include/x3hip.h)
 #define X3D_OK 0
+#define X3D_IO 1   // a read past the real end of the data (X3Error::Io)
 #define X3D_OUT_OF_BOUNDS_INVERSE 5
 #define X3D_MORE_THAN_ONE_CHANNEL 6
 #define X3D_FRAME_LENGTH 10

@@ -3,7 +3,7 @@
 //
 // The reference reads the whole WAV through an iterator and pushes the frames through a BufWriter one
 // byte at a time; its README lists "allocates everything up front" as a to-do.  Here a file is cut into
-// chunks of whole frames (64 MB of samples by default) that move through a small pool of workers, each
+// chunks of whole frames (16 MB of samples by default) that move through a small pool of workers, each
 // with its own context (stream + device scratch) and its own pinned staging buffers:
 //
 //   wav -> x3a : pread chunk i into pinned memory | H2D, encode, D2H (x3_encode's path) | pwrite at the
@@ -33,7 +33,7 @@ struct FilePipeCfg {
   int workers;
 };
 static FilePipeCfg file_pipe_cfg() {
-  FilePipeCfg cfg{3200, 3};
+  FilePipeCfg cfg{800, 4};  // 16 MB of samples per chunk; measured best on tmpfs (tools/file_bench.py)
   if (const char* e = std::getenv("X3HIP_FILE_CHUNK_FRAMES")) cfg.chunk_frames = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
   if (const char* e = std::getenv("X3HIP_FILE_WORKERS")) cfg.workers = std::max(1, std::min(16, std::atoi(e)));
   return cfg;

@@ -23,6 +23,7 @@
 #define X3I_LAST_BAD 1u // pushed, then the walk stops with BAD_ARG (samples == 0, payload < 2 bytes, ...)
 #define X3I_QUIET 2u    // header fine, payload runs past the end of the data: quiet stop, not a frame
 #define X3I_PLEN 3u     // header fine, payload longer than X3_READ_BUFFER_SIZE: hard error, not a frame
+#define X3I_IO 4u       // header fine, payload inside the bytes the reader believes in but past the real end: Io
 #define X3I_NONE 0xFFFFFFFFu
 #define X3I_READ_BUFFER 24576u
 
@@ -64,8 +65,11 @@ __device__ __forceinline__ int32_t x3i_read_header(const uint32_t* __restrict__ 
 }
 
 // what the walk does with a VALID header at `off` (decodefile.rs:114-121 and the decoder's preconditions)
-__device__ __forceinline__ uint32_t x3i_kind(uint64_t len, uint64_t off, uint32_t plen, uint32_t samples, uint32_t bl0) {
-  if (len - off - 20 < plen) return X3I_QUIET;
+// `believed` >= len: what the reader thinks the stream holds (X3aReader::open's 8 phantom bytes, decodefile.rs:62-66)
+__device__ __forceinline__ uint32_t x3i_kind(uint64_t len, uint64_t believed, uint64_t off, uint32_t plen,
+                                             uint32_t samples, uint32_t bl0) {
+  if (believed - off - 20 < plen) return X3I_QUIET;
+  if (len - off - 20 < plen) return X3I_IO;
   if (plen > X3I_READ_BUFFER) return X3I_PLEN;
   if (samples == 0 || plen < 2 || (bl0 && samples > 1)) return X3I_LAST_BAD;
   return X3I_CONT;
@@ -73,8 +77,8 @@ __device__ __forceinline__ uint32_t x3i_kind(uint64_t len, uint64_t off, uint32_
 
 // 1. candidates: thread t looks at the 8 even offsets of 16-byte chunk t.  cand == nullptr: count only.
 __global__ void __launch_bounds__(256)
-x3_index_candidates_kernel(const uint32_t* __restrict__ xw, uint64_t len, uint32_t bl0, X3Cand* __restrict__ cand,
-                           uint32_t cap, unsigned int* __restrict__ count) {
+x3_index_candidates_kernel(const uint32_t* __restrict__ xw, uint64_t len, uint64_t believed, uint32_t bl0,
+                           X3Cand* __restrict__ cand, uint32_t cap, unsigned int* __restrict__ count) {
   const uint64_t n_dw = (len + 3) >> 2;
   const uint64_t chunks = (len + 15) >> 4;
   for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < chunks; t += (uint64_t)gridDim.x * blockDim.x) {
@@ -92,7 +96,7 @@ x3_index_candidates_kernel(const uint32_t* __restrict__ xw, uint64_t len, uint32
       const unsigned int slot = atomicAdd(count, 1u);
       if (cand && slot < cap) {
         cand[slot].off = off;
-        cand[slot].plen_kind = plen | (x3i_kind(len, off, plen, samples, bl0) << 16);
+        cand[slot].plen_kind = plen | (x3i_kind(len, believed, off, plen, samples, bl0) << 16);
         cand[slot].samples = samples;
       }
     }
@@ -203,18 +207,20 @@ x3_index_emit_kernel(const X3Cand* __restrict__ cand, uint32_t n, uint32_t level
 }
 
 // 5. how the walk ends (one thread)
-__global__ void x3_index_finalize_kernel(const uint32_t* __restrict__ xw, uint64_t len, uint32_t bl0,
+__global__ void x3_index_finalize_kernel(const uint32_t* __restrict__ xw, uint64_t len, uint64_t believed, uint32_t bl0,
                                          const X3Cand* __restrict__ cand, uint32_t start, unsigned long long n_chain,
                                          const unsigned long long* __restrict__ wav_off, X3IndexSummary* __restrict__ sum) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const uint64_t n_dw = (len + 3) >> 2;
   auto ending_at = [&](uint64_t pos) -> int {  // the walk arrives at `pos` and finds no frame to push
-    if (len - pos <= 20) return X3D_OK;
+    if (believed - pos <= 20) return X3D_OK;
+    if (len - pos < 20) return X3D_IO;  // read_exact of a header the reader believes in
     uint32_t plen, samples;
     const int32_t st = x3i_read_header(xw, n_dw, pos, plen, samples);
     if (st != X3D_OK) return st;
-    const uint32_t kind = x3i_kind(len, pos, plen, samples, bl0);
+    const uint32_t kind = x3i_kind(len, believed, pos, plen, samples, bl0);
     if (kind == X3I_QUIET) return X3D_OK;
+    if (kind == X3I_IO) return X3D_IO;
     if (kind == X3I_PLEN) return X3D_FRAME_HEADER_INVALID_PAYLOAD_LEN;
     return X3D_BAD_ARG;  // unreachable: such a header is a candidate and would be part of the chain
   };
