@@ -846,7 +846,8 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
                        (dp.spf % 8u) == 0 && (g.fpc * (uint64_t)1 >= g.n_frames || (g.clip_stride % 8u) == 0);
     TimerScope ts(c, 1);
     if (split)
-      hipLaunchKernelGGL(x3_decode_split_kernel, dim3((unsigned)((F + 63) / 64)), dim3(128), 0, c->stream, d_x3, x3_len,
+      hipLaunchKernelGGL(x3_decode_split_kernel, dim3((unsigned)((F + 63) / 64)), dim3(128),
+                         std::getenv("X3HIP_DECODE_DYN_LDS") ? std::atoi(std::getenv("X3HIP_DECODE_DYN_LDS")) : 0, c->stream, d_x3, x3_len,
                          d_frame_offsets, F, g, dp, d_wav, wav_cap, d_status, (X3FrameMeta*)c->dec_meta.p);
     else if (fast)
       hipLaunchKernelGGL(x3_decode_fast_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, c->stream, d_x3, x3_len,

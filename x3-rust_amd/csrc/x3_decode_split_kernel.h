@@ -68,6 +68,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
 #ifdef X3_DBG_STAMPS
   unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long dbg_t = clock64();
+  const unsigned long long dbg_start = wall_clock64();
 #endif
 
   // ---- per-lane frame setup, done by both waves (same checks as the fast kernel)
@@ -419,6 +420,15 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     if (f < n_frames) status[f] = st;
   }
 #ifdef X3_DBG_STAMPS
+  dbg_acc[6] = dbg_start;          // constant-rate clock: which groups were resident together
+  dbg_acc[7] = wall_clock64();
+  {
+    uint32_t hw_id, xcc_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+    const unsigned long long where = ((unsigned long long)xcc_id << 32) | hw_id;
+    if (parser) dbg_acc[5] = where; else dbg_acc[6] = where;
+  }
   if (lane == 0 && blockIdx.x < 2048)
     for (int k = 0; k < 8; ++k) x3_dbg[(blockIdx.x * 2 + (parser ? 0 : 1)) * 8 + k] = dbg_acc[k];
 #endif
