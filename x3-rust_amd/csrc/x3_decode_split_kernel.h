@@ -148,13 +148,15 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       for (int k = 0; k < 8; ++k) park(c[k], v_next + 16u * k);
       v_next += 128;
     }
-    // window: w0 holds `s` unconsumed bits (its low s bits), then w1, w2; widx = ring index of w0
+    // window: w0 holds `s` unconsumed bits (its low s bits), then w1; widx = ring index of w0.  A pair of
+    // codewords is at most 32 bits, so one peek never reaches beyond w1; wn is the word behind w1, re-read from
+    // the ring after every consume (the read has a whole pair's time to arrive before the next shift needs it)
     const uint32_t skip = v_bits & 15u;
     const uint32_t a0 = skip & 3u;
     uint32_t widx = (skip >> 2) - (a0 == 0 ? 1u : 0u);  // a0 == 0: start with a fully consumed w0
     uint32_t s = (32u - 8u * a0) & 31u;
-    uint32_t w0 = row[widx & 31u], w1 = row[(widx + 1) & 31u], w2 = row[(widx + 2) & 31u];
-    uint32_t w3 = row[(widx + 3) & 31u];                // look-ahead word (re-read at every consume)
+    uint32_t w0 = row[widx & 31u], w1 = row[(widx + 1) & 31u];
+    uint32_t wn = row[(widx + 2) & 31u];
     // the ring is topped up every SECOND block with up to 6 chunks (96 bytes >= the 80 bytes two blocks can
     // consume: at most one word per pair).  Three of them are requested one service ahead -- most lanes need
     // one or two (0.53 bytes per sample), and a scattered 16-byte-per-lane load costs ~64 cycles of issue --
@@ -163,16 +165,16 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
 #pragma unroll
     for (int k = 0; k < (int)X3S_AHEAD; ++k) ld[k] = request(v_next + 16u * k);
     uint32_t v_req = v_next;
-    // consume n (<= 32) bits; the word shift is v_bfi with a VGPR mask (see x3_decode_fast_kernel)
-    auto consume = [&](uint32_t n) {
-      const int32_t s2 = (int32_t)s - (int32_t)n;
+    // consume -nn (<= 32) bits, given as the NEGATIVE count (that is what the codeword walk below has at hand);
+    // the word shift is v_bfi with a VGPR mask (see x3_decode_fast_kernel)
+    auto consume_neg = [&](uint32_t nn) {
+      const int32_t s2 = (int32_t)(s + nn);
       const uint32_t m = (uint32_t)(s2 >> 31);
       s = (uint32_t)s2 & 31u;
       w0 = x3_bfi(m, w1, w0);
-      w1 = x3_bfi(m, w2, w1);
-      w2 = x3_bfi(m, w3, w2);
+      w1 = x3_bfi(m, wn, w1);
       widx -= m;
-      w3 = row[(widx + 3u) & 31u];
+      wn = row[(widx + 2u) & 31u];
     };
     auto service = [&]() {
       const uint32_t used = wr_abs - widx;  // dwords from w0 on that the ring still needs
@@ -210,10 +212,10 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       // all of it as arithmetic on the 6 bits (no compares: selects on a stale VCC are slow on gfx950)
       const uint32_t ftype = hdr >> 4;
       const uint32_t zmask = (uint32_t)((int32_t)(15u - hdr) >> 31);     // all ones for Rice (hdr >= 16)
-      consume((cnt ? 0xFFFFFFFFu : 0u) & (6u - (zmask & 4u)));           // 6 header bits for BFP, 2 for Rice
+      consume_neg((cnt ? 0xFFFFFFFFu : 0u) & ((zmask & 4u) - 6u));       // 6 header bits for BFP, 2 for Rice
       const uint32_t width = x3_bfi(zmask, (1u << ftype) >> 1, (hdr & 15u) + 1u);  // Rice 1,2,4; BFP E
       const uint32_t lsh = (lsh_tab >> (8u * ftype)) & 0xFFu;            // 0, 0, k1, k2
-      const uint32_t rsh = 32u - width;
+      const uint32_t nwidth = 0u - width;
       // block buffer: five rows of 64 x 8 bytes (two pair dwords per lane per row), then the 64 header words
       uint32_t* const buf = xfer + (b & 1u) * (X3S_XROWS * 64u);
       buf[X3S_PAIRS * 64u + lane] = hdr;
@@ -226,14 +228,19 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
           uint32_t X[2];
 #pragma unroll
           for (uint32_t e = 0; e < 2; ++e) {
+            // a codeword = z zeros + `width` bits (z = 0 in BFP/literal blocks): n = z + width bits in all, and
+            // its field v = the top n bits of the peek (the zeros in front do not change the value).  With
+            // nn = -n, both "drop n bits" (alignbit by 32 - n) and "top n bits" (shift right by 32 - n) take
+            // nn as their shift count (the hardware uses its low five bits): 3 instructions per codeword.
             const uint32_t t = __builtin_amdgcn_alignbit(w0, w1, s);
             const uint32_t z1 = x3_ffbh(t) & zmask;
-            const uint32_t v1 = (t << (z1 & 31u)) >> rsh;
-            const uint32_t n1 = z1 + width;
-            const uint32_t t2 = t << (n1 & 31u);
+            const uint32_t nn1 = nwidth - z1;
+            const uint32_t t2 = __builtin_amdgcn_alignbit(t, 0u, nn1);   // t << n1
+            const uint32_t v1 = t >> (nn1 & 31u);
             const uint32_t z2 = x3_ffbh(t2) & zmask;
-            const uint32_t v2 = (t2 << (z2 & 31u)) >> rsh;
-            consume(n1 + z2 + width);
+            const uint32_t nn2 = nwidth - z2;
+            const uint32_t v2 = t2 >> (nn2 & 31u);
+            consume_neg(nn1 + nn2);
             X[e] = x3_pack_lo16((z1 << lsh) + v1, (z2 << lsh) + v2);
           }
           b2[(j >> 1) * 64u] = make_uint2(X[0], X[1]);
@@ -244,8 +251,9 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
         for (uint32_t j = 0; j < X3S_BL; ++j) {
           const uint32_t t = __builtin_amdgcn_alignbit(w0, w1, s);
           const uint32_t z = x3_ffbh(t) & zmask;
-          const uint32_t v = (t << (z & 31u)) >> rsh;
-          consume(j < cnt ? z + width : 0u);
+          const uint32_t nn = nwidth - z;
+          const uint32_t v = t >> (nn & 31u);
+          consume_neg(j < cnt ? nn : 0u);
           h[x3s_half_index(j, lane)] = (uint16_t)((z << lsh) + v);
         }
       }
