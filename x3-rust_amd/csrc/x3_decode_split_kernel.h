@@ -175,6 +175,9 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       w1 = x3_bfi(m, wn, w1);
       widx -= m;
       wn = row[(widx + 2u) & 31u];
+      // keep the read HERE: left to itself the scheduler sinks it to just in front of the next shift, where its
+      // whole LDS latency is waited for
+      __builtin_amdgcn_sched_barrier(0);
     };
     auto service = [&]() {
       const uint32_t used = wr_abs - widx;  // dwords from w0 on that the ring still needs
