@@ -56,7 +56,11 @@ __global__ void __launch_bounds__(128)
 x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uint64_t* __restrict__ frame_off,
                        uint64_t n_frames, X3Geom g, X3DevParams p, int16_t* __restrict__ wav, uint64_t wav_cap,
                        int32_t* __restrict__ status, X3FrameMeta* __restrict__ meta) {
-  __shared__ __attribute__((aligned(16))) uint32_t ring[64 * X3_DEC_RING_STRIDE];
+  // input ring, 32 dwords per lane in rows of exactly 128 bytes at 128-byte aligned addresses, stream word j in
+  // slot ~j & 31 (descending): the address of a word is then ONE v_and_or_b32 on a byte counter that a shift of
+  // the window decrements with one v_lshl_add_u32.  (Lanes are at different places in their rows, so the aligned
+  // rows do not line the reads up on one bank.)
+  __shared__ __attribute__((aligned(128))) uint32_t ring[64 * X3_DEC_RING_DW];
   __shared__ __attribute__((aligned(16))) uint32_t outs[64 * X3S_OUT_STRIDE];
   __shared__ __attribute__((aligned(16))) uint32_t xfer[2 * X3S_XROWS * 64];
   __shared__ unsigned long long s_wo[64];
@@ -110,8 +114,8 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
 
   if (parser) {
     // ================================================================= wave 0: parser
-    uint32_t* const row = ring + lane * X3_DEC_RING_STRIDE;
-    // input ring; words are parked BIG-ENDIAN
+    uint32_t* const row = ring + lane * X3_DEC_RING_DW;
+    // words are parked BIG-ENDIAN
     const uint32_t adj = (uint32_t)(reinterpret_cast<uintptr_t>(x3) & 15u);
     // offsets are relative to this lane's first 16-byte chunk (a frame is < 64 KB): a 64-bit pointer per lane,
     // 32-bit arithmetic on everything else, streams of any length
@@ -136,8 +140,9 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
           w[d] = r >= 4 ? w[d] : (r <= 0 ? 0u : (w[d] & ((1u << (8u * (uint32_t)r)) - 1u)));
         }
       }
-      *reinterpret_cast<uint4*>(row + (wr_abs & (X3_DEC_RING_DW - 1u))) =
-          make_uint4(x3_bswap32(w[0]), x3_bswap32(w[1]), x3_bswap32(w[2]), x3_bswap32(w[3]));
+      // words wr_abs .. wr_abs+3 -> slots ~wr_abs & 31 downwards = the aligned 16-byte block at slot ~(wr_abs+3) & 31
+      *reinterpret_cast<uint4*>(row + (~(wr_abs + 3u) & (X3_DEC_RING_DW - 1u))) =
+          make_uint4(x3_bswap32(w[3]), x3_bswap32(w[2]), x3_bswap32(w[1]), x3_bswap32(w[0]));
       wr_abs += 4;
     };
     {
@@ -153,10 +158,13 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     // the ring after every consume (the read has a whole pair's time to arrive before the next shift needs it)
     const uint32_t skip = v_bits & 15u;
     const uint32_t a0 = skip & 3u;
-    uint32_t widx = (skip >> 2) - (a0 == 0 ? 1u : 0u);  // a0 == 0: start with a fully consumed w0
+    const uint32_t widx0 = (skip >> 2) - (a0 == 0 ? 1u : 0u);  // a0 == 0: start with a fully consumed w0
     uint32_t s = (32u - 8u * a0) & 31u;
-    uint32_t w0 = row[widx & 31u], w1 = row[(widx + 1) & 31u];
-    uint32_t wn = row[(widx + 2) & 31u];
+    uint32_t w0 = row[~widx0 & 31u], w1 = row[~(widx0 + 1u) & 31u];
+    uint32_t wn = row[~(widx0 + 2u) & 31u];
+    // qb = 4 * ~(widx + 2): the byte offset of wn's slot before masking; widx itself is only needed by service()
+    uint32_t qb = 4u * ~(widx0 + 2u);
+    const uint32_t row_base = (uint32_t)(uintptr_t)row;  // LDS byte address of the row (low 7 bits zero)
     // the ring is topped up every SECOND block with up to 6 chunks (96 bytes >= the 80 bytes two blocks can
     // consume: at most one word per pair).  Three of them are requested one service ahead -- most lanes need
     // one or two (0.53 bytes per sample), and a scattered 16-byte-per-lane load costs ~64 cycles of issue --
@@ -167,19 +175,23 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     uint32_t v_req = v_next;
     // consume -nn (<= 32) bits, given as the NEGATIVE count (that is what the codeword walk below has at hand);
     // the word shift is v_bfi with a VGPR mask (see x3_decode_fast_kernel)
-    auto consume_neg = [&](uint32_t nn) {
-      const int32_t s2 = (int32_t)(s + nn);
+    auto consume_to = [&](int32_t s2) {  // s2 = s - bits consumed (>= -32)
       const uint32_t m = (uint32_t)(s2 >> 31);
       s = (uint32_t)s2 & 31u;
       w0 = x3_bfi(m, w1, w0);
       w1 = x3_bfi(m, wn, w1);
-      widx -= m;
-      wn = row[(widx + 2u) & 31u];
+      uint32_t addr;
+      asm("v_lshl_add_u32 %0, %2, 2, %0\n\t"                 // widx += 1 on a shift: qb -= 4
+          "v_and_or_b32 %1, %0, %3, %4"
+          : "+v"(qb), "=v"(addr) : "v"(m), "v"(124u), "v"(row_base));
+      wn = x3_lds_read_b32(addr);
       // keep the read HERE: left to itself the scheduler sinks it to just in front of the next shift, where its
       // whole LDS latency is waited for
       __builtin_amdgcn_sched_barrier(0);
     };
+    auto consume_neg = [&](uint32_t nn) { consume_to((int32_t)(s + nn)); };
     auto service = [&]() {
+      const uint32_t widx = ~((uint32_t)((int32_t)qb >> 2)) - 2u;
       const uint32_t used = wr_abs - widx;  // dwords from w0 on that the ring still needs
       const uint32_t fit = used >= X3_DEC_RING_DW ? 0u : (X3_DEC_RING_DW - used) >> 2;  // (widx may be -1)
 #pragma unroll
@@ -203,7 +215,9 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       for (int k = 0; k < (int)X3S_AHEAD; ++k) ld[k] = request(v_req + 16u * k);
     };
 
-    const uint32_t lsh_tab = (p.k[1] << 16) | (p.k[2] << 24);  // log2(level) by ftype
+    // log2(level) by ftype; 31 for BFP/literal blocks, where the zero run is not masked but shifted out of the
+    // 16 bits that are handed over
+    const uint32_t lsh_tab = 31u | (p.k[1] << 16) | (p.k[2] << 24);
     for (uint32_t b = 0; b < nblk_max; ++b) {
       const uint32_t cnt = remaining < X3S_BL ? remaining : X3S_BL;
       remaining -= cnt;
@@ -231,19 +245,26 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
           uint32_t X[2];
 #pragma unroll
           for (uint32_t e = 0; e < 2; ++e) {
-            // a codeword = z zeros + `width` bits (z = 0 in BFP/literal blocks): n = z + width bits in all, and
+            // a codeword = z zeros + `width` bits (z only counts in Rice blocks): n = z + width bits in all, and
             // its field v = the top n bits of the peek (the zeros in front do not change the value).  With
-            // nn = -n, both "drop n bits" (alignbit by 32 - n) and "top n bits" (shift right by 32 - n) take
-            // nn as their shift count (the hardware uses its low five bits): 3 instructions per codeword.
+            // nn = -n = z * zmask - width (one v_mad_i32_i24, zmask being -1 or 0), both "drop n bits"
+            // (alignbit by 32 - n) and "top n bits" (shift right by 32 - n) take nn as their shift count (the
+            // hardware uses its low five bits): 4 instructions per codeword.  One asm block, so that the
+            // compiler neither pads the dependent chain with s_nop nor reorders it.
             const uint32_t t = __builtin_amdgcn_alignbit(w0, w1, s);
-            const uint32_t z1 = x3_ffbh(t) & zmask;
-            const uint32_t nn1 = nwidth - z1;
-            const uint32_t t2 = __builtin_amdgcn_alignbit(t, 0u, nn1);   // t << n1
-            const uint32_t v1 = t >> (nn1 & 31u);
-            const uint32_t z2 = x3_ffbh(t2) & zmask;
-            const uint32_t nn2 = nwidth - z2;
-            const uint32_t v2 = t2 >> (nn2 & 31u);
-            consume_neg(nn1 + nn2);
+            uint32_t z1, z2, v1, v2, t2, nn1, nn2;
+            int32_t s2;
+            asm("v_ffbh_u32 %0, %8\n\t"
+                "v_mad_i32_i24 %4, %0, %9, %10\n\t"
+                "v_alignbit_b32 %6, %8, 0, %4\n\t"
+                "v_lshrrev_b32 %1, %4, %8\n\t"
+                "v_ffbh_u32 %2, %6\n\t"
+                "v_mad_i32_i24 %5, %2, %9, %10\n\t"
+                "v_lshrrev_b32 %3, %5, %6\n\t"
+                "v_add3_u32 %7, %11, %4, %5"
+                : "=&v"(z1), "=&v"(v1), "=&v"(z2), "=&v"(v2), "=&v"(nn1), "=&v"(nn2), "=&v"(t2), "=&v"(s2)
+                : "v"(t), "v"(zmask), "v"(nwidth), "v"(s));
+            consume_to(s2);
             X[e] = x3_pack_lo16((z1 << lsh) + v1, (z2 << lsh) + v2);
           }
           b2[(j >> 1) * 64u] = make_uint2(X[0], X[1]);

@@ -156,6 +156,22 @@ __device__ __forceinline__ uint32_t x3_bfi(uint32_t m, uint32_t a, uint32_t b) {
   asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
   return r;
 }
+// (a & b) | c
+__device__ __forceinline__ uint32_t x3_and_or(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// a * b + c on the signed low 24 bits of a and b (full rate)
+__device__ __forceinline__ uint32_t x3_mad_i24(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// one dword from an LDS byte address
+__device__ __forceinline__ uint32_t x3_lds_read_b32(uint32_t addr) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(addr);
+}
 // v_ffbh_u32 without __clz's clamp: -1 (not 32) for 0
 __device__ __forceinline__ uint32_t x3_ffbh(uint32_t a) {
   uint32_t r;
