@@ -215,9 +215,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       for (int k = 0; k < (int)X3S_AHEAD; ++k) ld[k] = request(v_req + 16u * k);
     };
 
-    // log2(level) by ftype; 31 for BFP/literal blocks, where the zero run is not masked but shifted out of the
-    // 16 bits that are handed over
-    const uint32_t lsh_tab = 31u | (p.k[1] << 16) | (p.k[2] << 24);
+    const uint32_t k_tab = (p.k[1] << 16) | (p.k[2] << 24);  // log2(level) by ftype
     for (uint32_t b = 0; b < nblk_max; ++b) {
       const uint32_t cnt = remaining < X3S_BL ? remaining : X3S_BL;
       remaining -= cnt;
@@ -231,7 +229,13 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       const uint32_t zmask = (uint32_t)((int32_t)(15u - hdr) >> 31);     // all ones for Rice (hdr >= 16)
       consume_neg((cnt ? 0xFFFFFFFFu : 0u) & ((zmask & 4u) - 6u));       // 6 header bits for BFP, 2 for Rice
       const uint32_t width = x3_bfi(zmask, (1u << ftype) >> 1, (hdr & 15u) + 1u);  // Rice 1,2,4; BFP E
-      const uint32_t lsh = (lsh_tab >> (8u * ftype)) & 0xFFu;            // 0, 0, k1, k2
+      const uint32_t kk = (k_tab >> (8u * ftype)) & 0xFFu;               // 0, 0, k1, k2
+      // what is handed over is the index into the reference's inverse table, i = (z << k) + r with r the k bits
+      // BEHIND the terminating one (decoder.rs:186 computes the same as r' + level * (n - 1) with the one
+      // included in r'), and the whole field in BFP/literal blocks: the last fw bits of the codeword, and a
+      // zero run shifted by 31 there, out of the 16 bits that go across
+      const uint32_t fw = x3_bfi(zmask, kk, width);
+      const uint32_t lsh = x3_bfi(zmask, kk, 31u);
       const uint32_t nwidth = 0u - width;
       // block buffer: five rows of 64 x 8 bytes (two pair dwords per lane per row), then the 64 header words
       uint32_t* const buf = xfer + (b & 1u) * (X3S_XROWS * 64u);
@@ -248,8 +252,8 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
             // a codeword = z zeros + `width` bits (z only counts in Rice blocks): n = z + width bits in all, and
             // its field v = the top n bits of the peek (the zeros in front do not change the value).  With
             // nn = -n = z * zmask - width (one v_mad_i32_i24, zmask being -1 or 0), both "drop n bits"
-            // (alignbit by 32 - n) and "top n bits" (shift right by 32 - n) take nn as their shift count (the
-            // hardware uses its low five bits): 4 instructions per codeword.  One asm block, so that the
+            // (alignbit by 32 - n) and "the fw bits that end n bits in" (v_bfe_u32 at 32 - n) take nn as their
+            // shift count (the hardware uses its low five bits): 4 instructions per codeword.  One asm block, so that the
             // compiler neither pads the dependent chain with s_nop nor reorders it.
             const uint32_t t = __builtin_amdgcn_alignbit(w0, w1, s);
             uint32_t z1, z2, v1, v2, t2, nn1, nn2;
@@ -257,13 +261,13 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
             asm("v_ffbh_u32 %0, %8\n\t"
                 "v_mad_i32_i24 %4, %0, %9, %10\n\t"
                 "v_alignbit_b32 %6, %8, 0, %4\n\t"
-                "v_lshrrev_b32 %1, %4, %8\n\t"
+                "v_bfe_u32 %1, %8, %4, %12\n\t"
                 "v_ffbh_u32 %2, %6\n\t"
                 "v_mad_i32_i24 %5, %2, %9, %10\n\t"
-                "v_lshrrev_b32 %3, %5, %6\n\t"
+                "v_bfe_u32 %3, %6, %5, %12\n\t"
                 "v_add3_u32 %7, %11, %4, %5"
                 : "=&v"(z1), "=&v"(v1), "=&v"(z2), "=&v"(v2), "=&v"(nn1), "=&v"(nn2), "=&v"(t2), "=&v"(s2)
-                : "v"(t), "v"(zmask), "v"(nwidth), "v"(s));
+                : "v"(t), "v"(zmask), "v"(nwidth), "v"(s), "v"(fw));
             consume_to(s2);
             X[e] = x3_pack_lo16((z1 << lsh) + v1, (z2 << lsh) + v2);
           }
@@ -276,7 +280,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
           const uint32_t t = __builtin_amdgcn_alignbit(w0, w1, s);
           const uint32_t z = x3_ffbh(t) & zmask;
           const uint32_t nn = nwidth - z;
-          const uint32_t v = t >> (nn & 31u);
+          const uint32_t v = (t >> (nn & 31u)) & ((1u << fw) - 1u);
           consume_neg(j < cnt ? nn : 0u);
           h[x3s_half_index(j, lane)] = (uint16_t)((z << lsh) + v);
         }
@@ -292,12 +296,10 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     s_wo[lane] = wo;
     s_ns[lane] = samples;
     bool alive = active;
-    uint32_t prevP = 0;  // the previous pair; its high half is the pending (even-index) sample
-    uint32_t LL = 0;     // (last, last)
+    uint32_t prevP = 0;  // the previous pair; its high half is the last sample so far (pending: even index)
     if (active) {
       const uint32_t first = ((uint32_t)x3[p0] << 8) | x3[p0 + 1];
       prevP = first << 16;
-      LL = first * 0x10001u;
       if (samples == 1u) o[0] = (int16_t)first;
     }
     // the usual group: 64 frames of the same size, one behind the other in wav
@@ -340,7 +342,6 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       X3_WAVE_LDS_ORDER();
     };
 
-    const uint32_t lsh_tab = (p.k[1] << 16) | (p.k[2] << 24);                                   // by ftype
     const uint32_t bound_tab = (p.inv_len[0] << 8) | (p.inv_len[1] << 16) | (p.inv_len[2] << 24);  // by ftype (< 256)
     for (uint32_t b = 0; b < nblk_max; ++b) {
       X3_STAMP(0);
@@ -358,15 +359,13 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       const uint32_t litmask = ~zmask & (uint32_t)((int32_t)(14u - (hdr & 15u)) >> 31);  // BFP with E == 16
       const uint32_t neg_thresh = ~zmask & (1u << (E - 1u));
       const uint32_t neg2 = (neg_thresh << 1) & ~litmask;
-      const uint32_t level = zmask & (1u << ((lsh_tab >> (8u * ftype)) & 0xFFu));
       const uint32_t bound = x3_bfi(zmask, (bound_tab >> (8u * ftype)) & 0xFFu, 0xFFFFFFFFu);
       if (cnt && alive && bfp && E <= 5u) {  // decoder.rs:209-216
         st = X3D_FRAME_DECODE_INVALID_BPF;
         alive = false;
       }
-      const uint32_t nlevel2 = ((0u - level) & 0xFFFFu) * 0x10001u;
-      const uint32_t nt2 = neg_thresh * 0x10001u;   // <= 0x8000 in each half
-      const uint32_t neg22 = neg2 * 0x10001u;       // <= 0x8000 in each half
+      const uint32_t tm12 = ((neg_thresh - 1u) & 0xFFFFu) * 0x10001u;  // thresh - 1 in each half
+      const uint32_t neg22 = (neg2 & 0xFFFFu) * 0x10001u;              // 2 * thresh = 2^E (0 for a literal block)
       uint32_t maxii2 = 0;
       uint32_t* const dst = orow + X3S_PAIRS * (b & (X3S_WBLK - 1u));
       X3_STAMP(2);
@@ -383,18 +382,17 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
 #pragma unroll
           for (uint32_t e = 0; e < 2; ++e) {
             const uint32_t X = e ? XX[r].y : XX[r].x;
-            // Rice: i = r + level*(n-1) (decoder.rs:186); inverse table = zigzag (x3.rs:200-204)
-            const uint32_t I = x3_pk_add_u16(X, nlevel2);
-            maxii2 = x3_pk_max_u16(maxii2, I);
-            const uint32_t R = x3_pk_lshr_b16_1(I) ^ x3_pk_sub_u16(0u, I & 0x00010001u);
-            // BFP: unsigned_to_i16 (decoder.rs:198-207): v - (v > thresh ? 2*thresh : 0), strict compare
-            const uint32_t M = x3_pk_ashr_i16_15(x3_pk_sub_u16(nt2, X));  // 0xFFFF where v > thresh
-            const uint32_t B = x3_pk_sub_u16(X, M & neg22);
+            // Rice: X = i, the index into the inverse table (decoder.rs:186), which is a zigzag (x3.rs:200-204)
+            maxii2 = x3_pk_max_u16(maxii2, X);
+            const uint32_t R = x3_pk_lshr_b16_1(X) ^ x3_pk_sub_u16(0u, X & 0x00010001u);
+            // BFP: unsigned_to_i16 (decoder.rs:198-207): v - (v > thresh ? 2*thresh : 0), strict compare.
+            // v < 2^E and thresh = 2^(E-1), so bit E of v + thresh - 1 says v > thresh.
+            const uint32_t B = x3_pk_sub_u16(X, x3_pk_add_u16(X, tm12) & neg22);
             const uint32_t D = x3_bfi(zmask, R, B);                        // (d1, d2)
-            const uint32_t Q = x3_pk_add_u16(D, D << 16);                  // (d1, d1 + d2)
-            uint32_t P = x3_pk_add_u16(Q, LL);                             // (last + d1, last + d1 + d2)
+            // (last + d1, last + d1 + d2), last = the high half of the previous pair: both halves of D plus last,
+            // then d1 once more onto the high half
+            uint32_t P = x3_pk_mad_u16_alo(D, 0x00010000u, x3_pk_add_u16_bhi(D, prevP));
             P = x3_bfi(litmask, X, P);                                     // literal: field = sample
-            LL = __builtin_amdgcn_perm(P, P, 0x07060706u);                 // (lb, lb)
             W[e] = __builtin_amdgcn_alignbit(P, prevP, 16);                // (pending sample, la)
             prevP = P;
           }
@@ -406,11 +404,11 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
         uint16_t* const oh = reinterpret_cast<uint16_t*>(orow);
         const uint32_t idx0 = 1u + X3S_BL * b - wbase;  // window-relative index of the block's first sample
         if (cnt) oh[idx0 - 1u] = (uint16_t)(prevP >> 16);
-        uint32_t last = LL & 0xFFFFu, maxii = 0;
+        uint32_t last = prevP >> 16, maxii = 0;
         for (uint32_t j = 0; j < X3S_BL; ++j) {
           if (j < cnt) {
             const uint32_t x = h[x3s_half_index(j, lane)];
-            const uint32_t ii = (x + (0u - level)) & 0xFFFFu;
+            const uint32_t ii = x;
             const uint32_t d_rice = (ii >> 1) ^ (0u - (ii & 1u));
             const uint32_t d_bfp = x - (x > neg_thresh ? neg2 : 0u);
             const uint32_t d = bfp ? d_bfp : d_rice;
@@ -420,7 +418,6 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
           }
         }
         maxii2 = maxii;
-        LL = last * 0x10001u;
         prevP = last << 16;
       }
       X3_STAMP(3);

@@ -146,6 +146,18 @@ __device__ __forceinline__ uint32_t x3_pk_ashr_i16_15(uint32_t a) {
   asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a));
   return r;
 }
+// (a.lo + b.hi, a.hi + b.hi): add the high half of b to both halves of a
+__device__ __forceinline__ uint32_t x3_pk_add_u16_bhi(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// (a.lo * k.lo + c.lo, a.lo * k.hi + c.hi): the low half of a times each half of k, plus c
+__device__ __forceinline__ uint32_t x3_pk_mad_u16_alo(uint32_t a, uint32_t k, uint32_t c) {
+  uint32_t r;
+  asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(k), "v"(c));
+  return r;
+}
 // (a & 0xFFFF) | (b << 16)
 __device__ __forceinline__ uint32_t x3_pack_lo16(uint32_t a, uint32_t b) {
   return __builtin_amdgcn_perm(b, a, 0x05040100u);
