@@ -9,8 +9,8 @@
 //
 //   wave 0, the PARSER: owns the input ring and the bit window.  Per block it reads the 6 header bits and
 //     walks the codewords: for every sample the zero run z and the field v behind it, two samples per
-//     32-bit peek.  It does not compute a single sample value; it hands over i = (z << lsh) + v (the index
-//     into the reference's inverse Rice table, or simply the field for BFP/literal blocks, where z = 0),
+//     32-bit peek.  It does not compute a single sample value; it hands over i = (z << k) + r (the index
+//     into the reference's inverse Rice table, or simply the field for BFP/literal blocks),
 //     two 16-bit values per dword, through a double-buffered LDS block buffer, and the header bits.
 //   wave 1, the VALUER: turns indices into differences (zigzag / unsigned_to_i16) and samples (running sum,
 //     in packed 16-bit arithmetic), checks the table bounds, stages the samples in LDS and flushes them to
