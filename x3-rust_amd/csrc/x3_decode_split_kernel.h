@@ -115,6 +115,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   if (parser) {
     // ================================================================= wave 0: parser
     uint32_t* const row = ring + lane * X3_DEC_RING_DW;
+    const uint32_t row_base = (uint32_t)(uintptr_t)row;  // LDS byte address of the row (low 7 bits zero)
     // words are parked BIG-ENDIAN
     const uint32_t adj = (uint32_t)(reinterpret_cast<uintptr_t>(x3) & 15u);
     // offsets are relative to this lane's first 16-byte chunk (a frame is < 64 KB): a 64-bit pointer per lane,
@@ -130,19 +131,22 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       const uint32_t a = v < v_last ? v : v_last;
       return *reinterpret_cast<const uint4*>(x3b + a);
     };
-    auto park = [&](uint4 c, uint32_t v) {
-      const int32_t left = (int32_t)(v_end - v);
+    // `near_end`: wave-uniform, some lane of the wave may be within the chunks of this service of the end of its
+    // payload (bytes behind the payload are parked as zeros, bitreader.rs:34-48)
+    auto park = [&](uint4 c, uint32_t v, bool near_end) {
       uint32_t w[4] = {c.x, c.y, c.z, c.w};
-      if (__any(left < 16)) {  // some lane is at (or past) the end of its payload
+      if (near_end) {
+        const int32_t left = (int32_t)(v_end - v);
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
           const int32_t r = left - 4 * d;
           w[d] = r >= 4 ? w[d] : (r <= 0 ? 0u : (w[d] & ((1u << (8u * (uint32_t)r)) - 1u)));
         }
       }
-      // words wr_abs .. wr_abs+3 -> slots ~wr_abs & 31 downwards = the aligned 16-byte block at slot ~(wr_abs+3) & 31
-      *reinterpret_cast<uint4*>(row + (~(wr_abs + 3u) & (X3_DEC_RING_DW - 1u))) =
-          make_uint4(x3_bswap32(w[3]), x3_bswap32(w[2]), x3_bswap32(w[1]), x3_bswap32(w[0]));
+      // words wr_abs .. wr_abs+3 -> slots ~wr_abs & 31 downwards = the aligned 16-byte block at slot ~(wr_abs+3) & 31:
+      // byte offset (-4 * wr_abs - 16) & 112 of the 128-byte aligned row
+      x3_lds_write_b128(x3_and_or(0u - 4u * wr_abs - 16u, 112u, row_base), x3_bswap32(w[3]), x3_bswap32(w[2]),
+                        x3_bswap32(w[1]), x3_bswap32(w[0]));
       wr_abs += 4;
     };
     {
@@ -150,7 +154,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
 #pragma unroll
       for (int k = 0; k < 8; ++k) c[k] = request(v_next + 16u * k);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) park(c[k], v_next + 16u * k);
+      for (int k = 0; k < 8; ++k) park(c[k], v_next + 16u * k, true);
       v_next += 128;
     }
     // window: w0 holds `s` unconsumed bits (its low s bits), then w1; widx = ring index of w0.  A pair of
@@ -164,7 +168,6 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     uint32_t wn = row[~(widx0 + 2u) & 31u];
     // qb = 4 * ~(widx + 2): the byte offset of wn's slot before masking; widx itself is only needed by service()
     uint32_t qb = 4u * ~(widx0 + 2u);
-    const uint32_t row_base = (uint32_t)(uintptr_t)row;  // LDS byte address of the row (low 7 bits zero)
     // the ring is topped up every SECOND block with up to 6 chunks (96 bytes >= the 80 bytes two blocks can
     // consume: at most one word per pair).  Three of them are requested one service ahead -- most lanes need
     // one or two (0.53 bytes per sample), and a scattered 16-byte-per-lane load costs ~64 cycles of issue --
@@ -194,11 +197,10 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       const uint32_t widx = ~((uint32_t)((int32_t)qb >> 2)) - 2u;
       const uint32_t used = wr_abs - widx;  // dwords from w0 on that the ring still needs
       const uint32_t fit = used >= X3_DEC_RING_DW ? 0u : (X3_DEC_RING_DW - used) >> 2;  // (widx may be -1)
+      const bool near_end = __any((int32_t)(v_end - v_req) < (int32_t)(16u * 3u * X3S_PERIOD));
 #pragma unroll
       for (uint32_t k = 0; k < X3S_AHEAD; ++k) {
-        if (__any(fit > k)) {
-          if (fit > k) park(ld[k], v_req + 16u * k);
-        }
+        if (fit > k) park(ld[k], v_req + 16u * k, near_end);
       }
       if (__any(fit > X3S_AHEAD)) {  // a lane went through more than that in two blocks (BFP / literal blocks)
         uint4 more[3u * X3S_PERIOD - X3S_AHEAD];
@@ -206,7 +208,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
         for (uint32_t k = 0; k < 3u * X3S_PERIOD - X3S_AHEAD; ++k) more[k] = request(v_req + 16u * (X3S_AHEAD + k));
 #pragma unroll
         for (uint32_t k = 0; k < 3u * X3S_PERIOD - X3S_AHEAD; ++k) {
-          if (fit > X3S_AHEAD + k) park(more[k], v_req + 16u * (X3S_AHEAD + k));
+          if (fit > X3S_AHEAD + k) park(more[k], v_req + 16u * (X3S_AHEAD + k), near_end);
         }
       }
       v_next += 16u * (fit > 3u * X3S_PERIOD ? 3u * X3S_PERIOD : fit);

@@ -184,6 +184,12 @@ __device__ __forceinline__ uint32_t x3_mad_i24(uint32_t a, uint32_t b, uint32_t 
 __device__ __forceinline__ uint32_t x3_lds_read_b32(uint32_t addr) {
   return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(addr);
 }
+// sixteen bytes to a 16-byte aligned LDS byte address
+typedef uint32_t x3_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void x3_lds_write_b128(uint32_t addr, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  x3_u32x4 v = {a, b, c, d};
+  *reinterpret_cast<__attribute__((address_space(3))) x3_u32x4*>(addr) = v;
+}
 // v_ffbh_u32 without __clz's clamp: -1 (not 32) for 0
 __device__ __forceinline__ uint32_t x3_ffbh(uint32_t a) {
   uint32_t r;
