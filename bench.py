@@ -217,7 +217,6 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # caller-owned pageable buffers, allocated and touched beforehand (a caller that streams audio has
         # them already); first call = cold (device scratch is allocated), second = steady state
-        import ctypes as C
         L = x3hip.lib()
         hwav = wav.cpu().numpy()
         hcap = L.x3_encode_bound(n, C.byref(p))

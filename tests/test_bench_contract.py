@@ -1,0 +1,49 @@
+"""bench.py is what the driver runs at the end of a round: keep it runnable.
+
+CPU: the script compiles and no function uses a name as a local before binding it (the classic way an
+`import x as C` inside a function breaks an earlier use of the module-level C).
+GPU: one small run end to end, and the JSON line carries every key of the contract."""
+import ast
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def test_bench_has_no_function_local_shadowing_of_module_imports():
+    tree = ast.parse(open(BENCH).read())
+    top = set()
+    for node in tree.body:
+        if isinstance(node, (ast.Import, ast.ImportFrom)):
+            top.update((a.asname or a.name).split(".")[0] for a in node.names)
+    for fn in [n for n in ast.walk(tree) if isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef))]:
+        for node in ast.walk(fn):
+            if isinstance(node, (ast.Import, ast.ImportFrom)):
+                for a in node.names:
+                    name = (a.asname or a.name).split(".")[0]
+                    assert name not in top, "bench.py: %s() re-imports module-level name %r (makes it a local)" % (fn.name, name)
+
+
+@pytest.mark.gpu
+def test_bench_small_run_prints_the_contract_line():
+    r = subprocess.run([sys.executable, BENCH, "--steps", "2", "--warmup", "1", "--samples", "20000000", "--cpu-sample",
+                        "2000000", "--cpu-reps", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["value"] > 0 and j["vs_baseline"] is None
+    assert "workload" in j["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in j["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in j["cpu_baseline"], k
+    assert j["host_buffer_api"]["encode_msamples_s"] > 0
