@@ -64,7 +64,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # X3_BENCH_FORCE_DIST=1: take the distributed path (RCCL init, length exchange, gather, barriers) with one rank
+    # too -- a way to exercise it on a one-GPU box (launch through torch.distributed.run --nproc-per-node 1)
+    if world > 1 or os.environ.get("X3_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -92,12 +94,15 @@ def main():
         rc = ctx.encode_dev(wav.data_ptr(), n, p, out.data_ptr(), cap, 0, off.data_ptr())
         assert rc == 0, (rc, ctx.last_error())
         work = None
-        if dist is not None:
+        mode = "after" if os.environ.get("X3_BENCH_EXCHANGE") == "after" else "beside"  # (diagnostic switch)
+        if dist is not None and mode == "beside":
             # the exchange step of the sharded path: sub-stream lengths -> global byte offsets.  Every rank decodes
             # its own frames, so the 8-byte all-gather runs beside the decoder and is waited for at the end of the step
             _, work = shard.exchange_lengths(off[F:F + 1], out=lens, async_op=True)
         rc = ctx.decode_dev(out.data_ptr(), cap, off.data_ptr(), F, p, back.data_ptr(), n, n_per_clip=n)
         assert rc == 0, (rc, ctx.last_error())
+        if dist is not None and mode == "after":
+            _, work = shard.exchange_lengths(off[F:F + 1], out=lens, async_op=True)
         if work is not None:
             work.wait()
 

@@ -140,7 +140,15 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
   } else {
     c->stream = stream;
   }
-  HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  {
+    // The side stream must not share a hardware queue with the caller's stream, or the check kernel runs behind
+    // the decoder instead of beside it (seen once RCCL had created its own streams: HIP maps streams of one
+    // priority onto a few hardware queues round robin).  Streams of another priority get queues of their own.
+    int lo = 0, hi = 0;
+    HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    if (hi < lo) HIPCHK(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi));
+    else HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  }
   HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   HIPCHK(c, hipMalloc(&c->d_xpow, X3_XP_SIZE * sizeof(uint16_t)));
