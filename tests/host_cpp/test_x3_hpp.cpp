@@ -4,7 +4,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
+#include <iterator>
 #include <sstream>
+#include <unistd.h>
 #include <vector>
 
 #include "../../oracle/x3_oracle.h"
@@ -137,6 +140,32 @@ int main(int argc, char** argv) {
     CHECK(n == fh.samples && !std::memcmp(one.data(), wav.data(), n * 2));
     uint16_t c = 0;
     CHECK(x3::crc::crc16(ctx, ref.data() + 20, fh.payload_len, &c) == x3::X3Error::Ok && c == fh.payload_crc);
+  }
+  // the file level (encodefile.rs:48-77, decodefile.rs:189-227) against the oracle's files, byte for byte
+  {
+    const char* dir = std::getenv("TMPDIR") ? std::getenv("TMPDIR") : "/tmp";
+    const std::string base = std::string(dir) + "/x3hpp_" + std::to_string((long)getpid());
+    const std::string in = base + ".wav", a = base + "_g.x3a", b = base + "_o.x3a", wa = base + "_g.wav", wb = base + "_o.wav";
+    uint8_t hdr[44];
+    x3o_wav_header_write(44100, wav.size(), hdr);
+    {
+      std::ofstream f(in, std::ios::binary);
+      f.write(reinterpret_cast<const char*>(hdr), 44);
+      f.write(reinterpret_cast<const char*>(wav.data()), (std::streamsize)(wav.size() * 2));
+    }
+    auto slurp = [](const std::string& path) {
+      std::ifstream f(path, std::ios::binary);
+      return std::string((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    };
+    uint64_t so[6], n1 = 0, e1 = 0, n2 = 0, e2 = 0;
+    CHECK(x3::encodefile::wav_to_x3a(ctx, in.c_str(), a.c_str(), false) == x3::X3Error::Ok);
+    CHECK(x3o_wav_to_x3a(in.c_str(), b.c_str(), so) == 0);
+    CHECK(slurp(a) == slurp(b) && slurp(a).size() > 320);
+    CHECK(x3::decodefile::x3a_to_wav(ctx, a.c_str(), wa.c_str(), &n1, &e1) == x3::X3Error::Ok);
+    CHECK(x3o_x3a_to_wav(b.c_str(), wb.c_str(), &n2, &e2) == 0);
+    CHECK(n1 == wav.size() && n2 == n1 && e1 == 0 && e2 == 0 && slurp(wa) == slurp(wb) && slurp(wa) == slurp(in));
+    CHECK(x3::encodefile::wav_to_x3a(ctx, (base + "_missing.wav").c_str(), a.c_str(), false) == x3::X3Error::Io);
+    for (const std::string& f : {in, a, b, wa, wb}) std::remove(f.c_str());
   }
   std::printf("x3.hpp checks ok\n");
   return 0;
