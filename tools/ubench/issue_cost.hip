@@ -63,16 +63,16 @@ __global__ void __launch_bounds__(64) k(unsigned long long* out, uint32_t seed) 
 template <int KIND>
 static void run(const char* name, int per_rep, int grid) {
   unsigned long long* d;
-  hipMalloc(&d, grid * 8);
+  (void)hipMalloc(&d, grid * 8);
   hipLaunchKernelGGL(k<KIND>, dim3(grid), dim3(64), 0, 0, d, 1u);
   hipLaunchKernelGGL(k<KIND>, dim3(grid), dim3(64), 0, 0, d, 2u);
-  hipDeviceSynchronize();
+  (void)hipDeviceSynchronize();
   std::vector<unsigned long long> h(grid);
-  hipMemcpy(h.data(), d, grid * 8, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(h.data(), d, grid * 8, hipMemcpyDeviceToHost);
   double s = 0;
   for (auto v : h) s += (double)v;
   printf("%-34s waves=%5d  cycles/instr = %.2f\n", name, grid, s / grid / ((double)ITER * 16 * per_rep));
-  hipFree(d);
+  (void)hipFree(d);
 }
 
 int main() {
