@@ -48,6 +48,8 @@ struct x3_ctx {
   uint32_t* d_xk16 = nullptr;          // [10][512][16]: x^(32*c*(511-t)) * x^b mod P (x3_encode_stream_kernel.h)
   uint16_t* d_crctab = nullptr;        // [6][256]: slicing-by-4 CRC tables + the two x^2048 rows
   uint32_t* d_kx64 = nullptr;          // [64][16] (x3_frame_check_kernel)
+  uint16_t* d_chktab = nullptr;        // [18][256] (x3_frame_check_kernel: T[s][k][v] and the x^8192 rows)
+  uint16_t* d_xinv8 = nullptr;         // x^(-8k), k < X3_CHECK_XINV_N
   int* d_status = nullptr;             // [0] size/scan pass, [1] encode pass
   unsigned long long* d_stats = nullptr;    // 6
   unsigned long long* d_end_pos = nullptr;  // 1
@@ -216,6 +218,26 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
       HIPCHK(c, hipMalloc(&c->d_kx64, kx.size() * sizeof(uint32_t)));
       HIPCHK(c, hipMemcpy(c->d_kx64, kx.data(), kx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
+    {
+      // x3_frame_check_kernel: T[s][k][v] = v * x^(8k + 16) * x^(2048 s); then "times x^8192" for v << 8 and v
+      std::vector<uint16_t> ct(X3_CHECK_TAB_U16);
+      for (int sr = 0; sr < 4; ++sr)
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t sh = gf_xpow_host(8ull * k + 16 + 2048ull * sr);
+          for (int v = 0; v < 256; ++v) ct[((size_t)sr * 4 + k) * 256 + v] = (uint16_t)gf_mul_host((uint32_t)v, sh);
+        }
+      for (int v = 0; v < 256; ++v) {
+        ct[16 * 256 + v] = (uint16_t)gf_mul_host((uint32_t)v, gf_xpow_host(8192 + 8));
+        ct[17 * 256 + v] = (uint16_t)gf_mul_host((uint32_t)v, gf_xpow_host(8192));
+      }
+      HIPCHK(c, hipMalloc(&c->d_chktab, ct.size() * sizeof(uint16_t)));
+      HIPCHK(c, hipMemcpy(c->d_chktab, ct.data(), ct.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+      // x^(-8k): x has order 32767 modulo P (P = (x + 1) * a primitive polynomial of degree 15)
+      std::vector<uint16_t> xi(X3_CHECK_XINV_N);
+      for (uint32_t k = 0; k < X3_CHECK_XINV_N; ++k) xi[k] = (uint16_t)gf_xpow_host((32767ull * 8 - 8ull * k) % 32767ull);
+      HIPCHK(c, hipMalloc(&c->d_xinv8, xi.size() * sizeof(uint16_t)));
+      HIPCHK(c, hipMemcpy(c->d_xinv8, xi.data(), xi.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
     HIPCHK(c, hipMalloc(&c->d_crctab, tab.size() * sizeof(uint16_t)));
     HIPCHK(c, hipMemcpy(c->d_crctab, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   }
@@ -266,6 +288,8 @@ extern "C" void x3_ctx_destroy(x3_ctx* c) {
   (void)hipFree(c->d_xk16);
   (void)hipFree(c->d_crctab);
   (void)hipFree(c->d_kx64);
+  (void)hipFree(c->d_chktab);
+  (void)hipFree(c->d_xinv8);
   (void)hipFree(c->d_status);
   (void)hipFree(c->d_summary);
   (void)hipFree(c->d_crc);
@@ -836,7 +860,7 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
     const uint64_t check_grid = std::min<uint64_t>((F + 3) / 4, (uint64_t)c->n_cus * check_wgs_per_cu);
     hipLaunchKernelGGL(x3_frame_check_kernel, dim3((unsigned)check_grid), dim3(256), 0, check_stream,
                        reinterpret_cast<const uint32_t*>(d_x3), x3_len, d_frame_offsets, F,
-                       (const uint16_t*)c->d_xpow, (const uint16_t*)c->d_crctab, (const uint32_t*)c->d_kx64,
+                       (const uint16_t*)c->d_xinv8, (const uint16_t*)c->d_chktab, (const uint32_t*)c->d_kx64,
                        (int32_t*)c->dec_cstatus.p, reinterpret_cast<unsigned long long*>(c->d_summary));
   }
   HIPCHK(c, hipEventRecord(c->ev_join, check_stream));

@@ -89,7 +89,12 @@ __device__ __forceinline__ int32_t x3_frame_header_check(const uint32_t* __restr
 
 // Payload-CRC tables in LDS: T[0..3][v] = crc0 of byte v followed by 0..3 zero bytes (slicing by 4),
 // T[4][v] = (v << 8) * x^2048, T[5][v] = v * x^2048 (a 16-bit state times x^(32*64) is T[4][hi] ^ T[5][lo]).
-#define X3_CHECK_TAB_DW 768u  // 6 * 256 uint16
+// LDS tables of x3_frame_check_kernel (uint16): T[s][k][v] = v * x^(8k + 16) * x^(2048 s), s, k = 0..3 -- the
+// contribution of the byte that k bytes follow in its dword, in a dword that s rows of 64 dwords follow --, then
+// the two rows of "times x^8192" (for v << 8 and for v)
+#define X3_CHECK_TAB_U16 (18u * 256u)
+#define X3_CHECK_TAB_DW (X3_CHECK_TAB_U16 / 2u)
+#define X3_CHECK_XINV_N 1024u  // x^(-8k), k < 1024: undoes the zero bytes the row grid adds behind a payload
 
 // One WAVE per frame, waves walk the frames grid-stride (the tables are loaded once per workgroup).
 // Lane t takes the payload dwords t, t + 64, t + 128, ... (every load is one contiguous 256-byte run of the
@@ -103,11 +108,10 @@ __device__ __forceinline__ int32_t x3_frame_header_check(const uint32_t* __restr
 
 __global__ void __launch_bounds__(256)
 x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const uint64_t* __restrict__ frame_off,
-                      uint64_t n_frames, const uint16_t* __restrict__ xpow, const uint16_t* __restrict__ tab_g,
+                      uint64_t n_frames, const uint16_t* __restrict__ xinv8, const uint16_t* __restrict__ tab_g,
                       const uint32_t* __restrict__ kx64, int32_t* __restrict__ status,
                       unsigned long long* __restrict__ summary) {
-  __shared__ __attribute__((aligned(16))) uint16_t tab[6 * 256];
-  __shared__ __attribute__((aligned(16))) uint32_t kxs[64 * 16];  // [m][b] = x^(32*m) * x^b
+  __shared__ __attribute__((aligned(16))) uint16_t tab[X3_CHECK_TAB_U16];
   // short and latency-bound: ahead of the decoder's waves it shares the SIMDs with, so that it is out of the way
   // early instead of being stretched to the decoder's whole duration
   __builtin_amdgcn_s_setprio(3);
@@ -120,14 +124,26 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
   }
   for (uint32_t i = threadIdx.x; i < X3_CHECK_TAB_DW; i += blockDim.x)
     reinterpret_cast<uint32_t*>(tab)[i] = reinterpret_cast<const uint32_t*>(tab_g)[i];
-  // kx64 is indexed by lane t = 63 - m
-  for (uint32_t i = threadIdx.x; i < 64u * 16u; i += blockDim.x) kxs[i] = kx64[(63u - (i >> 4)) * 16u + (i & 15u)];
   const uint32_t lane = threadIdx.x & 63u;
+  // this lane's dword of a row is followed by 63 - lane dwords of the row: x^(32 * (63 - lane)) * x^b, b = 0..15
+  uint32_t kk[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint4 k4 = reinterpret_cast<const uint4*>(kx64 + lane * 16u)[q];
+    kk[4 * q] = k4.x; kk[4 * q + 1] = k4.y; kk[4 * q + 2] = k4.z; kk[4 * q + 3] = k4.w;
+  }
   __syncthreads();
-  auto crc0_be32 = [&](uint32_t m) -> uint32_t {  // crc0 of four bytes held big-endian
-    return (uint32_t)tab[768u + (m >> 24)] ^ (uint32_t)tab[512u + ((m >> 16) & 0xFFu)] ^
-           (uint32_t)tab[256u + ((m >> 8) & 0xFFu)] ^ (uint32_t)tab[m & 0xFFu];
+  const uint32_t tab_base = x3_lds_addr(tab);
+  // sum over the four bytes of a big-endian dword of T[s][k][byte]: the byte selects are SDWA operands of the
+  // shift that turns the byte into a table offset, the row of the table is the immediate offset of the read
+  auto rowsum = [&](uint32_t be, uint32_t s_row) -> uint32_t {  // s_row: compile-time after unrolling
+    const uint32_t o = s_row * 2048u;
+    const uint32_t a3 = x3_sdwa_byte_x2(be, 3), a2 = x3_sdwa_byte_x2(be, 2), a1 = x3_sdwa_byte_x2(be, 1),
+                   a0 = x3_sdwa_byte_x2(be, 0);
+    return x3_lds_read_u16(tab_base + a3, o + 1536u) ^ x3_lds_read_u16(tab_base + a2, o + 1024u) ^
+           x3_lds_read_u16(tab_base + a1, o + 512u) ^ x3_lds_read_u16(tab_base + a0, o);
   };
+  auto crc0_be32 = [&](uint32_t m) -> uint32_t { return rowsum(m, 0u); };  // crc0 of four bytes held big-endian
   const uint64_t n_dw = (x3_len + 3) >> 2;
   const uint64_t waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
   const uint64_t f0 = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -185,49 +201,70 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
         crc = 0xFFFFu;
         for (uint32_t i = 0; i < plen; ++i) crc = x3_crc_byte(crc, x3_be32_at(xw, n_dw, p0 + i) >> 24);
       } else {
+        // The payload as rows of 64 aligned dwords, lane t on dword t of every row.  A dword that is followed by
+        // s more rows inside its group of four contributes T[s][.][its bytes]; between groups the partial sum
+        // is multiplied by x^8192 (four rows).  The grid ends on a whole group: R4 rows.  What it holds beyond
+        // the payload is masked to zero, which adds nothing to the sum but counts as trailing zero bytes: undone
+        // by one multiplication with x^(-8k) at the end.  The CRC's init value is XORed into payload bytes 0, 1.
         const uint32_t lead = (uint32_t)(p0 & 3u);       // header bytes in front, inside dword 0
         const uint32_t* __restrict__ const pw = xw + (p0 >> 2);
         const uint32_t nd = (lead + plen + 3u) >> 2;     // aligned dwords covering the payload
         const uint32_t tpad = 4u * nd - lead - plen;     // bytes behind the payload in the last dword
-        crc = 0;
-        auto fold = [&](uint32_t raw, uint32_t j) {      // dword j of the payload
-          if (j < nd) {
-            uint32_t be = x3_bswap32(raw);
-            if (j < 2u || j == nd - 1u) {  // only the first two dwords and the last one need fixing up
-              if (j == 0) {
-                be &= 0xFFFFFFFFu >> (8u * lead);
-                be ^= lead <= 2 ? (0xFFFF0000u >> (8u * lead)) : 0x000000FFu;  // CRC init folded into bytes 0,1
-              }
-              if (j == 1 && lead == 3) be ^= 0xFF000000u;
-              if (j == nd - 1u) be &= 0xFFFFFFFFu << (8u * tpad);
-            }
-            // partial = partial * x^2048 + crc0(dword)
-            crc = (uint32_t)tab[1024u + (crc >> 8)] ^ (uint32_t)tab[1280u + (crc & 0xFFu)] ^ crc0_be32(be);
-          }
-        };
-#pragma unroll
-        for (uint32_t u = 0; u < X3_CHECK_AHEAD; ++u) fold(pd[u], lane + 64u * u);
-        // payloads longer than the look-ahead (high-entropy data: up to 20 KB per frame): the same registers,
-        // X3_CHECK_AHEAD dwords per lane per round trip
-        for (uint32_t j0 = 64u * X3_CHECK_AHEAD; j0 < nd; j0 += 64u * X3_CHECK_AHEAD) {
-#pragma unroll
-          for (uint32_t u = 0; u < X3_CHECK_AHEAD; ++u) pd[u] = j0 + lane + 64u * u < nd ? pw[j0 + lane + 64u * u] : 0u;
-#pragma unroll
-          for (uint32_t u = 0; u < X3_CHECK_AHEAD; ++u) fold(pd[u], j0 + lane + 64u * u);
+        const uint32_t R = (nd + 63u) >> 6;              // rows that hold payload
+        const uint32_t last_lane = (nd - 1u) & 63u;
+        // row 0: header bytes in front of the payload off, CRC init in; row R-1: nothing behind the payload
+        uint32_t and0 = 0xFFFFFFFFu, xor0 = 0u;
+        if (lane == 0) {
+          and0 = 0xFFFFFFFFu >> (8u * lead);
+          xor0 = lead <= 2 ? (0xFFFF0000u >> (8u * lead)) : 0x000000FFu;
         }
-        // this lane's last dword is followed by m = (nd - 1 - lane) mod 64 dwords: times x^(32*m)
+        if (lane == 1 && lead == 3) xor0 = 0xFF000000u;
+        const uint32_t last_mask = lane < last_lane ? 0xFFFFFFFFu : (lane == last_lane ? 0xFFFFFFFFu << (8u * tpad) : 0u);
+        uint32_t acc = 0;
+        uint32_t rows_done = 0;
+        for (uint32_t rbase = 0; rbase < R; rbase += X3_CHECK_AHEAD) {
+          if (rbase) {
+            // payloads longer than the look-ahead (high-entropy data: up to 20 KB per frame): the same registers,
+            // X3_CHECK_AHEAD rows per round trip; only the last row can reach beyond the payload
+#pragma unroll
+            for (uint32_t u = 0; u < X3_CHECK_AHEAD; ++u) {
+              if (rbase + u < R) {
+                const uint32_t j = 64u * (rbase + u) + lane;
+                pd[u] = (rbase + u + 1u < R || j < nd) ? pw[j] : 0u;
+              }
+            }
+          }
+#pragma unroll
+          for (uint32_t g4 = 0; g4 < X3_CHECK_AHEAD; g4 += 4) {
+            if (rbase + g4 < R) {  // (whole wave)
+              if (rbase + g4)      // partial sum so far: four rows further from the end
+                acc = x3_lds_read_u16(tab_base + ((acc >> 8) << 1), 16u * 512u) ^
+                      x3_lds_read_u16(tab_base + ((acc & 0xFFu) << 1), 17u * 512u);
+#pragma unroll
+              for (uint32_t q = 0; q < 4; ++q) {
+                const uint32_t row = rbase + g4 + q;
+                uint32_t be = x3_bswap32(pd[g4 + q]);
+                if (g4 + q == 0) {
+                  if (rbase == 0) be = (be & and0) ^ xor0;
+                }
+                if (row + 1u >= R) be &= row + 1u == R ? last_mask : 0u;  // (whole wave)
+                acc ^= rowsum(be, 3u - q);
+              }
+              rows_done = rbase + g4 + 4u;
+            }
+          }
+        }
+        // this lane's dwords are followed by 63 - lane dwords in their rows: times x^(32 * (63 - lane))
         {
-          const uint4* kp = reinterpret_cast<const uint4*>(kxs + ((nd - 1u - lane) & 63u) * 16u);
-          const uint4 k0 = kp[0], k1 = kp[1], k2 = kp[2], k3 = kp[3];
-          const uint32_t kk[16] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w,
-                                   k2.x, k2.y, k2.z, k2.w, k3.x, k3.y, k3.z, k3.w};
           uint32_t r = 0;
 #pragma unroll
-          for (int bit = 0; bit < 16; ++bit) r ^= (0u - ((crc >> bit) & 1u)) & kk[bit];
-          crc = lane < nd ? r : 0u;
+          for (int bit = 0; bit < 16; ++bit) r ^= (0u - ((acc >> bit) & 1u)) & kk[bit];
+          crc = r;
         }
         crc = (uint32_t)__builtin_amdgcn_readlane((int)x3_wave_xor_to_lane63_dpp(crc), 63);
-        if (tpad) crc = x3_gf_mul(crc, xpow[X3_XINV8_INDEX(tpad)]);  // undo the virtual trailing zero bytes
+        // the grid counted 64 * rows_done dwords, the payload ends tpad bytes inside dword nd - 1
+        const uint32_t zeros = 4u * (64u * rows_done - nd) + tpad;
+        if (zeros) crc = x3_gf_mul(crc, xinv8[zeros]);
       }
       if (crc != pcrc) st = X3D_FRAME_HEADER_INVALID_PAYLOAD_CRC;
     }

@@ -184,6 +184,25 @@ __device__ __forceinline__ uint32_t x3_mad_i24(uint32_t a, uint32_t b, uint32_t 
 __device__ __forceinline__ uint32_t x3_lds_read_b32(uint32_t addr) {
   return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(addr);
 }
+// LDS byte address of an object in LDS
+__device__ __forceinline__ uint32_t x3_lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(const char*)p;
+}
+// byte k of a dword, times two (a uint16 table offset): one SDWA shift
+__device__ __forceinline__ uint32_t x3_sdwa_byte_x2(uint32_t v, int k) {
+  uint32_t r;
+  switch (k) {
+    case 0: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(1u), "v"(v)); break;
+    case 1: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(1u), "v"(v)); break;
+    case 2: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(1u), "v"(v)); break;
+    default: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(1u), "v"(v)); break;
+  }
+  return r;
+}
+// one uint16 from an LDS byte address + constant
+__device__ __forceinline__ uint32_t x3_lds_read_u16(uint32_t addr, uint32_t const_off) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) uint16_t*>(addr + const_off);
+}
 // sixteen bytes to a 16-byte aligned LDS byte address
 typedef uint32_t x3_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void x3_lds_write_b128(uint32_t addr, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {

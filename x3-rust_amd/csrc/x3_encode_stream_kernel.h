@@ -110,9 +110,6 @@ __device__ __forceinline__ void x3_dma_wait() {
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
   asm volatile("" ::: "memory");
 }
-__device__ __forceinline__ uint32_t x3_lds_addr(const void* p) {
-  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(const char*)p;
-}
 
 // a(x) * C(x) mod 0x11021 for a compile-time constant C: the sixteen C*x^b are immediates
 constexpr uint32_t x3_gf_xtime(uint32_t k) { return ((k << 1) ^ ((k & 0x8000u) ? 0x11021u : 0u)) & 0xFFFFu; }
