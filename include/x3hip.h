@@ -171,7 +171,9 @@ int x3_decode_frame(x3_ctx* ctx, const uint8_t* payload, uint64_t len, int16_t* 
  * (src/decodefile.rs:93-136,200-209) over an in-memory frame stream x3[0..len) (no archive
  * header): stop at end of data, at the first hard error (returned), or at the first frame whose
  * payload fails to decode (counted in *frame_errors, return 0).  wav receives the samples of
- * the frames before the stop; *n_out their count; *frames_ok the number of good frames. */
+ * the frames before the stop; *n_out their count; *frames_ok the number of good frames.
+ * (Streams of 4 MiB and more are uploaded first and walked on the GPU, x3_index_dev's way; shorter ones are
+ * walked on the host.  Same results either way.) */
 int x3_decode_stream(x3_ctx* ctx, const uint8_t* x3, uint64_t len, const x3_params* p, int16_t* wav,
                      uint64_t wav_cap, uint64_t* n_out, uint64_t* frames_ok, uint64_t* frame_errors);
 
