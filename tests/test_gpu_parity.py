@@ -675,3 +675,47 @@ def test_random_parameter_sweep(ctx, x3):
                     assert r[0] == 0 and np.array_equal(r[1], wav), (trial, bl, bpf, codes, thr)
             done += 1
     assert done >= 24
+
+
+def test_decode_dev_survives_wild_frame_offsets(ctx, x3):
+    """x3_decode_dev takes the frame index from the caller: offsets that point into payloads, past the end of the
+    stream or nowhere near a frame must end as per-frame errors, never as reads outside the stream buffer."""
+    rng = np.random.default_rng(11)
+    n = 64 * 10000 * 3
+    p = x3.Params.default()
+    wav = x3.synth(2, 91, 0, n)
+    rc, stream, _ = ctx.encode(wav, p)
+    assert rc == 0
+    F = n // 10000
+    good = np.array(frame_offsets(stream) + [stream.size], dtype=np.uint64)
+    assert good.size == F + 1
+    d_x3 = ctx.alloc(stream.size + 16); d_off = ctx.alloc(8 * (F + 1)); d_wav = ctx.alloc(2 * n)
+    L = x3.lib()
+    L.x3_dev_upload(ctx._h, d_x3, stream.ctypes.data, stream.size)
+    try:
+        for trial in range(6):
+            offs = good.copy()
+            k = rng.integers(0, F, size=F // 3)
+            if trial == 0:
+                offs[k] = rng.integers(0, stream.size, size=k.size)                 # anywhere inside
+            elif trial == 1:
+                offs[k] = stream.size - rng.integers(0, 40, size=k.size)            # the last bytes
+            elif trial == 2:
+                offs[k] = stream.size + rng.integers(0, 1 << 20, size=k.size)       # beyond the end
+            elif trial == 3:
+                offs[k] = np.uint64(1) << np.uint64(40)                             # far beyond
+            elif trial == 4:
+                offs[k] = offs[k] + np.uint64(2) * rng.integers(1, 9, size=k.size).astype(np.uint64)  # a few bytes off
+            else:
+                offs[:] = 0                                                         # every lane on frame 0
+            L.x3_dev_upload(ctx._h, d_off, offs.ctypes.data, offs.size * 8)
+            rc = ctx.decode_dev(d_x3, stream.size, d_off, F, p, d_wav, n, n_per_clip=n)
+            assert rc == 0
+            rc, first_bad, st, before = ctx.decode_result()
+            assert rc == 0 and first_bad <= F
+            if trial == 5:
+                assert first_bad == F  # sixty-four copies of frame 0 per group: all valid
+            else:
+                assert first_bad < F and st != 0 and first_bad == int(np.min(k)) or trial == 0
+    finally:
+        ctx.free(d_x3); ctx.free(d_off); ctx.free(d_wav)
