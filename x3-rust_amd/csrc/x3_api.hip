@@ -697,6 +697,8 @@ extern "C" int x3_encode_result(x3_ctx* c, uint64_t* out_pos, uint64_t stats[6])
   if (c->h_status[1] == X3D_SIZE_WAIT_TIMEOUT) {
     // the single-pass kernel's workgroups were not all resident (GPU shared with other work): its
     // bounded wait for frame sizes gave up.  Encode again with the two-pass kernels, which need no residency.
+    if (std::getenv("X3HIP_VERBOSE"))
+      std::fprintf(stderr, "x3hip: stream encoder gave up waiting for frame sizes (grid not co-resident): two-pass fallback\n");
     c->force_two_pass = true;
     auto a = c->last_enc;
     int rc = encode_dev_impl(c, a.d_wav, &a.b, &a.p, a.spf, a.d_out, a.out_cap, a.start_pos, a.d_off);
