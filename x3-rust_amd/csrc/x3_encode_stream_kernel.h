@@ -255,7 +255,7 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
   __syncthreads();
 
   // The two roles run their own frame loops (the branch is outside the loops so that loop-carried and
-  // hoisted values of one role are not live in the other) and meet at four barriers per frame.
+  // hoisted values of one role are not live in the other) and meet at four barriers per frame (B1, B3, B4, B4b).
   if (helper_wave) {
     // =============================================================== helper wave
     // Few instructions, all of them on the critical path of the eight compute waves (which wait for this
@@ -417,16 +417,21 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
         part[50] = hc;
       }
       X3_STAMP(4);
+      __syncthreads();  // B3: emission complete (a barrier of the compute waves; nothing of this wave's is due yet)
+      X3_STAMP(2);
+      // The prefetch and the size words are a memory round trip (several microseconds under the kernel's own
+      // traffic) behind B1.  They are due at B4, not at B3: the compute waves' CRC pass lies in between, and
+      // behind B4 they take the previous frame out (its offset) and analyse the next one (its samples).
       x3_dma_wait();    // the next frame's samples have landed in LDS (and the requested sizes behind them)
       X3_STAMP(6);
-      if (pending) resolve();  // the previous frame's offset: consumed by the compute waves behind B3
+      if (pending) resolve();  // the previous frame's offset: consumed by the compute waves behind B4
       X3_STAMP(5);
-      __syncthreads();  // B3: emission complete, next frame's samples landed, previous frame's offset known
+      __syncthreads();  // B4: CRC partials ready, next frame's samples landed, previous frame's offset known
       X3_STAMP(2);
       pend_f = f;
       pend_bytes = frame_bytes;
       pending = true;
-      __syncthreads();  // B4: CRC partials ready
+      __syncthreads();  // B4b: the previous frame has been copied out (its image is cleared behind this)
       X3_STAMP(2);
     }
     if (pending) {
@@ -668,12 +673,13 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
       if (cnt) atomicAdd(&part[32 + type], cnt);
 
       X3_STAMP(4);
-      __syncthreads();  // B3: emission complete, next frame's samples landed, previous frame's offset known
+      __syncthreads();  // B3: emission complete
+#ifdef X3_DBG_ALLWAVES
+      X3_STAMP(3);
+#else
       X3_STAMP(2);
+#endif
 
-      // ---- F: the PREVIOUS frame goes out now (its offset needed every predecessor's size: that wait
-      // overlapped this frame's analysis and emission)
-      if (have_prev) copy_out(img0 + (cur ^ 1u) * img_dwords, prev_bytes);
       X3_STAMP(6);
 
       uint32_t crc = 0;
@@ -711,8 +717,12 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
       if (lane == 63) part[16 + wid] = crc;
 
       X3_STAMP(5);
-      __syncthreads();  // B4: CRC partials are in LDS
+      __syncthreads();  // B4: CRC partials are in LDS; the next frame's samples and the previous frame's offset too
+#ifdef X3_DBG_ALLWAVES
+      X3_STAMP(7);
+#else
       X3_STAMP(2);
+#endif
       if (tid == 0) {
         uint32_t v = 0;
 #pragma unroll
@@ -729,8 +739,17 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
         img[3] = 0;
         img[4] = x3_bswap32((hc << 16) | (v & 0xFFFFu));
       }
-      // the image of the PREVIOUS frame went out behind B3 (every wave is past B4 now): clear what it used,
-      // ready for the frame after this one.  No barrier of its own: the next B1 separates it from emission.
+      // ---- F: the PREVIOUS frame goes out now: its offset needed every predecessor's size, and that wait (in
+      // the helper wave) overlapped this frame's analysis, emission and CRC
+      if (have_prev) copy_out(img0 + (cur ^ 1u) * img_dwords, prev_bytes);
+      X3_STAMP(6);
+      __syncthreads();  // B4b: the previous frame's image has been read by every wave
+#ifdef X3_DBG_ALLWAVES
+      X3_STAMP(7);
+#else
+      X3_STAMP(2);
+#endif
+      // clear what it used, ready for the frame after this one.  The next B1 separates this from emission.
       if (have_prev) {
         uint4* z4 = reinterpret_cast<uint4*>(img0 + (cur ^ 1u) * img_dwords);
         const uint32_t nz = (((prev_bytes + 3u) >> 2) + 3u) >> 2;
@@ -745,8 +764,14 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
     copy_out(img0 + (cur ^ 1u) * img_dwords, prev_bytes);
   }
 #ifdef X3_DBG_STAMPS
+#ifdef X3_DBG_ALLWAVES
+  // (blocks 0..63 and 256..319: with 512 workgroups on 256 CUs those are first and second on their CUs)
+  if (lane == 0 && (blockIdx.x < 64 || (blockIdx.x >= 256 && blockIdx.x < 320)))
+    for (int k = 0; k < 8; ++k) x3_dbg[(((blockIdx.x & 63u) + (blockIdx.x >= 256 ? 64u : 0u)) * 9 + wid) * 8 + k] = dbg_acc[k];
+#else
   if (lane == 0 && (wid == 0 || wid == 8) && blockIdx.x < 2048)
     for (int k = 0; k < 8; ++k) x3_dbg[(blockIdx.x * 2 + (wid == 8)) * 8 + k] = dbg_acc[k];
+#endif
 #endif
   __syncthreads();
   if (tid < 6) {
