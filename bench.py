@@ -39,8 +39,8 @@ SEED = 0x58330003
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--samples", type=int, default=N_SAMPLES, help="samples per GPU (default: config 3)")
     ap.add_argument("--kind", type=int, default=2, help="synthetic signal (2 = hydrophone noise)")
     ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="samples timed on the CPU baseline")
