@@ -450,17 +450,29 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
       if (off + total_bytes <= out_cap && part[40] == 0) {
         uint8_t* dst = out + off;
         const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u);
+        // sixteen bytes per lane and trip (a default frame is ~330 of them: one trip, two thirds of the lanes);
+        // the stream position is even, so the image is either dword-aligned to it or two bytes off
         if (mis == 0) {
-          const uint32_t ndw = total_bytes >> 2;
+          const uint32_t ndw = total_bytes >> 2, nq = ndw >> 2;
           uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);
-          for (uint32_t i = tid; i < ndw; i += nthr) d32[i] = img[i];
+          const uint4* img4 = reinterpret_cast<const uint4*>(img);
+          for (uint32_t i = tid; i < nq; i += nthr) *reinterpret_cast<uint4*>(d32 + 4u * i) = img4[i];
+          if (tid < (ndw & 3u)) d32[4u * nq + tid] = img[4u * nq + tid];
           if ((total_bytes & 2u) && tid == 0) *reinterpret_cast<uint16_t*>(dst + 4 * ndw) = (uint16_t)img[ndw];
         } else if (mis == 2) {
           if (tid == 0) *reinterpret_cast<uint16_t*>(dst) = (uint16_t)img[0];
           const uint32_t rem = total_bytes - 2u;
-          const uint32_t ndw = rem >> 2;
+          const uint32_t ndw = rem >> 2, nq = ndw >> 2;
           uint32_t* d32 = reinterpret_cast<uint32_t*>(dst + 2);
-          for (uint32_t i = tid; i < ndw; i += nthr) d32[i] = (img[i] >> 16) | (img[i + 1] << 16);
+          const uint4* img4 = reinterpret_cast<const uint4*>(img);
+          for (uint32_t i = tid; i < nq; i += nthr) {
+            const uint4 a = img4[i];
+            const uint32_t e = img[4u * i + 4u];
+            *reinterpret_cast<uint4*>(d32 + 4u * i) =
+                make_uint4(__builtin_amdgcn_alignbit(a.y, a.x, 16), __builtin_amdgcn_alignbit(a.z, a.y, 16),
+                           __builtin_amdgcn_alignbit(a.w, a.z, 16), __builtin_amdgcn_alignbit(e, a.w, 16));
+          }
+          if (tid < (ndw & 3u)) d32[4u * nq + tid] = (img[4u * nq + tid] >> 16) | (img[4u * nq + tid + 1u] << 16);
           if ((rem & 2u) && tid == 0) *reinterpret_cast<uint16_t*>(dst + 2 + 4 * ndw) = (uint16_t)(img[ndw] >> 16);
         } else {
           for (uint32_t i = tid; i < total_bytes; i += nthr) dst[i] = (uint8_t)(img[i >> 2] >> (8 * (i & 3u)));
