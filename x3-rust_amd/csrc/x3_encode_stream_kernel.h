@@ -270,6 +270,7 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
     // emission is done and CONSUMED one frame later (a loaded-latency of several microseconds under the
     // kernel's own streaming traffic, measured, hides behind the next frame's analysis and emission).
     uint32_t dq[X3_LB_WINDOWS];
+    uint32_t hdr_crc = 0, cur_img = 0;
     uint64_t pend_f = 0, my_off = 0;
     uint32_t pend_bytes = 0, my_bytes = 0;
     bool pending = false, first = true;
@@ -414,7 +415,7 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
                       (uint32_t)crc_tab[256u + ((m >> 8) & 0xFFu)] ^ (uint32_t)crc_tab[m & 0xFFu];
         hc = (uint32_t)crc_tab[768u + (hc >> 8)] ^ (uint32_t)crc_tab[512u + (hc & 0xFFu)];
         hc = (uint32_t)crc_tab[768u + (hc >> 8)] ^ (uint32_t)crc_tab[512u + (hc & 0xFFu)];
-        part[50] = hc;
+        hdr_crc = hc;
       }
       X3_STAMP(4);
       __syncthreads();  // B3: emission complete (a barrier of the compute waves; nothing of this wave's is due yet)
@@ -428,6 +429,22 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
       X3_STAMP(5);
       __syncthreads();  // B4: CRC partials ready, next frame's samples landed, previous frame's offset known
       X3_STAMP(2);
+      // this frame's header (encoder.rs:122-162): "x3", id, id, samples, payload_len, 8 zero time bytes, header
+      // crc over bytes 0..16, payload crc; audio frames use id 1.  Here, not in a compute wave: that one would
+      // keep the other seven waiting at the next barrier for its hundred scalar-like instructions.
+      if (lane == 0) {
+        uint32_t v = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 8; ++w) v ^= part[16 + w];
+        if (L & 2u) v = x3_gf_mul_const<X3_XINV16_C>(v);  // undo the 2 virtual pad-to-4 bytes
+        uint32_t* img = img0 + cur_img * img_dwords;
+        img[0] = x3_bswap32(0x78330101u);
+        img[1] = x3_bswap32(((n & 0xFFFFu) << 16) | (L & 0xFFFFu));
+        img[2] = 0;
+        img[3] = 0;
+        img[4] = x3_bswap32((hdr_crc << 16) | (v & 0xFFFFu));
+      }
+      cur_img ^= 1u;
       pend_f = f;
       pend_bytes = frame_bytes;
       pending = true;
@@ -735,22 +752,7 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
 #else
       X3_STAMP(2);
 #endif
-      if (tid == 0) {
-        uint32_t v = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < 8; ++w) v ^= part[16 + w];
-        if (L & 2u) v = x3_gf_mul_const<X3_XINV16_C>(v);  // undo the 2 virtual pad-to-4 bytes
-        // frame header (encoder.rs:122-162): "x3", id, id, samples, payload_len, 8 zero time bytes,
-        // header crc over bytes 0..16 (computed by the helper wave), payload crc; audio frames use id 1
-        const uint32_t h0 = 0x78330101u;
-        const uint32_t h1 = ((n & 0xFFFFu) << 16) | (L & 0xFFFFu);
-        const uint32_t hc = part[50];
-        img[0] = x3_bswap32(h0);
-        img[1] = x3_bswap32(h1);
-        img[2] = 0;
-        img[3] = 0;
-        img[4] = x3_bswap32((hc << 16) | (v & 0xFFFFu));
-      }
+      // (the helper wave writes this frame's header into the image behind this barrier)
       // ---- F: the PREVIOUS frame goes out now: its offset needed every predecessor's size, and that wait (in
       // the helper wave) overlapped this frame's analysis, emission and CRC
       if (have_prev) copy_out(img0 + (cur ^ 1u) * img_dwords, prev_bytes);
