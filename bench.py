@@ -7,12 +7,15 @@ on N MI355X GPUs, one process per GPU.
            --master-port P bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the hot path over one batch of synthetic audio already resident in HBM:
-x3_encode_dev (frame sizes -> scan -> encode+compact into the final stream) followed by
-x3_decode_dev (header + payload CRC check + decode) of the stream just produced.  With N > 1 the
-frames are sharded (weak scaling: every rank owns its own hour of audio = BASELINE config 4 at
-N = 8); the only data-path exchange per step is the RCCL all-gather of the sub-stream lengths that
-places each rank's sub-stream in the global .x3a byte range.  The full reassembly gather to rank 0
-is timed separately and reported under "gather" (DESIGN.md section "Multi-GPU").
+x3_encode_dev (single-pass encode + compaction into the final stream) followed by x3_decode_dev
+(header + payload CRC check + decode) of the stream just produced.  With N > 1 the frames are
+sharded -- weak scaling by default: every rank owns its own hour of audio (= BASELINE config 4 at
+N = 8); --strong: one stream of --total-samples cut into N frame ranges -- and the step ALSO holds
+the path's exchange: the RCCL all-gather of the sub-stream lengths (x3_shard_exchange_lengths) and
+the reassembly of the whole .x3a byte stream on rank 0 (x3_shard_gather: grouped ncclSend/ncclRecv,
+one xGMI link per peer), both through libx3hip.so's C ABI (librccl directly; torch.distributed only
+starts the ranks, hands the communicator id round and takes the max of the ranks' times).  The
+gather is also timed alone ("gather"), and --no-gather leaves it out of the step.
 
 Rank 0 prints ONE JSON line (see the contract in the task statement), with
   roofline     -- the encode kernel: algorithmic bytes (2 B/sample read + stream bytes written)
@@ -46,13 +49,15 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="samples timed on the CPU baseline")
     ap.add_argument("--cpu-reps", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="leave the reassembly on rank 0 out of the step")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: --total-samples cut into N frame ranges")
+    ap.add_argument("--total-samples", type=int, default=8 * N_SAMPLES, help="--strong: the whole stream (config 4: 8 h)")
+    ap.add_argument("--no-verify-all", action="store_true", help="compare only sampled frames with the CPU oracle")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import x3hip
-    from x3hip import shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -71,9 +76,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    n = args.samples
     p = x3hip.Params.default()
     L = x3hip.lib()
+    if args.strong:
+        first_sample, n = x3hip.shard_sample_range(args.total_samples, p, rank, world)
+    else:
+        first_sample, n = rank * args.samples, args.samples  # every rank owns a different hour of the same signal
     F = L.x3_num_frames(n, C.byref(p))
     cap = L.x3_encode_bound(n, C.byref(p))
 
@@ -84,27 +92,48 @@ def main():
     out = torch.empty(cap + 16, dtype=torch.uint8, device=dev)
     off = torch.empty(F + 1, dtype=torch.int64, device=dev)
     back = torch.empty(n, dtype=torch.int16, device=dev)
-    # every rank owns a different hour of the same seeded signal
-    ctx.synth_dev(args.kind, SEED, rank * n, n, wav.data_ptr())
+    ctx.synth_dev(args.kind, SEED, first_sample, n, wav.data_ptr())
     torch.cuda.synchronize(dev)
 
+    # ---- the group of ranks: librccl through the library's own C ABI (x3_shard_*)
+    rccl = None
+    shard_obj = None
     lens = torch.zeros(world, dtype=torch.int64, device=dev)
+    if dist is not None:
+        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(x3hip.shard_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, src=0)
+        shard_obj = x3hip.Shard(ctx, bytes(idt.cpu().numpy().tobytes()), rank, world)
+        rccl = "librccl via x3_shard_* (ncclAllGather of %d lengths; grouped ncclSend/ncclRecv to rank 0)" % world
+
+    gather_in_step = dist is not None and not args.no_gather
 
     def step():
         rc = ctx.encode_dev(wav.data_ptr(), n, p, out.data_ptr(), cap, 0, off.data_ptr())
         assert rc == 0, (rc, ctx.last_error())
-        work = None
-        mode = "after" if os.environ.get("X3_BENCH_EXCHANGE") == "after" else "beside"  # (diagnostic switch)
-        if dist is not None and mode == "beside":
-            # the exchange step of the sharded path: sub-stream lengths -> global byte offsets.  Every rank decodes
-            # its own frames, so the 8-byte all-gather runs beside the decoder and is waited for at the end of the step
-            _, work = shard.exchange_lengths(off[F:F + 1], out=lens, async_op=True)
         rc = ctx.decode_dev(out.data_ptr(), cap, off.data_ptr(), F, p, back.data_ptr(), n, n_per_clip=n)
         assert rc == 0, (rc, ctx.last_error())
-        if dist is not None and mode == "after":
-            _, work = shard.exchange_lengths(off[F:F + 1], out=lens, async_op=True)
-        if work is not None:
-            work.wait()
+        if shard_obj is not None:
+            # exchange step 1: sub-stream lengths -> global byte offsets (8 bytes per rank; no rank's decode needs
+            # another rank's length, so it is enqueued behind the decoder rather than in front of it)
+            shard_obj.exchange_lengths(off.data_ptr() + 8 * F, lens.data_ptr())
+        if gather_in_step:
+            # exchange step 2: the whole .x3a byte stream on rank 0.  The lengths have to reach the host first
+            # (they are the send/recv sizes): one small copy + sync per step, part of the path's cost
+            lens_h = lens.cpu().tolist()
+            wb = whole_buf(sum(lens_h)) if rank == 0 else None
+            shard_obj.gather(out.data_ptr(), lens_h, 0, wb.data_ptr() if rank == 0 else None,
+                             wb.numel() if rank == 0 else 0)
+
+    whole_holder = {}
+
+    def whole_buf(total):
+        t = whole_holder.get("t")
+        if t is None or t.numel() < total:
+            t = torch.empty(int(total * 1.05) + 4096, dtype=torch.uint8, device=dev)
+            whole_holder["t"] = t
+        return t
 
     def barrier():
         if dist is not None:
@@ -143,31 +172,52 @@ def main():
         ktimes[name] = ms / max(cnt, 1)
     ctx.enable_kernel_timing(False)
 
-    # ---- bit-exactness of the timed output
+    # ---- bit-exactness of the timed output: decode(encode(x)) == x, and the stream == the CPU oracle's
     assert torch.equal(back, wav), "decode(encode(x)) != x"
     import oracle_lib as O
     offs = off.cpu().numpy()
     assert int(offs[-1]) == pos
-    for f in [0, F // 3, F - 1]:
-        s = wav[f * p.spf:(f + 1) * p.spf].cpu().numpy()
-        enc = out[int(offs[f]):int(offs[f + 1])].cpu().numpy()
-        assert np.array_equal(enc, O.encode(s)[1]), "frame %d differs from the CPU oracle" % f
+    verified = 0
+    if rank == 0:
+        import concurrent.futures as cf
+        frames = list(range(F)) if not args.no_verify_all else [0, F // 3, F - 1]
+        host_wav = wav.cpu().numpy()
+        host_out = out[:pos].cpu().numpy()
+        chunk = 256 if not args.no_verify_all else 1
+        jobs = [(f0, min(F, f0 + chunk)) for f0 in range(0, F, chunk)] if not args.no_verify_all else [(f, f + 1) for f in frames]
 
-    # ---- optional: reassembly gather of the sub-streams to rank 0 (timed on its own)
+        def vwork(j):
+            a, b = j
+            enc = O.encode(host_wav[a * p.spf:min(n, b * p.spf)])[1]
+            return np.array_equal(enc, host_out[int(offs[a]):int(offs[b])]), j
+        with cf.ThreadPoolExecutor(max_workers=min(64, os.cpu_count() or 1)) as ex:
+            for ok, j in ex.map(vwork, jobs):
+                assert ok, "frames %d..%d differ from the CPU oracle" % j
+                verified += j[1] - j[0]
+        del host_wav, host_out
+
+    # ---- the reassembly on rank 0 alone (and its result: the ranks' sub-streams back to back)
     gather = None
-    if dist is not None and not args.no_gather:
-        lens_h = lens.cpu()
+    if shard_obj is not None:
+        lens_h = lens.cpu().tolist()
+        starts = x3hip.shard_offsets(lens_h)
+        assert lens_h[rank] == pos and all(v % 2 == 0 for v in starts)
+        wb = whole_buf(starts[-1]) if rank == 0 else None
         torch.cuda.synchronize(dev)
         barrier()
         g0 = time.perf_counter()
-        whole = shard.gather_stream(out, lens_h, dst=0)
+        greps = 3
+        for _ in range(greps):
+            shard_obj.gather(out.data_ptr(), lens_h, 0, wb.data_ptr() if rank == 0 else None, wb.numel() if rank == 0 else 0)
         torch.cuda.synchronize(dev)
         barrier()
         g1 = time.perf_counter()
-        starts = shard.global_offsets(lens_h)
-        del whole
-        gather = {"ms": round((g1 - g0) * 1e3, 3), "bytes": int(starts[-1]),
-                  "pattern": "grouped ncclSend/ncclRecv to rank 0 (one xGMI link per peer)"}
+        if rank == 0:
+            assert torch.equal(wb[starts[0]:starts[1]], out[:pos]), "rank 0's own part of the gathered stream"
+        gather = {"ms": round((g1 - g0) / greps * 1e3, 3), "bytes": int(starts[-1]),
+                  "gb_s": round(starts[-1] / ((g1 - g0) / greps) / 1e9, 1),
+                  "pattern": "x3_shard_gather: grouped ncclSend/ncclRecv to rank 0 (one xGMI link per peer)",
+                  "in_timed_region": bool(gather_in_step)}
 
     # ---- CPU baseline: the oracle (port of the reference algorithm), 1 thread, bounded sample
     cpu = None
@@ -276,7 +326,23 @@ def main():
             return {"bound": "hbm", "kernel": kname[k], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": traffic.get(kname[k], {}).get("hbm_bytes_per_launch"),
+                    "traffic_source": "profiles/traffic.json (rocprofv3 PMC passes of this command, recorded; not measured in this run)",
                     "algorithmic_bytes": int(alg[k]), "avg_launch_ms": round(ktimes[k], 4)}
+        secs = n / 192000.0
+        kinds = {0: "all zeros", 1: "white noise", 2: "hydrophone-like noise", 3: "sine", 4: "random walk"}
+        if n == N_SAMPLES:
+            workload = "config 3: 1 h 192 kHz mono %s, encode+decode round trip per GPU" % kinds.get(args.kind, "?")
+        else:
+            workload = "%d samples (%.1f s at 192 kHz) mono %s, encode+decode round trip per GPU -- NOT config 3's size" % (
+                n, secs, kinds.get(args.kind, "?"))
+        if world == 1:
+            sharding = "one GPU"
+        elif args.strong:
+            sharding = "strong: one stream of %d samples cut into %d contiguous frame ranges (config 4 = 8 h over 8 GPUs)" % (args.total_samples, world)
+        else:
+            sharding = "weak: every rank encodes+decodes its own hour (N = 8 is config 4)"
+        if world > 1:
+            sharding += "; per step: all-gather of the sub-stream lengths" + ("" if not gather_in_step else " + reassembly of the whole stream on rank 0")
         res = {
             "metric": "Msamples/s encode+decode (bit-exact), 1h 192kHz mono; % HBM-read roofline",
             "value": round(value, 2),
@@ -286,14 +352,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "i16",
             "data": "synthetic",
-            "config": {"workload": "config 3: 1 h 192 kHz mono hydrophone-like noise, encode+decode round trip per GPU",
+            "config": {"workload": workload,
                        "samples_per_gpu": n, "frames_per_gpu": int(F), "stream_bytes_per_gpu": int(pos),
                        "bytes_per_sample": round(pos / n, 4), "block_len": 20, "blocks_per_frame": 500,
-                       "sharding": "frames sharded across ranks; all-gather of sub-stream lengths per step"},
+                       "signal_kind": args.kind, "frames_verified_vs_oracle": int(verified),
+                       "sharding": sharding},
             "roofline": roof(dominant),
             "roofline_all": {k: roof(k) for k in alg},
             "encode_read_frac": round(2 * n / (ktimes["encode"] / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -304,8 +371,12 @@ def main():
             res["host_buffer_api"] = host_api
         if gather is not None:
             res["gather"] = gather
+            res["rccl_ranks"] = world
+            res["rccl"] = rccl
         print(json.dumps(res), flush=True)
 
+    if shard_obj is not None:
+        shard_obj.close()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -100,6 +100,20 @@ int x3_ctx_sync(x3_ctx* ctx);
 /* Text of the last HIP failure seen by this context ("" if none). */
 const char* x3_last_error(const x3_ctx* ctx);
 
+/* Tuning / testing knobs of a context.  Each has an X3HIP_* environment variable that gives its initial value;
+ * the environment is read ONCE, in x3_ctx_create -- no later call looks at it.
+ *   "two_pass" (X3HIP_TWO_PASS)            1: always encode with the two-pass kernels (no persistent grid)
+ *   "stream_wgs" (X3HIP_STREAM_WGS)        workgroups per CU of the single-pass encoder, 0 = derived from occupancy
+ *   "decode_single" (X3HIP_DECODE_SINGLE)  1: single-wave decoder kernels only
+ *   "host_walk" (X3HIP_HOST_WALK)          frame walk of x3_decode_stream: 1 host, 0 GPU, -1 by stream size
+ *   "file_chunk_frames" (X3HIP_FILE_CHUNK_FRAMES), "file_workers" (X3HIP_FILE_WORKERS)   x3_wav_to_x3a / x3_x3a_to_wav
+ *   "verbose" (X3HIP_VERBOSE)
+ * x3_ctx_get_option also reads "encode_fallbacks" (launches of the single-pass encoder that timed out waiting for
+ * a non-resident workgroup and were redone by the two-pass kernels) and "stream_wgs_in_use".
+ * Unknown name: X3_ERR_BAD_ARG. */
+int x3_ctx_set_option(x3_ctx* ctx, const char* name, long long value);
+int x3_ctx_get_option(const x3_ctx* ctx, const char* name, long long* value);
+
 /* HIP-event timing of individual kernels on the context's stream (bench.py's roofline leg).
  * which: 0 = encode kernel, 1 = decode kernel, 2 = frame-size kernel, 3 = scan kernel,
  *        4 = frame check (header + payload CRC) kernel. */
@@ -208,8 +222,8 @@ int x3_x3a_decode(x3_ctx* ctx, const uint8_t* x3a, uint64_t len, int16_t* wav, u
  * an output .wav that cannot be created: X3_ERR_HOUND (`WavWriter::create(..)?`).
  * x3_x3a_to_wav leaves, like the reference's dropped WavWriter, a valid WAV of the samples in front of the
  * frame that ended the walk, also when it returns an error.
- * Tuning (environment): X3HIP_FILE_CHUNK_FRAMES (default 800 frames = 16 MB of samples),
- * X3HIP_FILE_WORKERS (default 4). */
+ * Tuning (x3_ctx_set_option): "file_chunk_frames" (default 800 frames = 16 MB of samples), "file_workers"
+ * (default 4; several workers encode their chunks with the two-pass kernels, see x3_encode_dev). */
 int x3_wav_to_x3a(x3_ctx* ctx, const char* wav_path, const char* x3a_path, uint64_t stats[6]);
 int x3_x3a_to_wav(x3_ctx* ctx, const char* x3a_path, const char* wav_path, uint64_t* n_samples,
                   uint64_t* frame_errors);
@@ -254,7 +268,7 @@ int x3_decode_result(x3_ctx* ctx, uint64_t* first_bad, int* first_bad_status, ui
 
 /* GPU-side frame walk of a device-resident stream whose frame offsets are not known (SURVEY 8f.2;
  * X3aReader::decode_next_frame, src/decodefile.rs:105-121 + decoder::read_frame_header, src/decoder.rs:69-118):
- * every even offset is tested for a valid frame header in parallel, the chain off -> off + 20 + payload_len is
+ * every byte offset is tested for a valid frame header in parallel, the chain off -> off + 20 + payload_len is
  * resolved by pointer doubling.  d_frame_offsets[0..*n_frames) receives the byte offsets of the frames the walk
  * pushes, d_wav_offsets their exclusive sample offsets (both need room for max_frames entries); *terminal is
  * how the walk ends behind them: X3_OK (data exhausted / payload runs past the end), a header error, or
@@ -265,6 +279,61 @@ int x3_index_dev(x3_ctx* ctx, const uint8_t* d_x3, uint64_t len, uint64_t max_fr
  * results and status as x3_decode_stream on the same bytes; samples go to d_wav[0..*n_out). */
 int x3_decode_stream_dev(x3_ctx* ctx, const uint8_t* d_x3, uint64_t len, const x3_params* p, int16_t* d_wav,
                          uint64_t wav_cap, uint64_t* n_out, uint64_t* frames_ok, uint64_t* frame_errors);
+
+/* ------------------------------------------------------------------ multi-GPU (no reference analogue) */
+
+/* Frames are independent and 20 + even bytes long, so GPU g encodes a contiguous range of whole frames into its own
+ * sub-stream and the sub-streams concatenate without padding; the only coupling is each sub-stream's byte offset.
+ * RCCL over xGMI (librccl is opened at run time, on first use): an all-gather of the lengths (8 bytes per rank), and
+ * for the reassembly on one rank a grouped ncclSend / ncclRecv, every peer on its own link to the root.
+ *
+ * x3_shard: ONE rank of a group -- one process (or thread) per GPU, the way torch.distributed.run starts bench.py.
+ * Rank 0 makes the id, the others get it out of band; x3_shard_create blocks until all `world` ranks have joined
+ * (ncclCommInitRank) and ties the shard to the context's device and stream. */
+typedef struct x3_shard x3_shard;
+#define X3_SHARD_ID_BYTES 128
+int x3_shard_unique_id(uint8_t id[X3_SHARD_ID_BYTES]);
+int x3_shard_create(x3_ctx* ctx, const uint8_t id[X3_SHARD_ID_BYTES], int rank, int world, x3_shard** shard);
+void x3_shard_destroy(x3_shard* shard);
+int x3_shard_rank(const x3_shard* shard);
+int x3_shard_world(const x3_shard* shard);
+/* Host arithmetic of the sharding.  Rank r owns frames [first, first + count): contiguous, the remainder spread one
+ * frame each over the first ranks; samples accordingly (the stream's last frame may be short); starts[r] = exclusive
+ * scan of the lengths, starts[world] = total. */
+void x3_shard_frame_range(uint64_t n_frames, int rank, int world, uint64_t* first, uint64_t* count);
+void x3_shard_sample_range(uint64_t n_samples, const x3_params* p, int rank, int world, uint64_t* first, uint64_t* count);
+void x3_shard_offsets(const uint64_t* lengths, int world, uint64_t* starts /* world + 1 */);
+/* Step 1, after x3_encode_dev of this rank's samples: all-gather of the sub-stream lengths.  d_len: DEVICE pointer to
+ * this rank's length (the last frame offset x3_encode_dev wrote, for a sub-stream that starts at 0); d_lengths:
+ * device array of `world` entries or NULL for the shard's own.  Asynchronous on the context's stream.
+ * x3_shard_exchange_length_value: the same for a length the host holds.  x3_shard_lengths waits and copies the
+ * shard's own array to the host. */
+int x3_shard_exchange_lengths(x3_shard* shard, const uint64_t* d_len, uint64_t* d_lengths);
+int x3_shard_exchange_length_value(x3_shard* shard, uint64_t len, uint64_t* d_lengths);
+int x3_shard_lengths(x3_shard* shard, uint64_t* lengths /* host, world */);
+/* Step 2 (optional: a deployment that writes the file in parallel, or decodes where it encoded, never needs it): the
+ * whole stream on `root`, d_dst[starts[r] ..) = rank r's d_sub[0 .. lengths[r]).  lengths: host array, identical on
+ * all ranks.  d_dst / dst_cap only count on the root.  Asynchronous on the context's stream. */
+int x3_shard_gather(x3_shard* shard, const uint8_t* d_sub, const uint64_t* lengths, int root, uint8_t* d_dst,
+                    uint64_t dst_cap, uint64_t* total);
+
+/* x3_mgpu: all GPUs from ONE process -- a context, a shard and a host thread per device.  x3_mgpu_encode /
+ * x3_mgpu_decode_stream take and return the same host buffers, bytes and status as x3_encode / x3_decode_stream
+ * (encoder::encode, src/encoder.rs:51-111; the walk of src/decodefile.rs:105-136): the samples are dealt out by frame
+ * ranges, every GPU encodes its range, the lengths are exchanged and the sub-streams gathered on devices[0] as above;
+ * decoding walks the header chain once, deals the frames out and copies every GPU's samples straight to their place
+ * (no collective).  x3_mgpu_ctx / x3_mgpu_shard hand out the per-device objects for device-resident use. */
+typedef struct x3_mgpu x3_mgpu;
+int x3_mgpu_create(const int* devices, int n, x3_mgpu** m);
+void x3_mgpu_destroy(x3_mgpu* m);
+int x3_mgpu_devices(const x3_mgpu* m);
+x3_ctx* x3_mgpu_ctx(x3_mgpu* m, int g);
+x3_shard* x3_mgpu_shard(x3_mgpu* m, int g); /* NULL when the group has one GPU */
+const char* x3_mgpu_last_error(const x3_mgpu* m);
+int x3_mgpu_encode(x3_mgpu* m, const int16_t* wav, uint64_t n, uint32_t n_channels, const x3_params* p, uint8_t* out,
+                   uint64_t out_cap, uint64_t start_pos, uint64_t* out_pos, uint64_t stats[6]);
+int x3_mgpu_decode_stream(x3_mgpu* m, const uint8_t* x3, uint64_t len, const x3_params* p, int16_t* wav,
+                          uint64_t wav_cap, uint64_t* n_out, uint64_t* frames_ok, uint64_t* frame_errors);
 
 /* ------------------------------------------------------------------ synthetic inputs (bench/tests) */
 

@@ -47,3 +47,19 @@ def test_bench_small_run_prints_the_contract_line():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in j["cpu_baseline"], k
     assert j["host_buffer_api"]["encode_msamples_s"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_distributed_path_with_one_rank():
+    """the N > 1 code path (torch.distributed start-up, x3_shard over librccl: all-gather of the lengths + gather to
+    rank 0 inside the step) on the one GPU a test box has: launched through torch.distributed.run with one rank"""
+    env = dict(os.environ, X3_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29517", BENCH, "--gpus", "1", "--steps", "2",
+                        "--warmup", "1", "--samples", "20000000", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["rccl_ranks"] == 1 and "x3_shard" in j["rccl"]
+    assert j["gather"]["in_timed_region"] is True and j["gather"]["bytes"] == j["config"]["stream_bytes_per_gpu"]
+    assert j["config"]["frames_verified_vs_oracle"] == j["config"]["frames_per_gpu"]

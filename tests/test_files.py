@@ -87,20 +87,20 @@ def test_oracle_file_errors(tmp_path):
 
 # ------------------------------------------------------------------ GPU: the streaming pipeline vs the oracle
 
-class _env:
-    def __init__(self, **kv):
-        self.kv = kv
+class _opt:
+    """options of the context (x3_ctx_set_option) for a with-block"""
+
+    def __init__(self, ctx, **kv):
+        self.ctx, self.kv = ctx, kv
 
     def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kv}
-        os.environ.update(self.kv)
+        self.old = {k: self.ctx.get_option(k) for k in self.kv}
+        for k, v in self.kv.items():
+            self.ctx.set_option(k, v)
 
     def __exit__(self, *a):
         for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+            self.ctx.set_option(k, v)
 
 
 @pytest.fixture(scope="module")
@@ -142,7 +142,7 @@ def decode_both(ctx, tmp_path, x3a_path, tag):
 @pytest.mark.gpu
 @pytest.mark.parametrize("chunk_frames,workers", [(1, 3), (3, 2), (7, 4), (3200, 3), (2, 1)])
 def test_files_match_oracle(ctx, tmp_path, chunk_frames, workers):
-    with _env(X3HIP_FILE_CHUNK_FRAMES=str(chunk_frames), X3HIP_FILE_WORKERS=str(workers)):
+    with _opt(ctx, file_chunk_frames=chunk_frames, file_workers=workers):
         for kind, n, rate in ((2, 234567, 192000), (1, 70001, 8000), (4, 30000, 44100), (3, 10000, 96000), (0, 1, 1000),
                               (0, 0, 48000)):
             wav = x3hip.synth(kind, 50 + kind, 0, n) if n else np.zeros(0, dtype=np.int16)
@@ -156,7 +156,7 @@ def test_files_match_oracle(ctx, tmp_path, chunk_frames, workers):
 def test_wav_container_variants(ctx, tmp_path):
     wav = x3hip.synth(2, 61, 0, 25000)
     a = str(tmp_path / "v.wav")
-    with _env(X3HIP_FILE_CHUNK_FRAMES="1"):
+    with _opt(ctx, file_chunk_frames=1):
         write_wav(a, wav, 22050, extra_chunks=[(b"LIST", b"odd"), (b"bext", bytes(40))])
         both_ways(ctx, tmp_path, read(a), 22050, "chunks")
         write_wav(a, wav, 22050, extensible=True)
@@ -226,7 +226,7 @@ def test_broken_archives_match_oracle(ctx, tmp_path, chunk_frames, workers):
     cases["header_cut"] = good[:100]
     b = bytearray(good); b[offs[3] + 4] = 0; b[offs[3] + 5] = 0; _refresh(b, offs[3]); cases["zero_samples"] = b
     b = bytearray(good); b[40] ^= 1; cases["xml_crc"] = b  # XML payload CRC is not checked by the reader
-    with _env(X3HIP_FILE_CHUNK_FRAMES=str(chunk_frames), X3HIP_FILE_WORKERS=str(workers)):
+    with _opt(ctx, file_chunk_frames=chunk_frames, file_workers=workers):
         seen = set()
         for name, b in cases.items():
             p = str(tmp_path / (name + ".x3a"))

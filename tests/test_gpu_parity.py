@@ -53,12 +53,12 @@ def check_decode(ctx, x3, stream, params=None, wav_cap=None):
     r_o = O.decode_stream(stream, oparams(params), wav_cap=wav_cap)
     # x3_decode_stream walks the frame headers on the host for short streams and on the GPU for long ones:
     # both walks against the oracle, whatever the size
-    for host_walk in ("1", "0"):
-        os.environ["X3HIP_HOST_WALK"] = host_walk
+    for host_walk in (1, 0):
+        ctx.set_option("host_walk", host_walk)
         try:
             r_g = ctx.decode_stream(stream, params, wav_cap=wav_cap)
         finally:
-            del os.environ["X3HIP_HOST_WALK"]
+            ctx.set_option("host_walk", -1)
         assert (r_g[0], r_g[2], r_g[3]) == (r_o[0], r_o[2], r_o[3]), (host_walk, r_g[0], r_g[2:], r_o[0], r_o[2:])
         assert np.array_equal(r_g[1], r_o[1]), host_walk
     return r_o
@@ -465,10 +465,12 @@ def test_full_size_config3_roundtrip(ctx, x3):
     assert torch.equal(back, wav)
     offs = off.cpu().numpy()
     assert offs[0] == 0 and offs[-1] == pos and np.all(np.diff(offs) >= 22) and np.all(offs % 2 == 0)
-    for f in [0, 1, 12345, F // 2, F - 2, F - 1]:
-        s = wav[f * 10000:(f + 1) * 10000].cpu().numpy()
-        enc = out[int(offs[f]):int(offs[f + 1])].cpu().numpy()
-        assert np.array_equal(enc, O.encode(s)[1]), f
+    # the WHOLE stream against the CPU oracle, all 69 120 frames: chunks of whole frames on a thread pool (the
+    # oracle is C behind ctypes, which releases the GIL).  A round trip alone would also pass an encoder and a
+    # decoder that are wrong in the same way.
+    host_wav = wav.cpu().numpy()
+    host_out = out[:pos].cpu().numpy()
+    _compare_stream_with_oracle(host_wav, host_out, offs, 10000, 1, n)
     # the GPU-side frame walk finds the same 69 120 frames in the bare byte stream
     import time
     fo = torch.empty(F + 8, dtype=torch.int64, device=dev)
@@ -486,22 +488,112 @@ def test_full_size_config3_roundtrip(ctx, x3):
     assert torch.equal(back, wav)
 
 
-class _env:
-    """set an environment switch of libx3hip.so (read by the library at every call) for a with-block"""
+def _compare_stream_with_oracle(host_wav, host_out, offs, spf, n_clips, n_per_clip, clip_stride=None, chunk_frames=256,
+                                clips=None):
+    """every frame of the device-encoded stream == the oracle's encoding of the same samples.  offs: F+1 byte
+    offsets; frames never cross clips, so a chunk of whole frames of one clip encodes to a contiguous byte range."""
+    import concurrent.futures as cf
+    clip_stride = n_per_clip if clip_stride is None else clip_stride
+    fpc = (n_per_clip + spf - 1) // spf
+    jobs = []
+    for c in (range(n_clips) if clips is None else clips):
+        for f0 in range(0, fpc, chunk_frames):
+            jobs.append((c, f0, min(fpc, f0 + chunk_frames)))
 
-    def __init__(self, **kv):
-        self.kv = kv
+    def work(job):
+        c, f0, f1 = job
+        a = c * clip_stride + f0 * spf
+        b = c * clip_stride + min(n_per_clip, f1 * spf)
+        rc, enc, _ = O.encode(host_wav[a:b])
+        lo, hi = int(offs[c * fpc + f0]), int(offs[c * fpc + f1])
+        return rc == 0 and enc.size == hi - lo and np.array_equal(enc, host_out[lo:hi]), job
+
+    bad = []
+    with cf.ThreadPoolExecutor(max_workers=min(64, os.cpu_count() or 1)) as ex:
+        for ok, job in ex.map(work, jobs):
+            if not ok:
+                bad.append(job)
+    assert not bad, "frames differ from the CPU oracle in (clip, first frame, last frame): %s" % bad[:5]
+    return len(jobs)
+
+
+def test_full_size_config5_batch(ctx, x3):
+    """BASELINE config 5 at FULL size: 1000 clips x 1 min @ 96 kHz = 5.76 G samples (> 2^32: 64-bit sample and byte
+    indexing), 576 000 frames, encoded by one launch set and decoded from the encoder's frame index, all in HBM.
+    Size-independent properties over everything (identity, header chain, statistics) and the CPU oracle on whole
+    sampled clips -- the first ones, the last one (sample indices beyond 2^32) and a spread in between."""
+    torch = pytest.importorskip("torch")
+    n_clips, n_per = 1000, 5_760_000
+    n = n_clips * n_per
+    p = x3.Params.default()
+    fpc = n_per // 10000
+    F = fpc * n_clips
+    dev = torch.device("cuda:0")
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 34 * (1 << 30):
+        pytest.skip("needs ~30 GB of HBM")
+    wav = torch.empty(n, dtype=torch.int16, device=dev)
+    for c in range(n_clips):
+        ctx.synth_dev(2 if c % 7 else 4, 0x58330005 + c, 0, n_per, wav.data_ptr() + 2 * c * n_per)
+    ctx.sync()
+    cap = int(n * 0.75)
+    out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    off = torch.empty(F + 1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize(dev)
+    assert ctx.encode_dev(wav.data_ptr(), n_per, p, out.data_ptr(), cap, 0, off.data_ptr(), n_clips=n_clips) == 0
+    rc, pos, stats = ctx.encode_result()
+    assert rc == 0 and int(stats.sum()) == n - F, (rc, pos, ctx.last_error())
+    assert ctx.get_option("encode_fallbacks") == 0
+    back = torch.zeros(n, dtype=torch.int16, device=dev)
+    torch.cuda.synchronize(dev)
+    assert ctx.decode_dev(out.data_ptr(), pos, off.data_ptr(), F, p, back.data_ptr(), n, n_per_clip=n_per,
+                          n_clips=n_clips) == 0
+    assert ctx.decode_result() == (0, F, 0, n)
+    assert torch.equal(back, wav)
+    del back
+    # header chain: every frame's header says what the index says
+    offs = off.cpu().numpy()
+    d = np.diff(offs)
+    assert offs[0] == 0 and offs[-1] == pos and np.all(d >= 22) and np.all(offs % 2 == 0)
+    o_t = off[:F]
+    hdr = torch.stack([out[o_t + k] for k in (0, 1, 4, 5, 6, 7)], dim=1).cpu().numpy().astype(np.int64)
+    assert np.all(hdr[:, 0] == 0x78) and np.all(hdr[:, 1] == 0x33)
+    assert np.all(hdr[:, 2] * 256 + hdr[:, 3] == 10000)
+    assert np.array_equal(hdr[:, 4] * 256 + hdr[:, 5], d - 20)
+    # the oracle on whole clips: 24 of them, the last one included
+    clips = sorted(set([0, 1, 2, 6, 7, 499, 500, 998, 999] + list(range(13, 1000, 67))))
+    assert len(clips) >= 20 and clips[-1] == n_clips - 1
+    host_wav = np.empty(n, dtype=np.int16)      # only the sampled clips are filled in
+    host_out = np.empty(pos, dtype=np.uint8)
+    for c in clips:
+        host_wav[c * n_per:(c + 1) * n_per] = wav[c * n_per:(c + 1) * n_per].cpu().numpy()
+        lo, hi = int(offs[c * fpc]), int(offs[(c + 1) * fpc])
+        host_out[lo:hi] = out[lo:hi].cpu().numpy()
+    assert (clips[-1] + 1) * n_per > 2 ** 32
+    jobs = _compare_stream_with_oracle(host_wav, host_out, offs, 10000, n_clips, n_per, clips=clips, chunk_frames=96)
+    assert jobs == len(clips) * 6
+    # the GPU-side frame walk over the 3 GB stream finds the same 576 000 frames
+    fo = torch.empty(F + 8, dtype=torch.int64, device=dev)
+    wo = torch.empty(F + 8, dtype=torch.int64, device=dev)
+    rc, nf, ns, term = ctx.index_dev(out.data_ptr(), pos, F + 8, fo.data_ptr(), wo.data_ptr())
+    assert (rc, nf, ns, term) == (0, F, n, 0)
+    assert torch.equal(fo[:F], off[:F])
+
+
+class _opt:
+    """set an option of the context (x3_ctx_set_option) for a with-block"""
+
+    def __init__(self, ctx, **kv):
+        self.ctx, self.kv = ctx, kv
 
     def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kv}
-        os.environ.update(self.kv)
+        self.old = {k: self.ctx.get_option(k) for k in self.kv}
+        for k, v in self.kv.items():
+            self.ctx.set_option(k, v)
 
     def __exit__(self, *a):
         for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+            self.ctx.set_option(k, v)
 
 
 def test_decoder_kernels_agree(ctx, x3):
@@ -527,7 +619,7 @@ def test_decoder_kernels_agree(ctx, x3):
         cases.append(s)
     for s in cases:
         a = ctx.decode_stream(s, x3.Params.default(), wav_cap=wav.size + 70000)
-        with _env(X3HIP_DECODE_SINGLE="1"):
+        with _opt(ctx, decode_single=1):
             b = ctx.decode_stream(s, x3.Params.default(), wav_cap=wav.size + 70000)
         assert a[0] == b[0] and a[2:] == b[2:] and np.array_equal(a[1], b[1])
         o = O.decode_stream(s, O.Params.default(), wav_cap=wav.size + 70000)
@@ -540,7 +632,7 @@ def test_encoder_kernels_agree(ctx, x3):
     for kind, n in ((2, 1_234_567), (4, 10_000 * 700 + 1), (0, 20_001)):
         wav = x3.synth(kind, 120 + kind, 0, n)
         a = ctx.encode(wav, p)
-        with _env(X3HIP_TWO_PASS="1"):
+        with _opt(ctx, two_pass=1):
             b = ctx.encode(wav, p)
         assert a[0] == b[0] == 0 and np.array_equal(a[1], b[1]) and a[2].tolist() == b[2].tolist()
 
@@ -624,18 +716,55 @@ def test_encoder_falls_back_when_grid_not_resident(x3):
     (forced here: 3 workgroups per CU where 2 fit) must time out in bounded time and x3_encode_result must hand
     back the two-pass kernels' bit-exact result"""
     import time
-    with _env(X3HIP_STREAM_WGS="3"):
-        c = x3.Context(0)
-        try:
-            wav = x3.synth(2, 321, 0, 10000 * 1500 + 17)
-            t0 = time.perf_counter()
-            rc, out, stats = c.encode(wav, x3.Params.default())
-            dt = time.perf_counter() - t0
-        finally:
-            c.close()
+    c = x3.Context(0)
+    try:
+        natural = None
+        wav = x3.synth(2, 321, 0, 10000 * 1500 + 17)
+        rc, _, _ = c.encode(wav[:30000], x3.Params.default())
+        natural = c.get_option("stream_wgs_in_use")
+        assert rc == 0 and natural >= 1
+        c.set_option("stream_wgs", natural + 1)
+        t0 = time.perf_counter()
+        rc, out, stats = c.encode(wav, x3.Params.default())
+        dt = time.perf_counter() - t0
+        assert c.get_option("encode_fallbacks") == 1
+    finally:
+        c.close()
     rco, oo, so = O.encode(wav)
     assert rc == rco == 0 and np.array_equal(out, oo) and stats.tolist() == so.tolist()
     assert dt < 20.0, dt
+
+
+def test_encoder_fallback_leaves_the_prefix_alone(x3):
+    """x3_encode_dev with start_pos > 0 promises output at d_out[start_pos..) only.  A workgroup whose size wait
+    times out has no offset for its frames: none of them may be written (they used to land at d_out + 0), and the
+    two-pass re-run rewrites start_pos.. only -- a sentinel-filled prefix (an archive header, an earlier
+    sub-stream) must survive the fallback."""
+    c = x3.Context(0)
+    try:
+        p = x3.Params.default()
+        rc, _, _ = c.encode(x3.synth(2, 1, 0, 30000), p)
+        natural = c.get_option("stream_wgs_in_use")
+        c.set_option("stream_wgs", natural + 1)
+        n = 10000 * 1500 + 17
+        wav = x3.synth(2, 654, 0, n)
+        for start_pos in (4096, 321):
+            d_wav = c.alloc(2 * n + 64)
+            c.upload(d_wav, wav)
+            cap = start_pos + x3.lib().x3_encode_bound(n, C.byref(p)) + 16
+            d_out = c.alloc(cap)
+            c.upload(d_out, np.full(cap, 0xA5, dtype=np.uint8))
+            before = c.get_option("encode_fallbacks")
+            assert c.encode_dev(d_wav, n, p, d_out, cap, start_pos) == 0
+            rc, pos, stats = c.encode_result()
+            assert rc == 0 and c.get_option("encode_fallbacks") == before + 1
+            got = c.download(d_out, (pos + 3) & ~3)[:pos]
+            rco, oo, so = O.encode(wav, start_pos=start_pos)
+            assert pos == oo.size and np.array_equal(got[(start_pos + 1) & ~1:], oo[(start_pos + 1) & ~1:])
+            assert (got[:start_pos] == 0xA5).all(), "bytes in front of start_pos were overwritten"
+            c.free(d_wav); c.free(d_out)
+    finally:
+        c.close()
 
 
 def test_random_parameter_sweep(ctx, x3):
@@ -719,3 +848,57 @@ def test_decode_dev_survives_wild_frame_offsets(ctx, x3):
                 assert first_bad < F and st != 0 and first_bad == int(np.min(k)) or trial == 0
     finally:
         ctx.free(d_x3); ctx.free(d_off); ctx.free(d_wav)
+
+
+# ------------------------------------------------------------------ multi-GPU entry points on the one GPU of a test box
+
+def test_shard_world_of_one_over_rccl(ctx, x3):
+    """x3_shard_* with world = 1: librccl is opened, a communicator is built, the all-gather and the gather run --
+    the same calls every rank of an 8-GPU job makes (the offset arithmetic for more ranks is covered on the CPU:
+    tests/host_cpp/test_shard_logic.cpp, tests/test_sharding_gloo.py)"""
+    p = x3.Params.default()
+    n = 1_234_567
+    wav = x3.synth(2, 4711, 0, n)
+    F = x3.lib().x3_num_frames(n, C.byref(p))
+    cap = x3.lib().x3_encode_bound(n, C.byref(p))
+    d_wav, d_out, d_off, d_whole, d_len = ctx.alloc(2 * n + 64), ctx.alloc(cap), ctx.alloc(8 * (F + 1)), ctx.alloc(cap), ctx.alloc(64)
+    ctx.upload(d_wav, wav)
+    sh = x3.Shard(ctx, x3.shard_unique_id(), 0, 1)
+    try:
+        assert ctx.encode_dev(d_wav, n, p, d_out, cap, 0, d_off) == 0
+        sh.exchange_lengths(d_off + 8 * F)            # the shard's own array
+        sh.exchange_lengths(d_off + 8 * F, d_len)     # a caller's array
+        rc, pos, _ = ctx.encode_result()
+        assert rc == 0
+        lens = sh.lengths()
+        assert lens == [pos] and ctx.download(d_len, 8, np.uint64).tolist() == [pos]
+        assert sh.gather(d_out, lens, 0, d_whole, cap) == pos
+        ctx.sync()
+        ref = O.encode(wav)[1]
+        assert np.array_equal(ctx.download(d_whole, (pos + 3) & ~3)[:pos], ref)
+        with pytest.raises(x3.X3Error):
+            sh.gather(d_out, lens, 0, d_whole, pos - 2)  # destination too small
+    finally:
+        sh.close()
+        for d in (d_wav, d_out, d_off, d_whole, d_len):
+            ctx.free(d)
+
+
+def test_mgpu_with_one_device(x3):
+    """x3_mgpu_* (all GPUs from one process) on a group of one: same bytes and status as the single-context calls"""
+    m = x3.MultiGpu([0])
+    try:
+        for kind, n, sp in ((2, 345_678, 0), (4, 10_000, 3), (1, 25_001, 0), (0, 1, 1)):
+            wav = x3.synth(kind, 31 + kind, 0, n)
+            rc, out, stats = m.encode(wav, start_pos=sp)
+            rco, oo, so = O.encode(wav, start_pos=sp)
+            assert rc == rco == 0 and np.array_equal(out[sp:], oo[sp:]) and stats.tolist() == so.tolist()
+            body = oo[(sp + 1) & ~1:]
+            r = m.decode_stream(body, wav_cap=n)
+            assert r[0] == 0 and np.array_equal(r[1], wav) and r[3] == 0
+        assert m.encode(wav, n_channels=2)[0] == x3.ERR_MORE_THAN_ONE_CHANNEL
+        assert m.encode(x3.synth(2, 1, 0, 30000), cap=100)[0] == x3.ERR_BYTE_WRITER_INSUFFICIENT_MEMORY
+    finally:
+        m.close()
+    with pytest.raises(x3.X3Error):
+        x3.MultiGpu([0, 0])   # one rank per GPU

@@ -25,6 +25,19 @@ def build():
                     "-Wl,-rpath," + libdir, "-Wl,-rpath," + odir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
 
 
+def test_shard_offset_logic_two_to_eight_host_threads():
+    """tests/host_cpp/test_shard_logic.cpp: host threads play the ranks of the multi-GPU path (no GPU)"""
+    O.lib()
+    x3hip.lib()
+    exe = os.path.join(ROOT, "tests", "host_cpp", "test_shard_logic")
+    src = exe + ".cpp"
+    libdir = os.path.dirname(x3hip.LIB_PATH)
+    odir = os.path.join(ROOT, "oracle")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-pthread", "-o", exe, src, "-L" + libdir, "-lx3hip", "-L" + odir,
+                    "-lx3oracle", "-Wl,-rpath," + libdir, "-Wl,-rpath," + odir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    subprocess.run([exe], check=True, timeout=120)
+
+
 def test_x3_hpp_host_only():
     build()
     subprocess.run([EXE, "--host-only"], check=True, timeout=60)

@@ -124,3 +124,22 @@ def test_oracle_roundtrip_on_synthetic_kinds():
         assert rc == 0 and int(stats.sum()) == wav.size - 5
         rc, back, fok, ferr = O.decode_stream(stream, wav_cap=wav.size)
         assert (rc, fok, ferr) == (0, 5, 0) and np.array_equal(back, wav)
+
+
+def test_shard_arithmetic_matches_the_python_harness():
+    """x3_shard_frame_range / sample_range / offsets (C ABI, host arithmetic) == x3hip/shard.py (the gloo test harness)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "x3-rust_amd"))
+    from x3hip import shard
+    p = x3hip.Params.default()
+    for F in [0, 1, 2, 7, 8, 9, 69120, 552960]:
+        for world in [1, 2, 3, 4, 8]:
+            for r in range(world):
+                lo, hi = shard.frame_range(F, r, world)
+                assert x3hip.shard_frame_range(F, r, world) == (lo, hi - lo)
+    for n in [0, 1, 5, 9999, 10000, 10001, 123457, 691_200_000, 5_529_600_000]:
+        for world in [1, 2, 3, 8]:
+            got = [x3hip.shard_sample_range(n, p, r, world) for r in range(world)]
+            assert got == [shard.sample_range(n, 10000, r, world) for r in range(world)]
+            assert sum(c for _, c in got) == n
+    assert x3hip.shard_offsets([10, 0, 22, 4]) == [0, 10, 10, 32, 36] == shard.global_offsets([10, 0, 22, 4])

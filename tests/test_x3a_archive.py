@@ -52,10 +52,10 @@ def test_archive_header_errors_match_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("host_walk", ["1", "0"])
-def test_x3a_roundtrip_matches_oracle(host_walk, monkeypatch):
-    monkeypatch.setenv("X3HIP_HOST_WALK", host_walk)  # the frame walk on the host / on the GPU (x3_index_kernels.h)
+@pytest.mark.parametrize("host_walk", [1, 0])
+def test_x3a_roundtrip_matches_oracle(host_walk):
     ctx = x3hip.Context(0)
+    ctx.set_option("host_walk", host_walk)  # the frame walk on the host / on the GPU (x3_index_kernels.h)
     try:
         for kind, n, rate in ((2, 123457, 192000), (4, 10000, 44100), (1, 25001, 8000), (0, 1, 96000)):
             wav = x3hip.synth(kind, 900 + kind, 0, n)

@@ -27,7 +27,7 @@ with open(src, "wb") as f:
 try:
     for cf in a.chunk_frames.split(","):
         for w in a.workers.split(","):
-            os.environ["X3HIP_FILE_WORKERS"] = w; os.environ["X3HIP_FILE_CHUNK_FRAMES"] = cf
+            ctx.set_option("file_workers", int(w)); ctx.set_option("file_chunk_frames", int(cf))
             for rep in range(2):
                 t0 = time.perf_counter(); rc, stats = ctx.wav_to_x3a(src, x3a); t1 = time.perf_counter()
                 rc2, ns, ferr = ctx.x3a_to_wav(x3a, back); t2 = time.perf_counter()

@@ -36,7 +36,28 @@ struct KernelTimer {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> used, pool;
 };
 
+// Tuning / testing knobs of a context (x3_ctx_set_option).  The X3HIP_* environment variables give their
+// initial values and are read ONCE, when the context is created; no call reads the environment afterwards.
+struct X3Opts {
+  int two_pass = 0;           // X3HIP_TWO_PASS: always use the two-pass encoder kernels
+  int stream_wgs = 0;         // X3HIP_STREAM_WGS: workgroups per CU of the single-pass encoder (0 = derive)
+  int decode_single = 0;      // X3HIP_DECODE_SINGLE: single-wave decoder kernels only
+  int host_walk = -1;         // X3HIP_HOST_WALK: frame walk of x3_decode_stream on the host (1) / GPU (0) / by size (-1)
+  int verbose = 0;            // X3HIP_VERBOSE
+  long long file_chunk_frames = 800;  // X3HIP_FILE_CHUNK_FRAMES: 16 MB of samples per chunk (tools/file_bench.py)
+  int file_workers = 4;       // X3HIP_FILE_WORKERS
+#ifdef X3_PROFILING
+  // profiling builds only (-DX3_PROFILING): never in the shipped library
+  int check_serial = 0;       // X3HIP_CHECK_SERIAL: the check pass in front of the decoder, same stream
+  int no_check = 0;           // X3HIP_PROFILE_NO_CHECK: time the decoder alone (payload CRCs NOT verified)
+  int check_wgs = 8;          // X3HIP_CHECK_WGS: check-kernel workgroups per CU
+  int dyn_lds = 0;            // X3HIP_DECODE_DYN_LDS: extra LDS per decoder group (occupancy experiments)
+#endif
+};
+
 struct x3_ctx {
+  X3Opts opt;
+  unsigned long long encode_fallbacks = 0;  // launches of the single-pass encoder that timed out (two-pass re-run)
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -122,7 +143,28 @@ static uint32_t gf_xpow_host(uint64_t e) {  // x^e mod P
   return result;
 }
 
+static void opts_from_env(X3Opts* o) {
+  auto geti = [](const char* name, long long dflt) -> long long {
+    const char* e = std::getenv(name);
+    return e && *e ? std::strtoll(e, nullptr, 10) : dflt;
+  };
+  o->two_pass = std::getenv("X3HIP_TWO_PASS") ? 1 : 0;
+  o->stream_wgs = (int)std::max(0ll, geti("X3HIP_STREAM_WGS", 0));
+  o->decode_single = std::getenv("X3HIP_DECODE_SINGLE") ? 1 : 0;
+  if (const char* e = std::getenv("X3HIP_HOST_WALK")) o->host_walk = e[0] == '0' ? 0 : 1;
+  o->verbose = std::getenv("X3HIP_VERBOSE") ? 1 : 0;
+  o->file_chunk_frames = std::max(1ll, geti("X3HIP_FILE_CHUNK_FRAMES", o->file_chunk_frames));
+  o->file_workers = (int)std::max(1ll, std::min(16ll, geti("X3HIP_FILE_WORKERS", o->file_workers)));
+#ifdef X3_PROFILING
+  o->check_serial = std::getenv("X3HIP_CHECK_SERIAL") ? 1 : 0;
+  o->no_check = std::getenv("X3HIP_PROFILE_NO_CHECK") ? 1 : 0;
+  o->check_wgs = (int)std::max(1ll, geti("X3HIP_CHECK_WGS", o->check_wgs));
+  o->dyn_lds = (int)std::max(0ll, geti("X3HIP_DECODE_DYN_LDS", 0));
+#endif
+}
+
 static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
+  opts_from_env(&c->opt);
   int count = 0;
   HIPCHK(c, hipGetDeviceCount(&count));
   if (device < 0 || device >= count) {
@@ -311,6 +353,36 @@ extern "C" int x3_ctx_sync(x3_ctx* c) {
 }
 
 extern "C" const char* x3_last_error(const x3_ctx* c) { return c ? c->last_error.c_str() : ""; }
+
+extern "C" int x3_ctx_set_option(x3_ctx* c, const char* name, long long value) {
+  if (!c || !name) return X3_ERR_BAD_ARG;
+  const std::string n(name);
+  if (n == "two_pass") c->opt.two_pass = value != 0;
+  else if (n == "stream_wgs") { c->opt.stream_wgs = (int)std::max(0ll, value); c->stream_wg_per_cu = -1; }
+  else if (n == "decode_single") c->opt.decode_single = value != 0;
+  else if (n == "host_walk") c->opt.host_walk = value < 0 ? -1 : (value != 0);
+  else if (n == "verbose") c->opt.verbose = value != 0;
+  else if (n == "file_chunk_frames") c->opt.file_chunk_frames = std::max(1ll, value);
+  else if (n == "file_workers") c->opt.file_workers = (int)std::max(1ll, std::min(16ll, value));
+  else return X3_ERR_BAD_ARG;
+  return X3_OK;
+}
+
+extern "C" int x3_ctx_get_option(const x3_ctx* c, const char* name, long long* value) {
+  if (!c || !name || !value) return X3_ERR_BAD_ARG;
+  const std::string n(name);
+  if (n == "two_pass") *value = c->opt.two_pass;
+  else if (n == "stream_wgs") *value = c->opt.stream_wgs;
+  else if (n == "decode_single") *value = c->opt.decode_single;
+  else if (n == "host_walk") *value = c->opt.host_walk;
+  else if (n == "verbose") *value = c->opt.verbose;
+  else if (n == "file_chunk_frames") *value = c->opt.file_chunk_frames;
+  else if (n == "file_workers") *value = c->opt.file_workers;
+  else if (n == "encode_fallbacks") *value = (long long)c->encode_fallbacks;  // read-only counter
+  else if (n == "stream_wgs_in_use") *value = c->stream_wg_per_cu;            // read-only, -1 before the first launch
+  else return X3_ERR_BAD_ARG;
+  return X3_OK;
+}
 
 extern "C" const char* x3_strerror(int s) {
   static const char* names[] = {"Ok", "Io", "Hound", "BitPack", "InvalidEncodingThresh", "OutOfBoundsInverse",
@@ -587,8 +659,7 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
   // ---- single-pass path: default block length, 16-byte aligned frames (see x3_encode_stream_kernel.h)
   const bool stream_path = p->block_len == 20 && pl.nthr == 512 && (spf % 8) == 0 &&
                            (b->n_clips == 1 || (b->clip_stride % 8) == 0) &&
-                           (reinterpret_cast<uintptr_t>(d_wav) & 15u) == 0 && !c->force_two_pass &&
-                           !std::getenv("X3HIP_TWO_PASS");
+                           (reinterpret_cast<uintptr_t>(d_wav) & 15u) == 0 && !c->force_two_pass && !c->opt.two_pass;
   c->last_enc = {d_wav, *b, *p, spf, d_out, out_cap, start_pos, d_frame_offsets};
   if (stream_path) {
     if (c->stream_wg_per_cu < 0) {
@@ -610,8 +681,8 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
       c->stream_wg_per_cu = std::max(0, std::min(std::min(nb, 4), std::min(by_regs, by_lds)));
       // experiments and the fallback test: force a grid (one that is too large cannot be resident: the size
       // waits time out and x3_encode_result re-encodes with the two-pass kernels)
-      if (const char* e = std::getenv("X3HIP_STREAM_WGS")) c->stream_wg_per_cu = std::max(1, std::atoi(e));
-      if (std::getenv("X3HIP_VERBOSE"))
+      if (c->opt.stream_wgs > 0) c->stream_wg_per_cu = c->opt.stream_wgs;
+      if (c->opt.verbose)
         std::fprintf(stderr, "x3hip: stream encoder %d VGPRs, occupancy API %d, by_regs %d, by_lds %d -> %d workgroups/CU\n",
                      fa.numRegs, nb, by_regs, by_lds, c->stream_wg_per_cu);
     }
@@ -697,7 +768,8 @@ extern "C" int x3_encode_result(x3_ctx* c, uint64_t* out_pos, uint64_t stats[6])
   if (c->h_status[1] == X3D_SIZE_WAIT_TIMEOUT) {
     // the single-pass kernel's workgroups were not all resident (GPU shared with other work): its
     // bounded wait for frame sizes gave up.  Encode again with the two-pass kernels, which need no residency.
-    if (std::getenv("X3HIP_VERBOSE"))
+    ++c->encode_fallbacks;
+    if (c->opt.verbose)
       std::fprintf(stderr, "x3hip: stream encoder gave up waiting for frame sizes (grid not co-resident): two-pass fallback\n");
     c->force_two_pass = true;
     auto a = c->last_enc;
@@ -848,17 +920,22 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
   if ((rc = ensure(c, c->dec_cstatus, F * sizeof(int32_t)))) return rc;
   // fork: header + payload-CRC pass on the side stream, decoder on the main stream (independent;
   // the decoder's one-wave-per-SIMD dependency chains leave the CUs mostly idle)
-  // X3HIP_CHECK_SERIAL (experiments): the check pass in front of the decoder on the same stream
-  hipStream_t check_stream = std::getenv("X3HIP_CHECK_SERIAL") ? c->stream : c->stream2;
+#ifdef X3_PROFILING
+  hipStream_t check_stream = c->opt.check_serial ? c->stream : c->stream2;
+  const bool no_check = c->opt.no_check != 0;
+  const uint64_t check_wgs_per_cu = (uint64_t)c->opt.check_wgs;
+#else
+  hipStream_t check_stream = c->stream2;
+  const bool no_check = false;
+  const uint64_t check_wgs_per_cu = 8;
+#endif
   HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
   HIPCHK(c, hipStreamWaitEvent(check_stream, c->ev_fork, 0));
-  if (std::getenv("X3HIP_PROFILE_NO_CHECK")) {
-    // profiling aid only: time the decoder without the check pass beside it (payload CRCs are NOT verified)
+  if (no_check) {
+    // profiling builds only: time the decoder without the check pass beside it (payload CRCs are NOT verified)
     HIPCHK(c, hipMemsetAsync(c->dec_cstatus.p, 0, F * sizeof(int32_t), c->stream2));
   } else {
     TimerScope ts(c, 4, check_stream);
-    uint64_t check_wgs_per_cu = 8;
-    if (const char* e = std::getenv("X3HIP_CHECK_WGS")) check_wgs_per_cu = std::max(1, std::atoi(e));
     const uint64_t check_grid = std::min<uint64_t>((F + 3) / 4, (uint64_t)c->n_cus * check_wgs_per_cu);
     hipLaunchKernelGGL(x3_frame_check_kernel, dim3((unsigned)check_grid), dim3(256), 0, check_stream,
                        reinterpret_cast<const uint32_t*>(d_x3), x3_len, d_frame_offsets, F,
@@ -874,14 +951,24 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
       const uint32_t level = k == 0 ? 1u : (1u << dp.k[k]);
       fast = fast && (dp.inv_len[k] / level + 1 + widths[k] <= 32);
     }
-    // two waves per group of 64 frames (parser + valuer) when the geometry is the plain one
-    const bool split = fast && dp.block_len == X3S_BL && !d_wav_offsets && !c->force_single_wave_decode &&
-                       !std::getenv("X3HIP_DECODE_SINGLE") && (reinterpret_cast<uintptr_t>(d_wav) & 15u) == 0 &&
+    // two waves per group of 64 frames (parser + valuer) when the geometry is the plain one.  Its parser hands
+    // over i = (z << k) + r with r the k bits behind the terminating one, which equals the reference's
+    // r' + level * (n - 1) (decoder.rs:186, r' = the hard-wired 2 / 4 bits INCLUDING the one) only when the
+    // code of ftype 2 has one sub-bit and that of ftype 3 three -- the default codes; the single-wave kernels
+    // follow the reference's formula literally and take every other code set.
+    const bool split = fast && dp.block_len == X3S_BL && dp.k[1] == 1u && dp.k[2] == 3u && !d_wav_offsets &&
+                       !c->force_single_wave_decode &&
+                       !c->opt.decode_single && (reinterpret_cast<uintptr_t>(d_wav) & 15u) == 0 &&
                        (dp.spf % 8u) == 0 && (g.fpc * (uint64_t)1 >= g.n_frames || (g.clip_stride % 8u) == 0);
+#ifdef X3_PROFILING
+    const size_t dyn_lds = (size_t)c->opt.dyn_lds;
+#else
+    const size_t dyn_lds = 0;
+#endif
     TimerScope ts(c, 1);
     if (split)
       hipLaunchKernelGGL(x3_decode_split_kernel, dim3((unsigned)((F + 63) / 64)), dim3(128),
-                         std::getenv("X3HIP_DECODE_DYN_LDS") ? std::atoi(std::getenv("X3HIP_DECODE_DYN_LDS")) : 0, c->stream, d_x3, x3_len,
+                         dyn_lds, c->stream, d_x3, x3_len,
                          d_frame_offsets, F, g, dp, d_wav, wav_cap, d_status, (X3FrameMeta*)c->dec_meta.p);
     else if (fast)
       hipLaunchKernelGGL(x3_decode_fast_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, c->stream, d_x3, x3_len,
@@ -894,7 +981,7 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
   }
   // join, then merge the two status arrays and summarise
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-  if (std::getenv("X3HIP_PROFILE_NO_CHECK")) {  // otherwise the check kernel's first thread does this
+  if (no_check) {  // otherwise the check kernel's first thread does this
     X3DecodeSummary init;
     init.first_bad = F;
     init.samples_before = 0;
@@ -904,7 +991,8 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
     HIPCHK(c, hipMemcpyAsync(c->d_summary, c->h_summary_init, sizeof init, hipMemcpyHostToDevice, c->stream));
   }
   hipLaunchKernelGGL(x3_decode_merge_kernel, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, c->stream,
-                     (const int32_t*)c->dec_cstatus.p, d_status, (const X3FrameMeta*)c->dec_meta.p, F, c->d_summary);
+                     (const int32_t*)c->dec_cstatus.p, d_status, (const X3FrameMeta*)c->dec_meta.p, F, c->d_summary,
+                     d_x3, d_frame_offsets, g, d_wav_offsets, dp, d_wav);
   c->dec_status_ptr = d_status;
   HIPCHK(c, hipGetLastError());
   c->decode_pending = true;
@@ -1141,9 +1229,11 @@ static void walk_host(const uint8_t* buf, uint64_t buf_len, uint64_t real_total,
     int rc = x3_read_frame_header(buf + pos, 20, &h);
     if (rc) { w->terminal = rc; break; }
     if (remaining - 20 < h.payload_len) break;
+    // the buffer-size test comes before the payload is read (decodefile.rs:118-124): a payload that is both too
+    // long and cut off by the real end of the data is FrameHeaderInvalidPayloadLen, not Io
+    if (h.payload_len > X3_READ_BUFFER_SIZE) { w->terminal = X3_ERR_FRAME_HEADER_INVALID_PAYLOAD_LEN; break; }
     if (real_total - pos - 20 < h.payload_len) { w->terminal = X3_ERR_IO; break; }
     if (buf_len - pos - 20 < h.payload_len) { w->need_more = true; break; }
-    if (h.payload_len > X3_READ_BUFFER_SIZE) { w->terminal = X3_ERR_FRAME_HEADER_INVALID_PAYLOAD_LEN; break; }
     if (h.samples == 0 || h.payload_len < 2 || nsamp + h.samples > wav_cap || (p->block_len == 0 && h.samples > 1)) {
       // payload CRC is checked before decode_frame runs, so let the GPU look at this frame too:
       // it reports the CRC error if there is one, BAD_ARG (reference panic) otherwise
@@ -1167,7 +1257,8 @@ static void walk_host(const uint8_t* buf, uint64_t buf_len, uint64_t real_total,
 // decode the frames a walk collected from host memory into host memory: H2D, one decode launch, D2H of the
 // samples in front of the first frame that fails.  *first_bad == F: all of them decoded.
 static int decode_frames_host(x3_ctx* c, const uint8_t* x3, uint64_t len, const HostWalk& w, const x3_params* p,
-                              int16_t* wav, uint64_t wav_cap, uint64_t* before, uint64_t* first_bad, int* bad_status) {
+                              int16_t* wav, uint64_t wav_cap, uint64_t* before, uint64_t* first_bad, int* bad_status,
+                              bool download = true) {  // !download: the samples stay in c->out (x3_mgpu_decode_stream)
   const uint64_t F = w.offs.size();
   *before = 0;
   *first_bad = 0;
@@ -1188,7 +1279,8 @@ static int decode_frames_host(x3_ctx* c, const uint8_t* x3, uint64_t len, const 
                             (const uint64_t*)c->wav_off.p, &pp, (int16_t*)c->out.p, dev_wav_cap, nullptr)))
     return rc;
   if ((rc = x3_decode_result(c, first_bad, bad_status, before))) return rc;
-  if (*before) HIPCHK(c, hipMemcpyAsync(wav, c->out.p, *before * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
+  if (download && *before)
+    HIPCHK(c, hipMemcpyAsync(wav, c->out.p, *before * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return X3_OK;
 }
@@ -1217,9 +1309,9 @@ static int decode_stream_impl(x3_ctx* c, const uint8_t* x3, uint64_t len, uint64
   HIPCHK(c, hipSetDevice(c->device));
   // Long streams: the header chain is one dependent cache miss per frame on the host (10 ms for the 69 120
   // frames of config 3), and a few launches on the GPU once the bytes are there anyway.  Short ones: the
-  // other way round.  X3HIP_HOST_WALK=0/1 forces one or the other (tests run both).
+  // other way round.  Option "host_walk" = 0/1 forces one or the other (tests run both).
   bool gpu_walk = len >= (4u << 20);
-  if (const char* e = std::getenv("X3HIP_HOST_WALK")) gpu_walk = e[0] == '0';
+  if (c->opt.host_walk >= 0) gpu_walk = c->opt.host_walk == 0;
   if (gpu_walk && len > 0) {
     int rc = ensure(c, c->in, len + 16);
     if (rc) return rc;
@@ -1512,3 +1604,4 @@ extern "C" int x3_x3a_decode(x3_ctx* c, const uint8_t* x3a, uint64_t len, int16_
 }
 
 #include "x3_file_pipeline.h"
+#include "x3_mgpu.h"

@@ -28,6 +28,7 @@
 #include <type_traits>
 
 #include "x3_device.h"
+#include "x3_decode_replay.h"
 
 #define X3D_STREAM_ENDS_IN_FRAME (-1)  // quiet stop of the walk (decodefile.rs:107-116)
 
@@ -421,6 +422,7 @@ x3_decode_lanes_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
 
   uint64_t win = 0;          // next bits, MSB first
   uint32_t have = 0;         // valid bits in win
+  bool deferred = false;     // a zero run the reference's reader counts differently (x3_decode_replay.h)
   uint32_t nextw_raw = 0;    // ring dword behind the window, in memory byte order (swapped on use)
   int32_t last = 0;
   uint32_t remaining = 0;    // samples of this lane's frame still to decode
@@ -478,6 +480,16 @@ x3_decode_lanes_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   uint32_t wbase = 0;   // first sample index of the staged window (uniform, multiple of X3_DEC_WIN)
   int32_t carry = 0;    // even-indexed sample waiting for its odd partner
   auto flush = [&](uint32_t upto) {  // stage holds samples [wbase, upto) of every lane's frame
+    // A frame that ends inside this window: the cooperative flush stores only 16-byte pieces that lie fully inside
+    // the frame, so the owner stores the < 8 samples behind its last full piece -- HERE, while the window still
+    // holds them (the frame may end in the middle of a block of the longer frames beside it, and the window
+    // moves on before that block is over).
+    if (coop && st == X3D_OK && samples > wbase && samples <= upto) {
+      if (samples & 1u) orow[(samples - 1u - wbase) >> 1] = (uint32_t)carry & 0xFFFFu;
+      const uint32_t done = samples & ~7u;
+      const uint16_t* h = reinterpret_cast<const uint16_t*>(orow);
+      for (uint32_t s = done > wbase ? done : wbase; s < samples; ++s) o[s] = (int16_t)h[s - wbase];
+    }
     X3_WAVE_LDS_ORDER();
     const uint32_t pieces = (upto - wbase + 7u) >> 3;  // 16-byte pieces per frame in this window
     const uint32_t total = pieces * (uint32_t)LANES;
@@ -557,6 +569,7 @@ x3_decode_lanes_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
         uint32_t zextra = 0;
         if (!FAST) {
           if (zmask && top == 0) {  // zero run of >= 32 bits: keep counting (general parameters only)
+            deferred = true;        // ... and let the reference's reader have the last word (x3_decode_replay.h)
             do {
               win <<= 32;
               have -= 32;
@@ -606,20 +619,15 @@ x3_decode_lanes_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       }
     }
     X3_STAMP(4);
-    if (remaining) {
-      remaining -= cnt;
-      if (remaining == 0 && coop && st == X3D_OK) {
-        // this lane's frame is complete: the cooperative flush stores only 16-byte pieces that lie
-        // fully inside the frame, so the owner stores the < 8 samples behind the last full piece
-        if (samples & 1u) orow[(samples - 1u - wbase) >> 1] = (uint32_t)carry & 0xFFFFu;
-        const uint32_t done = samples & ~7u;
-        const uint32_t from = done > wbase ? done : wbase;
-        const uint16_t* h = reinterpret_cast<const uint16_t*>(orow);
-        for (uint32_t s = from; s < samples; ++s) o[s] = (int16_t)h[s - wbase];
-      }
-    }
+    if (remaining) remaining -= cnt;
   }
   if (i > wbase) flush(i);  // the partial last window
+  if (active) {
+    // bits taken from the ring (from its first chunk on) against the bits the payload holds there
+    const uint64_t taken = 32ull * rd_abs - have, held = 8ull * (v_end - (v_bits & ~15ull));
+    if (st == X3D_OUT_OF_BOUNDS_INVERSE || st == X3D_FRAME_DECODE_INVALID_BPF || deferred || taken > held)
+      st = X3D_REPLAY;
+  }
   if (decoder && f < n_frames) status[f] = st;
 #ifdef X3_DBG_STAMPS
   X3_STAMP(6);
@@ -796,6 +804,14 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
                        __builtin_amdgcn_readfirstlane((uint32_t)wo);
   const bool regular = __all(coop && samples == S0 && wo == wo0 + (uint64_t)lane * S0) && (S0 & 7u) == 0;
   auto flush = [&](uint32_t upto) {
+    // the < 8 samples behind the last full 16-byte piece of a frame that ends inside this window: stored by the
+    // owner, here, while the window still holds them (see x3_decode_lanes_kernel)
+    if (coop && st == X3D_OK && samples > wbase && samples <= upto) {
+      if (samples & 1u) orow[(samples - 1u - wbase) >> 1] = (uint32_t)carry & 0xFFFFu;
+      const uint32_t done = samples & ~7u;
+      const uint16_t* h = reinterpret_cast<const uint16_t*>(orow);
+      for (uint32_t sx = done > wbase ? done : wbase; sx < samples; ++sx) o[sx] = (int16_t)h[sx - wbase];
+    }
     X3_WAVE_LDS_ORDER();
     const uint32_t pieces = (upto - wbase + 7u) >> 3;
     if (pieces == X3_DEC_WIN / 8u && regular) {
@@ -1025,18 +1041,15 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
       cnt = 0;
       remaining = 0;
     }
-    if (remaining) {
-      remaining -= cnt;
-      if (remaining == 0 && coop && st == X3D_OK) {
-        if (samples & 1u) orow[(samples - 1u - wbase) >> 1] = (uint32_t)carry & 0xFFFFu;
-        const uint32_t done = samples & ~7u;
-        const uint32_t from = done > wbase ? done : wbase;
-        const uint16_t* h = reinterpret_cast<const uint16_t*>(orow);
-        for (uint32_t sx = from; sx < samples; ++sx) o[sx] = (int16_t)h[sx - wbase];
-      }
-    }
+    if (remaining) remaining -= cnt;
   }
   if (i > wbase) flush(i);
+  if (active) {
+    // read position (bits from the ring's first chunk on) against the end of the payload
+    const int32_t taken = 32 * (int32_t)widx + 32 - (int32_t)s;
+    if (st == X3D_OUT_OF_BOUNDS_INVERSE || st == X3D_FRAME_DECODE_INVALID_BPF || taken > (int32_t)(8u * v_end))
+      st = X3D_REPLAY;  // x3_decode_replay.h
+  }
   if (f < n_frames) status[f] = st;
 #ifdef X3_DBG_STAMPS
   X3_STAMP(6);
@@ -1055,11 +1068,15 @@ struct X3DecodeSummary {
 
 // Merge the two concurrent passes: a frame's status is the check pass's (header, then payload CRC --
 // the reference tests those first, decodefile.rs:112-121,96-100) if that is non-zero, else the
-// decoder's.  Also finds the first bad frame and the total sample count.  summary must be pre-set to
-// {n_frames, 0, 0}.
+// decoder's.  A frame the decoder deferred (X3D_REPLAY: decode error, zero run >= 32 bits or a read behind
+// the payload's end -- see x3_decode_replay.h) is decoded again here, by this thread alone, through the
+// reference's own reader semantics.  Also finds the first bad frame and the total sample count.
+// summary must be pre-set to {n_frames, 0, 0}.
 __global__ void __launch_bounds__(256)
 x3_decode_merge_kernel(const int32_t* __restrict__ cstatus, int32_t* __restrict__ status,
-                       const X3FrameMeta* __restrict__ meta, uint64_t n_frames, X3DecodeSummary* __restrict__ out) {
+                       const X3FrameMeta* __restrict__ meta, uint64_t n_frames, X3DecodeSummary* __restrict__ out,
+                       const uint8_t* __restrict__ x3, const uint64_t* __restrict__ frame_off, X3Geom g,
+                       const uint64_t* __restrict__ wav_off, X3DevParams p, int16_t* __restrict__ wav) {
   const uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long ns = 0;
   if (f < n_frames) {
@@ -1068,6 +1085,18 @@ x3_decode_merge_kernel(const int32_t* __restrict__ cstatus, int32_t* __restrict_
     if (cs != 0) {
       st = cs;
       status[f] = cs;
+    } else if (st == X3D_REPLAY) {
+      // (the decoder has validated the header, the sample count and the output range of this frame)
+      const X3FrameMeta m = meta[f];
+      uint64_t wo;
+      if (wav_off) {
+        wo = wav_off[f];
+      } else {
+        const uint64_t clip = f / g.fpc;
+        wo = clip * g.clip_stride + (f - clip * g.fpc) * (uint64_t)p.spf;
+      }
+      st = x3_replay_frame(x3 + frame_off[f] + 20, m.payload_len, m.samples, p, wav + wo);
+      status[f] = st;
     }
     if (st != 0) atomicMin(&out->first_bad, (unsigned long long)f);
     else ns = meta[f].samples;

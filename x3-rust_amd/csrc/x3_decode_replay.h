@@ -1,0 +1,167 @@
+// x3_decode_replay.h -- reference-exact decode of ONE frame by ONE thread.
+//
+// The lane-per-frame decoders (x3_decode_split_kernel, x3_decode_fast_kernel, x3_decode_lanes_kernel) read
+// the payload as an MSB-first bit string that is zero beyond its last byte and count zero runs exactly.
+// The reference's BitReader (src/bitreader.rs:51-176) does the same on every stream its encoder can
+// produce, but not on short or corrupt payloads:
+//   * count_zero_bits (:128-139) extends a run by at most ONE peeked word: a run that covers a whole
+//     32-bit word of the reader's grid is cut at the end of that word, and a word-aligned all-zero word
+//     returns 32 without peeking at all;
+//   * behind the last byte get_next (:148-163) leaves {leading_word 0, rem_bit 0}, and inc_bits (:76-92)
+//     then sets rem_bit = 32 - rem: later zero runs come back as those phantom counts (< 32, often a
+//     valid index of the inverse table), not as "no terminator";
+//   * the word grid is relative to payload[2..], the last word may hold 1..3 bytes (read_word, :29-49).
+// A frame whose header `samples` asks for more than the payload encodes therefore decodes "successfully"
+// in the reference, with values that depend on that state machine.  To be reference-exact there without
+// touching the hot loop, the fast decoders FLAG every frame in which they saw a decode error, a zero run
+// of 32 bits or more, or a read position behind the payload's last byte (status X3D_REPLAY), and
+// x3_decode_merge_kernel runs such a frame again through x3_replay_frame below: a scalar restatement of
+// decoder::decode_frame (src/decoder.rs:36-58) over the reference's own reader.  Conforming streams never
+// get here.
+#pragma once
+#include "x3_device.h"
+
+#define X3D_REPLAY 101  // internal: the fast decoder defers this frame to x3_replay_frame
+
+// BitReader (src/bitreader.rs:51-176)
+struct X3RefReader {
+  const uint8_t* a;  // payload[2..]
+  uint32_t len, idx, word, rem;
+
+  // read_word (:29-49): (word, bytes taken); a short last word is zero-padded (its third byte only counts
+  // when exactly three remain, as in the reference)
+  __device__ __forceinline__ uint32_t load(uint32_t at, uint32_t& took) const {
+    const uint32_t left = len - at;
+    if (left >= 4u) {
+      took = 4u;
+      return ((uint32_t)a[at] << 24) | ((uint32_t)a[at + 1] << 16) | ((uint32_t)a[at + 2] << 8) | (uint32_t)a[at + 3];
+    }
+    uint32_t w = 0;
+    if (left >= 1u) w |= (uint32_t)a[at] << 24;
+    if (left >= 2u) w |= (uint32_t)a[at + 1] << 16;
+    if (left == 3u) w |= (uint32_t)a[at + 2] << 8;
+    took = left;
+    return w;
+  }
+  __device__ __forceinline__ void open(const uint8_t* bytes, uint32_t n) {  // BitReader::new (:65-74)
+    a = bytes;
+    len = n;
+    uint32_t took;
+    word = load(0u, took);
+    idx = took;
+    rem = took * 8u;
+  }
+  __device__ __forceinline__ void next() {  // get_next over peek_next (:148-175)
+    if (idx >= len) {
+      word = 0u;
+      rem = 0u;
+    } else {
+      uint32_t took;
+      word = load(idx, took);
+      idx += took;
+      rem = took * 8u;
+    }
+  }
+  // inc_bits (:76-92); a shift count of 32 is taken modulo 32, as release-mode Rust does
+  __device__ __forceinline__ void skip(uint32_t n) {
+    if (n < rem) {
+      word <<= (n & 31u);
+      rem -= n;
+    } else if (n > rem) {
+      const uint32_t over = n - rem;
+      next();
+      rem = 32u - over;
+      word <<= (over & 31u);
+    } else {
+      next();
+    }
+  }
+  __device__ __forceinline__ uint32_t bits(uint32_t n) {  // read_nbits (:105-119)
+    if (n <= rem) {
+      const uint32_t r = word >> ((32u - n) & 31u);
+      skip(n);
+      return r;
+    }
+    const uint32_t over = n - rem;
+    uint32_t r = word >> ((32u - n) & 31u);
+    skip(rem);
+    r |= word >> ((32u - over) & 31u);
+    skip(over);
+    return r;
+  }
+  __device__ __forceinline__ uint32_t zeros() {  // count_zero_bits (:128-139)
+    uint32_t count = word ? (uint32_t)__clz(word) : 32u;
+    if (count > rem) {
+      if (idx >= len) {
+        count = rem;
+      } else {
+        uint32_t took;
+        const uint32_t w = load(idx, took);
+        count = rem + (w ? (uint32_t)__clz(w) : 32u);
+      }
+    }
+    skip(count);
+    return count;
+  }
+};
+
+// decoder::decode_frame (src/decoder.rs:36-58) with decode_block and the three block decoders (:132-235).
+// payload[0..plen), plen >= 2; samples >= 1; block_len >= 1; out has room for `samples` values.
+// Returns X3D_OK, X3D_OUT_OF_BOUNDS_INVERSE or X3D_FRAME_DECODE_INVALID_BPF.
+__device__ __noinline__ int32_t x3_replay_frame(const uint8_t* __restrict__ payload, uint32_t plen, uint32_t samples,
+                                                const X3DevParams& p, int16_t* __restrict__ out) {
+  uint32_t last = ((uint32_t)payload[0] << 8) | payload[1];  // kept modulo 2^16 (i16 arithmetic wraps in release)
+  out[0] = (int16_t)(uint16_t)last;
+  X3RefReader br;
+  br.open(payload + 2, plen - 2u);
+  uint32_t at = 1u, remaining = samples - 1u;
+  while (remaining) {
+    const uint32_t n = remaining < p.block_len ? remaining : p.block_len;
+    const uint32_t ftype = br.bits(2u);
+    if (ftype == 0u) {  // decode_bpf_block (:209-235)
+      const uint32_t E = br.bits(4u) + 1u;
+      if (E <= 5u) return X3D_FRAME_DECODE_INVALID_BPF;
+      if (E == 16u) {
+        for (uint32_t i = 0; i < n; ++i) {
+          last = br.bits(16u) & 0xFFFFu;
+          out[at + i] = (int16_t)(uint16_t)last;
+        }
+      } else {
+        const uint32_t half = 1u << (E - 1u);
+        for (uint32_t i = 0; i < n; ++i) {
+          uint32_t v = br.bits(E) & 0xFFFFu;
+          if (v > half) v -= half << 1;  // unsigned_to_i16 (:198-207): strict compare
+          last = (last + v) & 0xFFFFu;
+          out[at + i] = (int16_t)(uint16_t)last;
+        }
+      }
+    } else if (ftype == 1u) {  // decode_ricecode_block_r1 (:147-170)
+      const uint32_t bound = p.inv_len[0];
+      for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t ix = br.zeros();
+        (void)br.bits(1u);
+        if (ix >= bound) return X3D_OUT_OF_BOUNDS_INVERSE;
+        const uint32_t d = (ix & 1u) ? 0u - ((ix + 1u) >> 1) : (ix >> 1);  // INV_RICE_CODE (x3.rs:200-204)
+        last = (last + d) & 0xFFFFu;
+        out[at + i] = (int16_t)(uint16_t)last;
+      }
+    } else {  // decode_ricecode_block_r2r3 (:172-196): nb hard-wired, i16 arithmetic, `as usize` sign-extends
+      const uint32_t nb = ftype == 2u ? 2u : 4u;
+      const int32_t level = 1 << p.k[ftype - 1u];
+      const uint32_t bound = p.inv_len[ftype - 1u];
+      for (uint32_t i = 0; i < n; ++i) {
+        const int32_t nz = (int32_t)(int16_t)br.zeros();
+        const int32_t r = (int32_t)(int16_t)br.bits(nb);
+        const int32_t ix = (int32_t)(int16_t)(r + level * (nz - 1));
+        if (ix < 0 || (uint32_t)ix >= bound) return X3D_OUT_OF_BOUNDS_INVERSE;
+        const uint32_t u = (uint32_t)ix;
+        const uint32_t d = (u & 1u) ? 0u - ((u + 1u) >> 1) : (u >> 1);
+        last = (last + d) & 0xFFFFu;
+        out[at + i] = (int16_t)(uint16_t)last;
+      }
+    }
+    remaining -= n;
+    at += n;
+  }
+  return X3D_OK;
+}

@@ -65,6 +65,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   __shared__ __attribute__((aligned(16))) uint32_t xfer[2 * X3S_XROWS * 64];
   __shared__ unsigned long long s_wo[64];
   __shared__ uint32_t s_ns[64];
+  __shared__ uint32_t s_over[64];  // parser -> valuer: the frame was read beyond its payload (x3_decode_replay.h)
 
   const uint32_t lane = threadIdx.x & 63u;
   const bool parser = threadIdx.x < 64u;
@@ -291,6 +292,12 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       X3S_BARRIER();
       X3_STAMP(4);
     }
+    {
+      // read position (bits from the ring's first chunk on) against the end of the payload
+      const int32_t widx = (int32_t)~((uint32_t)((int32_t)qb >> 2)) - 2;
+      s_over[lane] = (32 * widx + 32 - (int32_t)s > (int32_t)(8u * v_end)) ? 1u : 0u;
+    }
+    X3S_BARRIER();
   } else {
     // ================================================================= wave 1: valuer
     uint32_t* const orow = outs + lane * X3S_OUT_STRIDE;
@@ -448,6 +455,9 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       }
     }
     if (nblk_max & (X3S_WBLK - 1u)) flush();
+    X3S_BARRIER();
+    if (active && (st == X3D_OUT_OF_BOUNDS_INVERSE || st == X3D_FRAME_DECODE_INVALID_BPF || s_over[lane]))
+      st = X3D_REPLAY;  // the reference's reader decides (x3_decode_replay.h; x3_decode_merge_kernel)
     if (f < n_frames) status[f] = st;
   }
 #ifdef X3_DBG_STAMPS

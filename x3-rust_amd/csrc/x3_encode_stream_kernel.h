@@ -198,7 +198,7 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
                         unsigned long long* __restrict__ end_pos, const uint32_t* __restrict__ xk16,
                         const uint16_t* __restrict__ crc_tab_g, uint32_t lds_in_bytes, uint32_t img_dwords) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // part: [0..7] scan partials, [16..23] CRC partials, [32..37] stats, [40] bad, [48..49] stream offset of
+  // part: [0..7] scan partials, [16..23] CRC partials, [32..37] stats, [40] bad, [41] offsets lost, [48..49] stream offset of
   // the frame being copied out, [50] header CRC
   uint32_t* part = reinterpret_cast<uint32_t*>(smem);
   int16_t* in_s = reinterpret_cast<int16_t*>(smem + X3_ENC_SMEM_HDR);
@@ -273,7 +273,7 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
     uint32_t hdr_crc = 0, cur_img = 0;
     uint64_t pend_f = 0, my_off = 0;
     uint32_t pend_bytes = 0, my_bytes = 0;
-    bool pending = false, first = true;
+    bool pending = false, first = true, lost = false;
     // Window w of a frame = the sizes of frames f-1-lane-64w.  Requests are raw loads at constant offsets
     // from one per-lane pointer (the array has X3_DESC_PAD words in front, so windows reaching below frame
     // 0 read padding); range and readiness are checked when a word is USED, so that requesting never waits.
@@ -346,16 +346,23 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
       X3_STAMP(1);  // windows examined
       // 8 windows x 64 lanes x 2^20 < 2^32: a 32-bit DPP scan, total in lane 63
       tot += (unsigned long long)__builtin_amdgcn_readlane(x3_wave_incl_scan_dpp(sum), 63);
-      uint64_t off = (first ? base_pos : my_off + my_bytes) + tot;
-      if (timeout) {
-        if (lane == 0) atomicMax(&status[1], X3D_SIZE_WAIT_TIMEOUT);
-        off = 0;
+      const uint64_t off = (first ? base_pos : my_off + my_bytes) + tot;
+      if (timeout && !lost) {
+        // This workgroup no longer knows where its frames go -- this one and, since each offset builds on the
+        // last, every later one.  Nothing of them may reach the output, the frame index or the end position:
+        // x3_encode_result re-encodes the whole call with the two-pass kernels, and those rewrite
+        // d_out[start_pos..) only -- bytes in front of start_pos belong to the caller.
+        lost = true;
+        if (lane == 0) {
+          atomicMax(&status[1], X3D_SIZE_WAIT_TIMEOUT);
+          part[41] = 1;  // read by copy_out
+        }
       }
       my_off = off;
       my_bytes = pend_bytes;
       first = false;
       X3_STAMP(0);  // reduced
-      if (lane == 0) {
+      if (lane == 0 && !lost) {
         part[48] = (uint32_t)off;
         part[49] = (uint32_t)(off >> 32);
         frame_off[pend_f] = off;
@@ -464,7 +471,7 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
     auto copy_out = [&](const uint32_t* img, uint32_t total_bytes) __attribute__((always_inline)) {
       // header + payload of a finished frame to its final stream position (part[48..49])
       const uint64_t off = (uint64_t)part[48] | ((uint64_t)part[49] << 32);
-      if (off + total_bytes <= out_cap && part[40] == 0) {
+      if (off + total_bytes <= out_cap && part[40] == 0 && part[41] == 0) {  // [41]: offsets lost to a size-wait time-out
         uint8_t* dst = out + off;
         const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u);
         // sixteen bytes per lane and trip (a default frame is ~330 of them: one trip, two thirds of the lanes);

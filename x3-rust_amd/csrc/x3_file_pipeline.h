@@ -32,11 +32,8 @@ struct FilePipeCfg {
   uint64_t chunk_frames;
   int workers;
 };
-static FilePipeCfg file_pipe_cfg() {
-  FilePipeCfg cfg{800, 4};  // 16 MB of samples per chunk; measured best on tmpfs (tools/file_bench.py)
-  if (const char* e = std::getenv("X3HIP_FILE_CHUNK_FRAMES")) cfg.chunk_frames = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
-  if (const char* e = std::getenv("X3HIP_FILE_WORKERS")) cfg.workers = std::max(1, std::min(16, std::atoi(e)));
-  return cfg;
+static FilePipeCfg file_pipe_cfg(const x3_ctx* c) {  // options "file_chunk_frames" / "file_workers"
+  return FilePipeCfg{(uint64_t)c->opt.file_chunk_frames, c->opt.file_workers};
 }
 
 static bool pread_full(int fd, void* buf, uint64_t n, uint64_t off) {
@@ -78,16 +75,30 @@ struct PinBuf {
 struct WorkerCtxs {
   std::vector<x3_ctx*> ctx;
   int rc = X3_OK;
-  WorkerCtxs(x3_ctx* c, int n) {
+  int saved_two_pass = 0;
+  // `encoders`: the workers encode concurrently on one GPU.  The single-pass encoder is a persistent grid sized
+  // for the whole chip whose workgroups wait for each other: two of them at once are not both resident, both
+  // spin to the bounded-wait limit (~0.1 s) and fall back.  Chunks of several workers therefore go through the
+  // two-pass kernels, which need no residency.
+  WorkerCtxs(x3_ctx* c, int n, bool encoders = false) {
+    saved_two_pass = c->opt.two_pass;
+    if (encoders && n > 1) c->opt.two_pass = 1;
     ctx.push_back(c);
     for (int k = 1; k < n; ++k) {
       x3_ctx* w = nullptr;
       rc = x3_ctx_create(c->device, &w);
       if (rc) { c->last_error = "file pipeline: cannot create a worker context"; break; }
+      w->opt = c->opt;
       ctx.push_back(w);
     }
   }
-  ~WorkerCtxs() { for (size_t k = 1; k < ctx.size(); ++k) x3_ctx_destroy(ctx[k]); }
+  ~WorkerCtxs() {
+    for (size_t k = 1; k < ctx.size(); ++k) {
+      ctx[0]->encode_fallbacks += ctx[k]->encode_fallbacks;
+      x3_ctx_destroy(ctx[k]);
+    }
+    ctx[0]->opt.two_pass = saved_two_pass;
+  }
 };
 
 // ---- RIFF/WAVE (hound::WavReader::new restated: chunks up to "data"; "fmt " must precede it)
@@ -194,12 +205,12 @@ extern "C" int x3_wav_to_x3a(x3_ctx* c, const char* wav_path, const char* x3a_pa
   if ((rc = x3_archive_header_write(wi.sample_rate, &p, hdr, sizeof hdr, &hlen))) return rc;
   if (!pwrite_full(out.fd, hdr, hlen, 0)) return X3_ERR_IO;
 
-  const FilePipeCfg cfg = file_pipe_cfg();
+  const FilePipeCfg cfg = file_pipe_cfg(c);
   const uint64_t spf = spf_of(&p);
   const uint64_t chunk_samples = cfg.chunk_frames * spf;
   const uint64_t n_chunks = (n + chunk_samples - 1) / chunk_samples;
   const int n_workers = (int)std::min<uint64_t>((uint64_t)cfg.workers, std::max<uint64_t>(n_chunks, 1));
-  WorkerCtxs pool(c, n_workers);
+  WorkerCtxs pool(c, n_workers, true);
   if (pool.rc) return pool.rc;
 
   struct Shared {
@@ -303,7 +314,7 @@ extern "C" int x3_x3a_to_wav(x3_ctx* c, const char* x3a_path, const char* wav_pa
   const uint64_t real_total0 = file_len - start;  // bytes that follow the archive header
   const uint64_t phantom = 8;                     // remaing_bytes = file length - header_size (decodefile.rs:62-66)
 
-  const FilePipeCfg cfg = file_pipe_cfg();
+  const FilePipeCfg cfg = file_pipe_cfg(c);
   const uint64_t spf = std::max<uint64_t>(spf_of(&p), 1);
   const uint64_t chunk_samples = cfg.chunk_frames * spf;
   // window: the chunk's samples at the worst-case rate plus one maximal frame, so that typical streams fill

@@ -3,7 +3,7 @@
 //
 // The walk is a linked list threaded through the stream: frame i+1 starts at off_i + 20 + payload_len_i.
 // Followed serially that is one dependent memory access per frame; here
-//   1. every even byte offset is tested IN PARALLEL for the key bytes "x3" and, on a hit, for a valid header
+//   1. every byte offset is tested IN PARALLEL for the key bytes "x3" and, on a hit, for a valid header
 //      (decoder::read_frame_header, decoder.rs:69-118: header CRC, key, channels, length) -> candidates
 //      {offset, payload_len, samples, kind}; a random pair of bytes is the key once in 65 536 and then still
 //      has to pass a 16-bit CRC, so candidates ~ frames;
@@ -69,27 +69,31 @@ __device__ __forceinline__ int32_t x3i_read_header(const uint32_t* __restrict__ 
 __device__ __forceinline__ uint32_t x3i_kind(uint64_t len, uint64_t believed, uint64_t off, uint32_t plen,
                                              uint32_t samples, uint32_t bl0) {
   if (believed - off - 20 < plen) return X3I_QUIET;
+  if (plen > X3I_READ_BUFFER) return X3I_PLEN;  // tested before the payload is read (decodefile.rs:118-124)
   if (len - off - 20 < plen) return X3I_IO;
-  if (plen > X3I_READ_BUFFER) return X3I_PLEN;
   if (samples == 0 || plen < 2 || (bl0 && samples > 1)) return X3I_LAST_BAD;
   return X3I_CONT;
 }
 
-// 1. candidates: thread t looks at the 8 even offsets of 16-byte chunk t.  cand == nullptr: count only.
+// 1. candidates: thread t looks at the 16 byte offsets of 16-byte chunk t.  cand == nullptr: count only.
+// (Every offset, not only the even ones an encoder produces: read_frame_header accepts any payload_len, and a
+// frame with an odd one puts its successor on an odd offset -- the host walk follows it there, so does this one.)
 __global__ void __launch_bounds__(256)
 x3_index_candidates_kernel(const uint32_t* __restrict__ xw, uint64_t len, uint64_t believed, uint32_t bl0,
                            X3Cand* __restrict__ cand, uint32_t cap, unsigned int* __restrict__ count) {
   const uint64_t n_dw = (len + 3) >> 2;
   const uint64_t chunks = (len + 15) >> 4;
   for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < chunks; t += (uint64_t)gridDim.x * blockDim.x) {
-    uint32_t w[4];
+    uint32_t w[5];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) w[d] = 4 * t + d < n_dw ? xw[4 * t + d] : 0u;
+    for (int d = 0; d < 5; ++d) w[d] = 4 * t + d < n_dw ? xw[4 * t + d] : 0u;
 #pragma unroll
-    for (int h = 0; h < 8; ++h) {
-      const uint32_t hw = (w[h >> 1] >> (16 * (h & 1))) & 0xFFFFu;
-      if (hw != 0x3378u) continue;  // bytes 0x78 0x33 in memory order
-      const uint64_t off = 16 * t + 2 * h;
+    for (int b = 0; b < 16; ++b) {
+      // bytes b, b+1 of the chunk in memory order
+      const uint32_t lo = w[b >> 2] >> (8 * (b & 3));
+      const uint32_t hw = ((b & 3) == 3 ? (lo & 0xFFu) | ((w[(b >> 2) + 1] & 0xFFu) << 8) : lo) & 0xFFFFu;
+      if (hw != 0x3378u) continue;  // bytes 0x78 0x33
+      const uint64_t off = 16 * t + b;
       if (off + 20 > len) continue;
       uint32_t plen, samples;
       if (x3i_read_header(xw, n_dw, off, plen, samples) != X3D_OK) continue;

@@ -1,0 +1,475 @@
+// x3_mgpu.h -- frames sharded over the GPUs of one node, RCCL over xGMI (no reference analogue:
+// the crate is single-threaded).
+//
+// Frames are independent in both directions (each re-seeds the predictor with a raw sample and carries its
+// own CRCs: encoder.rs:189, decoder.rs:42-46) and every frame is 20 + even bytes, so GPU g encodes a contiguous
+// range of whole frames into its own sub-stream and the sub-streams concatenate without padding.  The only
+// coupling is each sub-stream's byte offset = the exclusive scan of the sub-stream lengths:
+//   1. ncclAllGather of the lengths (8 bytes per rank) -> every rank knows every offset;
+//   2. optional reassembly on one rank: ncclGroupStart; root: ncclRecv(dst + off_r, len_r) from every peer,
+//      peers: ncclSend(sub, len, root); ncclGroupEnd -- each peer uses its own xGMI link to the root
+//      (7 links x ~153 GB/s), where a ring all-gather would be bound by one link and move world x the data.
+// Decoding shards the same way by frame index once the header chain has been walked; samples stay where
+// they were decoded (or go straight to the caller's host buffer): no collective.
+//
+// Two forms behind the C ABI (include/x3hip.h):
+//   x3_shard_*  one rank of a group (one process or thread per GPU, ncclCommInitRank with a shared id):
+//               what bench.py drives under torch.distributed.run, everything device-resident;
+//   x3_mgpu_*   all GPUs from one process: one context + one host thread per device, host buffers in and
+//               out, bytes identical to x3_encode / x3_decode_stream.
+// librccl is opened at run time (dlopen): single-GPU users never load it, and a process that already holds
+// PyTorch's copy (same SONAME) keeps exactly one RCCL.
+#pragma once
+#include <dlfcn.h>
+#include <pthread.h>
+#include <rccl/rccl.h>  // types and prototypes only; the entry points come from dlsym
+
+#include <atomic>
+#include <mutex>
+#include <thread>
+
+struct X3Rccl {
+  void* h = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string err;
+};
+
+static X3Rccl* x3_rccl() {
+  static X3Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      r.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (r.h) break;
+    }
+    if (!r.h) {
+      r.err = std::string("cannot open librccl: ") + (dlerror() ? dlerror() : "?");
+      return;
+    }
+    bool ok = true;
+    auto sym = [&](const char* n) -> void* {
+      void* p = dlsym(r.h, n);
+      if (!p) { ok = false; r.err = std::string("librccl lacks ") + n; }
+      return p;
+    };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+    r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+    r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!ok) { dlclose(r.h); r.h = nullptr; }
+  });
+  return r.h ? &r : nullptr;
+}
+
+struct x3_shard {
+  x3_ctx* ctx = nullptr;
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
+  unsigned long long* d_mine = nullptr;     // this rank's length, when it is not already on the device
+  unsigned long long* d_lengths = nullptr;  // [world]
+  unsigned long long* h_lengths = nullptr;  // pinned mirror
+};
+
+#define RCCLCHK(ctx, R, call)                                                                          \
+  do {                                                                                                 \
+    ncclResult_t r_ = (call);                                                                          \
+    if (r_ != ncclSuccess) {                                                                           \
+      if (ctx) (ctx)->last_error = std::string(#call) + ": " + ((R)->GetErrorString ? (R)->GetErrorString(r_) : "?"); \
+      return X3_ERR_HIP;                                                                               \
+    }                                                                                                  \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// host arithmetic of the sharding (no GPU involved; tests/test_host_logic.py, tests/host_cpp/test_shard_logic.cpp)
+// ------------------------------------------------------------------------------------------------
+extern "C" void x3_shard_frame_range(uint64_t n_frames, int rank, int world, uint64_t* first, uint64_t* count) {
+  // contiguous ranges of whole frames; the remainder goes to the first ranks, one frame each
+  const uint64_t w = world > 0 ? (uint64_t)world : 1, r = rank > 0 ? (uint64_t)rank : 0;
+  const uint64_t base = n_frames / w, rem = n_frames % w;
+  if (first) *first = r * base + std::min(r, rem);
+  if (count) *count = r < w ? base + (r < rem ? 1 : 0) : 0;
+}
+
+extern "C" void x3_shard_sample_range(uint64_t n_samples, const x3_params* p, int rank, int world, uint64_t* first,
+                                      uint64_t* count) {
+  const uint64_t spf = p ? spf_of(p) : 0;
+  uint64_t f0 = 0, fc = 0;
+  x3_shard_frame_range(spf ? (n_samples + spf - 1) / spf : 0, rank, world, &f0, &fc);
+  const uint64_t lo = f0 * spf, hi = std::min(n_samples, (f0 + fc) * spf);
+  if (first) *first = lo;
+  if (count) *count = hi > lo ? hi - lo : 0;
+}
+
+// exclusive scan of the sub-stream lengths: starts[r] = byte offset of rank r's sub-stream, starts[world] = total
+extern "C" void x3_shard_offsets(const uint64_t* lengths, int world, uint64_t* starts) {
+  uint64_t acc = 0;
+  for (int r = 0; r < world; ++r) {
+    starts[r] = acc;
+    acc += lengths[r];
+  }
+  starts[world] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// one rank
+// ------------------------------------------------------------------------------------------------
+extern "C" int x3_shard_unique_id(uint8_t id[X3_SHARD_ID_BYTES]) {
+  static_assert(sizeof(ncclUniqueId) == X3_SHARD_ID_BYTES, "ncclUniqueId is 128 bytes");
+  X3Rccl* R = x3_rccl();
+  if (!R || !id) return X3_ERR_HIP;
+  ncclUniqueId u;
+  if (R->GetUniqueId(&u) != ncclSuccess) return X3_ERR_HIP;
+  std::memcpy(id, &u, sizeof u);
+  return X3_OK;
+}
+
+extern "C" void x3_shard_destroy(x3_shard* s) {
+  if (!s) return;
+  if (s->ctx) {
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+  }
+  X3Rccl* R = x3_rccl();
+  if (s->comm && R) (void)R->CommDestroy(s->comm);
+  if (s->d_mine) (void)hipFree(s->d_mine);
+  if (s->d_lengths) (void)hipFree(s->d_lengths);
+  if (s->h_lengths) (void)hipHostFree(s->h_lengths);
+  delete s;
+}
+
+extern "C" int x3_shard_create(x3_ctx* c, const uint8_t id[X3_SHARD_ID_BYTES], int rank, int world, x3_shard** out) {
+  if (!c || !id || !out || world < 1 || rank < 0 || rank >= world) return X3_ERR_BAD_ARG;
+  *out = nullptr;
+  X3Rccl* R = x3_rccl();
+  if (!R) {
+    c->last_error = x3_rccl() ? "" : "librccl is not available";
+    return X3_ERR_HIP;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  x3_shard* s = new x3_shard();
+  s->ctx = c;
+  s->rank = rank;
+  s->world = world;
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof u);
+  ncclResult_t r = R->CommInitRank(&s->comm, world, u, rank);  // blocks until every rank has joined
+  if (r != ncclSuccess) {
+    c->last_error = std::string("ncclCommInitRank: ") + R->GetErrorString(r);
+    s->comm = nullptr;
+    x3_shard_destroy(s);
+    return X3_ERR_HIP;
+  }
+  if (hipMalloc(&s->d_mine, 16) != hipSuccess || hipMalloc(&s->d_lengths, sizeof(uint64_t) * (size_t)world) != hipSuccess ||
+      hipHostMalloc(&s->h_lengths, sizeof(uint64_t) * (size_t)world) != hipSuccess) {
+    c->last_error = "x3_shard_create: out of memory";
+    x3_shard_destroy(s);
+    return X3_ERR_HIP;
+  }
+  *out = s;
+  return X3_OK;
+}
+
+extern "C" int x3_shard_rank(const x3_shard* s) { return s ? s->rank : -1; }
+extern "C" int x3_shard_world(const x3_shard* s) { return s ? s->world : 0; }
+
+// Step 1: all-gather of the sub-stream lengths.  d_len: DEVICE pointer to this rank's length (e.g. the last
+// entry of the frame offsets x3_encode_dev wrote, when the sub-stream starts at 0); d_lengths: device array of
+// `world` entries, or NULL for the shard's own (then read with x3_shard_lengths).  Enqueued on the context's
+// stream behind the encoder; does not synchronise.
+extern "C" int x3_shard_exchange_lengths(x3_shard* s, const uint64_t* d_len, uint64_t* d_lengths) {
+  if (!s || !d_len) return X3_ERR_BAD_ARG;
+  X3Rccl* R = x3_rccl();
+  x3_ctx* c = s->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  RCCLCHK(c, R, R->AllGather(d_len, d_lengths ? (void*)d_lengths : (void*)s->d_lengths, 1, ncclUint64, s->comm, c->stream));
+  return X3_OK;
+}
+
+// the same for a length the host holds
+extern "C" int x3_shard_exchange_length_value(x3_shard* s, uint64_t len, uint64_t* d_lengths) {
+  if (!s) return X3_ERR_BAD_ARG;
+  x3_ctx* c = s->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  s->h_lengths[s->rank] = len;  // pinned: stays valid until the copy has run
+  HIPCHK(c, hipMemcpyAsync(s->d_mine, &s->h_lengths[s->rank], sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  return x3_shard_exchange_lengths(s, reinterpret_cast<const uint64_t*>(s->d_mine), d_lengths);
+}
+
+// waits for the last exchange into the shard's own array and hands the lengths to the host
+extern "C" int x3_shard_lengths(x3_shard* s, uint64_t* lengths) {
+  if (!s || !lengths) return X3_ERR_BAD_ARG;
+  x3_ctx* c = s->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(s->h_lengths, s->d_lengths, sizeof(uint64_t) * (size_t)s->world, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int r = 0; r < s->world; ++r) lengths[r] = s->h_lengths[r];
+  return X3_OK;
+}
+
+// Step 2: reassemble the whole stream on `root`: d_dst[starts[r] .. starts[r] + lengths[r]) = rank r's d_sub.
+// lengths: HOST array of `world` entries, the same on every rank (x3_shard_lengths).  d_dst / dst_cap only
+// count on the root.  Enqueued on the context's stream; does not synchronise.  *total = the stream's length.
+extern "C" int x3_shard_gather(x3_shard* s, const uint8_t* d_sub, const uint64_t* lengths, int root, uint8_t* d_dst,
+                               uint64_t dst_cap, uint64_t* total) {
+  if (!s || !lengths || root < 0 || root >= s->world) return X3_ERR_BAD_ARG;
+  X3Rccl* R = x3_rccl();
+  x3_ctx* c = s->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<uint64_t> starts((size_t)s->world + 1);
+  x3_shard_offsets(lengths, s->world, starts.data());
+  if (total) *total = starts[s->world];
+  if (s->rank == root) {
+    if (!d_dst || starts[s->world] > dst_cap) return X3_ERR_BYTE_WRITER_INSUFFICIENT_MEMORY;  // (the same test on no other rank:
+    // callers size the destination from the lengths before they get here, so that all ranks agree)
+    if (lengths[root] && d_sub != d_dst + starts[root])
+      HIPCHK(c, hipMemcpyAsync(d_dst + starts[root], d_sub, lengths[root], hipMemcpyDeviceToDevice, c->stream));
+    RCCLCHK(c, R, R->GroupStart());
+    for (int r = 0; r < s->world; ++r)
+      if (r != root && lengths[r]) {
+        ncclResult_t e = R->Recv(d_dst + starts[r], lengths[r], ncclUint8, r, s->comm, c->stream);
+        if (e != ncclSuccess) { (void)R->GroupEnd(); RCCLCHK(c, R, e); }
+      }
+    RCCLCHK(c, R, R->GroupEnd());
+  } else if (lengths[s->rank]) {
+    if (!d_sub) return X3_ERR_BAD_ARG;
+    RCCLCHK(c, R, R->GroupStart());
+    ncclResult_t e = R->Send(d_sub, lengths[s->rank], ncclUint8, root, s->comm, c->stream);
+    if (e != ncclSuccess) { (void)R->GroupEnd(); RCCLCHK(c, R, e); }
+    RCCLCHK(c, R, R->GroupEnd());
+  }
+  return X3_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// all GPUs from one process: one context, one shard and one host thread per device
+// ------------------------------------------------------------------------------------------------
+struct x3_mgpu {
+  std::vector<int> devices;
+  std::vector<x3_ctx*> ctx;
+  std::vector<x3_shard*> shard;
+  DevBuf whole;  // on devices[0]: the reassembled stream
+  std::string last_error;
+};
+
+template <class Fn>
+static void x3_mgpu_parallel(int n, Fn&& fn) {  // fn(g) on n host threads (the caller's is thread 0)
+  std::vector<std::thread> th;
+  for (int g = 1; g < n; ++g) th.emplace_back([&fn, g] { fn(g); });
+  fn(0);
+  for (auto& t : th) t.join();
+}
+
+extern "C" void x3_mgpu_destroy(x3_mgpu* m) {
+  if (!m) return;
+  if (!m->ctx.empty() && m->ctx[0] && m->whole.p) {
+    (void)hipSetDevice(m->ctx[0]->device);
+    (void)hipFree(m->whole.p);
+  }
+  // communicators are torn down by all ranks together
+  x3_mgpu_parallel((int)m->shard.size(), [&](int g) { x3_shard_destroy(m->shard[g]); });
+  for (x3_ctx* c : m->ctx) x3_ctx_destroy(c);
+  delete m;
+}
+
+extern "C" int x3_mgpu_create(const int* devices, int n, x3_mgpu** out) {
+  if (!devices || n < 1 || n > 64 || !out) return X3_ERR_BAD_ARG;
+  *out = nullptr;
+  for (int a = 0; a < n; ++a)
+    for (int b = a + 1; b < n; ++b)
+      if (devices[a] == devices[b]) return X3_ERR_BAD_ARG;  // one rank per GPU
+  x3_mgpu* m = new x3_mgpu();
+  m->devices.assign(devices, devices + n);
+  m->ctx.assign((size_t)n, nullptr);
+  m->shard.assign((size_t)n, nullptr);
+  uint8_t id[X3_SHARD_ID_BYTES];
+  int rc = n > 1 ? x3_shard_unique_id(id) : X3_OK;
+  if (rc) {
+    std::fprintf(stderr, "x3hip: x3_mgpu_create: %s\n", x3_rccl() ? "ncclGetUniqueId failed" : "librccl is not available");
+    delete m;
+    return rc;
+  }
+  std::vector<int> rcs((size_t)n, X3_OK);
+  for (int g = 0; g < n && !rc; ++g) rc = rcs[g] = x3_ctx_create(devices[g], &m->ctx[g]);
+  if (!rc && n > 1)  // ncclCommInitRank blocks until every rank has joined: one thread per rank
+    x3_mgpu_parallel(n, [&](int g) { rcs[g] = x3_shard_create(m->ctx[g], id, g, n, &m->shard[g]); });
+  for (int g = 0; g < n; ++g)
+    if (rcs[g]) {
+      rc = rcs[g];
+      if (m->ctx[g]) std::fprintf(stderr, "x3hip: x3_mgpu_create, device %d: %s\n", devices[g], m->ctx[g]->last_error.c_str());
+    }
+  if (rc) {
+    for (auto& s : m->shard) { if (s) { /* a half-built group cannot be torn down collectively */ } }
+    m->shard.clear();
+    for (x3_ctx* c : m->ctx) if (c) x3_ctx_destroy(c);
+    delete m;
+    return rc;
+  }
+  if (n == 1) m->shard.clear();  // a single GPU needs no communicator
+  *out = m;
+  return X3_OK;
+}
+
+extern "C" int x3_mgpu_devices(const x3_mgpu* m) { return m ? (int)m->devices.size() : 0; }
+extern "C" x3_ctx* x3_mgpu_ctx(x3_mgpu* m, int g) { return m && g >= 0 && g < (int)m->ctx.size() ? m->ctx[g] : nullptr; }
+extern "C" x3_shard* x3_mgpu_shard(x3_mgpu* m, int g) { return m && g >= 0 && g < (int)m->shard.size() ? m->shard[g] : nullptr; }
+extern "C" const char* x3_mgpu_last_error(const x3_mgpu* m) { return m ? m->last_error.c_str() : ""; }
+
+// `encoder::encode` (src/encoder.rs:51-111) over all GPUs: same arguments, same bytes, same status as x3_encode.
+extern "C" int x3_mgpu_encode(x3_mgpu* m, const int16_t* wav, uint64_t n, uint32_t n_channels, const x3_params* p,
+                              uint8_t* out, uint64_t out_cap, uint64_t start_pos, uint64_t* out_pos, uint64_t stats[6]) {
+  if (!m || !p || (!wav && n) || (!out && out_cap)) return X3_ERR_BAD_ARG;
+  if (n_channels > 1) return X3_ERR_MORE_THAN_ONE_CHANNEL;
+  if (n_channels == 0) return X3_ERR_BAD_ARG;
+  if (stats) std::memset(stats, 0, 6 * sizeof(uint64_t));
+  if (out_pos) *out_pos = start_pos;
+  int rc = x3_params_validate(p);
+  if (rc == X3_ERR_BAD_ARG) return rc;
+  const uint64_t spf = spf_of(p);
+  if (spf == 0 || n == 0) return X3_OK;
+  if (start_pos > out_cap) return X3_ERR_BYTE_WRITER_INSUFFICIENT_MEMORY;
+  const int G = (int)m->ctx.size();
+  if (G == 1) return x3_encode(m->ctx[0], wav, n, n_channels, p, out, out_cap, start_pos, out_pos, stats);
+
+  const uint64_t base = (start_pos + 1ull) & ~1ull;  // writer.align::<2>() (encoder.rs:182)
+  std::vector<int> rcs((size_t)G, X3_OK);
+  std::vector<uint64_t> lens((size_t)G, 0), st((size_t)G * 6, 0);
+  std::vector<std::vector<uint64_t>> all((size_t)G, std::vector<uint64_t>((size_t)G, 0));
+  pthread_barrier_t bar;
+  pthread_barrier_init(&bar, nullptr, (unsigned)G);
+  std::atomic<int> failed{0};
+  uint64_t total = 0;
+  x3_mgpu_parallel(G, [&](int g) {
+    x3_ctx* c = m->ctx[g];
+    x3_shard* s = m->shard[g];
+    int e = hipSetDevice(c->device) == hipSuccess ? X3_OK : X3_ERR_HIP;
+    uint64_t first = 0, cnt = 0;
+    x3_shard_sample_range(n, p, g, G, &first, &cnt);
+    uint64_t len = 0;
+    if (!e && cnt) {
+      const uint64_t bound = x3_encode_bound(cnt, p);
+      if (!(e = ensure(c, c->in, cnt * sizeof(int16_t) + 16)) && !(e = ensure(c, c->out, bound + 16))) {
+        if (hipMemcpyAsync(c->in.p, wav + first, cnt * sizeof(int16_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) e = X3_ERR_HIP;
+        x3_batch b{cnt, cnt, 1};
+        if (!e) e = encode_dev_impl(c, (const int16_t*)c->in.p, &b, p, spf, (uint8_t*)c->out.p, bound, 0, nullptr);
+        if (!e) e = x3_encode_result(c, &len, &st[(size_t)g * 6]);
+      }
+    }
+    if (e) { len = 0; failed.store(1); }
+    rcs[g] = e;
+    // step 1: every rank learns every length (a rank that failed still takes part: nobody may be left waiting)
+    int e2 = x3_shard_exchange_length_value(s, len, nullptr);
+    if (!e2) e2 = x3_shard_lengths(s, all[g].data());
+    if (e2) { failed.store(1); if (!rcs[g]) rcs[g] = e2; }
+    pthread_barrier_wait(&bar);
+    if (failed.load()) return;
+    uint64_t tot = 0;
+    for (int r = 0; r < G; ++r) tot += all[g][r];
+    if (g == 0) total = tot;
+    if (base + tot > out_cap) return;  // the same verdict on every rank; reported below
+    // step 2: sub-streams to devices[0] over xGMI, then one copy to the caller's buffer
+    if (g == 0 && (e = ensure(c, m->whole, tot + 16))) { rcs[0] = e; failed.store(1); }
+    pthread_barrier_wait(&bar);
+    if (failed.load()) return;
+    e = x3_shard_gather(s, (const uint8_t*)c->out.p, all[g].data(), 0, (uint8_t*)m->whole.p, tot, nullptr);
+    if (!e && hipStreamSynchronize(c->stream) != hipSuccess) e = X3_ERR_HIP;
+    if (!e && g == 0) {
+      if (start_pos & 1ull) out[start_pos] = 0;
+      if (tot && hipMemcpy(out + base, m->whole.p, tot, hipMemcpyDeviceToHost) != hipSuccess) e = X3_ERR_HIP;
+    }
+    if (e) rcs[g] = e;
+  });
+  pthread_barrier_destroy(&bar);
+  for (int g = 0; g < G; ++g)
+    if (rcs[g]) {
+      m->last_error = "device " + std::to_string(m->devices[g]) + ": " + m->ctx[g]->last_error;
+      return rcs[g];
+    }
+  if (out_pos) *out_pos = base + total;
+  if (base + total > out_cap) return X3_ERR_BYTE_WRITER_INSUFFICIENT_MEMORY;
+  if (stats)
+    for (int g = 0; g < G; ++g)
+      for (int k = 0; k < 6; ++k) stats[k] += st[(size_t)g * 6 + k];
+  return X3_OK;
+}
+
+// x3_decode_stream over all GPUs: the header chain is walked once (host), the frames are dealt out in contiguous
+// ranges, every GPU decodes its range and copies its samples straight to their place in the caller's buffer.
+// Same results and status as x3_decode_stream: nothing behind the first frame that fails is delivered.
+extern "C" int x3_mgpu_decode_stream(x3_mgpu* m, const uint8_t* x3, uint64_t len, const x3_params* p, int16_t* wav,
+                                     uint64_t wav_cap, uint64_t* n_out, uint64_t* frames_ok, uint64_t* frame_errors) {
+  if (!m || !p || (!x3 && len) || (!wav && wav_cap)) return X3_ERR_BAD_ARG;
+  if (n_out) *n_out = 0;
+  if (frames_ok) *frames_ok = 0;
+  if (frame_errors) *frame_errors = 0;
+  const int G = (int)m->ctx.size();
+  if (G == 1) return x3_decode_stream(m->ctx[0], x3, len, p, wav, wav_cap, n_out, frames_ok, frame_errors);
+  HostWalk w;
+  walk_host(x3, len, len, len, p, wav_cap, ~0ull, &w);
+  const uint64_t F = w.offs.size();
+  if (F == 0) return w.terminal;
+  struct Part {
+    uint64_t a = 0, cnt = 0, before = 0, first_bad = 0;
+    int bad_status = 0, rc = X3_OK;
+    HostWalk hw;
+  };
+  std::vector<Part> part((size_t)G);
+  x3_mgpu_parallel(G, [&](int g) {
+    Part& q = part[g];
+    x3_shard_frame_range(F, g, G, &q.a, &q.cnt);
+    if (!q.cnt) return;
+    x3_ctx* c = m->ctx[g];
+    if (hipSetDevice(c->device) != hipSuccess) { q.rc = X3_ERR_HIP; return; }
+    const uint64_t b0 = w.offs[q.a], s0 = w.woffs[q.a];
+    const uint64_t b1 = q.a + q.cnt < F ? w.offs[q.a + q.cnt] : w.end_pos;
+    const uint64_t s1 = q.a + q.cnt < F ? w.woffs[q.a + q.cnt] : w.nsamp;
+    for (uint64_t i = 0; i < q.cnt; ++i) {
+      q.hw.offs.push_back(w.offs[q.a + i] - b0);
+      q.hw.woffs.push_back(w.woffs[q.a + i] - s0);
+    }
+    q.hw.nsamp = s1 - s0;
+    q.rc = decode_frames_host(c, x3 + b0, b1 - b0, q.hw, p, nullptr, ~0ull, &q.before, &q.first_bad, &q.bad_status, false);
+  });
+  for (int g = 0; g < G; ++g)
+    if (part[g].rc) {
+      m->last_error = "device " + std::to_string(m->devices[g]) + ": " + m->ctx[g]->last_error;
+      return part[g].rc;
+    }
+  // the first frame that failed, over all ranges, ends the walk
+  uint64_t first_bad = F, before = w.nsamp;
+  int bad_status = 0, stop = G;
+  for (int g = 0; g < G; ++g)
+    if (part[g].cnt && part[g].first_bad < part[g].cnt) {
+      first_bad = part[g].a + part[g].first_bad;
+      before = w.woffs[part[g].a] + part[g].before;
+      bad_status = part[g].bad_status;
+      stop = g;
+      break;
+    }
+  std::vector<int> rcs((size_t)G, X3_OK);
+  x3_mgpu_parallel(G, [&](int g) {
+    const Part& q = part[g];
+    if (!q.cnt || g > stop) return;
+    x3_ctx* c = m->ctx[g];
+    const uint64_t take = g == stop ? q.before : q.hw.nsamp;
+    if (hipSetDevice(c->device) != hipSuccess) { rcs[g] = X3_ERR_HIP; return; }
+    if (take && hipMemcpy(wav + w.woffs[q.a], c->out.p, take * sizeof(int16_t), hipMemcpyDeviceToHost) != hipSuccess) rcs[g] = X3_ERR_HIP;
+  });
+  for (int g = 0; g < G; ++g)
+    if (rcs[g]) return rcs[g];
+  if (n_out) *n_out = before;
+  if (frames_ok) *frames_ok = first_bad;
+  return walk_result(F, first_bad, bad_status, w.terminal, frame_errors);
+}

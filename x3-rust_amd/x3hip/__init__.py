@@ -30,6 +30,7 @@ ERR_BAD_ARG = 24
 # every symbol include/x3hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "x3_strerror", "x3_ctx_create", "x3_ctx_create_on_stream", "x3_ctx_destroy", "x3_ctx_sync", "x3_last_error",
+    "x3_ctx_set_option", "x3_ctx_get_option",
     "x3_ctx_enable_kernel_timing", "x3_ctx_kernel_time", "x3_ctx_reset_kernel_time",
     "x3_params_default", "x3_params_validate", "x3_num_frames", "x3_encode_bound",
     "x3_crc16", "x3_crc16_dev", "x3_crc16_update",
@@ -39,6 +40,11 @@ SYMBOLS = [
     "x3_wav_to_x3a", "x3_x3a_to_wav",
     "x3_encode_dev", "x3_encode_result", "x3_decode_dev", "x3_decode_result", "x3_index_dev", "x3_decode_stream_dev",
     "x3_synth", "x3_synth_dev", "x3_dev_alloc", "x3_dev_free", "x3_dev_upload", "x3_dev_download",
+    "x3_shard_unique_id", "x3_shard_create", "x3_shard_destroy", "x3_shard_rank", "x3_shard_world",
+    "x3_shard_frame_range", "x3_shard_sample_range", "x3_shard_offsets", "x3_shard_exchange_lengths",
+    "x3_shard_exchange_length_value", "x3_shard_lengths", "x3_shard_gather",
+    "x3_mgpu_create", "x3_mgpu_destroy", "x3_mgpu_devices", "x3_mgpu_ctx", "x3_mgpu_shard", "x3_mgpu_last_error",
+    "x3_mgpu_encode", "x3_mgpu_decode_stream",
 ]
 
 
@@ -116,6 +122,8 @@ def lib():
     L.x3_ctx_sync.argtypes = [vp]
     L.x3_last_error.restype = C.c_char_p
     L.x3_last_error.argtypes = [vp]
+    L.x3_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_longlong]
+    L.x3_ctx_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_longlong)]
     L.x3_ctx_enable_kernel_timing.argtypes = [vp, i32]
     L.x3_ctx_kernel_time.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(u64)]
     L.x3_ctx_reset_kernel_time.argtypes = [vp]
@@ -156,8 +164,146 @@ def lib():
     L.x3_dev_free.argtypes = [vp, vp]
     L.x3_dev_upload.argtypes = [vp, vp, vp, u64]
     L.x3_dev_download.argtypes = [vp, vp, vp, u64]
+    L.x3_shard_unique_id.argtypes = [vp]
+    L.x3_shard_create.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
+    L.x3_shard_destroy.restype = None
+    L.x3_shard_destroy.argtypes = [vp]
+    L.x3_shard_rank.argtypes = [vp]
+    L.x3_shard_world.argtypes = [vp]
+    L.x3_shard_frame_range.restype = None
+    L.x3_shard_frame_range.argtypes = [u64, i32, i32, C.POINTER(u64), C.POINTER(u64)]
+    L.x3_shard_sample_range.restype = None
+    L.x3_shard_sample_range.argtypes = [u64, PP, i32, i32, C.POINTER(u64), C.POINTER(u64)]
+    L.x3_shard_offsets.restype = None
+    L.x3_shard_offsets.argtypes = [C.POINTER(u64), i32, C.POINTER(u64)]
+    L.x3_shard_exchange_lengths.argtypes = [vp, vp, vp]
+    L.x3_shard_exchange_length_value.argtypes = [vp, u64, vp]
+    L.x3_shard_lengths.argtypes = [vp, C.POINTER(u64)]
+    L.x3_shard_gather.argtypes = [vp, vp, C.POINTER(u64), i32, vp, u64, C.POINTER(u64)]
+    L.x3_mgpu_create.argtypes = [C.POINTER(i32), i32, C.POINTER(vp)]
+    L.x3_mgpu_destroy.restype = None
+    L.x3_mgpu_destroy.argtypes = [vp]
+    L.x3_mgpu_devices.argtypes = [vp]
+    L.x3_mgpu_ctx.restype = vp
+    L.x3_mgpu_ctx.argtypes = [vp, i32]
+    L.x3_mgpu_shard.restype = vp
+    L.x3_mgpu_shard.argtypes = [vp, i32]
+    L.x3_mgpu_last_error.restype = C.c_char_p
+    L.x3_mgpu_last_error.argtypes = [vp]
+    L.x3_mgpu_encode.argtypes = [vp, vp, u64, u32, PP, vp, u64, u64, C.POINTER(u64), vp]
+    L.x3_mgpu_decode_stream.argtypes = [vp, vp, u64, PP, vp, u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     _lib = L
     return L
+
+
+# ---- sharding arithmetic (host only: works without a GPU)
+
+def shard_frame_range(n_frames, rank, world):
+    a, c = C.c_uint64(0), C.c_uint64(0)
+    lib().x3_shard_frame_range(n_frames, rank, world, C.byref(a), C.byref(c))
+    return a.value, c.value
+
+
+def shard_sample_range(n_samples, params, rank, world):
+    a, c = C.c_uint64(0), C.c_uint64(0)
+    lib().x3_shard_sample_range(n_samples, C.byref(params), rank, world, C.byref(a), C.byref(c))
+    return a.value, c.value
+
+
+def shard_offsets(lengths):
+    n = len(lengths)
+    src = (C.c_uint64 * n)(*[int(v) for v in lengths])
+    dst = (C.c_uint64 * (n + 1))()
+    lib().x3_shard_offsets(src, n, dst)
+    return list(dst)
+
+
+def shard_unique_id():
+    """ncclGetUniqueId through the library: 128 bytes, made by rank 0 and handed to the other ranks out of band"""
+    buf = (C.c_uint8 * 128)()
+    rc = lib().x3_shard_unique_id(buf)
+    if rc:
+        raise X3Error(rc, "x3_shard_unique_id (librccl not available?)")
+    return bytes(buf)
+
+
+class Shard:
+    """one rank of a group of GPUs (x3_shard): RCCL communicator on the context's device and stream"""
+
+    def __init__(self, ctx, unique_id, rank, world):
+        self._h = C.c_void_p()
+        self.ctx, self.rank, self.world = ctx, rank, world
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        rc = lib().x3_shard_create(ctx._h, buf, rank, world, C.byref(self._h))
+        if rc:
+            raise X3Error(rc, "x3_shard_create: " + ctx.last_error())
+
+    def close(self):
+        if self._h:
+            lib().x3_shard_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def exchange_lengths(self, d_len, d_lengths=None):
+        rc = lib().x3_shard_exchange_lengths(self._h, d_len, d_lengths)
+        if rc:
+            raise X3Error(rc, "x3_shard_exchange_lengths: " + self.ctx.last_error())
+
+    def lengths(self):
+        out = (C.c_uint64 * self.world)()
+        rc = lib().x3_shard_lengths(self._h, out)
+        if rc:
+            raise X3Error(rc, "x3_shard_lengths: " + self.ctx.last_error())
+        return list(out)
+
+    def gather(self, d_sub, lengths, root, d_dst, dst_cap):
+        src = (C.c_uint64 * self.world)(*[int(v) for v in lengths])
+        tot = C.c_uint64(0)
+        rc = lib().x3_shard_gather(self._h, d_sub, src, root, d_dst, dst_cap, C.byref(tot))
+        if rc:
+            raise X3Error(rc, "x3_shard_gather: " + self.ctx.last_error())
+        return tot.value
+
+
+class MultiGpu:
+    """all GPUs from one process (x3_mgpu): host buffers in and out, same bytes as Context.encode / decode_stream"""
+
+    def __init__(self, devices):
+        self._h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        rc = lib().x3_mgpu_create(arr, len(devices), C.byref(self._h))
+        if rc:
+            raise X3Error(rc, "x3_mgpu_create")
+
+    def close(self):
+        if self._h:
+            lib().x3_mgpu_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def last_error(self):
+        return lib().x3_mgpu_last_error(self._h).decode()
+
+    def encode(self, wav, params=None, start_pos=0, cap=None, n_channels=1):
+        params = params or Params.default()
+        wav = np.ascontiguousarray(wav, dtype=np.int16)
+        if cap is None:
+            cap = start_pos + lib().x3_encode_bound(wav.size, C.byref(params)) + 1
+        out = np.zeros(max(cap, 1), dtype=np.uint8)
+        pos = C.c_uint64(0)
+        stats = np.zeros(6, dtype=np.uint64)
+        rc = lib().x3_mgpu_encode(self._h, wav.ctypes.data, wav.size, n_channels, C.byref(params), out.ctypes.data,
+                                  cap, start_pos, C.byref(pos), stats.ctypes.data)
+        return rc, out[: min(pos.value, cap)].copy(), stats
+
+    def decode_stream(self, x3, params=None, wav_cap=None):
+        params = params or Params.default()
+        x3 = np.ascontiguousarray(x3, dtype=np.uint8)
+        if wav_cap is None:
+            wav_cap = max(1, x3.size * 16)
+        wav = np.zeros(wav_cap, dtype=np.int16)
+        n, fok, ferr = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        rc = lib().x3_mgpu_decode_stream(self._h, x3.ctypes.data, x3.size, C.byref(params), wav.ctypes.data, wav_cap,
+                                         C.byref(n), C.byref(fok), C.byref(ferr))
+        return rc, wav[: n.value].copy(), fok.value, ferr.value
 
 
 def strerror(rc):
@@ -238,6 +384,19 @@ class Context:
 
     def last_error(self):
         return lib().x3_last_error(self._h).decode()
+
+    def set_option(self, name, value):
+        """tuning / testing knobs (include/x3hip.h: x3_ctx_set_option)"""
+        rc = lib().x3_ctx_set_option(self._h, name.encode(), int(value))
+        if rc:
+            raise X3Error(rc, "x3_ctx_set_option(%s)" % name)
+
+    def get_option(self, name):
+        v = C.c_longlong(0)
+        rc = lib().x3_ctx_get_option(self._h, name.encode(), C.byref(v))
+        if rc:
+            raise X3Error(rc, "x3_ctx_get_option(%s)" % name)
+        return v.value
 
     def sync(self):
         rc = lib().x3_ctx_sync(self._h)
