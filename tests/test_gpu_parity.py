@@ -719,7 +719,8 @@ def test_encoder_falls_back_when_grid_not_resident(x3):
     c = x3.Context(0)
     try:
         natural = None
-        wav = x3.synth(2, 321, 0, 10000 * 1500 + 17)
+        # (long enough that every resident workgroup has a second frame behind frames of workgroups that are not)
+        wav = x3.synth(2, 321, 0, 10000 * 3200 + 17)
         rc, _, _ = c.encode(wav[:30000], x3.Params.default())
         natural = c.get_option("stream_wgs_in_use")
         assert rc == 0 and natural >= 1
@@ -746,7 +747,7 @@ def test_encoder_fallback_leaves_the_prefix_alone(x3):
         rc, _, _ = c.encode(x3.synth(2, 1, 0, 30000), p)
         natural = c.get_option("stream_wgs_in_use")
         c.set_option("stream_wgs", natural + 1)
-        n = 10000 * 1500 + 17
+        n = 10000 * 3200 + 17
         wav = x3.synth(2, 654, 0, n)
         for start_pos in (4096, 321):
             d_wav = c.alloc(2 * n + 64)

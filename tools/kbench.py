@@ -12,8 +12,12 @@ ap.add_argument("--samples", type=int, default=691_200_000)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--kind", type=int, default=2)
 ap.add_argument("--clips", type=int, default=1, help="config-5 style batch: CLIPS clips of SAMPLES/CLIPS samples")
+ap.add_argument("--opt", action="append", default=[], help="context option name=value (x3_ctx_set_option), repeatable")
 a = ap.parse_args()
 ctx = x3hip.Context(0)
+for o in a.opt:
+    k, v = o.split("=")
+    ctx.set_option(k, int(v))
 p = x3hip.Params.default()
 n = a.samples
 L = x3hip.lib()
@@ -31,4 +35,5 @@ for _ in range(a.steps): step()
 rc, pos2, st2 = ctx.encode_result(); r2 = ctx.decode_result()
 assert rc == 0 and pos2 == pos and (os.environ.get("X3_NOCHECK") or r2[:3] == (0, F, 0)), (rc, pos2, r2)
 names = ["encode", "decode", "sizes", "scan", "check"]
-print(" ".join("%s=%.3f" % (names[i], ctx.kernel_time(i)[0] / a.steps) for i in range(5)), "ms; stream B/sample=%.4f" % (pos / n))
+print(" ".join("%s=%.3f" % (names[i], ctx.kernel_time(i)[0] / a.steps) for i in range(5)), "ms; stream B/sample=%.4f" % (pos / n),
+      "; wgs/CU=%d fallbacks=%d" % (ctx.get_option("stream_wgs_in_use"), ctx.get_option("encode_fallbacks")), a.opt)

@@ -21,6 +21,7 @@
 #include "x3_device.h"
 #include "x3_encode_kernel.h"
 #include "x3_encode_stream_kernel.h"
+#include "x3_encode_stream2_kernel.h"
 #include "x3_synth_core.h"
 #include "x3_util_kernels.h"
 
@@ -41,6 +42,7 @@ struct KernelTimer {
 struct X3Opts {
   int two_pass = 0;           // X3HIP_TWO_PASS: always use the two-pass encoder kernels
   int stream_wgs = 0;         // X3HIP_STREAM_WGS: workgroups per CU of the single-pass encoder (0 = derive)
+  int stream_v1 = 0;          // X3HIP_STREAM_V1: the first-generation single-pass encoder (9 waves, LDS sample tile)
   int decode_single = 0;      // X3HIP_DECODE_SINGLE: single-wave decoder kernels only
   int host_walk = -1;         // X3HIP_HOST_WALK: frame walk of x3_decode_stream on the host (1) / GPU (0) / by size (-1)
   int verbose = 0;            // X3HIP_VERBOSE
@@ -67,6 +69,7 @@ struct x3_ctx {
   // persistent small device state
   uint16_t* d_xpow = nullptr;          // X3_XP_SIZE entries
   uint32_t* d_xk16 = nullptr;          // [10][512][16]: x^(32*c*(511-t)) * x^b mod P (x3_encode_stream_kernel.h)
+  uint32_t* d_xk2 = nullptr;           // [10][X3_K2_DWORDS]: per-lane and per-wave multipliers (x3_encode_stream2_kernel.h)
   uint16_t* d_crctab = nullptr;        // [6][256]: slicing-by-4 CRC tables + the two x^2048 rows
   uint32_t* d_kx64 = nullptr;          // [64][16] (x3_frame_check_kernel)
   uint16_t* d_chktab = nullptr;        // [18][256] (x3_frame_check_kernel: T[s][k][v] and the x^8192 rows)
@@ -151,6 +154,7 @@ static void opts_from_env(X3Opts* o) {
   o->two_pass = std::getenv("X3HIP_TWO_PASS") ? 1 : 0;
   o->stream_wgs = (int)std::max(0ll, geti("X3HIP_STREAM_WGS", 0));
   o->decode_single = std::getenv("X3HIP_DECODE_SINGLE") ? 1 : 0;
+  o->stream_v1 = std::getenv("X3HIP_STREAM_V1") ? 1 : 0;
   if (const char* e = std::getenv("X3HIP_HOST_WALK")) o->host_walk = e[0] == '0' ? 0 : 1;
   o->verbose = std::getenv("X3HIP_VERBOSE") ? 1 : 0;
   o->file_chunk_frames = std::max(1ll, geti("X3HIP_FILE_CHUNK_FRAMES", o->file_chunk_frames));
@@ -236,6 +240,29 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
       }
     HIPCHK(c, hipMalloc(&c->d_xk16, xk.size() * sizeof(uint32_t)));
     HIPCHK(c, hipMemcpy(c->d_xk16, xk.data(), xk.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    {
+      // x3_encode_stream2_kernel: KL[l] = x^(32*c*(63-l)), KA[w] = x^(32*c*64*(7-w)), each as its sixteen shifts
+      std::vector<uint32_t> k2((size_t)10 * X3_K2_DWORDS, 0u);
+      for (int cd = 1; cd <= 10; ++cd) {
+        uint32_t* blk = k2.data() + (size_t)(cd - 1) * X3_K2_DWORDS;
+        for (int l = 0; l < 64; ++l) {
+          uint32_t k = gf_xpow_host(32ull * cd * (63 - l));
+          for (int b = 0; b < 16; ++b) {
+            blk[l * X3_K2_ROW + b] = k;
+            k = ((k << 1) ^ ((k & 0x8000u) ? 0x11021u : 0u)) & 0xFFFFu;
+          }
+        }
+        for (int w = 0; w < 8; ++w) {
+          uint32_t k = gf_xpow_host(32ull * cd * 64 * (7 - w));
+          for (int b = 0; b < 16; ++b) {
+            blk[X3_K2_KA + w * 16 + b] = k;
+            k = ((k << 1) ^ ((k & 0x8000u) ? 0x11021u : 0u)) & 0xFFFFu;
+          }
+        }
+      }
+      HIPCHK(c, hipMalloc(&c->d_xk2, k2.size() * sizeof(uint32_t)));
+      HIPCHK(c, hipMemcpy(c->d_xk2, k2.data(), k2.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     // T[j][v] = crc0 of byte v followed by j zero bytes = v * x^(8j+16) mod P
     // rows 4 and 5 (x3_frame_check_kernel): (v << 8) * x^2048 and v * x^2048
     std::vector<uint16_t> tab(6 * 256);
@@ -328,6 +355,7 @@ extern "C" void x3_ctx_destroy(x3_ctx* c) {
   }
   (void)hipFree(c->d_xpow);
   (void)hipFree(c->d_xk16);
+  (void)hipFree(c->d_xk2);
   (void)hipFree(c->d_crctab);
   (void)hipFree(c->d_kx64);
   (void)hipFree(c->d_chktab);
@@ -360,6 +388,7 @@ extern "C" int x3_ctx_set_option(x3_ctx* c, const char* name, long long value) {
   if (n == "two_pass") c->opt.two_pass = value != 0;
   else if (n == "stream_wgs") { c->opt.stream_wgs = (int)std::max(0ll, value); c->stream_wg_per_cu = -1; }
   else if (n == "decode_single") c->opt.decode_single = value != 0;
+  else if (n == "stream_v1") { c->opt.stream_v1 = value != 0; c->stream_wg_per_cu = -1; }
   else if (n == "host_walk") c->opt.host_walk = value < 0 ? -1 : (value != 0);
   else if (n == "verbose") c->opt.verbose = value != 0;
   else if (n == "file_chunk_frames") c->opt.file_chunk_frames = std::max(1ll, value);
@@ -374,6 +403,7 @@ extern "C" int x3_ctx_get_option(const x3_ctx* c, const char* name, long long* v
   if (n == "two_pass") *value = c->opt.two_pass;
   else if (n == "stream_wgs") *value = c->opt.stream_wgs;
   else if (n == "decode_single") *value = c->opt.decode_single;
+  else if (n == "stream_v1") *value = c->opt.stream_v1;
   else if (n == "host_walk") *value = c->opt.host_walk;
   else if (n == "verbose") *value = c->opt.verbose;
   else if (n == "file_chunk_frames") *value = c->opt.file_chunk_frames;
@@ -603,6 +633,29 @@ extern "C" int x3_crc16(x3_ctx* c, const uint8_t* data, uint64_t n, uint16_t* cr
 // ------------------------------------------------------------------------------------------------
 // encode
 // ------------------------------------------------------------------------------------------------
+// x3_encode_stream2_kernel has no "diff outside the reference's Rice table" test (the reference panics there:
+// X3_ERR_BAD_ARG from the two-pass kernels): true when no block can need it.  A block with max|d| = m <= thr[2] is
+// coded with code[ft(m)], ft = [m > thr0] + [m > thr1] (encoder.rs:241-247); it is inside that code's table when
+// m <= min(offset, len - offset - 1).
+static bool stream_safe_thresholds(const x3_params* p) {
+  uint32_t mmax[3] = {0, 0, 0};
+  bool used[3] = {false, false, false};
+  const uint32_t top = std::min<uint32_t>(p->thresholds[2], 70000u);
+  for (uint32_t m = 0; m <= top; ++m) {
+    const uint32_t ft = (m > p->thresholds[0] ? 1u : 0u) + (m > p->thresholds[1] ? 1u : 0u);
+    used[ft] = true;
+    mmax[ft] = m;
+  }
+  for (int ft = 0; ft < 3; ++ft) {
+    if (!used[ft]) continue;
+    const uint32_t cde = p->codes[ft];
+    if (cde > 3) return false;
+    const uint32_t inside = std::min(RICE_OFFSET[cde], RICE_LEN[cde] - RICE_OFFSET[cde] - 1u);
+    if (mmax[ft] > inside) return false;
+  }
+  return true;
+}
+
 struct EncPlan {
   X3DevParams dp;
   X3Geom g;
@@ -657,11 +710,64 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
   }
   HIPCHK(c, hipMemsetAsync(c->d_status, 0, 128, c->stream));
   // ---- single-pass path: default block length, 16-byte aligned frames (see x3_encode_stream_kernel.h)
-  const bool stream_path = p->block_len == 20 && pl.nthr == 512 && (spf % 8) == 0 &&
+  const bool stream_path = p->block_len == 20 && pl.nthr == 512 && (std::min<uint64_t>(spf, b->n_per_clip) + 18) / 20 <= 512 &&
+                           (spf % 8) == 0 &&
                            (b->n_clips == 1 || (b->clip_stride % 8) == 0) &&
                            (reinterpret_cast<uintptr_t>(d_wav) & 15u) == 0 && !c->force_two_pass && !c->opt.two_pass;
   c->last_enc = {d_wav, *b, *p, spf, d_out, out_cap, start_pos, d_frame_offsets};
-  if (stream_path) {
+  if (stream_path && !c->opt.stream_v1 && stream_safe_thresholds(p)) {
+    // second generation (x3_encode_stream2_kernel.h): eight waves, no sample tile in LDS
+    // part + two frame images + CRC tables + the multipliers of one chunk size
+    const size_t smem2 = X3_ENC_SMEM_HDR + 2 * (size_t)pl.img_dwords * 4 + 2048 + X3_K2_DWORDS * 4;
+    if (c->stream_wg_per_cu < 0) {
+      // Offsets wait on the other workgroups' frame sizes, so EVERY workgroup of the grid must be resident.  The
+      // occupancy API can over-report by one block per CU (MI355X_MICROARCH.md, "Residency"), so it is capped
+      // by the kernel's own register/LDS footprint: eight waves are two per SIMD, whatever the placement.
+      if (smem2 > 64 * 1024)
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_stream2_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
+      int nb = 0;
+      HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, x3_encode_stream2_kernel, X3_STREAM2_THREADS, smem2));
+      hipFuncAttributes fa;
+      HIPCHK(c, hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&x3_encode_stream2_kernel)));
+      const int alloc = ((fa.numRegs + 7) / 8) * 8;
+      const int wps = std::min(8, 512 / std::max(alloc, 8));
+      const int by_regs = (4 * wps) / 8;
+      const int by_lds = (int)((160 * 1024) / (smem2 + 256));  // (+ allocation granularity)
+      c->stream_wg_per_cu = std::max(0, std::min(std::min(nb, 4), std::min(by_regs, by_lds)));
+      // experiments and the fallback test: force a grid (one that is too large cannot be resident: the size
+      // waits time out and x3_encode_result re-encodes with the two-pass kernels)
+      if (c->opt.stream_wgs > 0) c->stream_wg_per_cu = c->opt.stream_wgs;
+      if (c->opt.verbose)
+        std::fprintf(stderr, "x3hip: stream encoder v2 %d VGPRs, %zu B LDS, occupancy API %d, by_regs %d, by_lds %d -> %d workgroups/CU\n",
+                     fa.numRegs, smem2, nb, by_regs, by_lds, c->stream_wg_per_cu);
+    }
+    if (c->stream_wg_per_cu >= 1 && smem2 <= 160 * 1024) {
+      // frame-size descriptors {epoch:12 | bytes:20}: the epoch makes last launch's words "not ready"
+      // without clearing the array (cleared when it is (re)allocated and when the epoch wraps)
+      const uint64_t grid = std::min<uint64_t>(std::min<uint64_t>(F, X3_STREAM2_MAX_GRID), (uint64_t)c->n_cus * c->stream_wg_per_cu);
+      const size_t desc_pad = 1024 + 64;  // words in front of desc[0]: the windows of the first frames reach below frame 0
+      const size_t desc_bytes = (F + desc_pad) * sizeof(uint32_t);
+      const bool fresh = c->desc.cap < desc_bytes;
+      if ((rc = ensure(c, c->desc, desc_bytes))) return rc;
+      if (fresh || ++c->desc_epoch > 0xFFFu) {
+        HIPCHK(c, hipMemsetAsync(c->desc.p, 0, c->desc.cap, c->stream));
+        c->desc_epoch = 1;
+      }
+      {
+        TimerScope ts(c, 0);
+        hipLaunchKernelGGL(x3_encode_stream2_kernel, dim3((unsigned)grid), dim3(X3_STREAM2_THREADS), smem2, c->stream,
+                           d_wav, pl.g, pl.dp, d_off, d_out, out_cap, start_pos, (uint32_t*)c->desc.p + desc_pad, c->desc_epoch,
+                           reinterpret_cast<unsigned char*>(c->d_status), (const uint32_t*)c->d_xk2,
+                           (const uint16_t*)c->d_crctab, pl.img_dwords);
+      }
+      HIPCHK(c, hipGetLastError());
+      c->encode_pending = true;
+      c->enc_start_pos = start_pos;
+      return X3_OK;
+    }
+  }
+  if (stream_path && c->opt.stream_v1) {
     if (c->stream_wg_per_cu < 0) {
       // Offsets wait on the other workgroups' frame sizes, so EVERY workgroup of the grid must be resident.  The
       // occupancy API can over-report by one block per CU (MI355X_MICROARCH.md, "Residency"), so it is
