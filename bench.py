@@ -299,6 +299,47 @@ def main():
                     "pcie_gb_s": round((2 * n + hpos.value) / te / 1e9, 1),
                     "note": "x3_encode + x3_decode_stream on caller-owned pageable host buffers: H2D, kernels, D2H "
                             "and the host-side frame walk, second call (the first also allocates device scratch)"}
+        # ---- the reference's incremental reader (X3aReader::decode_next_frame, one frame per call) over the same
+        # stream as an .x3a archive in host memory: x3_reader_* decodes a window of frames ahead per launch set and
+        # hands them out one by one (the loop below is a Python loop over the C entry point: ~1 us of ctypes per call)
+        rc_h, ahdr = x3hip.archive_header_write(192000, p)
+        assert rc_h == 0
+        x3a = np.concatenate([ahdr, hout[:hpos.value]])
+        rd = C.c_void_p()
+        assert L.x3_reader_open_mem(ctx._h, x3a.ctypes.data, x3a.size, C.byref(rd)) == 0
+        fbuf = np.zeros(65536, dtype=np.int16)
+        fn_ = C.c_uint64(0)
+        nf = tot = 0
+        nxt, fptr, fcap, fref = L.x3_reader_next_frame, fbuf.ctypes.data, fbuf.size, C.byref(fn_)
+        t0 = time.perf_counter()
+        while True:
+            rc = nxt(rd, fptr, fcap, fref)
+            if rc or fn_.value == 0:
+                break
+            nf += 1
+            tot += fn_.value
+        t1 = time.perf_counter()
+        assert rc == 0 and tot == n and nf == F and L.x3_reader_frame_errors(rd) == 0, (rc, tot, nf)
+        assert np.array_equal(fbuf[:p.spf], hwav[n - p.spf:]) if n % p.spf == 0 else True
+        L.x3_reader_close(rd)
+        per_frame = {"frames": nf, "ms": round((t1 - t0) * 1e3, 2), "msamples_s": round(n / (t1 - t0) / 1e6, 1),
+                     "us_per_call": round((t1 - t0) / max(nf, 1) * 1e6, 3),
+                     "note": "x3_reader_open_mem + a loop of x3_reader_next_frame (= decode_next_frame, decodefile.rs:105-136) "
+                             "over the whole stream from host memory into a host frame buffer; windows of %d frames are "
+                             "checked and decoded ahead on the GPU" % ctx.get_option("reader_window_frames")}
+        # ---- a FOREIGN stream resident in HBM (frame offsets unknown): GPU frame walk + check + decode
+        fs_ms = []
+        for _ in range(4):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            r4 = ctx.decode_stream_dev(out.data_ptr(), pos, p, back.data_ptr(), n)
+            fs_ms.append((time.perf_counter() - t0) * 1e3)
+            assert r4 == (0, n, F, 0), r4
+        assert torch.equal(back, wav)
+        foreign = {"ms": round(min(fs_ms[1:]), 3), "first_call_ms": round(fs_ms[0], 3),
+                   "note": "x3_decode_stream_dev on the device-resident stream: frame walk on the GPU (every byte offset "
+                           "tested for a header, successor chain by pointer doubling) + header/payload-CRC check + decode, "
+                           "host wall time incl. the summary's trip back"}
         del hwav, hout, hback
 
     if rank == 0:
@@ -307,7 +348,7 @@ def main():
         # algorithmic HBM bytes per launch (DESIGN.md "Kernels"): 2 B per sample + P stream bytes for
         # the encoder and the decoder; the size pass re-reads the samples; the check pass reads the stream
         alg = {"encode": 2 * n + pos, "decode": 2 * n + pos, "frame_sizes": 2 * n, "frame_check": pos}
-        kname = {"encode": "x3_encode_stream_kernel" if ktimes.get("frame_sizes", 0.0) == 0.0 else "x3_encode_frames_kernel<false>",
+        kname = {"encode": "x3_encode_stream2_kernel" if ktimes.get("frame_sizes", 0.0) == 0.0 else "x3_encode_frames_kernel<false>",
                  "decode": "x3_decode_split_kernel",
                  "frame_sizes": "x3_encode_frames_kernel<true>", "frame_check": "x3_frame_check_kernel"}
         alg = {k: v for k, v in alg.items() if ktimes.get(k, 0.0) > 0.0}  # the two-pass fallback kernels may not run
@@ -369,6 +410,9 @@ def main():
         }
         if host_api is not None:
             res["host_buffer_api"] = host_api
+            res["per_frame_api"] = per_frame
+            res["foreign_stream"] = foreign
+            res["foreign_stream_ms"] = foreign["ms"]
         if gather is not None:
             res["gather"] = gather
             res["rccl_ranks"] = world

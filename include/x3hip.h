@@ -107,6 +107,8 @@ const char* x3_last_error(const x3_ctx* ctx);
  *   "decode_single" (X3HIP_DECODE_SINGLE)  1: single-wave decoder kernels only
  *   "host_walk" (X3HIP_HOST_WALK)          frame walk of x3_decode_stream: 1 host, 0 GPU, -1 by stream size
  *   "file_chunk_frames" (X3HIP_FILE_CHUNK_FRAMES), "file_workers" (X3HIP_FILE_WORKERS)   x3_wav_to_x3a / x3_x3a_to_wav
+ *   "reader_window_frames" (X3HIP_READER_WINDOW_FRAMES)   frames x3_reader decodes ahead per launch set
+ *   "stream_v1" (X3HIP_STREAM_V1)          1: the first-generation single-pass encoder kernel
  *   "verbose" (X3HIP_VERBOSE)
  * x3_ctx_get_option also reads "encode_fallbacks" (launches of the single-pass encoder that timed out waiting for
  * a non-resident workgroup and were redone by the two-pass kernels) and "stream_wgs_in_use".
@@ -227,6 +229,23 @@ int x3_x3a_decode(x3_ctx* ctx, const uint8_t* x3a, uint64_t len, int16_t* wav, u
 int x3_wav_to_x3a(x3_ctx* ctx, const char* wav_path, const char* x3a_path, uint64_t stats[6]);
 int x3_x3a_to_wav(x3_ctx* ctx, const char* x3a_path, const char* wav_path, uint64_t* n_samples,
                   uint64_t* frame_errors);
+
+/* `X3aReader` (src/decodefile.rs:47-137): open / spec / decode_next_frame -- one frame per call, for callers written
+ * against the reference's incremental reader.  A call that finds nothing prepared decodes a window of frames ahead in
+ * one launch set (option "reader_window_frames", default 4096) and the following calls are a header parse and a
+ * memcpy.  x3_reader_next_frame = `decode_next_frame`: *n_out = the frame's sample count (Ok(Some(n))), or 0 with
+ * X3_OK for Ok(None) -- end of the data, a payload that runs past it, or a frame that fails to decode (counted:
+ * x3_reader_frame_errors) -- or an error status; as in the reference the reader has then consumed the frame and a
+ * further call goes on behind it.  wav needs room for the frame (<= 65535 samples).  x3_reader_open_mem reads an
+ * archive that is in memory (borrowed: it must outlive the reader). */
+typedef struct x3_reader x3_reader;
+int x3_reader_open(x3_ctx* ctx, const char* x3a_path, x3_reader** reader);
+int x3_reader_open_mem(x3_ctx* ctx, const uint8_t* x3a, uint64_t len, x3_reader** reader);
+int x3_reader_spec(const x3_reader* reader, uint32_t* sample_rate, x3_params* p, uint8_t* channels);
+int x3_reader_next_frame(x3_reader* reader, int16_t* wav, uint64_t wav_cap, uint64_t* n_out);
+uint64_t x3_reader_frame_errors(const x3_reader* reader);
+uint64_t x3_reader_position(const x3_reader* reader); /* byte offset in the archive of the next frame header */
+void x3_reader_close(x3_reader* reader);
 
 /* ------------------------------------------------------------------ device-resident API */
 

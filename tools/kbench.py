@@ -12,6 +12,8 @@ ap.add_argument("--samples", type=int, default=691_200_000)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--kind", type=int, default=2)
 ap.add_argument("--clips", type=int, default=1, help="config-5 style batch: CLIPS clips of SAMPLES/CLIPS samples")
+ap.add_argument("--pad", type=int, default=0, help="allocate PAD KiB first (shifts the addresses of everything behind it)")
+ap.add_argument("--repeat", type=int, default=1, help="re-allocate and re-measure REPEAT times in one process")
 ap.add_argument("--opt", action="append", default=[], help="context option name=value (x3_ctx_set_option), repeatable")
 a = ap.parse_args()
 ctx = x3hip.Context(0)
@@ -24,16 +26,28 @@ L = x3hip.lib()
 npc = n // a.clips
 n = npc * a.clips
 F = L.x3_num_frames(npc, C.byref(p)) * a.clips; cap = L.x3_encode_bound(npc, C.byref(p)) * a.clips
-d_wav = ctx.alloc(2 * n); d_out = ctx.alloc(cap + 16); d_off = ctx.alloc(8 * (F + 1)); d_back = ctx.alloc(2 * n)
-ctx.synth_dev(a.kind, 0x58330003, 0, n, d_wav)
-def step():
-    assert ctx.encode_dev(d_wav, npc, p, d_out, cap, 0, d_off, n_clips=a.clips, clip_stride=npc) == 0
-    assert ctx.decode_dev(d_out, cap, d_off, F, p, d_back, n, n_per_clip=npc, n_clips=a.clips, clip_stride=npc) == 0
-step(); rc, pos, st = ctx.encode_result(); assert rc == 0; r = ctx.decode_result(); assert os.environ.get("X3_NOCHECK") or r[:3] == (0, F, 0), r
-ctx.enable_kernel_timing(True); ctx.reset_kernel_time()
-for _ in range(a.steps): step()
-rc, pos2, st2 = ctx.encode_result(); r2 = ctx.decode_result()
-assert rc == 0 and pos2 == pos and (os.environ.get("X3_NOCHECK") or r2[:3] == (0, F, 0)), (rc, pos2, r2)
-names = ["encode", "decode", "sizes", "scan", "check"]
-print(" ".join("%s=%.3f" % (names[i], ctx.kernel_time(i)[0] / a.steps) for i in range(5)), "ms; stream B/sample=%.4f" % (pos / n),
-      "; wgs/CU=%d fallbacks=%d" % (ctx.get_option("stream_wgs_in_use"), ctx.get_option("encode_fallbacks")), a.opt)
+def run_once(tag):
+    d_wav = ctx.alloc(2 * n); d_out = ctx.alloc(cap + 16); d_off = ctx.alloc(8 * (F + 1)); d_back = ctx.alloc(2 * n)
+    ctx.synth_dev(a.kind, 0x58330003, 0, n, d_wav)
+    def step():
+        assert ctx.encode_dev(d_wav, npc, p, d_out, cap, 0, d_off, n_clips=a.clips, clip_stride=npc) == 0
+        assert ctx.decode_dev(d_out, cap, d_off, F, p, d_back, n, n_per_clip=npc, n_clips=a.clips, clip_stride=npc) == 0
+    ctx.enable_kernel_timing(False)
+    step(); rc, pos, st = ctx.encode_result(); assert rc == 0; r = ctx.decode_result(); assert os.environ.get("X3_NOCHECK") or r[:3] == (0, F, 0), r
+    ctx.enable_kernel_timing(True); ctx.reset_kernel_time()
+    for _ in range(a.steps): step()
+    rc, pos2, st2 = ctx.encode_result(); r2 = ctx.decode_result()
+    assert rc == 0 and pos2 == pos and (os.environ.get("X3_NOCHECK") or r2[:3] == (0, F, 0)), (rc, pos2, r2)
+    names = ["encode", "decode", "sizes", "scan", "check"]
+    print(" ".join("%s=%.3f" % (names[i], ctx.kernel_time(i)[0] / a.steps) for i in range(5)), "ms; stream B/sample=%.4f" % (pos / n),
+          "; wgs/CU=%d fallbacks=%d" % (ctx.get_option("stream_wgs_in_use"), ctx.get_option("encode_fallbacks")), a.opt, tag,
+          "wav=%x out=%x back=%x" % (d_wav, d_out, d_back), flush=True)
+    return d_wav, d_out, d_off, d_back
+pads = []
+if a.pad:
+    pads.append(ctx.alloc(a.pad * 1024))
+for rep in range(a.repeat):
+    bufs = run_once("rep %d" % rep)
+    if rep + 1 < a.repeat:
+        for d in bufs: ctx.free(d)
+        pads.append(ctx.alloc((rep + 1) * 1234 * 1024))

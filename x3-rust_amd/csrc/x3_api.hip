@@ -48,11 +48,14 @@ struct X3Opts {
   int verbose = 0;            // X3HIP_VERBOSE
   long long file_chunk_frames = 800;  // X3HIP_FILE_CHUNK_FRAMES: 16 MB of samples per chunk (tools/file_bench.py)
   int file_workers = 4;       // X3HIP_FILE_WORKERS
+  long long reader_window_frames = 4096;  // X3HIP_READER_WINDOW_FRAMES: frames x3_reader decodes ahead per launch set
+  int check_prio = 1;         // X3HIP_CHECK_PRIO: queue priority of the side stream the check kernel runs on (-1 low, 0 same, 1 high)
+  int check_first = 0;        // X3HIP_CHECK_FIRST: enqueue the check kernel in front of the decoder (1) or behind it (0)
+  int check_wgs = 8;          // X3HIP_CHECK_WGS: check-kernel workgroups per CU
 #ifdef X3_PROFILING
   // profiling builds only (-DX3_PROFILING): never in the shipped library
   int check_serial = 0;       // X3HIP_CHECK_SERIAL: the check pass in front of the decoder, same stream
   int no_check = 0;           // X3HIP_PROFILE_NO_CHECK: time the decoder alone (payload CRCs NOT verified)
-  int check_wgs = 8;          // X3HIP_CHECK_WGS: check-kernel workgroups per CU
   int dyn_lds = 0;            // X3HIP_DECODE_DYN_LDS: extra LDS per decoder group (occupancy experiments)
 #endif
 };
@@ -159,10 +162,13 @@ static void opts_from_env(X3Opts* o) {
   o->verbose = std::getenv("X3HIP_VERBOSE") ? 1 : 0;
   o->file_chunk_frames = std::max(1ll, geti("X3HIP_FILE_CHUNK_FRAMES", o->file_chunk_frames));
   o->file_workers = (int)std::max(1ll, std::min(16ll, geti("X3HIP_FILE_WORKERS", o->file_workers)));
+  o->reader_window_frames = std::max(1ll, geti("X3HIP_READER_WINDOW_FRAMES", o->reader_window_frames));
+  o->check_prio = (int)geti("X3HIP_CHECK_PRIO", o->check_prio);
+  o->check_first = (int)geti("X3HIP_CHECK_FIRST", o->check_first);
+  o->check_wgs = (int)std::max(1ll, geti("X3HIP_CHECK_WGS", o->check_wgs));
 #ifdef X3_PROFILING
   o->check_serial = std::getenv("X3HIP_CHECK_SERIAL") ? 1 : 0;
   o->no_check = std::getenv("X3HIP_PROFILE_NO_CHECK") ? 1 : 0;
-  o->check_wgs = (int)std::max(1ll, geti("X3HIP_CHECK_WGS", o->check_wgs));
   o->dyn_lds = (int)std::max(0ll, geti("X3HIP_DECODE_DYN_LDS", 0));
 #endif
 }
@@ -193,9 +199,11 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
     // the decoder instead of beside it (seen once RCCL had created its own streams: HIP maps streams of one
     // priority onto a few hardware queues round robin).  Streams of another priority get queues of their own.
     int lo = 0, hi = 0;
-    HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
-    if (hi < lo) HIPCHK(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi));
-    else HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = numerically greatest = lowest priority
+    if (hi < lo && c->opt.check_prio != 0)
+      HIPCHK(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, c->opt.check_prio > 0 ? hi : lo));
+    else
+      HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
   }
   HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
@@ -209,7 +217,7 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
   HIPCHK(c, hipHostMalloc(&c->h_status, 128));
   c->h_stats = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_status) + 32);
   HIPCHK(c, hipHostMalloc(&c->h_summary, sizeof(X3DecodeSummary)));
-  HIPCHK(c, hipHostMalloc(&c->h_summary_init, sizeof(X3DecodeSummary)));
+  HIPCHK(c, hipHostMalloc(&c->h_summary_init, 256));  // (also the pinned landing place of X3IndexSummary)
   HIPCHK(c, hipHostMalloc(&c->h_crc, 16));
   std::vector<uint16_t> xp(X3_XP_SIZE);
   for (int j = 0; j < X3_XP_LEVELS; ++j)
@@ -393,6 +401,9 @@ extern "C" int x3_ctx_set_option(x3_ctx* c, const char* name, long long value) {
   else if (n == "verbose") c->opt.verbose = value != 0;
   else if (n == "file_chunk_frames") c->opt.file_chunk_frames = std::max(1ll, value);
   else if (n == "file_workers") c->opt.file_workers = (int)std::max(1ll, std::min(16ll, value));
+  else if (n == "reader_window_frames") c->opt.reader_window_frames = std::max(1ll, value);
+  else if (n == "check_first") c->opt.check_first = value != 0;
+  else if (n == "check_wgs") c->opt.check_wgs = (int)std::max(1ll, value);
   else return X3_ERR_BAD_ARG;
   return X3_OK;
 }
@@ -408,6 +419,10 @@ extern "C" int x3_ctx_get_option(const x3_ctx* c, const char* name, long long* v
   else if (n == "verbose") *value = c->opt.verbose;
   else if (n == "file_chunk_frames") *value = c->opt.file_chunk_frames;
   else if (n == "file_workers") *value = c->opt.file_workers;
+  else if (n == "reader_window_frames") *value = c->opt.reader_window_frames;
+  else if (n == "check_first") *value = c->opt.check_first;
+  else if (n == "check_wgs") *value = c->opt.check_wgs;
+  else if (n == "check_prio") *value = c->opt.check_prio;
   else if (n == "encode_fallbacks") *value = (long long)c->encode_fallbacks;  // read-only counter
   else if (n == "stream_wgs_in_use") *value = c->stream_wg_per_cu;            // read-only, -1 before the first launch
   else return X3_ERR_BAD_ARG;
@@ -999,9 +1014,11 @@ extern "C" int x3_encode_batch(x3_ctx* c, const int16_t* const* wavs, const uint
 // ------------------------------------------------------------------------------------------------
 // decode
 // ------------------------------------------------------------------------------------------------
+// wav_off_aligned: the caller knows that every d_wav_offsets[f] is a multiple of eight samples (the two-wave decoder
+// writes 16-byte aligned rows); without that knowledge caller-supplied offsets go to the single-wave kernels
 static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint64_t* d_frame_offsets,
                            uint64_t F, const x3_batch* batch, const uint64_t* d_wav_offsets, const x3_params* p,
-                           int16_t* d_wav, uint64_t wav_cap, int32_t* d_status) {
+                           int16_t* d_wav, uint64_t wav_cap, int32_t* d_status, bool wav_off_aligned = false) {
   if (reinterpret_cast<uintptr_t>(d_x3) & 3u) return X3_ERR_BAD_ARG;
   if (reinterpret_cast<uintptr_t>(d_wav) & 1u) return X3_ERR_BAD_ARG;
   if (F == 0 || F > 0x7FFFFFFFull) return X3_ERR_BAD_ARG;
@@ -1029,26 +1046,33 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
 #ifdef X3_PROFILING
   hipStream_t check_stream = c->opt.check_serial ? c->stream : c->stream2;
   const bool no_check = c->opt.no_check != 0;
-  const uint64_t check_wgs_per_cu = (uint64_t)c->opt.check_wgs;
 #else
   hipStream_t check_stream = c->stream2;
   const bool no_check = false;
-  const uint64_t check_wgs_per_cu = 8;
 #endif
+  const uint64_t check_wgs_per_cu = (uint64_t)c->opt.check_wgs;
   HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
   HIPCHK(c, hipStreamWaitEvent(check_stream, c->ev_fork, 0));
-  if (no_check) {
-    // profiling builds only: time the decoder without the check pass beside it (payload CRCs are NOT verified)
-    HIPCHK(c, hipMemsetAsync(c->dec_cstatus.p, 0, F * sizeof(int32_t), c->stream2));
-  } else {
-    TimerScope ts(c, 4, check_stream);
-    const uint64_t check_grid = std::min<uint64_t>((F + 3) / 4, (uint64_t)c->n_cus * check_wgs_per_cu);
-    hipLaunchKernelGGL(x3_frame_check_kernel, dim3((unsigned)check_grid), dim3(256), 0, check_stream,
-                       reinterpret_cast<const uint32_t*>(d_x3), x3_len, d_frame_offsets, F,
-                       (const uint16_t*)c->d_xinv8, (const uint16_t*)c->d_chktab, (const uint32_t*)c->d_kx64,
-                       (int32_t*)c->dec_cstatus.p, reinterpret_cast<unsigned long long*>(c->d_summary));
-  }
-  HIPCHK(c, hipEventRecord(c->ev_join, check_stream));
+  // The check pass and the decoder are independent and run side by side; the decoder is enqueued first.  (Neither the
+  // order nor the side stream's queue priority selects between the decoder's timing modes -- 0.81 / 0.87 / 0.94 ms
+  // per process on one box, 0.98 on another with no check kernel at all: measured, tools/dbg_modes.sh, DESIGN.md.)
+  auto launch_check = [&]() -> int {
+    if (no_check) {
+      // profiling builds only: time the decoder without the check pass beside it (payload CRCs are NOT verified)
+      HIPCHK(c, hipMemsetAsync(c->dec_cstatus.p, 0, F * sizeof(int32_t), c->stream2));
+
+    } else {
+      TimerScope ts(c, 4, check_stream);
+      const uint64_t check_grid = std::min<uint64_t>((F + 3) / 4, (uint64_t)c->n_cus * check_wgs_per_cu);
+      hipLaunchKernelGGL(x3_frame_check_kernel, dim3((unsigned)check_grid), dim3(256), 0, check_stream,
+                         reinterpret_cast<const uint32_t*>(d_x3), x3_len, d_frame_offsets, F,
+                         (const uint16_t*)c->d_xinv8, (const uint16_t*)c->d_chktab, (const uint32_t*)c->d_kx64,
+                         (int32_t*)c->dec_cstatus.p, reinterpret_cast<unsigned long long*>(c->d_summary));
+    }
+    HIPCHK(c, hipEventRecord(c->ev_join, check_stream));
+    return X3_OK;
+  };
+  if (c->opt.check_first && (rc = launch_check())) return rc;
   {
     // the branch-free kernel needs every valid Rice codeword (zeros + terminator + sub-code) to fit 32 bits
     bool fast = true;
@@ -1062,10 +1086,10 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
     // r' + level * (n - 1) (decoder.rs:186, r' = the hard-wired 2 / 4 bits INCLUDING the one) only when the
     // code of ftype 2 has one sub-bit and that of ftype 3 three -- the default codes; the single-wave kernels
     // follow the reference's formula literally and take every other code set.
-    const bool split = fast && dp.block_len == X3S_BL && dp.k[1] == 1u && dp.k[2] == 3u && !d_wav_offsets &&
-                       !c->force_single_wave_decode &&
+    const bool split = fast && dp.block_len == X3S_BL && dp.k[1] == 1u && dp.k[2] == 3u &&
+                       (!d_wav_offsets || wav_off_aligned) && !c->force_single_wave_decode &&
                        !c->opt.decode_single && (reinterpret_cast<uintptr_t>(d_wav) & 15u) == 0 &&
-                       (dp.spf % 8u) == 0 && (g.fpc * (uint64_t)1 >= g.n_frames || (g.clip_stride % 8u) == 0);
+                       (d_wav_offsets || ((dp.spf % 8u) == 0 && (g.fpc * (uint64_t)1 >= g.n_frames || (g.clip_stride % 8u) == 0)));
 #ifdef X3_PROFILING
     const size_t dyn_lds = (size_t)c->opt.dyn_lds;
 #else
@@ -1075,7 +1099,7 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
     if (split)
       hipLaunchKernelGGL(x3_decode_split_kernel, dim3((unsigned)((F + 63) / 64)), dim3(128),
                          dyn_lds, c->stream, d_x3, x3_len,
-                         d_frame_offsets, F, g, dp, d_wav, wav_cap, d_status, (X3FrameMeta*)c->dec_meta.p);
+                         d_frame_offsets, F, g, d_wav_offsets, dp, d_wav, wav_cap, d_status, (X3FrameMeta*)c->dec_meta.p);
     else if (fast)
       hipLaunchKernelGGL(x3_decode_fast_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, c->stream, d_x3, x3_len,
                          d_frame_offsets, F, g, d_wav_offsets, dp, d_wav, wav_cap, d_status,
@@ -1085,6 +1109,7 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
                          d_x3, x3_len, d_frame_offsets, F, g, d_wav_offsets, dp, d_wav, wav_cap, d_status,
                          (X3FrameMeta*)c->dec_meta.p);
   }
+  if (!c->opt.check_first && (rc = launch_check())) return rc;
   // join, then merge the two status arrays and summarise
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
   if (no_check) {  // otherwise the check kernel's first thread does this
@@ -1145,27 +1170,33 @@ static int index_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t len, uint64_t
   if ((rc = ensure(c, c->idx_sum, 256))) return rc;
   unsigned int* d_count = reinterpret_cast<unsigned int*>((char*)c->idx_sum.p + 128);
   X3IndexSummary* d_sum = reinterpret_cast<X3IndexSummary*>(c->idx_sum.p);
-  X3IndexSummary init{0, 0, 0, X3I_NONE, ~0ull, 0, X3I_NONE, 0};
-  HIPCHK(c, hipMemcpyAsync(d_sum, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemsetAsync(d_count, 0, sizeof(unsigned int), c->stream));
+  hipLaunchKernelGGL(x3_index_init_kernel, dim3(1), dim3(64), 0, c->stream, d_sum, d_count);
   const uint64_t chunks = (len + 15) >> 4;
   const unsigned grid = (unsigned)std::min<uint64_t>((chunks + 255) / 256, (uint64_t)c->n_cus * 16);
-  // pass 1: how many candidates (the buffers are sized from the answer)
+  // ONE pass over the stream: the candidates go into a buffer sized for a frame every 256 bytes (the context keeps
+  // it; typical streams hold one every few kilobytes); only a stream with more than that is scanned a second time.
   unsigned int n_cand = 0;
   if (grid) {
+    const uint64_t guess = std::max<uint64_t>(4096, len / 256 + 1024);
+    if ((rc = ensure(c, c->idx_cand, (size_t)std::min<uint64_t>(guess, 0x7FFFFFFFull) * sizeof(X3Cand)))) return rc;
+    const uint32_t cap = (uint32_t)std::min<uint64_t>(c->idx_cand.cap / sizeof(X3Cand), 0x7FFFFFFFull);
     hipLaunchKernelGGL(x3_index_candidates_kernel, dim3(grid), dim3(256), 0, c->stream, xw, len, len + phantom, bl0,
-                       (X3Cand*)nullptr, 0u, d_count);
-    HIPCHK(c, hipMemcpyAsync(&n_cand, d_count, sizeof n_cand, hipMemcpyDeviceToHost, c->stream));
+                       (X3Cand*)c->idx_cand.p, cap, d_count);
+    HIPCHK(c, hipMemcpyAsync(c->h_crc, d_count, sizeof n_cand, hipMemcpyDeviceToHost, c->stream));  // (pinned)
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::memcpy(&n_cand, c->h_crc, sizeof n_cand);
+    if (n_cand > cap) {  // rare: denser than one frame per 256 bytes
+      if ((rc = ensure(c, c->idx_cand, (size_t)n_cand * sizeof(X3Cand)))) return rc;
+      HIPCHK(c, hipMemsetAsync(d_count, 0, sizeof(unsigned int), c->stream));
+      hipLaunchKernelGGL(x3_index_candidates_kernel, dim3(grid), dim3(256), 0, c->stream, xw, len, len + phantom, bl0,
+                         (X3Cand*)c->idx_cand.p, n_cand, d_count);
+    }
   }
-  uint32_t start = X3I_NONE;
-  unsigned long long n_chain = 0;
   if (n_cand) {
     uint32_t tsize = 1024;
     while (tsize < 2u * n_cand && tsize < 0x80000000u) tsize <<= 1;
     uint32_t levels = 1;
     while ((1ull << (levels - 1)) < n_cand) ++levels;  // the top level spans 2^(levels-1) >= n_cand >= any chain
-    if ((rc = ensure(c, c->idx_cand, (size_t)n_cand * sizeof(X3Cand)))) return rc;
     if ((rc = ensure(c, c->idx_keys, (size_t)tsize * sizeof(unsigned long long)))) return rc;
     if ((rc = ensure(c, c->idx_vals, (size_t)tsize * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(c, c->idx_J, (size_t)levels * n_cand * sizeof(uint32_t)))) return rc;
@@ -1177,10 +1208,7 @@ static int index_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t len, uint64_t
     uint32_t* J = (uint32_t*)c->idx_J.p;
     unsigned long long* S = (unsigned long long*)c->idx_S.p;
     uint32_t* L = (uint32_t*)c->idx_L.p;
-    HIPCHK(c, hipMemsetAsync(d_count, 0, sizeof(unsigned int), c->stream));
     HIPCHK(c, hipMemsetAsync(keys, 0, (size_t)tsize * sizeof(unsigned long long), c->stream));
-    hipLaunchKernelGGL(x3_index_candidates_kernel, dim3(grid), dim3(256), 0, c->stream, xw, len, len + phantom, bl0,
-                       cand, n_cand, d_count);
     const unsigned cg = (n_cand + 255) / 256;
     hipLaunchKernelGGL(x3_index_hash_insert_kernel, dim3(cg), dim3(256), 0, c->stream, (const X3Cand*)cand, n_cand,
                        keys, vals, tsize - 1);
@@ -1192,36 +1220,28 @@ static int index_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t len, uint64_t
                          (const unsigned long long*)(S + (size_t)(r - 1) * n_cand),
                          (const uint32_t*)(L + (size_t)(r - 1) * n_cand), J + (size_t)r * n_cand,
                          S + (size_t)r * n_cand, L + (size_t)r * n_cand);
-    HIPCHK(c, hipGetLastError());
     hipLaunchKernelGGL(x3_index_start_kernel, dim3(1), dim3(64), 0, c->stream, (const X3Cand*)cand,
                        (const unsigned long long*)keys, (const uint32_t*)vals, tsize - 1,
                        (const uint32_t*)(L + (size_t)(levels - 1) * n_cand), d_sum);
-    {
-      X3IndexSummary mid;
-      HIPCHK(c, hipMemcpyAsync(&mid, d_sum, sizeof mid, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      start = mid.start;
-      n_chain = mid.n_chain;
-    }
-    if (start != X3I_NONE) {
-      if (n_chain > max_frames) {
-        c->last_error = "x3_index_dev: more frames in the stream than max_frames";
-        return X3_ERR_BAD_ARG;
-      }
-      hipLaunchKernelGGL(x3_index_emit_kernel, dim3((unsigned)((n_chain + 255) / 256)), dim3(256), 0, c->stream,
-                         (const X3Cand*)cand, n_cand, levels, (const uint32_t*)J, (const unsigned long long*)S, start,
-                         n_chain, (unsigned long long)wav_cap, (unsigned long long*)d_frame_offsets,
-                         (unsigned long long*)d_wav_offsets, d_sum);
-    }
+    // start node and chain length stay on the device: the emit grid covers every candidate
+    hipLaunchKernelGGL(x3_index_emit_kernel, dim3(cg), dim3(256), 0, c->stream, (const X3Cand*)cand, n_cand, levels,
+                       (const uint32_t*)J, (const unsigned long long*)S, (unsigned long long)max_frames,
+                       (unsigned long long)wav_cap, (unsigned long long*)d_frame_offsets,
+                       (unsigned long long*)d_wav_offsets, d_sum);
     hipLaunchKernelGGL(x3_index_finalize_kernel, dim3(1), dim3(64), 0, c->stream, xw, len, len + phantom, bl0,
-                       (const X3Cand*)cand, start, n_chain, (const unsigned long long*)d_wav_offsets, d_sum);
+                       (const X3Cand*)cand, (const unsigned long long*)d_wav_offsets, d_sum);
   } else {
     hipLaunchKernelGGL(x3_index_finalize_kernel, dim3(1), dim3(64), 0, c->stream, xw, len, len + phantom, bl0,
-                       (const X3Cand*)nullptr, X3I_NONE, 0ull, (const unsigned long long*)nullptr, d_sum);
+                       (const X3Cand*)nullptr, (const unsigned long long*)nullptr, d_sum);
   }
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(result, d_sum, sizeof *result, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_summary_init, d_sum, sizeof *result, hipMemcpyDeviceToHost, c->stream));  // (pinned)
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::memcpy(result, c->h_summary_init, sizeof *result);
+  if (result->pad) {
+    c->last_error = "x3_index_dev: more frames in the stream than max_frames";
+    return X3_ERR_BAD_ARG;
+  }
   return X3_OK;
 }
 
@@ -1285,7 +1305,7 @@ static int decode_stream_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t len, 
     wav_cap = std::min<uint64_t>(wav_cap, r.n_samples + 65535);
   }
   if ((rc = decode_dev_impl(c, d_x3, len, (const uint64_t*)c->frame_off.p, F, nullptr, (const uint64_t*)c->wav_off.p,
-                            &pp, d_wav, wav_cap, nullptr)))
+                            &pp, d_wav, wav_cap, nullptr, r.unaligned == 0)))
     return rc;
   uint64_t first_bad = 0, before = 0;
   int bad_status = 0;
@@ -1381,8 +1401,10 @@ static int decode_frames_host(x3_ctx* c, const uint8_t* x3, uint64_t len, const 
   x3_params pp = *p;
   if (pp.block_len == 0) pp.block_len = 1;  // frames that need block_len were routed to BAD_ARG by the walk
   const uint64_t dev_wav_cap = std::min<uint64_t>(wav_cap, w.nsamp + 65535);
+  bool aligned = true;
+  for (uint64_t v : w.woffs) aligned = aligned && (v & 7ull) == 0;
   if ((rc = decode_dev_impl(c, (const uint8_t*)c->in.p, len, (const uint64_t*)c->frame_off.p, F, nullptr,
-                            (const uint64_t*)c->wav_off.p, &pp, (int16_t*)c->out.p, dev_wav_cap, nullptr)))
+                            (const uint64_t*)c->wav_off.p, &pp, (int16_t*)c->out.p, dev_wav_cap, nullptr, aligned)))
     return rc;
   if ((rc = x3_decode_result(c, first_bad, bad_status, before))) return rc;
   if (download && *before)
@@ -1710,4 +1732,5 @@ extern "C" int x3_x3a_decode(x3_ctx* c, const uint8_t* x3a, uint64_t len, int16_
 }
 
 #include "x3_file_pipeline.h"
+#include "x3_reader.h"
 #include "x3_mgpu.h"

@@ -500,7 +500,7 @@ x3_decode_lanes_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
         const uint2* src = reinterpret_cast<const uint2*>(outs + r * X3_DEC_OUT_STRIDE + 4u * q);
         const uint2 lo = src[0], hi = src[1];
 #ifndef X3_DBG_NOSTORE
-        *reinterpret_cast<uint4*>(wav + s_wo[r] + wbase + 8u * q) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        { const x3_u32x4 v = {lo.x, lo.y, hi.x, hi.y}; x3_store_stream16(wav + s_wo[r] + wbase + 8u * q, v); }
 #else
         if (lo.x == 0x12345678u && hi.y == 0x9abcdef0u) wav[0] = 1;
 #endif
@@ -824,7 +824,7 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
         if (inside || wbase + 8u * q + 8u <= S0) {
           const uint2* src = reinterpret_cast<const uint2*>(outs + r * X3_DEC_OUT_STRIDE + 4u * q);
           const uint2 lo = src[0], hi = src[1];
-          const_cast<uint4*>(w4)[r * (S0 >> 3) + q] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          { const x3_u32x4 v = {lo.x, lo.y, hi.x, hi.y}; x3_store_stream16(const_cast<uint4*>(w4) + (r * (S0 >> 3) + q), v); }
         }
         q += 4u;
         r += 3u;
@@ -838,7 +838,7 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
         if (wbase + 8u * q + 8u <= ns) {
           const uint2* src = reinterpret_cast<const uint2*>(outs + r * X3_DEC_OUT_STRIDE + 4u * q);
           const uint2 lo = src[0], hi = src[1];
-          *reinterpret_cast<uint4*>(wav + s_wo[r] + wbase + 8u * q) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          { const x3_u32x4 v = {lo.x, lo.y, hi.x, hi.y}; x3_store_stream16(wav + s_wo[r] + wbase + 8u * q, v); }
         }
         q += 4u;
         r += 3u;
@@ -852,7 +852,7 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
         if (wbase + 8u * q + 8u <= ns) {
           const uint2* src = reinterpret_cast<const uint2*>(outs + r * X3_DEC_OUT_STRIDE + 4u * q);
           const uint2 lo = src[0], hi = src[1];
-          *reinterpret_cast<uint4*>(wav + s_wo[r] + wbase + 8u * q) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          { const x3_u32x4 v = {lo.x, lo.y, hi.x, hi.y}; x3_store_stream16(wav + s_wo[r] + wbase + 8u * q, v); }
         }
       }
     }

@@ -24,6 +24,13 @@
 //
 // Geometry: block_len = 20 (ten pairs per block), staging window = 4 blocks = 80 samples, output frames
 // 16-byte aligned (the host launches x3_decode_fast_kernel otherwise).  Same results as the fast kernel.
+//
+// The samples go out with NON-TEMPORAL stores (x3_store_stream16).  With plain stores the kernel moved 1.20x its
+// algorithmic bytes (profiles/r1: WRITE_SIZE 1.17x the samples, FETCH_SIZE 1.29x the stream): the 160-byte runs
+// of a flush leave partially written lines in L2, which the streaming input evicts half-done and which evict the
+// input's lines in turn.  Streaming stores do neither: 1.025x / 1.03x, same kernel time (profiles/r2).  (A flush
+// that writes whole 64-byte-aligned chunks from a destination-indexed ring was built and measured as well: the
+// same traffic once its stores were non-temporal, 5 % slower for its address arithmetic -- not kept.)
 #pragma once
 #include "x3_decode_kernel.h"
 
@@ -54,8 +61,9 @@ __device__ __forceinline__ uint32_t x3s_half_index(uint32_t j, uint32_t lane) {
 
 __global__ void __launch_bounds__(128)
 x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uint64_t* __restrict__ frame_off,
-                       uint64_t n_frames, X3Geom g, X3DevParams p, int16_t* __restrict__ wav, uint64_t wav_cap,
-                       int32_t* __restrict__ status, X3FrameMeta* __restrict__ meta) {
+                       uint64_t n_frames, X3Geom g, const uint64_t* __restrict__ wav_off, X3DevParams p,
+                       int16_t* __restrict__ wav, uint64_t wav_cap, int32_t* __restrict__ status,
+                       X3FrameMeta* __restrict__ meta) {
   // input ring, 32 dwords per lane in rows of exactly 128 bytes at 128-byte aligned addresses, stream word j in
   // slot ~j & 31 (descending): the address of a word is then ONE v_and_or_b32 on a byte counter that a shift of
   // the window decrements with one v_lshl_add_u32.  (Lanes are at different places in their rows, so the aligned
@@ -98,9 +106,13 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       st = X3D_BAD_ARG;
       active = false;
     } else {
-      const uint64_t clip = f / g.fpc;
-      const uint64_t idx = f - clip * g.fpc;
-      wo = clip * g.clip_stride + idx * (uint64_t)p.spf;
+      if (wav_off) {  // (the caller vouches for multiples of eight samples: 16-byte aligned output rows)
+        wo = wav_off[f];
+      } else {
+        const uint64_t clip = f / g.fpc;
+        const uint64_t idx = f - clip * g.fpc;
+        wo = clip * g.clip_stride + idx * (uint64_t)p.spf;
+      }
       if (wo + samples > wav_cap) {
         st = X3D_BAD_ARG;
         active = false;
@@ -336,7 +348,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
         int16_t* const base = wav + wo0 + wbase;
 #pragma unroll
         for (uint32_t it = 0; it < X3S_WPIECES; ++it)
-          *reinterpret_cast<uint4*>(base + f_dst[it]) = *reinterpret_cast<const uint4*>(outs + f_src[it]);
+          x3_store_stream16(base + f_dst[it], *reinterpret_cast<const x3_u32x4*>(outs + f_src[it]));
       } else {
 #pragma unroll 2
         for (uint32_t it = 0; it < X3S_WPIECES; ++it) {
@@ -344,8 +356,8 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
           const uint32_t r = t / X3S_WPIECES, q = t - r * X3S_WPIECES;
           const uint32_t ns = s_ns[r];
           if (wbase + 8u * q + 8u <= ns)
-            *reinterpret_cast<uint4*>(wav + s_wo[r] + wbase + 8u * q) =
-                *reinterpret_cast<const uint4*>(outs + r * X3S_OUT_STRIDE + 4u * q);
+            x3_store_stream16(wav + s_wo[r] + wbase + 8u * q,
+                              *reinterpret_cast<const x3_u32x4*>(outs + r * X3S_OUT_STRIDE + 4u * q));
         }
       }
       X3_WAVE_LDS_ORDER();

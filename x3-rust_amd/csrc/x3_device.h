@@ -209,6 +209,11 @@ __device__ __forceinline__ void x3_lds_write_b128(uint32_t addr, uint32_t a, uin
   x3_u32x4 v = {a, b, c, d};
   *reinterpret_cast<__attribute__((address_space(3))) x3_u32x4*>(addr) = v;
 }
+// sixteen bytes to global memory as a streaming (non-temporal) store: output that is written once and not read
+// again by this kernel must not displace what the kernel is still reading from L2
+__device__ __forceinline__ void x3_store_stream16(void* p, x3_u32x4 v) {
+  __builtin_nontemporal_store(v, reinterpret_cast<x3_u32x4*>(p));
+}
 // v_ffbh_u32 without __clz's clamp: -1 (not 32) for 0
 __device__ __forceinline__ uint32_t x3_ffbh(uint32_t a) {
   uint32_t r;

@@ -41,7 +41,9 @@ struct X3IndexSummary {
   unsigned long long first_over;  // scratch: first frame that does not fit wav_cap
   unsigned long long n_chain;     // scratch: frames reachable from the start node
   uint32_t start;                 // scratch: candidate at offset 0 (X3I_NONE: the walk cannot step onto it)
-  uint32_t pad;
+  uint32_t pad;                   // 1: more frames than the caller's arrays hold
+  uint32_t unaligned;             // 1: some frame's sample offset is not a multiple of eight (picks the decoder kernel)
+  uint32_t pad2;
 };
 
 // decoder::read_frame_header only (no walk checks): status, payload_len, samples
@@ -73,6 +75,22 @@ __device__ __forceinline__ uint32_t x3i_kind(uint64_t len, uint64_t believed, ui
   if (len - off - 20 < plen) return X3I_IO;
   if (samples == 0 || plen < 2 || (bl0 && samples > 1)) return X3I_LAST_BAD;
   return X3I_CONT;
+}
+
+// 0. the summary and the candidate counter start clean (one launch instead of two small copies)
+__global__ void x3_index_init_kernel(X3IndexSummary* __restrict__ sum, unsigned int* __restrict__ count) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  sum->n_frames = 0;
+  sum->n_samples = 0;
+  sum->terminal = 0;
+  sum->last_node = X3I_NONE;
+  sum->first_over = ~0ull;
+  sum->n_chain = 0;
+  sum->start = X3I_NONE;
+  sum->pad = 0;
+  sum->unaligned = 0;
+  sum->pad2 = 0;
+  *count = 0;
 }
 
 // 1. candidates: thread t looks at the 16 byte offsets of 16-byte chunk t.  cand == nullptr: count only.
@@ -187,14 +205,22 @@ __global__ void x3_index_start_kernel(const X3Cand* __restrict__ cand, const uns
 }
 
 // 4. frame k = the k-th successor of the start node; its sample offset = the samples of the k nodes before it.
-// levels: J/S arrays of level r start at r*n.
+// levels: J/S arrays of level r start at r*n.  The start node and the chain's length come from the summary
+// (x3_index_start_kernel), so the host does not have to fetch them in between: the grid covers all n candidates.
+// A chain longer than max_frames: sum->pad = 1 (the caller's arrays are too small), nothing behind them is written.
 __global__ void __launch_bounds__(256)
 x3_index_emit_kernel(const X3Cand* __restrict__ cand, uint32_t n, uint32_t levels, const uint32_t* __restrict__ J,
-                     const unsigned long long* __restrict__ S, uint32_t start, unsigned long long n_chain,
+                     const unsigned long long* __restrict__ S, unsigned long long max_frames,
                      unsigned long long wav_cap, unsigned long long* __restrict__ frame_off,
                      unsigned long long* __restrict__ wav_off, X3IndexSummary* __restrict__ sum) {
   const unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n_chain) return;
+  const uint32_t start = sum->start;
+  const unsigned long long n_chain = sum->n_chain;
+  if (start == X3I_NONE || k >= n_chain) return;
+  if (n_chain > max_frames) {
+    if (k == 0) sum->pad = 1;
+    return;
+  }
   uint32_t node = start;
   unsigned long long acc = 0;
   for (uint32_t r = 0; r < levels; ++r) {
@@ -205,6 +231,7 @@ x3_index_emit_kernel(const X3Cand* __restrict__ cand, uint32_t n, uint32_t level
   }
   frame_off[k] = cand[node].off;
   wav_off[k] = acc;
+  if ((acc & 7ull) && sum->unaligned == 0) sum->unaligned = 1;  // a sample offset that is not a multiple of eight
   // decodefile walk as the host runs it: a frame that does not fit the output is pushed and ends the walk
   if ((cand[node].plen_kind >> 16) == X3I_CONT && acc + cand[node].samples > wav_cap) atomicMin(&sum->first_over, k);
   if (k == n_chain - 1) sum->last_node = node;
@@ -212,9 +239,12 @@ x3_index_emit_kernel(const X3Cand* __restrict__ cand, uint32_t n, uint32_t level
 
 // 5. how the walk ends (one thread)
 __global__ void x3_index_finalize_kernel(const uint32_t* __restrict__ xw, uint64_t len, uint64_t believed, uint32_t bl0,
-                                         const X3Cand* __restrict__ cand, uint32_t start, unsigned long long n_chain,
+                                         const X3Cand* __restrict__ cand,
                                          const unsigned long long* __restrict__ wav_off, X3IndexSummary* __restrict__ sum) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const uint32_t start = sum->start;
+  const unsigned long long n_chain = sum->n_chain;
+  if (sum->pad) return;  // more frames than the caller's arrays hold: the host reports it
   const uint64_t n_dw = (len + 3) >> 2;
   auto ending_at = [&](uint64_t pos) -> int {  // the walk arrives at `pos` and finds no frame to push
     if (believed - pos <= 20) return X3D_OK;

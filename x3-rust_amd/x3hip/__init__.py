@@ -38,6 +38,8 @@ SYMBOLS = [
     "x3_read_frame_header", "x3_decode_frame", "x3_decode_stream",
     "x3_archive_header_write", "x3_archive_header_read", "x3_x3a_encode", "x3_x3a_decode",
     "x3_wav_to_x3a", "x3_x3a_to_wav",
+    "x3_reader_open", "x3_reader_open_mem", "x3_reader_spec", "x3_reader_next_frame", "x3_reader_frame_errors",
+    "x3_reader_position", "x3_reader_close",
     "x3_encode_dev", "x3_encode_result", "x3_decode_dev", "x3_decode_result", "x3_index_dev", "x3_decode_stream_dev",
     "x3_synth", "x3_synth_dev", "x3_dev_alloc", "x3_dev_free", "x3_dev_upload", "x3_dev_download",
     "x3_shard_unique_id", "x3_shard_create", "x3_shard_destroy", "x3_shard_rank", "x3_shard_world",
@@ -164,6 +166,16 @@ def lib():
     L.x3_dev_free.argtypes = [vp, vp]
     L.x3_dev_upload.argtypes = [vp, vp, vp, u64]
     L.x3_dev_download.argtypes = [vp, vp, vp, u64]
+    L.x3_reader_open.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
+    L.x3_reader_open_mem.argtypes = [vp, vp, u64, C.POINTER(vp)]
+    L.x3_reader_spec.argtypes = [vp, C.POINTER(u32), PP, C.POINTER(C.c_uint8)]
+    L.x3_reader_next_frame.argtypes = [vp, vp, u64, C.POINTER(u64)]
+    L.x3_reader_frame_errors.restype = u64
+    L.x3_reader_frame_errors.argtypes = [vp]
+    L.x3_reader_position.restype = u64
+    L.x3_reader_position.argtypes = [vp]
+    L.x3_reader_close.restype = None
+    L.x3_reader_close.argtypes = [vp]
     L.x3_shard_unique_id.argtypes = [vp]
     L.x3_shard_create.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
     L.x3_shard_destroy.restype = None
@@ -225,6 +237,43 @@ def shard_unique_id():
     if rc:
         raise X3Error(rc, "x3_shard_unique_id (librccl not available?)")
     return bytes(buf)
+
+
+class Reader:
+    """X3aReader (decodefile.rs:47-137) over a file path or over archive bytes: spec() and next_frame()"""
+
+    def __init__(self, ctx, source):
+        self._h = C.c_void_p()
+        self.ctx = ctx
+        if isinstance(source, (str, bytes, os.PathLike)) and not isinstance(source, bytes):
+            rc = lib().x3_reader_open(ctx._h, os.fsencode(source), C.byref(self._h))
+        else:
+            self._keep = np.ascontiguousarray(source, dtype=np.uint8)   # borrowed by the reader
+            rc = lib().x3_reader_open_mem(ctx._h, self._keep.ctypes.data, self._keep.size, C.byref(self._h))
+        self.rc = rc
+        self._buf = np.zeros(65536, dtype=np.int16)
+
+    def spec(self):
+        rate, p, ch = C.c_uint32(0), Params(), C.c_uint8(0)
+        lib().x3_reader_spec(self._h, C.byref(rate), C.byref(p), C.byref(ch))
+        return rate.value, p, ch.value
+
+    def next_frame(self):
+        """-> (rc, samples or None): None = Ok(None) of the reference"""
+        n = C.c_uint64(0)
+        rc = lib().x3_reader_next_frame(self._h, self._buf.ctypes.data, self._buf.size, C.byref(n))
+        return rc, (self._buf[: n.value].copy() if (rc == 0 and n.value) else None)
+
+    def frame_errors(self):
+        return lib().x3_reader_frame_errors(self._h)
+
+    def position(self):
+        return lib().x3_reader_position(self._h)
+
+    def close(self):
+        if self._h:
+            lib().x3_reader_close(self._h)
+            self._h = C.c_void_p()
 
 
 class Shard:
