@@ -193,6 +193,35 @@ int x3_decode_frame(x3_ctx* ctx, const uint8_t* payload, uint64_t len, int16_t* 
 int x3_decode_stream(x3_ctx* ctx, const uint8_t* x3, uint64_t len, const x3_params* p, int16_t* wav,
                      uint64_t wav_cap, uint64_t* n_out, uint64_t* frames_ok, uint64_t* frame_errors);
 
+/* ------------------------------------------------------------------ bitreader.rs / bitpacker.rs / decode_block */
+
+/* The reference's small public items, for callers and known-answer tests written against them (x3_bits.h: not how the
+ * bulk paths work, and a call per field is not how a GPU should be driven -- but what they compute is computed by
+ * this library on the GPU, not by a CPU re-implementation).
+ * `BitReader` (src/bitreader.rs:51-176): state and a copy of the array live in device memory; each call runs the
+ * reference-exact reader (one thread) and brings the result back.  x3_bitreader_state: the reference's private
+ * fields (idx, leading_word, rem_bit), for tests that assert on them. */
+typedef struct x3_bitreader x3_bitreader;
+int x3_bitreader_new(x3_ctx* ctx, const uint8_t* array, uint64_t len, x3_bitreader** br);
+int x3_bitreader_read_nbits(x3_bitreader* br, uint32_t n, uint32_t* value);
+int x3_bitreader_count_zero_bits(x3_bitreader* br, uint32_t* count);
+int x3_bitreader_inc_bits(x3_bitreader* br, uint32_t n);
+int x3_bitreader_state(const x3_bitreader* br, uint64_t* idx, uint32_t* leading_word, uint32_t* rem_bit);
+void x3_bitreader_free(x3_bitreader* br);
+/* `decoder::decode_block` (src/decoder.rs:132-145): wav[0..n) from the reader's position, *last_wav in and out. */
+int x3_decode_block(x3_bitreader* br, int16_t* wav, uint32_t n, int16_t* last_wav, const x3_params* p);
+/* `BitPacker` (src/bitpacker.rs:46-177) over a slice writer at start_pos: write_bits / write_packed_zeros / word_align
+ * are recorded; x3_bitpacker_finish (= flush + len() + crc()) packs all recorded fields on the GPU (scan of the field
+ * widths, fields OR-ed into place), writes the bytes behind start_pos and returns their count, their CRC-16 (init
+ * 0xFFFF, as the packer keeps it) and the writer's position.  The packer can then be used again from there. */
+typedef struct x3_bitpacker x3_bitpacker;
+int x3_bitpacker_new(x3_ctx* ctx, uint8_t* out, uint64_t out_cap, uint64_t start_pos, x3_bitpacker** bp);
+int x3_bitpacker_write_bits(x3_bitpacker* bp, uint64_t value, uint32_t num_bits);
+int x3_bitpacker_write_packed_zeros(x3_bitpacker* bp, uint32_t num_zeros);
+int x3_bitpacker_word_align(x3_bitpacker* bp);
+int x3_bitpacker_finish(x3_bitpacker* bp, uint64_t* len, uint16_t* crc, uint64_t* out_pos);
+void x3_bitpacker_free(x3_bitpacker* bp);
+
 /* ------------------------------------------------------------------ .x3a archive (encodefile.rs / decodefile.rs) */
 
 /* `create_archive_header` (src/encodefile.rs:82-138): "X3ARCHIV" + a frame header with id 0 / 0 samples

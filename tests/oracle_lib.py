@@ -77,6 +77,12 @@ def lib(native=False):
     L.x3o_bp_write_bits.argtypes = [C.POINTER(BitPacker), C.c_uint64, C.c_size_t]
     L.x3o_bp_write_packed_zeros.argtypes = [C.POINTER(BitPacker), C.c_size_t]
     L.x3o_writer_init.argtypes = [C.POINTER(Writer), C.c_void_p, C.c_size_t]
+    L.x3o_writer_seek_start.argtypes = [C.POINTER(Writer), C.c_size_t]
+    L.x3o_bp_new.argtypes = [C.POINTER(BitPacker), C.POINTER(Writer)]
+    L.x3o_bp_new.restype = None
+    L.x3o_bp_word_align.argtypes = [C.POINTER(BitPacker)]
+    L.x3o_bp_drop.argtypes = [C.POINTER(BitPacker)]
+    L.x3o_br_count_zero_bits.argtypes = [C.POINTER(BitReader)]
     L.x3o_br_new.argtypes = [C.POINTER(BitReader), C.c_void_p, C.c_size_t]
     L.x3o_br_read_nbits.restype = C.c_uint32
     L.x3o_br_read_nbits.argtypes = [C.POINTER(BitReader), C.c_size_t]

@@ -1,0 +1,164 @@
+"""The reference's known-answer vectors for `BitReader` (src/bitreader.rs:195-303), `BitPacker`
+(src/bitpacker.rs:196-289) and `decode_block` (src/decoder.rs:257-355), through the product's own exports
+(x3_bitreader_*, x3_bitpacker_*, x3_decode_block: GPU work behind the C ABI), plus randomized comparisons with the
+oracle -- reads past the end of the array and zero runs across words included.  `pytest -m gpu`."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import x3hip
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return json.load(open(os.path.join(G, name)))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = x3hip.Context(0)
+    yield c
+    c.close()
+
+
+class GpuReader:
+    def __init__(self, ctx, arr):
+        self.L = x3hip.lib()
+        self.h = C.c_void_p()
+        self.arr = np.ascontiguousarray(arr, dtype=np.uint8)
+        assert self.L.x3_bitreader_new(ctx._h, self.arr.ctypes.data if self.arr.size else None, self.arr.size, C.byref(self.h)) == 0
+
+    def state(self):
+        idx, w, rem = C.c_uint64(0), C.c_uint32(0), C.c_uint32(0)
+        self.L.x3_bitreader_state(self.h, C.byref(idx), C.byref(w), C.byref(rem))
+        return idx.value, w.value, rem.value
+
+    def read(self, n):
+        v = C.c_uint32(0)
+        assert self.L.x3_bitreader_read_nbits(self.h, n, C.byref(v)) == 0
+        return v.value
+
+    def zeros(self):
+        v = C.c_uint32(0)
+        assert self.L.x3_bitreader_count_zero_bits(self.h, C.byref(v)) == 0
+        return v.value
+
+    def close(self):
+        self.L.x3_bitreader_free(self.h)
+
+
+def test_bitreader_kat(ctx):
+    for t in load("bitreader_kat.json")["traces"]:
+        br = GpuReader(ctx, t["bytes"])
+        _, w, rem = br.state()
+        assert rem == t["init"]["rem_bit"] and w == t["init"]["leading_word"], t["name"]
+        for op in t["ops"]:
+            r = br.zeros() if op["op"] == "zeros" else br.read(op["n"])
+            assert r == op["result"], (t["name"], op)
+            _, w, rem = br.state()
+            if "rem_bit" in op:
+                assert rem == op["rem_bit"], (t["name"], op)
+            assert w == op["leading_word"], (t["name"], op)
+        br.close()
+
+
+def test_bitreader_random_vs_oracle(ctx):
+    """random op sequences over short arrays, far past their end: result and private state equal the oracle's"""
+    rng = np.random.default_rng(42)
+    OL = O.lib()
+    for trial in range(12):
+        n = int(rng.integers(0, 14))
+        arr = rng.integers(0, 256, size=n, dtype=np.uint8)
+        if trial % 3 == 0:
+            arr[rng.integers(0, max(n, 1), size=max(n // 2, 0))] = 0   # long zero runs
+        br = GpuReader(ctx, arr)
+        ob = O.BitReader()
+        OL.x3o_br_new(C.byref(ob), arr.ctypes.data if n else None, n)
+        assert br.state() == (ob.idx, ob.leading_word, ob.rem_bit)
+        for _ in range(40):
+            if rng.random() < 0.4:
+                a, b = br.zeros(), OL.x3o_br_count_zero_bits(C.byref(ob))
+            else:
+                k = int(rng.integers(0, 32))
+                a, b = br.read(k), OL.x3o_br_read_nbits(C.byref(ob), k)
+            assert a == b, (trial, arr.tolist())
+            assert br.state() == (ob.idx, ob.leading_word, ob.rem_bit), (trial, arr.tolist())
+        br.close()
+
+
+def test_bitpacker_kat(ctx):
+    L = x3hip.lib()
+    for c in load("bitpacker_kat.json")["cases"]:
+        arr = np.array(c["init"], dtype=np.uint8)
+        bp = C.c_void_p()
+        assert L.x3_bitpacker_new(ctx._h, arr.ctypes.data, arr.size, 0, C.byref(bp)) == 0
+        for v, n in c["writes"]:
+            assert L.x3_bitpacker_write_bits(bp, v, n) == 0
+        ln, crc, pos = C.c_uint64(0), C.c_uint16(0), C.c_uint64(0)
+        assert L.x3_bitpacker_finish(bp, C.byref(ln), C.byref(crc), C.byref(pos)) == 0   # the reference's Drop flushes
+        L.x3_bitpacker_free(bp)
+        assert arr.tolist() == c["expected"], c
+        assert crc.value == O.crc16(arr[:ln.value]) and pos.value == ln.value
+
+
+def test_bitpacker_random_vs_oracle(ctx):
+    """random field lists (widths 0..33, over-wide values, zero runs), odd start positions, word_align: bytes, len()
+    and crc() equal the oracle's byte-at-a-time packer"""
+    rng = np.random.default_rng(9)
+    L, OL = x3hip.lib(), O.lib()
+    for trial in range(25):
+        start = int(rng.integers(0, 5))
+        nf = int(rng.integers(0, 700))
+        fields = [(int(rng.integers(0, 1 << 40)), int(rng.integers(0, 34))) for _ in range(nf)]
+        cap = start + nf * 5 + 16
+        a = np.full(cap, 0, dtype=np.uint8)
+        b = np.full(cap, 0, dtype=np.uint8)
+        bp = C.c_void_p()
+        assert L.x3_bitpacker_new(ctx._h, a.ctypes.data, cap, start, C.byref(bp)) == 0
+        w = O.Writer()
+        OL.x3o_writer_init(C.byref(w), b.ctypes.data, cap)
+        OL.x3o_writer_seek_start(C.byref(w), start)
+        ob = O.BitPacker()
+        OL.x3o_bp_new(C.byref(ob), C.byref(w))
+        for i, (v, n) in enumerate(fields):
+            if i % 17 == 5:
+                assert L.x3_bitpacker_write_packed_zeros(bp, n) == 0
+                assert OL.x3o_bp_write_packed_zeros(C.byref(ob), n) == 0
+            else:
+                assert L.x3_bitpacker_write_bits(bp, v, n) == 0
+                assert OL.x3o_bp_write_bits(C.byref(ob), v, n) == 0
+        assert L.x3_bitpacker_word_align(bp) == 0
+        assert OL.x3o_bp_word_align(C.byref(ob)) == 0
+        ln, crc, pos = C.c_uint64(0), C.c_uint16(0), C.c_uint64(0)
+        assert L.x3_bitpacker_finish(bp, C.byref(ln), C.byref(crc), C.byref(pos)) == 0
+        L.x3_bitpacker_free(bp)
+        assert (ln.value, crc.value, pos.value) == (ob.byte_len, ob.crc, w.p_byte), trial
+        assert np.array_equal(a, b), trial
+
+
+def test_decode_block_kat(ctx):
+    L = x3hip.lib()
+    p = x3hip.Params.default()
+    for b in load("decoder_kat.json")["blocks"]:
+        x = np.array(b["x3_inp"], dtype=np.uint8)
+        n = len(b["expected_wav"])
+        if b["first_sample_in_stream"]:   # the reference's tests read the first sample, then hand the rest to a BitReader
+            last = int(np.frombuffer(x[:2].tobytes(), dtype=">i2")[0])
+            br = GpuReader(ctx, x[2:])
+        else:
+            last = b["last_wav"]
+            br = GpuReader(ctx, x)
+            br.read(b["skip_bits"])
+        wav = np.zeros(n, dtype=np.int16)
+        lw = C.c_int16(last)
+        rc = L.x3_decode_block(br.h, wav.ctypes.data, n, C.byref(lw), C.byref(p))
+        assert rc == 0, (b["name"], rc)
+        assert wav.tolist() == b["expected_wav"], b["name"]
+        assert lw.value == b["expected_wav"][-1]
+        br.close()

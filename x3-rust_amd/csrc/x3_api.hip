@@ -1733,4 +1733,5 @@ extern "C" int x3_x3a_decode(x3_ctx* c, const uint8_t* x3a, uint64_t len, int16_
 
 #include "x3_file_pipeline.h"
 #include "x3_reader.h"
+#include "x3_bits.h"
 #include "x3_mgpu.h"

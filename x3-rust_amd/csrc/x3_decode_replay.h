@@ -105,61 +105,70 @@ struct X3RefReader {
   }
 };
 
-// decoder::decode_frame (src/decoder.rs:36-58) with decode_block and the three block decoders (:132-235).
-// payload[0..plen), plen >= 2; samples >= 1; block_len >= 1; out has room for `samples` values.
+// decoder::decode_block (src/decoder.rs:132-145) with the three block decoders (:147-235): n samples from the
+// reader's position into out[0..n); `last` = *last_wav, kept modulo 2^16 (i16 arithmetic wraps in release).
 // Returns X3D_OK, X3D_OUT_OF_BOUNDS_INVERSE or X3D_FRAME_DECODE_INVALID_BPF.
+__device__ __forceinline__ int32_t x3_replay_block(X3RefReader& br, uint32_t n, const X3DevParams& p, uint32_t& last,
+                                                   int16_t* __restrict__ out) {
+  const uint32_t ftype = br.bits(2u);
+  if (ftype == 0u) {  // decode_bpf_block (:209-235)
+    const uint32_t E = br.bits(4u) + 1u;
+    if (E <= 5u) return X3D_FRAME_DECODE_INVALID_BPF;
+    if (E == 16u) {
+      for (uint32_t i = 0; i < n; ++i) {
+        last = br.bits(16u) & 0xFFFFu;
+        out[i] = (int16_t)(uint16_t)last;
+      }
+    } else {
+      const uint32_t half = 1u << (E - 1u);
+      for (uint32_t i = 0; i < n; ++i) {
+        uint32_t v = br.bits(E) & 0xFFFFu;
+        if (v > half) v -= half << 1;  // unsigned_to_i16 (:198-207): strict compare
+        last = (last + v) & 0xFFFFu;
+        out[i] = (int16_t)(uint16_t)last;
+      }
+    }
+  } else if (ftype == 1u) {  // decode_ricecode_block_r1 (:147-170)
+    const uint32_t bound = p.inv_len[0];
+    for (uint32_t i = 0; i < n; ++i) {
+      const uint32_t ix = br.zeros();
+      (void)br.bits(1u);
+      if (ix >= bound) return X3D_OUT_OF_BOUNDS_INVERSE;
+      const uint32_t d = (ix & 1u) ? 0u - ((ix + 1u) >> 1) : (ix >> 1);  // INV_RICE_CODE (x3.rs:200-204)
+      last = (last + d) & 0xFFFFu;
+      out[i] = (int16_t)(uint16_t)last;
+    }
+  } else {  // decode_ricecode_block_r2r3 (:172-196): nb hard-wired, i16 arithmetic, `as usize` sign-extends
+    const uint32_t nb = ftype == 2u ? 2u : 4u;
+    const int32_t level = 1 << p.k[ftype - 1u];
+    const uint32_t bound = p.inv_len[ftype - 1u];
+    for (uint32_t i = 0; i < n; ++i) {
+      const int32_t nz = (int32_t)(int16_t)br.zeros();
+      const int32_t r = (int32_t)(int16_t)br.bits(nb);
+      const int32_t ix = (int32_t)(int16_t)(r + level * (nz - 1));
+      if (ix < 0 || (uint32_t)ix >= bound) return X3D_OUT_OF_BOUNDS_INVERSE;
+      const uint32_t u = (uint32_t)ix;
+      const uint32_t d = (u & 1u) ? 0u - ((u + 1u) >> 1) : (u >> 1);
+      last = (last + d) & 0xFFFFu;
+      out[i] = (int16_t)(uint16_t)last;
+    }
+  }
+  return X3D_OK;
+}
+
+// decoder::decode_frame (src/decoder.rs:36-58): payload[0..plen), plen >= 2; samples >= 1; block_len >= 1; out has
+// room for `samples` values.
 __device__ __noinline__ int32_t x3_replay_frame(const uint8_t* __restrict__ payload, uint32_t plen, uint32_t samples,
                                                 const X3DevParams& p, int16_t* __restrict__ out) {
-  uint32_t last = ((uint32_t)payload[0] << 8) | payload[1];  // kept modulo 2^16 (i16 arithmetic wraps in release)
+  uint32_t last = ((uint32_t)payload[0] << 8) | payload[1];
   out[0] = (int16_t)(uint16_t)last;
   X3RefReader br;
   br.open(payload + 2, plen - 2u);
   uint32_t at = 1u, remaining = samples - 1u;
   while (remaining) {
     const uint32_t n = remaining < p.block_len ? remaining : p.block_len;
-    const uint32_t ftype = br.bits(2u);
-    if (ftype == 0u) {  // decode_bpf_block (:209-235)
-      const uint32_t E = br.bits(4u) + 1u;
-      if (E <= 5u) return X3D_FRAME_DECODE_INVALID_BPF;
-      if (E == 16u) {
-        for (uint32_t i = 0; i < n; ++i) {
-          last = br.bits(16u) & 0xFFFFu;
-          out[at + i] = (int16_t)(uint16_t)last;
-        }
-      } else {
-        const uint32_t half = 1u << (E - 1u);
-        for (uint32_t i = 0; i < n; ++i) {
-          uint32_t v = br.bits(E) & 0xFFFFu;
-          if (v > half) v -= half << 1;  // unsigned_to_i16 (:198-207): strict compare
-          last = (last + v) & 0xFFFFu;
-          out[at + i] = (int16_t)(uint16_t)last;
-        }
-      }
-    } else if (ftype == 1u) {  // decode_ricecode_block_r1 (:147-170)
-      const uint32_t bound = p.inv_len[0];
-      for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t ix = br.zeros();
-        (void)br.bits(1u);
-        if (ix >= bound) return X3D_OUT_OF_BOUNDS_INVERSE;
-        const uint32_t d = (ix & 1u) ? 0u - ((ix + 1u) >> 1) : (ix >> 1);  // INV_RICE_CODE (x3.rs:200-204)
-        last = (last + d) & 0xFFFFu;
-        out[at + i] = (int16_t)(uint16_t)last;
-      }
-    } else {  // decode_ricecode_block_r2r3 (:172-196): nb hard-wired, i16 arithmetic, `as usize` sign-extends
-      const uint32_t nb = ftype == 2u ? 2u : 4u;
-      const int32_t level = 1 << p.k[ftype - 1u];
-      const uint32_t bound = p.inv_len[ftype - 1u];
-      for (uint32_t i = 0; i < n; ++i) {
-        const int32_t nz = (int32_t)(int16_t)br.zeros();
-        const int32_t r = (int32_t)(int16_t)br.bits(nb);
-        const int32_t ix = (int32_t)(int16_t)(r + level * (nz - 1));
-        if (ix < 0 || (uint32_t)ix >= bound) return X3D_OUT_OF_BOUNDS_INVERSE;
-        const uint32_t u = (uint32_t)ix;
-        const uint32_t d = (u & 1u) ? 0u - ((u + 1u) >> 1) : (u >> 1);
-        last = (last + d) & 0xFFFFu;
-        out[at + i] = (int16_t)(uint16_t)last;
-      }
-    }
+    const int32_t st = x3_replay_block(br, n, p, last, out + at);
+    if (st != X3D_OK) return st;
     remaining -= n;
     at += n;
   }

@@ -38,6 +38,10 @@ SYMBOLS = [
     "x3_read_frame_header", "x3_decode_frame", "x3_decode_stream",
     "x3_archive_header_write", "x3_archive_header_read", "x3_x3a_encode", "x3_x3a_decode",
     "x3_wav_to_x3a", "x3_x3a_to_wav",
+    "x3_bitreader_new", "x3_bitreader_read_nbits", "x3_bitreader_count_zero_bits", "x3_bitreader_inc_bits",
+    "x3_bitreader_state", "x3_bitreader_free", "x3_decode_block",
+    "x3_bitpacker_new", "x3_bitpacker_write_bits", "x3_bitpacker_write_packed_zeros", "x3_bitpacker_word_align",
+    "x3_bitpacker_finish", "x3_bitpacker_free",
     "x3_reader_open", "x3_reader_open_mem", "x3_reader_spec", "x3_reader_next_frame", "x3_reader_frame_errors",
     "x3_reader_position", "x3_reader_close",
     "x3_encode_dev", "x3_encode_result", "x3_decode_dev", "x3_decode_result", "x3_index_dev", "x3_decode_stream_dev",
@@ -166,6 +170,21 @@ def lib():
     L.x3_dev_free.argtypes = [vp, vp]
     L.x3_dev_upload.argtypes = [vp, vp, vp, u64]
     L.x3_dev_download.argtypes = [vp, vp, vp, u64]
+    L.x3_bitreader_new.argtypes = [vp, vp, u64, C.POINTER(vp)]
+    L.x3_bitreader_read_nbits.argtypes = [vp, u32, C.POINTER(u32)]
+    L.x3_bitreader_count_zero_bits.argtypes = [vp, C.POINTER(u32)]
+    L.x3_bitreader_inc_bits.argtypes = [vp, u32]
+    L.x3_bitreader_state.argtypes = [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32)]
+    L.x3_bitreader_free.restype = None
+    L.x3_bitreader_free.argtypes = [vp]
+    L.x3_decode_block.argtypes = [vp, vp, u32, C.POINTER(C.c_int16), PP]
+    L.x3_bitpacker_new.argtypes = [vp, vp, u64, u64, C.POINTER(vp)]
+    L.x3_bitpacker_write_bits.argtypes = [vp, u64, u32]
+    L.x3_bitpacker_write_packed_zeros.argtypes = [vp, u32]
+    L.x3_bitpacker_word_align.argtypes = [vp]
+    L.x3_bitpacker_finish.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_uint16), C.POINTER(u64)]
+    L.x3_bitpacker_free.restype = None
+    L.x3_bitpacker_free.argtypes = [vp]
     L.x3_reader_open.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
     L.x3_reader_open_mem.argtypes = [vp, vp, u64, C.POINTER(vp)]
     L.x3_reader_spec.argtypes = [vp, C.POINTER(u32), PP, C.POINTER(C.c_uint8)]
