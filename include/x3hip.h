@@ -130,6 +130,17 @@ void x3_params_default(x3_params* p);
 /* `Parameters::new`, src/x3.rs:98-122: INVALID_ENCODING_THRESH if thresholds[k] > offset of
  * code k for k = 0,1 (the reference checks only those two); BAD_ARG for a code > 3. */
 int x3_params_validate(const x3_params* p);
+/* `RiceCode` / `RiceCodes::get`, src/x3.rs:187-260: the code table Parameters.rice_codes[k] points at.  `code` and
+ * `num_bits` have `len` entries indexed by (difference + offset); `inv` has 60 entries of which inv_len are in use.  The
+ * pointers are to static read-only tables of the library (host memory; the kernels derive the same values arithmetically).
+ * BAD_ARG for a code number > 3 (the reference panics on the index). */
+typedef struct x3_rice_code {
+  uint32_t nsubs, offset, len, inv_len;
+  const uint32_t* code;
+  const uint32_t* num_bits;
+  const int16_t* inv;
+} x3_rice_code;
+int x3_rice_code_get(uint32_t code_number, x3_rice_code* out);
 /* number of frames `encode` cuts n samples into (encoder.rs:61-73) */
 uint64_t x3_num_frames(uint64_t n, const x3_params* p);
 /* worst-case bytes `encode` can produce for n samples (all-literal frames) */
@@ -211,15 +222,18 @@ void x3_bitreader_free(x3_bitreader* br);
 /* `decoder::decode_block` (src/decoder.rs:132-145): wav[0..n) from the reader's position, *last_wav in and out. */
 int x3_decode_block(x3_bitreader* br, int16_t* wav, uint32_t n, int16_t* last_wav, const x3_params* p);
 /* `BitPacker` (src/bitpacker.rs:46-177) over a slice writer at start_pos: write_bits / write_packed_zeros / word_align
- * are recorded; x3_bitpacker_finish (= flush + len() + crc()) packs all recorded fields on the GPU (scan of the field
- * widths, fields OR-ed into place), writes the bytes behind start_pos and returns their count, their CRC-16 (init
- * 0xFFFF, as the packer keeps it) and the writer's position.  The packer can then be used again from there. */
+ * are recorded; x3_bitpacker_finish (= flush, what Drop does) zero-pads a partial byte, packs all recorded fields on the
+ * GPU (scan of the field widths, fields OR-ed into place), writes the bytes not handed over yet behind start_pos and
+ * returns the reference's len() and crc() at that point (cumulative since new(); CRC-16 init 0xFFFF) and the writer's
+ * position; writing may go on from the next byte.  x3_bitpacker_peek = len() / crc() between writes: complete bytes
+ * so far and their CRC, nothing written. */
 typedef struct x3_bitpacker x3_bitpacker;
 int x3_bitpacker_new(x3_ctx* ctx, uint8_t* out, uint64_t out_cap, uint64_t start_pos, x3_bitpacker** bp);
 int x3_bitpacker_write_bits(x3_bitpacker* bp, uint64_t value, uint32_t num_bits);
 int x3_bitpacker_write_packed_zeros(x3_bitpacker* bp, uint32_t num_zeros);
 int x3_bitpacker_word_align(x3_bitpacker* bp);
 int x3_bitpacker_finish(x3_bitpacker* bp, uint64_t* len, uint16_t* crc, uint64_t* out_pos);
+int x3_bitpacker_peek(const x3_bitpacker* bp, uint64_t* len, uint16_t* crc);
 void x3_bitpacker_free(x3_bitpacker* bp);
 
 /* ------------------------------------------------------------------ .x3a archive (encodefile.rs / decodefile.rs) */

@@ -62,6 +62,13 @@ static void host_only() {
         spec.params.codes[2] == 3 && spec.params.thresholds[2] == 20);
   arc[0] = 'Y';
   CHECK(x3::archive::read_archive_header(arc, arc_len, &spec, &hsize) == x3::X3Error::ArchiveHeaderXMLInvalidKey);
+  // RiceCodes::get / Parameters.rice_codes (x3.rs:187-260): spot values of the reference's literal tables
+  CHECK(p.rice_codes[0]->offset == 6 && p.rice_codes[1]->offset == 11 && p.rice_codes[2]->offset == 28);
+  CHECK(p.rice_codes[2]->nsubs == 3 && p.rice_codes[2]->inv_len == 60 && p.rice_codes[2]->len == 56);
+  CHECK(p.rice_codes[2]->code[0] == 15 && p.rice_codes[2]->num_bits[0] == 10 && p.rice_codes[2]->code[28] == 8 &&
+        p.rice_codes[2]->num_bits[28] == 4 && p.rice_codes[0]->num_bits[13] == 15 && p.rice_codes[1]->inv[3] == -2);
+  const size_t c2[3] = {1, 2, 3};
+  CHECK(x3::RiceCodes::get(c2)[1]->offset == 20 && x3::RiceCodes::get(c2)[1]->code[1] == 5);
   std::printf("host-only checks ok\n");
 }
 
@@ -141,6 +148,53 @@ int main(int argc, char** argv) {
     uint16_t c = 0;
     CHECK(x3::crc::crc16(ctx, ref.data() + 20, fh.payload_len, &c) == x3::X3Error::Ok && c == fh.payload_crc);
   }
+  // the reference's own argument lists, on the default context: encode -> decode_stream, crc16
+  {
+    x3::Channel ch(0, wav.data(), 30000, 44100, params);
+    const x3::Channel* chans[1] = {&ch};
+    std::vector<uint8_t> out(60000);
+    x3::bytewriter::SliceByteWriter w(out.data(), out.size());
+    std::fflush(stdout);
+    CHECK(x3::encoder::encode(chans, 1, w) == x3::X3Error::Ok);
+    CHECK(w.position() > 60 && !std::memcmp(out.data(), ref.data(), 20));
+    std::vector<int16_t> back(30000);
+    x3::decoder::StreamResult r;
+    CHECK(x3::decoder::decode_stream(out.data(), w.position(), params, back.data(), back.size(), &r) == x3::X3Error::Ok);
+    CHECK(r.samples == 30000 && r.frames_ok == 3 && !std::memcmp(back.data(), wav.data(), 60000));
+    x3::FrameHeader fh;
+    CHECK(x3::decoder::read_frame_header(out.data(), 20, &fh) == x3::X3Error::Ok);
+    CHECK(x3::crc::crc16(out.data() + 20, fh.payload_len) == fh.payload_crc);
+  }
+  // decoder::decode_block over bitreader::BitReader (decoder.rs:257-277, test_decode_block_ftype_1), and the
+  // BitReader's own first test (bitreader.rs:195-202)
+  {
+    const uint8_t x3_inp[] = {0x01, 0x10, 0x23, 0x18, 0x14, 0x90, 0x40, 0x82, 0x58, 0x41, 0x02, 0x0C, 0x4C};
+    const int16_t expected[] = {-375, -372, -374, -374, -376, -376, -373, -374, -373, -372,
+                                -375, -372, -375, -374, -375, -375, -373, -376, -373};
+    x3::bitreader::BitReader br(x3_inp, sizeof x3_inp);
+    br.inc_bits(6);
+    int16_t out[19], last = -373;
+    CHECK(x3::decoder::decode_block(br, out, 19, &last, params) == x3::X3Error::Ok);
+    CHECK(!std::memcmp(out, expected, sizeof expected) && last == -373);
+    const uint8_t a4[] = {0x00, 0x00, 0x00, 0x3C};
+    x3::bitreader::BitReader b2(ctx, a4, 4);
+    CHECK(b2.count_zero_bits() == 26 && b2.read_nbits(4) == 0xF);
+  }
+  // bitpacker::BitPacker (bitpacker.rs:196-214, test_write_packed_bits): 3 bits then a 16-bit word
+  {
+    uint8_t out[8] = {0};
+    x3::bytewriter::SliceByteWriter w(out, sizeof out);
+    {
+      x3::bitpacker::BitPacker bp(w);
+      CHECK(bp.write_bits(0x3, 2) == x3::X3Error::Ok);
+      CHECK(bp.write_packed_zeros(5) == x3::X3Error::Ok);
+      CHECK(bp.write_bits(0x1FF, 9) == x3::X3Error::Ok);
+      CHECK(bp.word_align() == x3::X3Error::Ok);
+      const uint8_t packed[2] = {0xC1, 0xFF};
+      CHECK(bp.len() == 2 && bp.crc() == x3::crc::crc16(packed, 2));
+    }
+    CHECK(out[0] == 0xC1 && out[1] == 0xFF && w.position() == 2);
+  }
   // the file level (encodefile.rs:48-77, decodefile.rs:189-227) against the oracle's files, byte for byte
   {
     const char* dir = std::getenv("TMPDIR") ? std::getenv("TMPDIR") : "/tmp";
@@ -165,6 +219,22 @@ int main(int argc, char** argv) {
     CHECK(x3o_x3a_to_wav(b.c_str(), wb.c_str(), &n2, &e2) == 0);
     CHECK(n1 == wav.size() && n2 == n1 && e1 == 0 && e2 == 0 && slurp(wa) == slurp(wb) && slurp(wa) == slurp(in));
     CHECK(x3::encodefile::wav_to_x3a(ctx, (base + "_missing.wav").c_str(), a.c_str(), false) == x3::X3Error::Io);
+    // decodefile::X3aReader (decodefile.rs:47-136): the reference's own loop (decodefile.rs:200-209)
+    {
+      x3::decodefile::X3aReader rd;
+      CHECK(x3::decodefile::X3aReader::open(a.c_str(), &rd) == x3::X3Error::Ok);
+      CHECK(rd.spec().sample_rate == 44100 && rd.spec().params.block_len == 20);
+      static int16_t buf[x3::decodefile::X3_WRITE_BUFFER_SIZE];
+      std::vector<int16_t> all;
+      for (;;) {
+        size_t n = 0;
+        bool some = false;
+        CHECK(rd.decode_next_frame(buf, &n, &some) == x3::X3Error::Ok);
+        if (!some) break;
+        all.insert(all.end(), buf, buf + n);
+      }
+      CHECK(all == wav && rd.frame_errors() == 0);
+    }
     for (const std::string& f : {in, a, b, wa, wb}) std::remove(f.c_str());
   }
   std::printf("x3.hpp checks ok\n");

@@ -126,7 +126,15 @@ def test_bitpacker_random_vs_oracle(ctx):
         OL.x3o_writer_seek_start(C.byref(w), start)
         ob = O.BitPacker()
         OL.x3o_bp_new(C.byref(ob), C.byref(w))
+        ln, crc, pos = C.c_uint64(0), C.c_uint16(0), C.c_uint64(0)
         for i, (v, n) in enumerate(fields):
+            if i == nf // 2:   # len() / crc() between writes, then a flush in mid-stream (Drop of a first packer)
+                assert L.x3_bitpacker_peek(bp, C.byref(ln), C.byref(crc)) == 0
+                assert (ln.value, crc.value) == (ob.byte_len, ob.crc), trial
+                if trial % 2:
+                    assert L.x3_bitpacker_finish(bp, C.byref(ln), C.byref(crc), C.byref(pos)) == 0
+                    OL.x3o_bp_drop(C.byref(ob))
+                    assert (ln.value, crc.value, pos.value) == (ob.byte_len, ob.crc, w.p_byte), trial
             if i % 17 == 5:
                 assert L.x3_bitpacker_write_packed_zeros(bp, n) == 0
                 assert OL.x3o_bp_write_packed_zeros(C.byref(ob), n) == 0
@@ -135,7 +143,6 @@ def test_bitpacker_random_vs_oracle(ctx):
                 assert OL.x3o_bp_write_bits(C.byref(ob), v, n) == 0
         assert L.x3_bitpacker_word_align(bp) == 0
         assert OL.x3o_bp_word_align(C.byref(ob)) == 0
-        ln, crc, pos = C.c_uint64(0), C.c_uint16(0), C.c_uint64(0)
         assert L.x3_bitpacker_finish(bp, C.byref(ln), C.byref(crc), C.byref(pos)) == 0
         L.x3_bitpacker_free(bp)
         assert (ln.value, crc.value, pos.value) == (ob.byte_len, ob.crc, w.p_byte), trial

@@ -143,3 +143,18 @@ def test_shard_arithmetic_matches_the_python_harness():
             assert got == [shard.sample_range(n, 10000, r, world) for r in range(world)]
             assert sum(c for _, c in got) == n
     assert x3hip.shard_offsets([10, 0, 22, 4]) == [0, 10, 10, 32, 36] == shard.global_offsets([10, 0, 22, 4])
+
+
+def test_rice_code_tables_match_reference_literals():
+    """x3_rice_code_get (RiceCodes::get, src/x3.rs:206-260) against the reference's literal tables"""
+    import json
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rice_tables.json")))
+    L = x3hip.lib()
+    for k, t in enumerate(g["tables"]):
+        rc = x3hip.RiceCode()
+        assert L.x3_rice_code_get(k, C.byref(rc)) == 0
+        assert (rc.nsubs, rc.offset, rc.inv_len, rc.len) == (t["nsubs"], t["offset"], t["inv_len"], len(t["code"]))
+        assert [rc.code[i] for i in range(rc.len)] == t["code"]
+        assert [rc.num_bits[i] for i in range(rc.len)] == t["num_bits"]
+        assert [rc.inv[i] for i in range(60)] == g["inv"]
+    assert L.x3_rice_code_get(4, C.byref(x3hip.RiceCode())) == 24

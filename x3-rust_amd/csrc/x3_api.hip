@@ -520,6 +520,35 @@ extern "C" int x3_params_validate(const x3_params* p) {
   return X3_OK;
 }
 
+// RiceCodes::CODE (src/x3.rs:206-252) as arithmetic: entry i stands for the difference d = i - offset, folded to
+// u = 2d (d >= 0) or -2d - 1 (d < 0); the codeword is u >> k zeros, a one, then the k low bits of u.
+extern "C" int x3_rice_code_get(uint32_t code_number, x3_rice_code* out) {
+  struct Tables {
+    uint32_t code[4][56], num_bits[4][56];
+    int16_t inv[60];
+    Tables() {
+      for (uint32_t k = 0; k < 4; ++k)
+        for (uint32_t i = 0; i < RICE_LEN[k]; ++i) {
+          const int32_t d = (int32_t)i - (int32_t)RICE_OFFSET[k];
+          const uint32_t u = d >= 0 ? 2u * (uint32_t)d : 2u * (uint32_t)(-d) - 1u;
+          code[k][i] = (1u << k) | (u & ((1u << k) - 1u));
+          num_bits[k][i] = (u >> k) + 1u + k;
+        }
+      for (uint32_t i = 0; i < 60; ++i) inv[i] = (i & 1u) ? (int16_t)-(int32_t)((i + 1u) >> 1) : (int16_t)(i >> 1);
+    }
+  };
+  static const Tables t;
+  if (!out || code_number > 3) return X3_ERR_BAD_ARG;
+  out->nsubs = code_number;
+  out->offset = RICE_OFFSET[code_number];
+  out->len = RICE_LEN[code_number];
+  out->inv_len = RICE_INV_LEN[code_number];
+  out->code = t.code[code_number];
+  out->num_bits = t.num_bits[code_number];
+  out->inv = t.inv;
+  return X3_OK;
+}
+
 static uint64_t spf_of(const x3_params* p) { return (uint64_t)p->block_len * (uint64_t)p->blocks_per_frame; }
 
 // worst-case payload bytes of a frame of n samples: every block literal

@@ -160,8 +160,9 @@ extern "C" int x3_decode_block(x3_bitreader* b, int16_t* wav, uint32_t n, int16_
 struct x3_bitpacker {
   x3_ctx* c = nullptr;
   uint8_t* out = nullptr;
-  uint64_t out_cap = 0, start_pos = 0;
-  std::vector<uint32_t> val, nb;   // recorded fields (each <= 32 bits)
+  uint64_t out_cap = 0, start_pos = 0;  // start_pos: the writer's position at new()
+  uint64_t written = 0;                 // bytes behind start_pos already handed to `out`
+  std::vector<uint32_t> val, nb;        // every field recorded since new() (each <= 32 bits)
 };
 
 // pack fields [0, n): field i = the low nb[i] bits of val[i], MSB first, at the exclusive prefix sum of nb.  One
@@ -248,21 +249,14 @@ extern "C" int x3_bitpacker_word_align(x3_bitpacker* b) {
   if ((b->start_pos + (bits + to_byte) / 8) & 1) x3_bitpacker_write_packed_zeros(b, 8);
   return X3_OK;
 }
-// flush (:79-86) + len() / crc(): pack everything recorded on the GPU, write the bytes (a trailing partial byte is
-// zero-padded, as flush does) behind start_pos, return byte count, CRC-16 of those bytes (init 0xFFFF) and the
-// writer's position.  The recorder is left empty, positioned behind what was written.
-extern "C" int x3_bitpacker_finish(x3_bitpacker* b, uint64_t* len, uint16_t* crc, uint64_t* out_pos) {
-  if (!b) return X3_ERR_BAD_ARG;
+// pack every field recorded since new() into the context's scratch (c->out) and take the CRC-16 (init 0xFFFF) of its
+// first nbytes bytes
+static int bitpacker_pack(const x3_bitpacker* b, uint64_t nbytes, uint16_t* crc) {
   x3_ctx* c = b->c;
-  const uint64_t bits = bitpacker_bits(b);
-  const uint64_t nbytes = (bits + 7) / 8;
-  if (len) *len = nbytes;
-  if (out_pos) *out_pos = b->start_pos + nbytes;
-  if (b->start_pos + nbytes > b->out_cap) return X3_ERR_BYTE_WRITER_INSUFFICIENT_MEMORY;
   const uint32_t n = (uint32_t)b->val.size();
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
-  const size_t dst_bytes = ((nbytes + 3) & ~(size_t)3) + 8;
+  const size_t dst_bytes = (((bitpacker_bits(b) + 7) / 8 + 3) & ~(size_t)3) + 8;
   if ((rc = ensure(c, c->out, dst_bytes + 16))) return rc;
   if ((rc = ensure(c, c->in, (size_t)n * 8 + 16))) return rc;
   HIPCHK(c, hipMemsetAsync(c->out.p, 0, dst_bytes, c->stream));
@@ -274,12 +268,40 @@ extern "C" int x3_bitpacker_finish(x3_bitpacker* b, uint64_t* len, uint16_t* crc
     HIPCHK(c, hipGetLastError());
   }
   uint16_t v = 0xFFFF;
-  if ((rc = x3_crc16_dev(c, (const uint8_t*)c->out.p, nbytes, &v))) return rc;
+  if ((rc = x3_crc16_dev(c, (const uint8_t*)c->out.p, nbytes, &v))) return rc;  // syncs
   if (crc) *crc = v;
-  if (nbytes) HIPCHK(c, hipMemcpyAsync(b->out + b->start_pos, c->out.p, nbytes, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  b->start_pos += nbytes;
-  b->val.clear();
-  b->nb.clear();
+  return X3_OK;
+}
+
+// len() (:88-90) and crc() (:75-77) as the reference reports them between writes: the count of COMPLETE bytes so far
+// and the CRC-16 of those bytes.  Nothing is written to `out`.
+extern "C" int x3_bitpacker_peek(const x3_bitpacker* b, uint64_t* len, uint16_t* crc) {
+  if (!b) return X3_ERR_BAD_ARG;
+  const uint64_t nbytes = bitpacker_bits(b) / 8;
+  if (len) *len = nbytes;
+  return crc ? bitpacker_pack(b, nbytes, crc) : X3_OK;
+}
+
+// flush (:79-86), what Drop does: a trailing partial byte is zero-padded and counted; every field recorded since new()
+// is packed on the GPU, the bytes not handed over yet are written behind the writer's position.  *len and *crc are the
+// reference's len() / crc() at that point (cumulative since new()), *out_pos the writer's position.  Writing may go on
+// afterwards, from the next byte.
+extern "C" int x3_bitpacker_finish(x3_bitpacker* b, uint64_t* len, uint16_t* crc, uint64_t* out_pos) {
+  if (!b) return X3_ERR_BAD_ARG;
+  x3_ctx* c = b->c;
+  const uint64_t bits = bitpacker_bits(b);
+  x3_bitpacker_write_packed_zeros(b, (uint32_t)((8 - (bits & 7)) & 7));
+  const uint64_t nbytes = (bits + 7) / 8;
+  if (len) *len = nbytes;
+  if (out_pos) *out_pos = b->start_pos + nbytes;
+  if (b->start_pos + nbytes > b->out_cap) return X3_ERR_BYTE_WRITER_INSUFFICIENT_MEMORY;
+  int rc;
+  if ((rc = bitpacker_pack(b, nbytes, crc))) return rc;
+  if (nbytes > b->written) {
+    HIPCHK(c, hipMemcpyAsync(b->out + b->start_pos + b->written, (const uint8_t*)c->out.p + b->written, nbytes - b->written,
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    b->written = nbytes;
+  }
   return X3_OK;
 }

@@ -13,18 +13,32 @@
 //   crc::{crc16,update_crc16}         crc.rs:44-58      x3::crc::*
 //   encoder::{encode,encode_frame,write_frame_header}  encoder.rs:51-214   x3::encoder::*
 //   decoder::{read_frame_header,decode_frame}          decoder.rs:36-118   x3::decoder::*
+//   x3::RiceCode / RiceCodes::get     x3.rs:187-260     x3::RiceCode, x3::RiceCodes::get, Parameters::rice_codes
+//   decoder::decode_block             decoder.rs:132-145     x3::decoder::decode_block
+//   bitreader::BitReader              bitreader.rs:51-176    x3::bitreader::BitReader
+//   bitpacker::BitPacker              bitpacker.rs:46-190    x3::bitpacker::BitPacker
+//   decodefile::X3aReader             decodefile.rs:47-136   x3::decodefile::X3aReader
 //   X3aReader::decode_next_frame loop decodefile.rs:105-136,200-209        x3::decoder::decode_stream
 //
+// Every function exists twice: with the reference's own argument list (it then runs on x3::default_context(), a
+// process-wide context on device $X3HIP_DEVICE or 0, created on first use and serialized by a mutex), and with a
+// leading `Context&` for callers that manage devices and streams themselves.
+//
 // Every bulk call goes to libx3hip.so (HIP kernels on the MI355X); nothing here computes on the CPU
-// beyond argument marshalling.  BitPacker / BitReader have no host counterpart: on the GPU they are
-// per-block LDS scratch + a wavefront scan (encode) and a per-lane register bit window (decode).
+// beyond argument marshalling.  BitPacker / BitReader are handles to device state: their bit work runs in
+// kernels too (x3_bits.h) -- they exist for callers of the reference's building blocks, the frame kernels
+// do not go through them.
 #pragma once
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <iostream>
+#include <array>
+#include <cstdlib>
 #include <iterator>
+#include <mutex>
 #include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "../../include/x3hip.h"
@@ -58,6 +72,63 @@ class Context {
   x3_ctx* ctx_ = nullptr;
 };
 
+// The context behind the reference-shaped overloads (those without a Context& argument).  One per process, made on
+// first use; `lock()` serializes callers, a context is not re-entrant.
+inline Context& default_context() {
+  static Context ctx([] {
+    const char* e = std::getenv("X3HIP_DEVICE");
+    return e ? std::atoi(e) : 0;
+  }());
+  return ctx;
+}
+inline std::mutex& default_context_mutex() {
+  static std::mutex m;
+  return m;
+}
+struct MaybeLock {  // locks the default context's mutex for handles that were made on it
+  explicit MaybeLock(std::mutex* m) : m_(m) { if (m_) m_->lock(); }
+  ~MaybeLock() { if (m_) m_->unlock(); }
+  MaybeLock(const MaybeLock&) = delete;
+  MaybeLock& operator=(const MaybeLock&) = delete;
+  std::mutex* m_;
+};
+#define X3_WITH_DEFAULT_CONTEXT(expr)                               \
+  do {                                                              \
+    std::lock_guard<std::mutex> lk_(::x3::default_context_mutex()); \
+    ::x3::Context& ctx = ::x3::default_context();                   \
+    return (expr);                                                  \
+  } while (0)
+
+// x3.rs:187-194.  The tables live in the library (x3_rice_code_get); `code`/`num_bits` have `len` entries.
+struct RiceCode {
+  size_t nsubs = 0, offset = 0;
+  const uint32_t* code = nullptr;
+  const uint32_t* num_bits = nullptr;
+  const int16_t* inv = nullptr;
+  size_t inv_len = 0;
+  size_t len = 0;  // entries in code / num_bits (the slices' .len() in the reference)
+};
+// x3.rs:196-260
+struct RiceCodes {
+  static const RiceCode* code(size_t k) {
+    static const std::array<RiceCode, 4> t = [] {
+      std::array<RiceCode, 4> a;
+      for (uint32_t i = 0; i < 4; ++i) {
+        x3_rice_code c;
+        x3_rice_code_get(i, &c);
+        a[i].nsubs = c.nsubs; a[i].offset = c.offset; a[i].code = c.code; a[i].num_bits = c.num_bits;
+        a[i].inv = c.inv; a[i].inv_len = c.inv_len; a[i].len = c.len;
+      }
+      return a;
+    }();
+    if (k > 3) throw std::out_of_range("RiceCodes::get: code number > 3 (the reference panics on the index)");
+    return &t[k];
+  }
+  static std::array<const RiceCode*, 3> get(const size_t (&code_list)[3]) {
+    return {code(code_list[0]), code(code_list[1]), code(code_list[2])};
+  }
+};
+
 // x3.rs:81-134
 struct Parameters {
   static constexpr size_t MAX_BLOCK_LENGTH = 60;
@@ -68,6 +139,7 @@ struct Parameters {
   size_t blocks_per_frame = DEFAULT_BLOCKS_PER_FRAME;
   size_t codes[3] = {0, 1, 3};
   size_t thresholds[3] = {3, 8, 20};
+  std::array<const RiceCode*, 3> rice_codes = {RiceCodes::code(0), RiceCodes::code(1), RiceCodes::code(3)};
 
   // Parameters::new (x3.rs:98-122)
   static X3Error create(size_t block_len, size_t blocks_per_frame, const size_t (&codes)[3],
@@ -79,6 +151,7 @@ struct Parameters {
     x3_params c = p.c_params();
     int rc = x3_params_validate(&c);
     if (rc) return static_cast<X3Error>(rc);
+    p.rice_codes = RiceCodes::get(p.codes);
     *out = p;
     return X3Error::Ok;
   }
@@ -94,6 +167,7 @@ struct Parameters {
     p.block_len = c.block_len;
     p.blocks_per_frame = c.blocks_per_frame;
     for (int k = 0; k < 3; ++k) { p.codes[k] = c.codes[k]; p.thresholds[k] = c.thresholds[k]; }
+    p.rice_codes = RiceCodes::get(p.codes);
     return p;
   }
 };
@@ -239,7 +313,109 @@ inline uint16_t update_crc16(uint16_t c, uint8_t data) { return x3_crc16_update(
 inline X3Error crc16(Context& ctx, const uint8_t* data, size_t n, uint16_t* out) {
   return static_cast<X3Error>(x3_crc16(ctx.raw(), data, n, out));
 }
+inline uint16_t crc16(const uint8_t* data, size_t n) {  // the reference's own signature: no error path
+  std::lock_guard<std::mutex> lk(default_context_mutex());
+  uint16_t c = 0;
+  if (x3_crc16(default_context().raw(), data, n, &c)) throw std::runtime_error(x3_last_error(default_context().raw()));
+  return c;
+}
 }  // namespace crc
+
+// bitpacker.rs:46-190 (the subset the encoder uses: write_bits, write_packed_zeros, word_align, len, crc; dropping
+// it flushes).  The fields are packed by a kernel when the packer is finished or dropped.
+namespace bitpacker {
+class BitPacker {
+ public:
+  // BitPacker::new(&mut SliceByteWriter): packs into the slice from the writer's position on
+  explicit BitPacker(bytewriter::SliceByteWriter& writer) : BitPacker(default_context(), writer) {
+    mu_ = &default_context_mutex();
+  }
+  BitPacker(Context& ctx, bytewriter::SliceByteWriter& writer) : writer_(writer) {
+    MaybeLock lk(&ctx == &default_context() ? &default_context_mutex() : nullptr);
+    int rc = x3_bitpacker_new(ctx.raw(), writer.data(), writer.capacity(), writer.position(), &bp_);
+    if (rc) throw std::runtime_error("x3::bitpacker::BitPacker: x3_bitpacker_new failed");
+  }
+  BitPacker(const BitPacker&) = delete;
+  BitPacker& operator=(const BitPacker&) = delete;
+  ~BitPacker() {  // Drop (bitpacker.rs:56-62) flushes
+    finish();
+    x3_bitpacker_free(bp_);
+  }
+  X3Error write_bits(size_t value, size_t num_bits) {
+    return static_cast<X3Error>(x3_bitpacker_write_bits(bp_, value, (uint32_t)num_bits));
+  }
+  X3Error write_packed_zeros(size_t num_zeros) {
+    return static_cast<X3Error>(x3_bitpacker_write_packed_zeros(bp_, (uint32_t)num_zeros));
+  }
+  X3Error word_align() { return static_cast<X3Error>(x3_bitpacker_word_align(bp_)); }
+  // flush (bitpacker.rs:79-86): a partial byte is zero-padded, the packing kernel runs, the writer moves on
+  X3Error finish() {
+    MaybeLock lk(mu_);
+    uint64_t pos = 0, len = 0;
+    uint16_t crc = 0;
+    int rc = x3_bitpacker_finish(bp_, &len, &crc, &pos);
+    if (rc == 0) writer_.advance_to((size_t)pos);
+    return static_cast<X3Error>(rc);
+  }
+  // len() / crc() (bitpacker.rs:75-90): complete bytes so far and their CRC-16
+  size_t len() const {
+    uint64_t n = 0;
+    x3_bitpacker_peek(bp_, &n, nullptr);
+    return (size_t)n;
+  }
+  uint16_t crc() const {
+    MaybeLock lk(mu_);
+    uint16_t c = 0;
+    if (x3_bitpacker_peek(bp_, nullptr, &c)) throw std::runtime_error("x3::bitpacker::BitPacker::crc: HIP error");
+    return c;
+  }
+
+ private:
+  bytewriter::SliceByteWriter& writer_;
+  x3_bitpacker* bp_ = nullptr;
+  std::mutex* mu_ = nullptr;
+};
+}  // namespace bitpacker
+
+// bitreader.rs:51-176
+namespace bitreader {
+class BitReader {
+ public:
+  BitReader(const uint8_t* array, size_t len) : BitReader(default_context(), array, len) { mu_ = &default_context_mutex(); }
+  BitReader(Context& ctx, const uint8_t* array, size_t len) {
+    MaybeLock lk(&ctx == &default_context() ? &default_context_mutex() : nullptr);
+    if (x3_bitreader_new(ctx.raw(), array, len, &br_)) throw std::runtime_error("x3::bitreader::BitReader: x3_bitreader_new failed");
+  }
+  BitReader(const BitReader&) = delete;
+  BitReader& operator=(const BitReader&) = delete;
+  ~BitReader() { x3_bitreader_free(br_); }
+  void inc_bits(size_t n) {
+    MaybeLock lk(mu_);
+    check(x3_bitreader_inc_bits(br_, (uint32_t)n));
+  }
+  uint32_t read_nbits(size_t n) {
+    MaybeLock lk(mu_);
+    uint32_t v = 0;
+    check(x3_bitreader_read_nbits(br_, (uint32_t)n, &v));
+    return v;
+  }
+  size_t count_zero_bits() {
+    MaybeLock lk(mu_);
+    uint32_t v = 0;
+    check(x3_bitreader_count_zero_bits(br_, &v));
+    return v;
+  }
+  x3_bitreader* raw() { return br_; }
+  std::mutex* mutex() { return mu_; }
+
+ private:
+  static void check(int rc) {
+    if (rc) throw std::runtime_error(std::string("x3::bitreader::BitReader: ") + x3_strerror(rc));
+  }
+  x3_bitreader* br_ = nullptr;
+  std::mutex* mu_ = nullptr;
+};
+}  // namespace bitreader
 
 namespace encoder {
 using bytewriter::ByteWriter;
@@ -318,6 +494,18 @@ inline X3Error encode_frame(Context& ctx, const int16_t* wav, size_t n, ByteWrit
     for (int i = 0; i < 6; ++i) stats[i] += st[i];
   return e;
 }
+
+// the reference's own argument lists (encoder.rs:51, :175): no context, statistics printed as the `std` build does
+inline X3Error encode(const Channel* const* channels, size_t n_channels, ByteWriter& writer) {
+  X3_WITH_DEFAULT_CONTEXT(encode(ctx, channels, n_channels, writer, true));
+}
+template <class It>
+inline X3Error encode(IterChannel<It>* const* channels, size_t n_channels, ByteWriter& writer) {
+  X3_WITH_DEFAULT_CONTEXT(encode(ctx, channels, n_channels, writer, true));
+}
+inline X3Error encode_frame(const int16_t* wav, size_t n, ByteWriter& writer, const Parameters& params, uint64_t (&stats)[6]) {
+  X3_WITH_DEFAULT_CONTEXT(encode_frame(ctx, wav, n, writer, params, stats));
+}
 }  // namespace encoder
 
 namespace decoder {
@@ -344,6 +532,18 @@ inline X3Error decode_frame(Context& ctx, const uint8_t* x3_bytes, size_t len, i
   return static_cast<X3Error>(rc);
 }
 
+inline X3Error decode_frame(const uint8_t* x3_bytes, size_t len, int16_t* wav_buf, size_t wav_cap, const Parameters& params,
+                            size_t samples, size_t* n_out) {
+  X3_WITH_DEFAULT_CONTEXT(decode_frame(ctx, x3_bytes, len, wav_buf, wav_cap, params, samples, n_out));
+}
+
+// decoder.rs:132-145: one block of wav_len samples from the reader's position; *last_wav is read and updated
+inline X3Error decode_block(bitreader::BitReader& br, int16_t* wav, size_t wav_len, int16_t* last_wav, const Parameters& params) {
+  MaybeLock lk(br.mutex());
+  x3_params c = params.c_params();
+  return static_cast<X3Error>(x3_decode_block(br.raw(), wav, (uint32_t)wav_len, last_wav, &c));
+}
+
 // the X3aReader::decode_next_frame loop (decodefile.rs:105-136, 200-209) over an in-memory frame stream
 struct StreamResult {
   uint64_t samples = 0, frames_ok = 0, frame_errors = 0;
@@ -355,6 +555,10 @@ inline X3Error decode_stream(Context& ctx, const uint8_t* x3, size_t len, const 
   int rc = x3_decode_stream(ctx.raw(), x3, len, &c, wav, wav_cap, &r.samples, &r.frames_ok, &r.frame_errors);
   if (res) *res = r;
   return static_cast<X3Error>(rc);
+}
+inline X3Error decode_stream(const uint8_t* x3, size_t len, const Parameters& params, int16_t* wav, size_t wav_cap,
+                             StreamResult* res) {
+  X3_WITH_DEFAULT_CONTEXT(decode_stream(ctx, x3, len, params, wav, wav_cap, res));
 }
 // the same walk for a stream that is already in HBM: frame index and decode on the device (x3_index_dev)
 inline X3Error decode_stream_dev(Context& ctx, const uint8_t* d_x3, size_t len, const Parameters& params, int16_t* d_wav,
@@ -422,11 +626,67 @@ inline X3Error wav_to_x3a(Context& ctx, const char* wav_filename, const char* x3
   if (rc == X3_OK && print_statistics) encoder::detail::print_stats(stats);
   return static_cast<X3Error>(rc);
 }
+inline X3Error wav_to_x3a(const char* wav_filename, const char* x3a_filename) {  // encodefile.rs:48
+  X3_WITH_DEFAULT_CONTEXT(wav_to_x3a(ctx, wav_filename, x3a_filename, true));
+}
 }  // namespace encodefile
 namespace decodefile {
+constexpr size_t READ_BUFFER_SIZE = X3_READ_BUFFER_SIZE;       // decodefile.rs:44 (X3_READ_BUFFER_SIZE is the C macro)
+constexpr size_t X3_WRITE_BUFFER_SIZE = READ_BUFFER_SIZE * 8;  // decodefile.rs:45
+
+// decodefile.rs:47-136.  open() reads the archive header; decode_next_frame() hands out one frame per call with the
+// reference's per-call results: Ok + *some + *n = samples (Ok(Some(n)), n >= 1), Ok + !*some (Ok(None): end of the
+// data, a payload that runs past it, or a frame that failed to decode -- counted in frame_errors()), or the error the
+// reference returns for that frame (header CRC, key, payload CRC ...), after which a further call goes on behind it.
+// Behind it the library decodes windows of frames ahead on the GPU (x3_reader.h).
+class X3aReader {
+ public:
+  static X3Error open(const char* filename, X3aReader* out) { return open(default_context(), filename, out, &default_context_mutex()); }
+  static X3Error open(Context& ctx, const char* filename, X3aReader* out, std::mutex* mu = nullptr) {
+    MaybeLock lk(mu);
+    out->close_locked();
+    out->mu_ = mu;
+    int rc = x3_reader_open(ctx.raw(), filename, &out->r_);
+    if (rc) return static_cast<X3Error>(rc);
+    x3_params c;
+    x3_reader_spec(out->r_, &out->spec_.sample_rate, &c, &out->spec_.channels);
+    out->spec_.params = Parameters::from_c(c);
+    return X3Error::Ok;
+  }
+  X3aReader() = default;
+  X3aReader(const X3aReader&) = delete;
+  X3aReader& operator=(const X3aReader&) = delete;
+  ~X3aReader() {
+    MaybeLock lk(mu_);
+    close_locked();
+  }
+  const X3aSpec& spec() const { return spec_; }
+  X3Error decode_next_frame(int16_t (&wav_buf)[X3_WRITE_BUFFER_SIZE], size_t* n, bool* some) {
+    MaybeLock lk(mu_);
+    uint64_t got = 0;
+    int rc = x3_reader_next_frame(r_, wav_buf, X3_WRITE_BUFFER_SIZE, &got);
+    *some = rc == X3_OK && got != 0;
+    *n = (size_t)got;
+    return static_cast<X3Error>(rc);
+  }
+  size_t frame_errors() const { return r_ ? (size_t)x3_reader_frame_errors(r_) : 0; }
+
+ private:
+  void close_locked() {
+    if (r_) x3_reader_close(r_);
+    r_ = nullptr;
+  }
+  x3_reader* r_ = nullptr;
+  std::mutex* mu_ = nullptr;
+  X3aSpec spec_{0, Parameters{}, 0};
+};
+
 inline X3Error x3a_to_wav(Context& ctx, const char* x3a_filename, const char* wav_filename, uint64_t* samples = nullptr,
                           uint64_t* frame_errors = nullptr) {
   return static_cast<X3Error>(x3_x3a_to_wav(ctx.raw(), x3a_filename, wav_filename, samples, frame_errors));
+}
+inline X3Error x3a_to_wav(const char* x3a_filename, const char* wav_filename) {  // decodefile.rs:189
+  X3_WITH_DEFAULT_CONTEXT(x3a_to_wav(ctx, x3a_filename, wav_filename, nullptr, nullptr));
 }
 }  // namespace decodefile
 }  // namespace x3

@@ -32,7 +32,7 @@ SYMBOLS = [
     "x3_strerror", "x3_ctx_create", "x3_ctx_create_on_stream", "x3_ctx_destroy", "x3_ctx_sync", "x3_last_error",
     "x3_ctx_set_option", "x3_ctx_get_option",
     "x3_ctx_enable_kernel_timing", "x3_ctx_kernel_time", "x3_ctx_reset_kernel_time",
-    "x3_params_default", "x3_params_validate", "x3_num_frames", "x3_encode_bound",
+    "x3_params_default", "x3_params_validate", "x3_rice_code_get", "x3_num_frames", "x3_encode_bound",
     "x3_crc16", "x3_crc16_dev", "x3_crc16_update",
     "x3_encode", "x3_encode_frame", "x3_write_frame_header", "x3_encode_batch",
     "x3_read_frame_header", "x3_decode_frame", "x3_decode_stream",
@@ -41,7 +41,7 @@ SYMBOLS = [
     "x3_bitreader_new", "x3_bitreader_read_nbits", "x3_bitreader_count_zero_bits", "x3_bitreader_inc_bits",
     "x3_bitreader_state", "x3_bitreader_free", "x3_decode_block",
     "x3_bitpacker_new", "x3_bitpacker_write_bits", "x3_bitpacker_write_packed_zeros", "x3_bitpacker_word_align",
-    "x3_bitpacker_finish", "x3_bitpacker_free",
+    "x3_bitpacker_finish", "x3_bitpacker_peek", "x3_bitpacker_free",
     "x3_reader_open", "x3_reader_open_mem", "x3_reader_spec", "x3_reader_next_frame", "x3_reader_frame_errors",
     "x3_reader_position", "x3_reader_close",
     "x3_encode_dev", "x3_encode_result", "x3_decode_dev", "x3_decode_result", "x3_index_dev", "x3_decode_stream_dev",
@@ -52,6 +52,12 @@ SYMBOLS = [
     "x3_mgpu_create", "x3_mgpu_destroy", "x3_mgpu_devices", "x3_mgpu_ctx", "x3_mgpu_shard", "x3_mgpu_last_error",
     "x3_mgpu_encode", "x3_mgpu_decode_stream",
 ]
+
+
+class RiceCode(C.Structure):
+    """x3_rice_code (RiceCode, src/x3.rs:187-194)"""
+    _fields_ = [("nsubs", C.c_uint32), ("offset", C.c_uint32), ("len", C.c_uint32), ("inv_len", C.c_uint32),
+                ("code", C.POINTER(C.c_uint32)), ("num_bits", C.POINTER(C.c_uint32)), ("inv", C.POINTER(C.c_int16))]
 
 
 class Params(C.Structure):
@@ -136,6 +142,7 @@ def lib():
     L.x3_params_default.restype = None
     L.x3_params_default.argtypes = [PP]
     L.x3_params_validate.argtypes = [PP]
+    L.x3_rice_code_get.argtypes = [C.c_uint32, C.POINTER(RiceCode)]
     L.x3_num_frames.restype = u64
     L.x3_num_frames.argtypes = [u64, PP]
     L.x3_encode_bound.restype = u64
@@ -183,6 +190,7 @@ def lib():
     L.x3_bitpacker_write_packed_zeros.argtypes = [vp, u32]
     L.x3_bitpacker_word_align.argtypes = [vp]
     L.x3_bitpacker_finish.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_uint16), C.POINTER(u64)]
+    L.x3_bitpacker_peek.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_uint16)]
     L.x3_bitpacker_free.restype = None
     L.x3_bitpacker_free.argtypes = [vp]
     L.x3_reader_open.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
