@@ -226,7 +226,9 @@ int x3_decode_block(x3_bitreader* br, int16_t* wav, uint32_t n, int16_t* last_wa
  * GPU (scan of the field widths, fields OR-ed into place), writes the bytes not handed over yet behind start_pos and
  * returns the reference's len() and crc() at that point (cumulative since new(); CRC-16 init 0xFFFF) and the writer's
  * position; writing may go on from the next byte.  x3_bitpacker_peek = len() / crc() between writes: complete bytes
- * so far and their CRC, nothing written. */
+ * so far and their CRC, nothing written.  A packer over any other ByteWriter is made with out = NULL, out_cap = 0
+ * (start_pos = the writer's position: word_align needs its parity) and flushed with x3_bitpacker_take, which delivers
+ * the bytes not handed over yet into dst[0, *n_new) for the caller to pass on. */
 typedef struct x3_bitpacker x3_bitpacker;
 int x3_bitpacker_new(x3_ctx* ctx, uint8_t* out, uint64_t out_cap, uint64_t start_pos, x3_bitpacker** bp);
 int x3_bitpacker_write_bits(x3_bitpacker* bp, uint64_t value, uint32_t num_bits);
@@ -234,6 +236,7 @@ int x3_bitpacker_write_packed_zeros(x3_bitpacker* bp, uint32_t num_zeros);
 int x3_bitpacker_word_align(x3_bitpacker* bp);
 int x3_bitpacker_finish(x3_bitpacker* bp, uint64_t* len, uint16_t* crc, uint64_t* out_pos);
 int x3_bitpacker_peek(const x3_bitpacker* bp, uint64_t* len, uint16_t* crc);
+int x3_bitpacker_take(x3_bitpacker* bp, uint8_t* dst, uint64_t dst_cap, uint64_t* n_new, uint64_t* len, uint16_t* crc);
 void x3_bitpacker_free(x3_bitpacker* bp);
 
 /* ------------------------------------------------------------------ .x3a archive (encodefile.rs / decodefile.rs) */

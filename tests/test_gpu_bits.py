@@ -169,3 +169,39 @@ def test_decode_block_kat(ctx):
         assert wav.tolist() == b["expected_wav"], b["name"]
         assert lw.value == b["expected_wav"][-1]
         br.close()
+
+
+def test_bitpacker_unbound_take(ctx):
+    """a packer over "any other ByteWriter" (out = NULL): bytes delivered by x3_bitpacker_take in two flushes, at an odd
+    writer position, equal the oracle's"""
+    rng = np.random.default_rng(77)
+    L, OL = x3hip.lib(), O.lib()
+    fields = [(int(rng.integers(0, 1 << 32)), int(rng.integers(1, 33))) for _ in range(500)]
+    start = 3
+    b = np.zeros(4096, dtype=np.uint8)
+    w = O.Writer()
+    OL.x3o_writer_init(C.byref(w), b.ctypes.data, b.size)
+    OL.x3o_writer_seek_start(C.byref(w), start)
+    ob = O.BitPacker()
+    OL.x3o_bp_new(C.byref(ob), C.byref(w))
+    bp = C.c_void_p()
+    assert L.x3_bitpacker_new(ctx._h, None, 0, start, C.byref(bp)) == 0
+    got = bytearray()
+    n_new, ln, crc = C.c_uint64(0), C.c_uint64(0), C.c_uint16(0)
+    tmp = np.zeros(4096, dtype=np.uint8)
+    for i, (v, n) in enumerate(fields):
+        assert L.x3_bitpacker_write_bits(bp, v, n) == 0
+        assert OL.x3o_bp_write_bits(C.byref(ob), v, n) == 0
+        if i == 200:
+            assert L.x3_bitpacker_take(bp, tmp.ctypes.data, 1, C.byref(n_new), None, None) == 22   # ByteWriterInsufficientMemory
+            assert L.x3_bitpacker_take(bp, tmp.ctypes.data, tmp.size, C.byref(n_new), C.byref(ln), C.byref(crc)) == 0
+            got += tmp[:n_new.value].tobytes()
+            OL.x3o_bp_drop(C.byref(ob))
+            assert (ln.value, crc.value) == (ob.byte_len, ob.crc) and len(got) == ln.value
+    assert L.x3_bitpacker_word_align(bp) == 0
+    assert OL.x3o_bp_word_align(C.byref(ob)) == 0
+    assert L.x3_bitpacker_take(bp, tmp.ctypes.data, tmp.size, C.byref(n_new), C.byref(ln), C.byref(crc)) == 0
+    got += tmp[:n_new.value].tobytes()
+    L.x3_bitpacker_free(bp)
+    assert (ln.value, crc.value) == (ob.byte_len, ob.crc)
+    assert bytes(got) == b[start:w.p_byte].tobytes() and (start + len(got)) % 2 == 0

@@ -198,7 +198,7 @@ x3_pack_fields_kernel(const uint32_t* __restrict__ val, const uint32_t* __restri
 
 // BitPacker::new over a SliceByteWriter positioned at start_pos (src/bitpacker.rs:65-73)
 extern "C" int x3_bitpacker_new(x3_ctx* c, uint8_t* out, uint64_t out_cap, uint64_t start_pos, x3_bitpacker** bp) {
-  if (!c || (!out && out_cap) || !bp || start_pos > out_cap) return X3_ERR_BAD_ARG;
+  if (!c || (!out && out_cap) || !bp || (out && start_pos > out_cap)) return X3_ERR_BAD_ARG;
   x3_bitpacker* b = new x3_bitpacker();
   b->c = c;
   b->out = out;
@@ -286,22 +286,35 @@ extern "C" int x3_bitpacker_peek(const x3_bitpacker* b, uint64_t* len, uint16_t*
 // is packed on the GPU, the bytes not handed over yet are written behind the writer's position.  *len and *crc are the
 // reference's len() / crc() at that point (cumulative since new()), *out_pos the writer's position.  Writing may go on
 // afterwards, from the next byte.
-extern "C" int x3_bitpacker_finish(x3_bitpacker* b, uint64_t* len, uint16_t* crc, uint64_t* out_pos) {
-  if (!b) return X3_ERR_BAD_ARG;
+static int bitpacker_flush(x3_bitpacker* b, uint8_t* dst, uint64_t dst_cap, uint64_t* len, uint16_t* crc, uint64_t* n_new) {
   x3_ctx* c = b->c;
   const uint64_t bits = bitpacker_bits(b);
-  x3_bitpacker_write_packed_zeros(b, (uint32_t)((8 - (bits & 7)) & 7));
-  const uint64_t nbytes = (bits + 7) / 8;
+  const uint64_t nbytes = (bits + 7) / 8, fresh = nbytes - b->written;
   if (len) *len = nbytes;
-  if (out_pos) *out_pos = b->start_pos + nbytes;
-  if (b->start_pos + nbytes > b->out_cap) return X3_ERR_BYTE_WRITER_INSUFFICIENT_MEMORY;
+  if (n_new) *n_new = fresh;
+  if (fresh > dst_cap) return X3_ERR_BYTE_WRITER_INSUFFICIENT_MEMORY;
+  x3_bitpacker_write_packed_zeros(b, (uint32_t)((8 - (bits & 7)) & 7));
   int rc;
   if ((rc = bitpacker_pack(b, nbytes, crc))) return rc;
-  if (nbytes > b->written) {
-    HIPCHK(c, hipMemcpyAsync(b->out + b->start_pos + b->written, (const uint8_t*)c->out.p + b->written, nbytes - b->written,
-                             hipMemcpyDeviceToHost, c->stream));
+  if (fresh) {
+    HIPCHK(c, hipMemcpyAsync(dst, (const uint8_t*)c->out.p + b->written, fresh, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     b->written = nbytes;
   }
   return X3_OK;
+}
+extern "C" int x3_bitpacker_finish(x3_bitpacker* b, uint64_t* len, uint16_t* crc, uint64_t* out_pos) {
+  if (!b || !b->out) return X3_ERR_BAD_ARG;
+  uint64_t total = 0;
+  const uint64_t at = b->start_pos + b->written;
+  const int rc = bitpacker_flush(b, b->out + at, b->out_cap - at, &total, crc, nullptr);
+  if (len) *len = total;
+  if (out_pos) *out_pos = b->start_pos + total;
+  return rc;
+}
+// the same flush for a packer that is not bound to a slice (out == NULL at new(): any other ByteWriter): the bytes not
+// handed over yet go to dst[0, *n_new) and the caller passes them to its writer.
+extern "C" int x3_bitpacker_take(x3_bitpacker* b, uint8_t* dst, uint64_t dst_cap, uint64_t* n_new, uint64_t* len, uint16_t* crc) {
+  if (!b || (!dst && dst_cap)) return X3_ERR_BAD_ARG;
+  return bitpacker_flush(b, dst, dst_cap, len, crc, n_new);
 }

@@ -41,7 +41,7 @@ SYMBOLS = [
     "x3_bitreader_new", "x3_bitreader_read_nbits", "x3_bitreader_count_zero_bits", "x3_bitreader_inc_bits",
     "x3_bitreader_state", "x3_bitreader_free", "x3_decode_block",
     "x3_bitpacker_new", "x3_bitpacker_write_bits", "x3_bitpacker_write_packed_zeros", "x3_bitpacker_word_align",
-    "x3_bitpacker_finish", "x3_bitpacker_peek", "x3_bitpacker_free",
+    "x3_bitpacker_finish", "x3_bitpacker_peek", "x3_bitpacker_take", "x3_bitpacker_free",
     "x3_reader_open", "x3_reader_open_mem", "x3_reader_spec", "x3_reader_next_frame", "x3_reader_frame_errors",
     "x3_reader_position", "x3_reader_close",
     "x3_encode_dev", "x3_encode_result", "x3_decode_dev", "x3_decode_result", "x3_index_dev", "x3_decode_stream_dev",
@@ -191,6 +191,7 @@ def lib():
     L.x3_bitpacker_word_align.argtypes = [vp]
     L.x3_bitpacker_finish.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_uint16), C.POINTER(u64)]
     L.x3_bitpacker_peek.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_uint16)]
+    L.x3_bitpacker_take.argtypes = [vp, vp, u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_uint16)]
     L.x3_bitpacker_free.restype = None
     L.x3_bitpacker_free.argtypes = [vp]
     L.x3_reader_open.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
