@@ -1126,7 +1126,7 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
 #endif
     TimerScope ts(c, 1);
     if (split)
-      hipLaunchKernelGGL(x3_decode_split_kernel, dim3((unsigned)((F + 63) / 64)), dim3(128),
+      hipLaunchKernelGGL(x3_decode_split_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64 * X3S_WAVES),
                          dyn_lds, c->stream, d_x3, x3_len,
                          d_frame_offsets, F, g, d_wav_offsets, dp, d_wav, wav_cap, d_status, (X3FrameMeta*)c->dec_meta.p);
     else if (fast)

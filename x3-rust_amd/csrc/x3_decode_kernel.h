@@ -301,7 +301,7 @@ __device__ __forceinline__ uint32_t x3_wave_max_u32(uint32_t v) {
 // LDS traffic between lanes of ONE wave needs no s_barrier: a wave's DS instructions execute in
 // issue order.  This only stops the compiler from moving LDS accesses across the point.
 #ifdef X3_DBG_STAMPS
-__device__ unsigned long long x3_dbg[8 * 4096];
+__device__ unsigned long long x3_dbg[8 * 8192];
 #define X3_STAMP(k) do { unsigned long long t_ = clock64(); dbg_acc[k] += t_ - dbg_t; dbg_t = t_; } while (0)
 #else
 #define X3_STAMP(k) do { } while (0)

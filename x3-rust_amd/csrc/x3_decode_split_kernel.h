@@ -1,11 +1,11 @@
-// x3_decode_split_kernel.h -- the lane-per-frame decoder of x3_decode_fast_kernel split over TWO waves.
+// x3_decode_split_kernel.h -- the lane-per-frame decoder of x3_decode_fast_kernel split over THREE waves.
 //
 // Why: a frame is one serial bit stream, so decode parallelism is frames (69 120 in config 3 = 1 080
 // waves, about one per SIMD), and ONE wave can issue a VALU instruction only every ~5-8 cycles however
 // idle its SIMD is (tools/ubench/issue_cost.hip: 8.5 cycles dependent, 5.3 with four independent
 // chains; the SIMD itself sustains one every ~3).  The time of x3_decode_fast_kernel is therefore
 // (instructions per sample) x (that latency), with more than half of every SIMD unused.  Here each group
-// of 64 frames gets a workgroup of two waves on two SIMDs:
+// of 64 frames gets a workgroup of three waves:
 //
 //   wave 0, the PARSER: owns the input ring and the bit window.  Per block it reads the 6 header bits and
 //     walks the codewords: for every sample the zero run z and the field v behind it, two samples per
@@ -13,35 +13,40 @@
 //     into the reference's inverse Rice table, or simply the field for BFP/literal blocks),
 //     two 16-bit values per dword, through a double-buffered LDS block buffer, and the header bits.
 //   wave 1, the VALUER: turns indices into differences (zigzag / unsigned_to_i16) and samples (running sum,
-//     in packed 16-bit arithmetic), checks the table bounds, stages the samples in LDS and flushes them to
-//     HBM as 16-byte pieces of contiguous runs, and owns status and metadata.
+//     in packed 16-bit arithmetic), checks the table bounds, stages the samples in per-row LDS rings that are
+//     indexed by the DESTINATION address, and owns status and metadata.
+//   wave 2, the FLUSHER: one block behind the valuer it writes every 128-byte line of wav that has been
+//     completed in the rings -- whole, aligned lines only, eight per store instruction.  (Groups that are not
+//     64 equal frames side by side are flushed by the valuer, row by row: rare.)
 //
-// One s_barrier per 20-sample block: behind barrier k the parser works on block k+1 while the valuer
-// consumes block k.  Both waves derive the per-lane block sizes from the frame header alone, so their
-// loop trip counts agree whatever the payload holds; a lane whose frame fails (BFP exponent, table
-// bound) is only marked dead in the valuer -- the parser keeps walking its bits (lanes are independent,
-// and every read is bounded by the ring), the valuer stops storing for it.
+// One s_barrier per 20-sample block: behind barrier k the parser works on block k+1, the valuer on block k,
+// the flusher on what block k-1 completed.  All waves derive the per-lane block sizes from the frame header
+// alone, so their loop trip counts agree whatever the payload holds; a lane whose frame fails (BFP exponent,
+// table bound) is marked dead by the valuer -- the parser keeps walking its bits (lanes are independent, and
+// every read is bounded by the ring), the flusher stops storing for it.
 //
-// Geometry: block_len = 20 (ten pairs per block), staging window = 4 blocks = 80 samples, output frames
-// 16-byte aligned (the host launches x3_decode_fast_kernel otherwise).  Same results as the fast kernel.
+// Geometry: block_len = 20 (ten pairs per block), output frames 16-byte aligned (the host launches
+// x3_decode_fast_kernel otherwise).  Same results as the fast kernel.
 //
-// The samples go out with NON-TEMPORAL stores (x3_store_stream16).  With plain stores the kernel moved 1.20x its
-// algorithmic bytes (profiles/r1: WRITE_SIZE 1.17x the samples, FETCH_SIZE 1.29x the stream): the 160-byte runs
-// of a flush leave partially written lines in L2, which the streaming input evicts half-done and which evict the
-// input's lines in turn.  Streaming stores do neither: 1.025x / 1.03x, same kernel time (profiles/r2).  (A flush
-// that writes whole 64-byte-aligned chunks from a destination-indexed ring was built and measured as well: the
-// same traffic once its stores were non-temporal, 5 % slower for its address arithmetic -- not kept.)
+// What sets this kernel's time (measured, round 2; tools/dbg_stamps_split.py, tools/ubench/store_rate.hip):
+//   * The stores.  Without them the kernel takes 0.70 ms.  A flush of four-block windows -- 160-byte runs at 32-byte
+//     alignment, 6.4 rows per store instruction -- costs the memory side 0.64 ms for the 1.38 GB of config 3
+//     (non-temporal; 0.42 plain) against 0.26 ms as aligned 128-byte lines, and made the kernel run in two or three
+//     timing modes per process (0.81 / 0.87 / 0.94 ms).  With whole lines it is one mode.
+//   * Non-temporal stores keep the output out of L2: with plain stores the kernel moved 1.20x its algorithmic bytes
+//     (profiles/r1), now ~1.0x (profiles/r2).
+//   * The flush costs the valuer ~15 % of its time if it does it itself; a wave of its own does it for free.
+//   * Tried and dropped: a fourth wave that keeps the parser's ring filled (its requests, one block ahead, wait ~2 400
+//     clocks for HBM beside the write stream, and two blocks ahead needs a 256-byte ring per lane that LDS has no room
+//     for: +3 % at best, -5 % with the flusher beside it); touching the stream a line ahead (-3 %); s_setprio by
+//     dispatch order (the SQ issues oldest-first and the last groups run 20 % longer than the first, but handing
+//     the priority to them only moves the tail to the first groups).
 #pragma once
 #include "x3_decode_kernel.h"
 
 #define X3S_BL 20u             // block length served by this kernel
 #define X3S_PAIRS 10u
-#ifndef X3S_WBLK
-#define X3S_WBLK 4u            // blocks staged per lane between flushes (a power of two)
-#endif
-#define X3S_WIN (X3S_BL * X3S_WBLK)   // samples per staging window
-#define X3S_WPIECES (X3S_WIN / 8u)     // 16-byte pieces per row and window
-#define X3S_OUT_STRIDE (X3S_WIN / 2u + 4u)  // dwords per staging row: 16-byte aligned rows, spread over the banks
+#define X3S_RING_DW 64u        // staging ring per row: 64 dwords = two 128-byte lines of the destination
 #ifndef X3S_PERIOD
 #define X3S_PERIOD 2u         // the ring is topped up every X3S_PERIOD blocks (1 or 2)
 #endif
@@ -49,6 +54,7 @@
 #define X3S_AHEAD 3u          // 16-byte chunks per lane requested one service ahead (of up to 6 per service)
 #endif
 #define X3S_XROWS 11u          // transfer rows per block buffer: 10 pair dwords + the header word
+#define X3S_WAVES 3u            // parser, valuer, flusher
 
 // halfword index of sample j (0..19) of a block in its transfer buffer: pair j/2 is dword (j/2 & 1) of the
 // 8-byte slot of this lane in row j/4
@@ -56,10 +62,10 @@ __device__ __forceinline__ uint32_t x3s_half_index(uint32_t j, uint32_t lane) {
   return 2u * (((j >> 2) * 64u + lane) * 2u + ((j >> 1) & 1u)) + (j & 1u);
 }
 
-// LDS barrier of the two waves: LDS operations retired, nothing else waited for
+// LDS barrier of the group's waves: LDS operations retired, nothing else waited for
 #define X3S_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(64 * X3S_WAVES)
 x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uint64_t* __restrict__ frame_off,
                        uint64_t n_frames, X3Geom g, const uint64_t* __restrict__ wav_off, X3DevParams p,
                        int16_t* __restrict__ wav, uint64_t wav_cap, int32_t* __restrict__ status,
@@ -69,14 +75,14 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   // the window decrements with one v_lshl_add_u32.  (Lanes are at different places in their rows, so the aligned
   // rows do not line the reads up on one bank.)
   __shared__ __attribute__((aligned(128))) uint32_t ring[64 * X3_DEC_RING_DW];
-  __shared__ __attribute__((aligned(16))) uint32_t outs[64 * X3S_OUT_STRIDE];
+  __shared__ __attribute__((aligned(256))) uint32_t outs[64 * X3S_RING_DW];
   __shared__ __attribute__((aligned(16))) uint32_t xfer[2 * X3S_XROWS * 64];
-  __shared__ unsigned long long s_wo[64];
-  __shared__ uint32_t s_ns[64];
   __shared__ uint32_t s_over[64];  // parser -> valuer: the frame was read beyond its payload (x3_decode_replay.h)
+  __shared__ uint32_t s_dead[64];  // valuer -> flusher: the frame failed, no more stores for it
 
   const uint32_t lane = threadIdx.x & 63u;
   const bool parser = threadIdx.x < 64u;
+  const bool flusher = (threadIdx.x >> 6) == 2u;
   const uint64_t f = (uint64_t)blockIdx.x * 64 + lane;
 #ifdef X3_DBG_STAMPS
   unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -95,7 +101,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
                                (x3_len + (reinterpret_cast<uintptr_t>(x3) & 3u) + 3) >> 2,
                                x3_len + (reinterpret_cast<uintptr_t>(x3) & 3u),
                                frame_off[f] + (reinterpret_cast<uintptr_t>(x3) & 3u), plen, samples, pcrc_unused);
-    if (!parser) {
+    if ((threadIdx.x >> 6) == 1u) {
       meta[f].payload_len = plen;
       meta[f].samples = samples;
     }
@@ -125,51 +131,165 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   const uint32_t nblk_max = __builtin_amdgcn_readfirstlane(x3_wave_max_u32(nblk));
   uint32_t remaining = samples ? samples - 1u : 0u;
 
+  // ---- the input ring of this lane's frame (the parser fills and reads it)
+  uint32_t* const row = ring + lane * X3_DEC_RING_DW;
+  const uint32_t row_base = (uint32_t)(uintptr_t)row;  // LDS byte address of the row (low 7 bits zero)
+  // words are parked BIG-ENDIAN
+  const uint32_t adj = (uint32_t)(reinterpret_cast<uintptr_t>(x3) & 15u);
+  // offsets are relative to this lane's first 16-byte chunk (a frame is < 64 KB): a 64-bit pointer per lane,
+  // 32-bit arithmetic on everything else, streams of any length
+  const uint64_t abs_bits = (uint64_t)adj + p0 + 2u;
+  const uint8_t* __restrict__ const x3b = (x3 - adj) + (abs_bits & ~15ull);
+  const uint32_t v_bits = (uint32_t)(abs_bits & 15u);      // first block header
+  const uint32_t v_end = v_bits - 2u + plen;                 // end of the payload
+  const uint32_t v_last = (v_end - 1u) & ~15u;               // last 16-byte chunk that holds payload
+  uint32_t v_next = 0;
+  uint32_t wr_abs = 0;
+  constexpr uint32_t SVC_MAX = 3u * X3S_PERIOD;  // chunks a service can park per lane
+  constexpr uint32_t SVC_AHEAD = X3S_AHEAD;      // of which requested one service ahead
+  auto request = [&](uint32_t v) -> uint4 {
+    const uint32_t a = v < v_last ? v : v_last;
+    return *reinterpret_cast<const uint4*>(x3b + a);
+  };
+  // Bytes behind the end of the payload are parked as they come (the next frame's header): a frame that READS
+  // beyond its payload is flagged (s_over) and decoded again by the reference's reader, which knows about the
+  // zeros there (x3_decode_replay.h); no conforming frame does.
+  auto park = [&](uint4 c) {
+    const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+    // words wr_abs .. wr_abs+3 -> slots ~wr_abs & 31 downwards = the aligned 16-byte block at slot ~(wr_abs+3) & 31:
+    // byte offset (-4 * wr_abs - 16) & 112 of the 128-byte aligned row
+    x3_lds_write_b128(x3_and_or(0u - 4u * wr_abs - 16u, 112u, row_base), x3_bswap32(w[3]), x3_bswap32(w[2]),
+                      x3_bswap32(w[1]), x3_bswap32(w[0]));
+    wr_abs += 4;
+  };
+  uint4 ld[SVC_AHEAD];
+  uint32_t v_req = 0;
+  auto fill_ring = [&]() {  // the first 128 bytes, and the requests of the first service
+    uint4 c[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c[k] = request(v_next + 16u * k);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) park(c[k]);
+    v_next += 128;
+    // the ring is topped up with up to SVC_MAX chunks per service (>= what the blocks in between can consume: at
+    // most one word per pair).  SVC_AHEAD of them are requested one service ahead -- most lanes need one or two
+    // (0.53 bytes per sample), and a scattered 16-byte-per-lane load costs ~64 cycles of issue -- the others only
+    // when some lane does need them.
+#pragma unroll
+    for (int k = 0; k < (int)SVC_AHEAD; ++k) ld[k] = request(v_next + 16u * k);
+    v_req = v_next;
+  };
+  // widx = ring index of the parser's w0 (may be -1): everything in front of it is free
+  auto service = [&](uint32_t widx) {
+    const uint32_t used = wr_abs - widx;  // dwords from w0 on that the ring still needs
+    const uint32_t fit = used >= X3_DEC_RING_DW ? 0u : (X3_DEC_RING_DW - used) >> 2;
+#pragma unroll
+    for (uint32_t k = 0; k < SVC_AHEAD; ++k) {
+      if (fit > k) park(ld[k]);
+    }
+    if (__any(fit > SVC_AHEAD)) {  // a lane went through more than that since the last service (BFP / literal blocks)
+      uint4 more[SVC_MAX - SVC_AHEAD];
+#pragma unroll
+      for (uint32_t k = 0; k < SVC_MAX - SVC_AHEAD; ++k) more[k] = request(v_req + 16u * (SVC_AHEAD + k));
+#pragma unroll
+      for (uint32_t k = 0; k < SVC_MAX - SVC_AHEAD; ++k) {
+        if (fit > SVC_AHEAD + k) park(more[k]);
+      }
+    }
+    v_next += 16u * (fit > SVC_MAX ? SVC_MAX : fit);
+    v_req = v_next;
+#pragma unroll
+    for (int k = 0; k < (int)SVC_AHEAD; ++k) ld[k] = request(v_req + 16u * k);
+  };
+
+  // the usual group: 64 frames of the same size, one behind the other in wav.  Rows r, r + 4, r + 8 ... then have
+  // the same phase against the 128-byte lines (S0 a multiple of 16 samples), and a CLASS of 16 rows (r & 3 == c)
+  // completes its next line in the same block: two store instructions of eight whole lines each.
+  const uint32_t S0 = __builtin_amdgcn_readfirstlane(samples);
+  const uint64_t wo0 = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(wo >> 32)) << 32) |
+                       __builtin_amdgcn_readfirstlane((uint32_t)wo);
+  bool regular = __all(active && samples == S0 && wo == wo0 + (uint64_t)lane * S0) && (S0 & 15u) == 0;
+  const uint64_t B0 = (uint64_t)(uintptr_t)(wav + wo0);  // destination byte address of the group (16-byte aligned)
+  uint8_t* const line0 = reinterpret_cast<uint8_t*>(B0 & ~127ull);  // its first line
+  // this lane's part in the flush of class c, store i: piece `pc` of the current line of row rr[c][i]
+  const uint32_t pc = lane & 7u;
+  uint32_t f_src[4][2], f_dst[4][2];  // LDS byte address / byte offset from line0, for the row's FIRST line
+  uint32_t ph[4], nfl[4] = {0, 0, 0, 0};  // per class: dwords of the first line in front of the row; lines flushed
+#pragma unroll
+  for (uint32_t c = 0; c < 4; ++c) {
+    ph[c] = (uint32_t)(((B0 + (uint64_t)c * 2u * S0) & 127u) >> 2);
+#pragma unroll
+    for (uint32_t i = 0; i < 2; ++i) {
+      const uint32_t rr = 4u * ((lane >> 3) + 8u * i) + c;
+      const uint32_t off = (uint32_t)(B0 & 127u) + rr * 2u * S0;     // bytes from line0 to the row (< 2^32: 64 frames)
+      const uint32_t rrot = 16u * ((rr >> 2) & 15u);
+      f_dst[c][i] = (off & ~127u) + 16u * pc;
+      f_src[c][i] = x3_lds_addr(outs) + rr * (4u * X3S_RING_DW) +
+                    ((((uint32_t)B0 & ~127u) + (off & ~127u) + 16u * pc + rrot) & 255u);
+    }
+  }
+  // one line of every row of class c: line n of the row (n = 0: its first, possibly partial line), pieces
+  // [p_lo, p_hi) of it
+  auto flush_class = [&](uint32_t c, uint32_t c_src0, uint32_t c_src1, uint32_t c_dst0, uint32_t c_dst1, uint32_t n,
+                         uint32_t p_lo, uint32_t p_hi) {
+    X3_WAVE_LDS_ORDER();
+    const uint32_t flip = (n & 1u) << 7;
+    const x3_u32x4 v0 = x3_lds_read_b128(c_src0 ^ flip);
+    const x3_u32x4 v1 = x3_lds_read_b128(c_src1 ^ flip);
+    // a frame that failed is not written any further (the valuer says which)
+    const bool ok0 = s_dead[4u * (lane >> 3) + c] == 0u, ok1 = s_dead[4u * ((lane >> 3) + 8u) + c] == 0u;
+    if (pc >= p_lo && pc < p_hi) {
+      if (ok0) x3_store_stream16(line0 + (c_dst0 + 128u * n), v0);
+      if (ok1) x3_store_stream16(line0 + (c_dst1 + 128u * n), v1);
+    }
+    X3_WAVE_LDS_ORDER();
+  };
+  // every class whose rows have completed a line: k_done = dwords of each row that are staged
+#define X3S_FLUSH_CLASS(c)                                                                                       \
+  {                                                                                                              \
+    const uint32_t ld = (ph[c] + k_done) >> 5;                                                                   \
+    if (ld > nfl[c]) {                                                                                           \
+      flush_class(c, f_src[c][0], f_src[c][1], f_dst[c][0], f_dst[c][1], nfl[c], nfl[c] ? 0u : ph[c] >> 2, 8u);  \
+      nfl[c] = ld;                                                                                               \
+    }                                                                                                            \
+  }
+#define X3S_FLUSH_TAILS()                                                                                        \
+  _Pragma("unroll") for (uint32_t c = 0; c < 4; ++c) {                                                           \
+    const uint32_t tail = ((ph[c] + (S0 >> 1)) & 31u) >> 2; /* pieces of the last, partial line */               \
+    if (tail) flush_class(c, f_src[c][0], f_src[c][1], f_dst[c][0], f_dst[c][1], nfl[c], nfl[c] ? 0u : ph[c] >> 2, tail); \
+  }
+
+
+  if (flusher) {
+    // ================================================================= last wave: flusher
+    // Writes the lines that the valuer has completed in the staging rings of a regular group, one block behind it
+    // (behind barrier b the valuer's block b - 1 is staged; a line is overwritten five blocks after it was completed).
+    X3S_BARRIER();
+    uint32_t rem = S0 ? S0 - 1u : 0u, have = 0;
+    for (uint32_t b = 0; b < nblk_max; ++b) {
+      X3_STAMP(0);
+      X3S_BARRIER();
+      X3_STAMP(4);
+      if (regular && b) {
+        const uint32_t k_done = have >> 1;
+        X3S_FLUSH_CLASS(0) X3S_FLUSH_CLASS(1) X3S_FLUSH_CLASS(2) X3S_FLUSH_CLASS(3)
+      }
+      const uint32_t cnt = rem < X3S_BL ? rem : X3S_BL;
+      rem -= cnt;
+      have = 1u + X3S_BL * b + cnt - ((cnt && rem == 0u) ? 0u : 1u);  // staged once the valuer is through block b
+      X3_STAMP(1);
+    }
+    X3S_BARRIER();
+    if (regular) {
+      const uint32_t k_done = have >> 1;
+      X3S_FLUSH_CLASS(0) X3S_FLUSH_CLASS(1) X3S_FLUSH_CLASS(2) X3S_FLUSH_CLASS(3)
+      X3S_FLUSH_TAILS()
+    }
+  } else
   if (parser) {
     // ================================================================= wave 0: parser
-    uint32_t* const row = ring + lane * X3_DEC_RING_DW;
-    const uint32_t row_base = (uint32_t)(uintptr_t)row;  // LDS byte address of the row (low 7 bits zero)
-    // words are parked BIG-ENDIAN
-    const uint32_t adj = (uint32_t)(reinterpret_cast<uintptr_t>(x3) & 15u);
-    // offsets are relative to this lane's first 16-byte chunk (a frame is < 64 KB): a 64-bit pointer per lane,
-    // 32-bit arithmetic on everything else, streams of any length
-    const uint64_t abs_bits = (uint64_t)adj + p0 + 2u;
-    const uint8_t* __restrict__ const x3b = (x3 - adj) + (abs_bits & ~15ull);
-    const uint32_t v_bits = (uint32_t)(abs_bits & 15u);      // first block header
-    const uint32_t v_end = v_bits - 2u + plen;                 // end of the payload
-    const uint32_t v_last = (v_end - 1u) & ~15u;               // last 16-byte chunk that holds payload
-    uint32_t v_next = 0;
-    uint32_t wr_abs = 0;
-    auto request = [&](uint32_t v) -> uint4 {
-      const uint32_t a = v < v_last ? v : v_last;
-      return *reinterpret_cast<const uint4*>(x3b + a);
-    };
-    // `near_end`: wave-uniform, some lane of the wave may be within the chunks of this service of the end of its
-    // payload (bytes behind the payload are parked as zeros, bitreader.rs:34-48)
-    auto park = [&](uint4 c, uint32_t v, bool near_end) {
-      uint32_t w[4] = {c.x, c.y, c.z, c.w};
-      if (near_end) {
-        const int32_t left = (int32_t)(v_end - v);
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          const int32_t r = left - 4 * d;
-          w[d] = r >= 4 ? w[d] : (r <= 0 ? 0u : (w[d] & ((1u << (8u * (uint32_t)r)) - 1u)));
-        }
-      }
-      // words wr_abs .. wr_abs+3 -> slots ~wr_abs & 31 downwards = the aligned 16-byte block at slot ~(wr_abs+3) & 31:
-      // byte offset (-4 * wr_abs - 16) & 112 of the 128-byte aligned row
-      x3_lds_write_b128(x3_and_or(0u - 4u * wr_abs - 16u, 112u, row_base), x3_bswap32(w[3]), x3_bswap32(w[2]),
-                        x3_bswap32(w[1]), x3_bswap32(w[0]));
-      wr_abs += 4;
-    };
-    {
-      uint4 c[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) c[k] = request(v_next + 16u * k);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) park(c[k], v_next + 16u * k, true);
-      v_next += 128;
-    }
+    fill_ring();
+    X3S_BARRIER();  // the valuer has cleared s_dead
     // window: w0 holds `s` unconsumed bits (its low s bits), then w1; widx = ring index of w0.  A pair of
     // codewords is at most 32 bits, so one peek never reaches beyond w1; wn is the word behind w1, re-read from
     // the ring after every consume (the read has a whole pair's time to arrive before the next shift needs it)
@@ -181,14 +301,6 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     uint32_t wn = row[~(widx0 + 2u) & 31u];
     // qb = 4 * ~(widx + 2): the byte offset of wn's slot before masking; widx itself is only needed by service()
     uint32_t qb = 4u * ~(widx0 + 2u);
-    // the ring is topped up every SECOND block with up to 6 chunks (96 bytes >= the 80 bytes two blocks can
-    // consume: at most one word per pair).  Three of them are requested one service ahead -- most lanes need
-    // one or two (0.53 bytes per sample), and a scattered 16-byte-per-lane load costs ~64 cycles of issue --
-    // the other three only when some lane does need them.
-    uint4 ld[X3S_AHEAD];
-#pragma unroll
-    for (int k = 0; k < (int)X3S_AHEAD; ++k) ld[k] = request(v_next + 16u * k);
-    uint32_t v_req = v_next;
     // consume -nn (<= 32) bits, given as the NEGATIVE count (that is what the codeword walk below has at hand);
     // the word shift is v_bfi with a VGPR mask (see x3_decode_fast_kernel)
     auto consume_to = [&](int32_t s2) {  // s2 = s - bits consumed (>= -32)
@@ -206,36 +318,14 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       __builtin_amdgcn_sched_barrier(0);
     };
     auto consume_neg = [&](uint32_t nn) { consume_to((int32_t)(s + nn)); };
-    auto service = [&]() {
-      const uint32_t widx = ~((uint32_t)((int32_t)qb >> 2)) - 2u;
-      const uint32_t used = wr_abs - widx;  // dwords from w0 on that the ring still needs
-      const uint32_t fit = used >= X3_DEC_RING_DW ? 0u : (X3_DEC_RING_DW - used) >> 2;  // (widx may be -1)
-      const bool near_end = __any((int32_t)(v_end - v_req) < (int32_t)(16u * 3u * X3S_PERIOD));
-#pragma unroll
-      for (uint32_t k = 0; k < X3S_AHEAD; ++k) {
-        if (fit > k) park(ld[k], v_req + 16u * k, near_end);
-      }
-      if (__any(fit > X3S_AHEAD)) {  // a lane went through more than that in two blocks (BFP / literal blocks)
-        uint4 more[3u * X3S_PERIOD - X3S_AHEAD];
-#pragma unroll
-        for (uint32_t k = 0; k < 3u * X3S_PERIOD - X3S_AHEAD; ++k) more[k] = request(v_req + 16u * (X3S_AHEAD + k));
-#pragma unroll
-        for (uint32_t k = 0; k < 3u * X3S_PERIOD - X3S_AHEAD; ++k) {
-          if (fit > X3S_AHEAD + k) park(more[k], v_req + 16u * (X3S_AHEAD + k), near_end);
-        }
-      }
-      v_next += 16u * (fit > 3u * X3S_PERIOD ? 3u * X3S_PERIOD : fit);
-      v_req = v_next;
-#pragma unroll
-      for (int k = 0; k < (int)X3S_AHEAD; ++k) ld[k] = request(v_req + 16u * k);
-    };
+    auto ring_index = [&]() -> uint32_t { return ~((uint32_t)((int32_t)qb >> 2)) - 2u; };  // of w0
 
     const uint32_t k_tab = (p.k[1] << 16) | (p.k[2] << 24);  // log2(level) by ftype
     for (uint32_t b = 0; b < nblk_max; ++b) {
       const uint32_t cnt = remaining < X3S_BL ? remaining : X3S_BL;
       remaining -= cnt;
       X3_STAMP(0);
-      if ((b % X3S_PERIOD) == 0) service();
+      if ((b % X3S_PERIOD) == 0) service(ring_index());
       X3_STAMP(1);
       // block header: 2 bits ftype; ftype 0 -> 4 more bits E-1 (decoder.rs:138-144, 209-216)
       const uint32_t hdr = __builtin_amdgcn_alignbit(w0, w1, s) >> 26;
@@ -306,16 +396,25 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     }
     {
       // read position (bits from the ring's first chunk on) against the end of the payload
-      const int32_t widx = (int32_t)~((uint32_t)((int32_t)qb >> 2)) - 2;
+      const int32_t widx = (int32_t)ring_index();
       s_over[lane] = (32 * widx + 32 - (int32_t)s > (int32_t)(8u * v_end)) ? 1u : 0u;
     }
     X3S_BARRIER();
   } else {
     // ================================================================= wave 1: valuer
-    uint32_t* const orow = outs + lane * X3S_OUT_STRIDE;
+    // Staging: per lane (= frame = row of the output) a ring of 256 bytes that is indexed by the DESTINATION address:
+    // the sample pair that goes to byte address A of wav sits at ring byte (A + rot) & 255, rot a per-lane rotation
+    // (a multiple of 16 bytes) that spreads the rows over the LDS banks.  A 128-byte line of HBM is then 128
+    // contiguous bytes of the ring, and what leaves the CU are whole, aligned lines: 8 lanes x 16 bytes per line,
+    // 8 lines per store instruction.  (Why: the memory side retires a store instruction of eight aligned lines in
+    // ~60 % less time than one of 6.4 runs of 160 bytes at 32-byte alignment, which is what windows of four blocks
+    // gave -- tools/ubench/store_rate.hip: 0.26 against 0.64 ms for this kernel's 1.38 GB -- and with the runs the
+    // stores, not the arithmetic, set this kernel's time and its two timing modes.)
+    uint32_t* const orow = outs + lane * X3S_RING_DW;
+    const uint32_t orow_b = x3_lds_addr(orow);  // LDS byte address of the row (256-byte aligned)
     int16_t* __restrict__ const o = wav + wo;
-    s_wo[lane] = wo;
-    s_ns[lane] = samples;
+    const uint32_t rot = 16u * ((lane >> 2) & 15u);
+    const uint32_t pos0 = ((uint32_t)(uintptr_t)o + rot) & 255u;  // ring byte of sample 0 (a multiple of 16)
     bool alive = active;
     uint32_t prevP = 0;  // the previous pair; its high half is the last sample so far (pending: even index)
     if (active) {
@@ -323,48 +422,29 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       prevP = first << 16;
       if (samples == 1u) o[0] = (int16_t)first;
     }
-    // the usual group: 64 frames of the same size, one behind the other in wav
-    const uint32_t S0 = __builtin_amdgcn_readfirstlane(samples);
-    const uint64_t wo0 = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(wo >> 32)) << 32) |
-                         __builtin_amdgcn_readfirstlane((uint32_t)wo);
-    bool regular = __all(active && samples == S0 && wo == wo0 + (uint64_t)lane * S0) && (S0 & 7u) == 0;
-    uint32_t wbase = 0;  // first sample index of the staging window (a multiple of X3S_WIN)
-    X3_WAVE_LDS_ORDER();
-
-    // window [wbase, wbase + X3S_WIN): X3S_WPIECES pieces of 16 bytes per row, as many per lane.
-    // Which pieces a lane moves never changes: piece t = 64*it + lane of row r = t / 10.  For the regular
-    // group the LDS offset and the offset in wav (relative to the window) are computed once.
-    uint32_t f_src[X3S_WPIECES], f_dst[X3S_WPIECES];
-#pragma unroll
-    for (uint32_t it = 0; it < X3S_WPIECES; ++it) {
-      const uint32_t t = it * 64u + lane;
-      const uint32_t r = t / X3S_WPIECES, q = t - r * X3S_WPIECES;
-      f_src[it] = r * X3S_OUT_STRIDE + 4u * q;   // dwords into outs
-      f_dst[it] = r * S0 + 8u * q;               // samples behind wav + wo0 + wbase (< 2^32: 64 frames)
-    }
-    auto flush = [&]() {
+    // any other group (ragged sizes, a frame that failed, offsets from a frame index): every lane moves the finished
+    // 16-byte pieces of its own row -- slow, and rare
+    uint32_t my_fl = 0;  // 16-byte pieces of this lane's row that are in wav
+    auto flush_own = [&](uint32_t upto_samples) {  // pieces below upto_samples / 8
       X3_WAVE_LDS_ORDER();
-      if (regular && wbase + X3S_WIN <= S0) {
-        int16_t* const base = wav + wo0 + wbase;
-#pragma unroll
-        for (uint32_t it = 0; it < X3S_WPIECES; ++it)
-          x3_store_stream16(base + f_dst[it], *reinterpret_cast<const x3_u32x4*>(outs + f_src[it]));
-      } else {
-#pragma unroll 2
-        for (uint32_t it = 0; it < X3S_WPIECES; ++it) {
-          const uint32_t t = it * 64u + lane;
-          const uint32_t r = t / X3S_WPIECES, q = t - r * X3S_WPIECES;
-          const uint32_t ns = s_ns[r];
-          if (wbase + 8u * q + 8u <= ns)
-            x3_store_stream16(wav + s_wo[r] + wbase + 8u * q,
-                              *reinterpret_cast<const x3_u32x4*>(outs + r * X3S_OUT_STRIDE + 4u * q));
+      const uint32_t done = alive ? upto_samples >> 3 : my_fl;
+#pragma unroll 1
+      while (__any(my_fl < done)) {
+        if (my_fl < done) {
+          const x3_u32x4 v = x3_lds_read_b128(orow_b + ((pos0 + 16u * my_fl) & 255u));
+          x3_store_stream16(o + 8u * my_fl, v);
+          ++my_fl;
         }
       }
       X3_WAVE_LDS_ORDER();
     };
+    s_dead[lane] = 0u;
+    X3_WAVE_LDS_ORDER();
+    X3S_BARRIER();  // (s_dead is cleared)
 
     const uint32_t bound_tab = (p.inv_len[0] << 8) | (p.inv_len[1] << 16) | (p.inv_len[2] << 24);  // by ftype (< 256)
-    for (uint32_t b = 0; b < nblk_max; ++b) {
+    uint32_t posb = pos0;  // ring byte of the block's first pair, unmasked
+    for (uint32_t b = 0; b < nblk_max; ++b, posb += 2u * X3S_BL) {
       X3_STAMP(0);
       X3S_BARRIER();
       X3_STAMP(4);
@@ -388,7 +468,6 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       const uint32_t tm12 = ((neg_thresh - 1u) & 0xFFFFu) * 0x10001u;  // thresh - 1 in each half
       const uint32_t neg22 = (neg2 & 0xFFFFu) * 0x10001u;              // 2 * thresh = 2^E (0 for a literal block)
       uint32_t maxii2 = 0;
-      uint32_t* const dst = orow + X3S_PAIRS * (b & (X3S_WBLK - 1u));
       X3_STAMP(2);
 
       if (__all(cnt == X3S_BL || cnt == 0u)) {
@@ -417,14 +496,13 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
             W[e] = __builtin_amdgcn_alignbit(P, prevP, 16);                // (pending sample, la)
             prevP = P;
           }
-          *reinterpret_cast<uint2*>(dst + 2u * r) = make_uint2(W[0], W[1]);
+          // samples 20 b + 4 r .. + 3: eight bytes of the ring (positions are multiples of 8: no wrap inside)
+          x3_lds_write_b64(x3_and_or(posb + 8u * r, 248u, orow_b), W[0], W[1]);
         }
       } else {
         // short block somewhere in the group: one sample at a time, staged as halfwords
         const uint16_t* const h = reinterpret_cast<const uint16_t*>(buf);
-        uint16_t* const oh = reinterpret_cast<uint16_t*>(orow);
-        const uint32_t idx0 = 1u + X3S_BL * b - wbase;  // window-relative index of the block's first sample
-        if (cnt) oh[idx0 - 1u] = (uint16_t)(prevP >> 16);
+        if (cnt) x3_lds_write_u16(x3_and_or(posb, 254u, orow_b), prevP >> 16);
         uint32_t last = prevP >> 16, maxii = 0;
         for (uint32_t j = 0; j < X3S_BL; ++j) {
           if (j < cnt) {
@@ -435,7 +513,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
             const uint32_t d = bfp ? d_bfp : d_rice;
             last = litmask ? x : ((last + d) & 0xFFFFu);
             maxii = bfp ? maxii : (ii > maxii ? ii : maxii);
-            oh[idx0 + j] = (uint16_t)last;
+            x3_lds_write_u16(x3_and_or(posb + 2u * (j + 1u), 254u, orow_b), last);
           }
         }
         maxii2 = maxii;
@@ -447,26 +525,21 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
         st = X3D_OUT_OF_BOUNDS_INVERSE;
         alive = false;
       }
-      if (__any(active && !alive)) {  // a frame of the group failed: no more stores for it
-        regular = false;
-        if (!alive) s_ns[lane] = 0;
-      }
-      if (cnt && remaining == 0 && alive) {
-        // this lane's frame is complete: the flush stores only 16-byte pieces that lie inside the frame
-        if (samples & 1u) orow[(samples - 1u - wbase) >> 1] = prevP >> 16;
-        const uint32_t done = samples & ~7u;
-        const uint32_t from = done > wbase ? done : wbase;
-        const uint16_t* h = reinterpret_cast<const uint16_t*>(orow);
-        for (uint32_t sx = from; sx < samples; ++sx) o[sx] = (int16_t)h[sx - wbase];
-      }
+      const bool finished = cnt && remaining == 0;  // this lane's frame is complete
+      if (finished && alive && (samples & 1u))      // its last sample is a pending one: stage it
+        x3_lds_write_u16(x3_and_or(pos0 + 2u * (samples - 1u), 254u, orow_b), prevP >> 16);
       X3_STAMP(1);
-      if ((b & (X3S_WBLK - 1u)) == X3S_WBLK - 1u) {
-        flush();
-        wbase += X3S_WIN;
-        X3_STAMP(5);
+      if (regular && !alive) s_dead[lane] = 1u;  // (visible to the flusher behind the next barrier)
+      const uint32_t have = 1u + X3S_BL * b + cnt - ((finished || samples == 0u) ? 0u : 1u);  // samples staged so far
+      if (regular) {
+      } else {
+        flush_own(samples ? (have < samples ? have : samples) : 0u);
+        if (finished && alive)  // the ragged end of the frame: fewer than eight samples
+          for (uint32_t sx = samples & ~7u; sx < samples; ++sx)
+            o[sx] = (int16_t)x3_lds_read_u16(x3_and_or(pos0 + 2u * sx, 254u, orow_b), 0u);
       }
+      X3_STAMP(5);
     }
-    if (nblk_max & (X3S_WBLK - 1u)) flush();
     X3S_BARRIER();
     if (active && (st == X3D_OUT_OF_BOUNDS_INVERSE || st == X3D_FRAME_DECODE_INVALID_BPF || s_over[lane]))
       st = X3D_REPLAY;  // the reference's reader decides (x3_decode_replay.h; x3_decode_merge_kernel)
@@ -483,6 +556,6 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     if (parser) dbg_acc[5] = where; else dbg_acc[6] = where;
   }
   if (lane == 0 && blockIdx.x < 2048)
-    for (int k = 0; k < 8; ++k) x3_dbg[(blockIdx.x * 2 + (parser ? 0 : 1)) * 8 + k] = dbg_acc[k];
+    for (int k = 0; k < 8; ++k) x3_dbg[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + k] = dbg_acc[k];
 #endif
 }

@@ -209,6 +209,17 @@ __device__ __forceinline__ void x3_lds_write_b128(uint32_t addr, uint32_t a, uin
   x3_u32x4 v = {a, b, c, d};
   *reinterpret_cast<__attribute__((address_space(3))) x3_u32x4*>(addr) = v;
 }
+__device__ __forceinline__ x3_u32x4 x3_lds_read_b128(uint32_t addr) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) x3_u32x4*>(addr);
+}
+typedef uint32_t x3_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void x3_lds_write_b64(uint32_t addr, uint32_t a, uint32_t b) {
+  x3_u32x2 v = {a, b};
+  *reinterpret_cast<__attribute__((address_space(3))) x3_u32x2*>(addr) = v;
+}
+__device__ __forceinline__ void x3_lds_write_u16(uint32_t addr, uint32_t v) {
+  *reinterpret_cast<__attribute__((address_space(3))) uint16_t*>(addr) = (uint16_t)v;
+}
 // sixteen bytes to global memory as a streaming (non-temporal) store: output that is written once and not read
 // again by this kernel must not displace what the kernel is still reading from L2
 __device__ __forceinline__ void x3_store_stream16(void* p, x3_u32x4 v) {
