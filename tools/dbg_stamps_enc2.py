@@ -33,3 +33,12 @@ for w in range(8):
     print("%4d  " % w + "  ".join("%15.0f" % row[k] for k in range(8)) + "  %10.0f" % row.sum())
 tot = a.sum(axis=2).mean(axis=1)
 print("frame time per workgroup percentiles 0/25/50/75/100:", np.percentile(tot, [0, 25, 50, 75, 100]).round(0))
+# who waits least (the stragglers that everybody else waits for)?
+w = (a[:, :, 3] + a[:, :, 4]).min(axis=1)       # per workgroup: the wave that spent least in loads+settle+wait B3
+busy = a.sum(axis=2).mean(axis=1) - (a[:, :, 3] + a[:, :, 4]).mean(axis=1)
+print("loads+settle+wait-B3 per workgroup (least-waiting wave), percentiles 0/5/25/50/75/100:", np.percentile(w, [0, 5, 25, 50, 75, 100]).round(0))
+print("busy time outside of it, percentiles 0/25/50/75/95/100:", np.percentile(busy, [0, 25, 50, 75, 95, 100]).round(0))
+order = np.argsort(w)[:16]
+print("least-waiting workgroups (blockIdx: wait, busy):", [(int(i), int(w[i]), int(busy[i])) for i in order])
+for lo in range(0, NW, 100):
+    print("  blockIdx %3d..%3d: wait %.0f busy %.0f" % (lo, lo + 99, w[lo:lo + 100].mean(), busy[lo:lo + 100].mean()))

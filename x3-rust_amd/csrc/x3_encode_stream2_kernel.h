@@ -341,6 +341,10 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
     X3_STAMP(0);
     __syncthreads();  // B1: bit-length partials ready
     X3_STAMP(1);
+    // the sizes in front of the PREVIOUS frame, due behind this frame's emission: asked for as late as their latency
+    // allows -- the other workgroups publish theirs behind their B1, and a word that is read before it is written
+    // costs a poll (asked for a whole iteration ahead, 45 % of the frames found a size missing; tools/dbg_stamps_enc2.py)
+    if (have_prev) desc_load2(prev_f, q0, q1);
     uint32_t wave_base = 0, total = 0;
     {
       const uint4 a = reinterpret_cast<const uint4*>(part)[0], c = reinterpret_cast<const uint4*>(part)[1];
@@ -522,16 +526,17 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
       const uint4 zero = make_uint4(0, 0, 0, 0);
       for (uint32_t i = tid; i < nz; i += nthr) z4[i] = zero;
     }
-    // the sizes in front of THIS frame: due at the end of the next iteration's emission
     prev_f = f;
     prev_bytes = frame_bytes;
     have_prev = true;
-    desc_load2(prev_f, q0, q1);
     cur ^= 1u;
     X3_STAMP(0);
   }
   // ---- the workgroup's last frame
-  if (have_prev) settle();
+  if (have_prev) {
+    desc_load2(prev_f, q0, q1);
+    settle();
+  }
   __syncthreads();  // its size sums, its header
   if (have_prev) {
     const uint64_t off = resolve();
