@@ -81,6 +81,8 @@ struct x3_ctx {
   unsigned long long* d_stats = nullptr;    // 6
   unsigned long long* d_end_pos = nullptr;  // 1
   X3DecodeSummary* d_summary = nullptr;
+  uint32_t* d_pace = nullptr;          // x3_decode_split_kernel's pace word (see there), dec_epoch its launch count
+  uint32_t dec_epoch = 1;
   uint16_t* d_crc = nullptr;
   // pinned mirrors
   int* h_status = nullptr;
@@ -213,6 +215,8 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
   c->d_stats = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->d_status) + 32);
   c->d_end_pos = c->d_stats + 6;
   HIPCHK(c, hipMalloc(&c->d_summary, sizeof(X3DecodeSummary)));
+  HIPCHK(c, hipMalloc(&c->d_pace, 64));
+  HIPCHK(c, hipMemset(c->d_pace, 0, 64));
   HIPCHK(c, hipMalloc(&c->d_crc, 16));
   HIPCHK(c, hipHostMalloc(&c->h_status, 128));
   c->h_stats = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_status) + 32);
@@ -370,6 +374,7 @@ extern "C" void x3_ctx_destroy(x3_ctx* c) {
   (void)hipFree(c->d_xinv8);
   (void)hipFree(c->d_status);
   (void)hipFree(c->d_summary);
+  (void)hipFree(c->d_pace);
   (void)hipFree(c->d_crc);
   (void)hipHostFree(c->h_status);
   (void)hipHostFree(c->h_summary);
@@ -1125,10 +1130,18 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
     const size_t dyn_lds = 0;
 #endif
     TimerScope ts(c, 1);
-    if (split)
+    if (split) {
+      // the pace word's 12-bit epoch: launches 1, 2, ... 4095, then the word starts over
+      if ((c->dec_epoch & 0xFFFu) == 0u) {
+        HIPCHK(c, hipMemsetAsync(c->d_pace, 0, 4, c->stream));
+        ++c->dec_epoch;
+      }
       hipLaunchKernelGGL(x3_decode_split_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64 * X3S_WAVES),
                          dyn_lds, c->stream, d_x3, x3_len,
-                         d_frame_offsets, F, g, d_wav_offsets, dp, d_wav, wav_cap, d_status, (X3FrameMeta*)c->dec_meta.p);
+                         d_frame_offsets, F, g, d_wav_offsets, dp, d_wav, wav_cap, d_status, (X3FrameMeta*)c->dec_meta.p,
+                         c->d_pace, c->dec_epoch & 0xFFFu);
+      ++c->dec_epoch;
+    }
     else if (fast)
       hipLaunchKernelGGL(x3_decode_fast_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, c->stream, d_x3, x3_len,
                          d_frame_offsets, F, g, d_wav_offsets, dp, d_wav, wav_cap, d_status,

@@ -62,6 +62,26 @@ __device__ __forceinline__ uint32_t x3s_half_index(uint32_t j, uint32_t lane) {
   return 2u * (((j >> 2) * 64u + lane) * 2u + ((j >> 1) & 1u)) + (j & 1u);
 }
 
+// Pacing.  The SQ issues oldest-first, so the groups dispatched first run ahead of the ones dispatched last (group
+// lifetimes 555 / 650 / 680 / 740 us by quartile of blockIdx) and the kernel ends with the stragglers, 20 % behind
+// the mean.  Every 8 blocks a wave compares its block index with where the clock says it should be and sets its own
+// priority: ahead -> lower, behind -> higher.  The groups then finish within 3 % of each other: 0.76 -> 0.65 ms.
+// The target pace comes from the launch before: every group leaves (clock ticks per 16 blocks) in `pace` by
+// atomicMax, tagged with the launch's epoch; the next launch aims 7 % below the slowest group's.  A target that does
+// not fit (first launch of a context, other data) pins all waves at one priority: the unpaced kernel, nothing worse.
+#define X3S_PACE_BAND 6            // blocks ahead / behind that move a wave one priority level
+#define X3S_PACE_DEFAULT 2000u     // 10 ns ticks per 16 blocks when there is no launch to go by (1.25 us per block)
+#define X3S_PACE_EPOCH_SHIFT 20u   // pace word: epoch << 20 | ticks per 16 blocks
+#define X3S_PACE_STEP(b)                                                                       \
+  if (((b) & 7u) == 0u) {                                                                      \
+    const uint32_t el = (uint32_t)(wall_clock64() - pace_t0); /* 10 ns ticks */                \
+    const int32_t d = (int32_t)(b) - (int32_t)((el * pace_inv) >> 16);                         \
+    if (d > 2 * X3S_PACE_BAND) __builtin_amdgcn_s_setprio(0);                                  \
+    else if (d > 0) __builtin_amdgcn_s_setprio(1);                                             \
+    else if (d > -2 * X3S_PACE_BAND) __builtin_amdgcn_s_setprio(2);                            \
+    else __builtin_amdgcn_s_setprio(3);                                                        \
+  }
+
 // LDS barrier of the group's waves: LDS operations retired, nothing else waited for
 #define X3S_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -69,7 +89,7 @@ __global__ void __launch_bounds__(64 * X3S_WAVES)
 x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uint64_t* __restrict__ frame_off,
                        uint64_t n_frames, X3Geom g, const uint64_t* __restrict__ wav_off, X3DevParams p,
                        int16_t* __restrict__ wav, uint64_t wav_cap, int32_t* __restrict__ status,
-                       X3FrameMeta* __restrict__ meta) {
+                       X3FrameMeta* __restrict__ meta, uint32_t* __restrict__ pace, uint32_t pace_epoch) {
   // input ring, 32 dwords per lane in rows of exactly 128 bytes at 128-byte aligned addresses, stream word j in
   // slot ~j & 31 (descending): the address of a word is then ONE v_and_or_b32 on a byte counter that a shift of
   // the window decrements with one v_lshl_add_u32.  (Lanes are at different places in their rows, so the aligned
@@ -84,6 +104,15 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   const bool parser = threadIdx.x < 64u;
   const bool flusher = (threadIdx.x >> 6) == 2u;
   const uint64_t f = (uint64_t)blockIdx.x * 64 + lane;
+  const unsigned long long pace_t0 = wall_clock64();
+  uint32_t pace_inv;  // blocks per tick, 16.16 fixed point
+  {
+    const uint32_t w = __builtin_amdgcn_readfirstlane(*pace);
+    uint32_t ticks16 = (w >> X3S_PACE_EPOCH_SHIFT) == ((pace_epoch - 1u) & 0xFFFu) ? (w & ((1u << X3S_PACE_EPOCH_SHIFT) - 1u)) : 0u;
+    ticks16 = ticks16 ? ticks16 - ticks16 / 14u : X3S_PACE_DEFAULT;  // 7 % below the slowest group of the last launch
+    if (ticks16 < 64u) ticks16 = 64u;
+    pace_inv = (16u << 16) / ticks16;
+  }
 #ifdef X3_DBG_STAMPS
   unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long dbg_t = clock64();
@@ -267,6 +296,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     X3S_BARRIER();
     uint32_t rem = S0 ? S0 - 1u : 0u, have = 0;
     for (uint32_t b = 0; b < nblk_max; ++b) {
+      X3S_PACE_STEP(b)
       X3_STAMP(0);
       X3S_BARRIER();
       X3_STAMP(4);
@@ -322,6 +352,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
 
     const uint32_t k_tab = (p.k[1] << 16) | (p.k[2] << 24);  // log2(level) by ftype
     for (uint32_t b = 0; b < nblk_max; ++b) {
+      X3S_PACE_STEP(b)
       const uint32_t cnt = remaining < X3S_BL ? remaining : X3S_BL;
       remaining -= cnt;
       X3_STAMP(0);
@@ -445,6 +476,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     const uint32_t bound_tab = (p.inv_len[0] << 8) | (p.inv_len[1] << 16) | (p.inv_len[2] << 24);  // by ftype (< 256)
     uint32_t posb = pos0;  // ring byte of the block's first pair, unmasked
     for (uint32_t b = 0; b < nblk_max; ++b, posb += 2u * X3S_BL) {
+      X3S_PACE_STEP(b)
       X3_STAMP(0);
       X3S_BARRIER();
       X3_STAMP(4);
@@ -544,6 +576,11 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     if (active && (st == X3D_OUT_OF_BOUNDS_INVERSE || st == X3D_FRAME_DECODE_INVALID_BPF || s_over[lane]))
       st = X3D_REPLAY;  // the reference's reader decides (x3_decode_replay.h; x3_decode_merge_kernel)
     if (f < n_frames) status[f] = st;
+    if (lane == 0 && nblk_max >= 64u) {  // this group's pace, for the next launch
+      uint64_t t16 = ((wall_clock64() - pace_t0) * 16u) / nblk_max;
+      if (t16 >= (1u << X3S_PACE_EPOCH_SHIFT)) t16 = (1u << X3S_PACE_EPOCH_SHIFT) - 1u;
+      atomicMax(pace, ((pace_epoch & 0xFFFu) << X3S_PACE_EPOCH_SHIFT) | (uint32_t)t16);
+    }
   }
 #ifdef X3_DBG_STAMPS
   dbg_acc[6] = dbg_start;          // constant-rate clock: which groups were resident together
