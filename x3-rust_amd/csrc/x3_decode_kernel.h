@@ -93,7 +93,10 @@ __device__ __forceinline__ int32_t x3_frame_header_check(const uint32_t* __restr
 // LDS tables of x3_frame_check_kernel (uint16): T[s][k][v] = v * x^(8k + 16) * x^(2048 s), s, k = 0..3 -- the
 // contribution of the byte that k bytes follow in its dword, in a dword that s rows of 64 dwords follow --, then
 // the two rows of "times x^8192" (for v << 8 and for v)
-#define X3_CHECK_TAB_U16 (18u * 256u)
+#ifndef X3_CHECK_GROUP
+#define X3_CHECK_GROUP 4u  // rows per group: 4 G + 2 tables of 512 bytes (G = 2, 5 KB, to fit beside five decoder groups: no faster)
+#endif
+#define X3_CHECK_TAB_U16 ((4u * X3_CHECK_GROUP + 2u) * 256u)
 #define X3_CHECK_TAB_DW (X3_CHECK_TAB_U16 / 2u)
 #define X3_CHECK_XINV_N 1024u  // x^(-8k), k < 1024: undoes the zero bytes the row grid adds behind a payload
 
@@ -236,22 +239,22 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
             }
           }
 #pragma unroll
-          for (uint32_t g4 = 0; g4 < X3_CHECK_AHEAD; g4 += 4) {
+          for (uint32_t g4 = 0; g4 < X3_CHECK_AHEAD; g4 += X3_CHECK_GROUP) {
             if (rbase + g4 < R) {  // (whole wave)
-              if (rbase + g4)      // partial sum so far: four rows further from the end
-                acc = x3_lds_read_u16(tab_base + ((acc >> 8) << 1), 16u * 512u) ^
-                      x3_lds_read_u16(tab_base + ((acc & 0xFFu) << 1), 17u * 512u);
+              if (rbase + g4)      // partial sum so far: a group of rows further from the end
+                acc = x3_lds_read_u16(tab_base + ((acc >> 8) << 1), 4u * X3_CHECK_GROUP * 512u) ^
+                      x3_lds_read_u16(tab_base + ((acc & 0xFFu) << 1), (4u * X3_CHECK_GROUP + 1u) * 512u);
 #pragma unroll
-              for (uint32_t q = 0; q < 4; ++q) {
+              for (uint32_t q = 0; q < X3_CHECK_GROUP; ++q) {
                 const uint32_t row = rbase + g4 + q;
                 uint32_t be = x3_bswap32(pd[g4 + q]);
                 if (g4 + q == 0) {
                   if (rbase == 0) be = (be & and0) ^ xor0;
                 }
                 if (row + 1u >= R) be &= row + 1u == R ? last_mask : 0u;  // (whole wave)
-                acc ^= rowsum(be, 3u - q);
+                acc ^= rowsum(be, X3_CHECK_GROUP - 1u - q);
               }
-              rows_done = rbase + g4 + 4u;
+              rows_done = rbase + g4 + X3_CHECK_GROUP;
             }
           }
         }
