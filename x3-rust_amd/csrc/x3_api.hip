@@ -1164,7 +1164,7 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
     *c->h_summary_init = init;
     HIPCHK(c, hipMemcpyAsync(c->d_summary, c->h_summary_init, sizeof init, hipMemcpyHostToDevice, c->stream));
   }
-  hipLaunchKernelGGL(x3_decode_merge_kernel, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, c->stream,
+  hipLaunchKernelGGL(x3_decode_merge_kernel, dim3((unsigned)std::min<uint64_t>((F + 255) / 256, 64)), dim3(256), 0, c->stream,
                      (const int32_t*)c->dec_cstatus.p, d_status, (const X3FrameMeta*)c->dec_meta.p, F, c->d_summary,
                      d_x3, d_frame_offsets, g, d_wav_offsets, dp, d_wav);
   c->dec_status_ptr = d_status;
