@@ -802,6 +802,7 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
       if ((rc = ensure(c, c->desc, desc_bytes))) return rc;
       if (fresh || ++c->desc_epoch > 0xFFFu) {
         HIPCHK(c, hipMemsetAsync(c->desc.p, 0, c->desc.cap, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_pace + 1, 0, 4, c->stream));  // (the encoder's pace word carries the same epoch)
         c->desc_epoch = 1;
       }
       {
@@ -809,7 +810,7 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
         hipLaunchKernelGGL(x3_encode_stream2_kernel, dim3((unsigned)grid), dim3(X3_STREAM2_THREADS), smem2, c->stream,
                            d_wav, pl.g, pl.dp, d_off, d_out, out_cap, start_pos, (uint32_t*)c->desc.p + desc_pad, c->desc_epoch,
                            reinterpret_cast<unsigned char*>(c->d_status), (const uint32_t*)c->d_xk2,
-                           (const uint16_t*)c->d_crctab, pl.img_dwords);
+                           (const uint16_t*)c->d_crctab, pl.img_dwords, c->d_pace + 1);
       }
       HIPCHK(c, hipGetLastError());
       c->encode_pending = true;
@@ -856,6 +857,7 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
       if ((rc = ensure(c, c->desc, desc_bytes))) return rc;
       if (fresh || ++c->desc_epoch > 0xFFFu) {
         HIPCHK(c, hipMemsetAsync(c->desc.p, 0, c->desc.cap, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_pace + 1, 0, 4, c->stream));
         c->desc_epoch = 1;
       }
       {

@@ -803,8 +803,10 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
   int32_t carry = 0;
   // the usual wave: 64 frames of the same size, one behind the other in wav, size a multiple of 8 samples
   const uint32_t S0 = __builtin_amdgcn_readfirstlane(samples);
-  const uint64_t wo0 = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(wo >> 32)) << 32) |
-                       __builtin_amdgcn_readfirstlane((uint32_t)wo);
+  // (the builtin returns int: without the casts a low word with bit 31 set sign-extends over the high one, and every
+  // group whose sample offset has that bit stops being "regular" -- half of all groups beyond 2^31 samples)
+  const uint64_t wo0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(wo >> 32)) << 32) |
+                       (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)wo);
   const bool regular = __all(coop && samples == S0 && wo == wo0 + (uint64_t)lane * S0) && (S0 & 7u) == 0;
   auto flush = [&](uint32_t upto) {
     // the < 8 samples behind the last full 16-byte piece of a frame that ends inside this window: stored by the

@@ -69,11 +69,14 @@ __device__ __forceinline__ uint32_t x3s_half_index(uint32_t j, uint32_t lane) {
 // The target pace comes from the launch before: every group leaves (clock ticks per 16 blocks) in `pace` by
 // atomicMax, tagged with the launch's epoch; the next launch aims 7 % below the slowest group's.  A target that does
 // not fit (first launch of a context, other data) pins all waves at one priority: the unpaced kernel, nothing worse.
+#ifndef X3S_PACE_OFF
+#define X3S_PACE_OFF 0
+#endif
 #define X3S_PACE_BAND 6            // blocks ahead / behind that move a wave one priority level
 #define X3S_PACE_DEFAULT 2000u     // 10 ns ticks per 16 blocks when there is no launch to go by (1.25 us per block)
 #define X3S_PACE_EPOCH_SHIFT 20u   // pace word: epoch << 20 | ticks per 16 blocks
 #define X3S_PACE_STEP(b)                                                                       \
-  if (((b) & 7u) == 0u) {                                                                      \
+  if (!X3S_PACE_OFF && ((b) & 7u) == 0u) {                                                                      \
     const uint32_t el = (uint32_t)(wall_clock64() - pace_t0); /* 10 ns ticks */                \
     const int32_t d = (int32_t)(b) - (int32_t)((el * pace_inv) >> 16);                         \
     if (d > 2 * X3S_PACE_BAND) __builtin_amdgcn_s_setprio(0);                                  \
@@ -235,8 +238,10 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   // the same phase against the 128-byte lines (S0 a multiple of 16 samples), and a CLASS of 16 rows (r & 3 == c)
   // completes its next line in the same block: two store instructions of eight whole lines each.
   const uint32_t S0 = __builtin_amdgcn_readfirstlane(samples);
-  const uint64_t wo0 = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(wo >> 32)) << 32) |
-                       __builtin_amdgcn_readfirstlane((uint32_t)wo);
+  // (the builtin returns int: without the casts a low word with bit 31 set sign-extends over the high one, and every
+  // group whose sample offset has that bit stops being "regular" -- half of all groups beyond 2^31 samples)
+  const uint64_t wo0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(wo >> 32)) << 32) |
+                       (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)wo);
   bool regular = __all(active && samples == S0 && wo == wo0 + (uint64_t)lane * S0) && (S0 & 15u) == 0;
   const uint64_t B0 = (uint64_t)(uintptr_t)(wav + wo0);  // destination byte address of the group (16-byte aligned)
   uint8_t* const line0 = reinterpret_cast<uint8_t*>(B0 & ~127ull);  // its first line

@@ -63,7 +63,7 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
                          uint64_t* __restrict__ frame_off, uint8_t* __restrict__ out, uint64_t out_cap,
                          uint64_t start_pos, uint32_t* __restrict__ desc, uint32_t epoch,
                          unsigned char* __restrict__ ctl, const uint32_t* __restrict__ xk2,
-                         const uint16_t* __restrict__ crc_tab_g, uint32_t img_dwords) {
+                         const uint16_t* __restrict__ crc_tab_g, uint32_t img_dwords, uint32_t* __restrict__ pace) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* part = reinterpret_cast<uint32_t*>(smem);
   uint32_t* img0 = reinterpret_cast<uint32_t*>(smem + X3_ENC_SMEM_HDR);
@@ -255,7 +255,29 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
     }
   };
 
+  // Pacing (as in x3_decode_split_kernel.h): the SQ issues oldest-first, the first workgroup of a CU runs ahead and then
+  // polls for the sizes of the third.  Per frame a workgroup compares its frame count with where the clock says it
+  // should be -- the pace of the slowest workgroup of the launch before, less 6 % -- and sets its priority: ahead ->
+  // lower, behind -> higher.  0.684 -> 0.62 ms on config 3; a target that does not fit pins the priority: as unpaced.
+  const unsigned long long pace_t0 = wall_clock64();
+  uint32_t pace_k = 0, pace_inv = 0;  // frames done; sixteenths of a frame per 10 ns tick, 16.16 (0: no pacing)
+  {
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)*pace);
+    if ((w >> X3_DESC_BYTES_BITS) == epoch - 1u && (w & X3_DESC_BYTES_MASK) >= 64u) {
+      const uint32_t t = w & X3_DESC_BYTES_MASK;
+      pace_inv = (16u << 16) / (t - t / 16u);
+    }
+  }
   for (uint64_t f = blockIdx.x; f < g.n_frames; f += G) {
+    if (pace_inv) {
+      const uint32_t el = (uint32_t)(wall_clock64() - pace_t0);  // 10 ns ticks
+      const int32_t d = (int32_t)(pace_k * 16u) - (int32_t)((el * pace_inv) >> 16);  // sixteenths of a frame
+      if (d > 16) __builtin_amdgcn_s_setprio(0);
+      else if (d > 0) __builtin_amdgcn_s_setprio(1);
+      else if (d > -16) __builtin_amdgcn_s_setprio(2);
+      else __builtin_amdgcn_s_setprio(3);
+    }
+    ++pace_k;
     const int16_t* src;
     uint32_t n;
     geom_at(clip_f, idx_f, src, n);
@@ -549,6 +571,11 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
     x3_dbg[8 * 8 * 400 + (blockIdx.x * 8 + wid) * 2 + 1] = dbg_late;
   }
 #endif
+  if (tid == 0 && pace_k >= 16u) {  // this workgroup's pace, for the next launch
+    uint64_t t = (wall_clock64() - pace_t0) / pace_k;
+    if (t > X3_DESC_BYTES_MASK) t = X3_DESC_BYTES_MASK;
+    atomicMax(pace, (epoch << X3_DESC_BYTES_BITS) | (uint32_t)t);
+  }
   if (tid < 6) {
     const uint32_t v = part[32 + tid];  // < 2^32: at most ~270 frames x 10 000 samples per workgroup
     if (v) atomicAdd(&stats[tid], (unsigned long long)v);
