@@ -11,10 +11,10 @@ F = L.x3_num_frames(n, C.byref(p)); cap = L.x3_encode_bound(n, C.byref(p))
 d_wav = ctx.alloc(2*n); d_out = ctx.alloc(cap+16); d_off = ctx.alloc(8*(F+1))
 ctx.synth_dev(2, 0x58330003, 0, n, d_wav)
 ctx.enable_kernel_timing(True)
-for _ in range(3):
+for _ in range(8):
     assert ctx.encode_dev(d_wav, n, p, d_out, cap, 0, d_off) == 0
     ctx.encode_result()
-print("kernel ms (incl. stamp overhead):", ctx.kernel_time(0)[0] / 3, "wgs/CU", ctx.get_option("stream_wgs_in_use"))
+print("kernel ms (incl. stamp overhead):", ctx.kernel_time(0)[0] / 8, "wgs/CU", ctx.get_option("stream_wgs_in_use"))
 G = 256 * ctx.get_option("stream_wgs_in_use")
 fpw = F / G
 NW = 400

@@ -35,6 +35,9 @@
 
 #include "x3_encode_stream_kernel.h"
 
+#ifndef X3E_BAND
+#define X3E_BAND 16  // sixteenths of a frame ahead / behind that move a workgroup one priority level
+#endif
 #define X3_STREAM2_THREADS 512u
 #define X3_STREAM2_MAX_GRID 1024u  // two size words per thread cover 1023 predecessors
 #define X3_STREAM2_DESC_PAD 1088u  // words in front of desc[0]: the windows of the first frames reach below frame 0
@@ -272,9 +275,9 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
     if (pace_inv) {
       const uint32_t el = (uint32_t)(wall_clock64() - pace_t0);  // 10 ns ticks
       const int32_t d = (int32_t)(pace_k * 16u) - (int32_t)((el * pace_inv) >> 16);  // sixteenths of a frame
-      if (d > 16) __builtin_amdgcn_s_setprio(0);
+      if (d > X3E_BAND) __builtin_amdgcn_s_setprio(0);
       else if (d > 0) __builtin_amdgcn_s_setprio(1);
-      else if (d > -16) __builtin_amdgcn_s_setprio(2);
+      else if (d > -X3E_BAND) __builtin_amdgcn_s_setprio(2);
       else __builtin_amdgcn_s_setprio(3);
     }
     ++pace_k;
