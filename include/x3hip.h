@@ -219,6 +219,15 @@ int x3_bitreader_count_zero_bits(x3_bitreader* br, uint32_t* count);
 int x3_bitreader_inc_bits(x3_bitreader* br, uint32_t n);
 int x3_bitreader_state(const x3_bitreader* br, uint64_t* idx, uint32_t* leading_word, uint32_t* rem_bit);
 void x3_bitreader_free(x3_bitreader* br);
+/* Not in the reference: announce a frame stream in host memory (frames back to back, no archive header) whose frames
+ * will be handed to x3_decode_frame one by one, as a loop over `decode_frame` does.  Calls whose payload lies in the
+ * announced buffer are then served from windows of frames that are walked, checked and decoded ahead in one launch
+ * set (a header parse and a memcpy per call instead of a dispatch per call); every other call, and every frame the
+ * window did not decode cleanly, takes the per-call path: the results are those of x3_decode_frame without the
+ * announcement.  The buffer must stay unchanged until the next x3_decode_prefetch (x3 = NULL drops it) or
+ * x3_ctx_destroy. */
+int x3_decode_prefetch(x3_ctx* ctx, const uint8_t* x3, uint64_t len, const x3_params* p);
+
 /* `decoder::decode_block` (src/decoder.rs:132-145): wav[0..n) from the reader's position, *last_wav in and out. */
 int x3_decode_block(x3_bitreader* br, int16_t* wav, uint32_t n, int16_t* last_wav, const x3_params* p);
 /* `BitPacker` (src/bitpacker.rs:46-177) over a slice writer at start_pos: write_bits / write_packed_zeros / word_align

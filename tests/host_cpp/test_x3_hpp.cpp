@@ -147,6 +147,19 @@ int main(int argc, char** argv) {
     CHECK(n == fh.samples && !std::memcmp(one.data(), wav.data(), n * 2));
     uint16_t c = 0;
     CHECK(x3::crc::crc16(ctx, ref.data() + 20, fh.payload_len, &c) == x3::X3Error::Ok && c == fh.payload_crc);
+    // the reference's per-frame loop (decodefile.rs:105-136 without the file), announced first: same samples
+    CHECK(x3::decoder::prefetch(ctx, ref.data(), ref.size(), params) == x3::X3Error::Ok);
+    std::vector<int16_t> again;
+    for (size_t off = 0; off + 20 <= ref.size();) {
+      CHECK(x3::decoder::read_frame_header(ref.data() + off, ref.size() - off, &fh) == x3::X3Error::Ok);
+      std::vector<int16_t> fr(fh.samples);
+      CHECK(x3::decoder::decode_frame(ctx, ref.data() + off + 20, fh.payload_len, fr.data(), fr.size(), params, fh.samples, &n) ==
+            x3::X3Error::Ok);
+      again.insert(again.end(), fr.begin(), fr.begin() + n);
+      off += 20 + fh.payload_len;
+    }
+    CHECK(again == wav);
+    CHECK(x3::decoder::prefetch(ctx, nullptr, 0, params) == x3::X3Error::Ok);
   }
   // the reference's own argument lists, on the default context: encode -> decode_stream, crc16
   {

@@ -903,3 +903,54 @@ def test_mgpu_with_one_device(x3):
         m.close()
     with pytest.raises(x3.X3Error):
         x3.MultiGpu([0, 0])   # one rank per GPU
+
+
+def test_decode_frame_loop_with_prefetch(ctx):
+    """x3_decode_prefetch: a loop over decode_frame (decoder.rs:36-58) served from windows decoded ahead gives what the
+    per-call path gives -- also for a frame whose payload CRC is wrong (decode_frame does not look at it), a frame
+    called with another sample count than its header's, and payloads outside the announced buffer"""
+    import time
+    import x3hip
+    n = 10000 * 300 + 123
+    wav = x3hip.synth(2, 99, 0, n)
+    rc, x3, _ = ctx.encode(wav)
+    assert rc == 0
+    x3 = np.ascontiguousarray(x3)
+    bad = x3.copy()
+    frames = []
+    off = 0
+    while off + 20 <= x3.size:
+        h = x3hip.read_frame_header(x3[off:off + 20])
+        assert h[0] == 0
+        frames.append((off, h[1].payload_len, h[1].samples))
+        off += 20 + h[1].payload_len
+    assert len(frames) == 301
+    o7, l7, s7 = frames[7]
+    bad[o7 + 20 + l7 // 2] ^= 0x10   # payload of frame 7 tampered, CRC left alone
+
+    def loop(buf):
+        out = []
+        for (o, ln, ns) in frames:
+            out.append(ctx.decode_frame(buf[o + 20:o + 20 + ln], ns))
+        return out
+
+    for buf in (x3, bad):
+        ctx.decode_prefetch(None)
+        t0 = time.time(); plain = loop(buf); t1 = time.time()
+        assert ctx.decode_prefetch(buf) == 0
+        cached = loop(buf); t2 = time.time()
+        for (a, b) in zip(plain, cached):
+            assert a[0] == b[0] and np.array_equal(a[1], b[1])
+        print("decode_frame loop: %.1f ms per-call, %.1f ms with prefetch" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3))
+    good = np.concatenate([r[1] for r in loop(x3)])
+    assert np.array_equal(good, wav)
+    # another sample count than the header's, and a payload that is not in the announced buffer: the per-call path
+    o, ln, ns = frames[3]
+    a = ctx.decode_frame(x3[o + 20:o + 20 + ln], ns - 20)
+    ctx.decode_prefetch(None)
+    b = ctx.decode_frame(x3[o + 20:o + 20 + ln], ns - 20)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1])
+    ctx.decode_prefetch(x3)
+    c = ctx.decode_frame(x3[o + 20:o + 20 + ln].copy(), ns)
+    assert c[0] == 0 and np.array_equal(c[1], wav[3 * 10000:3 * 10000 + ns])
+    ctx.decode_prefetch(None)

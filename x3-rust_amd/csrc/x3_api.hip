@@ -81,6 +81,7 @@ struct x3_ctx {
   unsigned long long* d_stats = nullptr;    // 6
   unsigned long long* d_end_pos = nullptr;  // 1
   X3DecodeSummary* d_summary = nullptr;
+  struct x3_reader* fcache = nullptr;  // x3_decode_prefetch: the frame stream x3_decode_frame calls are served from
   uint32_t* d_pace = nullptr;          // x3_decode_split_kernel's pace word (see there), dec_epoch its launch count
   uint32_t dec_epoch = 1;
   uint16_t* d_crc = nullptr;
@@ -358,6 +359,7 @@ extern "C" void x3_ctx_destroy(x3_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->fcache) x3_reader_close(c->fcache);
   for (DevBuf* b : {&c->in, &c->out, &c->frame_bytes, &c->frame_off, &c->dec_status, &c->dec_cstatus, &c->dec_meta, &c->wav_off,
                     &c->seg_crc, &c->desc, &c->idx_cand, &c->idx_keys, &c->idx_vals, &c->idx_J, &c->idx_S,
                     &c->idx_L, &c->idx_sum})
@@ -1512,6 +1514,9 @@ static int decode_stream_impl(x3_ctx* c, const uint8_t* x3, uint64_t len, uint64
 
 // single bare payload (decoder::decode_frame): wrap it in a frame header so that the one decode
 // kernel serves both paths; decode_frame itself checks no CRC, so a correct one is supplied.
+#define X3_FRAME_CACHE_MISS (-1)
+static int frame_cache_serve(x3_ctx* c, const uint8_t* payload, uint64_t len, const x3_params* p, uint64_t samples, int16_t* wav);
+
 extern "C" int x3_decode_frame(x3_ctx* c, const uint8_t* payload, uint64_t len, int16_t* wav, uint64_t wav_cap,
                                const x3_params* p, uint64_t samples, uint64_t* n_out) {
   if (!c || !p || !payload || !wav) return X3_ERR_BAD_ARG;
@@ -1522,6 +1527,14 @@ extern "C" int x3_decode_frame(x3_ctx* c, const uint8_t* payload, uint64_t len, 
   if (samples > 0xFFFF || len >= X3_FRAME_MAX_LENGTH || len > X3_READ_BUFFER_SIZE) return X3_ERR_BAD_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
+  if (c->fcache) {  // a frame of the stream announced with x3_decode_prefetch: decoded ahead, a window at a time
+    rc = frame_cache_serve(c, payload, len, p, samples, wav);
+    if (rc == X3_OK) {
+      if (n_out) *n_out = samples;
+      return X3_OK;
+    }
+    if (rc != X3_FRAME_CACHE_MISS) return rc;
+  }
   if ((rc = ensure(c, c->in, 20 + len + 16))) return rc;
   if ((rc = ensure(c, c->frame_off, 2 * sizeof(uint64_t)))) return rc;
   if ((rc = ensure(c, c->wav_off, sizeof(uint64_t)))) return rc;

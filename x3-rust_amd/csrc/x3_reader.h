@@ -239,3 +239,59 @@ extern "C" int x3_reader_next_frame(x3_reader* r, int16_t* wav, uint64_t wav_cap
   if (n_out) *n_out = h.samples;
   return X3_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------ x3_decode_prefetch
+// `decoder::decode_frame` (src/decoder.rs:36-58) takes one payload per call; a loop over the frames of a stream is then
+// one dispatch per 10 000 samples.  A caller that has the whole stream in memory can announce it: x3_decode_frame calls
+// whose payload lies in the announced buffer are served from windows that are walked, checked and decoded ahead (the
+// reader's machinery over the frame stream, without an archive header).  A frame that the window did not decode
+// cleanly -- a payload CRC that does not match its header, which decode_frame does not look at; a decode error -- or
+// that is called with another length or sample count than its header says falls through to the per-call path, so the
+// results are those of x3_decode_frame without the announcement.
+extern "C" int x3_decode_prefetch(x3_ctx* c, const uint8_t* x3, uint64_t len, const x3_params* p) {
+  if (!c || (x3 && !p)) return X3_ERR_BAD_ARG;
+  if (c->fcache) {
+    x3_reader_close(c->fcache);
+    c->fcache = nullptr;
+  }
+  if (!x3 || len <= 20) return X3_OK;
+  x3_reader* r = new x3_reader();
+  r->c = c;
+  r->mem = x3;
+  r->start = 0;
+  r->real_total = len;
+  r->remaining = len;
+  r->p = *p;
+  c->fcache = r;
+  return X3_OK;
+}
+
+static int frame_cache_serve(x3_ctx* c, const uint8_t* payload, uint64_t len, const x3_params* p, uint64_t samples, int16_t* wav) {
+  x3_reader* r = c->fcache;
+  if (std::memcmp(p, &r->p, sizeof(x3_params)) != 0) return X3_FRAME_CACHE_MISS;
+  if (payload < r->mem + 20 || payload + len > r->mem + r->real_total) return X3_FRAME_CACHE_MISS;
+  const uint64_t fpos = (uint64_t)(payload - r->mem) - 20;
+  auto find = [&]() -> long {
+    if (fpos < r->w_pos || r->w_off.empty()) return -1;
+    const uint64_t rel = fpos - r->w_pos;
+    auto it = std::lower_bound(r->w_off.begin(), r->w_off.end(), rel);
+    return (it != r->w_off.end() && *it == rel) ? (long)(it - r->w_off.begin()) : -1;
+  };
+  long i = find();
+  if (i < 0) {
+    x3_frame_header h;  // only a position that holds a valid header of this very frame starts a window
+    if (x3_read_frame_header(r->mem + fpos, 20, &h) || h.payload_len != len || h.samples != samples) return X3_FRAME_CACHE_MISS;
+    r->pos = fpos;
+    r->remaining = r->real_total - fpos;
+    const int rc = reader_fill(r);
+    if (rc) return rc;
+    i = find();
+    if (i < 0) return X3_FRAME_CACHE_MISS;
+  }
+  if (r->w_status[(size_t)i] != 0) return X3_FRAME_CACHE_MISS;
+  x3_frame_header h;
+  if (x3_read_frame_header(r->mem + fpos, 20, &h) || h.payload_len != len || h.samples != samples) return X3_FRAME_CACHE_MISS;
+  std::memcpy(wav, static_cast<const int16_t*>(r->w_samples.p) + r->w_woff[(size_t)i], samples * sizeof(int16_t));
+  return X3_OK;
+}

@@ -537,6 +537,17 @@ inline X3Error decode_frame(const uint8_t* x3_bytes, size_t len, int16_t* wav_bu
   X3_WITH_DEFAULT_CONTEXT(decode_frame(ctx, x3_bytes, len, wav_buf, wav_cap, params, samples, n_out));
 }
 
+// Not in the reference: announce the frame stream a loop over decode_frame is about to walk (x3_decode_prefetch): the
+// calls are then served from windows decoded ahead instead of one dispatch each.  nullptr drops the announcement; the
+// buffer must stay unchanged while it stands.
+inline X3Error prefetch(Context& ctx, const uint8_t* x3, size_t len, const Parameters& params) {
+  x3_params c = params.c_params();
+  return static_cast<X3Error>(x3_decode_prefetch(ctx.raw(), x3, len, &c));
+}
+inline X3Error prefetch(const uint8_t* x3, size_t len, const Parameters& params) {
+  X3_WITH_DEFAULT_CONTEXT(prefetch(ctx, x3, len, params));
+}
+
 // decoder.rs:132-145: one block of wav_len samples from the reader's position; *last_wav is read and updated
 inline X3Error decode_block(bitreader::BitReader& br, int16_t* wav, size_t wav_len, int16_t* last_wav, const Parameters& params) {
   MaybeLock lk(br.mutex());

@@ -68,6 +68,7 @@ pub mod ffi {
         pub fn x3_read_frame_header(bytes: *const u8, len: u64, h: *mut x3_frame_header) -> c_int;
         pub fn x3_decode_frame(ctx: *mut x3_ctx, payload: *const u8, len: u64, wav: *mut i16, wav_cap: u64,
                                p: *const x3_params, samples: u64, n_out: *mut u64) -> c_int;
+        pub fn x3_decode_prefetch(ctx: *mut x3_ctx, x3: *const u8, len: u64, p: *const x3_params) -> c_int;
         pub fn x3_decode_stream(ctx: *mut x3_ctx, x3: *const u8, len: u64, p: *const x3_params, wav: *mut i16,
                                 wav_cap: u64, n_out: *mut u64, frames_ok: *mut u64, frame_errors: *mut u64) -> c_int;
         pub fn x3_bitreader_new(ctx: *mut x3_ctx, array: *const u8, len: u64, br: *mut *mut x3_bitreader) -> c_int;
@@ -862,6 +863,28 @@ pub mod decoder {
             })
         })?;
         Ok(Some(n as usize))
+    }
+
+    /// Not in the reference: announce the frame stream a loop over [`decode_frame`] is about to walk.  While the
+    /// guard lives, calls whose payload lies in `x3` are served from windows of frames that are checked and decoded
+    /// ahead on the GPU (a header parse and a memcpy per call) instead of one dispatch per call; the results are
+    /// those of `decode_frame` alone.
+    ///
+    /// # Safety
+    /// `decode_frame` wants `&mut [u8]` payloads, so the guard cannot hold a borrow of the buffer: the caller keeps
+    /// `x3` alive and unchanged until the guard is dropped.
+    pub unsafe fn prefetch(x3: &[u8], params: &x3::Parameters) -> Result<Prefetch, X3Error> {
+        let p = params.c()?;
+        gpu::with_default(|g| error::check(ffi::x3_decode_prefetch(g.raw(), x3.as_ptr(), x3.len() as u64, &p)))?;
+        Ok(Prefetch(()))
+    }
+    pub struct Prefetch(());
+    impl Drop for Prefetch {
+        fn drop(&mut self) {
+            let _ = gpu::with_default(|g| {
+                error::check(unsafe { ffi::x3_decode_prefetch(g.raw(), core::ptr::null(), 0, core::ptr::null()) })
+            });
+        }
     }
 
     /// src/decoder.rs:69-118

@@ -35,7 +35,7 @@ SYMBOLS = [
     "x3_params_default", "x3_params_validate", "x3_rice_code_get", "x3_num_frames", "x3_encode_bound",
     "x3_crc16", "x3_crc16_dev", "x3_crc16_update",
     "x3_encode", "x3_encode_frame", "x3_write_frame_header", "x3_encode_batch",
-    "x3_read_frame_header", "x3_decode_frame", "x3_decode_stream",
+    "x3_read_frame_header", "x3_decode_frame", "x3_decode_prefetch", "x3_decode_stream",
     "x3_archive_header_write", "x3_archive_header_read", "x3_x3a_encode", "x3_x3a_decode",
     "x3_wav_to_x3a", "x3_x3a_to_wav",
     "x3_bitreader_new", "x3_bitreader_read_nbits", "x3_bitreader_count_zero_bits", "x3_bitreader_inc_bits",
@@ -158,6 +158,7 @@ def lib():
     L.x3_encode_batch.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), u64, PP, vp, u64, C.POINTER(u64), vp]
     L.x3_read_frame_header.argtypes = [vp, u64, C.POINTER(FrameHeader)]
     L.x3_decode_frame.argtypes = [vp, vp, u64, vp, u64, PP, u64, C.POINTER(u64)]
+    L.x3_decode_prefetch.argtypes = [vp, vp, u64, PP]
     L.x3_decode_stream.argtypes = [vp, vp, u64, PP, vp, u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.x3_archive_header_write.argtypes = [u32, PP, vp, u64, C.POINTER(u64)]
     L.x3_archive_header_read.argtypes = [vp, u64, C.POINTER(u32), PP, C.POINTER(C.c_uint8), C.POINTER(u64)]
@@ -532,6 +533,16 @@ class Context:
         rc = lib().x3_decode_stream(self._h, x3.ctypes.data, x3.size, C.byref(params), wav.ctypes.data, wav_cap,
                                     C.byref(n), C.byref(fok), C.byref(ferr))
         return rc, wav[: n.value].copy(), fok.value, ferr.value
+
+    def decode_prefetch(self, x3=None, params=None):
+        """announce a frame stream (a contiguous uint8 array, kept alive here) for decode_frame loops; None drops it"""
+        if x3 is None:
+            self._prefetched = None
+            return lib().x3_decode_prefetch(self._h, None, 0, None)
+        params = params or Params.default()
+        assert x3.dtype == np.uint8 and x3.flags.c_contiguous
+        self._prefetched = x3
+        return lib().x3_decode_prefetch(self._h, x3.ctypes.data, x3.size, C.byref(params))
 
     def decode_frame(self, payload, samples, params=None, wav_cap=None):
         params = params or Params.default()
