@@ -445,34 +445,48 @@ def test_full_size_config3_roundtrip(ctx, x3):
     properties -- encode -> decode is the identity, the frame index is a consistent header chain,
     and sampled frames equal the CPU oracle's encoding of the same samples."""
     torch = pytest.importorskip("torch")
+    import time
+    tt = [time.perf_counter()]
+
+    def lap(what):
+        tt.append(time.perf_counter())
+        print("  [config 3] %-34s %.2f s" % (what, tt[-1] - tt[-2]), flush=True)
     n = 691_200_000
     p = x3.Params.default()
     F = x3.lib().x3_num_frames(n, C.byref(p))
     dev = torch.device("cuda:0")
     wav = torch.empty(n, dtype=torch.int16, device=dev)
     ctx.synth_dev(2, 0x58330003, 0, n, wav.data_ptr())
+    torch.cuda.synchronize(dev)
+    lap("signal in HBM")
     cap = int(n * 1.2)
     out = torch.empty(cap, dtype=torch.uint8, device=dev)
     off = torch.empty(F + 1, dtype=torch.int64, device=dev)
     assert ctx.encode_dev(wav.data_ptr(), n, p, out.data_ptr(), cap, 0, off.data_ptr()) == 0
     rc, pos, stats = ctx.encode_result()
     assert rc == 0 and int(stats.sum()) == n - F
+    lap("encode")
     back = torch.zeros(n, dtype=torch.int16, device=dev)
     torch.cuda.synchronize(dev)  # the fill ran on torch's stream, the decoder runs on the context's
     assert ctx.decode_dev(out.data_ptr(), pos, off.data_ptr(), F, p, back.data_ptr(), n, n_per_clip=n) == 0
     rc, first_bad, st, before = ctx.decode_result()
     assert (rc, first_bad, st, before) == (0, F, 0, n)
+    lap("decode")
     assert torch.equal(back, wav)
     offs = off.cpu().numpy()
+    lap("compare on the device")
     assert offs[0] == 0 and offs[-1] == pos and np.all(np.diff(offs) >= 22) and np.all(offs % 2 == 0)
     # the WHOLE stream against the CPU oracle, all 69 120 frames: chunks of whole frames on a thread pool (the
     # oracle is C behind ctypes, which releases the GIL).  A round trip alone would also pass an encoder and a
     # decoder that are wrong in the same way.
+    t0 = time.perf_counter()
     host_wav = wav.cpu().numpy()
     host_out = out[:pos].cpu().numpy()
+    t1 = time.perf_counter()
     _compare_stream_with_oracle(host_wav, host_out, offs, 10000, 1, n)
+    print("config 3: device -> host %.2f s, oracle compare of %d frames %.2f s on %d cpus (load %s)" % (
+        t1 - t0, F, time.perf_counter() - t1, os.cpu_count(), os.getloadavg()))
     # the GPU-side frame walk finds the same 69 120 frames in the bare byte stream
-    import time
     fo = torch.empty(F + 8, dtype=torch.int64, device=dev)
     wo = torch.empty(F + 8, dtype=torch.int64, device=dev)
     torch.cuda.synchronize(dev)
@@ -486,6 +500,7 @@ def test_full_size_config3_roundtrip(ctx, x3):
     torch.cuda.synchronize(dev)
     assert ctx.decode_stream_dev(out.data_ptr(), pos, p, back.data_ptr(), n) == (0, n, F, 0)
     assert torch.equal(back, wav)
+    lap("index + foreign-stream decode")
 
 
 def _compare_stream_with_oracle(host_wav, host_out, offs, spf, n_clips, n_per_clip, clip_stride=None, chunk_frames=256,
