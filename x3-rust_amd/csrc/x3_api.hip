@@ -48,6 +48,7 @@ struct X3Opts {
   int verbose = 0;            // X3HIP_VERBOSE
   long long file_chunk_frames = 800;  // X3HIP_FILE_CHUNK_FRAMES: 16 MB of samples per chunk (tools/file_bench.py)
   int file_workers = 4;       // X3HIP_FILE_WORKERS
+  int check_main = 0;         // X3HIP_CHECK_MAIN: the check pass on the caller's stream and the decoder on the side stream
   long long reader_window_frames = 4096;  // X3HIP_READER_WINDOW_FRAMES: frames x3_reader decodes ahead per launch set
   int check_prio = 1;         // X3HIP_CHECK_PRIO: queue priority of the side stream the check kernel runs on (-1 low, 0 same, 1 high)
   int check_first = 0;        // X3HIP_CHECK_FIRST: enqueue the check kernel in front of the decoder (1) or behind it (0)
@@ -166,6 +167,7 @@ static void opts_from_env(X3Opts* o) {
   o->file_chunk_frames = std::max(1ll, geti("X3HIP_FILE_CHUNK_FRAMES", o->file_chunk_frames));
   o->file_workers = (int)std::max(1ll, std::min(16ll, geti("X3HIP_FILE_WORKERS", o->file_workers)));
   o->reader_window_frames = std::max(1ll, geti("X3HIP_READER_WINDOW_FRAMES", o->reader_window_frames));
+  o->check_main = (int)geti("X3HIP_CHECK_MAIN", o->check_main);
   o->check_prio = (int)geti("X3HIP_CHECK_PRIO", o->check_prio);
   o->check_first = (int)geti("X3HIP_CHECK_FIRST", o->check_first);
   o->check_wgs = (int)std::max(1ll, geti("X3HIP_CHECK_WGS", o->check_wgs));
@@ -410,6 +412,7 @@ extern "C" int x3_ctx_set_option(x3_ctx* c, const char* name, long long value) {
   else if (n == "file_chunk_frames") c->opt.file_chunk_frames = std::max(1ll, value);
   else if (n == "file_workers") c->opt.file_workers = (int)std::max(1ll, std::min(16ll, value));
   else if (n == "reader_window_frames") c->opt.reader_window_frames = std::max(1ll, value);
+  else if (n == "check_main") c->opt.check_main = value != 0;
   else if (n == "check_first") c->opt.check_first = value != 0;
   else if (n == "check_wgs") c->opt.check_wgs = (int)std::max(1ll, value);
   else return X3_ERR_BAD_ARG;
@@ -428,6 +431,14 @@ extern "C" int x3_ctx_get_option(const x3_ctx* c, const char* name, long long* v
   else if (n == "file_chunk_frames") *value = c->opt.file_chunk_frames;
   else if (n == "file_workers") *value = c->opt.file_workers;
   else if (n == "reader_window_frames") *value = c->opt.reader_window_frames;
+  else if (n == "check_main") *value = c->opt.check_main;
+  else if (n == "decode_pace" || n == "encode_pace") {  // (read-only, syncs) the pace words: 10 ns ticks per 16 blocks / per frame
+    uint32_t w[2] = {0, 0};
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
+        hipMemcpy(w, c->d_pace, sizeof w, hipMemcpyDeviceToHost) != hipSuccess)
+      return X3_ERR_HIP;
+    *value = (long long)(w[n == "encode_pace" ? 1 : 0] & 0xFFFFFu);
+  }
   else if (n == "check_first") *value = c->opt.check_first;
   else if (n == "check_wgs") *value = c->opt.check_wgs;
   else if (n == "check_prio") *value = c->opt.check_prio;
@@ -1086,12 +1097,14 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
   hipStream_t check_stream = c->opt.check_serial ? c->stream : c->stream2;
   const bool no_check = c->opt.no_check != 0;
 #else
-  hipStream_t check_stream = c->stream2;
+  // (option check_main: the two passes swap streams -- the one on the side stream starts a cross-queue event later)
+  hipStream_t check_stream = c->opt.check_main ? c->stream : c->stream2;
   const bool no_check = false;
 #endif
+  hipStream_t dec_stream = check_stream == c->stream2 ? c->stream : c->stream2;
   const uint64_t check_wgs_per_cu = (uint64_t)c->opt.check_wgs;
   HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-  HIPCHK(c, hipStreamWaitEvent(check_stream, c->ev_fork, 0));
+  HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
   // The check pass and the decoder are independent and run side by side; the decoder is enqueued first.  (Neither the
   // order nor the side stream's queue priority selects between the decoder's timing modes -- 0.81 / 0.87 / 0.94 ms
   // per process on one box, 0.98 on another with no check kernel at all: measured, tools/dbg_modes.sh, DESIGN.md.)
@@ -1108,7 +1121,7 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
                          (const uint16_t*)c->d_xinv8, (const uint16_t*)c->d_chktab, (const uint32_t*)c->d_kx64,
                          (int32_t*)c->dec_cstatus.p, reinterpret_cast<unsigned long long*>(c->d_summary));
     }
-    HIPCHK(c, hipEventRecord(c->ev_join, check_stream));
+    if (check_stream == c->stream2) HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
     return X3_OK;
   };
   if (c->opt.check_first && (rc = launch_check())) return rc;
@@ -1134,28 +1147,30 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
 #else
     const size_t dyn_lds = 0;
 #endif
-    TimerScope ts(c, 1);
+    TimerScope ts(c, 1, dec_stream);
     if (split) {
       // the pace word's 12-bit epoch: launches 1, 2, ... 4095, then the word starts over
       if ((c->dec_epoch & 0xFFFu) == 0u) {
-        HIPCHK(c, hipMemsetAsync(c->d_pace, 0, 4, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_pace, 0, 4, dec_stream));
+        HIPCHK(c, hipMemsetAsync(c->d_pace + 2, 0, 4, dec_stream));
         ++c->dec_epoch;
       }
       hipLaunchKernelGGL(x3_decode_split_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64 * X3S_WAVES),
-                         dyn_lds, c->stream, d_x3, x3_len,
+                         dyn_lds, dec_stream, d_x3, x3_len,
                          d_frame_offsets, F, g, d_wav_offsets, dp, d_wav, wav_cap, d_status, (X3FrameMeta*)c->dec_meta.p,
                          c->d_pace, c->dec_epoch & 0xFFFu);
       ++c->dec_epoch;
     }
     else if (fast)
-      hipLaunchKernelGGL(x3_decode_fast_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, c->stream, d_x3, x3_len,
+      hipLaunchKernelGGL(x3_decode_fast_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, dec_stream, d_x3, x3_len,
                          d_frame_offsets, F, g, d_wav_offsets, dp, d_wav, wav_cap, d_status,
                          (X3FrameMeta*)c->dec_meta.p);
     else
-      hipLaunchKernelGGL((x3_decode_lanes_kernel<false, 64>), dim3((unsigned)((F + 63) / 64)), dim3(64), 0, c->stream,
+      hipLaunchKernelGGL((x3_decode_lanes_kernel<false, 64>), dim3((unsigned)((F + 63) / 64)), dim3(64), 0, dec_stream,
                          d_x3, x3_len, d_frame_offsets, F, g, d_wav_offsets, dp, d_wav, wav_cap, d_status,
                          (X3FrameMeta*)c->dec_meta.p);
   }
+  if (dec_stream == c->stream2) HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
   if (!c->opt.check_first && (rc = launch_check())) return rc;
   // join, then merge the two status arrays and summarise
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));

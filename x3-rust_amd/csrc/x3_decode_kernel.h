@@ -93,6 +93,12 @@ __device__ __forceinline__ int32_t x3_frame_header_check(const uint32_t* __restr
 // LDS tables of x3_frame_check_kernel (uint16): T[s][k][v] = v * x^(8k + 16) * x^(2048 s), s, k = 0..3 -- the
 // contribution of the byte that k bytes follow in its dword, in a dword that s rows of 64 dwords follow --, then
 // the two rows of "times x^8192" (for v << 8 and for v)
+#ifndef X3_CHECK_SCHED_FENCE
+#define X3_CHECK_SCHED_FENCE 1
+#endif
+#ifndef X3_CHECK_MIN_WGS
+#define X3_CHECK_MIN_WGS 3
+#endif
 #ifndef X3_CHECK_GROUP
 #define X3_CHECK_GROUP 4u  // rows per group: 4 G + 2 tables of 512 bytes (G = 2, 5 KB, to fit beside five decoder groups: no faster)
 #endif
@@ -110,7 +116,7 @@ __device__ __forceinline__ int32_t x3_frame_header_check(const uint32_t* __restr
 // X3_CHECK_AHEAD x 64 payload dwords one frame ahead.
 #define X3_CHECK_AHEAD 24u  // dwords per lane requested ahead: 6 KB of payload (a default frame is ~5.3 KB)
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, X3_CHECK_MIN_WGS)
 x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const uint64_t* __restrict__ frame_off,
                       uint64_t n_frames, const uint16_t* __restrict__ xinv8, const uint16_t* __restrict__ tab_g,
                       const uint32_t* __restrict__ kx64, int32_t* __restrict__ status,
@@ -129,13 +135,6 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
   for (uint32_t i = threadIdx.x; i < X3_CHECK_TAB_DW; i += blockDim.x)
     reinterpret_cast<uint32_t*>(tab)[i] = reinterpret_cast<const uint32_t*>(tab_g)[i];
   const uint32_t lane = threadIdx.x & 63u;
-  // this lane's dword of a row is followed by 63 - lane dwords of the row: x^(32 * (63 - lane)) * x^b, b = 0..15
-  uint32_t kk[16];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const uint4 k4 = reinterpret_cast<const uint4*>(kx64 + lane * 16u)[q];
-    kk[4 * q] = k4.x; kk[4 * q + 1] = k4.y; kk[4 * q + 2] = k4.z; kk[4 * q + 3] = k4.w;
-  }
   __syncthreads();
   const uint32_t tab_base = x3_lds_addr(tab);
   // sum over the four bytes of a big-endian dword of T[s][k][byte]: the byte selects are SDWA operands of the
@@ -155,16 +154,30 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
 
   // what is in flight for a frame: header dwords (6 aligned dwords cover 20 bytes at an even offset) and the
   // first X3_CHECK_AHEAD payload dwords of this lane
+  // Range-checked buffer loads: the frame is the wave's, so its address is uniform -- one descriptor per frame in
+  // SGPRs, ONE offset register (4 * lane) for all rows, the row in the instruction's immediate (and 4096 in the scalar
+  // offset from row 16 on); dwords behind the end of the stream read as zero.  (With a 64-bit address and a bounds
+  // select per load the kernel needed 167 VGPRs, and beside the decoder's groups a SIMD had room for ONE of its waves.)
+  const uint32_t lane4 = 4u * lane;
+  auto rsrc_at = [&](uint64_t dw) -> __amdgpu_buffer_rsrc_t {  // the stream from dword `dw` on (uniform)
+    const uint64_t left = dw < n_dw ? (n_dw - dw) * 4u : 0u;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)dw);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(dw >> 32));
+    const uint64_t d = ((uint64_t)hi << 32) | lo;
+    const uint32_t bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(left > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : left));
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(xw + d), 0, (int)bytes, 0x00020000);
+  };
+  auto load_rows = [&](const __amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t (&pd)[X3_CHECK_AHEAD]) {
+#pragma unroll
+    for (uint32_t u = 0; u < X3_CHECK_AHEAD; ++u)
+      pd[u] = u < 16u ? __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(voff + 256u * u), 0, 0)
+                      : __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(voff + 256u * (u - 16u)), 4096, 0);
+  };
   auto request = [&](uint64_t off, uint32_t (&hd)[6], uint32_t (&pd)[X3_CHECK_AHEAD]) {
-    const uint64_t a = off >> 2;
+    const __amdgpu_buffer_rsrc_t rh = rsrc_at(off >> 2);
 #pragma unroll
-    for (uint32_t i = 0; i < 6u; ++i) hd[i] = a + i < n_dw ? xw[a + i] : 0u;
-    const uint64_t pa = (off + 20) >> 2;
-#pragma unroll
-    for (uint32_t u = 0; u < X3_CHECK_AHEAD; ++u) {
-      const uint64_t j = pa + lane + 64u * u;
-      pd[u] = j < n_dw ? xw[j] : 0u;
-    }
+    for (uint32_t i = 0; i < 6u; ++i) hd[i] = __builtin_amdgcn_raw_buffer_load_b32(rh, (int)(4u * i), 0, 0);
+    load_rows(rsrc_at((off + 20) >> 2), lane4, pd);
   };
   uint64_t off_cur = frame_off[f0];
   uint64_t off_next = f0 + waves < n_frames ? frame_off[f0 + waves] : 0;
@@ -211,7 +224,6 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
         // the payload is masked to zero, which adds nothing to the sum but counts as trailing zero bytes: undone
         // by one multiplication with x^(-8k) at the end.  The CRC's init value is XORed into payload bytes 0, 1.
         const uint32_t lead = (uint32_t)(p0 & 3u);       // header bytes in front, inside dword 0
-        const uint32_t* __restrict__ const pw = xw + (p0 >> 2);
         const uint32_t nd = (lead + plen + 3u) >> 2;     // aligned dwords covering the payload
         const uint32_t tpad = 4u * nd - lead - plen;     // bytes behind the payload in the last dword
         const uint32_t R = (nd + 63u) >> 6;              // rows that hold payload
@@ -229,14 +241,8 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
         for (uint32_t rbase = 0; rbase < R; rbase += X3_CHECK_AHEAD) {
           if (rbase) {
             // payloads longer than the look-ahead (high-entropy data: up to 20 KB per frame): the same registers,
-            // X3_CHECK_AHEAD rows per round trip; only the last row can reach beyond the payload
-#pragma unroll
-            for (uint32_t u = 0; u < X3_CHECK_AHEAD; ++u) {
-              if (rbase + u < R) {
-                const uint32_t j = 64u * (rbase + u) + lane;
-                pd[u] = (rbase + u + 1u < R || j < nd) ? pw[j] : 0u;
-              }
-            }
+            // X3_CHECK_AHEAD rows per round trip (rows behind the payload are masked below)
+            load_rows(rsrc_at(p0 >> 2), lane4 + 256u * rbase, pd);
           }
 #pragma unroll
           for (uint32_t g4 = 0; g4 < X3_CHECK_AHEAD; g4 += X3_CHECK_GROUP) {
@@ -256,10 +262,22 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
               }
               rows_done = rbase + g4 + X3_CHECK_GROUP;
             }
+#if X3_CHECK_SCHED_FENCE
+            // keep the scheduler from hoisting every group's table look-ups to the front: their results in flight were
+            // most of the kernel's 167 VGPRs, and beside the decoder's groups a SIMD has room for ONE such wave
+            __builtin_amdgcn_sched_barrier(0);
+#endif
           }
         }
-        // this lane's dwords are followed by 63 - lane dwords in their rows: times x^(32 * (63 - lane))
+        // this lane's dwords are followed by 63 - lane dwords in their rows: times x^(32 * (63 - lane)) -- sixteen
+        // pre-shifted words per lane, fetched here (4 KB in all, L1-resident) rather than held in registers all along
         {
+          uint32_t kk[16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint4 k4 = reinterpret_cast<const uint4*>(kx64 + lane * 16u)[q];
+            kk[4 * q] = k4.x; kk[4 * q + 1] = k4.y; kk[4 * q + 2] = k4.z; kk[4 * q + 3] = k4.w;
+          }
           uint32_t r = 0;
 #pragma unroll
           for (int bit = 0; bit < 16; ++bit) r ^= (0u - ((acc >> bit) & 1u)) & kk[bit];

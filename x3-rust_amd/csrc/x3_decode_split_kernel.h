@@ -67,8 +67,9 @@ __device__ __forceinline__ uint32_t x3s_half_index(uint32_t j, uint32_t lane) {
 // the mean.  Every 8 blocks a wave compares its block index with where the clock says it should be and sets its own
 // priority: ahead -> lower, behind -> higher.  The groups then finish within 3 % of each other: 0.76 -> 0.65 ms.
 // The target pace comes from the launch before: every group leaves (clock ticks per 16 blocks) in `pace` by
-// atomicMax, tagged with the launch's epoch; the next launch aims 7 % below the slowest group's.  A target that does
-// not fit (first launch of a context, other data) pins all waves at one priority: the unpaced kernel, nothing worse.
+// atomicMax, tagged with the launch's epoch, and the next launch sets its target by that and by what the last one aimed
+// at (below).  A target that does not fit (first launch of a context, other data) pins all waves at one priority: the
+// unpaced kernel, nothing worse.
 #ifndef X3S_PACE_OFF
 #define X3S_PACE_OFF 0
 #endif
@@ -108,13 +109,30 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   const bool flusher = (threadIdx.x >> 6) == 2u;
   const uint64_t f = (uint64_t)blockIdx.x * 64 + lane;
   const unsigned long long pace_t0 = wall_clock64();
-  uint32_t pace_inv;  // blocks per tick, 16.16 fixed point
+  uint32_t pace_inv;        // blocks per tick, 16.16 fixed point
+  uint32_t pace_target;     // 10 ns ticks per 16 blocks that this launch aims at
   {
-    const uint32_t w = __builtin_amdgcn_readfirstlane(*pace);
-    uint32_t ticks16 = (w >> X3S_PACE_EPOCH_SHIFT) == ((pace_epoch - 1u) & 0xFFFu) ? (w & ((1u << X3S_PACE_EPOCH_SHIFT) - 1u)) : 0u;
-    ticks16 = ticks16 ? ticks16 - ticks16 / 14u : X3S_PACE_DEFAULT;  // 7 % below the slowest group of the last launch
-    if (ticks16 < 64u) ticks16 = 64u;
-    pace_inv = (16u << 16) / ticks16;
+    // pace[0]: what the slowest group of the last launch achieved (P); pace[2]: what that launch aimed at (T).  At its
+    // best the kernel achieves ~4.5 % more than it aims at; a target that is too fast by as little as 3 % throws the
+    // gain away (all waves end up "behind", at one priority: P jumps to 1.1 T), one that is too slow is simply met
+    // (P = T).  So: met -> aim 1.5 % faster; missed by more than 6 % -> back to 4.5 % under what was achieved; in
+    // between -> hold.  (Aiming a fixed fraction under P saw-toothed over the cliff every third or fourth launch:
+    // tools/pace_trace.py.)
+    const uint32_t mask = (1u << X3S_PACE_EPOCH_SHIFT) - 1u, prev = (pace_epoch - 1u) & 0xFFFu;
+    const uint32_t wp = __builtin_amdgcn_readfirstlane(pace[0]), wt = __builtin_amdgcn_readfirstlane(pace[2]);
+    const uint32_t P = (wp >> X3S_PACE_EPOCH_SHIFT) == prev ? (wp & mask) : 0u;
+    const uint32_t T = (wt >> X3S_PACE_EPOCH_SHIFT) == prev ? (wt & mask) : 0u;
+    uint32_t t16;
+    if (P == 0u) t16 = X3S_PACE_DEFAULT;
+    else if (T == 0u) t16 = P - P / 22u;
+    else {
+      const uint32_t r = (P << 8) / T;  // 256 = met exactly
+      t16 = r < 264u ? T - T / 64u : (r <= 272u ? T : P - P / 22u);
+    }
+    if (t16 < 64u) t16 = 64u;
+    if (t16 > mask) t16 = mask;
+    pace_target = t16;
+    pace_inv = (16u << 16) / t16;
   }
 #ifdef X3_DBG_STAMPS
   unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -585,6 +603,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       uint64_t t16 = ((wall_clock64() - pace_t0) * 16u) / nblk_max;
       if (t16 >= (1u << X3S_PACE_EPOCH_SHIFT)) t16 = (1u << X3S_PACE_EPOCH_SHIFT) - 1u;
       atomicMax(pace, ((pace_epoch & 0xFFFu) << X3S_PACE_EPOCH_SHIFT) | (uint32_t)t16);
+      if (blockIdx.x == 0) pace[2] = ((pace_epoch & 0xFFFu) << X3S_PACE_EPOCH_SHIFT) | pace_target;
     }
   }
 #ifdef X3_DBG_STAMPS

@@ -35,6 +35,9 @@
 
 #include "x3_encode_stream_kernel.h"
 
+#ifndef X3E_PACE_DIV
+#define X3E_PACE_DIV 16u  // the target is the slowest workgroup's pace of the launch before less 1/DIV
+#endif
 #ifndef X3E_BAND
 #define X3E_BAND 16  // sixteenths of a frame ahead / behind that move a workgroup one priority level
 #endif
@@ -268,7 +271,7 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)*pace);
     if ((w >> X3_DESC_BYTES_BITS) == epoch - 1u && (w & X3_DESC_BYTES_MASK) >= 64u) {
       const uint32_t t = w & X3_DESC_BYTES_MASK;
-      pace_inv = (16u << 16) / (t - t / 16u);
+      pace_inv = (16u << 16) / (t - t / X3E_PACE_DIV);
     }
   }
   for (uint64_t f = blockIdx.x; f < g.n_frames; f += G) {
