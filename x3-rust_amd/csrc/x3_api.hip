@@ -433,11 +433,11 @@ extern "C" int x3_ctx_get_option(const x3_ctx* c, const char* name, long long* v
   else if (n == "reader_window_frames") *value = c->opt.reader_window_frames;
   else if (n == "check_main") *value = c->opt.check_main;
   else if (n == "decode_pace" || n == "encode_pace") {  // (read-only, syncs) the pace words: 10 ns ticks per 16 blocks / per frame
-    uint32_t w[2] = {0, 0};
+    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
         hipMemcpy(w, c->d_pace, sizeof w, hipMemcpyDeviceToHost) != hipSuccess)
       return X3_ERR_HIP;
-    *value = (long long)(w[n == "encode_pace" ? 1 : 0] & 0xFFFFFu);
+    *value = (long long)(w[n == "encode_pace" ? 4 : 0] & 0xFFFFFu);
   }
   else if (n == "check_first") *value = c->opt.check_first;
   else if (n == "check_wgs") *value = c->opt.check_wgs;
@@ -815,7 +815,7 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
       if ((rc = ensure(c, c->desc, desc_bytes))) return rc;
       if (fresh || ++c->desc_epoch > 0xFFFu) {
         HIPCHK(c, hipMemsetAsync(c->desc.p, 0, c->desc.cap, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_pace + 1, 0, 4, c->stream));  // (the encoder's pace word carries the same epoch)
+        HIPCHK(c, hipMemsetAsync(c->d_pace + 4, 0, 16, c->stream));  // (the encoder's pace words carry the same epoch)
         c->desc_epoch = 1;
       }
       {
@@ -823,7 +823,7 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
         hipLaunchKernelGGL(x3_encode_stream2_kernel, dim3((unsigned)grid), dim3(X3_STREAM2_THREADS), smem2, c->stream,
                            d_wav, pl.g, pl.dp, d_off, d_out, out_cap, start_pos, (uint32_t*)c->desc.p + desc_pad, c->desc_epoch,
                            reinterpret_cast<unsigned char*>(c->d_status), (const uint32_t*)c->d_xk2,
-                           (const uint16_t*)c->d_crctab, pl.img_dwords, c->d_pace + 1);
+                           (const uint16_t*)c->d_crctab, pl.img_dwords, c->d_pace + 4);
       }
       HIPCHK(c, hipGetLastError());
       c->encode_pending = true;
@@ -870,7 +870,7 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
       if ((rc = ensure(c, c->desc, desc_bytes))) return rc;
       if (fresh || ++c->desc_epoch > 0xFFFu) {
         HIPCHK(c, hipMemsetAsync(c->desc.p, 0, c->desc.cap, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_pace + 1, 0, 4, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_pace + 4, 0, 16, c->stream));
         c->desc_epoch = 1;
       }
       {

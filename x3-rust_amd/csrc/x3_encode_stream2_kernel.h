@@ -35,6 +35,9 @@
 
 #include "x3_encode_stream_kernel.h"
 
+#ifndef X3E_PACE_CLIMB
+#define X3E_PACE_CLIMB 1
+#endif
 #ifndef X3E_PACE_DIV
 #define X3E_PACE_DIV 16u  // the target is the slowest workgroup's pace of the launch before less 1/DIV
 #endif
@@ -267,11 +270,25 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
   // lower, behind -> higher.  0.684 -> 0.62 ms on config 3; a target that does not fit pins the priority: as unpaced.
   const unsigned long long pace_t0 = wall_clock64();
   uint32_t pace_k = 0, pace_inv = 0;  // frames done; sixteenths of a frame per 10 ns tick, 16.16 (0: no pacing)
+  uint32_t pace_target = 0;
   {
-    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)*pace);
-    if ((w >> X3_DESC_BYTES_BITS) == epoch - 1u && (w & X3_DESC_BYTES_MASK) >= 64u) {
-      const uint32_t t = w & X3_DESC_BYTES_MASK;
-      pace_inv = (16u << 16) / (t - t / X3E_PACE_DIV);
+    // pace[0]: ticks per frame of the slowest workgroup of the launch before (P); pace[2]: what that launch aimed at (T).
+    // The controller of x3_decode_split_kernel.h with this kernel's numbers: at its best it achieves ~6 % more than it
+    // aims at; met to within 4 % -> aim 1.5 % faster; missed by more than 9 % -> back to 1/16 under what was achieved.
+    const uint32_t wp = (uint32_t)__builtin_amdgcn_readfirstlane((int)pace[0]);
+    const uint32_t wt = (uint32_t)__builtin_amdgcn_readfirstlane((int)pace[2]);
+    const uint32_t P = (wp >> X3_DESC_BYTES_BITS) == epoch - 1u ? (wp & X3_DESC_BYTES_MASK) : 0u;
+    const uint32_t T = (wt >> X3_DESC_BYTES_BITS) == epoch - 1u ? (wt & X3_DESC_BYTES_MASK) : 0u;
+    if (P >= 64u) {
+      uint32_t t = P - P / X3E_PACE_DIV;
+#if X3E_PACE_CLIMB
+      if (T >= 64u) {
+        const uint32_t r = (P << 8) / T;  // 256 = met exactly
+        t = r < 266u ? T - T / 64u : (r <= 279u ? T : P - P / X3E_PACE_DIV);
+      }
+#endif
+      pace_target = t;
+      pace_inv = (16u << 16) / t;
     }
   }
   for (uint64_t f = blockIdx.x; f < g.n_frames; f += G) {
@@ -581,6 +598,7 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
     uint64_t t = (wall_clock64() - pace_t0) / pace_k;
     if (t > X3_DESC_BYTES_MASK) t = X3_DESC_BYTES_MASK;
     atomicMax(pace, (epoch << X3_DESC_BYTES_BITS) | (uint32_t)t);
+    if (blockIdx.x == 0) pace[2] = (epoch << X3_DESC_BYTES_BITS) | pace_target;
   }
   if (tid < 6) {
     const uint32_t v = part[32 + tid];  // < 2^32: at most ~270 frames x 10 000 samples per workgroup
