@@ -127,7 +127,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     else if (T == 0u) t16 = P - P / 22u;
     else {
       const uint32_t r = (P << 8) / T;  // 256 = met exactly
-      t16 = r < 264u ? T - T / 64u : (r <= 272u ? T : P - P / 22u);
+      t16 = r < 259u ? T - T / 24u : (r < 264u ? T - T / 64u : (r <= 272u ? T : P - P / 22u));  // (met with room to spare: 4 % faster)
     }
     if (t16 < 64u) t16 = 64u;
     if (t16 > mask) t16 = mask;

@@ -274,17 +274,23 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
   {
     // pace[0]: ticks per frame of the slowest workgroup of the launch before (P); pace[2]: what that launch aimed at (T).
     // The controller of x3_decode_split_kernel.h with this kernel's numbers: at its best it achieves ~6 % more than it
-    // aims at; met to within 4 % -> aim 1.5 % faster; missed by more than 9 % -> back to 1/16 under what was achieved.
+    // aims at; met to within 2 % -> aim 4 % faster, to within 4 % -> 1.5 % faster; missed by more than 9 % -> back to 1/16
+    // under what was achieved.  (Wider "met" bands settle faster and then overshoot every few launches: tools/pace_trace.py.)
     const uint32_t wp = (uint32_t)__builtin_amdgcn_readfirstlane((int)pace[0]);
     const uint32_t wt = (uint32_t)__builtin_amdgcn_readfirstlane((int)pace[2]);
     const uint32_t P = (wp >> X3_DESC_BYTES_BITS) == epoch - 1u ? (wp & X3_DESC_BYTES_MASK) : 0u;
     const uint32_t T = (wt >> X3_DESC_BYTES_BITS) == epoch - 1u ? (wt & X3_DESC_BYTES_MASK) : 0u;
-    if (P >= 64u) {
+    if (P < 64u) {
+      // nothing to go by (a context's first launch): 6.6 us per frame of 10 000 samples, what config 3 settles on --
+      // a guess that does not fit the data pins the priorities, which is the unpaced kernel
+      pace_target = (p.spf * 66u) / 1000u;
+      if (pace_target >= 64u) pace_inv = (16u << 16) / pace_target;
+    } else {
       uint32_t t = P - P / X3E_PACE_DIV;
 #if X3E_PACE_CLIMB
       if (T >= 64u) {
         const uint32_t r = (P << 8) / T;  // 256 = met exactly
-        t = r < 266u ? T - T / 64u : (r <= 279u ? T : P - P / X3E_PACE_DIV);
+        t = r < 261u ? T - T / 24u : (r < 266u ? T - T / 64u : (r <= 279u ? T : P - P / X3E_PACE_DIV));  // (met by a wide margin: 4 % faster)
       }
 #endif
       pace_target = t;
