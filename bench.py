@@ -414,6 +414,12 @@ def main():
             res["foreign_stream"] = foreign
             res["foreign_stream_ms"] = foreign["ms"]
         if gather is not None:
+            if gather["in_timed_region"]:
+                # derived, for the reader who wants the compute alone beside the contract's `value`: one rank cannot take in
+                # N sub-streams as fast as N GPUs produce them (a stream leaves a GPU at ~270 GB/s, an xGMI link carries ~60)
+                rest = max(elapsed / args.steps - gather["ms"] / 1e3, 1e-9)
+                gather["step_ms_without_gather"] = round(rest * 1e3, 4)
+                gather["value_without_gather"] = round(total_samples / rest / 1e6, 2)
             res["gather"] = gather
             res["rccl_ranks"] = world
             res["rccl"] = rccl
