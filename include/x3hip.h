@@ -109,9 +109,14 @@ const char* x3_last_error(const x3_ctx* ctx);
  *   "file_chunk_frames" (X3HIP_FILE_CHUNK_FRAMES), "file_workers" (X3HIP_FILE_WORKERS)   x3_wav_to_x3a / x3_x3a_to_wav
  *   "reader_window_frames" (X3HIP_READER_WINDOW_FRAMES)   frames x3_reader decodes ahead per launch set
  *   "stream_v1" (X3HIP_STREAM_V1)          1: the first-generation single-pass encoder kernel
+ *   "check_main" (X3HIP_CHECK_MAIN)        1: the check pass on the context's stream, the decoder on the side stream (experiment)
+ *   "check_wgs", "check_prio", "check_first"   grid, queue priority and launch order of the check pass (experiments)
  *   "verbose" (X3HIP_VERBOSE)
  * x3_ctx_get_option also reads "encode_fallbacks" (launches of the single-pass encoder that timed out waiting for
- * a non-resident workgroup and were redone by the two-pass kernels) and "stream_wgs_in_use".
+ * a non-resident workgroup and were redone by the two-pass kernels), "stream_wgs_in_use", and "encode_pace" /
+ * "decode_pace": what the slowest workgroup of the last encoder / decoder launch achieved, in 10 ns ticks per frame /
+ * per 16 blocks -- the next launch paces its waves' priorities by it (x3_encode_stream2_kernel.h,
+ * x3_decode_split_kernel.h); reading them synchronizes.
  * Unknown name: X3_ERR_BAD_ARG. */
 int x3_ctx_set_option(x3_ctx* ctx, const char* name, long long value);
 int x3_ctx_get_option(const x3_ctx* ctx, const char* name, long long* value);
