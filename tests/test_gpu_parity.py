@@ -969,3 +969,37 @@ def test_decode_frame_loop_with_prefetch(ctx):
     c = ctx.decode_frame(x3[o + 20:o + 20 + ln].copy(), ns)
     assert c[0] == 0 and np.array_equal(c[1], wav[3 * 10000:3 * 10000 + ns])
     ctx.decode_prefetch(None)
+
+
+@pytest.mark.parametrize("bpf", [1, 2, 3, 4, 7, 8, 12, 16, 28, 64, 100, 500, 801])
+def test_split_decoder_frame_sizes(ctx, x3, bpf):
+    """the three-wave decoder over frame sizes on both sides of its "regular group" rule (64 equal frames side by
+    side, a multiple of 16 samples each: whole 128-byte lines by the flusher wave; anything else: row by row by the
+    valuer) -- 200 full frames and a ragged tail, all signal kinds incl. all-literal, decoded from the device API
+    with and without explicit sample offsets; every sample against the oracle's decode of the same stream"""
+    p = x3.Params.make(20, bpf)
+    spf = 20 * bpf
+    for kind, seed in ((2, 11), (1, 12), (0, 13), (4, 14)):
+        n = spf * 200 + (spf // 3 if bpf > 2 else 1)
+        wav = x3.synth(kind, seed + bpf, 0, n)
+        rc, stream, _ = ctx.encode(wav, p)
+        assert rc == 0
+        r = check_decode(ctx, x3, stream, p, wav_cap=n)
+        if r[0] != 0:   # (801 blocks of white noise: a payload beyond the reader's 24 576 bytes, decodefile.rs:118-121)
+            assert r[0] == x3.ERR_FRAME_HEADER_INVALID_PAYLOAD_LEN and kind == 1
+            continue
+        assert np.array_equal(r[1], wav)
+        # the device API with the encoder's frame index: the decoder writes straight into the caller's geometry
+        d_wav = ctx.alloc(2 * n + 64)
+        ctx.upload(d_wav, wav)
+        cap = int(x3.lib().x3_encode_bound(n, C.byref(p)))
+        F = int(x3.lib().x3_num_frames(n, C.byref(p)))
+        d_out, d_off, d_back = ctx.alloc(cap + 16), ctx.alloc(8 * (F + 1)), ctx.alloc(2 * n + 64)
+        assert ctx.encode_dev(d_wav, n, p, d_out, cap, 0, d_off) == 0
+        rc, pos, _ = ctx.encode_result()
+        assert rc == 0 and pos == stream.size
+        assert ctx.decode_dev(d_out, pos, d_off, F, p, d_back, n, n_per_clip=n) == 0
+        assert ctx.decode_result() == (0, F, 0, n)
+        assert np.array_equal(ctx.download(d_back, 2 * n, np.int16), wav), (bpf, kind)
+        for d in (d_wav, d_out, d_off, d_back):
+            ctx.free(d)
