@@ -266,7 +266,7 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
 
   // Pacing (as in x3_decode_split_kernel.h): the SQ issues oldest-first, the first workgroup of a CU runs ahead and then
   // polls for the sizes of the third.  Per frame a workgroup compares its frame count with where the clock says it
-  // should be -- the pace of the slowest workgroup of the launch before, less 6 % -- and sets its priority: ahead ->
+  // should be -- from the pace of the slowest workgroup of the launch before, below -- and sets its priority: ahead ->
   // lower, behind -> higher.  0.684 -> 0.62 ms on config 3; a target that does not fit pins the priority: as unpaced.
   const unsigned long long pace_t0 = wall_clock64();
   uint32_t pace_k = 0, pace_inv = 0;  // frames done; sixteenths of a frame per 10 ns tick, 16.16 (0: no pacing)
