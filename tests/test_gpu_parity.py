@@ -185,6 +185,22 @@ def test_encode_generic_geometry(ctx, x3, bl, bpf):
         check_decode(ctx, x3, out, p)
 
 
+@pytest.mark.parametrize("bpf", [500, 502, 504, 510])
+def test_encode_largest_single_pass_frames(ctx, x3, bpf):
+    """The longest payloads the single-pass encoder sees: full-scale noise (every block a literal) in frames of up
+    to 10 200 samples -- 20.8 KB, eleven payload dwords per lane in its CRC pass -- at both stream alignments."""
+    p = x3.Params.make(20, bpf)
+    rng = np.random.default_rng(bpf)
+    n = 20 * bpf * 6 + 1234
+    wav = rng.integers(-32768, 32768, size=n).astype(np.int16)
+    wav[20 * bpf * 2: 20 * bpf * 3] >>= 9       # one frame of short codes: the chunk size changes and changes back
+    for sp in (0, 2):
+        out = check_encode(ctx, x3, wav, p, start_pos=sp)
+    check_decode(ctx, x3, out[2:], p)
+    with _opt(ctx, stream_v1=1):                 # the first-generation single-pass kernel has the same pass
+        check_encode(ctx, x3, wav, p)
+
+
 @pytest.mark.parametrize("codes,thr", [((0, 1, 3), (3, 8, 20)), ((0, 1, 2), (3, 8, 18)), ((1, 2, 3), (5, 10, 25)),
                                        ((0, 2, 3), (2, 12, 27)), ((3, 3, 3), (1, 2, 3)), ((0, 0, 0), (1, 2, 5)),
                                        ((0, 1, 3), (6, 10, 27)), ((0, 1, 3), (0, 0, 0)), ((0, 1, 3), (8, 3, 20))])

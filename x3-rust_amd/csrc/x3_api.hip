@@ -72,8 +72,8 @@ struct x3_ctx {
   std::string last_error;
   // persistent small device state
   uint16_t* d_xpow = nullptr;          // X3_XP_SIZE entries
-  uint32_t* d_xk16 = nullptr;          // [10][512][16]: x^(32*c*(511-t)) * x^b mod P (x3_encode_stream_kernel.h)
-  uint32_t* d_xk2 = nullptr;           // [10][X3_K2_DWORDS]: per-lane and per-wave multipliers (x3_encode_stream2_kernel.h)
+  uint32_t* d_xk16 = nullptr;          // [11][512][16]: x^(32*c*(511-t)) * x^b mod P (x3_encode_stream_kernel.h)
+  uint32_t* d_xk2 = nullptr;           // [X3_K2_MAXC][X3_K2_DWORDS]: per-lane and per-wave multipliers (x3_encode_stream2_kernel.h)
   uint16_t* d_crctab = nullptr;        // [6][256]: slicing-by-4 CRC tables + the two x^2048 rows
   uint32_t* d_kx64 = nullptr;          // [64][16] (x3_frame_check_kernel)
   uint16_t* d_chktab = nullptr;        // [18][256] (x3_frame_check_kernel: T[s][k][v] and the x^8192 rows)
@@ -244,8 +244,9 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
   }
   HIPCHK(c, hipMemcpy(c->d_xpow, xp.data(), X3_XP_SIZE * sizeof(uint16_t), hipMemcpyHostToDevice));
   {
-    std::vector<uint32_t> xk((size_t)10 * 512 * 16);
-    for (int cd = 1; cd <= 10; ++cd)
+    // (chunk sizes 1..11: 512 blocks of literals are 5 207 payload dwords, a little over ten per thread)
+    std::vector<uint32_t> xk((size_t)11 * 512 * 16);
+    for (int cd = 1; cd <= 11; ++cd)
       for (int t = 0; t < 512; ++t) {
         uint32_t k = gf_xpow_host(32ull * cd * (511 - t));
         for (int b = 0; b < 16; ++b) {
@@ -257,8 +258,8 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
     HIPCHK(c, hipMemcpy(c->d_xk16, xk.data(), xk.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     {
       // x3_encode_stream2_kernel: KL[l] = x^(32*c*(63-l)), KA[w] = x^(32*c*64*(7-w)), each as its sixteen shifts
-      std::vector<uint32_t> k2((size_t)10 * X3_K2_DWORDS, 0u);
-      for (int cd = 1; cd <= 10; ++cd) {
+      std::vector<uint32_t> k2((size_t)X3_K2_MAXC * X3_K2_DWORDS, 0u);
+      for (int cd = 1; cd <= (int)X3_K2_MAXC; ++cd) {
         uint32_t* blk = k2.data() + (size_t)(cd - 1) * X3_K2_DWORDS;
         for (int l = 0; l < 64; ++l) {
           uint32_t k = gf_xpow_host(32ull * cd * (63 - l));

@@ -48,10 +48,23 @@
 #define X3_STREAM2_MAX_GRID 1024u  // two size words per thread cover 1023 predecessors
 #define X3_STREAM2_DESC_PAD 1088u  // words in front of desc[0]: the windows of the first frames reach below frame 0
 
-// CRC multipliers (x3_api.hip builds them, one block of X3_K2_DWORDS per chunk size c = 1..10):
+// The payload CRC pass can be left to the first X3E_CRC_WAVES waves of the workgroup while the others copy the previous
+// frame out: fewer waves pay the pass's fixed ~75 instructions (multipliers, reduction) for the same table work.  It
+// does not pay -- the pass is a chain of dependent LDS look-ups per lane, and a longer chain in fewer waves is time the
+// other waves then spend at B4: config 3 encodes in 0.78 / 0.66 / 0.63 / 0.613 / 0.615 ms with 1 / 2 / 3 / 4 / 8 waves.
+#ifndef X3E_CRC_WAVES
+#define X3E_CRC_WAVES 8u
+#endif
+#define X3E_CRC_LANES (64u * X3E_CRC_WAVES)
+// the longest payload of this path: 512 blocks of 20 literals, 20 828 bytes
+#define X3_STREAM2_MAX_PAYLOAD_DWORDS 5248u
+#define X3_K2_MAXC ((X3_STREAM2_MAX_PAYLOAD_DWORDS + X3E_CRC_LANES - 1u) / X3E_CRC_LANES)
+
+// CRC multipliers (x3_api.hip builds them, one block of X3_K2_DWORDS per chunk size c = 1..X3_K2_MAXC):
 //   KL[l][b], l < 64, rows of 20 dwords (16 used: the padding makes the per-lane ds_read_b128 conflict-free):
 //             x^(32*c*(63-l)) * x^b -- lane l's dwords are followed by c*(63-l) dwords of its WAVE's segment;
-//   KA[w][b], w < 8: x^(32*c*64*(7-w)) * x^b -- wave w's segment is followed by those of waves w+1..7.
+//   KA[w][b], w < 8: x^(32*c*64*(7-w)) * x^b -- a wave's segment is followed by those of the CRC waves behind it
+//             (CRC wave w of X3E_CRC_WAVES uses row 8 - X3E_CRC_WAVES + w).
 // crc0(payload) = XOR_w KA[w] * (XOR_l KL[l] * crc0(chunk of lane l of wave w)).  The block of the current chunk
 // size lives in LDS (5.5 KB; reloaded by the workgroup when c changes between frames, which it rarely does).
 #define X3_K2_ROW 20u
@@ -222,7 +235,9 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
     }
     return off;
   };
-  auto copy_out = [&](const uint32_t* img, uint64_t off, uint32_t total_bytes) __attribute__((always_inline)) {
+  auto copy_out = [&](const uint32_t* img, uint64_t off, uint32_t total_bytes, uint32_t tid, uint32_t nthr)
+                      __attribute__((always_inline)) {
+    // (tid, nthr: index in and size of the team of waves that copies)
     // header + payload of a finished frame to its final stream position.  Buffer stores over [dst, dst + bytes):
     // a uniform base and 32-bit per-lane offsets (no 64-bit address arithmetic per lane: registers are tight).
     if (off + total_bytes <= out_cap && part[41] == 0) {
@@ -413,7 +428,7 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
     const uint32_t L = (((total_bits + 7u) >> 3) + 1u) & ~1u;  // word_align (bitpacker.rs:124-132)
     const uint32_t frame_bytes = 20u + L;
     const uint32_t Lw = (L + 3u) >> 2;
-    const uint32_t c_dw = (Lw + nthr - 1) / nthr;  // payload dwords per lane in the CRC pass: 1..10 on this path
+    const uint32_t c_dw = (Lw + X3E_CRC_LANES - 1u) / X3E_CRC_LANES;  // payload dwords per lane in the CRC pass: 1..X3_K2_MAXC
     if (c_dw != ktab_c) {  // (workgroup-uniform, rare) the multipliers of this chunk size: used behind B3
       const uint32_t* __restrict__ src_k = xk2 + (size_t)(c_dw - 1u) * X3_K2_DWORDS;
       for (uint32_t i = tid; i < X3_K2_DWORDS; i += nthr) ktab[i] = src_k[i];
@@ -492,14 +507,15 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
     // overlapped this frame's analysis and emission
     if (have_prev) {
       const uint64_t off = resolve();
-      copy_out(img0 + (cur ^ 1u) * img_dwords, off, prev_bytes);
+      if (X3E_CRC_WAVES >= 8u) copy_out(img0 + (cur ^ 1u) * img_dwords, off, prev_bytes, tid, nthr);
+      else if (wid >= X3E_CRC_WAVES) copy_out(img0 + (cur ^ 1u) * img_dwords, off, prev_bytes, tid - X3E_CRC_LANES, nthr - X3E_CRC_LANES);
     }
     X3_STAMP(5);
     // ---- E: payload CRC-16 as a segmented reduction (see the multiplier tables above): lane chunks are right-
     // aligned in the payload, c_dw dwords each
     uint32_t crc = 0;
-    const int32_t j0 = (int32_t)(tid * c_dw) - (int32_t)(nthr * c_dw - Lw);
-    if (__any(j0 + (int32_t)c_dw > 0)) {  // (the first waves of a short payload hold nothing)
+    const int32_t j0 = (int32_t)(tid * c_dw) - (int32_t)(X3E_CRC_LANES * c_dw - Lw);
+    if (wid < X3E_CRC_WAVES && __any(j0 + (int32_t)c_dw > 0)) {  // (the first waves of a short payload hold nothing)
       for (uint32_t i = 0; i < c_dw; ++i) {
         const int32_t j = j0 + (int32_t)i;
         if (j >= 0) {
@@ -525,7 +541,7 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
       }
       crc = x3_wave_xor_to_lane63_dpp(crc);
     }
-    if (lane == 63) part[16 + wid] = crc;
+    if (lane == 63 && wid < X3E_CRC_WAVES) part[16 + wid] = crc;
     // header CRC (encoder.rs:153-154): it needs only the sample count and the payload length.  The state behind
     // the constant bytes "x3", id, id is a constant; the (samples, payload_len) word and the eight zero time
     // bytes go through the slicing tables (a zero word is two look-ups).  Lane 7 of wave 0 keeps it for the header.
@@ -544,13 +560,13 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
     X3_STAMP(7);
 
     // this frame's header (encoder.rs:122-162): "x3", id, id, samples, payload_len, 8 zero time bytes, header crc
-    // over bytes 0..16, payload crc; audio frames use id 1.  Lanes 0..7 of wave 0 weigh the eight wave partials
+    // over bytes 0..16, payload crc; audio frames use id 1.  The first lanes of wave 0 weigh the CRC waves' partials
     // (KA), lane 7 gathers them and writes the five words, while the other waves clear the old image.
     if (wid == 0) {
       uint32_t v = 0;
-      if (lane < 8) {
+      if (lane < X3E_CRC_WAVES) {
         const uint32_t pw = part[16 + lane];
-        const uint4* kp = reinterpret_cast<const uint4*>(ktab + X3_K2_KA + lane * 16u);
+        const uint4* kp = reinterpret_cast<const uint4*>(ktab + X3_K2_KA + (8u - X3E_CRC_WAVES + lane) * 16u);
         const uint4 kq0 = kp[0], kq1 = kp[1], kq2 = kp[2], kq3 = kp[3];
         const uint32_t kk[16] = {kq0.x, kq0.y, kq0.z, kq0.w, kq1.x, kq1.y, kq1.z, kq1.w,
                                  kq2.x, kq2.y, kq2.z, kq2.w, kq3.x, kq3.y, kq3.z, kq3.w};
@@ -591,7 +607,7 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
   __syncthreads();  // its size sums, its header
   if (have_prev) {
     const uint64_t off = resolve();
-    copy_out(img0 + (cur ^ 1u) * img_dwords, off, prev_bytes);
+    copy_out(img0 + (cur ^ 1u) * img_dwords, off, prev_bytes, tid, nthr);
   }
 #ifdef X3_DBG_STAMPS
   if (lane == 0 && blockIdx.x < 400) {

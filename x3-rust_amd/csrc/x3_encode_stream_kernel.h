@@ -723,7 +723,7 @@ x3_encode_stream_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
       // crc0(payload) = XOR over lanes t of crc0(chunk_t) * x^(32*c_dw*(511-t)) mod P; each lane
       // multiplies by ITS OWN power of x (table xk) and the products are XOR-reduced.
       const uint32_t Lw = (L + 3u) >> 2;
-      const uint32_t c_dw = (Lw + nthr - 1) / nthr;  // 1..10 on this path
+      const uint32_t c_dw = (Lw + nthr - 1) / nthr;  // 1..11 on this path
       const int32_t j0 = (int32_t)(tid * c_dw) - (int32_t)(nthr * c_dw - Lw);
       // this lane's multiplier x^(32*c_dw*(511-tid)), as its sixteen shifts K*x^b (requested now, used below)
       const uint4* kp = reinterpret_cast<const uint4*>(xk16 + ((size_t)(c_dw - 1u) * 512u + tid) * 16u);
