@@ -80,7 +80,13 @@ typedef uint32_t x3_v2u32 __attribute__((ext_vector_type(2)));
 // ctl: the context's 128-byte control block: int status[8] | u64 stats[6] | u64 end_pos
 // The host only takes this path for parameter sets whose thresholds keep every Rice block inside the reference's
 // table for its code (x3_api.hip, stream_safe_thresholds), so there is no "outside the table" test here.
-__global__ void __launch_bounds__(X3_STREAM2_THREADS, 6)
+// Waves per SIMD the register budget is cut for: 6 = 80 VGPRs (79 used) = three workgroups per CU, which is also what
+// two worst-case frame images per workgroup leave room for in LDS.  Four per CU were tried with 12 KB images (enough for
+// config 3) and a 64-VGPR build: 9 registers spill, 0.72 ms with three workgroups, 0.67 ms with four -- against 0.615.
+#ifndef X3E_WAVES_PER_SIMD
+#define X3E_WAVES_PER_SIMD 6
+#endif
+__global__ void __launch_bounds__(X3_STREAM2_THREADS, X3E_WAVES_PER_SIMD)
 x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p,
                          uint64_t* __restrict__ frame_off, uint8_t* __restrict__ out, uint64_t out_cap,
                          uint64_t start_pos, uint32_t* __restrict__ desc, uint32_t epoch,
