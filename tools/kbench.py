@@ -34,7 +34,7 @@ def run_once(tag):
         assert ctx.decode_dev(d_out, cap, d_off, F, p, d_back, n, n_per_clip=npc, n_clips=a.clips, clip_stride=npc) == 0
     ctx.enable_kernel_timing(False)
     step(); rc, pos, st = ctx.encode_result(); assert rc == 0; r = ctx.decode_result(); assert os.environ.get("X3_NOCHECK") or r[:3] == (0, F, 0), r
-    ctx.enable_kernel_timing(True); ctx.reset_kernel_time()
+    ctx.enable_kernel_timing(not os.environ.get('X3_NOTIMING')); ctx.reset_kernel_time()
     for _ in range(a.steps): step()
     rc, pos2, st2 = ctx.encode_result(); r2 = ctx.decode_result()
     assert rc == 0 and pos2 == pos and (os.environ.get("X3_NOCHECK") or r2[:3] == (0, F, 0)), (rc, pos2, r2)
