@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""Parity soak: the HIP path (through the C ABI) against the CPU oracle on randomly drawn inputs, for a time budget.
+Not part of the test suite (it runs as long as it is told to); a failure prints the seed and the drawn case, and
+`--seed S --only T` replays trial T of seed S.
+   python tools/fuzz_parity.py --minutes 10 [--seed 1]
+Families: (e) the single-pass encoders on block_len 20 with mixed content, many frames and ragged tails;
+          (g) arbitrary geometry / codes / thresholds; (d) decode of tampered streams with refreshed CRCs,
+          truncations and header damage; (b) batches of clips through the device API."""
+import argparse, ctypes as C, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "x3-rust_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import x3hip
+import oracle_lib as O
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--minutes", type=float, default=5.0)
+ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--only", type=int, default=-1)
+ap.add_argument("--families", default="egdb")
+a = ap.parse_args()
+ctx = x3hip.Context(0)
+
+
+def oparams(p):
+    return O.Params.make(p.block_len, p.blocks_per_frame, tuple(p.codes), tuple(p.thresholds))
+
+
+def content(rng, n):
+    """a signal stitched from segments of different character, so that frames mix block types"""
+    out = np.zeros(n, dtype=np.int64)
+    i = 0
+    while i < n:
+        seg = int(rng.choice([1, 7, 19, 20, 21, 40, 100, 400, 1000, 5000, 20000]))
+        seg = min(seg, n - i)
+        kind = int(rng.integers(0, 9))
+        if kind == 0:
+            v = np.zeros(seg)
+        elif kind == 1:
+            v = np.full(seg, int(rng.choice([-32768, 32767, 1, -1, 12345])))
+        elif kind == 2:
+            v = rng.integers(-32768, 32768, size=seg)
+        elif kind == 3:
+            amp = int(rng.choice([1, 2, 3, 4, 5, 8, 9, 10, 20, 21, 30, 64, 500, 8000, 16383, 16384]))
+            v = np.cumsum(rng.integers(-amp, amp + 1, size=seg))
+        elif kind == 4:
+            v = np.round(float(rng.choice([50, 1000, 20000, 32767])) * np.sin(np.arange(seg) * float(rng.uniform(0.001, 1.5))))
+        elif kind == 5:
+            v = np.tile(np.array([32767, -32768]), seg // 2 + 1)[:seg]
+        elif kind == 6:
+            amp = int(rng.choice([3, 4, 8, 9, 20, 21]))  # exactly at the Rice thresholds
+            v = np.cumsum(rng.choice([-amp, 0, amp], size=seg))
+        elif kind == 7:
+            v = rng.integers(-3, 4, size=seg) + (rng.random(seg) < 0.02) * rng.integers(-30000, 30000, size=seg)
+        else:
+            v = x3hip.synth(int(rng.choice([0, 1, 2, 3, 4])), int(rng.integers(0, 1 << 30)), 0, seg).astype(np.int64)
+        v = np.asarray(v, dtype=np.int64)
+        # fold back into the i16 range (cumulative sums wander)
+        v = ((v + 32768) % 65536) - 32768 if kind in (3, 6) and rng.random() < 0.3 else np.clip(v, -32768, 32767)
+        out[i:i + seg] = v
+        i += seg
+    return out.astype(np.int16)
+
+
+def frame_offsets(stream):
+    offs, pos = [], 0
+    while pos + 20 <= stream.size:
+        plen = int(stream[pos + 6]) << 8 | int(stream[pos + 7])
+        if pos + 20 + plen > stream.size:
+            break
+        offs.append(pos)
+        pos += 20 + plen
+    return offs
+
+
+def refresh_crcs(s, off):
+    plen = min(int(s[off + 6]) << 8 | int(s[off + 7]), s.size - off - 20)
+    hc = O.crc16(s[off:off + 16])
+    s[off + 16], s[off + 17] = hc >> 8, hc & 0xFF
+    pc = O.crc16(s[off + 20:off + 20 + plen])
+    s[off + 18], s[off + 19] = pc >> 8, pc & 0xFF
+
+
+def cmp_encode(wav, p, sp, tag, cap_cut=None):
+    spf = p.block_len * p.blocks_per_frame
+    cap = sp + 64 + ((wav.size + spf - 1) // spf) * 84 + 3 * wav.size   # the same, generous, capacity for both
+    if cap_cut is not None:
+        cap = int(cap_cut * cap)                                       # ... or one both run out of
+    rc_o, out_o, st_o = O.encode(wav, oparams(p), start_pos=sp, cap=cap)
+    rc_g, out_g, st_g = ctx.encode(wav, p, start_pos=sp, cap=cap)
+    assert rc_g == rc_o, (tag, "status", rc_g, rc_o, ctx.last_error())
+    if rc_o == 0:
+        assert out_g.size == out_o.size, (tag, "size", out_g.size, out_o.size)
+        if not np.array_equal(out_g[sp:], out_o[sp:]):
+            bad = np.nonzero(out_g[sp:] != out_o[sp:])[0]
+            raise AssertionError((tag, "bytes differ", int(bad[0]) + sp, int(bad.size)))
+        assert st_g.tolist() == st_o.tolist(), (tag, "stats")
+    return rc_o, out_o
+
+
+def cmp_decode(stream, p, cap, tag):
+    r_o = O.decode_stream(stream, oparams(p), wav_cap=cap)
+    for host_walk in (1, 0):
+        ctx.set_option("host_walk", host_walk)
+        try:
+            r_g = ctx.decode_stream(stream, p, wav_cap=cap)
+        finally:
+            ctx.set_option("host_walk", -1)
+        assert (r_g[0], r_g[2], r_g[3]) == (r_o[0], r_o[2], r_o[3]), (tag, host_walk, r_g[0], r_g[2:], r_o[0], r_o[2:])
+        assert np.array_equal(r_g[1], r_o[1]), (tag, host_walk, "samples")
+    return r_o
+
+
+def fam_e(rng, tag):
+    bpf = int(rng.choice([1, 2, 3, 4, 6, 8, 16, 50, 100, 250, 500, 502, 504, 510, 511, 512])) if rng.random() < 0.7 else int(rng.integers(1, 513))
+    p = x3hip.Params.make(20, bpf)
+    spf = 20 * bpf
+    frames = int(rng.choice([1, 2, 3, 5, 40, 300, 1500, 4000])) if bpf <= 16 else int(rng.choice([1, 2, 3, 7, 30, 90]))
+    n = max(1, spf * frames - int(rng.integers(0, spf)) + int(rng.integers(0, 3)))
+    wav = content(rng, n)
+    sp = int(rng.choice([0, 0, 1, 2, 3, 18]))
+    v1 = rng.random() < 0.25
+    ctx.set_option("stream_v1", 1 if v1 else 0)
+    try:
+        cut = float(rng.uniform(0.0, 0.3)) if rng.random() < 0.1 else None
+        rc, out = cmp_encode(wav, p, sp, (tag, "e", bpf, n, sp, v1, cut), cut)
+    finally:
+        ctx.set_option("stream_v1", 0)
+    if rc == 0:
+        r = cmp_decode(out[(sp + 1) & ~1:], p, n, (tag, "e-dec", bpf, n))
+        assert r[0] == 0 and np.array_equal(r[1], wav), (tag, "round trip")
+
+
+def fam_g(rng, tag):
+    offsets = [6, 11, 20, 28]
+    bl = int(rng.integers(1, 61))
+    bpf = int(rng.integers(1, 60)) if rng.random() < 0.7 else int(rng.choice([100, 333, 500, 1000]))
+    codes = (0, 1, 3) if rng.random() < 0.5 else tuple(int(c) for c in rng.integers(0, 4, size=3))
+    thr = tuple(int(rng.integers(0, offsets[c] + 1)) for c in codes)
+    if bl * bpf > 38000:   # the library's frames are LDS-resident: <= ~40 000 samples ("Limits")
+        bpf = 38000 // bl
+    p = x3hip.Params.make(bl, bpf, codes, thr)
+    if x3hip.lib().x3_params_validate(C.byref(p)) != 0:
+        return
+    n = int(rng.integers(1, 5 * bl * bpf + 40))
+    wav = content(rng, n)
+    sp = int(rng.integers(0, 4))
+    rc, out = cmp_encode(wav, p, sp, (tag, "g", bl, bpf, codes, thr, n, sp))
+    if rc == 0 and codes == (0, 1, 3):
+        cmp_decode(out[(sp + 1) & ~1:], p, n, (tag, "g-dec", bl, bpf, thr, n))
+
+
+def fam_d(rng, tag):
+    bpf = int(rng.choice([3, 10, 50, 500]))
+    p = x3hip.Params.make(20, bpf)
+    n = 20 * bpf * int(rng.integers(2, 9)) + int(rng.integers(0, 20 * bpf))
+    wav = content(rng, n)
+    stream = O.encode(wav, oparams(p))[1]
+    offs = frame_offsets(stream)
+    s = stream.copy()
+    for _ in range(int(rng.integers(1, 4))):
+        fi = int(rng.integers(0, len(offs)))
+        off = offs[fi]
+        plen = int(stream[off + 6]) << 8 | int(stream[off + 7])    # (of the intact stream: headers get damaged too)
+        kind = int(rng.integers(0, 8))
+        if kind == 0 and plen > 2:       # one bit, CRCs refreshed
+            s[off + 20 + int(rng.integers(0, plen))] ^= 1 << int(rng.integers(0, 8)); refresh_crcs(s, off)
+        elif kind == 1 and plen > 12:    # zero run
+            q = off + 20 + int(rng.integers(0, plen - 10)); s[q:q + int(rng.integers(1, 10))] = 0; refresh_crcs(s, off)
+        elif kind == 2 and plen > 12:    # random bytes
+            q = off + 20 + int(rng.integers(0, plen - 10)); k = int(rng.integers(1, 10))
+            s[q:q + k] = rng.integers(0, 256, size=k, dtype=np.uint8); refresh_crcs(s, off)
+        elif kind == 3:                  # sample count in the header raised or lowered
+            ns = int(s[off + 4]) << 8 | int(s[off + 5])
+            ns2 = max(0, min(65535, ns + int(rng.choice([-200, -20, -1, 1, 19, 20, 21, 300, 5000]))))
+            s[off + 4], s[off + 5] = ns2 >> 8, ns2 & 0xFF; refresh_crcs(s, off)
+        elif kind == 4:                  # payload bit without CRC refresh
+            s[off + 20 + int(rng.integers(0, max(1, plen)))] ^= 0x40
+        elif kind == 5:                  # header byte, header CRC refreshed or not
+            s[off + int(rng.integers(0, 16))] ^= 1 << int(rng.integers(0, 8))
+            if rng.random() < 0.5:
+                hc = O.crc16(s[off:off + 16]); s[off + 16], s[off + 17] = hc >> 8, hc & 0xFF
+        elif kind == 6 and plen > 40:    # all ones
+            q = off + 20 + int(rng.integers(0, plen - 10)); s[q:q + int(rng.integers(1, 10))] = 0xFF; refresh_crcs(s, off)
+        else:                            # the tail of the payload cleared (codes running off the end)
+            k = int(rng.integers(1, min(40, max(2, plen)))); s[off + 20 + plen - k:off + 20 + plen] = 0; refresh_crcs(s, off)
+    if rng.random() < 0.3:
+        s = s[:int(rng.integers(0, s.size + 1))].copy()
+    cmp_decode(s, p, n + 70000, (tag, "d", bpf, n))
+
+
+def fam_b(rng, tag):
+    """clips of equal length through the device batch API against per-clip oracle streams"""
+    bpf = int(rng.choice([2, 8, 100, 500]))
+    p = x3hip.Params.make(20, bpf)
+    spf = 20 * bpf
+    n_clips = int(rng.integers(1, 9))
+    npc = 8 * int(rng.integers(1, max(2, spf * 5 // 8)))
+    wav = content(rng, npc * n_clips)
+    L = x3hip.lib()
+    fpc = L.x3_num_frames(npc, C.byref(p))
+    F = fpc * n_clips
+    cap = L.x3_encode_bound(npc, C.byref(p)) * n_clips
+    d_wav = ctx.alloc(2 * wav.size); d_out = ctx.alloc(cap + 16); d_off = ctx.alloc(8 * (F + 1)); d_back = ctx.alloc(2 * wav.size)
+    try:
+        ctx.upload(d_wav, wav)
+        assert ctx.encode_dev(d_wav, npc, p, d_out, cap, 0, d_off, n_clips=n_clips, clip_stride=npc) == 0
+        rc, pos, st = ctx.encode_result()
+        assert rc == 0, (tag, rc)
+        expect = np.concatenate([O.encode(wav[c * npc:(c + 1) * npc], oparams(p))[1] for c in range(n_clips)])
+        got = ctx.download(d_out, pos)
+        assert pos == expect.size and np.array_equal(got, expect), (tag, "b", bpf, n_clips, npc)
+        assert ctx.decode_dev(d_out, cap, d_off, F, p, d_back, wav.size, n_per_clip=npc, n_clips=n_clips, clip_stride=npc) == 0
+        r = ctx.decode_result()
+        assert r[:3] == (0, F, 0), (tag, r)
+        assert np.array_equal(ctx.download(d_back, 2 * wav.size).view(np.int16), wav), (tag, "b round trip")
+    finally:
+        for d in (d_wav, d_out, d_off, d_back):
+            ctx.free(d)
+
+
+fams = {"e": fam_e, "g": fam_g, "d": fam_d, "b": fam_b}
+t_end = time.time() + 60 * a.minutes
+trial = 0
+counts = {k: 0 for k in fams}
+while time.time() < t_end:
+    if a.only >= 0:
+        trial = a.only
+    rng = np.random.default_rng([a.seed, trial])
+    k = a.families[int(rng.integers(0, len(a.families)))]
+    try:
+        fams[k](rng, (a.seed, trial))
+    except Exception:
+        print("FAILED: seed %d trial %d family %s" % (a.seed, trial, k), flush=True)
+        raise
+    counts[k] += 1
+    trial += 1
+    if a.only >= 0:
+        break
+print("fuzz_parity: seed %d, %d trials OK in %.1f min %s" % (a.seed, trial, a.minutes, counts), flush=True)
