@@ -37,6 +37,14 @@ def run_once(tag):
     ctx.enable_kernel_timing(not os.environ.get('X3_NOTIMING')); ctx.reset_kernel_time()
     for _ in range(a.steps): step()
     rc, pos2, st2 = ctx.encode_result(); r2 = ctx.decode_result()
+    if os.environ.get("X3_WALL"):   # the whole step, without the timers' events in the queues
+        import time
+        ctx.enable_kernel_timing(False)
+        for _ in range(10): step()
+        ctx.decode_result(); t0 = time.perf_counter()
+        for _ in range(a.steps): step()
+        ctx.decode_result(); t1 = time.perf_counter()
+        print("step wall %.4f ms" % ((t1 - t0) / a.steps * 1e3), end="  ")
     assert rc == 0 and pos2 == pos and (os.environ.get("X3_NOCHECK") or r2[:3] == (0, F, 0)), (rc, pos2, r2)
     names = ["encode", "decode", "sizes", "scan", "check"]
     print(" ".join("%s=%.3f" % (names[i], ctx.kernel_time(i)[0] / a.steps) for i in range(5)), "ms; stream B/sample=%.4f" % (pos / n),

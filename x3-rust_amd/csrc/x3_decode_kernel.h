@@ -114,7 +114,12 @@ __device__ __forceinline__ int32_t x3_frame_header_check(const uint32_t* __restr
 // dependent loads), so everything a frame needs is requested one frame ahead: its offset two frames ahead,
 // its header words and -- speculatively, the mapping does not depend on the payload length -- its first
 // X3_CHECK_AHEAD x 64 payload dwords one frame ahead.
+#ifndef X3_CHECK_SETPRIO
+#define X3_CHECK_SETPRIO 3
+#endif
+#ifndef X3_CHECK_AHEAD
 #define X3_CHECK_AHEAD 24u  // dwords per lane requested ahead: 6 KB of payload (a default frame is ~5.3 KB)
+#endif
 
 __global__ void __launch_bounds__(256, X3_CHECK_MIN_WGS)
 x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const uint64_t* __restrict__ frame_off,
@@ -124,7 +129,7 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
   __shared__ __attribute__((aligned(16))) uint16_t tab[X3_CHECK_TAB_U16];
   // short and latency-bound: ahead of the decoder's waves it shares the SIMDs with, so that it is out of the way
   // early instead of being stretched to the decoder's whole duration
-  __builtin_amdgcn_s_setprio(3);
+  __builtin_amdgcn_s_setprio(X3_CHECK_SETPRIO);
   // the summary x3_decode_merge_kernel reduces into starts as {first_bad = n_frames, samples_before = 0,
   // status 0} (X3DecodeSummary, 24 bytes); this kernel is joined in front of the merge, so it can set that up
   if (blockIdx.x == 0 && threadIdx.x == 0) {
