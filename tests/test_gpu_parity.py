@@ -1019,3 +1019,17 @@ def test_split_decoder_frame_sizes(ctx, x3, bpf):
         assert np.array_equal(ctx.download(d_back, 2 * n, np.int16), wav), (bpf, kind)
         for d in (d_wav, d_out, d_off, d_back):
             ctx.free(d)
+
+
+def test_parity_soak_sample(ctx):
+    """a fixed slice of tools/fuzz_parity.py (random content x geometry x damage, HIP path == oracle): 400 trials of
+    seed 7; the tool itself runs for as long as it is given"""
+    import importlib.util
+    import sys
+    path = os.path.join(os.path.dirname(G.rstrip("/")), "..", "tools", "fuzz_parity.py")
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.abspath(path))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["fuzz_parity"] = mod
+    spec.loader.exec_module(mod)
+    counts = mod.run(seed=7, trials=400, context=ctx)
+    assert sum(counts.values()) == 400 and all(v > 50 for v in counts.values()), counts

@@ -14,13 +14,7 @@ import numpy as np
 import x3hip
 import oracle_lib as O
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--minutes", type=float, default=5.0)
-ap.add_argument("--seed", type=int, default=1)
-ap.add_argument("--only", type=int, default=-1)
-ap.add_argument("--families", default="egdb")
-a = ap.parse_args()
-ctx = x3hip.Context(0)
+ctx = None   # the x3hip.Context under test (set by run())
 
 
 def oparams(p):
@@ -221,21 +215,44 @@ def fam_b(rng, tag):
 
 
 fams = {"e": fam_e, "g": fam_g, "d": fam_d, "b": fam_b}
-t_end = time.time() + 60 * a.minutes
-trial = 0
-counts = {k: 0 for k in fams}
-while time.time() < t_end:
-    if a.only >= 0:
-        trial = a.only
-    rng = np.random.default_rng([a.seed, trial])
-    k = a.families[int(rng.integers(0, len(a.families)))]
+
+
+def run(seed=1, minutes=None, trials=None, families="egdb", only=-1, context=None):
+    """draw and check cases until the time or the trial budget is used up -> {family: trials}"""
+    global ctx
+    own = context is None
+    ctx = context if context is not None else x3hip.Context(0)
+    t_end = time.time() + 60 * minutes if minutes is not None else None
+    trial = 0
+    counts = {k: 0 for k in fams}
     try:
-        fams[k](rng, (a.seed, trial))
-    except Exception:
-        print("FAILED: seed %d trial %d family %s" % (a.seed, trial, k), flush=True)
-        raise
-    counts[k] += 1
-    trial += 1
-    if a.only >= 0:
-        break
-print("fuzz_parity: seed %d, %d trials OK in %.1f min %s" % (a.seed, trial, a.minutes, counts), flush=True)
+        while (t_end is None or time.time() < t_end) and (trials is None or trial < trials):
+            if only >= 0:
+                trial = only
+            rng = np.random.default_rng([seed, trial])
+            k = families[int(rng.integers(0, len(families)))]
+            try:
+                fams[k](rng, (seed, trial))
+            except Exception:
+                print("FAILED: seed %d trial %d family %s" % (seed, trial, k), flush=True)
+                raise
+            counts[k] += 1
+            trial += 1
+            if only >= 0:
+                break
+    finally:
+        if own:
+            ctx.close()
+        ctx = None
+    return counts
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--minutes", type=float, default=5.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--only", type=int, default=-1)
+    ap.add_argument("--families", default="egdb")
+    a = ap.parse_args()
+    c = run(a.seed, a.minutes, None, a.families, a.only)
+    print("fuzz_parity: seed %d, %d trials OK in %.1f min %s" % (a.seed, sum(c.values()), a.minutes, c), flush=True)
