@@ -195,7 +195,11 @@ int x3_encode_batch(x3_ctx* ctx, const int16_t* const* wavs, const uint64_t* ns,
 int x3_read_frame_header(const uint8_t* bytes, uint64_t len, x3_frame_header* h);
 
 /* `decoder::decode_frame` (src/decoder.rs:36-58): payload[0..len) -> wav[0..samples).
- * Does not check any CRC (the reference does not either). */
+ * Does not check any CRC (the reference does not either).  wav_cap = `wav_buf.len()`: a buffer shorter than `samples`
+ * is the reference's slice-index panic (X3_ERR_BAD_ARG) at the first block that does not fit -- unless a block in
+ * front of it fails, whose error comes first, as in the reference (decoder.rs:49).  Payloads and sample counts beyond
+ * what a frame header or the walk's read buffer allow (>= 32 736 / > 24 576 bytes, > 65 535 samples) are decoded too,
+ * by the reference-exact reader on one GPU thread: correct, slow. */
 int x3_decode_frame(x3_ctx* ctx, const uint8_t* payload, uint64_t len, int16_t* wav, uint64_t wav_cap,
                     const x3_params* p, uint64_t samples, uint64_t* n_out);
 

@@ -531,16 +531,21 @@ int x3o_decode_frame(const uint8_t* x3_bytes, size_t len, int16_t* wav_buf, size
                      const x3o_params* p, size_t samples, size_t* n_out) {
   x3o_init();
   if (len < 2 || samples == 0 || wav_cap < 1) return X3O_BAD_ARG; /* reference panics */
-  if (p->block_len == 0 && samples > 1) return X3O_BAD_ARG;      /* reference never returns */
   int16_t last_wav = (int16_t)rd_be16(x3_bytes);
   size_t p_wav = 0;
   wav_buf[p_wav++] = last_wav;
   x3o_bitreader br;
   x3o_br_new(&br, x3_bytes + 2, len - 2);
   size_t remaining = samples - 1;
+  /* block_len == 0 (a damaged archive header can say so): every turn decodes an empty block and `remaining` stays --
+   * Rice blocks read their two type bits and nothing else, a BFP block fails (E <= 5) or panics on wav[len - 1]; behind
+   * the payload the reader yields zeros, which is a BFP block with E = 1: the loop ends there at the latest.  (The
+   * turn limit only guards this restatement.) */
+  size_t turns = 0;
   while (remaining > 0) {
     size_t block_len = remaining < p->block_len ? remaining : p->block_len;
     if (p_wav + block_len > wav_cap) return X3O_BAD_ARG; /* slice index panic */
+    if (block_len == 0 && ++turns > 4 * len + 64) return X3O_BAD_ARG; /* never returns */
     int rc = x3o_decode_block(&br, wav_buf + p_wav, block_len, &last_wav, p);
     if (rc) return rc;
     remaining -= block_len;

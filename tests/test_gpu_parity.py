@@ -1033,3 +1033,89 @@ def test_parity_soak_sample(ctx):
     spec.loader.exec_module(mod)
     counts = mod.run(seed=7, trials=400, context=ctx)
     assert sum(counts.values()) == 400 and all(v > 50 for v in counts.values()), counts
+
+
+def test_decode_frame_short_buffer_reports_the_earlier_error(ctx, x3):
+    """decode_frame slices wav per block (decoder.rs:49): with a buffer shorter than `samples` the reference panics at
+    the first block that does not fit, but a decode error in a block in front of it is returned first"""
+    p = x3.Params.default()
+    wav = x3.synth(2, 4242, 0, 10000)
+    stream = O.encode(wav)[1]
+    payload = stream[20:].copy()
+    for cap in (10000, 9999, 9981, 9980, 5000, 21, 20, 2, 1):
+        r_o = O.decode_frame(payload, 10000, oparams(p), wav_cap=cap)
+        r_g = ctx.decode_frame(payload, 10000, p, wav_cap=cap)
+        assert r_g[0] == r_o[0] == (0 if cap >= 10000 else x3.ERR_BAD_ARG), (cap, r_g[0], r_o[0])
+    bad = payload.copy()
+    bad[700:712] = 0                      # a zero run in the payload's first quarter: OutOfBoundsInverse / InvalidBPF there
+    full = O.decode_frame(bad, 10000, oparams(p), wav_cap=10000)
+    assert full[0] != 0
+    seen = set()
+    for cap in (10000, 9999, 6000, 3000, 2500, 2000, 1500, 1000, 500, 100, 21, 1):
+        r_o = O.decode_frame(bad, 10000, oparams(p), wav_cap=cap)
+        r_g = ctx.decode_frame(bad, 10000, p, wav_cap=cap)
+        assert r_g[0] == r_o[0], (cap, r_g[0], r_o[0])
+        seen.add(r_o[0])
+    assert full[0] in seen and x3.ERR_BAD_ARG in seen
+
+
+def test_decode_frame_beyond_the_walk_limits(ctx, x3):
+    """decoder::decode_frame has no payload or sample limit of its own (the 24 KB read buffer and Frame::MAX_LENGTH belong
+    to the walk): payloads of 30 KB and 70 KB, 70 000 samples -- what no frame header can describe -- equal the oracle"""
+    rng = np.random.default_rng(77)
+    p = x3.Params.default()
+    for n, amp in ((14000, 32768), (33000, 32768), (70000, 40), (70000, 32768)):
+        wav = rng.integers(-amp, amp, size=n).astype(np.int16)
+        pp = x3.Params.make(20, (n + 19) // 20)            # one frame
+        rc, stream, _ = O.encode(wav, oparams(pp))
+        assert rc == 0
+        payload = stream[20:].copy()                      # (the header's 16-bit fields have wrapped; the payload is whole)
+        r_o = O.decode_frame(payload, n, oparams(p))
+        r_g = ctx.decode_frame(payload, n, p)
+        assert r_o[0] == 0 and r_g[0] == 0 and np.array_equal(r_g[1], r_o[1]) and np.array_equal(r_g[1], wav), (n, amp)
+        bad = payload.copy(); bad[len(bad) // 2: len(bad) // 2 + 12] = 0
+        r_o = O.decode_frame(bad, n, oparams(p))
+        r_g = ctx.decode_frame(bad, n, p)
+        assert r_g[0] == r_o[0] and (r_o[0] != 0 or np.array_equal(r_g[1], r_o[1])), (n, amp, r_g[0], r_o[0])
+
+
+def test_block_len_zero_from_a_damaged_archive_header(ctx, x3):
+    """<BLKLEN>00</BLKLEN> (one flipped bit in the XML, which no CRC protects in the reference): decode_frame then walks
+    empty blocks -- Rice blocks read only their type bits, the first BFP block is FrameDecodeInvalidBPF (E <= 5) or the
+    reference's panic.  x3_x3a_decode, the reader and x3_decode_frame follow the oracle through both endings."""
+    rng = np.random.default_rng(99)
+    seen = set()
+    for trial in range(40):
+        n = int(rng.integers(2, 30000))
+        kind = trial % 4
+        if kind == 0:
+            wav = rng.integers(-32768, 32768, size=n).astype(np.int16)
+        elif kind == 1:
+            wav = np.cumsum(rng.integers(-40, 41, size=n)).astype(np.int16)
+        elif kind == 2:
+            wav = np.cumsum(rng.integers(-2, 3, size=n)).astype(np.int16)
+        else:
+            wav = x3.synth(2, 500 + trial, 0, n)
+        arch = O.x3a_encode(wav, 48000)[1].copy()
+        at = bytes(arch).find(b"<BLKLEN>20")
+        assert at > 0
+        arch[at + 8] = ord("0")
+        r_o = O.x3a_decode(arch, wav_cap=n + 70000)
+        r_g = ctx.x3a_decode(arch, wav_cap=n + 70000)
+        assert (r_g[0],) + tuple(r_g[2:]) == (r_o[0],) + tuple(r_o[2:]), (trial, r_g[0], r_g[2:], r_o[0], r_o[2:])
+        assert np.array_equal(r_g[1], r_o[1])
+        seen.add((r_o[0], r_o[4]))
+        rd = x3.Reader(ctx, arch)
+        assert rd.rc == 0
+        rc, smp = rd.next_frame()
+        assert (rc, rd.frame_errors()) == (r_o[0], r_o[4]), (trial, rc, rd.frame_errors(), r_o[0], r_o[4])
+        rd.close()
+        p0 = x3.Params.make(0, 500)
+        hdr = 28 + (int(arch[14]) << 8 | int(arch[15]))
+        plen = int(arch[hdr + 6]) << 8 | int(arch[hdr + 7])
+        ns = int(arch[hdr + 4]) << 8 | int(arch[hdr + 5])
+        payload = arch[hdr + 20: hdr + 20 + plen]
+        f_o = O.decode_frame(payload, ns, O.Params.make(0, 500))
+        f_g = ctx.decode_frame(payload, ns, p0)
+        assert f_g[0] == f_o[0] and f_o[0] in (x3.ERR_BAD_ARG, x3.ERR_FRAME_DECODE_INVALID_BPF), (trial, f_g[0], f_o[0])
+    assert (0, 1) in seen and (x3.ERR_BAD_ARG, 0) in seen, seen      # a counted frame error, and the panic

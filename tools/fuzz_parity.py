@@ -5,7 +5,8 @@ Not part of the test suite (it runs as long as it is told to); a failure prints 
    python tools/fuzz_parity.py --minutes 10 [--seed 1]
 Families: (e) the single-pass encoders on block_len 20 with mixed content, many frames and ragged tails;
           (g) arbitrary geometry / codes / thresholds; (d) decode of tampered streams with refreshed CRCs,
-          truncations and header damage; (b) batches of clips through the device API."""
+          truncations and header damage; (b) batches of clips through the device API; (a) .x3a archives in memory and
+          the incremental reader; (f) decode_frame frame by frame, with and without x3_decode_prefetch."""
 import argparse, ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "x3-rust_amd"))
@@ -145,13 +146,8 @@ def fam_g(rng, tag):
         cmp_decode(out[(sp + 1) & ~1:], p, n, (tag, "g-dec", bl, bpf, thr, n))
 
 
-def fam_d(rng, tag):
-    bpf = int(rng.choice([3, 10, 50, 500]))
-    p = x3hip.Params.make(20, bpf)
-    n = 20 * bpf * int(rng.integers(2, 9)) + int(rng.integers(0, 20 * bpf))
-    wav = content(rng, n)
-    stream = O.encode(wav, oparams(p))[1]
-    offs = frame_offsets(stream)
+def damage(rng, stream, offs):
+    """a copy of `stream` with one to three of its frames (byte offsets `offs`) tampered with, perhaps truncated"""
     s = stream.copy()
     for _ in range(int(rng.integers(1, 4))):
         fi = int(rng.integers(0, len(offs)))
@@ -181,7 +177,90 @@ def fam_d(rng, tag):
             k = int(rng.integers(1, min(40, max(2, plen)))); s[off + 20 + plen - k:off + 20 + plen] = 0; refresh_crcs(s, off)
     if rng.random() < 0.3:
         s = s[:int(rng.integers(0, s.size + 1))].copy()
+    return s
+
+
+def fam_d(rng, tag):
+    bpf = int(rng.choice([3, 10, 50, 500]))
+    p = x3hip.Params.make(20, bpf)
+    n = 20 * bpf * int(rng.integers(2, 9)) + int(rng.integers(0, 20 * bpf))
+    wav = content(rng, n)
+    stream = O.encode(wav, oparams(p))[1]
+    s = damage(rng, stream, frame_offsets(stream))
     cmp_decode(s, p, n + 70000, (tag, "d", bpf, n))
+
+
+def fam_a(rng, tag):
+    """.x3a archives in memory: encode == oracle; decode of intact and damaged archives through x3_x3a_decode and
+    through the incremental reader (random window) == the oracle's x3a_to_wav"""
+    rate = int(rng.choice([8000, 44100, 48000, 96000, 192000, 384000, 1, 999999, 1000000]))
+    n = int(rng.integers(1, 60000))
+    wav = content(rng, n)
+    rc_o, x_o, st_o = O.x3a_encode(wav, rate)
+    rc_g, x_g, st_g = ctx.x3a_encode(wav, rate)
+    assert rc_g == rc_o and np.array_equal(x_g, x_o) and st_g.tolist() == st_o.tolist(), (tag, "a-enc", rate, n)
+    arch = x_o
+    if rng.random() < 0.7:
+        hdr = 28 + (int(arch[8 + 6]) << 8 | int(arch[8 + 7]))
+        offs = [hdr + o for o in frame_offsets(arch[hdr:])]
+        if offs:
+            arch = damage(rng, arch, offs)
+        if rng.random() < 0.15 and arch.size > 40:   # the archive header itself
+            arch = arch.copy(); arch[int(rng.integers(0, min(arch.size, hdr)))] ^= 1 << int(rng.integers(0, 8))
+    cap = n + 70000
+    r_o = O.x3a_decode(arch, wav_cap=cap)
+    r_g = ctx.x3a_decode(arch, wav_cap=cap)
+    assert (r_g[0],) + tuple(r_g[2:]) == (r_o[0],) + tuple(r_o[2:]), (tag, "a-dec", rate, n, r_g[0], r_g[2:], r_o[0], r_o[2:])
+    assert np.array_equal(r_g[1], r_o[1]), (tag, "a-dec samples")
+    # the incremental reader, as x3a_to_wav drives it
+    ctx.set_option("reader_window_frames", int(rng.choice([1, 2, 3, 7, 64, 4096])))
+    r = x3hip.Reader(ctx, arch)
+    try:
+        if r.rc:
+            assert r.rc == r_o[0], (tag, "a-reader open", r.rc, r_o[0])
+        else:
+            out, rc = [], 0
+            while True:
+                rc, smp = r.next_frame()
+                if rc or smp is None:
+                    break
+                out.append(smp)
+            got = np.concatenate(out) if out else np.zeros(0, dtype=np.int16)
+            assert (rc, r.frame_errors()) == (r_o[0], r_o[4]), (tag, "a-reader rc", rc, r.frame_errors(), r_o[0], r_o[4])
+            assert np.array_equal(got, r_o[1]) and r.spec()[0] == r_o[2], (tag, "a-reader samples")
+    finally:
+        r.close()
+
+
+def fam_f(rng, tag):
+    """decoder::decode_frame frame by frame (with and without x3_decode_prefetch) on intact and damaged streams"""
+    bpf = int(rng.choice([1, 3, 10, 50, 500]))
+    p = x3hip.Params.make(20, bpf)
+    n = 20 * bpf * int(rng.integers(1, 7)) + int(rng.integers(0, 20 * bpf))
+    wav = content(rng, n)
+    stream = O.encode(wav, oparams(p))[1]
+    offs = frame_offsets(stream)
+    s = damage(rng, stream, offs) if rng.random() < 0.6 else stream
+    s = np.ascontiguousarray(s)
+    pre = rng.random() < 0.5
+    if pre:
+        assert ctx.decode_prefetch(s, p) == 0
+    try:
+        for off in frame_offsets(s):
+            plen = int(s[off + 6]) << 8 | int(s[off + 7])
+            ns = int(s[off + 4]) << 8 | int(s[off + 5])
+            if ns == 0:
+                continue
+            payload = s[off + 20:off + 20 + plen]
+            cap = int(rng.choice([ns, ns, ns + 5, max(0, ns - 1)]))
+            r_o = O.decode_frame(payload, ns, oparams(p), wav_cap=cap)
+            r_g = ctx.decode_frame(payload, ns, p, wav_cap=cap)
+            assert r_g[0] == r_o[0], (tag, "f rc", bpf, off, ns, plen, cap, r_g[0], r_o[0])
+            if r_o[0] == 0:
+                assert np.array_equal(r_g[1], r_o[1]), (tag, "f samples", bpf, off)
+    finally:
+        if pre:
+            ctx.decode_prefetch(None)
 
 
 def fam_b(rng, tag):
@@ -214,10 +293,10 @@ def fam_b(rng, tag):
             ctx.free(d)
 
 
-fams = {"e": fam_e, "g": fam_g, "d": fam_d, "b": fam_b}
+fams = {"e": fam_e, "g": fam_g, "d": fam_d, "b": fam_b, "a": fam_a, "f": fam_f}
 
 
-def run(seed=1, minutes=None, trials=None, families="egdb", only=-1, context=None):
+def run(seed=1, minutes=None, trials=None, families="egdbaf", only=-1, context=None):
     """draw and check cases until the time or the trial budget is used up -> {family: trials}"""
     global ctx
     own = context is None
@@ -252,7 +331,7 @@ if __name__ == "__main__":
     ap.add_argument("--minutes", type=float, default=5.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--only", type=int, default=-1)
-    ap.add_argument("--families", default="egdb")
+    ap.add_argument("--families", default="egdbaf")
     a = ap.parse_args()
     c = run(a.seed, a.minutes, None, a.families, a.only)
     print("fuzz_parity: seed %d, %d trials OK in %.1f min %s" % (a.seed, sum(c.values()), a.minutes, c), flush=True)

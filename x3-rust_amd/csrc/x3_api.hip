@@ -1069,7 +1069,8 @@ extern "C" int x3_encode_batch(x3_ctx* c, const int16_t* const* wavs, const uint
 // writes 16-byte aligned rows); without that knowledge caller-supplied offsets go to the single-wave kernels
 static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint64_t* d_frame_offsets,
                            uint64_t F, const x3_batch* batch, const uint64_t* d_wav_offsets, const x3_params* p,
-                           int16_t* d_wav, uint64_t wav_cap, int32_t* d_status, bool wav_off_aligned = false) {
+                           int16_t* d_wav, uint64_t wav_cap, int32_t* d_status, bool wav_off_aligned = false,
+                           bool bl0 = false) {  // bl0: the caller's block_len is 0 and p carries 1 (x3_decode_merge_kernel)
   if (reinterpret_cast<uintptr_t>(d_x3) & 3u) return X3_ERR_BAD_ARG;
   if (reinterpret_cast<uintptr_t>(d_wav) & 1u) return X3_ERR_BAD_ARG;
   if (F == 0 || F > 0x7FFFFFFFull) return X3_ERR_BAD_ARG;
@@ -1186,7 +1187,7 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
   }
   hipLaunchKernelGGL(x3_decode_merge_kernel, dim3((unsigned)std::min<uint64_t>((F + 255) / 256, 64)), dim3(256), 0, c->stream,
                      (const int32_t*)c->dec_cstatus.p, d_status, (const X3FrameMeta*)c->dec_meta.p, F, c->d_summary,
-                     d_x3, d_frame_offsets, g, d_wav_offsets, dp, d_wav);
+                     d_x3, d_frame_offsets, g, d_wav_offsets, dp, d_wav, bl0 ? 1u : 0u);
   c->dec_status_ptr = d_status;
   HIPCHK(c, hipGetLastError());
   c->decode_pending = true;
@@ -1368,7 +1369,7 @@ static int decode_stream_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t len, 
     wav_cap = std::min<uint64_t>(wav_cap, r.n_samples + 65535);
   }
   if ((rc = decode_dev_impl(c, d_x3, len, (const uint64_t*)c->frame_off.p, F, nullptr, (const uint64_t*)c->wav_off.p,
-                            &pp, d_wav, wav_cap, nullptr, r.unaligned == 0)))
+                            &pp, d_wav, wav_cap, nullptr, r.unaligned == 0, p->block_len == 0)))
     return rc;
   uint64_t first_bad = 0, before = 0;
   int bad_status = 0;
@@ -1467,7 +1468,8 @@ static int decode_frames_host(x3_ctx* c, const uint8_t* x3, uint64_t len, const 
   bool aligned = true;
   for (uint64_t v : w.woffs) aligned = aligned && (v & 7ull) == 0;
   if ((rc = decode_dev_impl(c, (const uint8_t*)c->in.p, len, (const uint64_t*)c->frame_off.p, F, nullptr,
-                            (const uint64_t*)c->wav_off.p, &pp, (int16_t*)c->out.p, dev_wav_cap, nullptr, aligned)))
+                            (const uint64_t*)c->wav_off.p, &pp, (int16_t*)c->out.p, dev_wav_cap, nullptr, aligned,
+                            p->block_len == 0)))
     return rc;
   if ((rc = x3_decode_result(c, first_bad, bad_status, before))) return rc;
   if (download && *before)
@@ -1533,17 +1535,53 @@ static int decode_stream_impl(x3_ctx* c, const uint8_t* x3, uint64_t len, uint64
 #define X3_FRAME_CACHE_MISS (-1)
 static int frame_cache_serve(x3_ctx* c, const uint8_t* payload, uint64_t len, const x3_params* p, uint64_t samples, int16_t* wav);
 
-extern "C" int x3_decode_frame(x3_ctx* c, const uint8_t* payload, uint64_t len, int16_t* wav, uint64_t wav_cap,
-                               const x3_params* p, uint64_t samples, uint64_t* n_out) {
+static int decode_frame_impl(x3_ctx* c, const uint8_t* payload, uint64_t len, int16_t* wav, uint64_t wav_cap,
+                             const x3_params* p, uint64_t samples, uint64_t* n_out, bool use_cache) {
   if (!c || !p || !payload || !wav) return X3_ERR_BAD_ARG;
   if (n_out) *n_out = 0;
   if (len < 2 || samples == 0 || wav_cap < 1) return X3_ERR_BAD_ARG;  // reference panics
-  if (p->block_len == 0 && samples > 1) return X3_ERR_BAD_ARG;         // reference never returns
-  if (samples > wav_cap) return X3_ERR_BAD_ARG;                        // slice index panic
-  if (samples > 0xFFFF || len >= X3_FRAME_MAX_LENGTH || len > X3_READ_BUFFER_SIZE) return X3_ERR_BAD_ARG;
+  // block_len == 0: every block is empty, the frame's fate is in its block type bits (x3_replay_frame) and no block
+  // ever fails to fit
+  const bool bl0 = p->block_len == 0 && samples > 1;
+  if (samples > wav_cap && !bl0) {
+    // decode_frame slices wav block by block (decoder.rs:49) and panics at the first block that does not fit -- but an
+    // error in a block in front of that one is returned first.  The blocks in front of it are a frame of their own:
+    const uint64_t bl = p->block_len ? p->block_len : 1;
+    const uint64_t n_fit = 1 + ((wav_cap - 1) / bl) * bl;  // the first sample and the whole blocks that fit
+    if (n_fit > 1) {
+      std::vector<int16_t> tmp(n_fit);
+      const int rc_fit = decode_frame_impl(c, payload, len, tmp.data(), n_fit, p, n_fit, nullptr, false);
+      if (rc_fit != X3_OK) return rc_fit;
+    }
+    return X3_ERR_BAD_ARG;  // slice index panic
+  }
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
-  if (c->fcache) {  // a frame of the stream announced with x3_decode_prefetch: decoded ahead, a window at a time
+  if (bl0 || samples > 0xFFFF || len >= X3_FRAME_MAX_LENGTH || len > X3_READ_BUFFER_SIZE) {
+    // not a frame the walk would hand over (decodefile.rs:118-121, x3.rs:145) and not one a header can describe, but
+    // decode_frame itself has no such limits: the reference's reader, one thread (x3_decode_replay.h)
+    if (samples > 0xFFFFFFFFull || len > 0xFFFFFFFFull) return X3_ERR_BAD_ARG;
+    X3DevParams dpr;
+    x3_params pr = *p;
+    if (pr.block_len == 0) pr.block_len = 1;
+    if ((rc = derive(&pr, 0, &dpr))) return rc;
+    if (bl0) dpr.block_len = 0;
+    if ((rc = ensure(c, c->in, len + 16))) return rc;
+    if ((rc = ensure(c, c->out, (samples + 16) * sizeof(int16_t)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->in.p, payload, len, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(x3_replay_one_kernel, dim3(1), dim3(64), 0, c->stream, (const uint8_t*)c->in.p, (uint32_t)len,
+                       (uint32_t)samples, dpr, (int16_t*)c->out.p, (int32_t*)c->d_crc);
+    HIPCHK(c, hipGetLastError());
+    int32_t st = 0;
+    HIPCHK(c, hipMemcpyAsync(&st, c->d_crc, sizeof st, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (st != X3D_OK) return st;
+    HIPCHK(c, hipMemcpyAsync(wav, c->out.p, samples * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n_out) *n_out = samples;
+    return X3_OK;
+  }
+  if (c->fcache && use_cache) {  // a frame of the stream announced with x3_decode_prefetch: decoded ahead, a window at a time
     rc = frame_cache_serve(c, payload, len, p, samples, wav);
     if (rc == X3_OK) {
       if (n_out) *n_out = samples;
@@ -1579,6 +1617,11 @@ extern "C" int x3_decode_frame(x3_ctx* c, const uint8_t* payload, uint64_t len, 
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (n_out) *n_out = samples;
   return X3_OK;
+}
+
+extern "C" int x3_decode_frame(x3_ctx* c, const uint8_t* payload, uint64_t len, int16_t* wav, uint64_t wav_cap,
+                               const x3_params* p, uint64_t samples, uint64_t* n_out) {
+  return decode_frame_impl(c, payload, len, wav, wav_cap, p, samples, n_out, true);
 }
 
 // ------------------------------------------------------------------------------------------------

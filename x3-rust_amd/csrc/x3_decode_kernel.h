@@ -1104,7 +1104,7 @@ __global__ void __launch_bounds__(256)
 x3_decode_merge_kernel(const int32_t* __restrict__ cstatus, int32_t* __restrict__ status,
                        const X3FrameMeta* __restrict__ meta, uint64_t n_frames, X3DecodeSummary* __restrict__ out,
                        const uint8_t* __restrict__ x3, const uint64_t* __restrict__ frame_off, X3Geom g,
-                       const uint64_t* __restrict__ wav_off, X3DevParams p, int16_t* __restrict__ wav) {
+                       const uint64_t* __restrict__ wav_off, X3DevParams p, int16_t* __restrict__ wav, uint32_t bl0) {
   // grid-stride, one atomic per workgroup: a thousand waves adding to ONE address took 11 of this kernel's 16 us
   __shared__ unsigned long long s_ns[4];
   unsigned long long ns = 0;
@@ -1114,6 +1114,15 @@ x3_decode_merge_kernel(const int32_t* __restrict__ cstatus, int32_t* __restrict_
     if (cs != 0) {
       st = cs;
       status[f] = cs;
+    } else if (bl0 && meta[f].samples > 1u && st != X3D_BAD_ARG) {
+      // Parameters.block_len == 0 (the kernels ran with 1): what the reference makes of such a frame is decided by its
+      // block TYPE bits alone (x3_replay_frame) -- FrameDecodeInvalidBPF or its panic; nothing is written behind out[0]
+      const X3FrameMeta m = meta[f];
+      X3DevParams q = p;
+      q.block_len = 0;
+      int16_t first_sample;
+      st = x3_replay_frame(x3 + frame_off[f] + 20, m.payload_len, m.samples, q, &first_sample);
+      status[f] = st;
     } else if (st == X3D_REPLAY) {
       // (the decoder has validated the header, the sample count and the output range of this frame)
       const X3FrameMeta m = meta[f];

@@ -128,6 +128,7 @@ __device__ __forceinline__ int32_t x3_replay_block(X3RefReader& br, uint32_t n, 
         out[i] = (int16_t)(uint16_t)last;
       }
     }
+    if (n == 0u) return X3D_BAD_ARG;  // `*last_wav = wav[wav.len() - 1]` on an empty block panics (:232)
   } else if (ftype == 1u) {  // decode_ricecode_block_r1 (:147-170)
     const uint32_t bound = p.inv_len[0];
     for (uint32_t i = 0; i < n; ++i) {
@@ -156,7 +157,7 @@ __device__ __forceinline__ int32_t x3_replay_block(X3RefReader& br, uint32_t n, 
   return X3D_OK;
 }
 
-// decoder::decode_frame (src/decoder.rs:36-58): payload[0..plen), plen >= 2; samples >= 1; block_len >= 1; out has
+// decoder::decode_frame (src/decoder.rs:36-58): payload[0..plen), plen >= 2; samples >= 1; out has
 // room for `samples` values.
 __device__ __noinline__ int32_t x3_replay_frame(const uint8_t* __restrict__ payload, uint32_t plen, uint32_t samples,
                                                 const X3DevParams& p, int16_t* __restrict__ out) {
@@ -165,12 +166,25 @@ __device__ __noinline__ int32_t x3_replay_frame(const uint8_t* __restrict__ payl
   X3RefReader br;
   br.open(payload + 2, plen - 2u);
   uint32_t at = 1u, remaining = samples - 1u;
+  // (block_len == 0 -- a damaged archive header can say so: empty blocks, `remaining` stays; Rice blocks read their type
+  // bits and nothing else, a BFP block is an error or the reference's panic, and behind the payload the reader yields
+  // zeros = a BFP block with E = 1, so the loop ends there at the latest; the turn limit only guards this restatement)
+  uint32_t turns = 0;
   while (remaining) {
     const uint32_t n = remaining < p.block_len ? remaining : p.block_len;
+    if (n == 0u && ++turns > 4u * plen + 64u) return X3D_BAD_ARG;
     const int32_t st = x3_replay_block(br, n, p, last, out + at);
     if (st != X3D_OK) return st;
     remaining -= n;
     at += n;
   }
   return X3D_OK;
+}
+
+// One frame through the reference's reader, for x3_decode_frame calls outside the fast decoders' geometry (a payload
+// longer than the walk's 24 KB read buffer or the header's length field, more samples than its 16-bit count): what
+// decoder::decode_frame itself does not limit.  One thread; status -> *status.
+__global__ void x3_replay_one_kernel(const uint8_t* __restrict__ payload, uint32_t plen, uint32_t samples, X3DevParams p,
+                                     int16_t* __restrict__ out, int32_t* __restrict__ status) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *status = x3_replay_frame(payload, plen, samples, p, out);
 }
