@@ -6,7 +6,8 @@ Not part of the test suite (it runs as long as it is told to); a failure prints 
 Families: (e) the single-pass encoders on block_len 20 with mixed content, many frames and ragged tails;
           (g) arbitrary geometry / codes / thresholds; (d) decode of tampered streams with refreshed CRCs,
           truncations and header damage; (b) batches of clips through the device API; (a) .x3a archives in memory and
-          the incremental reader; (f) decode_frame frame by frame, with and without x3_decode_prefetch."""
+          the incremental reader; (f) decode_frame frame by frame, with and without x3_decode_prefetch; (w) WAV and .x3a FILES through the
+          chunked pipeline (not in the default family set: file I/O)."""
 import argparse, ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "x3-rust_amd"))
@@ -293,7 +294,58 @@ def fam_b(rng, tag):
             ctx.free(d)
 
 
-fams = {"e": fam_e, "g": fam_g, "d": fam_d, "b": fam_b, "a": fam_a, "f": fam_f}
+def _write_wav(path, wav, rate, extra=()):
+    import struct
+    data = np.ascontiguousarray(wav, dtype="<i2").tobytes()
+    fmt = struct.pack("<HHIIHH", 1, 1, rate, rate * 2, 2, 16)
+    body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt
+    for cid, payload in extra:
+        body += cid + struct.pack("<I", len(payload)) + payload + (b"\0" if len(payload) & 1 else b"")
+    body += b"data" + struct.pack("<I", len(data)) + data
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+
+def fam_w(rng, tag):
+    """files: x3_wav_to_x3a / x3_x3a_to_wav (chunked pipeline, random chunk sizes and worker counts) == the oracle's
+    wav_to_x3a / x3a_to_wav, byte for byte; damaged archives too"""
+    import tempfile
+    d = tempfile.mkdtemp(prefix="x3fz", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        rate = int(rng.choice([8000, 44100, 96000, 192000]))
+        n = int(rng.integers(0, 400000)) if rng.random() < 0.8 else int(rng.integers(0, 30))
+        wav = content(rng, n) if n else np.zeros(0, dtype=np.int16)
+        a, b_o, b_g, c_o, c_g = (os.path.join(d, x) for x in ("in.wav", "o.x3a", "g.x3a", "o.wav", "g.wav"))
+        extra = [(b"LIST", bytes(int(rng.integers(0, 9))))] if rng.random() < 0.3 else []
+        _write_wav(a, wav, rate, extra)
+        ctx.set_option("file_chunk_frames", int(rng.choice([1, 2, 3, 5, 16, 64])))
+        ctx.set_option("file_workers", int(rng.choice([1, 2, 3, 4])))
+        rc_o, st_o = O.wav_to_x3a(a, b_o)
+        rc_g, st_g = ctx.wav_to_x3a(a, b_g)
+        assert rc_g == rc_o, (tag, "w enc rc", rc_g, rc_o)
+        if rc_o == 0:
+            x_o, x_g = open(b_o, "rb").read(), open(b_g, "rb").read()
+            assert x_o == x_g and st_g.tolist() == st_o.tolist(), (tag, "w enc bytes", n, rate)
+            if rng.random() < 0.5 and len(x_o) > 400:
+                arch = np.frombuffer(x_o, dtype=np.uint8)
+                hdr = 28 + (int(arch[14]) << 8 | int(arch[15]))
+                offs = [hdr + o for o in frame_offsets(arch[hdr:])]
+                if offs:
+                    arch = damage(rng, arch, offs)
+                    open(b_o, "wb").write(bytes(arch))
+            r_o = O.x3a_to_wav(b_o, c_o)
+            r_g = ctx.x3a_to_wav(b_o, c_g)
+            assert tuple(r_g) == tuple(r_o), (tag, "w dec", r_g, r_o)
+            if os.path.exists(c_o) or os.path.exists(c_g):
+                assert open(c_o, "rb").read() == open(c_g, "rb").read(), (tag, "w dec bytes")
+    finally:
+        ctx.set_option("file_chunk_frames", 800)
+        ctx.set_option("file_workers", 4)
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
+
+
+fams = {"w": fam_w, "e": fam_e, "g": fam_g, "d": fam_d, "b": fam_b, "a": fam_a, "f": fam_f}
 
 
 def run(seed=1, minutes=None, trials=None, families="egdbaf", only=-1, context=None):
