@@ -237,7 +237,8 @@ void x3_bitreader_free(x3_bitreader* br);
  * x3_ctx_destroy. */
 int x3_decode_prefetch(x3_ctx* ctx, const uint8_t* x3, uint64_t len, const x3_params* p);
 
-/* `decoder::decode_block` (src/decoder.rs:132-145): wav[0..n) from the reader's position, *last_wav in and out. */
+/* `decoder::decode_block` (src/decoder.rs:132-145): wav[0..n) from the reader's position, *last_wav in and out.
+ * n <= 60 (MAX_BLOCK_LENGTH); n == 0 is the reference's empty slice (type bits read; a BFP block then fails or panics). */
 int x3_decode_block(x3_bitreader* br, int16_t* wav, uint32_t n, int16_t* last_wav, const x3_params* p);
 /* `BitPacker` (src/bitpacker.rs:46-177) over a slice writer at start_pos: write_bits / write_packed_zeros / word_align
  * are recorded; x3_bitpacker_finish (= flush, what Drop does) zero-pads a partial byte, packs all recorded fields on the

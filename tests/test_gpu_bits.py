@@ -171,6 +171,34 @@ def test_decode_block_kat(ctx):
         br.close()
 
 
+def test_decode_block_random_and_empty(ctx):
+    """decode_block over random bits, n = 0..25 samples (an EMPTY block reads its type bits; a BFP one then fails or hits
+    the reference's `wav[wav.len() - 1]` panic): status, samples, last_wav and the reader's state equal the oracle's"""
+    rng = np.random.default_rng(31)
+    L, OL = x3hip.lib(), O.lib()
+    p, op = x3hip.Params.default(), O.Params.default()
+    seen = set()
+    for trial in range(300):
+        x = rng.integers(0, 256, size=int(rng.integers(1, 80)), dtype=np.uint8)
+        if trial % 3 == 0:
+            x[0] &= 0x3F                                    # ftype 0: BFP / literal
+        n = int(rng.choice([0, 0, 1, 2, 19, 20, 25]))
+        last = int(rng.integers(-32768, 32768))
+        br = GpuReader(ctx, x)
+        obr = O.BitReader()
+        OL.x3o_br_new(C.byref(obr), x.ctypes.data, x.size)
+        wav, owav = np.zeros(max(n, 1), dtype=np.int16), np.zeros(max(n, 1), dtype=np.int16)
+        lw, olw = C.c_int16(last), C.c_int16(last)
+        rc = L.x3_decode_block(br.h, wav.ctypes.data, n, C.byref(lw), C.byref(p))
+        orc = OL.x3o_decode_block(C.byref(obr), owav.ctypes.data, n, C.byref(olw), C.byref(op))
+        assert rc == orc, (trial, n, rc, orc, x[:4].tolist())
+        seen.add((n == 0, rc))
+        if rc == 0:
+            assert np.array_equal(wav[:n], owav[:n]) and lw.value == olw.value, (trial, n)
+        br.close()
+    assert (True, 0) in seen and (True, x3hip.ERR_BAD_ARG) in seen and (True, x3hip.ERR_FRAME_DECODE_INVALID_BPF) in seen, seen
+
+
 def test_bitpacker_unbound_take(ctx):
     """a packer over "any other ByteWriter" (out = NULL): bytes delivered by x3_bitpacker_take in two flushes, at an odd
     writer position, equal the oracle's"""

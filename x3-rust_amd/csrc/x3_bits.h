@@ -140,7 +140,9 @@ extern "C" int x3_bitreader_state(const x3_bitreader* b, uint64_t* idx, uint32_t
 
 // decoder::decode_block (src/decoder.rs:132-145): wav[0..n) from the reader's position; *last_wav in and out
 extern "C" int x3_decode_block(x3_bitreader* b, int16_t* wav, uint32_t n, int16_t* last_wav, const x3_params* p) {
-  if (!b || !wav || !last_wav || !p || n == 0 || n > 60) return X3_ERR_BAD_ARG;  // MAX_BLOCK_LENGTH (x3.rs:90)
+  // n <= MAX_BLOCK_LENGTH (x3.rs:90: what an encoder can have produced).  n == 0 is an empty slice: the block's type
+  // bits are read, a Rice block is then done and a BFP block fails or panics (x3_replay_block)
+  if (!b || !wav || !last_wav || !p || n > 60) return X3_ERR_BAD_ARG;
   x3_ctx* c = b->c;
   X3DevParams dp;
   int rc = derive(p, spf_of(p) > 0xFFFFFFFFull ? 0 : spf_of(p), &dp);
