@@ -209,7 +209,9 @@ int x3_decode_frame(x3_ctx* ctx, const uint8_t* payload, uint64_t len, int16_t* 
  * payload fails to decode (counted in *frame_errors, return 0).  wav receives the samples of
  * the frames before the stop; *n_out their count; *frames_ok the number of good frames.
  * (Streams of 4 MiB and more are uploaded first and walked on the GPU, x3_index_dev's way; shorter ones are
- * walked on the host.  Same results either way.) */
+ * walked on the host.  Same results either way.)  wav_cap is this API's, not the reference's (x3a_to_wav writes to a
+ * file): a frame that does not fit behind the samples so far ends the walk with X3_ERR_BAD_ARG once its CRCs have
+ * passed -- also when an early block of that very frame would not have decoded. */
 int x3_decode_stream(x3_ctx* ctx, const uint8_t* x3, uint64_t len, const x3_params* p, int16_t* wav,
                      uint64_t wav_cap, uint64_t* n_out, uint64_t* frames_ok, uint64_t* frame_errors);
 
