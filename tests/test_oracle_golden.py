@@ -163,3 +163,25 @@ def test_decode_of_encoder_kat_roundtrips():
         rc, wav, fok, ferr = O.decode_stream(x3)
         assert (rc, fok, ferr) == (0, 1, 0)
         assert wav.tolist() == f["wav"]
+
+
+def test_oracle_decode_frame_with_block_len_zero():
+    """Parameters.block_len == 0 (parse_xml accepts <BLKLEN>0</BLKLEN>; nothing in the reference tests it -- followed
+    from source): decode_frame (decoder.rs:36-58) then hands decode_block EMPTY slices and `remaining_samples` never
+    moves.  Rice blocks (:147-196) loop over `0..wav.len()` = nothing and return Ok; decode_bpf_block (:209-235) reads
+    its exponent, returns FrameDecodeInvalidBPF for E + 1 <= 5 and otherwise panics on `wav[wav.len() - 1]`; behind the
+    payload the reader yields zeros, i.e. a BFP block with exponent 0."""
+    import numpy as np
+    p0 = O.Params.make(0, 500)
+    INVALID_BPF, BAD_ARG = 20, 24
+
+    def run(bits, samples=100):
+        bits = bits + "0" * (-len(bits) % 8)
+        payload = np.array([0x12, 0x34] + [int(bits[i:i + 8], 2) for i in range(0, len(bits), 8)], dtype=np.uint8)
+        return O.decode_frame(payload, samples, p0)[0]
+
+    assert run("01" "10" "11" "00" "0011") == INVALID_BPF          # three Rice types, then BFP with E + 1 = 4
+    assert run("00" "1111") == BAD_ARG                             # literal block (E + 1 = 16) of no samples: panic
+    assert run("11" * 7 + "00" "0101") == BAD_ARG                  # BFP with E + 1 = 6 of no samples: panic
+    assert run("01" * 64) == INVALID_BPF                           # Rice types to the end, then the zeros behind it
+    assert O.decode_frame(np.array([0x12, 0x34, 0xFF], dtype=np.uint8), 1, p0) [0] == 0   # one sample: no block at all
