@@ -374,6 +374,10 @@ def run(seed=1, minutes=None, trials=None, families="egdbaf", only=-1, context=N
     finally:
         if own:
             ctx.close()
+        else:  # a borrowed context goes back with the options the families touch at their defaults
+            for name, value in (("reader_window_frames", 4096), ("stream_v1", 0), ("host_walk", -1),
+                                ("file_chunk_frames", 800), ("file_workers", 4)):
+                ctx.set_option(name, value)
         ctx = None
     return counts
 
