@@ -257,16 +257,15 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
     HIPCHK(c, hipMalloc(&c->d_xk16, xk.size() * sizeof(uint32_t)));
     HIPCHK(c, hipMemcpy(c->d_xk16, xk.data(), xk.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     {
-      // x3_encode_stream2_kernel: KL[l] = x^(32*c*(63-l)), KA[w] = x^(32*c*64*(7-w)), each as its sixteen shifts
+      // x3_encode_stream2_kernel: KN[l] = nibble tables of x^(32*c*(63-l)), KA[w] = x^(32*c*64*(7-w)) as its sixteen shifts
       std::vector<uint32_t> k2((size_t)X3_K2_MAXC * X3_K2_DWORDS, 0u);
       for (int cd = 1; cd <= (int)X3_K2_MAXC; ++cd) {
         uint32_t* blk = k2.data() + (size_t)(cd - 1) * X3_K2_DWORDS;
         for (int l = 0; l < 64; ++l) {
-          uint32_t k = gf_xpow_host(32ull * cd * (63 - l));
-          for (int b = 0; b < 16; ++b) {
-            blk[l * X3_K2_ROW + b] = k;
-            k = ((k << 1) ^ ((k & 0x8000u) ? 0x11021u : 0u)) & 0xFFFFu;
-          }
+          const uint32_t k = gf_xpow_host(32ull * cd * (63 - l));
+          uint16_t* row = reinterpret_cast<uint16_t*>(blk + l * X3_K2_ROW);
+          for (int j = 0; j < 4; ++j)
+            for (uint32_t v = 0; v < 16; ++v) row[j * 16 + v] = (uint16_t)gf_mul_host(v << (4 * j), k);
         }
         for (int w = 0; w < 8; ++w) {
           uint32_t k = gf_xpow_host(32ull * cd * 64 * (7 - w));

@@ -61,13 +61,15 @@
 #define X3_K2_MAXC ((X3_STREAM2_MAX_PAYLOAD_DWORDS + X3E_CRC_LANES - 1u) / X3E_CRC_LANES)
 
 // CRC multipliers (x3_api.hip builds them, one block of X3_K2_DWORDS per chunk size c = 1..X3_K2_MAXC):
-//   KL[l][b], l < 64, rows of 20 dwords (16 used: the padding makes the per-lane ds_read_b128 conflict-free):
-//             x^(32*c*(63-l)) * x^b -- lane l's dwords are followed by c*(63-l) dwords of its WAVE's segment;
+//   KN[l][j][v], l < 64, j < 4, v < 16 (uint16; rows of 33 dwords, 32 used: consecutive lanes start one bank apart):
+//             (v << 4j) * x^(32*c*(63-l)) mod P -- lane l's dwords are followed by c*(63-l) dwords of its WAVE's segment,
+//             and its 16-bit partial is multiplied by that power nibble by nibble: four look-ups and ten instructions
+//             where sixteen pre-shifted words and their bit tests took 48;
 //   KA[w][b], w < 8: x^(32*c*64*(7-w)) * x^b -- a wave's segment is followed by those of the CRC waves behind it
 //             (CRC wave w of X3E_CRC_WAVES uses row 8 - X3E_CRC_WAVES + w).
-// crc0(payload) = XOR_w KA[w] * (XOR_l KL[l] * crc0(chunk of lane l of wave w)).  The block of the current chunk
-// size lives in LDS (5.5 KB; reloaded by the workgroup when c changes between frames, which it rarely does).
-#define X3_K2_ROW 20u
+// crc0(payload) = XOR_w KA[w] * (XOR_l KN[l] * crc0(chunk of lane l of wave w)).  The block of the current chunk
+// size lives in LDS (8.75 KB; reloaded by the workgroup when c changes between frames, which it rarely does).
+#define X3_K2_ROW 33u
 #define X3_K2_KA (64u * X3_K2_ROW)
 #define X3_K2_DWORDS (X3_K2_KA + 8u * 16u)
 
@@ -536,14 +538,12 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
         }
       }
       {
-        const uint4* kp = reinterpret_cast<const uint4*>(ktab + lane * X3_K2_ROW);
-        const uint4 kq0 = kp[0], kq1 = kp[1], kq2 = kp[2], kq3 = kp[3];
-        const uint32_t kk[16] = {kq0.x, kq0.y, kq0.z, kq0.w, kq1.x, kq1.y, kq1.z, kq1.w,
-                                 kq2.x, kq2.y, kq2.z, kq2.w, kq3.x, kq3.y, kq3.z, kq3.w};
-        uint32_t r = 0;
-#pragma unroll
-        for (int bit = 0; bit < 16; ++bit) r ^= (0u - ((crc >> bit) & 1u)) & kk[bit];
-        crc = r;
+        // times this lane's x^(32*c*(63-lane)): one 16-entry table per nibble (KN above)
+        const uint32_t rowb = x3_lds_addr(ktab) + lane * (X3_K2_ROW * 4u);
+        crc = (uint32_t)x3_lds_read_u16(rowb + ((crc & 15u) << 1), 0u) ^
+              (uint32_t)x3_lds_read_u16(rowb + (((crc >> 4) & 15u) << 1), 32u) ^
+              (uint32_t)x3_lds_read_u16(rowb + (((crc >> 8) & 15u) << 1), 64u) ^
+              (uint32_t)x3_lds_read_u16(rowb + (((crc >> 12) & 15u) << 1), 96u);
       }
       crc = x3_wave_xor_to_lane63_dpp(crc);
     }
