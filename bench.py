@@ -39,6 +39,51 @@ N_SAMPLES = 691_200_000  # config 3: 1 h @ 192 kHz mono
 SEED = 0x58330003
 
 
+def measure_traffic(n, kind, timeout=180):
+    """HBM bytes per launch and kernel from two rocprofv3 PMC passes over tools/kbench.py (the same kernels on the same
+    workload, three steps each) -> ({kernel: {...}}, source) or ({}, why not).  Counter units and the gfx950 correction
+    as in tools/make_traffic.py: KiB; FETCH_SIZE counts a 128-byte request of a 16-byte-per-lane read as 64 bytes."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    from collections import defaultdict
+    if shutil.which("rocprofv3") is None:
+        return {}, "rocprofv3 not found"
+    if any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return {}, "this run is itself under a profiler"
+    d = tempfile.mkdtemp(prefix="x3pmc_", dir="/tmp")
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", os.path.join(d, counter), "-o", "pmc",
+                   "--output-format", "csv", "--", sys.executable, os.path.join(ROOT, "tools", "kbench.py"),
+                   "--steps", "3", "--samples", str(n), "--kind", str(kind)]
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+            acc = defaultdict(list)
+            for f in glob.glob(os.path.join(d, counter, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == counter:
+                        acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+            vals[counter] = {k: sum(v) / len(v) for k, v in acc.items()}
+    except Exception as e:
+        return {}, "PMC pass failed: %s" % type(e).__name__
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    out = {}
+    for k in set(vals["FETCH_SIZE"]) | set(vals["WRITE_SIZE"]):
+        if k.startswith("x3_"):
+            fb = vals["FETCH_SIZE"].get(k, 0.0) * 1024 * 2
+            wb = vals["WRITE_SIZE"].get(k, 0.0) * 1024
+            out[k] = {"hbm_bytes_per_launch": int(fb + wb), "fetch_bytes": int(fb), "write_bytes": int(wb)}
+    if not out:
+        return {}, "the PMC passes returned no x3 kernels"
+    return out, ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over "
+                 "tools/kbench.py on the same workload; KiB x 1024, FETCH_SIZE x 2 (gfx950 128-byte requests)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,6 +98,8 @@ def main():
     ap.add_argument("--strong", action="store_true", help="strong scaling: --total-samples cut into N frame ranges")
     ap.add_argument("--total-samples", type=int, default=8 * N_SAMPLES, help="--strong: the whole stream (config 4: 8 h)")
     ap.add_argument("--no-verify-all", action="store_true", help="compare only sampled frames with the CPU oracle")
+    ap.add_argument("--no-measure-traffic", action="store_true",
+                    help="roofline.traffic from profiles/traffic.json instead of two rocprofv3 PMC passes run here")
     args = ap.parse_args()
 
     import numpy as np
@@ -355,11 +402,20 @@ def main():
         # the dominant kernel of the step's critical path: the frame check runs BESIDE the decoder on a second
         # stream (its co-running time is stretched by the decoder's waves), so it is reported but not a candidate
         dominant = max((k for k in alg if k != "frame_check"), key=lambda k: ktimes[k])
-        traffic = {}
-        try:  # HBM bytes per launch from rocprofv3 PMC passes (profiles/, see DESIGN.md "Measurement")
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        except Exception:
-            pass
+        # HBM bytes per launch: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- separate runs, MI355X_MICROARCH.md)
+        # of the same kernels on the same workload, run here as child processes once the timing is done; the recorded
+        # profiles/traffic.json when that is not possible (no rocprofv3, N > 1, already under a profiler)
+        traffic, traffic_source = {}, None
+        if world == 1 and not args.no_measure_traffic:
+            traffic, traffic_source = measure_traffic(n, args.kind)
+        if not traffic:
+            why = traffic_source
+            try:
+                traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+                traffic_source = "profiles/traffic.json (rocprofv3 PMC passes of this workload, recorded; not measured in this run%s)" % (
+                    ": " + why if why else "")
+            except Exception:
+                traffic, traffic_source = {}, "none"
 
         def roof(k):
             t = ktimes[k] / 1e3
@@ -367,7 +423,7 @@ def main():
             return {"bound": "hbm", "kernel": kname[k], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": traffic.get(kname[k], {}).get("hbm_bytes_per_launch"),
-                    "traffic_source": "profiles/traffic.json (rocprofv3 PMC passes of this command, recorded; not measured in this run)",
+                    "traffic_source": traffic_source,
                     "algorithmic_bytes": int(alg[k]), "avg_launch_ms": round(ktimes[k], 4)}
         secs = n / 192000.0
         kinds = {0: "all zeros", 1: "white noise", 2: "hydrophone-like noise", 3: "sine", 4: "random walk"}

@@ -47,6 +47,12 @@ def test_bench_small_run_prints_the_contract_line():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in j["cpu_baseline"], k
     assert j["host_buffer_api"]["encode_msamples_s"] > 0
+    # roofline.traffic is measured by the run itself (two rocprofv3 PMC passes as child processes) where rocprofv3 exists
+    import shutil
+    if shutil.which("rocprofv3"):
+        assert j["roofline"]["traffic_source"].startswith("measured in this run"), j["roofline"]["traffic_source"]
+        alg = j["roofline"]["algorithmic_bytes"]
+        assert 0.9 * alg < j["roofline"]["traffic"] < 1.3 * alg, (j["roofline"]["traffic"], alg)
 
 
 @pytest.mark.gpu
@@ -56,7 +62,7 @@ def test_bench_distributed_path_with_one_rank():
     env = dict(os.environ, X3_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                         "--master-addr", "127.0.0.1", "--master-port", "29517", BENCH, "--gpus", "1", "--steps", "2",
-                        "--warmup", "1", "--samples", "20000000", "--no-cpu-baseline"],
+                        "--warmup", "1", "--samples", "20000000", "--no-cpu-baseline", "--no-measure-traffic"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
