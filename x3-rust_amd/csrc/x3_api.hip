@@ -22,6 +22,7 @@
 #include "x3_encode_kernel.h"
 #include "x3_encode_stream_kernel.h"
 #include "x3_encode_stream2_kernel.h"
+#include "x3_encode_wave_kernel.h"
 #include "x3_synth_core.h"
 #include "x3_util_kernels.h"
 
@@ -43,6 +44,9 @@ struct X3Opts {
   int two_pass = 0;           // X3HIP_TWO_PASS: always use the two-pass encoder kernels
   int stream_wgs = 0;         // X3HIP_STREAM_WGS: workgroups per CU of the single-pass encoder (0 = derive)
   int stream_v1 = 0;          // X3HIP_STREAM_V1: the first-generation single-pass encoder (9 waves, LDS sample tile)
+  int enc_gen = 3;            // X3HIP_ENC_GEN: 3 = one wave per frame (x3_encode_wave_kernel.h), 2 = eight waves per frame
+  int wave_nwg = 0;           // X3HIP_WAVE_NWG: workgroups of the wave encoder (0 = one per CU, at most 256) -- tests: many generations on small inputs
+  int wave_m = 0;             // X3HIP_WAVE_M: frames per workgroup generation (0 = derive, 1..16)
   int decode_single = 0;      // X3HIP_DECODE_SINGLE: single-wave decoder kernels only
   int host_walk = -1;         // X3HIP_HOST_WALK: frame walk of x3_decode_stream on the host (1) / GPU (0) / by size (-1)
   int verbose = 0;            // X3HIP_VERBOSE
@@ -74,6 +78,7 @@ struct x3_ctx {
   uint16_t* d_xpow = nullptr;          // X3_XP_SIZE entries
   uint32_t* d_xk16 = nullptr;          // [11][512][16]: x^(32*c*(511-t)) * x^b mod P (x3_encode_stream_kernel.h)
   uint32_t* d_xk2 = nullptr;           // [X3_K2_MAXC][X3_K2_DWORDS]: per-lane and per-wave multipliers (x3_encode_stream2_kernel.h)
+  uint32_t* d_wtab = nullptr;          // X3W_TAB_BYTES: the LDS tables of x3_encode_wave_kernel
   uint16_t* d_crctab = nullptr;        // [6][256]: slicing-by-4 CRC tables + the two x^2048 rows
   uint32_t* d_kx64 = nullptr;          // [64][16] (x3_frame_check_kernel)
   uint16_t* d_chktab = nullptr;        // [18][256] (x3_frame_check_kernel: T[s][k][v] and the x^8192 rows)
@@ -103,6 +108,9 @@ struct x3_ctx {
   // bookkeeping of the last async calls
   bool encode_pending = false, decode_pending = false;
   bool force_two_pass = false;
+  bool force_gen2 = false;    // the call is being encoded again because a frame did not fit the wave encoder's image
+  int wave_skip = 0;          // calls the wave encoder sits out after such a launch (dense content)
+  unsigned long long encode_dense_reruns = 0;
   struct {
     const int16_t* d_wav; x3_batch b; x3_params p; uint64_t spf; uint8_t* d_out; uint64_t out_cap, start_pos; uint64_t* d_off;
   } last_enc;
@@ -162,6 +170,9 @@ static void opts_from_env(X3Opts* o) {
   o->stream_wgs = (int)std::max(0ll, geti("X3HIP_STREAM_WGS", 0));
   o->decode_single = std::getenv("X3HIP_DECODE_SINGLE") ? 1 : 0;
   o->stream_v1 = std::getenv("X3HIP_STREAM_V1") ? 1 : 0;
+  o->enc_gen = (int)geti("X3HIP_ENC_GEN", o->enc_gen) == 2 ? 2 : 3;
+  o->wave_nwg = (int)std::max(0ll, std::min(256ll, geti("X3HIP_WAVE_NWG", 0)));
+  o->wave_m = (int)std::max(0ll, std::min(16ll, geti("X3HIP_WAVE_M", 0)));
   if (const char* e = std::getenv("X3HIP_HOST_WALK")) o->host_walk = e[0] == '0' ? 0 : 1;
   o->verbose = std::getenv("X3HIP_VERBOSE") ? 1 : 0;
   o->file_chunk_frames = std::max(1ll, geti("X3HIP_FILE_CHUNK_FRAMES", o->file_chunk_frames));
@@ -323,6 +334,27 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
       HIPCHK(c, hipMalloc(&c->d_xinv8, xi.size() * sizeof(uint16_t)));
       HIPCHK(c, hipMemcpy(c->d_xinv8, xi.data(), xi.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
+    {
+      // x3_encode_wave_kernel: the six rows above, then per lane the sixteen shifts of x^(32*(63-t)) as uint16, then x^(-16k)
+      std::vector<uint16_t> wt(X3W_TAB_BYTES / 2);
+      for (size_t i = 0; i < tab.size(); ++i) wt[i] = tab[i];
+      for (int t = 0; t < 64; ++t) {
+        uint32_t k = gf_xpow_host(32ull * (63 - t));
+        for (int b = 0; b < 16; ++b) {
+          wt[1536 + (size_t)t * 16 + b] = (uint16_t)k;
+          k = ((k << 1) ^ ((k & 0x8000u) ? 0x11021u : 0u)) & 0xFFFFu;
+        }
+      }
+      // x^(-16k), k < 128 (x has order 32767 modulo P): undoes the zero bytes behind a payload in its last image row
+      for (uint64_t k = 0; k < 128; ++k) wt[2560 + k] = (uint16_t)gf_xpow_host((32767ull * 16 - 16ull * k) % 32767ull);
+      // (v << 8) * x^4096 and v * x^4096: a 16-bit state two rows of 64 dwords on
+      for (int v = 0; v < 256; ++v) {
+        wt[2688 + v] = (uint16_t)gf_mul_host((uint32_t)v, gf_xpow_host(4096 + 8));
+        wt[2944 + v] = (uint16_t)gf_mul_host((uint32_t)v, gf_xpow_host(4096));
+      }
+      HIPCHK(c, hipMalloc(&c->d_wtab, X3W_TAB_BYTES));
+      HIPCHK(c, hipMemcpy(c->d_wtab, wt.data(), X3W_TAB_BYTES, hipMemcpyHostToDevice));
+    }
     HIPCHK(c, hipMalloc(&c->d_crctab, tab.size() * sizeof(uint16_t)));
     HIPCHK(c, hipMemcpy(c->d_crctab, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   }
@@ -373,6 +405,7 @@ extern "C" void x3_ctx_destroy(x3_ctx* c) {
   (void)hipFree(c->d_xpow);
   (void)hipFree(c->d_xk16);
   (void)hipFree(c->d_xk2);
+  (void)hipFree(c->d_wtab);
   (void)hipFree(c->d_crctab);
   (void)hipFree(c->d_kx64);
   (void)hipFree(c->d_chktab);
@@ -407,6 +440,9 @@ extern "C" int x3_ctx_set_option(x3_ctx* c, const char* name, long long value) {
   else if (n == "stream_wgs") { c->opt.stream_wgs = (int)std::max(0ll, value); c->stream_wg_per_cu = -1; }
   else if (n == "decode_single") c->opt.decode_single = value != 0;
   else if (n == "stream_v1") { c->opt.stream_v1 = value != 0; c->stream_wg_per_cu = -1; }
+  else if (n == "enc_gen") { c->opt.enc_gen = value == 2 ? 2 : 3; c->wave_skip = 0; }
+  else if (n == "wave_nwg") c->opt.wave_nwg = (int)std::max(0ll, std::min(256ll, value));
+  else if (n == "wave_m") c->opt.wave_m = (int)std::max(0ll, std::min(16ll, value));
   else if (n == "host_walk") c->opt.host_walk = value < 0 ? -1 : (value != 0);
   else if (n == "verbose") c->opt.verbose = value != 0;
   else if (n == "file_chunk_frames") c->opt.file_chunk_frames = std::max(1ll, value);
@@ -426,6 +462,8 @@ extern "C" int x3_ctx_get_option(const x3_ctx* c, const char* name, long long* v
   else if (n == "stream_wgs") *value = c->opt.stream_wgs;
   else if (n == "decode_single") *value = c->opt.decode_single;
   else if (n == "stream_v1") *value = c->opt.stream_v1;
+  else if (n == "enc_gen") *value = c->opt.enc_gen;
+  else if (n == "encode_dense_reruns") *value = (long long)c->encode_dense_reruns;  // read-only counter
   else if (n == "host_walk") *value = c->opt.host_walk;
   else if (n == "verbose") *value = c->opt.verbose;
   else if (n == "file_chunk_frames") *value = c->opt.file_chunk_frames;
@@ -778,6 +816,62 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
                            (b->n_clips == 1 || (b->clip_stride % 8) == 0) &&
                            (reinterpret_cast<uintptr_t>(d_wav) & 15u) == 0 && !c->force_two_pass && !c->opt.two_pass;
   c->last_enc = {d_wav, *b, *p, spf, d_out, out_cap, start_pos, d_frame_offsets};
+  if (stream_path && !c->opt.stream_v1 && c->opt.enc_gen == 3 && !c->force_gen2 && c->opt.stream_wgs == 0 &&
+      stream_safe_thresholds(p)) {
+    if (c->wave_skip > 0) {
+      --c->wave_skip;  // the last launch met frames that do not fit the image: a few calls with the second generation
+    } else {
+      // third generation (x3_encode_wave_kernel.h): one wave per frame, sixteen waves per CU, one workgroup per CU
+      static_assert(X3W_SMEM <= 160 * 1024, "LDS");
+      HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_wave_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3W_SMEM));
+      uint64_t nwg_max = std::min<uint64_t>((uint64_t)c->n_cus, X3W_MAX_NWG);
+      if (c->opt.wave_nwg > 0) nwg_max = std::min<uint64_t>(nwg_max, (uint64_t)c->opt.wave_nwg);
+      X3WaveArgs wa;
+      wa.m = (uint32_t)std::min<uint64_t>(X3W_WAVES, (F + nwg_max - 1) / nwg_max);
+      if (c->opt.wave_m > 0) wa.m = (uint32_t)c->opt.wave_m;
+      const uint64_t n_wggen = (F + wa.m - 1) / wa.m;
+      wa.nwg = (uint32_t)std::min<uint64_t>(nwg_max, n_wggen);
+      wa.n_wggen = (uint32_t)n_wggen;
+      const uint64_t step = (uint64_t)wa.nwg * wa.m;
+      wa.step_clip = (uint32_t)(step / pl.g.fpc);
+      wa.step_idx = (uint32_t)(step % pl.g.fpc);
+      const size_t desc_bytes = (n_wggen + X3W_DESC_PAD) * sizeof(uint32_t);
+      const bool fresh = c->desc.cap < desc_bytes;
+      if ((rc = ensure(c, c->desc, desc_bytes))) return rc;
+      if (fresh || ++c->desc_epoch > 0xFFFu) {
+        HIPCHK(c, hipMemsetAsync(c->desc.p, 0, c->desc.cap, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_pace + 4, 0, 16, c->stream));
+        c->desc_epoch = 1;
+      }
+      wa.wav = d_wav;
+      wa.out = d_out;
+      wa.frame_off = d_off;
+      wa.desc = (uint32_t*)c->desc.p + X3W_DESC_PAD;
+      wa.ctl = reinterpret_cast<unsigned char*>(c->d_status);
+      wa.tabs = c->d_wtab;
+      wa.out_cap = out_cap;
+      wa.start_pos = start_pos;
+      wa.n_per_clip = pl.g.n_per_clip;
+      wa.clip_stride = pl.g.clip_stride;
+      wa.n_frames = F;
+      wa.fpc = pl.g.fpc;
+      wa.spf = pl.dp.spf;
+      wa.epoch = c->desc_epoch;
+      wa.thr0 = pl.dp.thr[0];
+      wa.thr1 = pl.dp.thr[1];
+      wa.thr2 = pl.dp.thr[2];
+      wa.kpack = pl.dp.k[0] | (pl.dp.k[1] << 8) | (pl.dp.k[2] << 16);
+      {
+        TimerScope ts(c, 0);
+        hipLaunchKernelGGL(x3_encode_wave_kernel, dim3(wa.nwg), dim3(X3W_THREADS), X3W_SMEM, c->stream, wa);
+      }
+      HIPCHK(c, hipGetLastError());
+      c->encode_pending = true;
+      c->enc_start_pos = start_pos;
+      return X3_OK;
+    }
+  }
   if (stream_path && !c->opt.stream_v1 && stream_safe_thresholds(p)) {
     // second generation (x3_encode_stream2_kernel.h): eight waves, no sample tile in LDS
     // part + two frame images + CRC tables + the multipliers of one chunk size
@@ -936,7 +1030,24 @@ extern "C" int x3_encode_result(x3_ctx* c, uint64_t* out_pos, uint64_t stats[6])
   HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_status, 128, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->encode_pending = false;
+  if (c->h_status[1] == X3D_IMAGE_OVERFLOW) {
+    // a frame of this call did not fit the wave encoder's LDS image (dense content: more than 9 728 payload bytes):
+    // the call is encoded again by the second-generation kernel, which holds worst-case images
+    ++c->encode_dense_reruns;
+    c->wave_skip = 8;
+    c->force_gen2 = true;
+    auto a = c->last_enc;
+    int rc = encode_dev_impl(c, a.d_wav, &a.b, &a.p, a.spf, a.d_out, a.out_cap, a.start_pos, a.d_off);
+    c->force_gen2 = false;
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_status, 128, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->encode_pending = false;
+  }
   if (c->h_status[1] == X3D_SIZE_WAIT_TIMEOUT) {
+    if (c->opt.verbose)
+      std::fprintf(stderr, "x3hip: size wait gave up: kind %d generation %d wave %d gen %d masks %08x %08x %06x\n", c->h_status[2],
+                   c->h_status[3], c->h_status[4] & 0xFF, c->h_status[4] >> 8, c->h_status[5], c->h_status[6], c->h_status[7]);
     // the single-pass kernel's workgroups were not all resident (GPU shared with other work): its
     // bounded wait for frame sizes gave up.  Encode again with the two-pass kernels, which need no residency.
     ++c->encode_fallbacks;

@@ -1,0 +1,782 @@
+// x3_encode_wave_kernel.h -- single-pass frame encoder for block_len = 20, third generation: ONE WAVE PER FRAME.
+//
+// Replaces encoder::encode / encode_frame / x3_encode_block / encode_rice_block / encode_bfp_block / encode_literal
+// (src/encoder.rs:51-315), BitPacker (src/bitpacker.rs:46-177) and the running crc16 (src/crc.rs:44-58).
+//
+// The second generation (x3_encode_stream2_kernel.h: eight waves per frame, one block of 20 samples per lane) is bound by
+// VALU issue, and about half of its 565 vector instructions per wave and frame do not depend on the number of
+// samples: bit-length scans, the size words, CRC multipliers and reductions, header, copy-out bookkeeping, three
+// barriers (profiles/r2/pmc_sq.txt).  Here that part is paid once per FRAME instead of once per 1 280 samples:
+//
+//  * a frame (<= 10 240 samples) belongs to ONE wave: two half-frames of 5 120 samples, a lane takes FOUR consecutive
+//    blocks (80 samples, 160 contiguous bytes) of each.  Consecutive blocks share one bit accumulator: one start
+//    position, one final flush per lane and half.  No barrier anywhere in the frame loop -- everything between lanes is
+//    DPP or the wave's own LDS image (a wave's DS instructions execute in order);
+//  * sixteen such waves per CU (one workgroup of 1 024 threads, <= 128 VGPRs) share 5 KB of CRC tables; each has a
+//    frame image of 38 rows x 256 B in LDS.  The samples of both halves live in registers (2 x 41 dwords) and are
+//    turned IN PLACE into the emission source (zigzag / difference / raw per pair) by the analysis; the next frame's
+//    halves are requested as soon as the emission has consumed a half and fly under the rest of the frame;
+//  * the frame loop is skewed: a frame's size is published right behind the analysis of its two halves, at the top of
+//    an iteration, and its offset is asked for one iteration LATER, behind the analysis of the next frame (the image
+//    waits in LDS meanwhile).  A frame's offset needs the sizes of the up to 4 095 frames in front of it that are in
+//    flight; with the size out at 20 % of a frame's work and the offset due at 120 %, a wave waits only for waves that
+//    are a whole frame behind it (measured without the skew: a third of every wave's time, tools/scratch/dbg_stamps_wave.py);
+//  * payload CRC-16: lane t folds dword t of every 64-dword row of the image Horner-style (times x^2048 per row: two
+//    look-ups, plus the slicing-by-4 look-ups of the dword; the 0xFFFF init is folded into the first 16 payload
+//    bits), multiplies by its fixed x^(32*(63-t)), the lanes are XOR-reduced by DPP, and the zero bytes between the
+//    payload's end and the end of its last row are undone by one multiplication with x^(-8 z): no per-size tables;
+//  * stream offsets: the sixteen frames of a workgroup's generation are CONSECUTIVE frames; their sizes meet in LDS
+//    (slot + arrival counter, the last arriver publishes the generation's total as one {epoch:12 | bytes:20} word),
+//    and a generation's base is its predecessor's base plus the <= 256 totals in between (x3_encode_stream_kernel.h's
+//    scheme, one level up).  A wave asks for those words when its emission is done and prefetches the next frame's
+//    samples behind the request.
+//
+// A frame whose payload does not fit the image (> 9 728 bytes: dense content) flags the launch; x3_encode_result then
+// runs the call again with the second-generation kernel, and the context remembers (x3_api.hip).
+#pragma once
+#include "x3_encode_stream2_kernel.h"
+
+#ifndef X3W_EXP
+#define X3W_EXP 0
+#endif
+#ifndef X3W_PRIO
+#define X3W_PRIO 1  // 1: priorities from the arrival rank in the workgroup's generation; >= 2: this priority until the size is out; 0: none
+#endif
+#define X3W_WAVES 16u
+#define X3W_THREADS (64u * X3W_WAVES)
+#define X3W_TAB_BYTES 6400u   // T0..T3 slicing-by-4, T4/T5 "times x^2048" (6 x 256 x u16), lane weights 64 x 16 x u16, x^(-16k) k < 128, T6/T7 "times x^4096"
+#define X3W_BOOK_BYTES 1024u
+#define X3W_IMG_ROWS 38u
+#define X3W_IMG_BYTES (X3W_IMG_ROWS * 256u)
+#define X3W_SMEM (X3W_TAB_BYTES + X3W_BOOK_BYTES + X3W_WAVES * X3W_IMG_BYTES)  // 163 072 of 163 840
+#define X3W_PART 5120u         // samples per part: 64 lanes x 4 blocks x 20
+#define X3W_MAX_NWG 256u      // a generation's base sums at most this many totals: four words per lane
+#define X3W_DESC_PAD 320u     // words in front of desc[0]: the windows of the first generation reach below 0
+#define X3D_IMAGE_OVERFLOW 101  // internal: a frame did not fit its LDS image (x3_encode_result re-runs the call)
+
+struct X3WaveArgs {
+  const int16_t* wav;
+  uint8_t* out;
+  uint64_t* frame_off;
+  uint32_t* desc;           // one word per workgroup generation, X3W_DESC_PAD words in front
+  unsigned char* ctl;       // int status[8] | u64 stats[6] | u64 end_pos
+  const uint32_t* tabs;     // X3W_TAB_BYTES
+  uint64_t out_cap, start_pos, n_per_clip, clip_stride, n_frames;
+  uint32_t fpc, spf, epoch;
+  uint32_t m;               // frames per workgroup generation = active waves per workgroup (1..16)
+  uint32_t nwg;             // workgroups (<= X3W_MAX_NWG)
+  uint32_t n_wggen;         // ceil(n_frames / m)
+  uint32_t step_clip, step_idx;  // (nwg * m) frames as clips + frames
+  uint32_t thr0, thr1, thr2, kpack;
+};
+
+__device__ __forceinline__ uint32_t x3_pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// the wave's LDS traffic between lanes needs no barrier (DS instructions of a wave execute in order); this only
+// keeps the compiler from moving LDS accesses across the point
+__device__ __forceinline__ void x3w_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); asm volatile("" ::: "memory"); }
+
+// ---- analysis of block Q of a lane's four (x3_encode_block, encoder.rs:289-315).  X[10Q .. 10Q+10] hold samples
+// 20Q .. 20Q+21 of the lane's run as (even, odd) pairs; the block is samples 20Q+1 .. 20Q+20, predicted from 20Q.
+// cnt is 20, 19 (the last block of a full frame) or 0 (behind the frame): frames with any other block take the generic
+// path below.  X[10Q .. 10Q+9] are REPLACED, pair by pair, by the emission source (zigzag / exact difference / raw samples;
+// X[10Q+10], the next block's first word, stays) and meta (15 bits) says how to emit it:
+// hdr value [0..5] | bits per field [6..10] | Rice [11] | statistics index [12..14]; 0: no block.
+// No temporaries survive a pair (the registers are full: two halves of a frame); the rare literal block, whose raw
+// samples the saturated differences no longer hold, reads its 44 bytes again (rs, vo: the lane's run in the frame).
+template <int Q>
+__device__ __forceinline__ void x3w_analyse(uint32_t (&X)[41], uint32_t cnt, uint32_t thr0, uint32_t thr1, uint32_t thr2,
+                                            uint32_t kpack, __amdgpu_buffer_rsrc_t rs, uint32_t vo, uint32_t so,
+                                            uint32_t& nbits, uint32_t& meta) {
+  constexpr int B = 10 * Q;
+  uint32_t mn = 0, mx = 0;
+#pragma unroll
+  for (int j = 0; j < 10; ++j) {
+    const uint32_t Xj = __builtin_amdgcn_alignbit(X[B + j + 1], X[B + j], 16);  // (s[2j+1], s[2j+2])
+    uint32_t d = x3_pk_sub_sat(Xj, X[B + j]);                                    // (d[2j+1], d[2j+2]), saturated
+    if (j == 9) d &= cnt == 20u ? 0xFFFFFFFFu : 0x0000FFFFu;                     // a 19-sample block has no sample 20
+    X[B + j] = d;
+    mn = x3_pk_min_i16(mn, d);
+    mx = x3_pk_max_i16(mx, d);
+  }
+  const int32_t dmin = min((int32_t)(int16_t)(mn & 0xFFFFu), (int32_t)mn >> 16);
+  const int32_t dmax = max((int32_t)(int16_t)(mx & 0xFFFFu), (int32_t)mx >> 16);
+  const int32_t maxabs = (-dmin) > dmax ? (-dmin) : dmax;
+  uint32_t nb_ = 0, mt = 0;
+  if (maxabs <= (int32_t)thr2) {
+    const uint32_t ft = (maxabs > (int32_t)thr0 ? 1u : 0u) + (maxabs > (int32_t)thr1 ? 1u : 0u);
+    const uint32_t k = (kpack >> (8u * ft)) & 0xFFu;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      const uint32_t z = x3_pk_shl_b16(X[B + j], 1) ^ x3_pk_sar_i16(X[B + j], 15);  // zigzag, per half (0 stays 0)
+      X[B + j] = z;
+      sum = x3_pk_add_u16(sum, x3_pk_shr_u16(z, k));
+    }
+    nb_ = 2u + cnt * (k + 1u) + (sum & 0xFFFFu) + (sum >> 16);
+    mt = (ft + 1u) | ((k + 1u) << 6) | (1u << 11) | (k << 12);
+  } else {
+    const uint32_t nb = 32u - (uint32_t)__clz(maxabs);
+    if (nb >= 15u) {
+      nb_ = 6u + 16u * cnt;
+      // raw samples: the block's dwords again (range-checked as the first time: zeros behind the frame)
+      uint32_t prev = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(vo + 4u * B), (int)so, 0);
+#pragma unroll
+      for (int j = 0; j < 10; ++j) {
+        const uint32_t nxt = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(vo + 4u * (B + j + 1)), (int)so, 0);
+        X[B + j] = __builtin_amdgcn_alignbit(nxt, prev, 16);
+        prev = nxt;
+      }
+      mt = 15u | (16u << 6) | (5u << 12);
+    } else {
+      nb_ = 6u + cnt * (nb + 1u);  // X holds the exact differences (|d| < 16 384: nothing was saturated)
+      mt = nb | ((nb + 1u) << 6) | (4u << 12);
+    }
+  }
+  nbits = cnt ? nb_ : 0u;
+  meta = cnt ? mt : 0u;
+}
+
+// ---- the generic path: frames whose last block has 1..18 samples (the ragged tail frame of a clip).  Sample by
+// sample from memory as the reference does it (x3_encode_block, encoder.rs:289-315), in 32-bit arithmetic; it shares
+// nothing with the register arrays of the fast path.  bi: block index in the frame, cnt: its samples (1..20).
+__device__ __forceinline__ int32_t x3w_sample(__amdgpu_buffer_rsrc_t rs, uint32_t i) {
+  return (int32_t)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)(2u * i), 0, 0);
+}
+__device__ __forceinline__ void x3w_slow_analyse(__amdgpu_buffer_rsrc_t rs, uint32_t bi, uint32_t cnt, uint32_t thr0,
+                                                 uint32_t thr1, uint32_t thr2, uint32_t kpack, uint32_t& nbits, uint32_t& meta) {
+  nbits = 0;
+  meta = 0;
+  if (cnt == 0) return;
+  int32_t prev = x3w_sample(rs, 20u * bi), maxabs = 0;
+  for (uint32_t i = 1; i <= cnt; ++i) {
+    const int32_t sv = x3w_sample(rs, 20u * bi + i), d = sv - prev;
+    prev = sv;
+    maxabs = max(maxabs, d < 0 ? -d : d);
+  }
+  if (maxabs <= (int32_t)thr2) {
+    const uint32_t ft = (maxabs > (int32_t)thr0 ? 1u : 0u) + (maxabs > (int32_t)thr1 ? 1u : 0u);
+    const uint32_t k = (kpack >> (8u * ft)) & 0xFFu;
+    uint32_t sum = 0;
+    prev = x3w_sample(rs, 20u * bi);
+    for (uint32_t i = 1; i <= cnt; ++i) {
+      const int32_t sv = x3w_sample(rs, 20u * bi + i), d = sv - prev;
+      prev = sv;
+      const uint32_t u = d >= 0 ? 2u * (uint32_t)d : 2u * (uint32_t)(-d) - 1u;
+      sum += u >> k;
+    }
+    nbits = 2u + cnt * (k + 1u) + sum;
+    meta = (ft + 1u) | ((k + 1u) << 6) | (1u << 11) | (k << 12);
+  } else {
+    const uint32_t nb = 32u - (uint32_t)__clz(maxabs);
+    if (nb >= 15u) {
+      nbits = 6u + 16u * cnt;
+      meta = 15u | (16u << 6) | (5u << 12);
+    } else {
+      nbits = 6u + cnt * (nb + 1u);
+      meta = nb | ((nb + 1u) << 6) | (4u << 12);
+    }
+  }
+}
+struct X3WEmit;
+__device__ __forceinline__ void x3w_slow_emit(__amdgpu_buffer_rsrc_t rs, uint32_t bi, uint32_t cnt, uint32_t meta, X3WEmit& e);
+
+struct X3WEmit {
+  uint64_t acc;    // low `pend` bits are waiting for their word
+  uint32_t pend;
+  uint32_t waddr;  // LDS byte address of the word the accumulator flushes to
+  __device__ __forceinline__ void put(uint32_t code, uint32_t len) {  // len <= 32, code < 2^len
+    acc = (acc << len) | (unsigned long long)code;
+    pend += len;
+    if (pend >= 32u) {
+      pend -= 32u;
+      x3_lds_or_b32(waddr, (uint32_t)(acc >> pend));
+      waddr += 4u;
+    }
+  }
+  __device__ __forceinline__ void finish() {
+    if (pend) x3_lds_or_b32(waddr, (uint32_t)(acc << (32u - pend)));
+  }
+};
+
+// ---- emission of block Q (encode_rice_block / encode_bfp_block / encode_literal, encoder.rs:233-285): the image
+// holds the stream's bytes as big-endian dword VALUES (bit 31 of a word = the first bit of the stream in it).
+template <int Q>
+__device__ __forceinline__ void x3w_emit(const uint32_t (&W)[41], uint32_t meta, uint32_t cnt, X3WEmit& e) {
+  constexpr int B = 10 * Q;
+  if (meta) {
+    const uint32_t lbase = (meta >> 6) & 31u, rice = (meta >> 11) & 1u;
+    const uint32_t kq = lbase - rice;
+    e.put(meta & 63u, rice ? 2u : 6u);
+    // (code, len) of a sample v: ((v & amask) | orc, (v >> kq) * rice + lbase) -- both samples of a pair at once in
+    // packed 16-bit arithmetic, the halves combined with SDWA operand selects (x3_encode_stream_kernel.h)
+    const uint32_t qsh2 = kq * 0x10001u, lbase2 = lbase * 0x10001u, qmul2 = rice * 0x10001u;
+    const uint32_t amask2 = ((1u << kq) - 1u) * 0x10001u, orc2 = (rice << kq) * 0x10001u;
+    const uint32_t last_on = cnt == 20u ? 0xFFFFFFFFu : 0x0000FFFFu;
+    uint64_t acc = e.acc;
+    uint32_t pend = e.pend, waddr = e.waddr;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      uint32_t Lp = x3_pk_mad_u16(x3_pk_lshr_b16(W[B + j], qsh2), qmul2, lbase2);  // (la, lc)
+      uint32_t Cp = x3_and_or(W[B + j], amask2, orc2);                              // (ca, cc)
+      if (j == 9) { Lp &= last_on; Cp &= last_on; }
+      const uint32_t tot = x3_sdwa_add_w0_w1(Lp);                                   // la + lc <= 32
+      const uint32_t pair = x3_sdwa_or_w1(x3_sdwa_shl_w0_by_w1(Cp, Lp), Cp);        // (ca << lc) | cc
+      acc = (acc << tot) | (unsigned long long)pair;
+      pend += tot;
+#if X3W_EXP == 1   /* timing experiment: no LDS atomics */
+      if (pend >= 32u) {
+        pend -= 32u;
+        waddr += 4u + (uint32_t)(acc >> pend);
+      }
+#elif X3W_EXP == 2 /* timing experiment: no branch, flush always */
+      {
+        const uint32_t fl = pend >> 5;
+        pend &= 31u;
+        x3_lds_or_b32(waddr, (uint32_t)(acc >> pend));
+        waddr += 4u * fl;
+      }
+#else
+      if (pend >= 32u) {
+        pend -= 32u;
+        x3_lds_or_b32(waddr, (uint32_t)(acc >> pend));
+        waddr += 4u;
+      }
+#endif
+    }
+    e.acc = acc;
+    e.pend = pend;
+    e.waddr = waddr;
+  }
+}
+
+__device__ __forceinline__ void x3w_slow_emit(__amdgpu_buffer_rsrc_t rs, uint32_t bi, uint32_t cnt, uint32_t meta, X3WEmit& e) {
+  if (meta == 0) return;
+  const uint32_t lbase = (meta >> 6) & 31u, rice = (meta >> 11) & 1u;
+  e.put(meta & 63u, rice ? 2u : 6u);
+  int32_t prev = x3w_sample(rs, 20u * bi);
+  for (uint32_t i = 1; i <= cnt; ++i) {
+    const int32_t sv = x3w_sample(rs, 20u * bi + i), d = sv - prev;
+    prev = sv;
+    if (rice) {
+      const uint32_t k = lbase - 1u;
+      const uint32_t u = d >= 0 ? 2u * (uint32_t)d : 2u * (uint32_t)(-d) - 1u;
+      e.put((1u << k) | (u & ((1u << k) - 1u)), (u >> k) + k + 1u);   // (u >> k) zeros, then 1 and the k low bits
+    } else if (lbase == 16u) {
+      e.put((uint32_t)sv & 0xFFFFu, 16u);                             // literal: the raw sample
+    } else {
+      e.put((uint32_t)d & ((1u << lbase) - 1u), lbase);               // BFP: the difference in nb + 1 bits
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t x3w_cnt_of(int32_t rem, int q) {
+  const int32_t c = rem - 20 * q;
+  return c <= 0 ? 0u : (c < 20 ? (uint32_t)c : 20u);
+}
+
+__global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t* const tab = reinterpret_cast<uint16_t*>(smem);
+  uint32_t* const book = reinterpret_cast<uint32_t*>(smem + X3W_TAB_BYTES);
+  // book: [0..127] size slots {tag:12 | bytes:20} of the waves, eight generations (a wave is at most a few generations
+  //       ahead of another one of its workgroup: it passes generation g+1 only behind the total of g, which every wave
+  //       has contributed to); [128..135] arrival counters; [136] waves that have left; [140..145] statistics
+  const uint32_t tid = threadIdx.x;
+  uint32_t lane = tid & 63u;
+  const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  uint32_t* const img = reinterpret_cast<uint32_t*>(smem + X3W_TAB_BYTES + X3W_BOOK_BYTES + w * X3W_IMG_BYTES);
+  const uint32_t img_addr = x3_lds_addr(img);
+  const uint32_t tab_base = x3_lds_addr(tab);
+  int* const status = reinterpret_cast<int*>(a.ctl);
+  unsigned long long* const stats = reinterpret_cast<unsigned long long*>(a.ctl + 32);
+  unsigned long long* const end_pos = stats + 6;
+
+  // ---- prologue: tables, bookkeeping, clear images
+  for (uint32_t i = tid; i < X3W_TAB_BYTES / 4u; i += X3W_THREADS) reinterpret_cast<uint32_t*>(smem)[i] = a.tabs[i];
+  if (tid < X3W_BOOK_BYTES / 4u) book[tid] = 0;
+  for (uint32_t i = lane; i < X3W_IMG_BYTES / 16u; i += 64u) reinterpret_cast<uint4*>(img)[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  if (w >= a.m) return;  // (whole waves; nothing below is a workgroup barrier)
+
+  const uint32_t b = blockIdx.x;
+  const uint32_t ready_tag = a.epoch << X3_DESC_BYTES_BITS;
+
+  // frame of generation 0: f = b * m + w as (clip, idx); advanced by nwg * m frames per generation
+  uint64_t clip;
+  uint32_t idx;
+  {
+    const uint64_t f0 = (uint64_t)b * a.m + w;
+    clip = f0 / a.fpc;
+    idx = (uint32_t)(f0 - clip * a.fpc);
+  }
+  auto geom_at = [&](uint64_t clip_, uint32_t idx_, const int16_t*& src, uint32_t& n) __attribute__((always_inline)) {
+    const uint64_t left = a.n_per_clip - (uint64_t)idx_ * (uint64_t)a.spf;
+    n = left < a.spf ? (uint32_t)left : a.spf;
+    src = a.wav + clip_ * a.clip_stride + (uint64_t)idx_ * (uint64_t)a.spf;
+  };
+
+  // a lane's run of half h of a frame of n samples at src: samples 5120 h + 80 l .. + 81 as 41 (even, odd) pairs.
+  // Range-checked buffer loads (descriptor = the frame): dwords behind the frame read as zero.
+  uint32_t X0[41], X1[41];
+  auto load_half = [&](uint32_t (&X)[41], const int16_t* src, uint32_t n, uint32_t h) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(src), 0, (int)((2u * n + 3u) & ~3u), 0x00020000);
+    uint32_t vo = 160u * lane;
+    // (opaque: hipcc otherwise hoists the sums vo + 16 i out of the frame loop into registers of their own; inside
+    // the loop they fold into the instructions' immediate offsets)
+    asm volatile("" : "+v"(vo));
+    const uint32_t so = 2u * X3W_PART * h;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const x3_v4u32 q = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(vo + 16u * i), (int)so, 0);
+      X[4 * i] = q.x; X[4 * i + 1] = q.y; X[4 * i + 2] = q.z; X[4 * i + 3] = q.w;
+    }
+    X[40] = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(vo + 160u), (int)so, 0);
+  };
+
+  uint64_t gen_base = 0;   // stream offset of the generation of the frame in waiting (its workgroup's base)
+  uint32_t gen = 0;
+  uint64_t wgi = b, f = 0;
+  const int16_t* src = nullptr;
+  uint32_t n = 0;
+  bool lost = false;       // a size wait timed out: this wave no longer knows where its frames go
+  uint32_t rank = 0;       // how many waves of the workgroup had published their size of the last generation before this one
+
+  // the frame in waiting: emitted and summed, its image in LDS, its offset not asked for yet
+  bool have_prev = false, prev_ovf = false;
+  uint64_t prev_f = 0, prev_wgi = 0;
+  uint32_t prev_n = 0, prev_L = 0, prev_crc = 0, prev_gen = 0;
+
+#ifdef X3_DBG_STAMPS
+  // phase times: 0 wait for samples, 1 analysis, 2 scan + size, 3 emission, 4 CRC, 5 offset waits, 6 copy-out,
+  // 7 clearing + bookkeeping
+  unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long dbg_t = clock64();
+#endif
+
+  // ---- F2 + F3 for the frame in waiting: where it goes (the generation's base needs the totals of the generations
+  // between this workgroup's previous one, inclusive, and this one), then header and payload to their final place
+  auto finish_prev = [&]() __attribute__((always_inline)) {
+    const uint32_t par = prev_gen & 7u;
+    const uint32_t gtag = ((prev_gen + 1u) & 0xFFFu) << X3_DESC_BYTES_BITS;
+    const uint32_t L = prev_L, frame_bytes = 20u + prev_L, rtot = (prev_L + 255u) >> 8;
+    uint32_t intra = 0;
+    {
+      // the wave's predecessors in that generation (LDS)
+      uint32_t spins = 0;
+      for (;;) {
+        const uint32_t v = lane < w ? __hip_atomic_load(&book[16u * par + (lane & 15u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                                    : gtag;
+        if (!__any((v & ~X3_DESC_BYTES_MASK) != gtag)) {
+          intra = (uint32_t)__builtin_amdgcn_readlane((int)x3_wave_incl_scan_dpp(v & X3_DESC_BYTES_MASK), 63);
+          break;
+        }
+        if (++spins > (X3_SPIN_LIMIT << 4)) {
+          lost = true;
+          if (lane == 0 && atomicCAS(&status[2], 0, 1) == 0) {  // diagnosis of the first wait that gave up
+            status[3] = (int)prev_wgi; status[4] = (int)(w | (prev_gen << 8)); status[5] = (int)__ballot((v & ~X3_DESC_BYTES_MASK) != gtag);
+          }
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    if (!lost) {
+      const uint32_t need = prev_gen == 0 ? b : a.nwg;  // totals in front of generation prev_wgi that count
+      const bool in0 = lane < need, in1 = lane + 64u < need, in2 = lane + 128u < need, in3 = lane + 192u < need;
+      const uint32_t* p0 = a.desc + prev_wgi - 1u - lane;
+      uint32_t spins = 0;
+      for (;;) {
+        const uint32_t q0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t q1 = __hip_atomic_load(p0 - 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t q2 = __hip_atomic_load(p0 - 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t q3 = __hip_atomic_load(p0 - 192, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t v0 = in0 ? q0 : ready_tag, v1 = in1 ? q1 : ready_tag, v2 = in2 ? q2 : ready_tag, v3 = in3 ? q3 : ready_tag;
+        if (!__any(((v0 >> X3_DESC_BYTES_BITS) != a.epoch) || ((v1 >> X3_DESC_BYTES_BITS) != a.epoch) ||
+                   ((v2 >> X3_DESC_BYTES_BITS) != a.epoch) || ((v3 >> X3_DESC_BYTES_BITS) != a.epoch))) {
+          // 256 totals < 2^20 each: a 32-bit sum
+          const uint32_t sum = x3_wave_incl_scan_dpp((v0 & X3_DESC_BYTES_MASK) + (v1 & X3_DESC_BYTES_MASK) +
+                                                     (v2 & X3_DESC_BYTES_MASK) + (v3 & X3_DESC_BYTES_MASK));
+          const uint64_t from = prev_gen == 0 ? ((a.start_pos + 1ull) & ~1ull) : gen_base;  // writer.align::<2>() (encoder.rs:182)
+          gen_base = from + (uint32_t)__builtin_amdgcn_readlane((int)sum, 63);
+          break;
+        }
+        // give up after the bounded spin -- or as soon as ANY wave has: the host encodes the call again
+        if (++spins > X3_SPIN_LIMIT ||
+            __hip_atomic_load(&status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == X3D_SIZE_WAIT_TIMEOUT) {
+          lost = true;
+          if (spins > X3_SPIN_LIMIT && lane == 0 && atomicCAS(&status[2], 0, 2) == 0) {
+            const unsigned long long nr = __ballot((v0 >> X3_DESC_BYTES_BITS) != a.epoch);
+            status[3] = (int)prev_wgi; status[4] = (int)(w | (prev_gen << 8)); status[5] = (int)nr; status[6] = (int)(nr >> 32);
+            status[7] = (int)(__popcll(__ballot((v1 >> X3_DESC_BYTES_BITS) != a.epoch)) | (__popcll(__ballot((v2 >> X3_DESC_BYTES_BITS) != a.epoch)) << 8) |
+                              (__popcll(__ballot((v3 >> X3_DESC_BYTES_BITS) != a.epoch)) << 16));
+          }
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    if (lost) {
+      // This wave no longer knows where its frames go -- this one and, since each base builds on the last, every
+      // later one.  Nothing of them may reach the output, the frame index or the end position.
+      if (lane == 0) atomicMax(&status[1], X3D_SIZE_WAIT_TIMEOUT);
+      return;
+    }
+    const uint64_t off = gen_base + intra;
+    X3_STAMP(5);
+
+    if (lane == 0) {
+      a.frame_off[prev_f] = off;
+      if (off + frame_bytes > a.out_cap) atomicMax(&status[0], X3D_BYTE_WRITER_INSUFFICIENT_MEMORY);
+      if (prev_f == a.n_frames - 1) {
+        a.frame_off[a.n_frames] = off + frame_bytes;
+        *end_pos = off + frame_bytes;
+      }
+      if (prev_f == 0 && (a.start_pos & 1ull) && a.start_pos < a.out_cap) a.out[a.start_pos] = 0;  // align pad byte
+    }
+    if (!prev_ovf && off + frame_bytes <= a.out_cap) {
+      uint8_t* const dst = a.out + off;
+      // header (encoder.rs:122-162): "x3", id, id, samples, payload_len, 8 zero time bytes, header crc over bytes
+      // 0..16, payload crc; audio frames use id 1.  Ten big-endian halfwords at an even address.  The header CRC
+      // (encoder.rs:153-154): the state behind the constant bytes "x3", id, id is a constant; the (samples,
+      // payload_len) word and the eight zero time bytes go through the slicing tables.
+      if (lane < 10) {
+        constexpr uint32_t K4 = x3_crc16_const4(0x78u, 0x33u, 0x01u, 0x01u);
+        const uint32_t mm = (((prev_n & 0xFFFFu) << 16) | (L & 0xFFFFu)) ^ (K4 << 16);
+        uint32_t hc = (uint32_t)tab[768u + (mm >> 24)] ^ (uint32_t)tab[512u + ((mm >> 16) & 0xFFu)] ^
+                      (uint32_t)tab[256u + ((mm >> 8) & 0xFFu)] ^ (uint32_t)tab[mm & 0xFFu];
+        hc = (uint32_t)tab[768u + (hc >> 8)] ^ (uint32_t)tab[512u + (hc & 0xFFu)];
+        hc = (uint32_t)tab[768u + (hc >> 8)] ^ (uint32_t)tab[512u + (hc & 0xFFu)];
+        const uint32_t hw = lane == 0 ? 0x7833u : lane == 1 ? 0x0101u : lane == 2 ? (prev_n & 0xFFFFu) : lane == 3 ? (L & 0xFFFFu)
+                          : lane == 8 ? hc : lane == 9 ? prev_crc : 0u;
+        reinterpret_cast<uint16_t*>(dst)[lane] = (uint16_t)(((hw & 0xFFu) << 8) | ((hw >> 8) & 0xFFu));
+      }
+      // payload: image bytes [0, L) -> dst + 20 ...; sixteen bytes per lane and trip, aligned to the DESTINATION.
+      // Both are at even addresses, so a destination dword is one image dword or the halves of two.  The pieces in
+      // front of the first and behind the last whole unit go out as halfwords (at most seven each).
+      uint8_t* const pdst = dst + 20;
+      const uint32_t dmis = (uint32_t)(reinterpret_cast<uintptr_t>(pdst) & 15u);
+      const uint32_t head = (16u - dmis) & 15u;                  // payload bytes in front of the first aligned unit
+      if (L >= head + 16u) {
+        const uint32_t nfull = (L - head) >> 4;
+        uint8_t* const abase = pdst + head;                     // 16-byte aligned
+        // memory order of a stored dword = stream order: bytes (31..24), (23..16), (15..8), (7..0) of the image's value
+        if (head & 2u) {
+          for (uint32_t u = lane; u < nfull; u += 64u) {
+            const uint32_t ia = img_addr + ((head + 16u * u) & ~3u);  // the unit starts in the low half of this dword
+            const uint32_t v0 = x3_lds_read_b32(ia), v1 = x3_lds_read_b32(ia + 4u), v2 = x3_lds_read_b32(ia + 8u),
+                           v3 = x3_lds_read_b32(ia + 12u), v4 = x3_lds_read_b32(ia + 16u);
+            const x3_u32x4 vv = {__builtin_amdgcn_perm(v1, v0, 0x06070001u), __builtin_amdgcn_perm(v2, v1, 0x06070001u),
+                                 __builtin_amdgcn_perm(v3, v2, 0x06070001u), __builtin_amdgcn_perm(v4, v3, 0x06070001u)};
+            *reinterpret_cast<x3_u32x4*>(abase + 16u * u) = vv;
+          }
+        } else {
+          for (uint32_t u = lane; u < nfull; u += 64u) {
+            const uint32_t ia = img_addr + head + 16u * u;
+            const uint32_t v0 = x3_lds_read_b32(ia), v1 = x3_lds_read_b32(ia + 4u), v2 = x3_lds_read_b32(ia + 8u),
+                           v3 = x3_lds_read_b32(ia + 12u);
+            const x3_u32x4 vv = {__builtin_amdgcn_perm(0u, v0, 0x00010203u), __builtin_amdgcn_perm(0u, v1, 0x00010203u),
+                                 __builtin_amdgcn_perm(0u, v2, 0x00010203u), __builtin_amdgcn_perm(0u, v3, 0x00010203u)};
+            *reinterpret_cast<x3_u32x4*>(abase + 16u * u) = vv;
+          }
+        }
+        // halfword h of the payload: bits 31..16 (h even) or 15..0 (h odd) of image dword h / 2, first byte on top
+        const uint32_t tail0 = head + 16u * nfull;               // first byte behind the whole units
+        const uint32_t nh = head >> 1, nt = (L - tail0) >> 1;   // halfwords in front / behind: < 8 each
+        if (lane < nh + nt) {
+          const uint32_t hb = lane < nh ? 2u * lane : tail0 + 2u * (lane - nh);
+          const uint32_t v = x3_lds_read_b32(img_addr + (hb & ~3u));
+          const uint32_t hv = (hb & 2u) ? (v & 0xFFFFu) : (v >> 16);
+          *reinterpret_cast<uint16_t*>(pdst + hb) = (uint16_t)(((hv & 0xFFu) << 8) | (hv >> 8));
+        }
+      } else {
+        // a payload shorter than the first aligned unit and one more: all of it by halfwords (L < 31)
+        if (lane < (L >> 1)) {
+          const uint32_t hb = 2u * lane;
+          const uint32_t v = x3_lds_read_b32(img_addr + (hb & ~3u));
+          const uint32_t hv = (hb & 2u) ? (v & 0xFFFFu) : (v >> 16);
+          *reinterpret_cast<uint16_t*>(pdst + hb) = (uint16_t)(((hv & 0xFFu) << 8) | (hv >> 8));
+        }
+      }
+    }
+    X3_STAMP(6);
+    // clear what the frame used (all lanes' reads of the image are done: same wave, in order)
+    x3w_lds_fence();
+    if (!prev_ovf) {
+      const uint32_t nq = rtot * 16u;  // 16-byte pieces
+      for (uint32_t i = lane; i < nq; i += 64u) reinterpret_cast<uint4*>(img)[i] = make_uint4(0, 0, 0, 0);
+    }
+    x3w_lds_fence();
+    X3_STAMP(7);
+  };
+
+  f = wgi * a.m + w;
+  if (wgi < a.n_wggen && f < a.n_frames) {
+    geom_at(clip, idx, src, n);
+    load_half(X0, src, n, 0);
+    load_half(X1, src, n, 1);
+
+    for (;;) {
+      // (opaque per frame: nothing derived from the lane index is kept in registers across the loop -- hipcc otherwise
+      // hoists a dozen lane masks and offsets out of it and spills them)
+      asm volatile("" : "+v"(lane));
+#if X3W_PRIO == 1
+      // Feedback priorities.  The SQ issues oldest-first, so left alone the first wave of every SIMD runs a generation
+      // ahead and then sits at its offset wait for the sizes of the waves it has starved, and the SIMD runs on the
+      // waves that are left.  A wave's arrival rank among the sixteen of its workgroup generation says where it
+      // stands: the first arrivers yield, the last ones are served first.
+      if (rank >= 12u) __builtin_amdgcn_s_setprio(3);
+      else if (rank >= 8u) __builtin_amdgcn_s_setprio(2);
+      else if (rank >= 4u) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+#elif X3W_PRIO >= 2
+      // a wave that still owes its frame's size goes first: everybody's offsets wait for it
+      __builtin_amdgcn_s_setprio(X3W_PRIO);
+#endif
+      const uint32_t tail = (n - 1u) % 20u;
+      const bool plain = tail == 0u || tail == 19u;  // every block has 20 samples, or 19 in the frame's last block
+      const uint32_t s_first = X0[0] & 0xFFFFu;      // (lane 0: the frame's first sample)
+#ifdef X3_DBG_STAMPS
+      x3_dma_wait();
+      X3_STAMP(0);
+#endif
+
+      // ---- B: analysis.  rem = samples behind this lane's predecessor sample; block q has clamp(rem - 20 q, 0, 20).
+      const int32_t rem0 = (int32_t)n - 1 - 80 * (int32_t)lane, rem1 = rem0 - (int32_t)X3W_PART;
+      uint32_t nb0 = 0, nb1 = 0, mA, mB, mC, mD;  // metas: blocks 0, 1 | 2, 3 of half 0, of half 1 (16 bits each)
+      {
+        uint32_t t, m0, m1, m2, m3;
+        const __amdgpu_buffer_rsrc_t rs_cur =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(src), 0, (int)((2u * n + 3u) & ~3u), 0x00020000);
+        const uint32_t vo_cur = 160u * lane;
+        auto stat = [&](uint32_t mt, uint32_t cnt) __attribute__((always_inline)) {
+          // statistics (encoder.rs:199): stats[index] += block.len(), summed per workgroup in LDS
+          if (mt) atomicAdd(&book[140u + ((mt >> 12) & 7u)], cnt);
+        };
+        if (plain) {
+          x3w_analyse<0>(X0, x3w_cnt_of(rem0, 0), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 0u, t, m0); nb0 += t;
+          x3w_analyse<1>(X0, x3w_cnt_of(rem0, 1), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 0u, t, m1); nb0 += t;
+          x3w_analyse<2>(X0, x3w_cnt_of(rem0, 2), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 0u, t, m2); nb0 += t;
+          x3w_analyse<3>(X0, x3w_cnt_of(rem0, 3), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 0u, t, m3); nb0 += t;
+        } else {
+          x3w_slow_analyse(rs_cur, 4u * lane + 0u, x3w_cnt_of(rem0, 0), a.thr0, a.thr1, a.thr2, a.kpack, t, m0); nb0 += t;
+          x3w_slow_analyse(rs_cur, 4u * lane + 1u, x3w_cnt_of(rem0, 1), a.thr0, a.thr1, a.thr2, a.kpack, t, m1); nb0 += t;
+          x3w_slow_analyse(rs_cur, 4u * lane + 2u, x3w_cnt_of(rem0, 2), a.thr0, a.thr1, a.thr2, a.kpack, t, m2); nb0 += t;
+          x3w_slow_analyse(rs_cur, 4u * lane + 3u, x3w_cnt_of(rem0, 3), a.thr0, a.thr1, a.thr2, a.kpack, t, m3); nb0 += t;
+        }
+        stat(m0, x3w_cnt_of(rem0, 0)); stat(m1, x3w_cnt_of(rem0, 1)); stat(m2, x3w_cnt_of(rem0, 2)); stat(m3, x3w_cnt_of(rem0, 3));
+        mA = m0 | (m1 << 16);
+        mB = m2 | (m3 << 16);
+        if (plain) {
+          x3w_analyse<0>(X1, x3w_cnt_of(rem1, 0), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 2u * X3W_PART, t, m0); nb1 += t;
+          x3w_analyse<1>(X1, x3w_cnt_of(rem1, 1), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 2u * X3W_PART, t, m1); nb1 += t;
+          x3w_analyse<2>(X1, x3w_cnt_of(rem1, 2), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 2u * X3W_PART, t, m2); nb1 += t;
+          x3w_analyse<3>(X1, x3w_cnt_of(rem1, 3), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 2u * X3W_PART, t, m3); nb1 += t;
+        } else {
+          x3w_slow_analyse(rs_cur, 256u + 4u * lane + 0u, x3w_cnt_of(rem1, 0), a.thr0, a.thr1, a.thr2, a.kpack, t, m0); nb1 += t;
+          x3w_slow_analyse(rs_cur, 256u + 4u * lane + 1u, x3w_cnt_of(rem1, 1), a.thr0, a.thr1, a.thr2, a.kpack, t, m1); nb1 += t;
+          x3w_slow_analyse(rs_cur, 256u + 4u * lane + 2u, x3w_cnt_of(rem1, 2), a.thr0, a.thr1, a.thr2, a.kpack, t, m2); nb1 += t;
+          x3w_slow_analyse(rs_cur, 256u + 4u * lane + 3u, x3w_cnt_of(rem1, 3), a.thr0, a.thr1, a.thr2, a.kpack, t, m3); nb1 += t;
+        }
+        stat(m0, x3w_cnt_of(rem1, 0)); stat(m1, x3w_cnt_of(rem1, 1)); stat(m2, x3w_cnt_of(rem1, 2)); stat(m3, x3w_cnt_of(rem1, 3));
+        mC = m0 | (m1 << 16);
+        mD = m2 | (m3 << 16);
+      }
+      X3_STAMP(1);
+
+      // ---- C: bit offsets (the BitPacker's running position as two wave scans)
+      const uint32_t incl0 = x3_wave_incl_scan_dpp(nb0), incl1 = x3_wave_incl_scan_dpp(nb1);
+      const uint32_t tot0 = (uint32_t)__builtin_amdgcn_readlane((int)incl0, 63);
+      const uint32_t tot1 = (uint32_t)__builtin_amdgcn_readlane((int)incl1, 63);
+      const uint32_t bits = 16u + tot0 + tot1;                 // <Audio State> + blocks (encoder.rs:189-200)
+      const uint32_t L = (((bits + 7u) >> 3) + 1u) & ~1u;      // word_align (bitpacker.rs:124-132)
+      const uint32_t rtot = (L + 255u) >> 8;                   // image rows that hold payload
+      const bool ovf = L > X3W_IMG_BYTES;
+
+      // ---- F1: this frame's size to the workgroup; the last arriver of the generation publishes its total
+      // (the word is its own flag: cdna_hip_programming.md G16, form R2)
+      uint32_t arrived = 0;
+      if (lane == 0) {
+        const uint64_t left_f = a.n_frames - wgi * a.m;
+        const uint32_t m_eff = left_f < a.m ? (uint32_t)left_f : a.m;
+        const uint32_t par = gen & 7u;
+        const uint32_t gtag = ((gen + 1u) & 0xFFFu) << X3_DESC_BYTES_BITS;
+        __hip_atomic_store(&book[16u * par + w], gtag | (20u + L), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t old = __hip_atomic_fetch_add(&book[128u + par], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        arrived = old;
+        if (old == m_eff - 1u) {
+          uint32_t tb = 0;
+          for (uint32_t i = 0; i < m_eff; ++i)
+            tb += __hip_atomic_load(&book[16u * par + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & X3_DESC_BYTES_MASK;
+          __hip_atomic_store(&book[128u + par], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(&a.desc[wgi], ready_tag | tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      rank = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
+#if X3W_PRIO >= 2
+      __builtin_amdgcn_s_setprio(0);
+#endif
+      // the geometry of this wave's next frame
+      bool have_next;
+      uint32_t n_next = 0;
+      const int16_t* src_next = nullptr;
+      {
+        const uint64_t wgi_n = wgi + a.nwg;
+        have_next = wgi_n < a.n_wggen && wgi_n * a.m + w < a.n_frames;
+        idx += a.step_idx;
+        clip += a.step_clip;
+        if (idx >= a.fpc) { idx -= a.fpc; ++clip; }
+        if (have_next) geom_at(clip, idx, src_next, n_next);
+      }
+      X3_STAMP(2);
+
+      // ---- the frame in waiting leaves its image now (its size went out a whole iteration ago)
+      if (have_prev) {
+        finish_prev();
+        if (lost) break;
+      }
+
+      // ---- D: emission, half 0 then half 1; the next frame's halves are requested as their registers fall free.
+      // Lane 0 starts with the frame's first sample.
+      if (!ovf) {
+        X3WEmit e;
+        const uint32_t bp = lane ? 16u + incl0 - nb0 : 0u;
+        e.acc = 0;
+        e.pend = bp & 31u;
+        e.waddr = img_addr + 4u * (bp >> 5);
+        if (lane == 0) e.put(s_first, 16u);
+        if (plain) {
+          x3w_emit<0>(X0, mA & 0xFFFFu, x3w_cnt_of(rem0, 0), e); x3w_emit<1>(X0, mA >> 16, x3w_cnt_of(rem0, 1), e);
+          x3w_emit<2>(X0, mB & 0xFFFFu, x3w_cnt_of(rem0, 2), e); x3w_emit<3>(X0, mB >> 16, x3w_cnt_of(rem0, 3), e);
+        } else {
+          const __amdgpu_buffer_rsrc_t rs_cur =
+              __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(src), 0, (int)((2u * n + 3u) & ~3u), 0x00020000);
+          x3w_slow_emit(rs_cur, 4u * lane + 0u, x3w_cnt_of(rem0, 0), mA & 0xFFFFu, e);
+          x3w_slow_emit(rs_cur, 4u * lane + 1u, x3w_cnt_of(rem0, 1), mA >> 16, e);
+          x3w_slow_emit(rs_cur, 4u * lane + 2u, x3w_cnt_of(rem0, 2), mB & 0xFFFFu, e);
+          x3w_slow_emit(rs_cur, 4u * lane + 3u, x3w_cnt_of(rem0, 3), mB >> 16, e);
+        }
+        if (nb0 || lane == 0) e.finish();
+      }
+      if (have_next) load_half(X0, src_next, n_next, 0);
+      if (!ovf) {
+        X3WEmit e;
+        const uint32_t bp = 16u + tot0 + incl1 - nb1;
+        e.acc = 0;
+        e.pend = bp & 31u;
+        e.waddr = img_addr + 4u * (bp >> 5);
+        if (plain) {
+          x3w_emit<0>(X1, mC & 0xFFFFu, x3w_cnt_of(rem1, 0), e); x3w_emit<1>(X1, mC >> 16, x3w_cnt_of(rem1, 1), e);
+          x3w_emit<2>(X1, mD & 0xFFFFu, x3w_cnt_of(rem1, 2), e); x3w_emit<3>(X1, mD >> 16, x3w_cnt_of(rem1, 3), e);
+        } else {
+          const __amdgpu_buffer_rsrc_t rs_cur =
+              __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(src), 0, (int)((2u * n + 3u) & ~3u), 0x00020000);
+          x3w_slow_emit(rs_cur, 256u + 4u * lane + 0u, x3w_cnt_of(rem1, 0), mC & 0xFFFFu, e);
+          x3w_slow_emit(rs_cur, 256u + 4u * lane + 1u, x3w_cnt_of(rem1, 1), mC >> 16, e);
+          x3w_slow_emit(rs_cur, 256u + 4u * lane + 2u, x3w_cnt_of(rem1, 2), mD & 0xFFFFu, e);
+          x3w_slow_emit(rs_cur, 256u + 4u * lane + 3u, x3w_cnt_of(rem1, 3), mD >> 16, e);
+        }
+        if (nb1) e.finish();
+      }
+      if (have_next) load_half(X1, src_next, n_next, 1);
+      X3_STAMP(3);
+      x3w_lds_fence();
+
+      // ---- E: payload CRC-16 (crc.rs:44-58 as a segmented reduction, see the file header)
+      uint32_t crc = 0;
+      if (!ovf) {
+        // two independent Horner chains, over the even and the odd rows counted from the END of the payload (times
+        // x^4096 per step): the look-ups of one chain fly under those of the other.  An odd number of rows starts
+        // with a row of zeros in front, which adds nothing.
+        auto crc0dw = [&](uint32_t d) __attribute__((always_inline)) -> uint32_t {
+          const uint32_t a3 = x3_sdwa_byte_x2(d, 3), a2 = x3_sdwa_byte_x2(d, 2), a1 = x3_sdwa_byte_x2(d, 1), a0 = x3_sdwa_byte_x2(d, 0);
+          return (uint32_t)x3_lds_read_u16(tab_base + a3, 1536u) ^ (uint32_t)x3_lds_read_u16(tab_base + a2, 1024u) ^
+                 (uint32_t)x3_lds_read_u16(tab_base + a1, 512u) ^ (uint32_t)x3_lds_read_u16(tab_base + a0, 0u);
+        };
+        uint32_t sa = 0, sb = 0;
+        const uint32_t odd = rtot & 1u;
+        uint32_t ra = img_addr + 4u * lane;
+        {
+          // the first step: row 0 is in chain b if the count is odd (chain a sees the row of zeros), else in chain a
+          uint32_t d0 = x3_lds_read_b32(ra);
+          if (lane == 0) d0 ^= 0xFFFF0000u;  // CRC init 0xFFFF folded into the first 16 message bits
+          if (odd) {
+            sb = crc0dw(d0);
+            ra += 256u;
+          } else {
+            const uint32_t d1 = x3_lds_read_b32(ra + 256u);
+            sa = crc0dw(d0);
+            sb = crc0dw(d1);
+            ra += 512u;
+          }
+        }
+        for (uint32_t r = 2u - odd; r < rtot; r += 2u) {
+          const uint32_t da = x3_lds_read_b32(ra), db = x3_lds_read_b32(ra + 256u);
+          ra += 512u;
+          const uint32_t ca = crc0dw(da), cb = crc0dw(db);
+          sa = (uint32_t)x3_lds_read_u16(tab_base + x3_sdwa_byte_x2(sa, 1), 5376u) ^ (uint32_t)x3_lds_read_u16(tab_base + x3_sdwa_byte_x2(sa, 0), 5888u) ^ ca;
+          sb = (uint32_t)x3_lds_read_u16(tab_base + x3_sdwa_byte_x2(sb, 1), 5376u) ^ (uint32_t)x3_lds_read_u16(tab_base + x3_sdwa_byte_x2(sb, 0), 5888u) ^ cb;
+        }
+        // chain a ends one row in front of chain b
+        const uint32_t s = (uint32_t)x3_lds_read_u16(tab_base + x3_sdwa_byte_x2(sa, 1), 2048u) ^
+                           (uint32_t)x3_lds_read_u16(tab_base + x3_sdwa_byte_x2(sa, 0), 2560u) ^ sb;
+        // times this lane's x^(32*(63-lane)): sixteen pre-shifted words
+        const x3_u32x4 k0 = x3_lds_read_b128(tab_base + 3072u + 32u * lane);
+        const x3_u32x4 k1 = x3_lds_read_b128(tab_base + 3072u + 32u * lane + 16u);
+        const uint32_t kk[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+        uint32_t rr = 0;
+#pragma unroll
+        for (int bit = 0; bit < 16; ++bit) {
+          const uint32_t kv = (bit & 1) ? (kk[bit >> 1] >> 16) : (kk[bit >> 1] & 0xFFFFu);
+          rr ^= (0u - ((s >> bit) & 1u)) & kv;
+        }
+        crc = (uint32_t)__builtin_amdgcn_readlane((int)x3_wave_xor_to_lane63_dpp(rr), 63) & 0xFFFFu;
+        // the rows counted 256 rtot bytes, the payload has L: undo the zero bytes behind it
+        const uint32_t zb = 256u * rtot - L;
+        if (zb) {
+          const uint32_t kx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tab[2560u + (zb >> 1)]);
+          crc = x3_gf_mul(crc, kx) & 0xFFFFu;
+        }
+      } else if (lane == 0) {
+        atomicMax(&status[1], X3D_IMAGE_OVERFLOW);
+      }
+      X3_STAMP(4);
+
+      // ---- this frame waits in its image; the wave goes on to its next one
+      have_prev = true;
+      prev_ovf = ovf;
+      prev_f = f;
+      prev_wgi = wgi;
+      prev_gen = gen;
+      prev_n = n;
+      prev_L = L;
+      prev_crc = crc;
+      if (!have_next) break;
+      ++gen;
+      wgi += a.nwg;
+      f = wgi * a.m + w;
+      src = src_next;
+      n = n_next;
+    }
+    if (have_prev && !lost) finish_prev();
+  }
+
+#ifdef X3_DBG_STAMPS
+  if (lane == 0)
+    for (int k = 0; k < 8; ++k) x3_dbg[(blockIdx.x * 16 + w) * 8 + k] = dbg_acc[k];
+#endif
+  // statistics: the last wave to leave adds the workgroup's sums
+  if (lane == 0) {
+    const uint32_t old = __hip_atomic_fetch_add(&book[136], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (old == a.m - 1u) {
+      for (uint32_t i = 0; i < 6; ++i) {
+        const uint32_t v = __hip_atomic_load(&book[140u + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (v) atomicAdd(&stats[i], (unsigned long long)v);
+      }
+    }
+  }
+}
