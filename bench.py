@@ -98,8 +98,10 @@ def main():
     ap.add_argument("--strong", action="store_true", help="strong scaling: --total-samples cut into N frame ranges")
     ap.add_argument("--total-samples", type=int, default=8 * N_SAMPLES, help="--strong: the whole stream (config 4: 8 h)")
     ap.add_argument("--no-verify-all", action="store_true", help="compare only sampled frames with the CPU oracle")
-    ap.add_argument("--settle", type=int, default=12,
-                    help="untimed steps in front of the warm-up: the library's pace controllers settle over ~10 launches")
+    ap.add_argument("--settle", type=int, default=0,
+                    help="extra untimed steps in front of the warm-up (0: none -- a context's first launch is paced from the data)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the cold-context, frame-walk and extreme-content measurements that ride on the line")
     ap.add_argument("--no-measure-traffic", action="store_true",
                     help="roofline.traffic from profiles/traffic.json instead of two rocprofv3 PMC passes run here")
     args = ap.parse_args()
@@ -188,10 +190,8 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # The kernels pace themselves against the launch before (the target climbs by 1.5-4 % per
-    # launch until it stops being met), so a context needs about ten launches to reach the speed it then keeps.  Those
-    # launches are made here, as part of setting the context up, in front of the contract's W warm-up steps; they
-    # are reported in config.settle_steps.
+    # (--settle: extra untimed launches in front of the contract's W warm-up steps, reported as config.settle_steps.
+    # Round 2 needed twelve for the kernels' pace controllers; a first launch is now paced from the data: 0.)
     for _ in range(args.settle):
         step()
     for _ in range(args.warmup):
@@ -226,6 +226,7 @@ def main():
         ms, cnt = ctx.kernel_time(which)
         ktimes[name] = ms / max(cnt, 1)
     ctx.enable_kernel_timing(False)
+    enc_gen = int(ctx.get_option("enc_gen")) if ctx.get_option("encode_dense_reruns") == 0 else 2
 
     # ---- bit-exactness of the timed output: decode(encode(x)) == x, and the stream == the CPU oracle's
     assert torch.equal(back, wav), "decode(encode(x)) != x"
@@ -233,6 +234,12 @@ def main():
     offs = off.cpu().numpy()
     assert int(offs[-1]) == pos
     verified = 0
+    if rank != 0:
+        # every rank checks a sample of its own frames against the oracle (rank 0: all of them, below)
+        for fr in sorted({0, F // 3, (2 * F) // 3, F - 1}):
+            a_, b_ = fr * p.spf, min(n, (fr + 1) * p.spf)
+            enc = O.encode(wav[a_:b_].cpu().numpy())[1]
+            assert np.array_equal(enc, out[int(offs[fr]):int(offs[fr + 1])].cpu().numpy()), "rank %d frame %d differs from the CPU oracle" % (rank, fr)
     if rank == 0:
         import concurrent.futures as cf
         frames = list(range(F)) if not args.no_verify_all else [0, F // 3, F - 1]
@@ -397,13 +404,82 @@ def main():
                            "host wall time incl. the summary's trip back"}
         del hwav, hout, hback
 
+    # ---- what the headline does not say: a fresh context's first step, the round trip with the frame walk
+    # in it, and the two adversarial contents of SURVEY 8(d) -- all timed here, in this run
+    cold = with_walk = extremes = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        def timed_steps(c, fn, k):
+            c.enable_kernel_timing(True); c.reset_kernel_time()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(k):
+                fn()
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t0) / k
+            kt = {}
+            for name, which in (("encode", 0), ("decode", 1), ("frame_sizes", 2), ("scan", 3), ("frame_check", 4)):
+                ms, cnt = c.kernel_time(which)
+                if cnt:
+                    kt[name] = round(ms / cnt, 4)
+            c.enable_kernel_timing(False)
+            return dt, kt
+        # (a) cold: a NEW context (own stream, no history: no pace words, no scratch), ONE step
+        c2 = x3hip.Context(local_rank)
+        def step2():
+            assert c2.encode_dev(wav.data_ptr(), n, p, out.data_ptr(), cap, 0, off.data_ptr()) == 0
+            assert c2.decode_dev(out.data_ptr(), cap, off.data_ptr(), F, p, back.data_ptr(), n, n_per_clip=n) == 0
+            c2.sync()
+        back.zero_()
+        dt, kt = timed_steps(c2, step2, 1)
+        assert c2.encode_result()[0] == 0 and c2.decode_result()[:3] == (0, F, 0) and torch.equal(back, wav)
+        cold = {"ms_per_step": round(dt * 1e3, 4), "value": round(n / dt / 1e6, 2), "kernels_ms": kt,
+                "note": "first encode+decode of a fresh context (scratch allocation, no launch history), host wall time"}
+        c2.close()
+        # (b) the round trip when the decoder does not get the encoder's frame index: x3_encode_dev + x3_decode_stream_dev
+        def step_walk():
+            assert ctx.encode_dev(wav.data_ptr(), n, p, out.data_ptr(), cap, 0, off.data_ptr()) == 0
+            r4 = ctx.decode_stream_dev(out.data_ptr(), pos, p, back.data_ptr(), n)
+            assert r4 == (0, n, F, 0), r4
+        step_walk()
+        dt, kt = timed_steps(ctx, step_walk, 10)
+        assert ctx.encode_result()[0] == 0 and torch.equal(back, wav)
+        with_walk = {"ms_per_step": round(dt * 1e3, 4), "value": round(n / dt / 1e6, 2), "kernels_ms": kt,
+                     "note": "x3_encode_dev + x3_decode_stream_dev (frame walk on the GPU, check, decode; the call returns the "
+                             "summary, so every step ends with a trip to the host)"}
+        # (c) SURVEY 8(d)'s extremes on the same 691.2 M samples: minimum and maximum output
+        extremes = {}
+        for kind, name in ((0, "zeros"), (1, "white_noise")):
+            ctx.synth_dev(kind, SEED, 0, n, wav.data_ptr())
+            torch.cuda.synchronize(dev)
+            # (the first call on new content is collected before anything is chained behind it: a context that meets
+            # frames too dense for the wave encoder encodes that call twice and keeps to the second generation after)
+            assert ctx.encode_dev(wav.data_ptr(), n, p, out.data_ptr(), cap, 0, off.data_ptr()) == 0
+            assert ctx.encode_result()[0] == 0
+            for _ in range(3):
+                step()
+            rc_e, pos_e, _ = ctx.encode_result()
+            assert rc_e == 0 and ctx.decode_result()[:3] == (0, F, 0)
+            dt, kt = timed_steps(ctx, step, 10)
+            rc_e, pos_e, _ = ctx.encode_result()
+            assert rc_e == 0 and ctx.decode_result()[:3] == (0, F, 0) and torch.equal(back, wav), name
+            offs_e = off.cpu().numpy()
+            for fr in sorted({0, F // 2, F - 1}):   # sampled frames against the oracle
+                enc = O.encode(wav[fr * p.spf:min(n, (fr + 1) * p.spf)].cpu().numpy())[1]
+                assert np.array_equal(enc, out[int(offs_e[fr]):int(offs_e[fr + 1])].cpu().numpy()), (name, fr)
+            extremes[name] = {"ms_per_step": round(dt * 1e3, 4), "value": round(n / dt / 1e6, 2), "kernels_ms": kt,
+                              "bytes_per_sample": round(pos_e / n, 4)}
+        extremes["encoder"] = {"gen": int(ctx.get_option("enc_gen")), "dense_reruns": int(ctx.get_option("encode_dense_reruns")),
+                               "note": "white noise does not fit the wave encoder's LDS images: the first such call is encoded twice, "
+                                       "then the context keeps to the second-generation kernel (x3_encode_stream2_kernel) until its "
+                                       "streams come out sparse again"}
+
     if rank == 0:
         total_samples = n * world
         value = total_samples * args.steps / elapsed / 1e6
         # algorithmic HBM bytes per launch (DESIGN.md "Kernels"): 2 B per sample + P stream bytes for
         # the encoder and the decoder; the size pass re-reads the samples; the check pass reads the stream
         alg = {"encode": 2 * n + pos, "decode": 2 * n + pos, "frame_sizes": 2 * n, "frame_check": pos}
-        kname = {"encode": "x3_encode_stream2_kernel" if ktimes.get("frame_sizes", 0.0) == 0.0 else "x3_encode_frames_kernel<false>",
+        kname = {"encode": ("x3_encode_wave_kernel" if enc_gen == 3 else "x3_encode_stream2_kernel") if ktimes.get("frame_sizes", 0.0) == 0.0 else "x3_encode_frames_kernel<false>",
                  "decode": "x3_decode_split_kernel",
                  "frame_sizes": "x3_encode_frames_kernel<true>", "frame_check": "x3_frame_check_kernel"}
         alg = {k: v for k, v in alg.items() if ktimes.get(k, 0.0) > 0.0}  # the two-pass fallback kernels may not run
@@ -465,7 +541,7 @@ def main():
                        "samples_per_gpu": n, "frames_per_gpu": int(F), "stream_bytes_per_gpu": int(pos),
                        "bytes_per_sample": round(pos / n, 4), "block_len": 20, "blocks_per_frame": 500,
                        "signal_kind": args.kind, "frames_verified_vs_oracle": int(verified),
-                       "settle_steps": args.settle,  # untimed launches in front of the warm-up (pace controllers)
+                       "settle_steps": args.settle,  # extra untimed launches in front of the warm-up
                        "sharding": sharding},
             "roofline": roof(dominant),
             "roofline_all": {k: roof(k) for k in alg},
@@ -473,6 +549,11 @@ def main():
             "kernels_ms": {k: round(v, 4) for k, v in ktimes.items()},
             "cpu_baseline": cpu,
         }
+        if cold is not None:
+            res["cold"] = cold
+            res["value_with_frame_walk"] = with_walk["value"]
+            res["with_frame_walk"] = with_walk
+            res["extremes"] = extremes
         if host_api is not None:
             res["host_buffer_api"] = host_api
             res["per_frame_api"] = per_frame

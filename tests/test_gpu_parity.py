@@ -742,20 +742,30 @@ def test_decode_stream_dev_matches_host_api(ctx, x3):
         ctx.free(d_wav)
 
 
-def test_encoder_falls_back_when_grid_not_resident(x3):
-    """the single-pass encoder's workgroups wait for each other's frame sizes; a grid that cannot be co-resident
-    (forced here: 3 workgroups per CU where 2 fit) must time out in bounded time and x3_encode_result must hand
-    back the two-pass kernels' bit-exact result"""
-    import time
-    c = x3.Context(0)
-    try:
-        natural = None
-        # (long enough that every resident workgroup has a second frame behind frames of workgroups that are not)
-        wav = x3.synth(2, 321, 0, 10000 * 3200 + 17)
-        rc, _, _ = c.encode(wav[:30000], x3.Params.default())
+def _make_encoder_lose_its_grid(c, gen):
+    """-> what to undo.  Second generation (eight waves per frame): one workgroup per CU more than fit, so that part of
+    the grid is not resident.  Third generation (one wave per frame): one workgroup generation never publishes its total
+    (option wave_drop), which is what a workgroup that is not resident looks like to all the others."""
+    c.set_option("enc_gen", gen)
+    if gen == 2:
+        rc, _, _ = c.encode(np.zeros(30000, dtype=np.int16), None)
         natural = c.get_option("stream_wgs_in_use")
         assert rc == 0 and natural >= 1
         c.set_option("stream_wgs", natural + 1)
+    else:
+        c.set_option("wave_drop", 300)
+
+
+@pytest.mark.parametrize("gen", [3, 2])
+def test_encoder_falls_back_when_grid_not_resident(x3, gen):
+    """the single-pass encoders' workgroups wait for each other's frame sizes; when part of the grid is not there, the
+    waits must time out in bounded time and x3_encode_result must hand back the two-pass kernels' bit-exact result"""
+    import time
+    c = x3.Context(0)
+    try:
+        # (long enough that every resident workgroup has a second frame behind frames of workgroups that are not)
+        wav = x3.synth(2, 321, 0, 10000 * 6400 + 17)
+        _make_encoder_lose_its_grid(c, gen)
         t0 = time.perf_counter()
         rc, out, stats = c.encode(wav, x3.Params.default())
         dt = time.perf_counter() - t0
@@ -767,18 +777,17 @@ def test_encoder_falls_back_when_grid_not_resident(x3):
     assert dt < 20.0, dt
 
 
-def test_encoder_fallback_leaves_the_prefix_alone(x3):
-    """x3_encode_dev with start_pos > 0 promises output at d_out[start_pos..) only.  A workgroup whose size wait
-    times out has no offset for its frames: none of them may be written (they used to land at d_out + 0), and the
+@pytest.mark.parametrize("gen", [3, 2])
+def test_encoder_fallback_leaves_the_prefix_alone(x3, gen):
+    """x3_encode_dev with start_pos > 0 promises output at d_out[start_pos..) only.  A wave or workgroup whose size
+    wait times out has no offset for its frames: none of them may be written (they used to land at d_out + 0), and the
     two-pass re-run rewrites start_pos.. only -- a sentinel-filled prefix (an archive header, an earlier
     sub-stream) must survive the fallback."""
     c = x3.Context(0)
     try:
         p = x3.Params.default()
-        rc, _, _ = c.encode(x3.synth(2, 1, 0, 30000), p)
-        natural = c.get_option("stream_wgs_in_use")
-        c.set_option("stream_wgs", natural + 1)
-        n = 10000 * 3200 + 17
+        _make_encoder_lose_its_grid(c, gen)
+        n = 10000 * 6400 + 17
         wav = x3.synth(2, 654, 0, n)
         for start_pos in (4096, 321):
             d_wav = c.alloc(2 * n + 64)
@@ -797,6 +806,63 @@ def test_encoder_fallback_leaves_the_prefix_alone(x3):
             c.free(d_wav); c.free(d_out)
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("nwg,m", [(1, 1), (1, 16), (3, 5), (7, 3), (16, 16), (64, 2), (256, 1)])
+def test_wave_encoder_many_generations(x3, nwg, m):
+    """the wave-per-frame encoder on small inputs with few workgroups / few waves (options wave_nwg, wave_m): dozens to
+    hundreds of generations per workgroup, every one with the size exchange in LDS, the generation totals and bases,
+    the last generation short -- byte for byte against the oracle, with no fallback"""
+    c = x3.Context(0)
+    try:
+        c.set_option("wave_nwg", nwg)
+        c.set_option("wave_m", m)
+        for n in (10000 * 37 + 123, 10000 * 200, 10000 * 513 + 1):
+            wav = x3.synth(x3.SYNTH_HYDROPHONE, 0x58330002, 0, n)
+            rc_o, s_o, st_o = O.encode(wav)
+            for rep in range(2):
+                rc, s, st = c.encode(wav)
+                assert rc == rc_o == 0 and np.array_equal(s, s_o) and st.tolist() == st_o.tolist(), (nwg, m, n, rep)
+        assert c.get_option("encode_fallbacks") == 0 and c.get_option("encode_dense_reruns") == 0
+    finally:
+        c.close()
+
+
+def test_wave_encoder_dense_content_reruns(x3):
+    """frames whose payload does not fit the wave encoder's LDS image (more than 9 728 bytes: loud or noisy content) flag
+    the launch; x3_encode_result encodes the call again with the second-generation kernel -- same bytes as the oracle --
+    and the context keeps to that kernel until its streams come out sparse again (twice as many sparse calls in a row
+    every time the wave encoder comes back to dense frames)"""
+    c = x3.Context(0)
+    try:
+        quiet = x3.synth(x3.SYNTH_HYDROPHONE, 5, 0, 400000)
+        loud = quiet.copy()
+        loud[123456:123456 + 30000] = np.random.default_rng(7).integers(-32768, 32767, 30000, dtype=np.int16)
+        white = x3.synth(x3.SYNTH_WHITE, 6, 0, 250000)
+        # (content, dense reruns counted so far): quiet fits; loud is encoded twice and switches the context over; white and
+        # loud keep it there without a second encode; two sparse calls in a row bring the wave encoder back
+        for wav, reruns in ((quiet, 0), (loud, 1), (white, 1), (quiet, 1), (quiet, 1), (quiet, 1), (loud, 2), (loud, 2),
+                            (quiet, 2), (quiet, 2), (quiet, 2), (loud, 3)):
+            rc_o, s_o, st_o = O.encode(wav)
+            rc, s, st = c.encode(wav)
+            assert rc == rc_o == 0 and np.array_equal(s, s_o) and st.tolist() == st_o.tolist()
+            assert c.get_option("encode_dense_reruns") == reruns, (reruns, c.get_option("encode_dense_reruns"))
+        c.set_option("enc_gen", 3)   # (setting the option starts over)
+        rc, s, st = c.encode(loud)
+        assert rc == 0 and c.get_option("encode_dense_reruns") == 4
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 21, 22, 41, 82, 5121, 5122, 5141, 10002, 10018, 25121, 160001])
+@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4])
+def test_wave_encoder_ragged_frames(ctx, x3, kind, n):
+    """frames whose last block has 1..18 samples take the wave encoder's generic path (sample by sample from memory);
+    all five signal kinds, lengths around the half-frame and frame boundaries"""
+    wav = x3.synth(kind, 77, 0, n)
+    rc_o, s_o, st_o = O.encode(wav)
+    rc, s, st = ctx.encode(wav)
+    assert rc == rc_o == 0 and np.array_equal(s, s_o) and st.tolist() == st_o.tolist()
 
 
 def test_random_parameter_sweep(ctx, x3):

@@ -30,3 +30,18 @@ for k in range(8): print("  %-16s %9.0f  %5.1f %%" % (names[k], m[k], 100 * m[k]
 print("  total %.0f ticks per frame; per wave total min/median/max: %s" % (m.sum(), np.percentile(a.sum(axis=2), [0, 50, 100]).round(0)))
 print("by wave index (total ticks per frame):", (a.sum(axis=2).mean(axis=0) / fpw).round(0))
 print("offset waits by wave index:", (a[:, :, 5].mean(axis=0) / fpw).round(0))
+c = out[32768:32768 + 256*16*4].reshape(256, 16, 4).astype(np.float64) / fpw
+print("per frame and wave: polls of the LDS slots %.2f, trips to the descriptors %.3f, polls there %.3f, ticks in the slot wait %.0f" % tuple(c.mean(axis=(0, 1))))
+print("trips to the descriptors by wave index:", c[:, :, 1].mean(axis=0).round(3))
+print("polls there by wave index:", c[:, :, 2].mean(axis=0).round(2))
+print("slot-wait ticks by wave index:", c[:, :, 3].mean(axis=0).round(0))
+tot = a.sum(axis=2); busy = tot - a[:, :, 5]
+wg_busy = busy.mean(axis=1); wg_tot = tot.mean(axis=1); wg_wait = a[:, :, 5].mean(axis=1)
+gens = np.where(np.arange(256) < (F // 16) - 16 * 256, 17, 16) if F // 16 > 16 * 256 else np.full(256, F / 4096.0)
+print("per workgroup: busy ticks per frame percentiles 0/5/50/95/100:", np.percentile(wg_busy / gens, [0, 5, 50, 95, 100]).round(0))
+print("per workgroup: wait ticks per frame percentiles 0/5/50/95/100:", np.percentile(wg_wait / gens, [0, 5, 50, 95, 100]).round(0))
+print("busy per frame by XCD (blockIdx % 8):", np.array([(wg_busy / gens)[x::8].mean() for x in range(8)]).round(0))
+print("wait per frame by XCD (blockIdx % 8):", np.array([(wg_wait / gens)[x::8].mean() for x in range(8)]).round(0))
+order = np.argsort(wg_wait / gens)
+print("workgroups that wait least (blockIdx, wait, busy per frame):", [(int(i), int((wg_wait / gens)[i]), int((wg_busy / gens)[i])) for i in order[:12]])
+print("workgroups that wait most:", [(int(i), int((wg_wait / gens)[i]), int((wg_busy / gens)[i])) for i in order[-6:]])

@@ -47,6 +47,8 @@ struct X3Opts {
   int enc_gen = 3;            // X3HIP_ENC_GEN: 3 = one wave per frame (x3_encode_wave_kernel.h), 2 = eight waves per frame
   int wave_nwg = 0;           // X3HIP_WAVE_NWG: workgroups of the wave encoder (0 = one per CU, at most 256) -- tests: many generations on small inputs
   int wave_m = 0;             // X3HIP_WAVE_M: frames per workgroup generation (0 = derive, 1..16)
+  long long wave_drop = -1;   // tests: the workgroup generation whose total the wave encoder never publishes -- what a workgroup
+                              // that is not resident looks like to the others: their bounded waits give up (-1 = none)
   int decode_single = 0;      // X3HIP_DECODE_SINGLE: single-wave decoder kernels only
   int host_walk = -1;         // X3HIP_HOST_WALK: frame walk of x3_decode_stream on the host (1) / GPU (0) / by size (-1)
   int verbose = 0;            // X3HIP_VERBOSE
@@ -109,7 +111,12 @@ struct x3_ctx {
   bool encode_pending = false, decode_pending = false;
   bool force_two_pass = false;
   bool force_gen2 = false;    // the call is being encoded again because a frame did not fit the wave encoder's image
-  int wave_skip = 0;          // calls the wave encoder sits out after such a launch (dense content)
+  bool last_was_wave = false; // the pending encode was launched on the wave encoder
+  // Dense content (frames that do not fit the wave encoder's image): the context then keeps to the second-generation
+  // kernel until `dense_need` calls in a row have come out sparse again (stream bytes per sample, known at
+  // x3_encode_result); dense_need doubles every time the wave encoder is tried again and meets dense frames again.
+  bool dense_mode = false;
+  int dense_calm = 0, dense_need = 1;
   unsigned long long encode_dense_reruns = 0;
   struct {
     const int16_t* d_wav; x3_batch b; x3_params p; uint64_t spf; uint8_t* d_out; uint64_t out_cap, start_pos; uint64_t* d_off;
@@ -440,9 +447,10 @@ extern "C" int x3_ctx_set_option(x3_ctx* c, const char* name, long long value) {
   else if (n == "stream_wgs") { c->opt.stream_wgs = (int)std::max(0ll, value); c->stream_wg_per_cu = -1; }
   else if (n == "decode_single") c->opt.decode_single = value != 0;
   else if (n == "stream_v1") { c->opt.stream_v1 = value != 0; c->stream_wg_per_cu = -1; }
-  else if (n == "enc_gen") { c->opt.enc_gen = value == 2 ? 2 : 3; c->wave_skip = 0; }
+  else if (n == "enc_gen") { c->opt.enc_gen = value == 2 ? 2 : 3; c->dense_mode = false; c->dense_calm = 0; c->dense_need = 1; }
   else if (n == "wave_nwg") c->opt.wave_nwg = (int)std::max(0ll, std::min(256ll, value));
   else if (n == "wave_m") c->opt.wave_m = (int)std::max(0ll, std::min(16ll, value));
+  else if (n == "wave_drop") c->opt.wave_drop = value;
   else if (n == "host_walk") c->opt.host_walk = value < 0 ? -1 : (value != 0);
   else if (n == "verbose") c->opt.verbose = value != 0;
   else if (n == "file_chunk_frames") c->opt.file_chunk_frames = std::max(1ll, value);
@@ -475,7 +483,8 @@ extern "C" int x3_ctx_get_option(const x3_ctx* c, const char* name, long long* v
     if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
         hipMemcpy(w, c->d_pace, sizeof w, hipMemcpyDeviceToHost) != hipSuccess)
       return X3_ERR_HIP;
-    *value = (long long)(w[n == "encode_pace" ? 4 : 0] & 0xFFFFFu);
+    // (the decoder keeps one word per launch parity: the newer one carries the larger epoch tag)
+    *value = (long long)((n == "encode_pace" ? w[4] : std::max(w[0], w[1])) & 0xFFFFFu);
   }
   else if (n == "check_first") *value = c->opt.check_first;
   else if (n == "check_wgs") *value = c->opt.check_wgs;
@@ -818,8 +827,8 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
   c->last_enc = {d_wav, *b, *p, spf, d_out, out_cap, start_pos, d_frame_offsets};
   if (stream_path && !c->opt.stream_v1 && c->opt.enc_gen == 3 && !c->force_gen2 && c->opt.stream_wgs == 0 &&
       stream_safe_thresholds(p)) {
-    if (c->wave_skip > 0) {
-      --c->wave_skip;  // the last launch met frames that do not fit the image: a few calls with the second generation
+    if (c->dense_mode) {
+      // the last launches met frames that do not fit the image: the second generation, until the content is sparse again
     } else {
       // third generation (x3_encode_wave_kernel.h): one wave per frame, sixteen waves per CU, one workgroup per CU
       static_assert(X3W_SMEM <= 160 * 1024, "LDS");
@@ -862,11 +871,13 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
       wa.thr1 = pl.dp.thr[1];
       wa.thr2 = pl.dp.thr[2];
       wa.kpack = pl.dp.k[0] | (pl.dp.k[1] << 8) | (pl.dp.k[2] << 16);
+      wa.drop_wgi = c->opt.wave_drop >= 0 ? (uint32_t)c->opt.wave_drop : 0xFFFFFFFFu;
       {
         TimerScope ts(c, 0);
         hipLaunchKernelGGL(x3_encode_wave_kernel, dim3(wa.nwg), dim3(X3W_THREADS), X3W_SMEM, c->stream, wa);
       }
       HIPCHK(c, hipGetLastError());
+      c->last_was_wave = true;
       c->encode_pending = true;
       c->enc_start_pos = start_pos;
       return X3_OK;
@@ -1030,11 +1041,16 @@ extern "C" int x3_encode_result(x3_ctx* c, uint64_t* out_pos, uint64_t stats[6])
   HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_status, 128, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->encode_pending = false;
+  if (c->last_was_wave && c->h_status[1] == 0 && c->dense_need > 1) --c->dense_need;  // content that fits: the back-off relaxes
+  const bool was_wave = c->last_was_wave;
+  c->last_was_wave = false;
   if (c->h_status[1] == X3D_IMAGE_OVERFLOW) {
     // a frame of this call did not fit the wave encoder's LDS image (dense content: more than 9 728 payload bytes):
     // the call is encoded again by the second-generation kernel, which holds worst-case images
     ++c->encode_dense_reruns;
-    c->wave_skip = 8;
+    c->dense_mode = true;
+    c->dense_calm = 0;
+    c->dense_need = std::min(1 << 20, c->dense_need * 2);
     c->force_gen2 = true;
     auto a = c->last_enc;
     int rc = encode_dev_impl(c, a.d_wav, &a.b, &a.p, a.spf, a.d_out, a.out_cap, a.start_pos, a.d_off);
@@ -1066,6 +1082,16 @@ extern "C" int x3_encode_result(x3_ctx* c, uint64_t* out_pos, uint64_t stats[6])
   if (stats)
     for (int i = 0; i < 6; ++i) stats[i] = c->h_stats[i];
   int st = std::max(c->h_status[0], c->h_status[1]);
+  if (c->dense_mode && !was_wave && st == 0) {
+    // sparse again?  (0.6 stream bytes per sample: a default frame of 6 000 bytes, the image holds 9 728)
+    const unsigned long long samples = c->last_enc.b.n_per_clip * c->last_enc.b.n_clips;
+    const unsigned long long bytes = c->h_stats[6] - c->last_enc.start_pos;
+    if (samples && bytes * 10ull < samples * 6ull) {
+      if (++c->dense_calm >= c->dense_need) c->dense_mode = false;
+    } else {
+      c->dense_calm = 0;
+    }
+  }
   return st;
 }
 
@@ -1263,8 +1289,7 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
     if (split) {
       // the pace word's 12-bit epoch: launches 1, 2, ... 4095, then the word starts over
       if ((c->dec_epoch & 0xFFFu) == 0u) {
-        HIPCHK(c, hipMemsetAsync(c->d_pace, 0, 4, dec_stream));
-        HIPCHK(c, hipMemsetAsync(c->d_pace + 2, 0, 4, dec_stream));
+        HIPCHK(c, hipMemsetAsync(c->d_pace, 0, 16, dec_stream));  // (achieved and aimed-at, one word per launch parity)
         ++c->dec_epoch;
       }
       hipLaunchKernelGGL(x3_decode_split_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64 * X3S_WAVES),

@@ -79,7 +79,7 @@ __device__ __forceinline__ uint32_t x3s_half_index(uint32_t j, uint32_t lane) {
 #define X3S_PACE_STEP(b)                                                                       \
   if (!X3S_PACE_OFF && ((b) & 7u) == 0u) {                                                                      \
     const uint32_t el = (uint32_t)(wall_clock64() - pace_t0); /* 10 ns ticks */                \
-    const int32_t d = (int32_t)(b) - (int32_t)((el * pace_inv) >> 16);                         \
+    const int32_t d = (int32_t)(b) - (int32_t)(((unsigned long long)el * pace_inv) >> 16); /* (64-bit: 80 ms of ticks times the rate pass 2^32) */ \
     if (d > 2 * X3S_PACE_BAND) __builtin_amdgcn_s_setprio(0);                                  \
     else if (d > 0) __builtin_amdgcn_s_setprio(1);                                             \
     else if (d > -2 * X3S_PACE_BAND) __builtin_amdgcn_s_setprio(2);                            \
@@ -112,18 +112,33 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   uint32_t pace_inv;        // blocks per tick, 16.16 fixed point
   uint32_t pace_target;     // 10 ns ticks per 16 blocks that this launch aims at
   {
-    // pace[0]: what the slowest group of the last launch achieved (P); pace[2]: what that launch aimed at (T).  At its
-    // best the kernel achieves ~4.5 % more than it aims at; a target that is too fast by as little as 3 % throws the
-    // gain away (all waves end up "behind", at one priority: P jumps to 1.1 T), one that is too slow is simply met
-    // (P = T).  So: met -> aim 1.5 % faster; missed by more than 6 % -> back to 4.5 % under what was achieved; in
-    // between -> hold.  (Aiming a fixed fraction under P saw-toothed over the cliff every third or fourth launch:
-    // tools/pace_trace.py.)
-    const uint32_t mask = (1u << X3S_PACE_EPOCH_SHIFT) - 1u, prev = (pace_epoch - 1u) & 0xFFFu;
-    const uint32_t wp = __builtin_amdgcn_readfirstlane(pace[0]), wt = __builtin_amdgcn_readfirstlane(pace[2]);
+    // pace[q], pace[2 + q], q = parity of the launch before: what the slowest group of that launch achieved (P) and what it
+    // aimed at (T).  This launch writes the words of ITS parity, so that a group that is dispatched late -- a grid larger
+    // than the chip holds -- still reads what the first groups read, not what the first finishers of this launch have
+    // left.  At its best the kernel achieves ~4.5 % more than it aims at; a target that is too fast by as
+    // little as 3 % throws the gain away (all waves end up "behind", at one priority: P jumps to 1.1 T), one that is too
+    // slow is simply met (P = T).  So: met -> aim 1.5 % faster; missed by more than 6 % -> back to 4.5 % under what was
+    // achieved; in between -> hold.  (Aiming a fixed fraction under P saw-toothed over the cliff every third or fourth
+    // launch: tools/pace_trace.py.)
+    const uint32_t mask = (1u << X3S_PACE_EPOCH_SHIFT) - 1u, prev = (pace_epoch - 1u) & 0xFFFu, q = prev & 1u;
+    const uint32_t wp = __builtin_amdgcn_readfirstlane(pace[q]), wt = __builtin_amdgcn_readfirstlane(pace[2u + q]);
     const uint32_t P = (wp >> X3S_PACE_EPOCH_SHIFT) == prev ? (wp & mask) : 0u;
     const uint32_t T = (wt >> X3S_PACE_EPOCH_SHIFT) == prev ? (wt & mask) : 0u;
     uint32_t t16;
-    if (P == 0u) t16 = X3S_PACE_DEFAULT;
+    if (P == 0u) {
+      // No launch to go by (a context's first one): from the DATA.  A group's time per block is linear in the bytes it
+      // has to pull in per block -- settled paces of 1.16 / 1.28 / 1.82 / 1.92 us per block at 0.14 / 0.53 / 1.66 / 2.04
+      // stream bytes per sample (zeros, hydrophone noise, sine, white noise) are 1.10 us + 0.40 us
+      // per byte and sample, the target that settles there is 4.5 % under what is achieved -- and the stream's density is
+      // in the frame offsets.
+      t16 = X3S_PACE_DEFAULT;
+      if (n_frames >= 2u && p.spf) {
+        const unsigned long long span = frame_off[n_frames - 1u] - frame_off[0];
+        const unsigned long long samples = (unsigned long long)(n_frames - 1u) * p.spf;
+        const unsigned long long t = 1684ull + (612ull * span) / samples;   // 10 ns ticks per 16 blocks
+        t16 = t > mask ? mask : (uint32_t)t;
+      }
+    }
     else if (T == 0u) t16 = P - P / 22u;
     else {
       const uint32_t r = (P << 8) / T;  // 256 = met exactly
@@ -602,8 +617,8 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     if (lane == 0 && nblk_max >= 64u) {  // this group's pace, for the next launch
       uint64_t t16 = ((wall_clock64() - pace_t0) * 16u) / nblk_max;
       if (t16 >= (1u << X3S_PACE_EPOCH_SHIFT)) t16 = (1u << X3S_PACE_EPOCH_SHIFT) - 1u;
-      atomicMax(pace, ((pace_epoch & 0xFFFu) << X3S_PACE_EPOCH_SHIFT) | (uint32_t)t16);
-      if (blockIdx.x == 0) pace[2] = ((pace_epoch & 0xFFFu) << X3S_PACE_EPOCH_SHIFT) | pace_target;
+      atomicMax(pace + (pace_epoch & 1u), ((pace_epoch & 0xFFFu) << X3S_PACE_EPOCH_SHIFT) | (uint32_t)t16);
+      if (blockIdx.x == 0) pace[2u + (pace_epoch & 1u)] = ((pace_epoch & 0xFFFu) << X3S_PACE_EPOCH_SHIFT) | pace_target;
     }
   }
 #ifdef X3_DBG_STAMPS

@@ -36,6 +36,9 @@
 #pragma once
 #include "x3_encode_stream2_kernel.h"
 
+#ifndef X3W_CLAIM
+#define X3W_CLAIM 1
+#endif
 #ifndef X3W_EXP
 #define X3W_EXP 0
 #endif
@@ -68,6 +71,7 @@ struct X3WaveArgs {
   uint32_t n_wggen;         // ceil(n_frames / m)
   uint32_t step_clip, step_idx;  // (nwg * m) frames as clips + frames
   uint32_t thr0, thr1, thr2, kpack;
+  uint32_t drop_wgi;        // tests: the generation whose total is never published (a workgroup that is not resident); ~0: none
 };
 
 __device__ __forceinline__ uint32_t x3_pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) {
@@ -86,36 +90,35 @@ __device__ __forceinline__ void x3w_lds_fence() { __builtin_amdgcn_fence(__ATOMI
 // X[10Q+10], the next block's first word, stays) and meta (15 bits) says how to emit it:
 // hdr value [0..5] | bits per field [6..10] | Rice [11] | statistics index [12..14]; 0: no block.
 // No temporaries survive a pair (the registers are full: two halves of a frame); the rare literal block, whose raw
-// samples the saturated differences no longer hold, reads its 44 bytes again (rs, vo: the lane's run in the frame).
+// samples the saturated differences no longer hold, reads its 44 bytes again (rs, vo: the lane's run in the frame),
+// and the rare BFP block turns its zigzag values back into differences.
 template <int Q>
 __device__ __forceinline__ void x3w_analyse(uint32_t (&X)[41], uint32_t cnt, uint32_t thr0, uint32_t thr1, uint32_t thr2,
                                             uint32_t kpack, __amdgpu_buffer_rsrc_t rs, uint32_t vo, uint32_t so,
                                             uint32_t& nbits, uint32_t& meta) {
   constexpr int B = 10 * Q;
-  uint32_t mn = 0, mx = 0;
+  // one pass: differences, zigzag in place, and the largest zigzag value -- max|d| = (max zigzag + 1) >> 1 exactly
+  // (u = 2 d for d >= 0, -2 d - 1 for d < 0: the largest u belongs to the largest |d|, and a saturated +-32768 stays
+  // the largest), so one unsigned maximum replaces the signed minimum and maximum of the differences
+  uint32_t mxu = 0;
 #pragma unroll
   for (int j = 0; j < 10; ++j) {
     const uint32_t Xj = __builtin_amdgcn_alignbit(X[B + j + 1], X[B + j], 16);  // (s[2j+1], s[2j+2])
     uint32_t d = x3_pk_sub_sat(Xj, X[B + j]);                                    // (d[2j+1], d[2j+2]), saturated
     if (j == 9) d &= cnt == 20u ? 0xFFFFFFFFu : 0x0000FFFFu;                     // a 19-sample block has no sample 20
-    X[B + j] = d;
-    mn = x3_pk_min_i16(mn, d);
-    mx = x3_pk_max_i16(mx, d);
+    const uint32_t z = x3_pk_shl_b16(d, 1) ^ x3_pk_sar_i16(d, 15);               // zigzag, per half (0 stays 0)
+    X[B + j] = z;
+    mxu = x3_pk_max_u16(mxu, z);
   }
-  const int32_t dmin = min((int32_t)(int16_t)(mn & 0xFFFFu), (int32_t)mn >> 16);
-  const int32_t dmax = max((int32_t)(int16_t)(mx & 0xFFFFu), (int32_t)mx >> 16);
-  const int32_t maxabs = (-dmin) > dmax ? (-dmin) : dmax;
+  const uint32_t umax = max(mxu & 0xFFFFu, mxu >> 16);
+  const int32_t maxabs = (int32_t)((umax + 1u) >> 1);
   uint32_t nb_ = 0, mt = 0;
   if (maxabs <= (int32_t)thr2) {
     const uint32_t ft = (maxabs > (int32_t)thr0 ? 1u : 0u) + (maxabs > (int32_t)thr1 ? 1u : 0u);
     const uint32_t k = (kpack >> (8u * ft)) & 0xFFu;
     uint32_t sum = 0;
 #pragma unroll
-    for (int j = 0; j < 10; ++j) {
-      const uint32_t z = x3_pk_shl_b16(X[B + j], 1) ^ x3_pk_sar_i16(X[B + j], 15);  // zigzag, per half (0 stays 0)
-      X[B + j] = z;
-      sum = x3_pk_add_u16(sum, x3_pk_shr_u16(z, k));
-    }
+    for (int j = 0; j < 10; ++j) sum = x3_pk_add_u16(sum, x3_pk_shr_u16(X[B + j], k));
     nb_ = 2u + cnt * (k + 1u) + (sum & 0xFFFFu) + (sum >> 16);
     mt = (ft + 1u) | ((k + 1u) << 6) | (1u << 11) | (k << 12);
   } else {
@@ -132,7 +135,13 @@ __device__ __forceinline__ void x3w_analyse(uint32_t (&X)[41], uint32_t cnt, uin
       }
       mt = 15u | (16u << 6) | (5u << 12);
     } else {
-      nb_ = 6u + cnt * (nb + 1u);  // X holds the exact differences (|d| < 16 384: nothing was saturated)
+      nb_ = 6u + cnt * (nb + 1u);
+      // the exact differences back from their zigzag values (|d| < 16 384: nothing was saturated): d = (u >> 1) ^ -(u & 1)
+#pragma unroll
+      for (int j = 0; j < 10; ++j) {
+        const uint32_t z = X[B + j];
+        X[B + j] = x3_pk_lshr_b16_1(z) ^ x3_pk_sub_u16(0u, z & 0x00010001u);
+      }
       mt = nb | ((nb + 1u) << 6) | (4u << 12);
     }
   }
@@ -284,7 +293,8 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
   uint32_t* const book = reinterpret_cast<uint32_t*>(smem + X3W_TAB_BYTES);
   // book: [0..127] size slots {tag:12 | bytes:20} of the waves, eight generations (a wave is at most a few generations
   //       ahead of another one of its workgroup: it passes generation g+1 only behind the total of g, which every wave
-  //       has contributed to); [128..135] arrival counters; [136] waves that have left; [140..145] statistics
+  //       has contributed to); [128..135] arrival counters; [136] waves that have left; [140..145] statistics;
+  //       [160..167] / [168..175] / [176..183] tag, low and high word of the generations' bases; [184..191] who fetches them
   const uint32_t tid = threadIdx.x;
   uint32_t lane = tid & 63u;
   const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
@@ -375,9 +385,10 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
           intra = (uint32_t)__builtin_amdgcn_readlane((int)x3_wave_incl_scan_dpp(v & X3_DESC_BYTES_MASK), 63);
           break;
         }
-        if (++spins > (X3_SPIN_LIMIT << 4)) {
+        if (++spins > (X3_SPIN_LIMIT << 4) ||
+            ((spins & 1023u) == 0u && __hip_atomic_load(&status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == X3D_SIZE_WAIT_TIMEOUT)) {
           lost = true;
-          if (lane == 0 && atomicCAS(&status[2], 0, 1) == 0) {  // diagnosis of the first wait that gave up
+          if (spins > (X3_SPIN_LIMIT << 4) && lane == 0 && atomicCAS(&status[2], 0, 1) == 0) {  // diagnosis of the first wait that gave up
             status[3] = (int)prev_wgi; status[4] = (int)(w | (prev_gen << 8)); status[5] = (int)__ballot((v & ~X3_DESC_BYTES_MASK) != gtag);
           }
           break;
@@ -385,7 +396,45 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
         __builtin_amdgcn_s_sleep(2);
       }
     }
+    // The generation's base is the same for the sixteen waves: whoever has summed it leaves it in LDS, the others
+    // take it from there (about one wave in two pays the trip to the descriptors: they arrive in clusters).
+    bool have_base = false;
     if (!lost) {
+      const uint32_t t = __hip_atomic_load(&book[160u + par], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (t == gtag) {
+        const uint32_t lo = __hip_atomic_load(&book[168u + par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t hi = __hip_atomic_load(&book[176u + par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        gen_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+        have_base = true;
+      }
+    }
+#if X3W_CLAIM
+    // one wave per generation makes the trip; the others wait for its result in LDS (the descriptors are polled by
+    // 256 waves instead of 4 096)
+    if (!lost && !have_base) {
+      uint32_t mine = 0;
+      if (lane == 0) mine = __hip_atomic_fetch_max(&book[184u + par], prev_gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != prev_gen + 1u;
+      if (!(uint32_t)__builtin_amdgcn_readfirstlane((int)mine)) {
+        uint32_t spins = 0;
+        for (;;) {
+          if (__hip_atomic_load(&book[160u + par], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == gtag) {
+            const uint32_t lo = __hip_atomic_load(&book[168u + par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t hi = __hip_atomic_load(&book[176u + par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            gen_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+            have_base = true;
+            break;
+          }
+          if (++spins > (X3_SPIN_LIMIT << 4) ||
+              ((spins & 1023u) == 0u && __hip_atomic_load(&status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == X3D_SIZE_WAIT_TIMEOUT)) {
+            lost = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+    }
+#endif
+    if (!lost && !have_base) {
       const uint32_t need = prev_gen == 0 ? b : a.nwg;  // totals in front of generation prev_wgi that count
       const bool in0 = lane < need, in1 = lane + 64u < need, in2 = lane + 128u < need, in3 = lane + 192u < need;
       const uint32_t* p0 = a.desc + prev_wgi - 1u - lane;
@@ -403,6 +452,11 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
                                                      (v2 & X3_DESC_BYTES_MASK) + (v3 & X3_DESC_BYTES_MASK));
           const uint64_t from = prev_gen == 0 ? ((a.start_pos + 1ull) & ~1ull) : gen_base;  // writer.align::<2>() (encoder.rs:182)
           gen_base = from + (uint32_t)__builtin_amdgcn_readlane((int)sum, 63);
+          if (lane == 0) {
+            __hip_atomic_store(&book[168u + par], (uint32_t)gen_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&book[176u + par], (uint32_t)(gen_base >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&book[160u + par], gtag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
           break;
         }
         // give up after the bounded spin -- or as soon as ANY wave has: the host encodes the call again
@@ -445,12 +499,14 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
       // (encoder.rs:153-154): the state behind the constant bytes "x3", id, id is a constant; the (samples,
       // payload_len) word and the eight zero time bytes go through the slicing tables.
       if (lane < 10) {
-        constexpr uint32_t K4 = x3_crc16_const4(0x78u, 0x33u, 0x01u, 0x01u);
-        const uint32_t mm = (((prev_n & 0xFFFFu) << 16) | (L & 0xFFFFu)) ^ (K4 << 16);
-        uint32_t hc = (uint32_t)tab[768u + (mm >> 24)] ^ (uint32_t)tab[512u + ((mm >> 16) & 0xFFu)] ^
-                      (uint32_t)tab[256u + ((mm >> 8) & 0xFFu)] ^ (uint32_t)tab[mm & 0xFFu];
-        hc = (uint32_t)tab[768u + (hc >> 8)] ^ (uint32_t)tab[512u + (hc & 0xFFu)];
-        hc = (uint32_t)tab[768u + (hc >> 8)] ^ (uint32_t)tab[512u + (hc & 0xFFu)];
+        // (table-free byte steps on wave-uniform values: the scalar unit's work, not the vector unit's)
+        uint32_t hc = x3_crc16_const4(0x78u, 0x33u, 0x01u, 0x01u);
+        hc = x3_crc_byte(hc, (prev_n >> 8) & 0xFFu);
+        hc = x3_crc_byte(hc, prev_n & 0xFFu);
+        hc = x3_crc_byte(hc, (L >> 8) & 0xFFu);
+        hc = x3_crc_byte(hc, L & 0xFFu);
+#pragma unroll
+        for (int zb8 = 0; zb8 < 8; ++zb8) hc = x3_crc_byte(hc, 0u);
         const uint32_t hw = lane == 0 ? 0x7833u : lane == 1 ? 0x0101u : lane == 2 ? (prev_n & 0xFFFFu) : lane == 3 ? (L & 0xFFFFu)
                           : lane == 8 ? hc : lane == 9 ? prev_crc : 0u;
         reinterpret_cast<uint16_t*>(dst)[lane] = (uint16_t)(((hw & 0xFFu) << 8) | ((hw >> 8) & 0xFFu));
@@ -613,7 +669,7 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
           for (uint32_t i = 0; i < m_eff; ++i)
             tb += __hip_atomic_load(&book[16u * par + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & X3_DESC_BYTES_MASK;
           __hip_atomic_store(&book[128u + par], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_store(&a.desc[wgi], ready_tag | tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (wgi != a.drop_wgi) __hip_atomic_store(&a.desc[wgi], ready_tag | tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       rank = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
@@ -682,7 +738,6 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
         }
         if (nb1) e.finish();
       }
-      if (have_next) load_half(X1, src_next, n_next, 1);
       X3_STAMP(3);
       x3w_lds_fence();
 
@@ -714,12 +769,28 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
             ra += 512u;
           }
         }
-        for (uint32_t r = 2u - odd; r < rtot; r += 2u) {
+        auto x4096 = [&](uint32_t v) __attribute__((always_inline)) -> uint32_t {
+          return (uint32_t)x3_lds_read_u16(tab_base + x3_sdwa_byte_x2(v, 1), 5376u) ^ (uint32_t)x3_lds_read_u16(tab_base + x3_sdwa_byte_x2(v, 0), 5888u);
+        };
+        // (four rows a trip: the sixteen look-ups of their bytes are in flight together.  Preparing the next trip's words
+        // and look-ups under this trip's chain steps as well -- software pipelining by hand -- made the pass slower:
+        // with sixteen waves the LDS pipe is bound by the look-ups' bank conflicts, not by their latency)
+        uint32_t r = 2u - odd;
+        for (; r + 3u < rtot; r += 4u) {
+          const uint32_t da0 = x3_lds_read_b32(ra), db0 = x3_lds_read_b32(ra + 256u), da1 = x3_lds_read_b32(ra + 512u),
+                         db1 = x3_lds_read_b32(ra + 768u);
+          ra += 1024u;
+          const uint32_t ca0 = crc0dw(da0), cb0 = crc0dw(db0), ca1 = crc0dw(da1), cb1 = crc0dw(db1);
+          sa = x4096(sa) ^ ca0;
+          sb = x4096(sb) ^ cb0;
+          sa = x4096(sa) ^ ca1;
+          sb = x4096(sb) ^ cb1;
+        }
+        if (r < rtot) {
           const uint32_t da = x3_lds_read_b32(ra), db = x3_lds_read_b32(ra + 256u);
-          ra += 512u;
           const uint32_t ca = crc0dw(da), cb = crc0dw(db);
-          sa = (uint32_t)x3_lds_read_u16(tab_base + x3_sdwa_byte_x2(sa, 1), 5376u) ^ (uint32_t)x3_lds_read_u16(tab_base + x3_sdwa_byte_x2(sa, 0), 5888u) ^ ca;
-          sb = (uint32_t)x3_lds_read_u16(tab_base + x3_sdwa_byte_x2(sb, 1), 5376u) ^ (uint32_t)x3_lds_read_u16(tab_base + x3_sdwa_byte_x2(sb, 0), 5888u) ^ cb;
+          sa = x4096(sa) ^ ca;
+          sb = x4096(sb) ^ cb;
         }
         // chain a ends one row in front of chain b
         const uint32_t s = (uint32_t)x3_lds_read_u16(tab_base + x3_sdwa_byte_x2(sa, 1), 2048u) ^
@@ -744,6 +815,9 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
       } else if (lane == 0) {
         atomicMax(&status[1], X3D_IMAGE_OVERFLOW);
       }
+      // the next frame's second half: behind the CRC pass (whose look-ups want the registers), in front of the
+      // analysis of its first half
+      if (have_next) load_half(X1, src_next, n_next, 1);
       X3_STAMP(4);
 
       // ---- this frame waits in its image; the wave goes on to its next one
