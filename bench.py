@@ -423,7 +423,10 @@ def main():
                     kt[name] = round(ms / cnt, 4)
             c.enable_kernel_timing(False)
             return dt, kt
-        # (a) cold: a NEW context (own stream, no history: no pace words, no scratch), ONE step
+        # (a) cold: a NEW context (own stream, no history: no pace words, no scratch), ONE step.  (Two steps of the old
+        # context first: the verification above kept the host busy for seconds and the GPU's clocks have dropped.)
+        step(); step()
+        assert ctx.encode_result()[0] == 0 and ctx.decode_result()[:3] == (0, F, 0)
         c2 = x3hip.Context(local_rank)
         def step2():
             assert c2.encode_dev(wav.data_ptr(), n, p, out.data_ptr(), cap, 0, off.data_ptr()) == 0
@@ -433,7 +436,8 @@ def main():
         dt, kt = timed_steps(c2, step2, 1)
         assert c2.encode_result()[0] == 0 and c2.decode_result()[:3] == (0, F, 0) and torch.equal(back, wav)
         cold = {"ms_per_step": round(dt * 1e3, 4), "value": round(n / dt / 1e6, 2), "kernels_ms": kt,
-                "note": "first encode+decode of a fresh context (scratch allocation, no launch history), host wall time"}
+                "note": "first encode+decode of a fresh context (scratch allocation, no launch history) on a GPU that is awake; "
+                        "ms_per_step is host wall time incl. the allocations, kernels_ms the kernels alone"}
         c2.close()
         # (b) the round trip when the decoder does not get the encoder's frame index: x3_encode_dev + x3_decode_stream_dev
         def step_walk():

@@ -164,8 +164,10 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
   // offset from row 16 on); dwords behind the end of the stream read as zero.  (With a 64-bit address and a bounds
   // select per load the kernel needed 167 VGPRs, and beside the decoder's groups a SIMD had room for ONE of its waves.)
   const uint32_t lane4 = 4u * lane;
-  auto rsrc_at = [&](uint64_t dw) -> __amdgpu_buffer_rsrc_t {  // the stream from dword `dw` on (uniform)
-    const uint64_t left = dw < n_dw ? (n_dw - dw) * 4u : 0u;
+  // the stream from dword `dw` on (uniform), `cap` bytes of it at most
+  auto rsrc_at = [&](uint64_t dw, uint64_t cap = ~0ull) -> __amdgpu_buffer_rsrc_t {
+    uint64_t left = dw < n_dw ? (n_dw - dw) * 4u : 0u;
+    if (left > cap) left = cap;
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)dw);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(dw >> 32));
     const uint64_t d = ((uint64_t)hi << 32) | lo;
@@ -178,22 +180,34 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
       pd[u] = u < 16u ? __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(voff + 256u * u), 0, 0)
                       : __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(voff + 256u * (u - 16u)), 4096, 0);
   };
-  auto request = [&](uint64_t off, uint32_t (&hd)[6], uint32_t (&pd)[X3_CHECK_AHEAD]) {
+  // `span`: bytes from this frame's header to the next frame's, where the frame index says so (the descriptor then ends
+  // with the frame: rows behind it cost no memory traffic -- fetching 24 rows = 6 KB of every 5.3 KB frame was 1.23 x the
+  // stream in HBM reads); ~0: not known, the payload is asked for speculatively up to the end of the stream
+  auto request = [&](uint64_t off, uint64_t span, uint32_t (&hd)[6], uint32_t (&pd)[X3_CHECK_AHEAD]) {
     const __amdgpu_buffer_rsrc_t rh = rsrc_at(off >> 2);
 #pragma unroll
     for (uint32_t i = 0; i < 6u; ++i) hd[i] = __builtin_amdgcn_raw_buffer_load_b32(rh, (int)(4u * i), 0, 0);
-    load_rows(rsrc_at((off + 20) >> 2), lane4, pd);
+    // (whole dwords from the aligned dword of payload byte 0 to the one of the frame's last byte)
+    const uint64_t cap = span == ~0ull || span < 20u ? ~0ull : ((((off + span + 3u) >> 2) - ((off + 20u) >> 2)) << 2);
+    load_rows(rsrc_at((off + 20) >> 2, cap), lane4, pd);
+  };
+  auto span_of = [&](uint64_t f_) -> uint64_t {  // (frame_off holds n_frames entries: the last frame's end is not known)
+    if (f_ + 1u >= n_frames) return ~0ull;
+    const uint64_t a_ = frame_off[f_], b_ = frame_off[f_ + 1u];
+    return b_ > a_ ? b_ - a_ : ~0ull;
   };
   uint64_t off_cur = frame_off[f0];
   uint64_t off_next = f0 + waves < n_frames ? frame_off[f0 + waves] : 0;
+  uint64_t span_cur = span_of(f0), span_next = f0 + waves < n_frames ? span_of(f0 + waves) : ~0ull;
   uint32_t hd[6], pd[X3_CHECK_AHEAD];
-  request(off_cur, hd, pd);
+  request(off_cur, span_cur, hd, pd);
 
   for (uint64_t f = f0; f < n_frames; f += waves) {
     // ---- requests for the frames behind this one
     const uint64_t off_next2 = f + 2 * waves < n_frames ? frame_off[f + 2 * waves] : 0;
+    const uint64_t span_next2 = f + 2 * waves < n_frames ? span_of(f + 2 * waves) : ~0ull;
     uint32_t hn[6], pn[X3_CHECK_AHEAD];
-    if (f + waves < n_frames) request(off_next, hn, pn);
+    if (f + waves < n_frames) request(off_next, span_next, hn, pn);
     // ---- this frame: header (decoder.rs:69-118 + the walk's checks)
     const uint64_t off = off_cur;
     uint32_t plen = 0, samples = 0, pcrc = 0;
@@ -243,6 +257,9 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
         const uint32_t last_mask = lane < last_lane ? 0xFFFFFFFFu : (lane == last_lane ? 0xFFFFFFFFu << (8u * tpad) : 0u);
         uint32_t acc = 0;
         uint32_t rows_done = 0;
+        // (a frame index that disagrees with the header -- the caller's offsets are closer together than the frames are
+        // long: the speculative fetch was cut short; the payload again, unbounded)
+        if (span_cur != ~0ull && 20ull + plen > span_cur) load_rows(rsrc_at(p0 >> 2), lane4, pd);
         for (uint32_t rbase = 0; rbase < R; rbase += X3_CHECK_AHEAD) {
           if (rbase) {
             // payloads longer than the look-ahead (high-entropy data: up to 20 KB per frame): the same registers,
@@ -299,6 +316,8 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
     // ---- rotate
     off_cur = off_next;
     off_next = off_next2;
+    span_cur = span_next;
+    span_next = span_next2;
 #pragma unroll
     for (uint32_t i = 0; i < 6u; ++i) hd[i] = hn[i];
 #pragma unroll

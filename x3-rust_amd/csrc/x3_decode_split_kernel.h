@@ -142,7 +142,10 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     else if (T == 0u) t16 = P - P / 22u;
     else {
       const uint32_t r = (P << 8) / T;  // 256 = met exactly
-      t16 = r < 259u ? T - T / 24u : (r < 264u ? T - T / 64u : (r <= 272u ? T : P - P / 22u));  // (met with room to spare: 4 % faster)
+      // (met with room to spare: 4 % faster.  Missed: back off, but by no more than 3 % a launch -- a launch that missed by
+      // far did so for another reason, e.g. the first one of a process on idle clocks, and the target was right)
+      const uint32_t back = P - P / 22u, cap3 = T + T / 32u;
+      t16 = r < 259u ? T - T / 24u : (r < 264u ? T - T / 64u : (r <= 272u ? T : (back < cap3 ? back : cap3)));
     }
     if (t16 < 64u) t16 = 64u;
     if (t16 > mask) t16 = mask;

@@ -188,15 +188,22 @@ __device__ __forceinline__ uint32_t x3_lds_read_b32(uint32_t addr) {
 __device__ __forceinline__ uint32_t x3_lds_addr(const void* p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(const char*)p;
 }
-// byte k of a dword, times two (a uint16 table offset): one SDWA shift
+// byte k of a dword, times two (a uint16 table offset): one SDWA shift (the shift count from a scalar register: a
+// vector register holding the constant 1 for the life of a kernel is one register too many in the tightest ones)
 __device__ __forceinline__ uint32_t x3_sdwa_byte_x2(uint32_t v, int k) {
   uint32_t r;
   switch (k) {
-    case 0: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(1u), "v"(v)); break;
-    case 1: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(1u), "v"(v)); break;
-    case 2: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(1u), "v"(v)); break;
-    default: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(1u), "v"(v)); break;
+    case 0: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "s"(1u), "v"(v)); break;
+    case 1: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "s"(1u), "v"(v)); break;
+    case 2: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "s"(1u), "v"(v)); break;
+    default: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "s"(1u), "v"(v)); break;
   }
+  return r;
+}
+// a << 1 per half, the count as an inline constant
+__device__ __forceinline__ uint32_t x3_pk_shl_b16_1(uint32_t a) {
+  uint32_t r;
+  asm("v_pk_lshlrev_b16 %0, 1, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a));
   return r;
 }
 // one uint16 from an LDS byte address + constant

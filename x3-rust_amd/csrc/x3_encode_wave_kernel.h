@@ -106,7 +106,7 @@ __device__ __forceinline__ void x3w_analyse(uint32_t (&X)[41], uint32_t cnt, uin
     const uint32_t Xj = __builtin_amdgcn_alignbit(X[B + j + 1], X[B + j], 16);  // (s[2j+1], s[2j+2])
     uint32_t d = x3_pk_sub_sat(Xj, X[B + j]);                                    // (d[2j+1], d[2j+2]), saturated
     if (j == 9) d &= cnt == 20u ? 0xFFFFFFFFu : 0x0000FFFFu;                     // a 19-sample block has no sample 20
-    const uint32_t z = x3_pk_shl_b16(d, 1) ^ x3_pk_sar_i16(d, 15);               // zigzag, per half (0 stays 0)
+    const uint32_t z = x3_pk_shl_b16_1(d) ^ x3_pk_ashr_i16_15(d);                // zigzag, per half (0 stays 0)
     X[B + j] = z;
     mxu = x3_pk_max_u16(mxu, z);
   }
@@ -564,7 +564,9 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
     x3w_lds_fence();
     if (!prev_ovf) {
       const uint32_t nq = rtot * 16u;  // 16-byte pieces
-      for (uint32_t i = lane; i < nq; i += 64u) reinterpret_cast<uint4*>(img)[i] = make_uint4(0, 0, 0, 0);
+      uint32_t z0 = 0;
+      asm volatile("" : "+v"(z0));    // (made here: hipcc otherwise keeps four registers of zeros for the whole kernel -- and spills them)
+      for (uint32_t i = lane; i < nq; i += 64u) reinterpret_cast<uint4*>(img)[i] = make_uint4(z0, z0, z0, z0);
     }
     x3w_lds_fence();
     X3_STAMP(7);
@@ -595,7 +597,6 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
 #endif
       const uint32_t tail = (n - 1u) % 20u;
       const bool plain = tail == 0u || tail == 19u;  // every block has 20 samples, or 19 in the frame's last block
-      const uint32_t s_first = X0[0] & 0xFFFFu;      // (lane 0: the frame's first sample)
 #ifdef X3_DBG_STAMPS
       x3_dma_wait();
       X3_STAMP(0);
@@ -645,9 +646,14 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
       X3_STAMP(1);
 
       // ---- C: bit offsets (the BitPacker's running position as two wave scans)
-      const uint32_t incl0 = x3_wave_incl_scan_dpp(nb0), incl1 = x3_wave_incl_scan_dpp(nb1);
-      const uint32_t tot0 = (uint32_t)__builtin_amdgcn_readlane((int)incl0, 63);
-      const uint32_t tot1 = (uint32_t)__builtin_amdgcn_readlane((int)incl1, 63);
+      uint32_t excl0, excl1, tot0, tot1;  // (only the exclusive sums stay: whether a lane has blocks is in its metas)
+      {
+        const uint32_t incl0 = x3_wave_incl_scan_dpp(nb0), incl1 = x3_wave_incl_scan_dpp(nb1);
+        tot0 = (uint32_t)__builtin_amdgcn_readlane((int)incl0, 63);
+        tot1 = (uint32_t)__builtin_amdgcn_readlane((int)incl1, 63);
+        excl0 = incl0 - nb0;
+        excl1 = incl1 - nb1;
+      }
       const uint32_t bits = 16u + tot0 + tot1;                 // <Audio State> + blocks (encoder.rs:189-200)
       const uint32_t L = (((bits + 7u) >> 3) + 1u) & ~1u;      // word_align (bitpacker.rs:124-132)
       const uint32_t rtot = (L + 255u) >> 8;                   // image rows that hold payload
@@ -697,46 +703,54 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
       }
 
       // ---- D: emission, half 0 then half 1; the next frame's halves are requested as their registers fall free.
-      // Lane 0 starts with the frame's first sample.
+      // Lane 0 starts with the frame's first sample.  (The block sizes are worked out again rather than kept from the
+      // analysis: registers.)
+      int32_t rem0e, rem1e;
+      {
+        uint32_t lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        rem0e = (int32_t)n - 1 - 80 * (int32_t)lane_e;
+        rem1e = rem0e - (int32_t)X3W_PART;
+      }
       if (!ovf) {
         X3WEmit e;
-        const uint32_t bp = lane ? 16u + incl0 - nb0 : 0u;
+        const uint32_t bp = lane ? 16u + excl0 : 0u;
         e.acc = 0;
         e.pend = bp & 31u;
         e.waddr = img_addr + 4u * (bp >> 5);
-        if (lane == 0) e.put(s_first, 16u);
+        if (lane == 0) e.put(*reinterpret_cast<const uint32_t*>(src) & 0xFFFFu, 16u);  // the frame's first sample (frames are 16-byte aligned)
         if (plain) {
-          x3w_emit<0>(X0, mA & 0xFFFFu, x3w_cnt_of(rem0, 0), e); x3w_emit<1>(X0, mA >> 16, x3w_cnt_of(rem0, 1), e);
-          x3w_emit<2>(X0, mB & 0xFFFFu, x3w_cnt_of(rem0, 2), e); x3w_emit<3>(X0, mB >> 16, x3w_cnt_of(rem0, 3), e);
+          x3w_emit<0>(X0, mA & 0xFFFFu, x3w_cnt_of(rem0e, 0), e); x3w_emit<1>(X0, mA >> 16, x3w_cnt_of(rem0e, 1), e);
+          x3w_emit<2>(X0, mB & 0xFFFFu, x3w_cnt_of(rem0e, 2), e); x3w_emit<3>(X0, mB >> 16, x3w_cnt_of(rem0e, 3), e);
         } else {
           const __amdgpu_buffer_rsrc_t rs_cur =
               __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(src), 0, (int)((2u * n + 3u) & ~3u), 0x00020000);
-          x3w_slow_emit(rs_cur, 4u * lane + 0u, x3w_cnt_of(rem0, 0), mA & 0xFFFFu, e);
-          x3w_slow_emit(rs_cur, 4u * lane + 1u, x3w_cnt_of(rem0, 1), mA >> 16, e);
-          x3w_slow_emit(rs_cur, 4u * lane + 2u, x3w_cnt_of(rem0, 2), mB & 0xFFFFu, e);
-          x3w_slow_emit(rs_cur, 4u * lane + 3u, x3w_cnt_of(rem0, 3), mB >> 16, e);
+          x3w_slow_emit(rs_cur, 4u * lane + 0u, x3w_cnt_of(rem0e, 0), mA & 0xFFFFu, e);
+          x3w_slow_emit(rs_cur, 4u * lane + 1u, x3w_cnt_of(rem0e, 1), mA >> 16, e);
+          x3w_slow_emit(rs_cur, 4u * lane + 2u, x3w_cnt_of(rem0e, 2), mB & 0xFFFFu, e);
+          x3w_slow_emit(rs_cur, 4u * lane + 3u, x3w_cnt_of(rem0e, 3), mB >> 16, e);
         }
-        if (nb0 || lane == 0) e.finish();
+        if ((mA | mB) || lane == 0) e.finish();
       }
       if (have_next) load_half(X0, src_next, n_next, 0);
       if (!ovf) {
         X3WEmit e;
-        const uint32_t bp = 16u + tot0 + incl1 - nb1;
+        const uint32_t bp = 16u + tot0 + excl1;
         e.acc = 0;
         e.pend = bp & 31u;
         e.waddr = img_addr + 4u * (bp >> 5);
         if (plain) {
-          x3w_emit<0>(X1, mC & 0xFFFFu, x3w_cnt_of(rem1, 0), e); x3w_emit<1>(X1, mC >> 16, x3w_cnt_of(rem1, 1), e);
-          x3w_emit<2>(X1, mD & 0xFFFFu, x3w_cnt_of(rem1, 2), e); x3w_emit<3>(X1, mD >> 16, x3w_cnt_of(rem1, 3), e);
+          x3w_emit<0>(X1, mC & 0xFFFFu, x3w_cnt_of(rem1e, 0), e); x3w_emit<1>(X1, mC >> 16, x3w_cnt_of(rem1e, 1), e);
+          x3w_emit<2>(X1, mD & 0xFFFFu, x3w_cnt_of(rem1e, 2), e); x3w_emit<3>(X1, mD >> 16, x3w_cnt_of(rem1e, 3), e);
         } else {
           const __amdgpu_buffer_rsrc_t rs_cur =
               __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(src), 0, (int)((2u * n + 3u) & ~3u), 0x00020000);
-          x3w_slow_emit(rs_cur, 256u + 4u * lane + 0u, x3w_cnt_of(rem1, 0), mC & 0xFFFFu, e);
-          x3w_slow_emit(rs_cur, 256u + 4u * lane + 1u, x3w_cnt_of(rem1, 1), mC >> 16, e);
-          x3w_slow_emit(rs_cur, 256u + 4u * lane + 2u, x3w_cnt_of(rem1, 2), mD & 0xFFFFu, e);
-          x3w_slow_emit(rs_cur, 256u + 4u * lane + 3u, x3w_cnt_of(rem1, 3), mD >> 16, e);
+          x3w_slow_emit(rs_cur, 256u + 4u * lane + 0u, x3w_cnt_of(rem1e, 0), mC & 0xFFFFu, e);
+          x3w_slow_emit(rs_cur, 256u + 4u * lane + 1u, x3w_cnt_of(rem1e, 1), mC >> 16, e);
+          x3w_slow_emit(rs_cur, 256u + 4u * lane + 2u, x3w_cnt_of(rem1e, 2), mD & 0xFFFFu, e);
+          x3w_slow_emit(rs_cur, 256u + 4u * lane + 3u, x3w_cnt_of(rem1e, 3), mD >> 16, e);
         }
-        if (nb1) e.finish();
+        if (mC | mD) e.finish();
       }
       X3_STAMP(3);
       x3w_lds_fence();
