@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
   uint32_t* const book = reinterpret_cast<uint32_t*>(smem + X3W_TAB_BYTES);
   // book: [0..127] size slots {tag:12 | bytes:20} of the waves, eight generations (a wave is at most a few generations
   //       ahead of another one of its workgroup: it passes generation g+1 only behind the total of g, which every wave
-  //       has contributed to); [128..135] arrival counters; [136] waves that have left; [140..145] statistics;
+  //       has contributed to); [128..135] arrival counters; [136] waves that have left; [192..255] statistics (eight copies of six counters);
   //       [160..167] / [168..175] / [176..183] tag, low and high word of the generations' bases; [184..191] who fetches them
   const uint32_t tid = threadIdx.x;
   uint32_t lane = tid & 63u;
@@ -612,7 +612,9 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
         const uint32_t vo_cur = 160u * lane;
         auto stat = [&](uint32_t mt, uint32_t cnt) __attribute__((always_inline)) {
           // statistics (encoder.rs:199): stats[index] += block.len(), summed per workgroup in LDS
-          if (mt) atomicAdd(&book[140u + ((mt >> 12) & 7u)], cnt);
+          // (eight copies of the six counters, by lane: sixty-four lanes adding to two or three addresses serialise in
+          // the LDS -- 4 % of the kernel's time with one copy)
+          if (mt) atomicAdd(&book[192u + 8u * (lane & 7u) + ((mt >> 12) & 7u)], cnt);
         };
         if (plain) {
           x3w_analyse<0>(X0, x3w_cnt_of(rem0, 0), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 0u, t, m0); nb0 += t;
@@ -862,7 +864,8 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
     const uint32_t old = __hip_atomic_fetch_add(&book[136], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (old == a.m - 1u) {
       for (uint32_t i = 0; i < 6; ++i) {
-        const uint32_t v = __hip_atomic_load(&book[140u + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint32_t v = 0;
+        for (uint32_t c8 = 0; c8 < 8; ++c8) v += __hip_atomic_load(&book[192u + 8u * c8 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (v) atomicAdd(&stats[i], (unsigned long long)v);
       }
     }
