@@ -94,7 +94,14 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="samples timed on the CPU baseline")
     ap.add_argument("--cpu-reps", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gather", action="store_true", help="leave the reassembly on rank 0 out of the step")
+    ap.add_argument("--no-gather", action="store_true", help="= --gather none")
+    ap.add_argument("--gather", choices=("in-step", "overlapped", "none"), default="in-step",
+                    help="N > 1: the reassembly of the whole stream on rank 0 -- inside every step on the context's stream (the "
+                         "contract's `value`), beside the next steps on the shard's own stream and communicator, or not at all; "
+                         "the other two modes are timed as well (gather_modes)")
+    ap.add_argument("--mode-steps", type=int, default=10, help="timed steps for each of the gather modes that is not --gather")
+    ap.add_argument("--verify-gather", action="store_true",
+                    help="rank 0 compares the reassembled stream with the oracle's encoding of the whole signal (small totals)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: --total-samples cut into N frame ranges")
     ap.add_argument("--total-samples", type=int, default=8 * N_SAMPLES, help="--strong: the whole stream (config 4: 8 h)")
     ap.add_argument("--no-verify-all", action="store_true", help="compare only sampled frames with the CPU oracle")
@@ -158,33 +165,85 @@ def main():
         shard_obj = x3hip.Shard(ctx, bytes(idt.cpu().numpy().tobytes()), rank, world)
         rccl = "librccl via x3_shard_* (ncclAllGather of %d lengths; grouped ncclSend/ncclRecv to rank 0)" % world
 
-    gather_in_step = dist is not None and not args.no_gather
+    if args.no_gather:
+        args.gather = "none"
+    gather_mode = args.gather if dist is not None else "none"
+    gather_in_step = gather_mode == "in-step"
 
-    def step():
-        rc = ctx.encode_dev(wav.data_ptr(), n, p, out.data_ptr(), cap, 0, off.data_ptr())
+    # The overlapped reassembly needs the sub-stream of step k-1 to stay put while step k+1 is encoded: three output
+    # buffers (and frame indexes, length vectors) in rotation; the other modes use the first one only.
+    NB = 3 if dist is not None else 1
+    outs = [out] + [torch.empty(cap + 16, dtype=torch.uint8, device=dev) for _ in range(NB - 1)]
+    offs_b = [off] + [torch.empty(F + 1, dtype=torch.int64, device=dev) for _ in range(NB - 1)]
+    lens_b = [lens] + [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(NB - 1)]
+    lens_pin = [torch.zeros(world, dtype=torch.int64).pin_memory() for _ in range(NB)] if dist is not None else []
+    lens_ev = [torch.cuda.Event() for _ in range(NB)] if dist is not None else []
+    pipe = {"k": 0, "issued": -1}   # steps enqueued so far in overlapped mode; the last step whose reassembly was issued
+
+    def one_step(mode, b=0):
+        """encode + decode (+ the exchange of the lengths, + the reassembly as `mode` says) with output buffer b"""
+        rc = ctx.encode_dev(wav.data_ptr(), n, p, outs[b].data_ptr(), cap, 0, offs_b[b].data_ptr())
         assert rc == 0, (rc, ctx.last_error())
-        rc = ctx.decode_dev(out.data_ptr(), cap, off.data_ptr(), F, p, back.data_ptr(), n, n_per_clip=n)
+        rc = ctx.decode_dev(outs[b].data_ptr(), cap, offs_b[b].data_ptr(), F, p, back.data_ptr(), n, n_per_clip=n)
         assert rc == 0, (rc, ctx.last_error())
         if shard_obj is not None:
             # exchange step 1: sub-stream lengths -> global byte offsets (8 bytes per rank; no rank's decode needs
             # another rank's length, so it is enqueued behind the decoder rather than in front of it)
-            shard_obj.exchange_lengths(off.data_ptr() + 8 * F, lens.data_ptr())
-        if gather_in_step:
+            shard_obj.exchange_lengths(offs_b[b].data_ptr() + 8 * F, lens_b[b].data_ptr())
+        if mode == "in-step":
             # exchange step 2: the whole .x3a byte stream on rank 0.  The lengths have to reach the host first
             # (they are the send/recv sizes): one small copy + sync per step, part of the path's cost
-            lens_h = lens.cpu().tolist()
-            wb = whole_buf(sum(lens_h)) if rank == 0 else None
-            shard_obj.gather(out.data_ptr(), lens_h, 0, wb.data_ptr() if rank == 0 else None,
-                             wb.numel() if rank == 0 else 0)
+            lens_h = lens_b[b].cpu().tolist()
+            wb = whole_buf(sum(lens_h))
+            shard_obj.gather(outs[b].data_ptr(), lens_h, 0, wb.data_ptr() if rank == 0 else None, wb.numel())
+
+    def issue_gather(j):
+        """overlapped mode: the reassembly of step j on the shard's own stream (its lengths are on the host by now)"""
+        bj = j % NB
+        lens_ev[bj].synchronize()            # step j has run (the steps behind it go on)
+        lens_h = lens_pin[bj].tolist()
+        shard_obj.gather_wait(on_stream=True)   # one in flight; what is enqueued from here on may reuse ITS buffers
+        wb = whole_buf(sum(lens_h))
+        shard_obj.gather(outs[bj].data_ptr(), lens_h, 0, wb.data_ptr() if rank == 0 else None, wb.numel(), overlapped=True)
+        pipe["issued"] = j
+
+    def step_overlapped():
+        k = pipe["k"]
+        b = k % NB
+        one_step("overlapped", b)
+        lens_pin[b].copy_(lens_b[b], non_blocking=True)
+        lens_ev[b].record(stream)
+        if k >= 1:
+            issue_gather(k - 1)              # beside step k (and k + 1 ...), out of the buffer step k + 2 will write to
+        pipe["k"] = k + 1
+
+    def drain_overlapped():
+        """the last step's reassembly, and the end of all of them"""
+        if pipe["k"] >= 1 and pipe["issued"] < pipe["k"] - 1:
+            issue_gather(pipe["k"] - 1)
+        shard_obj.gather_wait(on_stream=False)
+        pipe["k"], pipe["issued"] = 0, -1
+
+    def step():
+        if gather_mode == "overlapped":
+            step_overlapped()
+        else:
+            one_step(gather_mode)
 
     whole_holder = {}
 
     def whole_buf(total):
+        # (every rank sizes it alike, so that every rank passes the same capacity to the reassembly; only rank 0's is written)
         t = whole_holder.get("t")
         if t is None or t.numel() < total:
-            t = torch.empty(int(total * 1.05) + 4096, dtype=torch.uint8, device=dev)
+            t = torch.empty((int(total * 1.05) + 4096) if rank == 0 else 16, dtype=torch.uint8, device=dev)
             whole_holder["t"] = t
-        return t
+            whole_holder["cap"] = int(total * 1.05) + 4096
+        class _W:   # what the callers use: pointer and the ROOT's capacity
+            def __init__(self, t, cap): self.t, self.cap = t, cap
+            def data_ptr(self): return self.t.data_ptr()
+            def numel(self): return self.cap
+        return _W(t, whole_holder["cap"])
 
     def barrier():
         if dist is not None:
@@ -196,6 +255,8 @@ def main():
         step()
     for _ in range(args.warmup):
         step()
+    if gather_mode == "overlapped":
+        drain_overlapped()
     rc, pos, stats = ctx.encode_result()
     assert rc == 0, (rc, ctx.last_error())
     rc, first_bad, st, before = ctx.decode_result()
@@ -208,6 +269,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if gather_mode == "overlapped":
+        drain_overlapped()   # (the last reassembly is part of the K steps)
     torch.cuda.synchronize(dev)
     barrier()
     t1 = time.perf_counter()
@@ -260,26 +323,74 @@ def main():
 
     # ---- the reassembly on rank 0 alone (and its result: the ranks' sub-streams back to back)
     gather = None
+    gather_modes = None
     if shard_obj is not None:
         lens_h = lens.cpu().tolist()
         starts = x3hip.shard_offsets(lens_h)
         assert lens_h[rank] == pos and all(v % 2 == 0 for v in starts)
-        wb = whole_buf(starts[-1]) if rank == 0 else None
+        wb = whole_buf(starts[-1])
         torch.cuda.synchronize(dev)
         barrier()
         g0 = time.perf_counter()
         greps = 3
         for _ in range(greps):
-            shard_obj.gather(out.data_ptr(), lens_h, 0, wb.data_ptr() if rank == 0 else None, wb.numel() if rank == 0 else 0)
+            shard_obj.gather(out.data_ptr(), lens_h, 0, wb.data_ptr() if rank == 0 else None, wb.numel())
         torch.cuda.synchronize(dev)
         barrier()
         g1 = time.perf_counter()
+        whole_ok = None
         if rank == 0:
-            assert torch.equal(wb[starts[0]:starts[1]], out[:pos]), "rank 0's own part of the gathered stream"
+            wt = wb.t
+            assert torch.equal(wt[starts[0]:starts[1]], out[:pos]), "rank 0's own part of the gathered stream"
+            if args.verify_gather:
+                # the whole reassembled stream against the oracle's encoding of the whole signal (the ranks' signals are
+                # consecutive stretches of one generator: weak -- every rank n samples -- and strong alike)
+                tot_n = args.total_samples if args.strong else n * world
+                full = x3hip.synth(args.kind, SEED, 0, tot_n)
+                rc_o, ref, _ = O.encode(full)
+                whole_ok = bool(rc_o == 0 and ref.size == starts[-1] and np.array_equal(ref, wt[:starts[-1]].cpu().numpy()))
+                assert whole_ok, "the reassembled stream differs from the oracle's encoding of the whole signal"
         gather = {"ms": round((g1 - g0) / greps * 1e3, 3), "bytes": int(starts[-1]),
                   "gb_s": round(starts[-1] / ((g1 - g0) / greps) / 1e9, 1),
                   "pattern": "x3_shard_gather: grouped ncclSend/ncclRecv to rank 0 (one xGMI link per peer)",
-                  "in_timed_region": bool(gather_in_step)}
+                  "in_timed_region": bool(gather_in_step), "mode": gather_mode,
+                  "whole_stream_verified_vs_oracle": whole_ok}
+        # ---- the other two ways of placing the reassembly, timed like the headline (barrier + synchronize on both sides,
+        # maximum over the ranks): in the step, beside the following steps, not at all
+        gather_modes = {}
+        for mode in ("in-step", "overlapped", "none"):
+            if mode == gather_mode:
+                gather_modes[mode] = {"ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                                      "value": round(n * world * args.steps / elapsed / 1e6, 2), "steps": args.steps, "is_value": True}
+                continue
+            def mstep():
+                if mode == "overlapped":
+                    step_overlapped()
+                else:
+                    one_step(mode)
+            for _ in range(3):
+                mstep()
+            if mode == "overlapped":
+                drain_overlapped()
+            barrier()
+            torch.cuda.synchronize(dev)
+            m0 = time.perf_counter()
+            for _ in range(args.mode_steps):
+                mstep()
+            if mode == "overlapped":
+                drain_overlapped()
+            torch.cuda.synchronize(dev)
+            barrier()
+            mt = torch.tensor([time.perf_counter() - m0], dtype=torch.float64, device=dev)
+            dist.all_reduce(mt, op=dist.ReduceOp.MAX)
+            mt = float(mt.item())
+            rc_m = ctx.encode_result()[0]
+            assert rc_m == 0 and ctx.decode_result()[:3] == (0, F, 0), mode
+            gather_modes[mode] = {"ms_per_step": round(mt / args.mode_steps * 1e3, 4),
+                                  "value": round(n * world * args.mode_steps / mt / 1e6, 2), "steps": args.mode_steps, "is_value": False}
+        if rank == 0 and gather_mode != "none":
+            # (the reassembled stream of the last mode run is rank 0's sub-stream followed by the others')
+            assert torch.equal(whole_buf(starts[-1]).t[starts[0]:starts[1]], out[:pos])
 
     # ---- CPU baseline: the oracle (port of the reference algorithm), 1 thread, bounded sample
     cpu = None
@@ -571,6 +682,7 @@ def main():
                 gather["step_ms_without_gather"] = round(rest * 1e3, 4)
                 gather["value_without_gather"] = round(total_samples / rest / 1e6, 2)
             res["gather"] = gather
+            res["gather_modes"] = gather_modes
             res["rccl_ranks"] = world
             res["rccl"] = rccl
         print(json.dumps(res), flush=True)

@@ -399,9 +399,18 @@ int x3_shard_exchange_length_value(x3_shard* shard, uint64_t len, uint64_t* d_le
 int x3_shard_lengths(x3_shard* shard, uint64_t* lengths /* host, world */);
 /* Step 2 (optional: a deployment that writes the file in parallel, or decodes where it encoded, never needs it): the
  * whole stream on `root`, d_dst[starts[r] ..) = rank r's d_sub[0 .. lengths[r]).  lengths: host array, identical on
- * all ranks.  d_dst / dst_cap only count on the root.  Asynchronous on the context's stream. */
+ * all ranks.  d_dst only counts on the root; dst_cap is the ROOT's capacity: every rank that passes it (non-zero) comes
+ * to the same verdict before anything is sent, a rank that passes 0 does not check (and would be left waiting in its
+ * send if the root refused: size the destination from the lengths first).  Asynchronous on the context's stream. */
 int x3_shard_gather(x3_shard* shard, const uint8_t* d_sub, const uint64_t* lengths, int root, uint8_t* d_dst,
                     uint64_t dst_cap, uint64_t* total);
+/* The same reassembly beside the context's work: starts behind everything enqueued on the context's stream so far, runs
+ * on the shard's own stream and communicator (ncclCommSplit), and the context may go on with its next batch -- into
+ * ANOTHER output buffer: d_sub and d_dst stay untouched until x3_shard_gather_wait (on_stream != 0: the context's
+ * stream waits, the host does not; 0: the host waits).  One reassembly in flight per shard.  No reference analogue. */
+int x3_shard_gather_async(x3_shard* shard, const uint8_t* d_sub, const uint64_t* lengths, int root, uint8_t* d_dst,
+                          uint64_t dst_cap, uint64_t* total);
+int x3_shard_gather_wait(x3_shard* shard, int on_stream);
 
 /* x3_mgpu: all GPUs from ONE process -- a context, a shard and a host thread per device.  x3_mgpu_encode /
  * x3_mgpu_decode_stream take and return the same host buffers, bytes and status as x3_encode / x3_decode_stream

@@ -68,4 +68,5 @@ def test_bench_distributed_path_with_one_rank():
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert j["rccl_ranks"] == 1 and "x3_shard" in j["rccl"]
     assert j["gather"]["in_timed_region"] is True and j["gather"]["bytes"] == j["config"]["stream_bytes_per_gpu"]
+    assert set(j["gather_modes"]) == {"in-step", "overlapped", "none"} and j["gather_modes"]["in-step"]["is_value"] is True
     assert j["config"]["frames_verified_vs_oracle"] == j["config"]["frames_per_gpu"]

@@ -953,7 +953,8 @@ def test_decode_dev_survives_wild_frame_offsets(ctx, x3):
 def test_shard_world_of_one_over_rccl(ctx, x3):
     """x3_shard_* with world = 1: librccl is opened, a communicator is built, the all-gather and the gather run --
     the same calls every rank of an 8-GPU job makes (the offset arithmetic for more ranks is covered on the CPU:
-    tests/host_cpp/test_shard_logic.cpp, tests/test_sharding_gloo.py)"""
+    tests/host_cpp/test_shard_logic.cpp, tests/test_sharding_gloo.py; more ranks on a box that has them:
+    test_mgpu_over_all_visible_devices, test_bench_strong_scaling_over_all_visible_devices)"""
     p = x3.Params.default()
     n = 1_234_567
     wav = x3.synth(2, 4711, 0, n)
@@ -976,30 +977,82 @@ def test_shard_world_of_one_over_rccl(ctx, x3):
         assert np.array_equal(ctx.download(d_whole, (pos + 3) & ~3)[:pos], ref)
         with pytest.raises(x3.X3Error):
             sh.gather(d_out, lens, 0, d_whole, pos - 2)  # destination too small
+        # the overlapped form: on the shard's own stream, behind what the context has enqueued; one in flight
+        ctx.upload(d_whole, np.zeros(cap, dtype=np.uint8))
+        assert sh.gather(d_out, lens, 0, d_whole, cap, overlapped=True) == pos
+        with pytest.raises(x3.X3Error):
+            sh.gather(d_out, lens, 0, d_whole, cap, overlapped=True)   # the first one has not been waited for
+        sh.gather_wait(on_stream=False)
+        assert np.array_equal(ctx.download(d_whole, (pos + 3) & ~3)[:pos], ref)
+        assert sh.gather(d_out, lens, 0, d_whole, cap, overlapped=True) == pos
+        sh.gather_wait(on_stream=True)
+        ctx.sync()
     finally:
         sh.close()
         for d in (d_wav, d_out, d_off, d_whole, d_len):
             ctx.free(d)
 
 
-def test_mgpu_with_one_device(x3):
-    """x3_mgpu_* (all GPUs from one process) on a group of one: same bytes and status as the single-context calls"""
-    m = x3.MultiGpu([0])
+def _visible_devices():
+    import torch
+    return max(1, torch.cuda.device_count())   # (counting devices does not initialise the GPU)
+
+
+def test_mgpu_over_all_visible_devices(x3):
+    """x3_mgpu_* (all GPUs from one process: a context, a shard and a host thread per device; lengths by ncclAllGather,
+    sub-streams to device 0 by grouped send/recv) over EVERY device the box shows -- one on the single-GPU boxes, eight
+    on a node: same bytes and status as the single-context calls and as the oracle"""
+    G = _visible_devices()
+    m = x3.MultiGpu(list(range(G)))
     try:
-        for kind, n, sp in ((2, 345_678, 0), (4, 10_000, 3), (1, 25_001, 0), (0, 1, 1)):
+        # (enough frames for every device to get some, and sizes that leave the last devices with none or a ragged tail)
+        for kind, n, sp in ((2, 345_678, 0), (4, 10_000, 3), (1, 25_001, 0), (0, 1, 1), (2, 10_000 * (3 * G + 1) + 17, 0),
+                            (3, 10_000 * G, 2)):
             wav = x3.synth(kind, 31 + kind, 0, n)
             rc, out, stats = m.encode(wav, start_pos=sp)
             rco, oo, so = O.encode(wav, start_pos=sp)
-            assert rc == rco == 0 and np.array_equal(out[sp:], oo[sp:]) and stats.tolist() == so.tolist()
+            assert rc == rco == 0 and np.array_equal(out[sp:], oo[sp:]) and stats.tolist() == so.tolist(), (G, kind, n, sp)
             body = oo[(sp + 1) & ~1:]
             r = m.decode_stream(body, wav_cap=n)
-            assert r[0] == 0 and np.array_equal(r[1], wav) and r[3] == 0
+            assert r[0] == 0 and np.array_equal(r[1], wav) and r[3] == 0, (G, kind, n, sp)
         assert m.encode(wav, n_channels=2)[0] == x3.ERR_MORE_THAN_ONE_CHANNEL
-        assert m.encode(x3.synth(2, 1, 0, 30000), cap=100)[0] == x3.ERR_BYTE_WRITER_INSUFFICIENT_MEMORY
+        assert m.encode(x3.synth(2, 1, 0, 30000 * G), cap=100)[0] == x3.ERR_BYTE_WRITER_INSUFFICIENT_MEMORY
+        # a damaged frame in the middle: nothing behind it is delivered, whichever device it falls to
+        wav = x3.synth(2, 77, 0, 10_000 * (2 * G + 3))
+        good = O.encode(wav)[1].copy()
+        bad = good.copy()
+        bad[len(bad) // 2] ^= 0x40
+        r_g = m.decode_stream(bad, wav_cap=wav.size)
+        r_o = O.decode_stream(bad, wav_cap=wav.size)
+        assert r_g[0] == r_o[0] and r_g[2] == r_o[2] and np.array_equal(r_g[1], r_o[1])
     finally:
         m.close()
     with pytest.raises(x3.X3Error):
         x3.MultiGpu([0, 0])   # one rank per GPU
+
+
+def test_bench_strong_scaling_over_all_visible_devices():
+    """bench.py --strong under torch.distributed.run with one rank per visible device (skipped on a single-GPU box): the
+    ranks encode their frame ranges, exchange the lengths over RCCL and reassemble the stream on rank 0 in all three
+    gather modes; rank 0 compares the reassembled stream with the oracle's encoding of the whole signal, byte for byte"""
+    import subprocess
+    import sys
+    G = _visible_devices()
+    if G < 2:
+        pytest.skip("one GPU: the one-rank form of this run is test_bench_distributed_path_with_one_rank")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for mode in ("in-step", "overlapped"):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(G),
+                            "--master-addr", "127.0.0.1", "--master-port", "29521", os.path.join(root, "bench.py"), "--gpus", str(G),
+                            "--steps", "3", "--warmup", "2", "--strong", "--total-samples", str(10_000 * (37 * G + 5) + 123),
+                            "--verify-gather", "--gather", mode, "--mode-steps", "3"],
+                           capture_output=True, text=True, timeout=900, cwd=root, env=env)
+        assert r.returncode == 0, (mode, r.stdout[-1500:], r.stderr[-3000:])
+        j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+        assert j["n_gpus"] == G and j["rccl_ranks"] == G and j["scaling"] == "strong"
+        assert j["gather"]["whole_stream_verified_vs_oracle"] is True and j["gather"]["mode"] == mode
+        assert set(j["gather_modes"]) == {"in-step", "overlapped", "none"}
 
 
 def test_decode_frame_loop_with_prefetch(ctx):

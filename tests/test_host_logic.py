@@ -126,23 +126,25 @@ def test_oracle_roundtrip_on_synthetic_kinds():
         assert (rc, fok, ferr) == (0, 5, 0) and np.array_equal(back, wav)
 
 
-def test_shard_arithmetic_matches_the_python_harness():
-    """x3_shard_frame_range / sample_range / offsets (C ABI, host arithmetic) == x3hip/shard.py (the gloo test harness)"""
-    import sys
-    sys.path.insert(0, os.path.join(ROOT, "x3-rust_amd"))
-    from x3hip import shard
+def test_shard_arithmetic():
+    """x3_shard_frame_range / sample_range / offsets (C ABI, host arithmetic): contiguous ranges of whole frames that
+    cover everything once, the remainder one frame each to the first ranks, offsets = exclusive scan of the lengths"""
     p = x3hip.Params.default()
     for F in [0, 1, 2, 7, 8, 9, 69120, 552960]:
         for world in [1, 2, 3, 4, 8]:
-            for r in range(world):
-                lo, hi = shard.frame_range(F, r, world)
-                assert x3hip.shard_frame_range(F, r, world) == (lo, hi - lo)
+            base, rem = divmod(F, world)
+            got = [x3hip.shard_frame_range(F, r, world) for r in range(world)]
+            assert got == [(r * base + min(r, rem), base + (1 if r < rem else 0)) for r in range(world)]
+            assert got[0][0] == 0 and got[-1][0] + got[-1][1] == F
     for n in [0, 1, 5, 9999, 10000, 10001, 123457, 691_200_000, 5_529_600_000]:
         for world in [1, 2, 3, 8]:
+            F = (n + 9999) // 10000
             got = [x3hip.shard_sample_range(n, p, r, world) for r in range(world)]
-            assert got == [shard.sample_range(n, 10000, r, world) for r in range(world)]
+            for r, (lo, cnt) in enumerate(got):
+                f_lo, f_n = x3hip.shard_frame_range(F, r, world)
+                assert lo == f_lo * 10000 and cnt == max(0, min(n, (f_lo + f_n) * 10000) - lo)
             assert sum(c for _, c in got) == n
-    assert x3hip.shard_offsets([10, 0, 22, 4]) == [0, 10, 10, 32, 36] == shard.global_offsets([10, 0, 22, 4])
+    assert x3hip.shard_offsets([10, 0, 22, 4]) == [0, 10, 10, 32, 36]
 
 
 def test_rice_code_tables_match_reference_literals():

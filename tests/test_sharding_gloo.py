@@ -1,7 +1,11 @@
-"""world_size-2/3 gloo tests (CPU) of the multi-GPU path's sharding + exchange logic
-(x3-rust_amd/x3hip/shard.py, used unchanged by bench.py with the nccl/RCCL backend).
-Each rank encodes its frame range with the CPU oracle (there is no GPU here); rank 0 checks that the
-reassembled stream is byte-identical to the oracle's encoding of the whole signal."""
+"""world_size-2/3 gloo tests (CPU) of the multi-GPU path's sharding arithmetic and exchange pattern.
+
+What ships is the C ABI: x3_shard_frame_range / x3_shard_sample_range / x3_shard_offsets (host arithmetic, no GPU needed)
+and, on the GPUs, the RCCL calls of x3_shard_exchange_lengths / x3_shard_gather.  Here every rank takes ITS ranges and
+offsets from those C functions (through libx3hip.so, as bench.py does), encodes its frame range with the CPU oracle --
+there is no GPU in this container -- and gloo only moves the bytes the way RCCL does on the GPUs: one all-gather of the
+lengths, then point-to-point sends to the root at the offsets x3_shard_offsets gave.  Rank 0 checks that the reassembled
+stream is byte-identical to the oracle's encoding of the whole signal."""
 import os
 import socket
 import sys
@@ -26,28 +30,40 @@ def _free_port():
 def _worker(rank, world, port, n, result_path):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     sys.path.insert(0, os.path.join(ROOT, "x3-rust_amd"))
+    import ctypes as C
     import oracle_lib as O
     import x3hip
-    from x3hip import shard
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        spf = 10000
-        s_lo, s_n = shard.sample_range(n, spf, rank, world)
+        p = x3hip.Params.default()
+        s_lo, s_n = x3hip.shard_sample_range(n, p, rank, world)          # x3_shard_sample_range
+        f_lo, f_n = x3hip.shard_frame_range((n + p.spf - 1) // p.spf, rank, world)   # x3_shard_frame_range
+        assert s_lo == f_lo * p.spf and s_n == max(0, min(n, (f_lo + f_n) * p.spf) - s_lo)
         wav = x3hip.synth(x3hip.SYNTH_HYDROPHONE, 77, s_lo, s_n)
         rc, sub, stats = O.encode(wav) if s_n else (0, np.zeros(0, dtype=np.uint8), None)
         assert rc == 0
         local = torch.from_numpy(np.ascontiguousarray(sub))
-        lens = shard.exchange_lengths(local.numel())
-        assert lens.tolist()[rank] == local.numel()
-        # the overlapped form bench.py uses: same result once the work handle has been waited for
-        lens2, work = shard.exchange_lengths(local.numel(), async_op=True)
-        work.wait()
-        assert lens2.tolist() == lens.tolist()
-        starts = shard.global_offsets(lens)
+        # step 1 (x3_shard_exchange_lengths on the GPUs: ncclAllGather of one uint64 per rank)
+        mine = torch.tensor([local.numel()], dtype=torch.int64)
+        got = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(got, mine)
+        lens = [int(t.item()) for t in got]
+        assert lens[rank] == local.numel()
+        starts = x3hip.shard_offsets(lens)                                # x3_shard_offsets
+        assert len(starts) == world + 1 and starts[-1] == sum(lens)
         assert all(s % 2 == 0 for s in starts)  # sub-streams concatenate without padding
-        whole = shard.gather_stream(local, lens, dst=0)
+        # step 2 (x3_shard_gather on the GPUs: grouped ncclRecv on the root at starts[r], ncclSend on the peers)
+        whole = None
+        if rank == 0:
+            whole = torch.zeros(starts[-1], dtype=torch.uint8)
+            whole[starts[0]:starts[1]] = local
+            reqs = [dist.irecv(whole[starts[r]:starts[r + 1]], src=r) for r in range(1, world) if lens[r]]
+            for q in reqs:
+                q.wait()
+        elif lens[rank]:
+            dist.send(local, dst=0)
         if rank == 0:
             full = x3hip.synth(x3hip.SYNTH_HYDROPHONE, 77, 0, n)
             rc, ref, _ = O.encode(full)
@@ -72,10 +88,10 @@ def test_sharded_encode_reassembles_to_the_reference_stream(tmp_path, world, n):
 
 def test_frame_ranges_cover_everything():
     sys.path.insert(0, os.path.join(ROOT, "x3-rust_amd"))
-    from x3hip import shard
+    import x3hip
     for F in [0, 1, 2, 7, 8, 9, 69120, 552960]:
         for world in [1, 2, 3, 4, 8]:
-            ranges = [shard.frame_range(F, r, world) for r in range(world)]
-            assert ranges[0][0] == 0 and ranges[-1][1] == F
-            assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
-            assert max(h - l for l, h in ranges) - min(h - l for l, h in ranges) <= 1
+            ranges = [x3hip.shard_frame_range(F, r, world) for r in range(world)]   # (first, count)
+            assert ranges[0][0] == 0 and ranges[-1][0] + ranges[-1][1] == F
+            assert all(ranges[i][0] + ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+            assert max(c for _, c in ranges) - min(c for _, c in ranges) <= 1

@@ -39,8 +39,14 @@ struct X3Rccl {
   decltype(&ncclSend) Send = nullptr;
   decltype(&ncclRecv) Recv = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommSplit) CommSplit = nullptr;  // optional (RCCL >= 2.18): a communicator of its own for the reassembly
+  decltype(&ncclCommAbort) CommAbort = nullptr;  // optional: teardown of a half-built group
   std::string err;
 };
+static std::string& x3_rccl_error() {
+  static std::string e;
+  return e;
+}
 
 static X3Rccl* x3_rccl() {
   static X3Rccl r;
@@ -70,7 +76,12 @@ static X3Rccl* x3_rccl() {
     r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
     if (!ok) { dlclose(r.h); r.h = nullptr; }
+    if (r.h) {
+      r.CommSplit = reinterpret_cast<decltype(r.CommSplit)>(dlsym(r.h, "ncclCommSplit"));
+      r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.h, "ncclCommAbort"));
+    }
   });
+  if (!r.h) x3_rccl_error() = r.err;
   return r.h ? &r : nullptr;
 }
 
@@ -81,6 +92,12 @@ struct x3_shard {
   unsigned long long* d_mine = nullptr;     // this rank's length, when it is not already on the device
   unsigned long long* d_lengths = nullptr;  // [world]
   unsigned long long* h_lengths = nullptr;  // pinned mirror
+  // the overlapped reassembly (x3_shard_gather_async): a stream and a communicator of its own, so that neither the
+  // context's kernels nor its length exchanges queue behind a 360 MB transfer
+  ncclComm_t gcomm = nullptr;               // ncclCommSplit of comm; comm itself where RCCL has no split
+  hipStream_t gstream = nullptr;
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  bool gather_pending = false;
 };
 
 #define RCCLCHK(ctx, R, call)                                                                          \
@@ -143,7 +160,12 @@ extern "C" void x3_shard_destroy(x3_shard* s) {
     (void)hipStreamSynchronize(s->ctx->stream);
   }
   X3Rccl* R = x3_rccl();
+  if (s->gstream) (void)hipStreamSynchronize(s->gstream);
+  if (s->gcomm && s->gcomm != s->comm && R) (void)R->CommDestroy(s->gcomm);
   if (s->comm && R) (void)R->CommDestroy(s->comm);
+  if (s->gstream) (void)hipStreamDestroy(s->gstream);
+  if (s->ev_ready) (void)hipEventDestroy(s->ev_ready);
+  if (s->ev_done) (void)hipEventDestroy(s->ev_done);
   if (s->d_mine) (void)hipFree(s->d_mine);
   if (s->d_lengths) (void)hipFree(s->d_lengths);
   if (s->h_lengths) (void)hipHostFree(s->h_lengths);
@@ -155,7 +177,7 @@ extern "C" int x3_shard_create(x3_ctx* c, const uint8_t id[X3_SHARD_ID_BYTES], i
   *out = nullptr;
   X3Rccl* R = x3_rccl();
   if (!R) {
-    c->last_error = x3_rccl() ? "" : "librccl is not available";
+    c->last_error = "librccl is not available: " + x3_rccl_error();
     return X3_ERR_HIP;
   }
   HIPCHK(c, hipSetDevice(c->device));
@@ -173,10 +195,19 @@ extern "C" int x3_shard_create(x3_ctx* c, const uint8_t id[X3_SHARD_ID_BYTES], i
     return X3_ERR_HIP;
   }
   if (hipMalloc(&s->d_mine, 16) != hipSuccess || hipMalloc(&s->d_lengths, sizeof(uint64_t) * (size_t)world) != hipSuccess ||
-      hipHostMalloc(&s->h_lengths, sizeof(uint64_t) * (size_t)world) != hipSuccess) {
+      hipHostMalloc(&s->h_lengths, sizeof(uint64_t) * (size_t)world) != hipSuccess ||
+      hipStreamCreateWithFlags(&s->gstream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming) != hipSuccess) {
     c->last_error = "x3_shard_create: out of memory";
     x3_shard_destroy(s);
     return X3_ERR_HIP;
+  }
+  // (collective: every rank splits; the same members in the same order)
+  s->gcomm = s->comm;
+  if (R->CommSplit && world > 1) {
+    ncclComm_t g2 = nullptr;
+    if (R->CommSplit(s->comm, 0, rank, &g2, nullptr) == ncclSuccess && g2) s->gcomm = g2;
   }
   *out = s;
   return X3_OK;
@@ -220,36 +251,81 @@ extern "C" int x3_shard_lengths(x3_shard* s, uint64_t* lengths) {
 }
 
 // Step 2: reassemble the whole stream on `root`: d_dst[starts[r] .. starts[r] + lengths[r]) = rank r's d_sub.
-// lengths: HOST array of `world` entries, the same on every rank (x3_shard_lengths).  d_dst / dst_cap only
-// count on the root.  Enqueued on the context's stream; does not synchronise.  *total = the stream's length.
-extern "C" int x3_shard_gather(x3_shard* s, const uint8_t* d_sub, const uint64_t* lengths, int root, uint8_t* d_dst,
-                               uint64_t dst_cap, uint64_t* total) {
-  if (!s || !lengths || root < 0 || root >= s->world) return X3_ERR_BAD_ARG;
+// lengths: HOST array of `world` entries, the same on every rank (x3_shard_lengths).  d_dst only counts on the root;
+// dst_cap is the ROOT's capacity and every rank that passes it (non-zero) comes to the same verdict -- a rank that passes
+// 0 does not check, and is left waiting in its send if the root then refuses: callers size the destination from the
+// lengths before they get here (bench.py, x3_mgpu_encode).  Enqueued on the context's stream; does not synchronise.
+// *total = the stream's length.
+static int x3_shard_gather_on(x3_shard* s, const uint8_t* d_sub, const uint64_t* lengths, int root, uint8_t* d_dst,
+                              uint64_t dst_cap, uint64_t* total, ncclComm_t comm, hipStream_t stream) {
   X3Rccl* R = x3_rccl();
   x3_ctx* c = s->ctx;
-  HIPCHK(c, hipSetDevice(c->device));
   std::vector<uint64_t> starts((size_t)s->world + 1);
   x3_shard_offsets(lengths, s->world, starts.data());
   if (total) *total = starts[s->world];
+  if ((s->rank == root || dst_cap) && starts[s->world] > dst_cap) return X3_ERR_BYTE_WRITER_INSUFFICIENT_MEMORY;
   if (s->rank == root) {
-    if (!d_dst || starts[s->world] > dst_cap) return X3_ERR_BYTE_WRITER_INSUFFICIENT_MEMORY;  // (the same test on no other rank:
-    // callers size the destination from the lengths before they get here, so that all ranks agree)
+    if (!d_dst && starts[s->world]) return X3_ERR_BAD_ARG;
     if (lengths[root] && d_sub != d_dst + starts[root])
-      HIPCHK(c, hipMemcpyAsync(d_dst + starts[root], d_sub, lengths[root], hipMemcpyDeviceToDevice, c->stream));
-    RCCLCHK(c, R, R->GroupStart());
-    for (int r = 0; r < s->world; ++r)
-      if (r != root && lengths[r]) {
-        ncclResult_t e = R->Recv(d_dst + starts[r], lengths[r], ncclUint8, r, s->comm, c->stream);
-        if (e != ncclSuccess) { (void)R->GroupEnd(); RCCLCHK(c, R, e); }
-      }
-    RCCLCHK(c, R, R->GroupEnd());
+      HIPCHK(c, hipMemcpyAsync(d_dst + starts[root], d_sub, lengths[root], hipMemcpyDeviceToDevice, stream));
+    if (s->world > 1) {
+      RCCLCHK(c, R, R->GroupStart());
+      for (int r = 0; r < s->world; ++r)
+        if (r != root && lengths[r]) {
+          ncclResult_t e = R->Recv(d_dst + starts[r], lengths[r], ncclUint8, r, comm, stream);
+          if (e != ncclSuccess) { (void)R->GroupEnd(); RCCLCHK(c, R, e); }
+        }
+      RCCLCHK(c, R, R->GroupEnd());
+    }
   } else if (lengths[s->rank]) {
     if (!d_sub) return X3_ERR_BAD_ARG;
     RCCLCHK(c, R, R->GroupStart());
-    ncclResult_t e = R->Send(d_sub, lengths[s->rank], ncclUint8, root, s->comm, c->stream);
+    ncclResult_t e = R->Send(d_sub, lengths[s->rank], ncclUint8, root, comm, stream);
     if (e != ncclSuccess) { (void)R->GroupEnd(); RCCLCHK(c, R, e); }
     RCCLCHK(c, R, R->GroupEnd());
   }
+  return X3_OK;
+}
+
+extern "C" int x3_shard_gather(x3_shard* s, const uint8_t* d_sub, const uint64_t* lengths, int root, uint8_t* d_dst,
+                               uint64_t dst_cap, uint64_t* total) {
+  if (!s || !lengths || root < 0 || root >= s->world) return X3_ERR_BAD_ARG;
+  HIPCHK(s->ctx, hipSetDevice(s->ctx->device));
+  return x3_shard_gather_on(s, d_sub, lengths, root, d_dst, dst_cap, total, s->comm, s->ctx->stream);
+}
+
+// The same reassembly beside the context's work: it starts when everything enqueued on the context's stream SO FAR has
+// run (the sub-stream is complete) and runs on the shard's own stream and communicator, while the context goes on with
+// its next batch -- into another output buffer: d_sub (and the root's d_dst) must stay untouched until
+// x3_shard_gather_wait.  One reassembly in flight per shard.
+extern "C" int x3_shard_gather_async(x3_shard* s, const uint8_t* d_sub, const uint64_t* lengths, int root, uint8_t* d_dst,
+                                     uint64_t dst_cap, uint64_t* total) {
+  if (!s || !lengths || root < 0 || root >= s->world) return X3_ERR_BAD_ARG;
+  x3_ctx* c = s->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (s->gather_pending) {
+    c->last_error = "x3_shard_gather_async: the reassembly before this one has not been waited for";
+    return X3_ERR_BAD_ARG;
+  }
+  HIPCHK(c, hipEventRecord(s->ev_ready, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(s->gstream, s->ev_ready, 0));
+  int rc = x3_shard_gather_on(s, d_sub, lengths, root, d_dst, dst_cap, total, s->gcomm, s->gstream);
+  if (rc) return rc;
+  HIPCHK(c, hipEventRecord(s->ev_done, s->gstream));
+  s->gather_pending = true;
+  return X3_OK;
+}
+
+// on_stream != 0: the context's stream waits for the reassembly in flight (what is enqueued behind this call may reuse
+// the buffers; the host does not block); on_stream == 0: the host waits.  No reassembly in flight: nothing happens.
+extern "C" int x3_shard_gather_wait(x3_shard* s, int on_stream) {
+  if (!s) return X3_ERR_BAD_ARG;
+  x3_ctx* c = s->ctx;
+  if (!s->gather_pending) return X3_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (on_stream) HIPCHK(c, hipStreamWaitEvent(c->stream, s->ev_done, 0));
+  else HIPCHK(c, hipEventSynchronize(s->ev_done));
+  s->gather_pending = false;
   return X3_OK;
 }
 
@@ -297,7 +373,7 @@ extern "C" int x3_mgpu_create(const int* devices, int n, x3_mgpu** out) {
   uint8_t id[X3_SHARD_ID_BYTES];
   int rc = n > 1 ? x3_shard_unique_id(id) : X3_OK;
   if (rc) {
-    std::fprintf(stderr, "x3hip: x3_mgpu_create: %s\n", x3_rccl() ? "ncclGetUniqueId failed" : "librccl is not available");
+    std::fprintf(stderr, "x3hip: x3_mgpu_create: %s\n", x3_rccl() ? "ncclGetUniqueId failed" : ("librccl is not available: " + x3_rccl_error()).c_str());
     delete m;
     return rc;
   }
@@ -311,7 +387,19 @@ extern "C" int x3_mgpu_create(const int* devices, int n, x3_mgpu** out) {
       if (m->ctx[g]) std::fprintf(stderr, "x3hip: x3_mgpu_create, device %d: %s\n", devices[g], m->ctx[g]->last_error.c_str());
     }
   if (rc) {
-    for (auto& s : m->shard) { if (s) { /* a half-built group cannot be torn down collectively */ } }
+    // a half-built group: the ranks that did join are aborted (a collective destroy would wait for the ones that did
+    // not), every rank on its own thread, then their device and pinned buffers go
+    X3Rccl* R = x3_rccl();
+    x3_mgpu_parallel(n, [&](int g) {
+      x3_shard* sh = m->shard[g];
+      if (!sh) return;
+      if (R && R->CommAbort) {
+        if (sh->gcomm && sh->gcomm != sh->comm) (void)R->CommAbort(sh->gcomm);
+        if (sh->comm) (void)R->CommAbort(sh->comm);
+        sh->gcomm = sh->comm = nullptr;
+      }
+      x3_shard_destroy(sh);
+    });
     m->shard.clear();
     for (x3_ctx* c : m->ctx) if (c) x3_ctx_destroy(c);
     delete m;
@@ -373,16 +461,17 @@ extern "C" int x3_mgpu_encode(x3_mgpu* m, const int16_t* wav, uint64_t n, uint32
     int e2 = x3_shard_exchange_length_value(s, len, nullptr);
     if (!e2) e2 = x3_shard_lengths(s, all[g].data());
     if (e2) { failed.store(1); if (!rcs[g]) rcs[g] = e2; }
-    pthread_barrier_wait(&bar);
-    if (failed.load()) return;
+    pthread_barrier_wait(&bar);  // B1: every rank has every length -- or has raised `failed`
     uint64_t tot = 0;
     for (int r = 0; r < G; ++r) tot += all[g][r];
     if (g == 0) total = tot;
-    if (base + tot > out_cap) return;  // the same verdict on every rank; reported below
-    // step 2: sub-streams to devices[0] over xGMI, then one copy to the caller's buffer
-    if (g == 0 && (e = ensure(c, m->whole, tot + 16))) { rcs[0] = e; failed.store(1); }
-    pthread_barrier_wait(&bar);
-    if (failed.load()) return;
+    const bool over = base + tot > out_cap;  // the same verdict on every rank; reported below
+    // step 2: sub-streams to devices[0] over xGMI, then one copy to the caller's buffer.  (Every thread passes BOTH
+    // barriers whatever has happened, and looks at `failed` only behind the second: a thread that left between them would
+    // leave the others waiting for ever -- ADVICE r2.)
+    if (g == 0 && !failed.load() && !over && (e = ensure(c, m->whole, tot + 16))) { rcs[0] = e; failed.store(1); }
+    pthread_barrier_wait(&bar);  // B2
+    if (failed.load() || over) return;
     e = x3_shard_gather(s, (const uint8_t*)c->out.p, all[g].data(), 0, (uint8_t*)m->whole.p, tot, nullptr);
     if (!e && hipStreamSynchronize(c->stream) != hipSuccess) e = X3_ERR_HIP;
     if (!e && g == 0) {

@@ -48,7 +48,7 @@ SYMBOLS = [
     "x3_synth", "x3_synth_dev", "x3_dev_alloc", "x3_dev_free", "x3_dev_upload", "x3_dev_download",
     "x3_shard_unique_id", "x3_shard_create", "x3_shard_destroy", "x3_shard_rank", "x3_shard_world",
     "x3_shard_frame_range", "x3_shard_sample_range", "x3_shard_offsets", "x3_shard_exchange_lengths",
-    "x3_shard_exchange_length_value", "x3_shard_lengths", "x3_shard_gather",
+    "x3_shard_exchange_length_value", "x3_shard_lengths", "x3_shard_gather", "x3_shard_gather_async", "x3_shard_gather_wait",
     "x3_mgpu_create", "x3_mgpu_destroy", "x3_mgpu_devices", "x3_mgpu_ctx", "x3_mgpu_shard", "x3_mgpu_last_error",
     "x3_mgpu_encode", "x3_mgpu_decode_stream",
 ]
@@ -221,6 +221,8 @@ def lib():
     L.x3_shard_exchange_length_value.argtypes = [vp, u64, vp]
     L.x3_shard_lengths.argtypes = [vp, C.POINTER(u64)]
     L.x3_shard_gather.argtypes = [vp, vp, C.POINTER(u64), i32, vp, u64, C.POINTER(u64)]
+    L.x3_shard_gather_async.argtypes = [vp, vp, C.POINTER(u64), i32, vp, u64, C.POINTER(u64)]
+    L.x3_shard_gather_wait.argtypes = [vp, i32]
     L.x3_mgpu_create.argtypes = [C.POINTER(i32), i32, C.POINTER(vp)]
     L.x3_mgpu_destroy.restype = None
     L.x3_mgpu_destroy.argtypes = [vp]
@@ -333,13 +335,21 @@ class Shard:
             raise X3Error(rc, "x3_shard_lengths: " + self.ctx.last_error())
         return list(out)
 
-    def gather(self, d_sub, lengths, root, d_dst, dst_cap):
+    def gather(self, d_sub, lengths, root, d_dst, dst_cap, overlapped=False):
+        """reassembly on `root`; overlapped=True: on the shard's own stream and communicator, beside whatever the context
+        does next (x3_shard_gather_async) -- d_sub / d_dst stay untouched until gather_wait()"""
         src = (C.c_uint64 * self.world)(*[int(v) for v in lengths])
         tot = C.c_uint64(0)
-        rc = lib().x3_shard_gather(self._h, d_sub, src, root, d_dst, dst_cap, C.byref(tot))
+        fn = lib().x3_shard_gather_async if overlapped else lib().x3_shard_gather
+        rc = fn(self._h, d_sub, src, root, d_dst, dst_cap, C.byref(tot))
         if rc:
             raise X3Error(rc, "x3_shard_gather: " + self.ctx.last_error())
         return tot.value
+
+    def gather_wait(self, on_stream=True):
+        rc = lib().x3_shard_gather_wait(self._h, 1 if on_stream else 0)
+        if rc:
+            raise X3Error(rc, "x3_shard_gather_wait: " + self.ctx.last_error())
 
 
 class MultiGpu:
