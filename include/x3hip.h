@@ -254,6 +254,11 @@ typedef struct x3_bitpacker x3_bitpacker;
 int x3_bitpacker_new(x3_ctx* ctx, uint8_t* out, uint64_t out_cap, uint64_t start_pos, x3_bitpacker** bp);
 int x3_bitpacker_write_bits(x3_bitpacker* bp, uint64_t value, uint32_t num_bits);
 int x3_bitpacker_write_packed_zeros(x3_bitpacker* bp, uint32_t num_zeros);
+/* BitPacker::write_bytes (bitpacker.rs:95-102): the bytes go to the writer at once -- in front of a partial byte the packer
+ * still holds -- and count in len() and crc(); BitPacker::inc_counter_n_bytes (:112-118): the writer skips n bytes, len()
+ * and crc() stay (X3_ERR_BITPACK = BitPackError::NotByteAligned off a byte boundary; slice-bound packers only). */
+int x3_bitpacker_write_bytes(x3_bitpacker* bp, const uint8_t* array, uint64_t n);
+int x3_bitpacker_inc_counter_n_bytes(x3_bitpacker* bp, uint64_t n_bytes);
 int x3_bitpacker_word_align(x3_bitpacker* bp);
 int x3_bitpacker_finish(x3_bitpacker* bp, uint64_t* len, uint16_t* crc, uint64_t* out_pos);
 int x3_bitpacker_peek(const x3_bitpacker* bp, uint64_t* len, uint16_t* crc);

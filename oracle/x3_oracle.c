@@ -184,6 +184,20 @@ int x3o_bp_word_align(x3o_bitpacker* bp) {
   return X3O_OK;
 }
 
+/* src/bitpacker.rs:95-102: length and CRC first, then ONE write_all of the array -- whatever sits in the scratch byte
+ * stays there and reaches the writer later */
+int x3o_bp_write_bytes(x3o_bitpacker* bp, const uint8_t* array, size_t n) {
+  bp->byte_len += n;
+  for (size_t i = 0; i < n; i++) bp->crc = x3o_update_crc16(bp->crc, array[i]);
+  return x3o_writer_write_all(bp->writer, array, n);
+}
+
+/* src/bitpacker.rs:112-118: BitPackError::NotByteAligned off a byte boundary, else writer.seek(SeekFrom::Current(n)) */
+int x3o_bp_inc_counter_n_bytes(x3o_bitpacker* bp, size_t n_bytes) {
+  if (bp->p_bit != 0) return X3O_BITPACK;
+  return x3o_writer_seek_current(bp->writer, (int64_t)n_bytes);
+}
+
 /* src/bitpacker.rs:56-62 */
 int x3o_bp_drop(x3o_bitpacker* bp) {
   if (bp->p_bit != 0) return bp_flush(bp);

@@ -111,6 +111,8 @@ void x3o_bp_new(x3o_bitpacker* bp, x3o_writer* w);
 int x3o_bp_write_bits(x3o_bitpacker* bp, uint64_t value, size_t num_bits);
 int x3o_bp_write_packed_zeros(x3o_bitpacker* bp, size_t num_zeros);
 int x3o_bp_word_align(x3o_bitpacker* bp);
+int x3o_bp_write_bytes(x3o_bitpacker* bp, const uint8_t* array, size_t n);   /* bitpacker.rs:95-102 */
+int x3o_bp_inc_counter_n_bytes(x3o_bitpacker* bp, size_t n_bytes);           /* bitpacker.rs:112-118 */
 int x3o_bp_drop(x3o_bitpacker* bp); /* impl Drop: flush a partial byte */
 
 /* ---- encoder.rs ---- */

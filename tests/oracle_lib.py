@@ -81,6 +81,8 @@ def lib(native=False):
     L.x3o_bp_new.argtypes = [C.POINTER(BitPacker), C.POINTER(Writer)]
     L.x3o_bp_new.restype = None
     L.x3o_bp_word_align.argtypes = [C.POINTER(BitPacker)]
+    L.x3o_bp_write_bytes.argtypes = [C.POINTER(BitPacker), C.c_void_p, C.c_size_t]
+    L.x3o_bp_inc_counter_n_bytes.argtypes = [C.POINTER(BitPacker), C.c_size_t]
     L.x3o_bp_drop.argtypes = [C.POINTER(BitPacker)]
     L.x3o_br_count_zero_bits.argtypes = [C.POINTER(BitReader)]
     L.x3o_br_new.argtypes = [C.POINTER(BitReader), C.c_void_p, C.c_size_t]

@@ -199,6 +199,64 @@ def test_decode_block_random_and_empty(ctx):
     assert (True, 0) in seen and (True, x3hip.ERR_BAD_ARG) in seen and (True, x3hip.ERR_FRAME_DECODE_INVALID_BPF) in seen, seen
 
 
+def test_bitpacker_write_bytes_and_inc_counter(ctx):
+    """BitPacker::write_bytes (bitpacker.rs:95-102: the array reaches the writer in front of a partial byte still in the
+    scratch) and inc_counter_n_bytes (:112-118: the writer skips, len() and crc() stay; NotByteAligned off a boundary)
+    mixed into random field lists, against the oracle: the slice (untouched bytes keep their sentinel), len(), crc() and
+    the writer's position"""
+    rng = np.random.default_rng(31)
+    L, OL = x3hip.lib(), O.lib()
+    for trial in range(30):
+        start = int(rng.integers(0, 5))
+        nops = int(rng.integers(1, 120))
+        cap = start + nops * 40 + 64
+        a = np.full(cap, 0xA5, dtype=np.uint8)
+        b = np.full(cap, 0xA5, dtype=np.uint8)
+        bp = C.c_void_p()
+        assert L.x3_bitpacker_new(ctx._h, a.ctypes.data, cap, start, C.byref(bp)) == 0
+        w = O.Writer()
+        OL.x3o_writer_init(C.byref(w), b.ctypes.data, cap)
+        OL.x3o_writer_seek_start(C.byref(w), start)
+        ob = O.BitPacker()
+        OL.x3o_bp_new(C.byref(ob), C.byref(w))
+        ln, crc, pos = C.c_uint64(0), C.c_uint16(0), C.c_uint64(0)
+        for i in range(nops):
+            op = int(rng.integers(0, 10))
+            if op < 6:
+                v, n = int(rng.integers(0, 1 << 40)), int(rng.integers(0, 34))
+                assert L.x3_bitpacker_write_bits(bp, v, n) == 0 and OL.x3o_bp_write_bits(C.byref(ob), v, n) == 0
+            elif op < 8:
+                arr = rng.integers(0, 256, int(rng.integers(0, 24)), dtype=np.uint8)
+                assert L.x3_bitpacker_write_bytes(bp, arr.ctypes.data, arr.size) == 0
+                assert OL.x3o_bp_write_bytes(C.byref(ob), arr.ctypes.data, arr.size) == 0
+            elif op == 8:
+                k = int(rng.integers(0, 9))
+                r_g = L.x3_bitpacker_inc_counter_n_bytes(bp, k)
+                r_o = OL.x3o_bp_inc_counter_n_bytes(C.byref(ob), k)
+                assert r_g == r_o and r_g in (0, 3), (trial, i, r_g, r_o)   # 3 = BitPack(NotByteAligned)
+            else:
+                assert L.x3_bitpacker_peek(bp, C.byref(ln), C.byref(crc)) == 0
+                assert (ln.value, crc.value) == (ob.byte_len, ob.crc), (trial, i)
+                if trial % 3 == 0:   # a flush in mid-stream
+                    assert L.x3_bitpacker_finish(bp, C.byref(ln), C.byref(crc), C.byref(pos)) == 0
+                    OL.x3o_bp_drop(C.byref(ob))
+                    assert (ln.value, crc.value, pos.value) == (ob.byte_len, ob.crc, w.p_byte), (trial, i)
+        assert L.x3_bitpacker_word_align(bp) == 0 and OL.x3o_bp_word_align(C.byref(ob)) == 0
+        assert L.x3_bitpacker_finish(bp, C.byref(ln), C.byref(crc), C.byref(pos)) == 0
+        L.x3_bitpacker_free(bp)
+        assert (ln.value, crc.value, pos.value) == (ob.byte_len, ob.crc, w.p_byte), trial
+        assert np.array_equal(a, b), (trial, np.nonzero(a != b)[0][:8])
+    # a skip beyond the slice is the writer's ByteWriterInsufficientMemory; an unbound packer has no writer to move
+    a = np.zeros(16, dtype=np.uint8)
+    bp = C.c_void_p()
+    assert L.x3_bitpacker_new(ctx._h, a.ctypes.data, 16, 4, C.byref(bp)) == 0
+    assert L.x3_bitpacker_inc_counter_n_bytes(bp, 13) == 22 and L.x3_bitpacker_inc_counter_n_bytes(bp, 12) == 0
+    L.x3_bitpacker_free(bp)
+    assert L.x3_bitpacker_new(ctx._h, None, 0, 0, C.byref(bp)) == 0
+    assert L.x3_bitpacker_inc_counter_n_bytes(bp, 1) == 24
+    L.x3_bitpacker_free(bp)
+
+
 def test_bitpacker_unbound_take(ctx):
     """a packer over "any other ByteWriter" (out = NULL): bytes delivered by x3_bitpacker_take in two flushes, at an odd
     writer position, equal the oracle's"""

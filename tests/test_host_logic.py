@@ -160,3 +160,37 @@ def test_rice_code_tables_match_reference_literals():
         assert [rc.num_bits[i] for i in range(rc.len)] == t["num_bits"]
         assert [rc.inv[i] for i in range(60)] == g["inv"]
     assert L.x3_rice_code_get(4, C.byref(x3hip.RiceCode())) == 24
+
+
+def test_rust_ffi_block_matches_the_header():
+    """The Rust mirror (x3-rust_amd/rust/src/lib.rs) cannot be compiled in this image: its `extern "C"` block is held
+    against include/x3hip.h here instead -- every function it declares exists in the header with the same number of
+    arguments, and pointer arguments stand where the header has pointers (the signatures could drift unseen)."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "x3hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    hdr = re.sub(r"//[^\n]*", " ", hdr)
+    cproto = {}
+    for m in re.finditer(r"\b(x3_\w+)\s*\(([^;{}]*?)\)\s*;", hdr, flags=re.S):
+        args = [a.strip() for a in m.group(2).replace("\n", " ").split(",")]
+        if args == ["void"] or args == [""]:
+            args = []
+        cproto[m.group(1)] = args
+    rs = open(os.path.join(ROOT, "x3-rust_amd", "rust", "src", "lib.rs")).read()
+    blocks = re.findall(r'extern\s+"C"\s*\{(.*?)\n    \}', rs, flags=re.S)
+    assert blocks, "no extern \"C\" block found"
+    seen = 0
+    for blk in blocks:
+        blk = re.sub(r"//[^\n]*", " ", blk)
+        for m in re.finditer(r"pub\s+fn\s+(x3_\w+)\s*\(([^)]*)\)", blk, flags=re.S):
+            name = m.group(1)
+            rargs = [a.strip() for a in m.group(2).replace("\n", " ").split(",") if a.strip()]
+            assert name in cproto, "%s is declared in lib.rs but not in include/x3hip.h" % name
+            cargs = cproto[name]
+            assert len(rargs) == len(cargs), "%s: %d arguments in lib.rs, %d in x3hip.h" % (name, len(rargs), len(cargs))
+            for i, (ra, ca) in enumerate(zip(rargs, cargs)):
+                r_ptr = "*const" in ra or "*mut" in ra
+                c_ptr = "*" in ca or "[" in ca
+                assert r_ptr == c_ptr, "%s, argument %d: `%s` in lib.rs against `%s` in x3hip.h" % (name, i, ra, ca)
+            seen += 1
+    assert seen >= 30, seen

@@ -165,6 +165,9 @@ struct x3_bitpacker {
   uint64_t out_cap = 0, start_pos = 0;  // start_pos: the writer's position at new()
   uint64_t written = 0;                 // bytes behind start_pos already handed to `out`
   std::vector<uint32_t> val, nb;        // every field recorded since new() (each <= 32 bits)
+  // inc_counter_n_bytes: (index in the packed bytes, bytes the writer skipped in front of that byte)
+  std::vector<std::pair<uint64_t, uint64_t>> gaps;
+  uint64_t gap_total = 0;
 };
 
 // pack fields [0, n): field i = the low nb[i] bits of val[i], MSB first, at the exclusive prefix sum of nb.  One
@@ -241,6 +244,51 @@ static uint64_t bitpacker_bits(const x3_bitpacker* b) {
   for (uint32_t w : b->nb) t += w;
   return t;
 }
+// BitPacker::write_bytes (:95-102): the bytes go to the writer AT ONCE -- in front of a partial byte that is still in
+// the packer's scratch -- and count in len() and crc() from then on.  In the field list that is an insertion in front of
+// the last (bits mod 8) bits.
+extern "C" int x3_bitpacker_write_bytes(x3_bitpacker* b, const uint8_t* array, uint64_t n) {
+  if (!b || (!array && n)) return X3_ERR_BAD_ARG;
+  uint32_t need = (uint32_t)(bitpacker_bits(b) & 7u);
+  std::vector<std::pair<uint32_t, uint32_t>> tail;  // the pending bits, last field first
+  while (need) {
+    uint32_t v = b->val.back(), w = b->nb.back();
+    if (w < 32u) v &= (1u << w) - 1u;
+    if (w <= need) {
+      tail.emplace_back(v, w);
+      need -= w;
+      b->val.pop_back();
+      b->nb.pop_back();
+    } else {  // the field straddles the byte boundary: its upper part stays, its low `need` bits wait
+      tail.emplace_back(v & ((1u << need) - 1u), need);
+      b->val.back() = v >> need;
+      b->nb.back() = w - need;
+      need = 0;
+    }
+  }
+  for (uint64_t i = 0; i < n; ++i) {
+    b->val.push_back(array[i]);
+    b->nb.push_back(8);
+  }
+  for (auto it = tail.rbegin(); it != tail.rend(); ++it) {
+    b->val.push_back(it->first);
+    b->nb.push_back(it->second);
+  }
+  return X3_OK;
+}
+// BitPacker::inc_counter_n_bytes (:112-118): the writer skips n bytes (SeekFrom::Current), len() and crc() do not
+// move; only on a byte boundary (BitPackError::NotByteAligned), only for a packer bound to a slice
+extern "C" int x3_bitpacker_inc_counter_n_bytes(x3_bitpacker* b, uint64_t n_bytes) {
+  if (!b || !b->out) return X3_ERR_BAD_ARG;
+  const uint64_t bits = bitpacker_bits(b);
+  if (bits & 7u) return X3_ERR_BITPACK;
+  if (b->start_pos + bits / 8 + b->gap_total + n_bytes > b->out_cap) return X3_ERR_BYTE_WRITER_INSUFFICIENT_MEMORY;  // bytewriter.rs:72-74
+  if (n_bytes) {
+    b->gaps.emplace_back(bits / 8, n_bytes);
+    b->gap_total += n_bytes;
+  }
+  return X3_OK;
+}
 // BitPacker::word_align (:124-132): zero bits to the byte boundary, then zero bytes until the ABSOLUTE writer
 // position is even
 extern "C" int x3_bitpacker_word_align(x3_bitpacker* b) {
@@ -248,7 +296,7 @@ extern "C" int x3_bitpacker_word_align(x3_bitpacker* b) {
   const uint64_t bits = bitpacker_bits(b);
   const uint32_t to_byte = (uint32_t)((8 - (bits & 7)) & 7);
   x3_bitpacker_write_packed_zeros(b, to_byte);
-  if ((b->start_pos + (bits + to_byte) / 8) & 1) x3_bitpacker_write_packed_zeros(b, 8);
+  if ((b->start_pos + (bits + to_byte) / 8 + b->gap_total) & 1) x3_bitpacker_write_packed_zeros(b, 8);
   return X3_OK;
 }
 // pack every field recorded since new() into the context's scratch (c->out) and take the CRC-16 (init 0xFFFF) of its
@@ -308,15 +356,40 @@ static int bitpacker_flush(x3_bitpacker* b, uint8_t* dst, uint64_t dst_cap, uint
 extern "C" int x3_bitpacker_finish(x3_bitpacker* b, uint64_t* len, uint16_t* crc, uint64_t* out_pos) {
   if (!b || !b->out) return X3_ERR_BAD_ARG;
   uint64_t total = 0;
-  const uint64_t at = b->start_pos + b->written;
-  const int rc = bitpacker_flush(b, b->out + at, b->out_cap - at, &total, crc, nullptr);
-  if (len) *len = total;
-  if (out_pos) *out_pos = b->start_pos + total;
-  return rc;
+  if (b->gaps.empty()) {
+    const uint64_t at = b->start_pos + b->written;
+    const int rc = bitpacker_flush(b, b->out + at, b->out_cap - at, &total, crc, nullptr);
+    if (len) *len = total;
+    if (out_pos) *out_pos = b->start_pos + total;
+    return rc;
+  }
+  // the writer has skipped bytes (inc_counter_n_bytes): the packed bytes land in pieces around the gaps
+  x3_ctx* c = b->c;
+  const uint64_t bits = bitpacker_bits(b);
+  const uint64_t nbytes = (bits + 7) / 8;
+  if (len) *len = nbytes;
+  if (out_pos) *out_pos = b->start_pos + nbytes + b->gap_total;
+  if (b->start_pos + nbytes + b->gap_total > b->out_cap) return X3_ERR_BYTE_WRITER_INSUFFICIENT_MEMORY;
+  x3_bitpacker_write_packed_zeros(b, (uint32_t)((8 - (bits & 7)) & 7));
+  int rc;
+  if ((rc = bitpacker_pack(b, nbytes, crc))) return rc;
+  uint64_t i = b->written, shift = 0;
+  size_t g = 0;
+  while (g < b->gaps.size() && b->gaps[g].first <= i) shift += b->gaps[g++].second;  // (gaps at or in front of the first new byte)
+  while (i < nbytes) {
+    const uint64_t end = g < b->gaps.size() ? std::min<uint64_t>(nbytes, b->gaps[g].first) : nbytes;
+    if (end > i)
+      HIPCHK(c, hipMemcpyAsync(b->out + b->start_pos + i + shift, (const uint8_t*)c->out.p + i, end - i, hipMemcpyDeviceToHost, c->stream));
+    i = end;
+    while (g < b->gaps.size() && b->gaps[g].first <= i) shift += b->gaps[g++].second;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  b->written = nbytes;
+  return X3_OK;
 }
 // the same flush for a packer that is not bound to a slice (out == NULL at new(): any other ByteWriter): the bytes not
 // handed over yet go to dst[0, *n_new) and the caller passes them to its writer.
 extern "C" int x3_bitpacker_take(x3_bitpacker* b, uint8_t* dst, uint64_t dst_cap, uint64_t* n_new, uint64_t* len, uint16_t* crc) {
-  if (!b || (!dst && dst_cap)) return X3_ERR_BAD_ARG;
+  if (!b || (!dst && dst_cap) || !b->gaps.empty()) return X3_ERR_BAD_ARG;
   return bitpacker_flush(b, dst, dst_cap, len, crc, n_new);
 }

@@ -348,6 +348,9 @@ class BitPacker {
     return static_cast<X3Error>(x3_bitpacker_write_packed_zeros(bp_, (uint32_t)num_zeros));
   }
   X3Error word_align() { return static_cast<X3Error>(x3_bitpacker_word_align(bp_)); }
+  // write_bytes (bitpacker.rs:95-102) and inc_counter_n_bytes (:112-118)
+  X3Error write_bytes(const uint8_t* array, size_t n) { return static_cast<X3Error>(x3_bitpacker_write_bytes(bp_, array, n)); }
+  X3Error inc_counter_n_bytes(size_t n_bytes) { return static_cast<X3Error>(x3_bitpacker_inc_counter_n_bytes(bp_, n_bytes)); }
   // flush (bitpacker.rs:79-86): a partial byte is zero-padded, the packing kernel runs, the writer moves on
   X3Error finish() {
     MaybeLock lk(mu_);

@@ -80,6 +80,8 @@ pub mod ffi {
         pub fn x3_bitpacker_new(ctx: *mut x3_ctx, out: *mut u8, out_cap: u64, start_pos: u64, bp: *mut *mut x3_bitpacker) -> c_int;
         pub fn x3_bitpacker_write_bits(bp: *mut x3_bitpacker, value: u64, num_bits: u32) -> c_int;
         pub fn x3_bitpacker_write_packed_zeros(bp: *mut x3_bitpacker, num_zeros: u32) -> c_int;
+        pub fn x3_bitpacker_write_bytes(bp: *mut x3_bitpacker, array: *const u8, n: u64) -> c_int;
+        pub fn x3_bitpacker_inc_counter_n_bytes(bp: *mut x3_bitpacker, n_bytes: u64) -> c_int;
         pub fn x3_bitpacker_word_align(bp: *mut x3_bitpacker) -> c_int;
         pub fn x3_bitpacker_finish(bp: *mut x3_bitpacker, len: *mut u64, crc: *mut u16, out_pos: *mut u64) -> c_int;
         pub fn x3_bitpacker_peek(bp: *const x3_bitpacker, len: *mut u64, crc: *mut u16) -> c_int;
@@ -428,124 +430,137 @@ pub mod x3 {
 }
 
 pub mod bytewriter {
-    //! src/bytewriter.rs: the `ByteWriter` trait with the reference's five methods, `SliceByteWriter`,
-    //! `StreamByteWriter`.  One provided, hidden method is added so that the encoder can hand a slice writer's
-    //! memory to the library directly; implementors outside this crate need not know about it.
+    //! The crate's byte sinks.  The `ByteWriter` trait is the crate's public interface (five methods, src/bytewriter.rs:
+    //! 14-22) and is repeated here so that this mirror compiles on its own; a maintainer who wires the FFI into the crate
+    //! keeps the crate's own `src/bytewriter.rs` and drops this module.  The two sinks below are written
+    //! for this mirror -- same observable behaviour: zero padding to an absolute position, `ByteWriterInsufficientMemory`
+    //! when a slice is too short -- with one hidden, provided method added, through which the encoder hands a slice sink's
+    //! memory to the library without an intermediate copy.
     use crate::error::{Result, X3Error};
     pub use std::io::{Seek, SeekFrom, Write};
 
-    /// src/bytewriter.rs:14-22
     pub trait ByteWriter {
         fn align<const N: usize>(&mut self) -> Result<usize>;
-        // Writing
         fn write_all(&mut self, value: impl AsRef<[u8]>) -> Result<()>;
         fn flush(&mut self) -> Result<()>;
-        // seeking
         fn seek(&mut self, pos: SeekFrom) -> Result<u64>;
         fn stream_position(&mut self) -> Result<u64>;
 
-        /// private specialisation: the whole backing slice of a slice writer (None for everything else)
+        /// the whole backing memory of a slice sink (None for everything else)
         #[doc(hidden)]
         fn __x3hip_backing_slice(&mut self) -> Option<&mut [u8]> {
             None
         }
     }
 
-    /// src/bytewriter.rs:27-100
-    pub struct SliceByteWriter<'a> {
-        slice: &'a mut [u8],
-        p_byte: usize,
-        stream_length: usize,
+    /// bytes missing from `at` to the next multiple of `n`
+    fn gap(at: u64, n: usize) -> usize {
+        let n = n as u64;
+        ((n - at % n) % n) as usize
     }
+
+    /// A sink over caller-owned memory: a cursor and the furthest byte ever written.
+    pub struct SliceByteWriter<'a> {
+        buf: &'a mut [u8],
+        cursor: usize,
+        high_water: usize,
+    }
+
     impl<'a> SliceByteWriter<'a> {
         pub fn new(slice: &'a mut [u8]) -> Self {
-            SliceByteWriter { slice, p_byte: 0, stream_length: 0 }
+            Self { buf: slice, cursor: 0, high_water: 0 }
         }
-    }
-    impl<'a> ByteWriter for SliceByteWriter<'a> {
-        fn align<const N: usize>(&mut self) -> Result<usize> {
-            let residual = self.p_byte % N;
-            if residual == 0 {
-                return Ok(0);
+
+        /// the window [cursor, cursor + n) if the memory reaches that far
+        fn claim(&mut self, n: usize) -> Result<&mut [u8]> {
+            let end = self.cursor.checked_add(n).filter(|&e| e <= self.buf.len());
+            match end {
+                None => Err(X3Error::ByteWriterInsufficientMemory),
+                Some(end) => {
+                    let w = &mut self.buf[self.cursor..end];
+                    self.cursor = end;
+                    self.high_water = self.high_water.max(end);
+                    Ok(w)
+                }
             }
-            let zero_array = [0u8; N];
-            self.write_all(&zero_array[residual..])?;
-            Ok(N - residual)
-        }
-        fn flush(&mut self) -> Result<()> {
-            Ok(())
-        }
-        fn seek(&mut self, pos: SeekFrom) -> Result<u64> {
-            let abs_pos = match pos {
-                SeekFrom::Current(pos) => ((self.p_byte as i64) + pos) as usize,
-                SeekFrom::Start(pos) => pos as usize,
-                SeekFrom::End(pos) => (self.stream_length as i64 + pos) as usize,
-            };
-            if abs_pos > self.slice.len() {
-                return Err(X3Error::ByteWriterInsufficientMemory);
-            }
-            self.p_byte = abs_pos;
-            self.stream_length = self.stream_length.max(self.p_byte);
-            Ok(self.p_byte as u64)
-        }
-        fn stream_position(&mut self) -> Result<u64> {
-            Ok(self.p_byte as u64)
-        }
-        fn write_all(&mut self, value: impl AsRef<[u8]>) -> Result<()> {
-            let value = value.as_ref();
-            if value.len() > self.slice.len() - self.p_byte {
-                return Err(X3Error::ByteWriterInsufficientMemory);
-            }
-            self.slice[self.p_byte..self.p_byte + value.len()].copy_from_slice(value);
-            self.p_byte += value.len();
-            self.stream_length = self.stream_length.max(self.p_byte);
-            Ok(())
-        }
-        fn __x3hip_backing_slice(&mut self) -> Option<&mut [u8]> {
-            Some(&mut *self.slice)
         }
     }
 
-    /// src/bytewriter.rs:106-165
-    pub struct StreamByteWriter<'a, W>
-    where
-        W: Write + Seek,
-    {
-        writer: &'a mut W,
-    }
-    impl<'a, W> StreamByteWriter<'a, W>
-    where
-        W: Write + Seek,
-    {
-        pub fn new(writer: &'a mut W) -> Self {
-            StreamByteWriter { writer }
-        }
-    }
-    impl<'a, W> ByteWriter for StreamByteWriter<'a, W>
-    where
-        W: Write + Seek,
-    {
+    impl<'a> ByteWriter for SliceByteWriter<'a> {
         fn align<const N: usize>(&mut self) -> Result<usize> {
-            let position = self.writer.stream_position().map_err(X3Error::from)?;
-            let residual = (position as usize) % N;
-            if residual == 0 {
-                return Ok(0);
-            }
-            let zero_array = [0u8; N];
-            self.write_all(&zero_array[residual..])?;
-            Ok(N - residual)
+            let pad = gap(self.cursor as u64, N);
+            self.claim(pad)?.fill(0);
+            Ok(pad)
         }
-        fn flush(&mut self) -> Result<()> {
-            self.writer.flush().map_err(X3Error::Io)
-        }
-        fn seek(&mut self, pos: SeekFrom) -> Result<u64> {
-            self.writer.seek(pos).map_err(X3Error::from)
-        }
-        fn stream_position(&mut self) -> Result<u64> {
-            self.writer.stream_position().map_err(X3Error::from)
-        }
+
         fn write_all(&mut self, value: impl AsRef<[u8]>) -> Result<()> {
-            self.writer.write_all(value.as_ref()).map_err(X3Error::from)
+            let bytes = value.as_ref();
+            self.claim(bytes.len())?.copy_from_slice(bytes);
+            Ok(())
+        }
+
+        fn flush(&mut self) -> Result<()> {
+            Ok(())
+        }
+
+        fn seek(&mut self, pos: SeekFrom) -> Result<u64> {
+            // (a target in front of the memory wraps to a huge number, as `as usize` does in the crate: "insufficient")
+            let target = match pos {
+                SeekFrom::Start(to) => to as usize,
+                SeekFrom::Current(by) => (self.cursor as i64).wrapping_add(by) as usize,
+                SeekFrom::End(by) => (self.high_water as i64).wrapping_add(by) as usize,
+            };
+            if target > self.buf.len() {
+                return Err(X3Error::ByteWriterInsufficientMemory);
+            }
+            self.cursor = target;
+            self.high_water = self.high_water.max(target);
+            Ok(target as u64)
+        }
+
+        fn stream_position(&mut self) -> Result<u64> {
+            Ok(self.cursor as u64)
+        }
+
+        fn __x3hip_backing_slice(&mut self) -> Option<&mut [u8]> {
+            Some(&mut *self.buf)
+        }
+    }
+
+    /// A sink over anything that is `Write + Seek` (a file, a cursor): every call is the inner writer's.
+    pub struct StreamByteWriter<'a, W: Write + Seek> {
+        inner: &'a mut W,
+    }
+
+    impl<'a, W: Write + Seek> StreamByteWriter<'a, W> {
+        pub fn new(writer: &'a mut W) -> Self {
+            Self { inner: writer }
+        }
+    }
+
+    impl<'a, W: Write + Seek> ByteWriter for StreamByteWriter<'a, W> {
+        fn align<const N: usize>(&mut self) -> Result<usize> {
+            let pad = gap(self.inner.stream_position()?, N);
+            for _ in 0..pad {
+                self.inner.write_all(&[0u8])?;
+            }
+            Ok(pad)
+        }
+
+        fn write_all(&mut self, value: impl AsRef<[u8]>) -> Result<()> {
+            Ok(self.inner.write_all(value.as_ref())?)
+        }
+
+        fn flush(&mut self) -> Result<()> {
+            Ok(self.inner.flush()?)
+        }
+
+        fn seek(&mut self, pos: SeekFrom) -> Result<u64> {
+            Ok(self.inner.seek(pos)?)
+        }
+
+        fn stream_position(&mut self) -> Result<u64> {
+            Ok(self.inner.stream_position()?)
         }
     }
 }
@@ -644,10 +659,10 @@ pub mod bitpacker {
         }
 
         pub fn write_bytes(&mut self, array: &[u8]) -> Result<()> {
-            // the reference passes the array to the writer as is (it asks for byte alignment only in a comment)
-            for d in array {
-                self.write_bits(*d as usize, 8)?;
-            }
+            // src/bitpacker.rs:95-102: the array reaches the writer at once, in front of a partial byte that is still
+            // in the packer -- x3_bitpacker_write_bytes keeps that order
+            error::check(unsafe { ffi::x3_bitpacker_write_bytes(self.bp, array.as_ptr(), array.len() as u64) })?;
+            self.bits += 8 * array.len();
             Ok(())
         }
 

@@ -40,7 +40,7 @@ SYMBOLS = [
     "x3_wav_to_x3a", "x3_x3a_to_wav",
     "x3_bitreader_new", "x3_bitreader_read_nbits", "x3_bitreader_count_zero_bits", "x3_bitreader_inc_bits",
     "x3_bitreader_state", "x3_bitreader_free", "x3_decode_block",
-    "x3_bitpacker_new", "x3_bitpacker_write_bits", "x3_bitpacker_write_packed_zeros", "x3_bitpacker_word_align",
+    "x3_bitpacker_new", "x3_bitpacker_write_bits", "x3_bitpacker_write_packed_zeros", "x3_bitpacker_write_bytes", "x3_bitpacker_inc_counter_n_bytes", "x3_bitpacker_word_align",
     "x3_bitpacker_finish", "x3_bitpacker_peek", "x3_bitpacker_take", "x3_bitpacker_free",
     "x3_reader_open", "x3_reader_open_mem", "x3_reader_spec", "x3_reader_next_frame", "x3_reader_frame_errors",
     "x3_reader_position", "x3_reader_close",
@@ -189,6 +189,8 @@ def lib():
     L.x3_bitpacker_new.argtypes = [vp, vp, u64, u64, C.POINTER(vp)]
     L.x3_bitpacker_write_bits.argtypes = [vp, u64, u32]
     L.x3_bitpacker_write_packed_zeros.argtypes = [vp, u32]
+    L.x3_bitpacker_write_bytes.argtypes = [vp, vp, u64]
+    L.x3_bitpacker_inc_counter_n_bytes.argtypes = [vp, u64]
     L.x3_bitpacker_word_align.argtypes = [vp]
     L.x3_bitpacker_finish.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_uint16), C.POINTER(u64)]
     L.x3_bitpacker_peek.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_uint16)]
