@@ -1,7 +1,7 @@
 """Where do the parser and valuer waves of the split decoder land (XCD, SE, CU, SIMD), and does a group's
 duration depend on what shares its SIMDs?  (stamps build: X3HIP_LIB=...libx3hip_stamps.so)"""
 import ctypes as C, os, sys, collections
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "x3-rust_amd"))
 import numpy as np, x3hip
 x3hip.LIB_PATH = os.environ["X3HIP_LIB"]

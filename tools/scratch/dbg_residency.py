@@ -1,7 +1,7 @@
 """How many split-decoder workgroups are resident at once?  (stamps build: X3HIP_LIB=...libx3hip_stamps.so)
 Counts the groups that started before the first one finished, for a grid larger than the chip holds."""
 import ctypes as C, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "x3-rust_amd"))
 import numpy as np, x3hip
 x3hip.LIB_PATH = os.environ["X3HIP_LIB"]

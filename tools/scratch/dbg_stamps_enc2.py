@@ -1,6 +1,6 @@
 """Per-wave phase times of x3_encode_stream2_kernel (build with -DX3_DBG_STAMPS, X3HIP_LIB=...libx3hip_stamps.so)."""
 import ctypes as C, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "x3-rust_amd"))
 import numpy as np, x3hip
 x3hip.LIB_PATH = os.environ["X3HIP_LIB"]

@@ -1,7 +1,7 @@
 """Per-wave phase times of x3_encode_stream_kernel (build with -DX3_DBG_STAMPS -DX3_DBG_ALLWAVES, X3HIP_LIB=...):
 which wave of a workgroup is late at which barrier?"""
 import ctypes as C, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "x3-rust_amd"))
 import numpy as np, x3hip
 x3hip.LIB_PATH = os.environ["X3HIP_LIB"]

@@ -1,7 +1,7 @@
 """Per-wave phase times of x3_decode_split_kernel (library built with -DX3_DBG_STAMPS, X3HIP_LIB=<that .so>):
 parser and valuer rows separately, plus a histogram of group lifetimes by the number of groups that share the CU."""
 import ctypes as C, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "x3-rust_amd"))
 import numpy as np, x3hip
 x3hip.LIB_PATH = os.environ["X3HIP_LIB"]

@@ -342,11 +342,17 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
       HIPCHK(c, hipMemcpy(c->d_xinv8, xi.data(), xi.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
     {
-      // x3_encode_wave_kernel: the six rows above, then per lane the sixteen shifts of x^(32*(63-t)) as uint16, then x^(-16k)
+      // x3_encode_wave_kernel: M[k][v] = v * x^(8k + 4096) (byte k of a 32-bit chain state, two rows of 64 dwords on), the
+      // two "16-bit state times x^2048" rows above, then per lane the sixteen shifts of its weight as uint16, then x^(-16k).
+      // A lane's folded column is held times x^4096; the weight x^(32*(63-t)) carries the x^(16 - 4096) that makes it a CRC.
       std::vector<uint16_t> wt(X3W_TAB_BYTES / 2);
-      for (size_t i = 0; i < tab.size(); ++i) wt[i] = tab[i];
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t sh = gf_xpow_host(8ull * k + 4096);
+        for (int v = 0; v < 256; ++v) wt[(size_t)k * 256 + v] = (uint16_t)gf_mul_host((uint32_t)v, sh);
+      }
+      for (size_t i = 4 * 256; i < 6 * 256; ++i) wt[i] = tab[i];
       for (int t = 0; t < 64; ++t) {
-        uint32_t k = gf_xpow_host(32ull * (63 - t));
+        uint32_t k = gf_xpow_host((32ull * (63 - t) + 16 + 32767ull - 4096) % 32767ull);
         for (int b = 0; b < 16; ++b) {
           wt[1536 + (size_t)t * 16 + b] = (uint16_t)k;
           k = ((k << 1) ^ ((k & 0x8000u) ? 0x11021u : 0u)) & 0xFFFFu;
@@ -354,11 +360,6 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
       }
       // x^(-16k), k < 128 (x has order 32767 modulo P): undoes the zero bytes behind a payload in its last image row
       for (uint64_t k = 0; k < 128; ++k) wt[2560 + k] = (uint16_t)gf_xpow_host((32767ull * 16 - 16ull * k) % 32767ull);
-      // (v << 8) * x^4096 and v * x^4096: a 16-bit state two rows of 64 dwords on
-      for (int v = 0; v < 256; ++v) {
-        wt[2688 + v] = (uint16_t)gf_mul_host((uint32_t)v, gf_xpow_host(4096 + 8));
-        wt[2944 + v] = (uint16_t)gf_mul_host((uint32_t)v, gf_xpow_host(4096));
-      }
       HIPCHK(c, hipMalloc(&c->d_wtab, X3W_TAB_BYTES));
       HIPCHK(c, hipMemcpy(c->d_wtab, wt.data(), X3W_TAB_BYTES, hipMemcpyHostToDevice));
     }

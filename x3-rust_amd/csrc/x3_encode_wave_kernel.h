@@ -21,10 +21,11 @@
 //    waits in LDS meanwhile).  A frame's offset needs the sizes of the up to 4 095 frames in front of it that are in
 //    flight; with the size out at 20 % of a frame's work and the offset due at 120 %, a wave waits only for waves that
 //    are a whole frame behind it (measured without the skew: a third of every wave's time, tools/scratch/dbg_stamps_wave.py);
-//  * payload CRC-16: lane t folds dword t of every 64-dword row of the image Horner-style (times x^2048 per row: two
-//    look-ups, plus the slicing-by-4 look-ups of the dword; the 0xFFFF init is folded into the first 16 payload
-//    bits), multiplies by its fixed x^(32*(63-t)), the lanes are XOR-reduced by DPP, and the zero bytes between the
-//    payload's end and the end of its last row are undone by one multiplication with x^(-8 z): no per-size tables;
+//  * payload CRC-16: lane t folds dword t of every 64-dword row of the image Horner-style -- a 32-bit state that is
+//    congruent to the sum so far, times x^4096 per step of one of two chains: four look-ups per dword, the incoming
+//    dword is not reduced; the 0xFFFF init is folded into the first 16 payload bits -- multiplies by its fixed
+//    x^(32*(63-t)), the lanes are XOR-reduced by DPP, and the zero bytes between the payload's end and the end of its
+//    last row are undone by one multiplication with x^(-8 z): no per-size tables;
 //  * stream offsets: the sixteen frames of a workgroup's generation are CONSECUTIVE frames; their sizes meet in LDS
 //    (slot + arrival counter, the last arriver publishes the generation's total as one {epoch:12 | bytes:20} word),
 //    and a generation's base is its predecessor's base plus the <= 256 totals in between (x3_encode_stream_kernel.h's
@@ -39,19 +40,16 @@
 #ifndef X3W_CLAIM
 #define X3W_CLAIM 1
 #endif
-#ifndef X3W_EXP
-#define X3W_EXP 0
-#endif
 #ifndef X3W_PRIO
 #define X3W_PRIO 1  // 1: priorities from the arrival rank in the workgroup's generation; >= 2: this priority until the size is out; 0: none
 #endif
 #define X3W_WAVES 16u
 #define X3W_THREADS (64u * X3W_WAVES)
-#define X3W_TAB_BYTES 6400u   // T0..T3 slicing-by-4, T4/T5 "times x^2048" (6 x 256 x u16), lane weights 64 x 16 x u16, x^(-16k) k < 128, T6/T7 "times x^4096"
+#define X3W_TAB_BYTES 5376u   // M0..M3 "byte k of a 32-bit state times x^4096", T4/T5 "16-bit state times x^2048" (6 x 256 x u16), lane weights 64 x 16 x u16, x^(-16k) k < 128
 #define X3W_BOOK_BYTES 1024u
 #define X3W_IMG_ROWS 38u
 #define X3W_IMG_BYTES (X3W_IMG_ROWS * 256u)
-#define X3W_SMEM (X3W_TAB_BYTES + X3W_BOOK_BYTES + X3W_WAVES * X3W_IMG_BYTES)  // 163 072 of 163 840
+#define X3W_SMEM (X3W_TAB_BYTES + X3W_BOOK_BYTES + X3W_WAVES * X3W_IMG_BYTES)  // 162 048 of 163 840
 #define X3W_PART 5120u         // samples per part: 64 lanes x 4 blocks x 20
 #define X3W_MAX_NWG 256u      // a generation's base sums at most this many totals: four words per lane
 #define X3W_DESC_PAD 320u     // words in front of desc[0]: the windows of the first generation reach below 0
@@ -90,35 +88,42 @@ __device__ __forceinline__ void x3w_lds_fence() { __builtin_amdgcn_fence(__ATOMI
 // X[10Q+10], the next block's first word, stays) and meta (15 bits) says how to emit it:
 // hdr value [0..5] | bits per field [6..10] | Rice [11] | statistics index [12..14]; 0: no block.
 // No temporaries survive a pair (the registers are full: two halves of a frame); the rare literal block, whose raw
-// samples the saturated differences no longer hold, reads its 44 bytes again (rs, vo: the lane's run in the frame),
-// and the rare BFP block turns its zigzag values back into differences.
+// samples the saturated differences no longer hold, reads its 44 bytes again (rs, vo: the lane's run in the frame).
 template <int Q>
 __device__ __forceinline__ void x3w_analyse(uint32_t (&X)[41], uint32_t cnt, uint32_t thr0, uint32_t thr1, uint32_t thr2,
                                             uint32_t kpack, __amdgpu_buffer_rsrc_t rs, uint32_t vo, uint32_t so,
                                             uint32_t& nbits, uint32_t& meta) {
   constexpr int B = 10 * Q;
-  // one pass: differences, zigzag in place, and the largest zigzag value -- max|d| = (max zigzag + 1) >> 1 exactly
-  // (u = 2 d for d >= 0, -2 d - 1 for d < 0: the largest u belongs to the largest |d|, and a saturated +-32768 stays
-  // the largest), so one unsigned maximum replaces the signed minimum and maximum of the differences
-  uint32_t mxu = 0;
+  // one pass: the (saturated) differences in place, their maximum and minimum per half.  (Until round 3 this pass left
+  // zigzag values and the BFP blocks turned them back: four instructions per pair that every wave paid, because some
+  // lane of 64 nearly always has a BFP block -- 12.7 % of config 3's blocks.  Now the Rice blocks do the zigzag, in
+  // the pass that sums their code lengths, and BFP blocks find their differences ready.)
+  uint32_t mx = 0x80008000u, mn = 0x7FFF7FFFu;
 #pragma unroll
   for (int j = 0; j < 10; ++j) {
     const uint32_t Xj = __builtin_amdgcn_alignbit(X[B + j + 1], X[B + j], 16);  // (s[2j+1], s[2j+2])
     uint32_t d = x3_pk_sub_sat(Xj, X[B + j]);                                    // (d[2j+1], d[2j+2]), saturated
     if (j == 9) d &= cnt == 20u ? 0xFFFFFFFFu : 0x0000FFFFu;                     // a 19-sample block has no sample 20
-    const uint32_t z = x3_pk_shl_b16_1(d) ^ x3_pk_ashr_i16_15(d);                // zigzag, per half (0 stays 0)
-    X[B + j] = z;
-    mxu = x3_pk_max_u16(mxu, z);
+    X[B + j] = d;
+    mx = x3_pk_max_i16(mx, d);
+    mn = x3_pk_min_i16(mn, d);
   }
-  const uint32_t umax = max(mxu & 0xFFFFu, mxu >> 16);
-  const int32_t maxabs = (int32_t)((umax + 1u) >> 1);
+  // max |d|: max(mx, -mn) per half, then over the halves.  -(-32768) saturates to 32767 and a saturated difference stands
+  // for anything beyond: both are literal blocks (nb >= 15) whatever the exact value (thresholds are < 32: stream_safe_thresholds)
+  const uint32_t ab = x3_pk_max_i16(mx, x3_pk_sub_sat(0u, mn));
+  const int32_t maxabs = (int32_t)max(ab & 0xFFFFu, ab >> 16);
   uint32_t nb_ = 0, mt = 0;
   if (maxabs <= (int32_t)thr2) {
     const uint32_t ft = (maxabs > (int32_t)thr0 ? 1u : 0u) + (maxabs > (int32_t)thr1 ? 1u : 0u);
     const uint32_t k = (kpack >> (8u * ft)) & 0xFFu;
     uint32_t sum = 0;
 #pragma unroll
-    for (int j = 0; j < 10; ++j) sum = x3_pk_add_u16(sum, x3_pk_shr_u16(X[B + j], k));
+    for (int j = 0; j < 10; ++j) {
+      const uint32_t d = X[B + j];
+      const uint32_t z = x3_pk_shl_b16_1(d) ^ x3_pk_ashr_i16_15(d);              // zigzag, per half (0 stays 0)
+      X[B + j] = z;
+      sum = x3_pk_add_u16(sum, x3_pk_shr_u16(z, k));
+    }
     nb_ = 2u + cnt * (k + 1u) + (sum & 0xFFFFu) + (sum >> 16);
     mt = (ft + 1u) | ((k + 1u) << 6) | (1u << 11) | (k << 12);
   } else {
@@ -135,13 +140,8 @@ __device__ __forceinline__ void x3w_analyse(uint32_t (&X)[41], uint32_t cnt, uin
       }
       mt = 15u | (16u << 6) | (5u << 12);
     } else {
+      // (X holds the exact differences: |d| < 16 384, nothing was saturated)
       nb_ = 6u + cnt * (nb + 1u);
-      // the exact differences back from their zigzag values (|d| < 16 384: nothing was saturated): d = (u >> 1) ^ -(u & 1)
-#pragma unroll
-      for (int j = 0; j < 10; ++j) {
-        const uint32_t z = X[B + j];
-        X[B + j] = x3_pk_lshr_b16_1(z) ^ x3_pk_sub_u16(0u, z & 0x00010001u);
-      }
       mt = nb | ((nb + 1u) << 6) | (4u << 12);
     }
   }
@@ -194,20 +194,27 @@ struct X3WEmit;
 __device__ __forceinline__ void x3w_slow_emit(__amdgpu_buffer_rsrc_t rs, uint32_t bi, uint32_t cnt, uint32_t meta, X3WEmit& e);
 
 struct X3WEmit {
-  uint64_t acc;    // low `pend` bits are waiting for their word
-  uint32_t pend;
+  uint64_t acc;    // low (q + 32) bits are waiting for their word
+  uint32_t q;      // bits waiting MINUS 32 (mod 2^32): adding a length carries out exactly when a word is complete, and
+                   // the sum is then the shift that brings the word down -- one v_add_co instead of add + compare
   uint32_t waddr;  // LDS byte address of the word the accumulator flushes to
+  __device__ __forceinline__ void start(uint32_t bit_pos, uint32_t img_addr) {
+    acc = 0;
+    q = (bit_pos & 31u) - 32u;
+    waddr = img_addr + 4u * (bit_pos >> 5);
+  }
   __device__ __forceinline__ void put(uint32_t code, uint32_t len) {  // len <= 32, code < 2^len
     acc = (acc << len) | (unsigned long long)code;
-    pend += len;
-    if (pend >= 32u) {
-      pend -= 32u;
-      x3_lds_or_b32(waddr, (uint32_t)(acc >> pend));
+    uint32_t q2;
+    if (__builtin_add_overflow(q, len, &q2)) {
+      x3_lds_or_b32(waddr, (uint32_t)(acc >> q2));
       waddr += 4u;
+      q2 -= 32u;
     }
+    q = q2;
   }
   __device__ __forceinline__ void finish() {
-    if (pend) x3_lds_or_b32(waddr, (uint32_t)(acc << (32u - pend)));
+    if (q != 0u - 32u) x3_lds_or_b32(waddr, (uint32_t)acc << ((0u - q) & 31u));
   }
 };
 
@@ -226,7 +233,7 @@ __device__ __forceinline__ void x3w_emit(const uint32_t (&W)[41], uint32_t meta,
     const uint32_t amask2 = ((1u << kq) - 1u) * 0x10001u, orc2 = (rice << kq) * 0x10001u;
     const uint32_t last_on = cnt == 20u ? 0xFFFFFFFFu : 0x0000FFFFu;
     uint64_t acc = e.acc;
-    uint32_t pend = e.pend, waddr = e.waddr;
+    uint32_t q = e.q, waddr = e.waddr;
 #pragma unroll
     for (int j = 0; j < 10; ++j) {
       uint32_t Lp = x3_pk_mad_u16(x3_pk_lshr_b16(W[B + j], qsh2), qmul2, lbase2);  // (la, lc)
@@ -235,29 +242,16 @@ __device__ __forceinline__ void x3w_emit(const uint32_t (&W)[41], uint32_t meta,
       const uint32_t tot = x3_sdwa_add_w0_w1(Lp);                                   // la + lc <= 32
       const uint32_t pair = x3_sdwa_or_w1(x3_sdwa_shl_w0_by_w1(Cp, Lp), Cp);        // (ca << lc) | cc
       acc = (acc << tot) | (unsigned long long)pair;
-      pend += tot;
-#if X3W_EXP == 1   /* timing experiment: no LDS atomics */
-      if (pend >= 32u) {
-        pend -= 32u;
-        waddr += 4u + (uint32_t)(acc >> pend);
-      }
-#elif X3W_EXP == 2 /* timing experiment: no branch, flush always */
-      {
-        const uint32_t fl = pend >> 5;
-        pend &= 31u;
-        x3_lds_or_b32(waddr, (uint32_t)(acc >> pend));
-        waddr += 4u * fl;
-      }
-#else
-      if (pend >= 32u) {
-        pend -= 32u;
-        x3_lds_or_b32(waddr, (uint32_t)(acc >> pend));
+      uint32_t q2;
+      if (__builtin_add_overflow(q, tot, &q2)) {
+        x3_lds_or_b32(waddr, (uint32_t)(acc >> q2));
         waddr += 4u;
+        q2 -= 32u;
       }
-#endif
+      q = q2;
     }
     e.acc = acc;
-    e.pend = pend;
+    e.q = q;
     e.waddr = waddr;
   }
 }
@@ -716,10 +710,7 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
       }
       if (!ovf) {
         X3WEmit e;
-        const uint32_t bp = lane ? 16u + excl0 : 0u;
-        e.acc = 0;
-        e.pend = bp & 31u;
-        e.waddr = img_addr + 4u * (bp >> 5);
+        e.start(lane ? 16u + excl0 : 0u, img_addr);
         if (lane == 0) e.put(*reinterpret_cast<const uint32_t*>(src) & 0xFFFFu, 16u);  // the frame's first sample (frames are 16-byte aligned)
         if (plain) {
           x3w_emit<0>(X0, mA & 0xFFFFu, x3w_cnt_of(rem0e, 0), e); x3w_emit<1>(X0, mA >> 16, x3w_cnt_of(rem0e, 1), e);
@@ -737,10 +728,7 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
       if (have_next) load_half(X0, src_next, n_next, 0);
       if (!ovf) {
         X3WEmit e;
-        const uint32_t bp = 16u + tot0 + excl1;
-        e.acc = 0;
-        e.pend = bp & 31u;
-        e.waddr = img_addr + 4u * (bp >> 5);
+        e.start(16u + tot0 + excl1, img_addr);
         if (plain) {
           x3w_emit<0>(X1, mC & 0xFFFFu, x3w_cnt_of(rem1e, 0), e); x3w_emit<1>(X1, mC >> 16, x3w_cnt_of(rem1e, 1), e);
           x3w_emit<2>(X1, mD & 0xFFFFu, x3w_cnt_of(rem1e, 2), e); x3w_emit<3>(X1, mD >> 16, x3w_cnt_of(rem1e, 3), e);
@@ -760,11 +748,14 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
       // ---- E: payload CRC-16 (crc.rs:44-58 as a segmented reduction, see the file header)
       uint32_t crc = 0;
       if (!ovf) {
-        // two independent Horner chains, over the even and the odd rows counted from the END of the payload (times
-        // x^4096 per step): the look-ups of one chain fly under those of the other.  An odd number of rows starts
-        // with a row of zeros in front, which adds nothing.
-        auto crc0dw = [&](uint32_t d) __attribute__((always_inline)) -> uint32_t {
-          const uint32_t a3 = x3_sdwa_byte_x2(d, 3), a2 = x3_sdwa_byte_x2(d, 2), a1 = x3_sdwa_byte_x2(d, 1), a0 = x3_sdwa_byte_x2(d, 0);
+        // Two independent Horner chains, over the even and the odd rows counted from the END of the payload (times
+        // x^4096 per step): the look-ups of one chain fly under those of the other.  An odd number of rows starts with a
+        // row of zeros in front, which adds nothing.  A chain's state is a 32-bit polynomial A that is only CONGRUENT to
+        // the sum so far:  A' = (A * x^4096 mod P) ^ dword  -- four look-ups, one per byte of A in the table of its
+        // weight, and no reduction of the incoming dword at all (until round 3: four look-ups to reduce the dword to
+        // crc0 form and two more to move the 16-bit state on).
+        auto m4096 = [&](uint32_t v) __attribute__((always_inline)) -> uint32_t {
+          const uint32_t a3 = x3_sdwa_byte_x2(v, 3), a2 = x3_sdwa_byte_x2(v, 2), a1 = x3_sdwa_byte_x2(v, 1), a0 = x3_sdwa_byte_x2(v, 0);
           return (uint32_t)x3_lds_read_u16(tab_base + a3, 1536u) ^ (uint32_t)x3_lds_read_u16(tab_base + a2, 1024u) ^
                  (uint32_t)x3_lds_read_u16(tab_base + a1, 512u) ^ (uint32_t)x3_lds_read_u16(tab_base + a0, 0u);
         };
@@ -776,42 +767,39 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
           uint32_t d0 = x3_lds_read_b32(ra);
           if (lane == 0) d0 ^= 0xFFFF0000u;  // CRC init 0xFFFF folded into the first 16 message bits
           if (odd) {
-            sb = crc0dw(d0);
+            sb = d0;
             ra += 256u;
           } else {
-            const uint32_t d1 = x3_lds_read_b32(ra + 256u);
-            sa = crc0dw(d0);
-            sb = crc0dw(d1);
+            sa = d0;
+            sb = x3_lds_read_b32(ra + 256u);
             ra += 512u;
           }
         }
-        auto x4096 = [&](uint32_t v) __attribute__((always_inline)) -> uint32_t {
-          return (uint32_t)x3_lds_read_u16(tab_base + x3_sdwa_byte_x2(v, 1), 5376u) ^ (uint32_t)x3_lds_read_u16(tab_base + x3_sdwa_byte_x2(v, 0), 5888u);
-        };
-        // (four rows a trip: the sixteen look-ups of their bytes are in flight together.  Preparing the next trip's words
-        // and look-ups under this trip's chain steps as well -- software pipelining by hand -- made the pass slower:
-        // with sixteen waves the LDS pipe is bound by the look-ups' bank conflicts, not by their latency)
+        // (four rows a trip: their words are in flight together.  Preparing the next trip's words and look-ups under
+        // this trip's chain steps as well -- software pipelining by hand -- made the pass slower: with sixteen waves the
+        // LDS pipe is bound by the look-ups' bank conflicts, not by their latency)
         uint32_t r = 2u - odd;
         for (; r + 3u < rtot; r += 4u) {
           const uint32_t da0 = x3_lds_read_b32(ra), db0 = x3_lds_read_b32(ra + 256u), da1 = x3_lds_read_b32(ra + 512u),
                          db1 = x3_lds_read_b32(ra + 768u);
           ra += 1024u;
-          const uint32_t ca0 = crc0dw(da0), cb0 = crc0dw(db0), ca1 = crc0dw(da1), cb1 = crc0dw(db1);
-          sa = x4096(sa) ^ ca0;
-          sb = x4096(sb) ^ cb0;
-          sa = x4096(sa) ^ ca1;
-          sb = x4096(sb) ^ cb1;
+          sa = m4096(sa) ^ da0;
+          sb = m4096(sb) ^ db0;
+          sa = m4096(sa) ^ da1;
+          sb = m4096(sb) ^ db1;
         }
         if (r < rtot) {
           const uint32_t da = x3_lds_read_b32(ra), db = x3_lds_read_b32(ra + 256u);
-          const uint32_t ca = crc0dw(da), cb = crc0dw(db);
-          sa = x4096(sa) ^ ca;
-          sb = x4096(sb) ^ cb;
+          sa = m4096(sa) ^ da;
+          sb = m4096(sb) ^ db;
         }
-        // chain a ends one row in front of chain b
+        // both states times x^4096, reduced to 16 bits; chain a ends one row in front of chain b.  s = (the lane's column
+        // as a polynomial) * x^4096 mod P -- the factor x^(16 - 4096) that makes a CRC of it is in the lanes' weights
+        sa = m4096(sa);
+        sb = m4096(sb);
         const uint32_t s = (uint32_t)x3_lds_read_u16(tab_base + x3_sdwa_byte_x2(sa, 1), 2048u) ^
                            (uint32_t)x3_lds_read_u16(tab_base + x3_sdwa_byte_x2(sa, 0), 2560u) ^ sb;
-        // times this lane's x^(32*(63-lane)): sixteen pre-shifted words
+        // times this lane's x^(32*(63-lane) + 16 - 4096): sixteen pre-shifted words
         const x3_u32x4 k0 = x3_lds_read_b128(tab_base + 3072u + 32u * lane);
         const x3_u32x4 k1 = x3_lds_read_b128(tab_base + 3072u + 32u * lane + 16u);
         const uint32_t kk[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
