@@ -31,10 +31,11 @@ print("  total %.0f ticks per frame; per wave total min/median/max: %s" % (m.sum
 print("by wave index (total ticks per frame):", (a.sum(axis=2).mean(axis=0) / fpw).round(0))
 print("offset waits by wave index:", (a[:, :, 5].mean(axis=0) / fpw).round(0))
 c = out[32768:32768 + 256*16*4].reshape(256, 16, 4).astype(np.float64) / fpw
-print("per frame and wave: polls of the LDS slots %.2f, trips to the descriptors %.3f, polls there %.3f, ticks in the slot wait %.0f" % tuple(c.mean(axis=(0, 1))))
+print("per frame and wave: descriptor polls %.3f, trips to the descriptors %.3f, ticks there %.0f, ticks waiting for another wave's base %.0f" % tuple(c.mean(axis=(0, 1))))
+print("ticks per trip: %.0f, polls per trip %.2f" % (c[:, :, 2].sum() / max(c[:, :, 1].sum(), 1e-9), c[:, :, 0].sum() / max(c[:, :, 1].sum(), 1e-9)))
 print("trips to the descriptors by wave index:", c[:, :, 1].mean(axis=0).round(3))
-print("polls there by wave index:", c[:, :, 2].mean(axis=0).round(2))
-print("slot-wait ticks by wave index:", c[:, :, 3].mean(axis=0).round(0))
+print("ticks there by wave index:", c[:, :, 2].mean(axis=0).round(0))
+print("base-wait ticks by wave index:", c[:, :, 3].mean(axis=0).round(0))
 tot = a.sum(axis=2); busy = tot - a[:, :, 5]
 wg_busy = busy.mean(axis=1); wg_tot = tot.mean(axis=1); wg_wait = a[:, :, 5].mean(axis=1)
 gens = np.where(np.arange(256) < (F // 16) - 16 * 256, 17, 16) if F // 16 > 16 * 256 else np.full(256, F / 4096.0)

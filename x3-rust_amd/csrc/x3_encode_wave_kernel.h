@@ -360,6 +360,10 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
   // 7 clearing + bookkeeping
   unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long dbg_t = clock64();
+  unsigned long long dbg_cnt[4] = {0, 0, 0, 0};  // descriptor polls, trips to the descriptors, ticks there, ticks waiting for another wave's base
+#define X3W_DBG(x) x
+#else
+#define X3W_DBG(x)
 #endif
 
   // ---- F2 + F3 for the frame in waiting: where it goes (the generation's base needs the totals of the generations
@@ -410,6 +414,7 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
       if (lane == 0) mine = __hip_atomic_fetch_max(&book[184u + par], prev_gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != prev_gen + 1u;
       if (!(uint32_t)__builtin_amdgcn_readfirstlane((int)mine)) {
         uint32_t spins = 0;
+        X3W_DBG(const unsigned long long tw0 = clock64();)
         for (;;) {
           if (__hip_atomic_load(&book[160u + par], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == gtag) {
             const uint32_t lo = __hip_atomic_load(&book[168u + par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -425,6 +430,7 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
           }
           __builtin_amdgcn_s_sleep(2);
         }
+        X3W_DBG(dbg_cnt[3] += clock64() - tw0;)
       }
     }
 #endif
@@ -433,7 +439,9 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
       const bool in0 = lane < need, in1 = lane + 64u < need, in2 = lane + 128u < need, in3 = lane + 192u < need;
       const uint32_t* p0 = a.desc + prev_wgi - 1u - lane;
       uint32_t spins = 0;
+      X3W_DBG(const unsigned long long td0 = clock64(); dbg_cnt[1] += 1;)
       for (;;) {
+        X3W_DBG(dbg_cnt[0] += 1;)
         const uint32_t q0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t q1 = __hip_atomic_load(p0 - 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t q2 = __hip_atomic_load(p0 - 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -467,6 +475,7 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
         }
         __builtin_amdgcn_s_sleep(8);
       }
+      X3W_DBG(dbg_cnt[2] += clock64() - td0;)
     }
     if (lost) {
       // This wave no longer knows where its frames go -- this one and, since each base builds on the last, every
@@ -846,6 +855,8 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
 #ifdef X3_DBG_STAMPS
   if (lane == 0)
     for (int k = 0; k < 8; ++k) x3_dbg[(blockIdx.x * 16 + w) * 8 + k] = dbg_acc[k];
+  if (lane == 0)
+    for (int k = 0; k < 4; ++k) x3_dbg[32768 + (blockIdx.x * 16 + w) * 4 + k] = dbg_cnt[k];
 #endif
   // statistics: the last wave to leave adds the workgroup's sums
   if (lane == 0) {
