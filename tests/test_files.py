@@ -153,6 +153,17 @@ def test_files_match_oracle(ctx, tmp_path, chunk_frames, workers):
 
 
 @pytest.mark.gpu
+def test_file_workers_share_the_single_pass_encoder(ctx, tmp_path):
+    """wav -> x3a over four workers: the workers' persistent-grid encoders take turns (one gate per pipeline, round 3)
+    instead of colliding -- no launch gives up its size wait (encode_fallbacks stays) -- and the archive is the oracle's"""
+    wav = x3hip.synth(2, 77, 0, 1_500_000)
+    before = ctx.get_option("encode_fallbacks")
+    with _opt(ctx, file_chunk_frames=16, file_workers=4):   # 10 chunks of 160 000 samples
+        both_ways(ctx, tmp_path, wav, 192000, "gate")
+    assert ctx.get_option("encode_fallbacks") == before
+
+
+@pytest.mark.gpu
 def test_wav_container_variants(ctx, tmp_path):
     wav = x3hip.synth(2, 61, 0, 25000)
     a = str(tmp_path / "v.wav")

@@ -36,7 +36,7 @@ try:
                 cf, w, (t1 - t0) * 1e3, n / (t1 - t0) / 1e6, (t2 - t1) * 1e3, n / (t2 - t1) / 1e6, os.path.getsize(x3a)), flush=True)
     with open(back, "rb") as f:
         assert f.read() == hdr + wav.tobytes()
-    print("round trip identical")
+    print("round trip identical; encode_fallbacks %d, dense reruns %d" % (ctx.get_option("encode_fallbacks"), ctx.get_option("encode_dense_reruns")))
     if a.cpu_samples:
         import oracle_lib as O
         m = min(n, a.cpu_samples)

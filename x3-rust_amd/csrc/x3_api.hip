@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/x3hip.h"
@@ -110,6 +111,10 @@ struct x3_ctx {
   // bookkeeping of the last async calls
   bool encode_pending = false, decode_pending = false;
   bool force_two_pass = false;
+  // Contexts that encode concurrently on ONE GPU (the file pipeline's workers) share this gate: the single-pass encoders
+  // are persistent grids whose workgroups wait for each other, so only one of them may be in flight on a device.  A
+  // context holds the gate from its launch to the end of x3_encode_result; copies and file I/O stay outside.
+  std::mutex* enc_gate = nullptr;
   bool force_gen2 = false;    // the call is being encoded again because a frame did not fit the wave encoder's image
   bool last_was_wave = false; // the pending encode was launched on the wave encoder
   // Dense content (frames that do not fit the wave encoder's image): the context then keeps to the second-generation
@@ -1118,10 +1123,17 @@ static int encode_host(x3_ctx* c, const int16_t* const* wavs, uint64_t n_per_cli
   if (start_pos > out_cap) return X3_ERR_BYTE_WRITER_INSUFFICIENT_MEMORY;
   const uint64_t dev_cap = std::min<uint64_t>(out_cap, start_pos + 1 + bound);
   if ((rc = ensure(c, c->out, dev_cap + 16))) return rc;
-  if ((rc = encode_dev_impl(c, (const int16_t*)c->in.p, &b, &pp, spf, (uint8_t*)c->out.p, out_cap, start_pos, nullptr)))
-    return rc;
   uint64_t pos = 0;
-  rc = x3_encode_result(c, &pos, stats);
+  {
+    std::unique_lock<std::mutex> gate;
+    if (c->enc_gate) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));  // the upload is not the gate's business
+      gate = std::unique_lock<std::mutex>(*c->enc_gate);
+    }
+    if ((rc = encode_dev_impl(c, (const int16_t*)c->in.p, &b, &pp, spf, (uint8_t*)c->out.p, out_cap, start_pos, nullptr)))
+      return rc;
+    rc = x3_encode_result(c, &pos, stats);
+  }
   if (out_pos) *out_pos = pos;
   if (rc) return rc;
   if (pos > start_pos)

@@ -75,14 +75,13 @@ struct PinBuf {
 struct WorkerCtxs {
   std::vector<x3_ctx*> ctx;
   int rc = X3_OK;
-  int saved_two_pass = 0;
-  // `encoders`: the workers encode concurrently on one GPU.  The single-pass encoder is a persistent grid sized
-  // for the whole chip whose workgroups wait for each other: two of them at once are not both resident, both
-  // spin to the bounded-wait limit (~0.1 s) and fall back.  Chunks of several workers therefore go through the
-  // two-pass kernels, which need no residency.
+  // `encoders`: the workers encode on one GPU.  The single-pass encoders are persistent grids whose workgroups wait
+  // for each other: two of them in flight at once are not both resident, both spin to the bounded-wait limit (~0.1 s)
+  // and fall back to the two-pass kernels.  The workers therefore share ONE gate (x3_ctx::enc_gate): a chunk's kernel
+  // -- tens of microseconds -- runs alone, the uploads, downloads and file I/O of the other workers run beside it.
+  // (Until round 3 the workers were simply put on the two-pass kernels, four times slower.)
+  std::mutex gate;
   WorkerCtxs(x3_ctx* c, int n, bool encoders = false) {
-    saved_two_pass = c->opt.two_pass;
-    if (encoders && n > 1) c->opt.two_pass = 1;
     ctx.push_back(c);
     for (int k = 1; k < n; ++k) {
       x3_ctx* w = nullptr;
@@ -91,13 +90,16 @@ struct WorkerCtxs {
       w->opt = c->opt;
       ctx.push_back(w);
     }
+    if (encoders && ctx.size() > 1)
+      for (x3_ctx* w : ctx) w->enc_gate = &gate;
   }
   ~WorkerCtxs() {
+    ctx[0]->enc_gate = nullptr;
     for (size_t k = 1; k < ctx.size(); ++k) {
       ctx[0]->encode_fallbacks += ctx[k]->encode_fallbacks;
+      ctx[0]->encode_dense_reruns += ctx[k]->encode_dense_reruns;
       x3_ctx_destroy(ctx[k]);
     }
-    ctx[0]->opt.two_pass = saved_two_pass;
   }
 };
 
