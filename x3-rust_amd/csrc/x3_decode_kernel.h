@@ -115,7 +115,7 @@ __device__ __forceinline__ int32_t x3_frame_header_check(const uint32_t* __restr
 // its header words and -- speculatively, the mapping does not depend on the payload length -- its first
 // X3_CHECK_AHEAD x 64 payload dwords one frame ahead.
 #ifndef X3_CHECK_SETPRIO
-#define X3_CHECK_SETPRIO 3
+#define X3_CHECK_SETPRIO 1   // (round 3, with the leaner kernel: 3 -> it is done in 0.38 ms and the decoder needs 0.73; 1 with 4 workgroups per CU: 0.54 beside a 0.65 ms decoder; 0: 0.53 / 0.65 with 8)
 #endif
 #ifndef X3_CHECK_AHEAD
 #define X3_CHECK_AHEAD 24u  // dwords per lane requested ahead: 6 KB of payload (a default frame is ~5.3 KB)
@@ -154,7 +154,16 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
   auto crc0_be32 = [&](uint32_t m) -> uint32_t { return rowsum(m, 0u); };  // crc0 of four bytes held big-endian
   const uint64_t n_dw = (x3_len + 3) >> 2;
   const uint64_t waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+  // (the wave index through readfirstlane: the frame number is then provably uniform, and the frame offsets, spans,
+  // descriptors and the walk's checks are scalar loads and scalar arithmetic instead of 64-bit vector arithmetic)
+#ifndef X3_CHECK_UNIFORM
+#define X3_CHECK_UNIFORM 1
+#endif
+#if X3_CHECK_UNIFORM
+  const uint64_t f0 = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#else
   const uint64_t f0 = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+#endif
   if (f0 >= n_frames) return;  // whole wave
 
   // what is in flight for a frame: header dwords (6 aligned dwords cover 20 bytes at an even offset) and the
