@@ -43,6 +43,9 @@
 #ifndef X3W_PRIO
 #define X3W_PRIO 1  // 1: priorities from the arrival rank in the workgroup's generation; >= 2: this priority until the size is out; 0: none
 #endif
+#ifndef X3W_BARRIER
+#define X3W_BARRIER 0
+#endif
 #define X3W_WAVES 16u
 #define X3W_THREADS (64u * X3W_WAVES)
 #define X3W_TAB_BYTES 5376u   // M0..M3 "byte k of a 32-bit state times x^4096", T4/T5 "16-bit state times x^2048" (6 x 256 x u16), lane weights 64 x 16 x u16, x^(-16k) k < 128
@@ -360,10 +363,14 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
   // 7 clearing + bookkeeping
   unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long dbg_t = clock64();
-  unsigned long long dbg_cnt[4] = {0, 0, 0, 0};  // descriptor polls, trips to the descriptors, ticks there, ticks waiting for another wave's base
+  unsigned long long dbg_cnt[4] = {0, 0, 0, 0};
+  unsigned long long dbg_far[4] = {0, 0, 0, 0};  // totals missing at a trip's first look, by distance  // descriptor polls, trips to the descriptors, ticks there, ticks waiting for another wave's base
 #define X3W_DBG(x) x
+  const int dbg_tl = b == 0 ? 0 : b == 64 ? 1 : b == 128 ? 2 : b == 192 ? 3 : b == 255 ? 4 : -1;  // timeline of five workgroups
+#define X3W_TL(g, k) do { if (dbg_tl >= 0 && (g) < 20u && lane == 0) x3_dbg[49152 + ((dbg_tl * 16 + w) * 20 + (g)) * 4 + (k)] = wall_clock64(); } while (0)
 #else
 #define X3W_DBG(x)
+#define X3W_TL(g, k) do { } while (0)
 #endif
 
   // ---- F2 + F3 for the frame in waiting: where it goes (the generation's base needs the totals of the generations
@@ -373,6 +380,7 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
     const uint32_t gtag = ((prev_gen + 1u) & 0xFFFu) << X3_DESC_BYTES_BITS;
     const uint32_t L = prev_L, frame_bytes = 20u + prev_L, rtot = (prev_L + 255u) >> 8;
     uint32_t intra = 0;
+    X3W_TL(prev_gen, 1);
     {
       // the wave's predecessors in that generation (LDS)
       uint32_t spins = 0;
@@ -484,6 +492,7 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
       return;
     }
     const uint64_t off = gen_base + intra;
+    X3W_TL(prev_gen, 2);
     X3_STAMP(5);
 
     if (lane == 0) {
@@ -649,6 +658,10 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
         mD = m2 | (m3 << 16);
       }
       X3_STAMP(1);
+#if X3W_BARRIER
+      // experiment: the sixteen waves of the workgroup meet behind their analyses (waves that have ended do not count)
+      __builtin_amdgcn_s_barrier();
+#endif
 
       // ---- C: bit offsets (the BitPacker's running position as two wave scans)
       uint32_t excl0, excl1, tot0, tot1;  // (only the exclusive sums stay: whether a lane has blocks is in its metas)
@@ -684,6 +697,7 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
         }
       }
       rank = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
+      X3W_TL(gen, 0);
 #if X3W_PRIO >= 2
       __builtin_amdgcn_s_setprio(0);
 #endif
