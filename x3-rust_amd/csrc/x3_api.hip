@@ -326,18 +326,14 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
       HIPCHK(c, hipMemcpy(c->d_kx64, kx.data(), kx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     {
-      // x3_frame_check_kernel: T[s][k][v] = v * x^(8k + 16) * x^(2048 s), s < G; then "times x^(2048 G)" for v << 8 and v
+      // x3_frame_check_kernel: T0[k][v] = v * x^(8k + 16), M2[k][v] = v * x^(8k + 2048), M4[k][v] = v * x^(8k + 4096)
       std::vector<uint16_t> ct(X3_CHECK_TAB_U16);
-      const int G = (int)X3_CHECK_GROUP;
-      for (int sr = 0; sr < G; ++sr)
+      const uint64_t shifts[3] = {16, 2048, 4096};
+      for (int t = 0; t < 3; ++t)
         for (int k = 0; k < 4; ++k) {
-          const uint32_t sh = gf_xpow_host(8ull * k + 16 + 2048ull * sr);
-          for (int v = 0; v < 256; ++v) ct[((size_t)sr * 4 + k) * 256 + v] = (uint16_t)gf_mul_host((uint32_t)v, sh);
+          const uint32_t sh = gf_xpow_host(8ull * k + shifts[t]);
+          for (int v = 0; v < 256; ++v) ct[((size_t)t * 4 + k) * 256 + v] = (uint16_t)gf_mul_host((uint32_t)v, sh);
         }
-      for (int v = 0; v < 256; ++v) {
-        ct[(size_t)4 * G * 256 + v] = (uint16_t)gf_mul_host((uint32_t)v, gf_xpow_host(2048ull * G + 8));
-        ct[((size_t)4 * G + 1) * 256 + v] = (uint16_t)gf_mul_host((uint32_t)v, gf_xpow_host(2048ull * G));
-      }
       HIPCHK(c, hipMalloc(&c->d_chktab, ct.size() * sizeof(uint16_t)));
       HIPCHK(c, hipMemcpy(c->d_chktab, ct.data(), ct.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
       // x^(-8k): x has order 32767 modulo P (P = (x + 1) * a primitive polynomial of degree 15)

@@ -99,10 +99,10 @@ __device__ __forceinline__ int32_t x3_frame_header_check(const uint32_t* __restr
 #ifndef X3_CHECK_MIN_WGS
 #define X3_CHECK_MIN_WGS 3
 #endif
-#ifndef X3_CHECK_GROUP
-#define X3_CHECK_GROUP 4u  // rows per group: 4 G + 2 tables of 512 bytes (G = 2, 5 KB, to fit beside five decoder groups: no faster)
-#endif
-#define X3_CHECK_TAB_U16 ((4u * X3_CHECK_GROUP + 2u) * 256u)
+// LDS tables (uint16, twelve rows of 256): T0[k][v] = v * x^(8k + 16) (crc0 of byte k of a big-endian dword: the header
+// CRC and the final reduction), M2[k][v] = v * x^(8k + 2048) and M4[k][v] = v * x^(8k + 4096) (a dword one / two rows of 64
+// dwords further from the end): 6 KB (round 2: sixteen row tables + two, 9 KB)
+#define X3_CHECK_TAB_U16 (12u * 256u)
 #define X3_CHECK_TAB_DW (X3_CHECK_TAB_U16 / 2u)
 #define X3_CHECK_XINV_N 1024u  // x^(-8k), k < 1024: undoes the zero bytes the row grid adds behind a payload
 
@@ -152,6 +152,19 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
            x3_lds_read_u16(tab_base + a1, o + 512u) ^ x3_lds_read_u16(tab_base + a0, o);
   };
   auto crc0_be32 = [&](uint32_t m) -> uint32_t { return rowsum(m, 0u); };  // crc0 of four bytes held big-endian
+  // a 32-bit state (big-endian polynomial) times x^4096 mod P: byte k in the table of its weight
+  auto m4096 = [&](uint32_t v) -> uint32_t {
+    const uint32_t a3 = x3_sdwa_byte_x2(v, 3), a2 = x3_sdwa_byte_x2(v, 2), a1 = x3_sdwa_byte_x2(v, 1), a0 = x3_sdwa_byte_x2(v, 0);
+    return x3_lds_read_u16(tab_base + a3, 4096u + 1536u) ^ x3_lds_read_u16(tab_base + a2, 4096u + 1024u) ^
+           x3_lds_read_u16(tab_base + a1, 4096u + 512u) ^ x3_lds_read_u16(tab_base + a0, 4096u);
+  };
+  // a dword AS LOADED (little-endian: stream byte j is byte j) times x^2048 mod P: stream byte j has the weight of byte
+  // 3 - j of the big-endian value -- the byte swap is in the choice of the table
+  auto m2048_le = [&](uint32_t raw) -> uint32_t {
+    const uint32_t a3 = x3_sdwa_byte_x2(raw, 3), a2 = x3_sdwa_byte_x2(raw, 2), a1 = x3_sdwa_byte_x2(raw, 1), a0 = x3_sdwa_byte_x2(raw, 0);
+    return x3_lds_read_u16(tab_base + a0, 2048u + 1536u) ^ x3_lds_read_u16(tab_base + a1, 2048u + 1024u) ^
+           x3_lds_read_u16(tab_base + a2, 2048u + 512u) ^ x3_lds_read_u16(tab_base + a3, 2048u);
+  };
   const uint64_t n_dw = (x3_len + 3) >> 2;
   const uint64_t waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
   // (the wave index through readfirstlane: the frame number is then provably uniform, and the frame offsets, spans,
@@ -246,25 +259,30 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
         crc = 0xFFFFu;
         for (uint32_t i = 0; i < plen; ++i) crc = x3_crc_byte(crc, x3_be32_at(xw, n_dw, p0 + i) >> 24);
       } else {
-        // The payload as rows of 64 aligned dwords, lane t on dword t of every row.  A dword that is followed by
-        // s more rows inside its group of four contributes T[s][.][its bytes]; between groups the partial sum
-        // is multiplied by x^8192 (four rows).  The grid ends on a whole group: R4 rows.  What it holds beyond
-        // the payload is masked to zero, which adds nothing to the sum but counts as trailing zero bytes: undone
-        // by one multiplication with x^(-8k) at the end.  The CRC's init value is XORed into payload bytes 0, 1.
+        // The payload as rows of 64 aligned dwords, lane t on dword t of every row, folded Horner-style two rows a step on a
+        // 32-bit state that is only CONGRUENT to the sum so far (the wave encoder's trick, round 3):
+        //     A' = (A * x^4096 mod P)  ^  (row r * x^2048 mod P)  ^  row r+1
+        // four look-ups for the state, four for the first row of the pair, none for the second: 4 per dword (round 2:
+        // 4.5, in groups of four rows on a 16-bit sum) and 17 instead of 47 / 2 vector instructions per two rows; a
+        // frame of 21 rows pays for 22 (then: 24).  The rows are taken as loaded (little-endian); only the second row of
+        // a pair is byte-swapped.  The grid ends on a whole pair: what it holds beyond the payload is masked to zero,
+        // which adds nothing to the sum but counts as trailing zero bytes, undone by one multiplication with x^(-8k) at
+        // the end.  The CRC's init value is XORed into payload bytes 0, 1.
         const uint32_t lead = (uint32_t)(p0 & 3u);       // header bytes in front, inside dword 0
         const uint32_t nd = (lead + plen + 3u) >> 2;     // aligned dwords covering the payload
         const uint32_t tpad = 4u * nd - lead - plen;     // bytes behind the payload in the last dword
         const uint32_t R = (nd + 63u) >> 6;              // rows that hold payload
         const uint32_t last_lane = (nd - 1u) & 63u;
-        // row 0: header bytes in front of the payload off, CRC init in; row R-1: nothing behind the payload
+        // masks on the dwords AS LOADED (stream byte j = byte j).  Row 0: header bytes in front of the payload off, CRC
+        // init in; row R-1: nothing behind the payload
         uint32_t and0 = 0xFFFFFFFFu, xor0 = 0u;
         if (lane == 0) {
-          and0 = 0xFFFFFFFFu >> (8u * lead);
-          xor0 = lead <= 2 ? (0xFFFF0000u >> (8u * lead)) : 0x000000FFu;
+          and0 = 0xFFFFFFFFu << (8u * lead);
+          xor0 = lead <= 2 ? (0x0000FFFFu << (8u * lead)) : 0xFF000000u;
         }
-        if (lane == 1 && lead == 3) xor0 = 0xFF000000u;
-        const uint32_t last_mask = lane < last_lane ? 0xFFFFFFFFu : (lane == last_lane ? 0xFFFFFFFFu << (8u * tpad) : 0u);
-        uint32_t acc = 0;
+        if (lane == 1 && lead == 3) xor0 = 0x000000FFu;
+        const uint32_t last_mask = lane < last_lane ? 0xFFFFFFFFu : (lane == last_lane ? 0xFFFFFFFFu >> (8u * tpad) : 0u);
+        uint32_t A = 0;
         uint32_t rows_done = 0;
         // (a frame index that disagrees with the header -- the caller's offsets are closer together than the frames are
         // long: the speculative fetch was cut short; the payload again, unbounded)
@@ -276,30 +294,28 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
             load_rows(rsrc_at(p0 >> 2), lane4 + 256u * rbase, pd);
           }
 #pragma unroll
-          for (uint32_t g4 = 0; g4 < X3_CHECK_AHEAD; g4 += X3_CHECK_GROUP) {
-            if (rbase + g4 < R) {  // (whole wave)
-              if (rbase + g4)      // partial sum so far: a group of rows further from the end
-                acc = x3_lds_read_u16(tab_base + ((acc >> 8) << 1), 4u * X3_CHECK_GROUP * 512u) ^
-                      x3_lds_read_u16(tab_base + ((acc & 0xFFu) << 1), (4u * X3_CHECK_GROUP + 1u) * 512u);
-#pragma unroll
-              for (uint32_t q = 0; q < X3_CHECK_GROUP; ++q) {
-                const uint32_t row = rbase + g4 + q;
-                uint32_t be = x3_bswap32(pd[g4 + q]);
-                if (g4 + q == 0) {
-                  if (rbase == 0) be = (be & and0) ^ xor0;
-                }
-                if (row + 1u >= R) be &= row + 1u == R ? last_mask : 0u;  // (whole wave)
-                acc ^= rowsum(be, X3_CHECK_GROUP - 1u - q);
+          for (uint32_t g2 = 0; g2 < X3_CHECK_AHEAD; g2 += 2u) {
+            if (rbase + g2 < R) {  // (whole wave)
+              const uint32_t row = rbase + g2;
+              uint32_t d0 = pd[g2], d1 = pd[g2 + 1u];
+              if (g2 == 0) {
+                if (rbase == 0) d0 = (d0 & and0) ^ xor0;
               }
-              rows_done = rbase + g4 + X3_CHECK_GROUP;
+              if (row + 1u >= R) d0 &= last_mask;                          // (whole wave) row is the last one
+              if (row + 2u >= R) d1 &= row + 2u == R ? last_mask : 0u;     // (whole wave) row + 1 is the last one, or behind it
+              uint32_t a2 = m2048_le(d0) ^ x3_bswap32(d1);
+              if (row) a2 ^= m4096(A);
+              A = a2;
+              rows_done = row + 2u;
             }
 #if X3_CHECK_SCHED_FENCE
-            // keep the scheduler from hoisting every group's table look-ups to the front: their results in flight were
+            // keep the scheduler from hoisting every pair's table look-ups to the front: their results in flight were
             // most of the kernel's 167 VGPRs, and beside the decoder's groups a SIMD has room for ONE such wave
             __builtin_amdgcn_sched_barrier(0);
 #endif
           }
         }
+        const uint32_t acc = crc0_be32(A);   // the lane's column as a CRC-0 value (times x^16, reduced)
         // this lane's dwords are followed by 63 - lane dwords in their rows: times x^(32 * (63 - lane)) -- sixteen
         // pre-shifted words per lane, fetched here (4 KB in all, L1-resident) rather than held in registers all along
         {
