@@ -3,12 +3,14 @@
 #   tools/profile_round.sh gpurun_out/r1
 # 1. the default bench line; 2. rocprofv3 --kernel-trace --stats of the same command; 3. separate PMC
 # passes (FETCH_SIZE, WRITE_SIZE, SQ counters) as MI355X_MICROARCH.md prescribes (no other trace domains).
+# (the stats run skips the extras -- cold context, frame walk, extreme contents -- so that its per-kernel averages are those
+# of the timed steps and agree with the HIP-event averages in the bench line)
 out=$1
 mkdir -p $out
 export TMPDIR=/tmp
 root=$PWD
 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
-(cd /tmp && rocprofv3 --kernel-trace --stats -d $root/$out/stats -o bench --output-format csv -- python3 $root/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-measure-traffic > $root/$out/stats.log 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $root/$out/stats -o bench --output-format csv -- python3 $root/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-measure-traffic --no-extras > $root/$out/stats.log 2>&1)
 cp $out/stats/bench_kernel_stats.csv $out/bench_kernel_stats.csv 2>/dev/null
 cp $out/stats/bench_domain_stats.csv $out/bench_domain_stats.csv 2>/dev/null
 i=0
