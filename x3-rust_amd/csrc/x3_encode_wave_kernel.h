@@ -46,6 +46,25 @@
 #ifndef X3W_BARRIER
 #define X3W_BARRIER 0
 #endif
+// Polls are far apart: a waiting wave that looks again every 128 clocks takes issue slots and LDS / L2 bandwidth from the
+// waves it is waiting for.  s_sleep 24 (1 500 clocks) between looks at the workgroup's LDS words and 127 (8 000 clocks)
+// between trips to the size words: 0.4225 ms on every box seen, against 0.427-0.439 with 2 and 8
+// (sweeps of five pairs of values x four to six processes on three boxes, round 3).
+#ifndef X3W_SLEEP_LDS
+#define X3W_SLEEP_LDS 24
+#endif
+#ifndef X3W_SLEEP_DESC
+#define X3W_SLEEP_DESC 127
+#endif
+// bounded waits of about 0.2 s with those sleeps
+#define X3W_SPINS_LDS (X3_SPIN_LIMIT << 2)
+#define X3W_SPINS_DESC (X3_SPIN_LIMIT >> 1)
+#ifndef X3W_NOWAIT
+#define X3W_NOWAIT 0
+#endif
+#ifndef X3W_COPY_UNROLL
+#define X3W_COPY_UNROLL 2
+#endif
 #define X3W_WAVES 16u
 #define X3W_THREADS (64u * X3W_WAVES)
 #define X3W_TAB_BYTES 5376u   // M0..M3 "byte k of a 32-bit state times x^4096", T4/T5 "16-bit state times x^2048" (6 x 256 x u16), lane weights 64 x 16 x u16, x^(-16k) k < 128
@@ -380,8 +399,12 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
     const uint32_t gtag = ((prev_gen + 1u) & 0xFFFu) << X3_DESC_BYTES_BITS;
     const uint32_t L = prev_L, frame_bytes = 20u + prev_L, rtot = (prev_L + 255u) >> 8;
     uint32_t intra = 0;
+#if X3W_NOWAIT
+    // timing experiment only (the stream is NOT valid): every frame at a fixed stride, nobody waits for anybody
+    gen_base = prev_f * 10240ull;
+#endif
     X3W_TL(prev_gen, 1);
-    {
+    if (!X3W_NOWAIT) {
       // the wave's predecessors in that generation (LDS)
       uint32_t spins = 0;
       for (;;) {
@@ -391,10 +414,10 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
           intra = (uint32_t)__builtin_amdgcn_readlane((int)x3_wave_incl_scan_dpp(v & X3_DESC_BYTES_MASK), 63);
           break;
         }
-        if (++spins > (X3_SPIN_LIMIT << 4) ||
+        if (++spins > X3W_SPINS_LDS ||
             ((spins & 1023u) == 0u && __hip_atomic_load(&status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == X3D_SIZE_WAIT_TIMEOUT)) {
           lost = true;
-          if (spins > (X3_SPIN_LIMIT << 4) && lane == 0 && atomicCAS(&status[2], 0, 1) == 0) {  // diagnosis of the first wait that gave up
+          if (spins > X3W_SPINS_LDS && lane == 0 && atomicCAS(&status[2], 0, 1) == 0) {  // diagnosis of the first wait that gave up
             status[3] = (int)prev_wgi; status[4] = (int)(w | (prev_gen << 8)); status[5] = (int)__ballot((v & ~X3_DESC_BYTES_MASK) != gtag);
           }
           break;
@@ -404,8 +427,8 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
     }
     // The generation's base is the same for the sixteen waves: whoever has summed it leaves it in LDS, the others
     // take it from there (about one wave in two pays the trip to the descriptors: they arrive in clusters).
-    bool have_base = false;
-    if (!lost) {
+    bool have_base = X3W_NOWAIT != 0;
+    if (!lost && !X3W_NOWAIT) {
       const uint32_t t = __hip_atomic_load(&book[160u + par], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (t == gtag) {
         const uint32_t lo = __hip_atomic_load(&book[168u + par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -431,12 +454,12 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
             have_base = true;
             break;
           }
-          if (++spins > (X3_SPIN_LIMIT << 4) ||
+          if (++spins > X3W_SPINS_LDS ||
               ((spins & 1023u) == 0u && __hip_atomic_load(&status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == X3D_SIZE_WAIT_TIMEOUT)) {
             lost = true;
             break;
           }
-          __builtin_amdgcn_s_sleep(2);
+          __builtin_amdgcn_s_sleep(X3W_SLEEP_LDS);
         }
         X3W_DBG(dbg_cnt[3] += clock64() - tw0;)
       }
@@ -470,10 +493,10 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
           break;
         }
         // give up after the bounded spin -- or as soon as ANY wave has: the host encodes the call again
-        if (++spins > X3_SPIN_LIMIT ||
+        if (++spins > X3W_SPINS_DESC ||
             __hip_atomic_load(&status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == X3D_SIZE_WAIT_TIMEOUT) {
           lost = true;
-          if (spins > X3_SPIN_LIMIT && lane == 0 && atomicCAS(&status[2], 0, 2) == 0) {
+          if (spins > X3W_SPINS_DESC && lane == 0 && atomicCAS(&status[2], 0, 2) == 0) {
             const unsigned long long nr = __ballot((v0 >> X3_DESC_BYTES_BITS) != a.epoch);
             status[3] = (int)prev_wgi; status[4] = (int)(w | (prev_gen << 8)); status[5] = (int)nr; status[6] = (int)(nr >> 32);
             status[7] = (int)(__popcll(__ballot((v1 >> X3_DESC_BYTES_BITS) != a.epoch)) | (__popcll(__ballot((v2 >> X3_DESC_BYTES_BITS) != a.epoch)) << 8) |
@@ -481,7 +504,7 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
           }
           break;
         }
-        __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_s_sleep(X3W_SLEEP_DESC);
       }
       X3W_DBG(dbg_cnt[2] += clock64() - td0;)
     }
@@ -534,6 +557,11 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
         uint8_t* const abase = pdst + head;                     // 16-byte aligned
         // memory order of a stored dword = stream order: bytes (31..24), (23..16), (15..8), (7..0) of the image's value
         if (head & 2u) {
+#if X3W_COPY_UNROLL == 2
+#pragma unroll 2
+#elif X3W_COPY_UNROLL == 3
+#pragma unroll 3
+#endif
           for (uint32_t u = lane; u < nfull; u += 64u) {
             const uint32_t ia = img_addr + ((head + 16u * u) & ~3u);  // the unit starts in the low half of this dword
             const uint32_t v0 = x3_lds_read_b32(ia), v1 = x3_lds_read_b32(ia + 4u), v2 = x3_lds_read_b32(ia + 8u),
@@ -543,6 +571,11 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
             *reinterpret_cast<x3_u32x4*>(abase + 16u * u) = vv;
           }
         } else {
+#if X3W_COPY_UNROLL == 2
+#pragma unroll 2
+#elif X3W_COPY_UNROLL == 3
+#pragma unroll 3
+#endif
           for (uint32_t u = lane; u < nfull; u += 64u) {
             const uint32_t ia = img_addr + head + 16u * u;
             const uint32_t v0 = x3_lds_read_b32(ia), v1 = x3_lds_read_b32(ia + 4u), v2 = x3_lds_read_b32(ia + 8u),
