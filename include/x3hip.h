@@ -215,6 +215,24 @@ int x3_decode_frame(x3_ctx* ctx, const uint8_t* payload, uint64_t len, int16_t* 
 int x3_decode_stream(x3_ctx* ctx, const uint8_t* x3, uint64_t len, const x3_params* p, int16_t* wav,
                      uint64_t wav_cap, uint64_t* n_out, uint64_t* frames_ok, uint64_t* frame_errors);
 
+/* ------------------------------------------------------------------ multi-channel (extension) */
+
+/* NOT in the reference: `encoder::encode` returns MoreThanOneChannel for more than one channel (src/encoder.rs:55-57) and
+ * `read_frame_header` refuses frames that announce more than one (src/decoder.rs:90-94) -- and so do x3_encode /
+ * x3_decode_stream and every other entry point above.  These two follow what the format foresees: the frame header's
+ * <Num Channels> (src/x3.rs:155-156, src/encoder.rs:134) and "pack the data block for each channel" (src/encoder.rs:197):
+ * <Audio State> = the first sample of each channel; then for every block index the block of channel 0 .. n-1, each coded
+ * as a mono block against its own channel; header byte 3 = n_channels, `samples` = samples per channel.  With
+ * n_channels = 1 the bytes are x3_encode's.  wavs[k] = channel k, n samples each (host memory).  n_channels <= 8; a frame
+ * whose payload would pass the 24 KB a reader takes is X3_ERR_FRAME_LENGTH (choose shorter frames).
+ * x3_decode_stream_mc walks, checks and decodes such a stream (x3_decode_stream's rules; a frame must announce exactly
+ * n_channels) into wavs[k][0 .. *n_samples). */
+int x3_encode_mc(x3_ctx* ctx, const int16_t* const* wavs, uint32_t n_channels, uint64_t n, const x3_params* p, uint8_t* out,
+                 uint64_t out_cap, uint64_t start_pos, uint64_t* out_pos, uint64_t stats[6]);
+int x3_decode_stream_mc(x3_ctx* ctx, const uint8_t* x3, uint64_t len, uint32_t n_channels, const x3_params* p,
+                        int16_t* const* wavs, uint64_t wav_cap, uint64_t* n_samples, uint64_t* frames_ok,
+                        uint64_t* frame_errors);
+
 /* ------------------------------------------------------------------ bitreader.rs / bitpacker.rs / decode_block */
 
 /* The reference's small public items, for callers and known-answer tests written against them (x3_bits.h: not how the

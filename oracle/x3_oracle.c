@@ -621,6 +621,151 @@ static int decode_stream_phantom(const uint8_t* x3, uint64_t len, uint64_t phant
   return rc;
 }
 
+/* --------------------------------------------------------------- multi-channel (extension) */
+
+/* NOT in the reference: encoder::encode returns MoreThanOneChannel for more than one channel (encoder.rs:55-57) and
+ * read_frame_header rejects a frame whose <Num Channels> is above one (decoder.rs:90-94).  What the format foresees is in
+ * the header -- a channel count (x3.rs:155-156, encoder.rs:134) -- and in encode_frame's own comment, "pack the data block
+ * for each channel" (encoder.rs:197).  The extension follows that: <Audio State> = the first sample of every channel,
+ * 16 bits each, in channel order; then, for every block index, the block of channel 0, 1, ... C-1, each coded exactly
+ * like a mono block against ITS channel's previous sample; then word_align.  Header: source id 1, byte 3 = C,
+ * `samples` = samples per channel.  With C = 1 every byte is the reference's (tests pin that).  Parity unpinned by the
+ * reference for C > 1: there is nothing to compare with. */
+int x3o_encode_frame_mc(const int16_t* const* wavs, uint32_t n_ch, size_t n, x3o_writer* w, const x3o_params* p,
+                        uint64_t stats[6]) {
+  int rc;
+  x3o_init();
+  if (n == 0 || n_ch == 0 || n_ch > 255) return X3O_BAD_ARG;
+  if ((rc = x3o_writer_align(w, 2))) return rc;
+  size_t frame_header_pos = w->p_byte;
+  if ((rc = x3o_writer_seek_current(w, 20))) return rc;
+  x3o_bitpacker bp;
+  x3o_bp_new(&bp, w);
+  for (uint32_t c = 0; c < n_ch; c++)
+    if ((rc = x3o_bp_write_bits(&bp, (uint64_t)(int64_t)wavs[c][0], 16))) return rc; /* <Audio State>, per channel */
+  if (p->block_len == 0 && n > 1) return X3O_BAD_ARG;
+  for (size_t s = 1; s < n; s += p->block_len) {
+    size_t bl = n - s < p->block_len ? n - s : p->block_len;
+    for (uint32_t c = 0; c < n_ch; c++) {
+      size_t ftype = 0;
+      if ((rc = x3o_encode_block(wavs[c] + s, bl, wavs[c][s - 1], &bp, p, &ftype))) return rc;
+      stats[ftype] += bl;
+    }
+  }
+  if ((rc = x3o_bp_word_align(&bp))) return rc;
+  size_t payload_len = bp.byte_len;
+  uint16_t payload_crc = bp.crc;
+  if (payload_len > 1024 * 24) return X3O_FRAME_LENGTH; /* no reader would take it (decodefile.rs:118-121) */
+  size_t return_position = w->p_byte;
+  if ((rc = x3o_writer_seek_start(w, frame_header_pos))) return rc;
+  uint8_t hdr[20];
+  x3o_write_frame_header(n, 1, payload_len, payload_crc, hdr);
+  hdr[3] = (uint8_t)n_ch;
+  be16(hdr + 16, x3o_crc16(hdr, 16));
+  if ((rc = x3o_writer_write_all(w, hdr, 20))) return rc;
+  return x3o_writer_seek_start(w, return_position);
+}
+
+int x3o_encode_mc(const int16_t* const* wavs, uint32_t n_ch, uint64_t n, const x3o_params* p, uint8_t* out,
+                  uint64_t out_cap, uint64_t start_pos, uint64_t* out_pos, uint64_t stats[6]) {
+  x3o_init();
+  if (n_ch == 0 || n_ch > 255) return X3O_BAD_ARG;
+  uint64_t st[6] = {0, 0, 0, 0, 0, 0};
+  x3o_writer w;
+  x3o_writer_init(&w, out, out_cap);
+  if (start_pos > out_cap) return X3O_BYTE_WRITER_INSUFFICIENT_MEMORY;
+  w.p_byte = w.stream_length = start_pos;
+  size_t spf = (size_t)p->block_len * (size_t)p->blocks_per_frame;
+  const int16_t* at[255];
+  int rc = X3O_OK;
+  uint64_t pos = 0;
+  for (;;) {
+    size_t take = (n - pos) < spf ? (size_t)(n - pos) : spf;
+    if (take == 0) break;
+    for (uint32_t c = 0; c < n_ch; c++) at[c] = wavs[c] + pos;
+    pos += take;
+    if ((rc = x3o_encode_frame_mc(at, n_ch, take, &w, p, st))) break;
+  }
+  if (out_pos) *out_pos = w.p_byte;
+  if (stats) memcpy(stats, st, sizeof st);
+  return rc;
+}
+
+/* decode_frame (decoder.rs:36-58) with n_ch predictors: wavs[c][0 .. samples) */
+int x3o_decode_frame_mc(const uint8_t* x3_bytes, size_t len, int16_t* const* wavs, size_t wav_cap, uint32_t n_ch,
+                        const x3o_params* p, size_t samples, size_t* n_out) {
+  x3o_init();
+  if (n_ch == 0 || n_ch > 255 || len < 2u * n_ch || samples == 0 || wav_cap < 1) return X3O_BAD_ARG;
+  int16_t last[255];
+  for (uint32_t c = 0; c < n_ch; c++) {
+    last[c] = (int16_t)rd_be16(x3_bytes + 2 * c);
+    wavs[c][0] = last[c];
+  }
+  size_t p_wav = 1;
+  x3o_bitreader br;
+  x3o_br_new(&br, x3_bytes + 2 * n_ch, len - 2 * n_ch);
+  size_t remaining = samples - 1;
+  size_t turns = 0;
+  while (remaining > 0) {
+    size_t block_len = remaining < p->block_len ? remaining : p->block_len;
+    if (p_wav + block_len > wav_cap) return X3O_BAD_ARG;
+    if (block_len == 0 && ++turns > 4 * len + 64) return X3O_BAD_ARG;
+    for (uint32_t c = 0; c < n_ch; c++) {
+      int rc = x3o_decode_block(&br, wavs[c] + p_wav, block_len, &last[c], p);
+      if (rc) return rc;
+    }
+    remaining -= block_len;
+    p_wav += block_len;
+  }
+  if (n_out) *n_out = p_wav;
+  return X3O_OK;
+}
+
+/* the frame walk of decode_stream_phantom for frames of n_ch channels: the header's <Num Channels> must say n_ch */
+int x3o_decode_stream_mc(const uint8_t* x3, uint64_t len, uint32_t n_ch, const x3o_params* p, int16_t* const* wavs,
+                         uint64_t wav_cap, uint64_t* n_out, uint64_t* frames_ok, uint64_t* frame_errors) {
+  x3o_init();
+  if (n_ch == 0 || n_ch > 255) return X3O_BAD_ARG;
+  uint64_t pos = 0, remaining = len, nsamp = 0, nframes = 0, nerr = 0;
+  int rc = X3O_OK;
+  int16_t* at[255];
+  for (;;) {
+    if (remaining <= 20) break;
+    if (len - pos < 20) { rc = X3O_IO; break; }
+    x3o_frame_header h;
+    uint8_t hb[20];
+    memcpy(hb, x3 + pos, 20);
+    /* read_frame_header with the channel test turned into "is it n_ch" (check order kept: length, CRC, key, channels) */
+    rc = X3O_OK;
+    if (rd_be16(hb + 16) != x3o_crc16(hb, 16)) rc = X3O_FRAME_HEADER_INVALID_HEADER_CRC;
+    else if (rd_be16(hb) != 30771) rc = X3O_FRAME_HEADER_INVALID_KEY;
+    else if (hb[3] != n_ch) rc = X3O_MORE_THAN_ONE_CHANNEL;
+    else if (rd_be16(hb + 6) >= 0x7fe0) rc = X3O_FRAME_LENGTH;
+    h.samples = rd_be16(hb + 4);
+    h.payload_len = rd_be16(hb + 6);
+    h.payload_crc = rd_be16(hb + 18);
+    pos += 20; remaining -= 20;
+    if (rc) break;
+    if (remaining < h.payload_len) break;
+    if (h.payload_len > 1024 * 24) { rc = X3O_FRAME_HEADER_INVALID_PAYLOAD_LEN; break; }
+    if (len - pos < h.payload_len) { rc = X3O_IO; break; }
+    const uint8_t* payload = x3 + pos;
+    pos += h.payload_len; remaining -= h.payload_len;
+    if (x3o_crc16(payload, h.payload_len) != h.payload_crc) { rc = X3O_FRAME_HEADER_INVALID_PAYLOAD_CRC; break; }
+    size_t got = 0;
+    for (uint32_t c = 0; c < n_ch; c++) at[c] = wavs[c] + nsamp;
+    int drc = x3o_decode_frame_mc(payload, h.payload_len, at, (size_t)(wav_cap - nsamp), n_ch, p, h.samples, &got);
+    if (drc == X3O_BAD_ARG) { rc = drc; break; }
+    if (drc) { nerr += 1; break; }
+    nsamp += got;
+    nframes += 1;
+  }
+  if (n_out) *n_out = nsamp;
+  if (frames_ok) *frames_ok = nframes;
+  if (frame_errors) *frame_errors = nerr;
+  return rc;
+}
+
 /* ----------------------------------------------- encodefile.rs / decodefile.rs: archive */
 
 #include <stdio.h>

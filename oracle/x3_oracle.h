@@ -161,6 +161,17 @@ int x3o_decode_stream(const uint8_t* x3, uint64_t len, const x3o_params* p, int1
                       uint64_t wav_cap, uint64_t* n_out, uint64_t* frames_ok,
                       uint64_t* frame_errors);
 
+/* ---- multi-channel extension (not in the reference: see x3_oracle.c) ---- */
+int x3o_encode_frame_mc(const int16_t* const* wavs, uint32_t n_ch, size_t n, x3o_writer* w, const x3o_params* p,
+                        uint64_t stats[6]);
+int x3o_encode_mc(const int16_t* const* wavs, uint32_t n_ch, uint64_t n, const x3o_params* p, uint8_t* out,
+                  uint64_t out_cap, uint64_t start_pos, uint64_t* out_pos, uint64_t stats[6]);
+int x3o_decode_frame_mc(const uint8_t* x3_bytes, size_t len, int16_t* const* wavs, size_t wav_cap, uint32_t n_ch,
+                        const x3o_params* p, size_t samples, size_t* n_out);
+int x3o_decode_stream_mc(const uint8_t* x3, uint64_t len, uint32_t n_ch, const x3o_params* p, int16_t* const* wavs,
+                         uint64_t wav_cap, uint64_t* n_out, uint64_t* frames_ok, uint64_t* frame_errors);
+
+
 /* ---- encodefile.rs / decodefile.rs: the .x3a archive around the frame stream (no file I/O).
  * Unpinned by any reference test (its file tests are commented out): follows the source.
  * quick-xml (Cargo.toml: 0.38, not in the reference tree) is restated as "text of the first

@@ -164,6 +164,42 @@ def decode_stream(x3, params=None, wav_cap=None):
     return rc, wav[: n.value].copy(), fok.value, ferr.value
 
 
+def encode_mc(wavs, params=None, start_pos=0, cap=None):
+    """multi-channel extension (x3o_encode_mc): wavs = list of equally long int16 arrays -> (rc, bytes, stats[6])"""
+    params = params or Params.default()
+    wavs = [np.ascontiguousarray(w, dtype=np.int16) for w in wavs]
+    n = wavs[0].size
+    assert all(w.size == n for w in wavs)
+    cap = len(wavs) * encode_bound(n, params) + start_pos + 64 if cap is None else cap
+    out = np.zeros(max(cap, 1), dtype=np.uint8)
+    pos = C.c_uint64(0)
+    stats = np.zeros(6, dtype=np.uint64)
+    ptrs = (C.c_void_p * len(wavs))(*[w.ctypes.data for w in wavs])
+    L = lib()
+    L.x3o_encode_mc.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                C.c_void_p, C.c_void_p]
+    rc = L.x3o_encode_mc(ptrs, len(wavs), n, C.byref(params), out.ctypes.data, cap, start_pos, C.byref(pos),
+                         stats.ctypes.data)
+    return rc, out[: pos.value].copy(), stats
+
+
+def decode_stream_mc(x3, n_ch, params=None, wav_cap=None):
+    """-> (rc, [samples of channel c], frames_ok, frame_errors)"""
+    params = params or Params.default()
+    x3 = np.ascontiguousarray(x3, dtype=np.uint8)
+    if wav_cap is None:
+        wav_cap = max(1, x3.size * 16)
+    wavs = [np.zeros(wav_cap, dtype=np.int16) for _ in range(n_ch)]
+    ptrs = (C.c_void_p * n_ch)(*[w.ctypes.data for w in wavs])
+    n = C.c_uint64(0); fok = C.c_uint64(0); ferr = C.c_uint64(0)
+    L = lib()
+    L.x3o_decode_stream_mc.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = L.x3o_decode_stream_mc(x3.ctypes.data, x3.size, n_ch, C.byref(params), ptrs, wav_cap, C.byref(n), C.byref(fok),
+                                C.byref(ferr))
+    return rc, [w[: n.value].copy() for w in wavs], fok.value, ferr.value
+
+
 def decode_frame(payload, samples, params=None, wav_cap=None):
     params = params or Params.default()
     payload = np.ascontiguousarray(payload, dtype=np.uint8)

@@ -1,0 +1,101 @@
+"""Multi-channel extension (x3_mc.h): x3_encode_mc / x3_decode_stream_mc through the C ABI against the
+oracle's x3o_encode_mc / x3o_decode_stream_mc.  The reference itself stops at MoreThanOneChannel (encoder.rs:55-57,
+decoder.rs:90-94), so for more than one channel the oracle IS the definition (parity unpinned by the reference); with ONE
+channel the extension must reproduce the reference-pinned mono path byte for byte, which is what ties it down."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import x3hip
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = x3hip.Context(0)
+    yield c
+    c.close()
+
+
+def _signals(n, k, seed):
+    kinds = [2, 4, 3, 0, 2, 4, 3, 2]
+    return [x3hip.synth(kinds[i % len(kinds)], seed + i, 0, n) for i in range(k)]
+
+
+@pytest.mark.parametrize("n", [1, 2, 21, 9999, 10000, 10001, 30001, 70003])
+def test_one_channel_is_the_mono_stream(ctx, n):
+    """C = 1: the extension's bytes are x3_encode's (and the oracle's, which the reference's KATs pin)"""
+    wav = x3hip.synth(2, 5, 0, n)
+    rc, mono, st = ctx.encode(wav)
+    rc_o, mono_o, st_o = O.encode(wav)
+    rcm, mc, stm = ctx.encode_mc([wav])
+    rcm_o, mc_o, stm_o = O.encode_mc([wav])
+    assert rc == rc_o == rcm == rcm_o == 0
+    assert np.array_equal(mono, mono_o) and np.array_equal(mc, mono) and np.array_equal(mc_o, mono)
+    assert st.tolist() == stm.tolist() == stm_o.tolist()
+    rcd, back, fok, ferr = ctx.decode_stream_mc(mc, 1, wav_cap=n + 16)
+    assert (rcd, ferr) == (0, 0) and np.array_equal(back[0], wav)
+
+
+@pytest.mark.parametrize("n_ch", [2, 3, 4, 8])
+@pytest.mark.parametrize("n,bpf", [(30001, 500), (4000, 100), (1, 500), (20, 50), (250123, 250)])
+def test_channels_match_the_oracle(ctx, n_ch, n, bpf):
+    p = x3hip.Params.default()
+    p.blocks_per_frame = bpf
+    po = O.Params.default()
+    po.blocks_per_frame = bpf
+    wavs = _signals(n, n_ch, 100 * n_ch + bpf)
+    rc_o, x_o, st_o = O.encode_mc(wavs, po)
+    rc_g, x_g, st_g = ctx.encode_mc(wavs, p)
+    assert rc_g == rc_o, (rc_g, rc_o, ctx.last_error())
+    if rc_o != 0:
+        return
+    assert np.array_equal(x_g, x_o), (x_g.size, x_o.size, np.nonzero(x_g[: min(x_g.size, x_o.size)] != x_o[: min(x_g.size, x_o.size)])[0][:4])
+    assert st_g.tolist() == st_o.tolist()
+    assert x_g[3] == n_ch  # <Num Channels> of the first frame
+    rc_d, back, fok, ferr = ctx.decode_stream_mc(x_g, n_ch, p, wav_cap=n + 64)
+    rc_do, back_o, fok_o, ferr_o = O.decode_stream_mc(x_o, n_ch, po, wav_cap=n + 64)
+    assert (rc_d, fok, ferr) == (rc_do, fok_o, ferr_o) == (0, (n + 20 * bpf - 1) // (20 * bpf), 0)
+    for k in range(n_ch):
+        assert np.array_equal(back[k], wavs[k]) and np.array_equal(back_o[k], wavs[k]), k
+
+
+def test_a_frame_no_reader_takes_is_frame_length(ctx):
+    """three channels of full-scale noise in default frames: 60 KB of payload per frame -> FrameLength on both sides"""
+    rng = np.random.default_rng(3)
+    wavs = [rng.integers(-32768, 32768, 25000).astype(np.int16) for _ in range(3)]
+    rc_o, _, _ = O.encode_mc(wavs)
+    rc_g, _, _ = ctx.encode_mc(wavs)
+    assert rc_o == rc_g == 10  # X3Error::FrameLength
+    p = x3hip.Params.default(); p.blocks_per_frame = 100
+    po = O.Params.default(); po.blocks_per_frame = 100
+    rc_o, x_o, _ = O.encode_mc(wavs, po)
+    rc_g, x_g, _ = ctx.encode_mc(wavs, p)
+    assert rc_o == rc_g == 0 and np.array_equal(x_g, x_o)   # 2 000-sample frames: 12 KB of literal blocks, fine
+
+
+def test_damaged_and_mismatched_streams(ctx):
+    wavs = _signals(45000, 2, 77)
+    rc, x, _ = ctx.encode_mc(wavs)
+    assert rc == 0
+    cases = {"intact": x}
+    y = x.copy(); y[20 + 300] ^= 0x10; cases["payload bit"] = y                 # payload CRC of frame 0
+    y = x.copy(); y[5] ^= 1; cases["header bit"] = y                            # header CRC
+    cases["truncated"] = x[: x.size - 7]
+    cases["half"] = x[: x.size // 2]
+    for tag, s in cases.items():
+        got = ctx.decode_stream_mc(s, 2, wav_cap=46000)
+        want = O.decode_stream_mc(s, 2, wav_cap=46000)
+        assert (got[0], got[2], got[3]) == (want[0], want[2], want[3]), (tag, got[0], got[2:], want[0], want[2:])
+        for k in range(2):
+            assert np.array_equal(got[1][k], want[1][k]), (tag, k)
+    # a two-channel stream is not a one-channel stream, nor a three-channel one -- for the extension and for the reference
+    for n_ch in (1, 3):
+        got = ctx.decode_stream_mc(x, n_ch, wav_cap=46000)
+        want = O.decode_stream_mc(x, n_ch, wav_cap=46000)
+        assert got[0] == want[0] == 6 and got[2] == want[2] == 0, (n_ch, got[0], want[0])   # X3Error::MoreThanOneChannel
+    rc, _, _, _ = ctx.decode_stream(x, wav_cap=46000)
+    assert rc == 6   # the reference's reader (x3_decode_stream) refuses the frame, as the crate does
+    # arguments
+    assert ctx.encode_mc([wavs[0]] * 9)[0] == x3hip.ERR_BAD_ARG

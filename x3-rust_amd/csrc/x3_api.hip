@@ -687,12 +687,18 @@ extern "C" void x3_write_frame_header(uint64_t num_samples, uint8_t id, uint64_t
   out[18] = (uint8_t)(payload_crc >> 8); out[19] = (uint8_t)payload_crc;
 }
 
+// n_ch == 1: the reference's test (a channel count above one is refused, decoder.rs:90-94); n_ch > 1 (the multi-channel
+// extension): the frame must say exactly n_ch
+static int read_frame_header_ch(const uint8_t* b, uint64_t len, x3_frame_header* h, uint32_t n_ch);
 extern "C" int x3_read_frame_header(const uint8_t* b, uint64_t len, x3_frame_header* h) {
+  return read_frame_header_ch(b, len, h, 1u);
+}
+static int read_frame_header_ch(const uint8_t* b, uint64_t len, x3_frame_header* h, uint32_t n_ch) {
   if (!b || !h) return X3_ERR_BAD_ARG;
   if (len < 20) return X3_ERR_FRAME_DECODE_UNEXPECTED_END;
   if ((((uint16_t)b[16] << 8) | b[17]) != header_crc16_host(b, 16)) return X3_ERR_FRAME_HEADER_INVALID_HEADER_CRC;
   if (b[0] != 0x78 || b[1] != 0x33) return X3_ERR_FRAME_HEADER_INVALID_KEY;
-  if (b[3] > 1) return X3_ERR_MORE_THAN_ONE_CHANNEL;
+  if (n_ch == 1u ? b[3] > 1 : b[3] != n_ch) return X3_ERR_MORE_THAN_ONE_CHANNEL;
   uint32_t plen = ((uint32_t)b[6] << 8) | b[7];
   if (plen >= X3_FRAME_MAX_LENGTH) return X3_ERR_FRAME_LENGTH;
   h->source_id = b[2];
@@ -1004,7 +1010,7 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
     hipLaunchKernelGGL(x3_encode_frames_kernel<true>, dim3((unsigned)F), dim3(pl.nthr),
                        X3_ENC_SMEM_HDR + pl.lds_in_bytes, c->stream, d_wav, pl.g, pl.dp, (const uint64_t*)nullptr,
                        (uint32_t*)c->frame_bytes.p, (uint8_t*)nullptr, start_pos, c->d_stats, c->d_status,
-                       (const uint16_t*)c->d_xpow, pl.lds_in_bytes, 0u);
+                       (const uint16_t*)c->d_xpow, pl.lds_in_bytes, 0u, 1u, (uint64_t)0);
   }
   {
     TimerScope ts(c, 3);
@@ -1015,7 +1021,7 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
     TimerScope ts(c, 0);
     hipLaunchKernelGGL(x3_encode_frames_kernel<false>, dim3((unsigned)F), dim3(pl.nthr), pl.smem, c->stream, d_wav,
                        pl.g, pl.dp, (const uint64_t*)d_off, (uint32_t*)nullptr, d_out, start_pos, c->d_stats,
-                       c->d_status, (const uint16_t*)c->d_xpow, pl.lds_in_bytes, pl.img_dwords);
+                       c->d_status, (const uint16_t*)c->d_xpow, pl.lds_in_bytes, pl.img_dwords, 1u, (uint64_t)0);
   }
   HIPCHK(c, hipGetLastError());
   c->encode_pending = true;
@@ -1266,7 +1272,7 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
       hipLaunchKernelGGL(x3_frame_check_kernel, dim3((unsigned)check_grid), dim3(256), 0, check_stream,
                          reinterpret_cast<const uint32_t*>(d_x3), x3_len, d_frame_offsets, F,
                          (const uint16_t*)c->d_xinv8, (const uint16_t*)c->d_chktab, (const uint32_t*)c->d_kx64,
-                         (int32_t*)c->dec_cstatus.p, reinterpret_cast<unsigned long long*>(c->d_summary));
+                         (int32_t*)c->dec_cstatus.p, reinterpret_cast<unsigned long long*>(c->d_summary), 1u);
     }
     if (check_stream == c->stream2) HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
     return X3_OK;
@@ -1553,14 +1559,14 @@ struct HostWalk {
   bool need_more = false;
 };
 static void walk_host(const uint8_t* buf, uint64_t buf_len, uint64_t real_total, uint64_t believed_total,
-                      const x3_params* p, uint64_t wav_cap, uint64_t max_samples, HostWalk* w) {
+                      const x3_params* p, uint64_t wav_cap, uint64_t max_samples, HostWalk* w, uint32_t n_ch = 1u) {
   uint64_t pos = 0, remaining = believed_total, nsamp = 0;
   for (;;) {
     if (remaining <= 20) break;
     if (real_total - pos < 20) { w->terminal = X3_ERR_IO; break; }  // read_exact past the real end of the data
     if (buf_len - pos < 20) { w->need_more = true; break; }
     x3_frame_header h;
-    int rc = x3_read_frame_header(buf + pos, 20, &h);
+    int rc = read_frame_header_ch(buf + pos, 20, &h, n_ch);
     if (rc) { w->terminal = rc; break; }
     if (remaining - 20 < h.payload_len) break;
     // the buffer-size test comes before the payload is read (decodefile.rs:118-124): a payload that is both too
@@ -1568,7 +1574,7 @@ static void walk_host(const uint8_t* buf, uint64_t buf_len, uint64_t real_total,
     if (h.payload_len > X3_READ_BUFFER_SIZE) { w->terminal = X3_ERR_FRAME_HEADER_INVALID_PAYLOAD_LEN; break; }
     if (real_total - pos - 20 < h.payload_len) { w->terminal = X3_ERR_IO; break; }
     if (buf_len - pos - 20 < h.payload_len) { w->need_more = true; break; }
-    if (h.samples == 0 || h.payload_len < 2 || nsamp + h.samples > wav_cap || (p->block_len == 0 && h.samples > 1)) {
+    if (h.samples == 0 || h.payload_len < 2 * n_ch || nsamp + h.samples > wav_cap || (p->block_len == 0 && h.samples > 1)) {
       // payload CRC is checked before decode_frame runs, so let the GPU look at this frame too:
       // it reports the CRC error if there is one, BAD_ARG (reference panic) otherwise
       w->offs.push_back(pos);
@@ -1996,3 +2002,4 @@ extern "C" int x3_x3a_decode(x3_ctx* c, const uint8_t* x3a, uint64_t len, int16_
 #include "x3_reader.h"
 #include "x3_bits.h"
 #include "x3_mgpu.h"
+#include "x3_mc.h"

@@ -57,13 +57,14 @@ __device__ __forceinline__ uint32_t x3_be32_at(const uint32_t* __restrict__ xw, 
 // hc = CRC-16 of the first 16 header bytes, computed by the caller (table-free or from LDS tables)
 __device__ __forceinline__ int32_t x3_frame_header_check_words(uint32_t h0, uint32_t h1, uint32_t h4, uint32_t hc,
                                                                uint64_t x3_len, uint64_t off, uint32_t& plen,
-                                                               uint32_t& samples, uint32_t& pcrc) {
+                                                               uint32_t& samples, uint32_t& pcrc, uint32_t n_ch = 1u) {
   samples = h1 >> 16;
   plen = h1 & 0xFFFFu;
   pcrc = h4 & 0xFFFFu;
   if ((h4 >> 16) != hc) return X3D_FRAME_HEADER_INVALID_HEADER_CRC;
   if ((h0 >> 16) != 0x7833u) return X3D_FRAME_HEADER_INVALID_KEY;
-  if ((h0 & 0xFFu) > 1u) return X3D_MORE_THAN_ONE_CHANNEL;
+  // (n_ch > 1: the multi-channel extension -- the frame must say exactly n_ch; else the reference's test)
+  if (n_ch == 1u ? (h0 & 0xFFu) > 1u : (h0 & 0xFFu) != n_ch) return X3D_MORE_THAN_ONE_CHANNEL;
   if (plen >= 0x7fe0u) return X3D_FRAME_LENGTH;
   if (off + 20 + plen > x3_len) return X3D_STREAM_ENDS_IN_FRAME;   // decodefile.rs:114-116
   if (plen > 24576u) return X3D_FRAME_HEADER_INVALID_PAYLOAD_LEN;  // decodefile.rs:118-121
@@ -125,7 +126,7 @@ __global__ void __launch_bounds__(256, X3_CHECK_MIN_WGS)
 x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const uint64_t* __restrict__ frame_off,
                       uint64_t n_frames, const uint16_t* __restrict__ xinv8, const uint16_t* __restrict__ tab_g,
                       const uint32_t* __restrict__ kx64, int32_t* __restrict__ status,
-                      unsigned long long* __restrict__ summary) {
+                      unsigned long long* __restrict__ summary, uint32_t n_ch) {
   __shared__ __attribute__((aligned(16))) uint16_t tab[X3_CHECK_TAB_U16];
   // short and latency-bound: ahead of the decoder's waves it shares the SIMDs with, so that it is out of the way
   // early instead of being stretched to the decoder's whole duration
@@ -249,7 +250,7 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
       hc = crc0_be32(h[1] ^ (hc << 16));
       hc = crc0_be32(h[2] ^ (hc << 16));
       hc = crc0_be32(h[3] ^ (hc << 16));
-      st = x3_frame_header_check_words(h[0], h[1], h[4], hc, x3_len, off, plen, samples, pcrc);
+      st = x3_frame_header_check_words(h[0], h[1], h[4], hc, x3_len, off, plen, samples, pcrc, n_ch);
     }
     // ---- payload CRC (decodefile.rs:96-100)
     if (st == X3D_OK) {

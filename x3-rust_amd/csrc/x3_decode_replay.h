@@ -188,3 +188,44 @@ __global__ void x3_replay_one_kernel(const uint8_t* __restrict__ payload, uint32
                                      int16_t* __restrict__ out, int32_t* __restrict__ status) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *status = x3_replay_frame(payload, plen, samples, p, out);
 }
+
+// ---- multi-channel extension (not in the reference: decoder.rs:90-94 refuses such frames; oracle/x3_oracle.c says what
+// the extension's layout is).  One thread per frame over the reference's own reader: the first sample of every channel,
+// then for every block index the block of channel 0 .. n_ch-1, each against its own channel's last sample.  Channel c
+// goes to wav + c * ch_stride.  status[f]: X3D_OK or the block decoder's error; frames the check kernel has refused
+// (cstatus[f] != 0) are skipped.
+#define X3_MAX_CHANNELS 8u
+__global__ void __launch_bounds__(64)
+x3_decode_mc_kernel(const uint8_t* __restrict__ x3, const uint64_t* __restrict__ frame_off, const uint64_t* __restrict__ wav_off,
+                    uint64_t n_frames, X3DevParams p, uint32_t n_ch, int16_t* __restrict__ wav, uint64_t ch_stride,
+                    uint64_t wav_cap, const int32_t* __restrict__ cstatus, int32_t* __restrict__ status) {
+  const uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n_frames) return;
+  if (cstatus[f] != X3D_OK) { status[f] = X3D_OK; return; }
+  const uint8_t* __restrict__ h = x3 + frame_off[f];
+  const uint32_t samples = ((uint32_t)h[4] << 8) | h[5], plen = ((uint32_t)h[6] << 8) | h[7];
+  const uint8_t* __restrict__ payload = h + 20;
+  const uint64_t wo = wav_off[f];
+  if (samples == 0u || plen < 2u * n_ch || wo + samples > wav_cap) { status[f] = X3D_BAD_ARG; return; }
+  uint32_t last[X3_MAX_CHANNELS];
+  for (uint32_t c = 0; c < n_ch; ++c) {
+    last[c] = ((uint32_t)payload[2u * c] << 8) | payload[2u * c + 1u];
+    wav[(uint64_t)c * ch_stride + wo] = (int16_t)(uint16_t)last[c];
+  }
+  X3RefReader br;
+  br.open(payload + 2u * n_ch, plen - 2u * n_ch);
+  uint32_t at = 1u, remaining = samples - 1u, turns = 0;
+  int32_t st = X3D_OK;
+  while (remaining && st == X3D_OK) {
+    const uint32_t n = remaining < p.block_len ? remaining : p.block_len;
+    if (n == 0u && ++turns > 4u * plen + 64u) { st = X3D_BAD_ARG; break; }
+    for (uint32_t c = 0; c < n_ch && st == X3D_OK; ++c) {
+      uint32_t l = last[c];
+      st = x3_replay_block(br, n, p, l, wav + (uint64_t)c * ch_stride + wo + at);
+      last[c] = l;
+    }
+    remaining -= n;
+    at += n;
+  }
+  status[f] = st;
+}

@@ -62,7 +62,13 @@ x3_encode_frames_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
                         const uint64_t* __restrict__ frame_off, uint32_t* __restrict__ frame_bytes,
                         uint8_t* __restrict__ out, uint64_t start_pos,
                         unsigned long long* __restrict__ stats, int* __restrict__ status,
-                        const uint16_t* __restrict__ xpow, uint32_t lds_in_bytes, uint32_t img_dwords) {
+                        const uint16_t* __restrict__ xpow, uint32_t lds_in_bytes, uint32_t img_dwords,
+                        uint32_t n_ch, uint64_t ch_stride) {
+  // n_ch > 1: the multi-channel extension (not in the reference, which stops at MoreThanOneChannel: encoder.rs:55-57).
+  // Channel c's samples are at wav + c * ch_stride; a frame holds n samples of EVERY channel: <Audio State> = the
+  // first sample of each channel, then the blocks in the order (block index, channel) -- "pack the data block for each
+  // channel", encoder.rs:197 -- every block coded as a mono block against its own channel.  Everything behind the
+  // per-block analysis (scan of the bit lengths, emission, CRC, copy-out) only sees items in stream order.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* part = reinterpret_cast<uint32_t*>(smem);  // [0..31] wave partials, [32..37] stats, [40] bad flag
   int16_t* in_s = reinterpret_cast<int16_t*>(smem + X3_ENC_SMEM_HDR);
@@ -87,14 +93,18 @@ x3_encode_frames_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
   const int16_t* __restrict__ src = wav + s_start;
 
   // ---- A: stage samples, zero the frame image
-  if ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
-    const uint32_t nvec = n >> 3;
-    const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(src);
-    uint4* d4 = reinterpret_cast<uint4*>(in_s);
-    for (uint32_t i = tid; i < nvec; i += nthr) d4[i] = s4[i];
-    for (uint32_t i = nvec * 8 + tid; i < n; i += nthr) in_s[i] = src[i];
-  } else {
-    for (uint32_t i = tid; i < n; i += nthr) in_s[i] = src[i];
+  // (several channels: the blocks read their samples where they are -- a frame of every channel does not fit LDS beside
+  // its image, and this is the generic path)
+  if (n_ch == 1u) {
+    if ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
+      const uint32_t nvec = n >> 3;
+      const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(src);
+      uint4* d4 = reinterpret_cast<uint4*>(in_s);
+      for (uint32_t i = tid; i < nvec; i += nthr) d4[i] = s4[i];
+      for (uint32_t i = nvec * 8 + tid; i < n; i += nthr) in_s[i] = src[i];
+    } else {
+      for (uint32_t i = tid; i < n; i += nthr) in_s[i] = src[i];
+    }
   }
   if (!SIZES_ONLY) {
     uint4* z4 = reinterpret_cast<uint4*>(img);
@@ -103,26 +113,32 @@ x3_encode_frames_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
   }
   if (tid >= 32 && tid < 48) part[tid] = 0;
   __syncthreads();
-  // <Audio State>: wav[0] raw in the first 16 payload bits (encoder.rs:189)
-  if (!SIZES_ONLY && tid == 0) atomicOr(&img[5], x3_bswap32(((uint32_t)(uint16_t)in_s[0]) << 16));
+  // <Audio State>: wav[0] raw in the first 16 payload bits (encoder.rs:189), of every channel in turn
+  if (!SIZES_ONLY && tid < n_ch) {
+    const uint32_t first = (uint32_t)(uint16_t)(n_ch == 1u ? in_s[0] : src[(uint64_t)tid * ch_stride]);
+    atomicOr(&img[5 + (tid >> 1)], x3_bswap32(first << ((tid & 1u) ? 0 : 16)));
+  }
 
   // ---- B..D in rounds of nthr blocks (one round for the default 500 blocks / 512 lanes)
   const uint32_t bl = p.block_len;
-  const uint32_t nblocks = (n - 1 + bl - 1) / bl;
-  uint32_t base_bits = 16;  // <Audio State>: wav[0] raw (encoder.rs:189)
+  const uint32_t nblocks = (n - 1 + bl - 1) / bl;   // per channel
+  const uint32_t nitems = nblocks * n_ch;            // blocks in stream order: (block index, channel)
+  uint32_t base_bits = 16 * n_ch;  // <Audio State>: wav[0] raw (encoder.rs:189), per channel
   uint32_t bad = 0;
 
-  for (uint32_t b0 = 0; b0 < nblocks; b0 += nthr) {
-    const uint32_t b = b0 + tid;
-    const bool valid = b < nblocks;
+  for (uint32_t b0 = 0; b0 < nitems; b0 += nthr) {
+    const uint32_t item = b0 + tid;
+    const bool valid = item < nitems;
+    const uint32_t b = n_ch == 1 ? item : item / n_ch;
+    const int16_t* const in_c = n_ch == 1u ? in_s : src + (uint64_t)(item - b * n_ch) * ch_stride;   // this item's channel
     const uint32_t s0 = 1 + b * bl;  // blocks start at wav[1] (encoder.rs:194)
     const uint32_t cnt = valid ? (n - s0 < bl ? n - s0 : bl) : 0;
 
     // B: diff filter + range (encoder.rs:296-302)
     int32_t dmin = 0, dmax = 0;
-    int32_t prev = valid ? (int32_t)in_s[s0 - 1] : 0;
+    int32_t prev = valid ? (int32_t)in_c[s0 - 1] : 0;
     for (uint32_t i = 0; i < cnt; ++i) {
-      int32_t s = in_s[s0 + i];
+      int32_t s = in_c[s0 + i];
       int32_t d = s - prev;
       prev = s;
       dmin = d < dmin ? d : dmin;
@@ -143,9 +159,9 @@ x3_encode_frames_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
         bad = 1;  // the reference indexes outside its Rice table here (panic)
       } else {
         uint32_t sum = 0;
-        int32_t pv = valid ? (int32_t)in_s[s0 - 1] : 0;
+        int32_t pv = valid ? (int32_t)in_c[s0 - 1] : 0;
         for (uint32_t i = 0; i < cnt; ++i) {
-          int32_t s = in_s[s0 + i];
+          int32_t s = in_c[s0 + i];
           int32_t d = s - pv;
           pv = s;
           uint32_t u = ((uint32_t)d << 1) ^ (uint32_t)(d >> 31);
@@ -187,9 +203,9 @@ x3_encode_frames_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
         if (type <= 3) {
           e.put(ft + 1, 2);
           const uint32_t mask = (1u << k) - 1u;
-          int32_t pv = in_s[s0 - 1];
+          int32_t pv = in_c[s0 - 1];
           for (uint32_t i = 0; i < cnt; ++i) {
-            int32_t s = in_s[s0 + i];
+            int32_t s = in_c[s0 + i];
             int32_t d = s - pv;
             pv = s;
             uint32_t u = ((uint32_t)d << 1) ^ (uint32_t)(d >> 31);
@@ -198,16 +214,16 @@ x3_encode_frames_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
         } else if (type == 4) {
           e.put(nb, 6);
           const uint32_t mask = (1u << (nb + 1)) - 1u;
-          int32_t pv = in_s[s0 - 1];
+          int32_t pv = in_c[s0 - 1];
           for (uint32_t i = 0; i < cnt; ++i) {
-            int32_t s = in_s[s0 + i];
+            int32_t s = in_c[s0 + i];
             int32_t d = s - pv;
             pv = s;
             e.put((uint32_t)d & mask, nb + 1);
           }
         } else {
           e.put(15, 6);
-          for (uint32_t i = 0; i < cnt; ++i) e.put((uint32_t)(uint16_t)in_s[s0 + i], 16);
+          for (uint32_t i = 0; i < cnt; ++i) e.put((uint32_t)(uint16_t)in_c[s0 + i], 16);
         }
         e.finish();
       }
@@ -231,6 +247,8 @@ x3_encode_frames_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
     if (tid == 0) {
       frame_bytes[f] = 20u + L;
       if (part[40]) atomicMax(&status[0], X3D_BAD_ARG);
+      // several channels can make a payload that no reader takes (24 KB read buffer, decodefile.rs:118-121); one cannot
+      else if (n_ch > 1u && L > 24576u) atomicMax(&status[0], X3D_FRAME_LENGTH);
     }
     return;
   }
@@ -273,7 +291,7 @@ x3_encode_frames_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
       if (L & 2u) v = x3_gf_mul(v, xpow[X3_XINV16_INDEX]);  // undo the 2 virtual pad-to-4 bytes
       // frame header (encoder.rs:122-162): "x3", id, id, samples, payload_len, 8 zero time
       // bytes, header crc over bytes 0..16, payload crc; audio frames use id 1 (encoder.rs:210)
-      const uint32_t h0 = 0x78330101u;
+      const uint32_t h0 = 0x78330100u | n_ch;  // "x3", source id 1, <Num Channels>
       const uint32_t h1 = ((n & 0xFFFFu) << 16) | (L & 0xFFFFu);
       uint32_t hc = 0xFFFFu;
       hc = x3_crc_be32(hc, h0);

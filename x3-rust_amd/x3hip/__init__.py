@@ -51,6 +51,7 @@ SYMBOLS = [
     "x3_shard_exchange_length_value", "x3_shard_lengths", "x3_shard_gather", "x3_shard_gather_async", "x3_shard_gather_wait",
     "x3_mgpu_create", "x3_mgpu_destroy", "x3_mgpu_devices", "x3_mgpu_ctx", "x3_mgpu_shard", "x3_mgpu_last_error",
     "x3_mgpu_encode", "x3_mgpu_decode_stream",
+    "x3_encode_mc", "x3_decode_stream_mc",
 ]
 
 
@@ -545,6 +546,40 @@ class Context:
         rc = lib().x3_decode_stream(self._h, x3.ctypes.data, x3.size, C.byref(params), wav.ctypes.data, wav_cap,
                                     C.byref(n), C.byref(fok), C.byref(ferr))
         return rc, wav[: n.value].copy(), fok.value, ferr.value
+
+    def encode_mc(self, wavs, params=None, start_pos=0, cap=None):
+        """multi-channel extension (x3_encode_mc): wavs = equally long int16 arrays -> (rc, bytes, stats[6])"""
+        params = params or Params.default()
+        wavs = [np.ascontiguousarray(w, dtype=np.int16) for w in wavs]
+        n = wavs[0].size
+        assert all(w.size == n for w in wavs)
+        L = lib()
+        cap = len(wavs) * L.x3_encode_bound(n, C.byref(params)) + start_pos + 64 if cap is None else cap
+        out = np.zeros(max(cap, 1), dtype=np.uint8)
+        pos = C.c_uint64(0)
+        stats = np.zeros(6, dtype=np.uint64)
+        ptrs = (C.c_void_p * len(wavs))(*[w.ctypes.data for w in wavs])
+        L.x3_encode_mc.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
+                                   C.c_uint64, C.c_void_p, C.c_void_p]
+        rc = L.x3_encode_mc(self._h, ptrs, len(wavs), n, C.byref(params), out.ctypes.data, cap, start_pos, C.byref(pos),
+                            stats.ctypes.data)
+        return rc, out[: pos.value].copy(), stats
+
+    def decode_stream_mc(self, x3, n_ch, params=None, wav_cap=None):
+        """-> (rc, [samples of channel k], frames_ok, frame_errors)"""
+        params = params or Params.default()
+        x3 = np.ascontiguousarray(x3, dtype=np.uint8)
+        if wav_cap is None:
+            wav_cap = max(1, x3.size * 16)
+        wavs = [np.zeros(wav_cap, dtype=np.int16) for _ in range(n_ch)]
+        ptrs = (C.c_void_p * n_ch)(*[w.ctypes.data for w in wavs])
+        n, fok, ferr = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        L = lib()
+        L.x3_decode_stream_mc.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
+                                          C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        rc = L.x3_decode_stream_mc(self._h, x3.ctypes.data, x3.size, n_ch, C.byref(params), ptrs, wav_cap, C.byref(n),
+                                   C.byref(fok), C.byref(ferr))
+        return rc, [w[: n.value].copy() for w in wavs], fok.value, ferr.value
 
     def decode_prefetch(self, x3=None, params=None):
         """announce a frame stream (a contiguous uint8 array, kept alive here) for decode_frame loops; None drops it"""
