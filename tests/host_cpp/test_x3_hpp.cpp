@@ -132,6 +132,29 @@ int main(int argc, char** argv) {
     const std::string s = os.str();
     CHECK(s.size() == ref.size() + 2 && s[1] == 0 && !std::memcmp(s.data() + 2, ref.data(), ref.size()));
   }
+  // the multi-channel extension (the crate itself stops at MoreThanOneChannel, checked above): two channels against the
+  // oracle's definition, and back
+  {
+    std::vector<int16_t> left(wav.begin(), wav.begin() + 50000), right(wav.begin() + 60000, wav.begin() + 110000);
+    x3::Channel l(0, left.data(), left.size(), 44100, params), r(1, right.data(), right.size(), 44100, params);
+    const x3::Channel* chans[2] = {&l, &r};
+    std::vector<uint8_t> out(400000), want(400000);
+    x3::bytewriter::SliceByteWriter w(out.data(), out.size());
+    uint64_t stats[6] = {0}, stats_o[6] = {0}, pos = 0, pos_o = 0;
+    CHECK(x3::multichannel::encode(ctx, chans, 2, w, stats) == x3::X3Error::Ok);
+    w.stream_position(&pos);
+    x3o_params po;
+    x3o_params_default(&po);
+    const int16_t* planes[2] = {left.data(), right.data()};
+    CHECK(x3o_encode_mc(planes, 2, left.size(), &po, want.data(), want.size(), 0, &pos_o, stats_o) == 0);
+    CHECK(pos == pos_o && !std::memcmp(out.data(), want.data(), pos) && !std::memcmp(stats, stats_o, sizeof stats) && out[3] == 2);
+    std::vector<int16_t> bl(left.size()), br(right.size());
+    int16_t* back[2] = {bl.data(), br.data()};
+    x3::decoder::StreamResult res;
+    CHECK(x3::multichannel::decode_stream(ctx, out.data(), pos, 2, params, back, bl.size(), &res) == x3::X3Error::Ok);
+    CHECK(res.samples == left.size() && res.frames_ok == 5 && res.frame_errors == 0 && bl == left && br == right);
+    CHECK(x3::decoder::decode_stream(ctx, out.data(), pos, params, bl.data(), bl.size(), &res) == x3::X3Error::MoreThanOneChannel);
+  }
   // decode: walk + decode the stream, then one frame through decode_frame
   {
     std::vector<int16_t> back(wav.size());

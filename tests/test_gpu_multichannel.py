@@ -99,3 +99,45 @@ def test_damaged_and_mismatched_streams(ctx):
     assert rc == 6   # the reference's reader (x3_decode_stream) refuses the frame, as the crate does
     # arguments
     assert ctx.encode_mc([wavs[0]] * 9)[0] == x3hip.ERR_BAD_ARG
+
+
+def test_random_multichannel_sweep(ctx):
+    """seeded sweep: channels x geometry x codes/thresholds x content x damage, GPU == oracle (status, bytes, samples)"""
+    rng = np.random.default_rng(2026)
+    for trial in range(60):
+        n_ch = int(rng.integers(1, 9))
+        bl = int(rng.choice([20, 20, 20, 7, 33, 60]))
+        bpf = int(rng.integers(1, 120))
+        n = int(rng.integers(1, 4 * bl * bpf + 50))
+        p = x3hip.Params.default(); po = O.Params.default()
+        for q in (p, po):
+            q.block_len, q.blocks_per_frame = bl, bpf
+        wavs = []
+        for k in range(n_ch):
+            kind = int(rng.integers(0, 4))
+            if kind == 0:
+                w = np.cumsum(rng.integers(-4, 5, n)).astype(np.int16)
+            elif kind == 1:
+                w = rng.integers(-25, 26, n).astype(np.int16)
+            elif kind == 2:
+                w = (rng.integers(-2000, 2000, n) * (rng.random(n) < 0.1)).astype(np.int16)
+            else:
+                w = rng.integers(-32768, 32768, n).astype(np.int16)
+            wavs.append(w)
+        start = int(rng.integers(0, 4))
+        rc_o, x_o, st_o = O.encode_mc(wavs, po, start_pos=start)
+        rc_g, x_g, st_g = ctx.encode_mc(wavs, p, start_pos=start)
+        assert rc_g == rc_o, (trial, rc_g, rc_o, n_ch, bl, bpf, n, ctx.last_error())
+        if rc_o:
+            continue
+        assert np.array_equal(x_g[start:], x_o[start:]) and st_g.tolist() == st_o.tolist(), (trial, n_ch, bl, bpf, n)
+        s = x_o[start + (start & 1):].copy()
+        if trial % 3 == 1 and s.size > 40:
+            s[int(rng.integers(0, s.size))] ^= 1 << int(rng.integers(0, 8))
+        elif trial % 3 == 2 and s.size > 40:
+            s = s[: int(rng.integers(1, s.size))]
+        got = ctx.decode_stream_mc(s, n_ch, p, wav_cap=n + 8)
+        want = O.decode_stream_mc(s, n_ch, po, wav_cap=n + 8)
+        assert (got[0], got[2], got[3]) == (want[0], want[2], want[3]), (trial, got[0], got[2:], want[0], want[2:])
+        for k in range(n_ch):
+            assert np.array_equal(got[1][k], want[1][k]), (trial, k)

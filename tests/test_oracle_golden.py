@@ -185,3 +185,27 @@ def test_oracle_decode_frame_with_block_len_zero():
     assert run("11" * 7 + "00" "0101") == BAD_ARG                  # BFP with E + 1 = 6 of no samples: panic
     assert run("01" * 64) == INVALID_BPF                           # Rice types to the end, then the zeros behind it
     assert O.decode_frame(np.array([0x12, 0x34, 0xFF], dtype=np.uint8), 1, p0) [0] == 0   # one sample: no block at all
+
+
+def test_multichannel_extension_of_the_oracle():
+    """x3o_encode_mc / x3o_decode_stream_mc (the extension's definition; the reference stops at MoreThanOneChannel): with ONE
+    channel they are the reference-pinned mono functions byte for byte; with more, a round trip, the header's channel
+    byte, and the mono reader's refusal"""
+    rng = np.random.default_rng(8)
+    n = 25003
+    walk = np.cumsum(rng.integers(-9, 10, n)).astype(np.int16)
+    noise = rng.integers(-300, 300, n).astype(np.int16)
+    loud = rng.integers(-32768, 32768, n).astype(np.int16)
+    for w in (walk, noise, loud):
+        rc1, a, st1 = O.encode(w)
+        rc2, b, st2 = O.encode_mc([w])
+        assert rc1 == rc2 == 0 and np.array_equal(a, b) and st1.tolist() == st2.tolist()
+    p = O.Params.default()
+    p.blocks_per_frame = 100   # 2 000-sample frames: three channels of literal blocks stay under the reader's 24 KB
+    rc, x, st = O.encode_mc([walk, noise, loud], p)
+    assert rc == 0 and x[3] == 3 and int(st.sum()) == 3 * (n - 13)   # 13 frames: their first samples are not in a block
+    rc, back, fok, ferr = O.decode_stream_mc(x, 3, p, wav_cap=n + 8)
+    assert (rc, fok, ferr) == (0, 13, 0)
+    assert all(np.array_equal(a, b) for a, b in zip(back, (walk, noise, loud)))
+    assert O.decode_stream(x, p, wav_cap=n + 8)[0] == 6          # X3Error::MoreThanOneChannel, as the crate
+    assert O.encode_mc([walk, noise, loud])[0] == 10              # default frames: 60 KB payloads -> FrameLength

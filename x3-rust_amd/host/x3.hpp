@@ -585,6 +585,36 @@ inline X3Error decode_stream_dev(Context& ctx, const uint8_t* d_x3, size_t len, 
 }
 }  // namespace decoder
 
+// Multi-channel extension (x3_mc.h; NOT in the crate, whose encode() returns MoreThanOneChannel for more than one channel
+// and whose reader refuses such frames -- as encoder::encode and decoder::decode_stream above do): the layout the frame
+// header's <Num Channels> and "pack the data block for each channel" (encoder.rs:197) foresee.  Channels of equal length.
+namespace multichannel {
+inline X3Error encode(Context& ctx, const Channel* const* channels, size_t n_channels, bytewriter::SliceByteWriter& writer,
+                      uint64_t (&stats)[6]) {
+  if (n_channels == 0) return X3Error::BadArg;
+  std::vector<const int16_t*> wavs(n_channels);
+  for (size_t k = 0; k < n_channels; ++k) {
+    if (channels[k]->len != channels[0]->len) return X3Error::BadArg;
+    wavs[k] = channels[k]->wav;
+  }
+  x3_params c = channels[0]->params.c_params();
+  uint64_t pos = 0;
+  int rc = x3_encode_mc(ctx.raw(), wavs.data(), (uint32_t)n_channels, channels[0]->len, &c, writer.data(), writer.capacity(),
+                        writer.position(), &pos, stats);
+  if (rc == 0) writer.advance_to((size_t)pos);
+  return static_cast<X3Error>(rc);
+}
+inline X3Error decode_stream(Context& ctx, const uint8_t* x3, size_t len, size_t n_channels, const Parameters& params,
+                             int16_t* const* wavs, size_t wav_cap, decoder::StreamResult* res) {
+  x3_params c = params.c_params();
+  decoder::StreamResult r;
+  int rc = x3_decode_stream_mc(ctx.raw(), x3, len, (uint32_t)n_channels, &c, wavs, wav_cap, &r.samples, &r.frames_ok,
+                               &r.frame_errors);
+  if (res) *res = r;
+  return static_cast<X3Error>(rc);
+}
+}  // namespace multichannel
+
 // encodefile.rs / decodefile.rs without the files: the .x3a archive header and the whole-buffer conversions
 namespace archive {
 struct X3aSpec {  // decodefile.rs:36-43

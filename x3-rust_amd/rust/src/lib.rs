@@ -71,6 +71,11 @@ pub mod ffi {
         pub fn x3_decode_prefetch(ctx: *mut x3_ctx, x3: *const u8, len: u64, p: *const x3_params) -> c_int;
         pub fn x3_decode_stream(ctx: *mut x3_ctx, x3: *const u8, len: u64, p: *const x3_params, wav: *mut i16,
                                 wav_cap: u64, n_out: *mut u64, frames_ok: *mut u64, frame_errors: *mut u64) -> c_int;
+        pub fn x3_encode_mc(ctx: *mut x3_ctx, wavs: *const *const i16, n_channels: u32, n: u64, p: *const x3_params,
+                            out: *mut u8, out_cap: u64, start_pos: u64, out_pos: *mut u64, stats: *mut u64) -> c_int;
+        pub fn x3_decode_stream_mc(ctx: *mut x3_ctx, x3: *const u8, len: u64, n_channels: u32, p: *const x3_params,
+                                   wavs: *const *mut i16, wav_cap: u64, n_samples: *mut u64, frames_ok: *mut u64,
+                                   frame_errors: *mut u64) -> c_int;
         pub fn x3_bitreader_new(ctx: *mut x3_ctx, array: *const u8, len: u64, br: *mut *mut x3_bitreader) -> c_int;
         pub fn x3_bitreader_read_nbits(br: *mut x3_bitreader, n: u32, value: *mut u32) -> c_int;
         pub fn x3_bitreader_count_zero_bits(br: *mut x3_bitreader, count: *mut u32) -> c_int;
@@ -927,6 +932,50 @@ pub mod decoder {
             error::check(unsafe {
                 ffi::x3_decode_stream(g.raw(), x3.as_ptr(), x3.len() as u64, &p, wav.as_mut_ptr(), wav.len() as u64,
                                       &mut n, &mut ok, &mut bad)
+            })
+        })?;
+        Ok((n as usize, ok as usize, bad as usize))
+    }
+}
+
+pub mod multichannel {
+    //! Not in the reference crate, whose `encoder::encode` returns `MoreThanOneChannel` for more than one channel
+    //! (src/encoder.rs:55-57) and whose reader refuses such frames (src/decoder.rs:90-94) -- as `encoder::encode` and
+    //! `decoder::decode_stream` of this crate do.  The layout is the one the frame header's `<Num Channels>` and
+    //! "pack the data block for each channel" (src/encoder.rs:197) foresee; include/x3hip.h, x3_mc.h.
+    use crate::error::{self, X3Error};
+    use crate::{ffi, gpu, x3};
+
+    /// channels of equal length into `out[start_pos..]`; -> the writer's position behind the last frame
+    pub fn encode(channels: &[&[i16]], params: &x3::Parameters, out: &mut [u8], start_pos: usize) -> Result<usize, X3Error> {
+        let n = channels.first().ok_or(X3Error::BadArg)?.len();
+        if channels.iter().any(|c| c.len() != n) {
+            return Err(X3Error::BadArg);
+        }
+        let p = params.c()?;
+        let ptrs: Vec<*const i16> = channels.iter().map(|c| c.as_ptr()).collect();
+        let n_ch = u32::try_from(ptrs.len()).map_err(|_| X3Error::BadArg)?;
+        let mut pos = 0u64;
+        gpu::with_default(|g| {
+            error::check(unsafe {
+                ffi::x3_encode_mc(g.raw(), ptrs.as_ptr(), n_ch, n as u64, &p, out.as_mut_ptr(), out.len() as u64,
+                                  start_pos as u64, &mut pos, std::ptr::null_mut())
+            })
+        })?;
+        Ok(pos as usize)
+    }
+
+    /// -> (samples per channel, good frames, counted frame errors); every channel slice must hold `wav_cap` samples
+    pub fn decode_stream(x3: &[u8], params: &x3::Parameters, channels: &mut [&mut [i16]]) -> Result<(usize, usize, usize), X3Error> {
+        let cap = channels.iter().map(|c| c.len()).min().ok_or(X3Error::BadArg)?;
+        let p = params.c()?;
+        let ptrs: Vec<*mut i16> = channels.iter_mut().map(|c| c.as_mut_ptr()).collect();
+        let n_ch = u32::try_from(ptrs.len()).map_err(|_| X3Error::BadArg)?;
+        let (mut n, mut ok, mut bad) = (0u64, 0u64, 0u64);
+        gpu::with_default(|g| {
+            error::check(unsafe {
+                ffi::x3_decode_stream_mc(g.raw(), x3.as_ptr(), x3.len() as u64, n_ch, &p, ptrs.as_ptr(), cap as u64, &mut n,
+                                         &mut ok, &mut bad)
             })
         })?;
         Ok((n as usize, ok as usize, bad as usize))
