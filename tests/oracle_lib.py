@@ -135,7 +135,9 @@ def encode_bound(n, params):
     if spf == 0:
         return 64
     nf = (n + spf - 1) // spf
-    return nf * (20 + 2 * spf + spf // 8 + 64) + 64
+    # per frame: header, 16 bits per sample, 6 header bits per block (block_len may be 1), alignment
+    nblocks = (spf + params.block_len - 1) // params.block_len
+    return nf * (20 + 2 * spf + (6 * nblocks + 7) // 8 + 64) + 64
 
 
 def encode(wav, params=None, start_pos=0, cap=None, n_channels=1):

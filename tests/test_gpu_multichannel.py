@@ -125,8 +125,9 @@ def test_random_multichannel_sweep(ctx):
                 w = rng.integers(-32768, 32768, n).astype(np.int16)
             wavs.append(w)
         start = int(rng.integers(0, 4))
-        rc_o, x_o, st_o = O.encode_mc(wavs, po, start_pos=start)
-        rc_g, x_g, st_g = ctx.encode_mc(wavs, p, start_pos=start)
+        cap = n_ch * O.encode_bound(n, po) + start + 64
+        rc_o, x_o, st_o = O.encode_mc(wavs, po, start_pos=start, cap=cap)
+        rc_g, x_g, st_g = ctx.encode_mc(wavs, p, start_pos=start, cap=cap)
         assert rc_g == rc_o, (trial, rc_g, rc_o, n_ch, bl, bpf, n, ctx.last_error())
         if rc_o:
             continue

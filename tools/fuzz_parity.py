@@ -345,7 +345,40 @@ def fam_w(rng, tag):
         shutil.rmtree(d, ignore_errors=True)
 
 
-fams = {"w": fam_w, "e": fam_e, "g": fam_g, "d": fam_d, "b": fam_b, "a": fam_a, "f": fam_f}
+def fam_m(rng, tag):
+    """multi-channel extension: x3_encode_mc / x3_decode_stream_mc == the oracle's x3o_encode_mc / x3o_decode_stream_mc over
+    channels x geometry x content x start position, intact, damaged and truncated streams, wrong channel counts"""
+    n_ch = int(rng.integers(1, 9))
+    bl = int(rng.choice([20, 20, 20, 7, 33, 60, 1]))
+    bpf = int(rng.integers(1, 200))
+    n = int(rng.integers(1, 5 * bl * bpf + 50)) if rng.random() < 0.9 else int(rng.integers(1, 4))
+    p, po = x3hip.Params.default(), O.Params.default()
+    for q in (p, po):
+        q.block_len, q.blocks_per_frame = bl, bpf
+    wavs = [content(rng, n) for _ in range(n_ch)]
+    start = int(rng.integers(0, 5))
+    cap = n_ch * O.encode_bound(n, po) + start + 64   # (the same capacity on both sides: running out of it is part of the result)
+    rc_o, x_o, st_o = O.encode_mc(wavs, po, start_pos=start, cap=cap)
+    rc_g, x_g, st_g = ctx.encode_mc(wavs, p, start_pos=start, cap=cap)
+    assert rc_g == rc_o, (tag, "m enc rc", rc_g, rc_o, n_ch, bl, bpf, n)
+    if rc_o:
+        return
+    assert np.array_equal(x_g[start:], x_o[start:]) and st_g.tolist() == st_o.tolist(), (tag, "m enc bytes", n_ch, bl, bpf, n)
+    s = x_o[start + (start & 1):].copy()
+    what = int(rng.integers(0, 4))
+    if what == 1 and s.size > 40:
+        s[int(rng.integers(0, s.size))] ^= 1 << int(rng.integers(0, 8))
+    elif what == 2 and s.size > 40:
+        s = s[: int(rng.integers(1, s.size))]
+    ask = n_ch if what != 3 else int(rng.integers(1, 9))
+    got = ctx.decode_stream_mc(s, ask, p, wav_cap=n + 8)
+    want = O.decode_stream_mc(s, ask, po, wav_cap=n + 8)
+    assert (got[0], got[2], got[3]) == (want[0], want[2], want[3]), (tag, "m dec", got[0], got[2:], want[0], want[2:])
+    for k in range(ask):
+        assert np.array_equal(got[1][k], want[1][k]), (tag, "m samples", k)
+
+
+fams = {"w": fam_w, "e": fam_e, "g": fam_g, "d": fam_d, "b": fam_b, "a": fam_a, "f": fam_f, "m": fam_m}
 
 
 def run(seed=1, minutes=None, trials=None, families="egdbaf", only=-1, context=None):
