@@ -6,6 +6,7 @@
 // is done by the kernels in x3_encode_kernel.h / x3_decode_kernel.h / x3_util_kernels.h.
 // There is no CPU fallback: every bulk entry point needs a live x3_ctx (a HIP device).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -510,12 +511,19 @@ extern "C" const char* x3_strerror(int s) {
 }
 
 // ---- kernel timing
+// Two ways of timing a launch with HIP events.  The plain one brackets the launch with two hipEventRecord on its stream: the
+// events are packets of their own, and what lies between them is the kernel plus a few microseconds of queue (2 % of a
+// 0.43 ms kernel: the HIP-event averages of round 2's bench line sat 2-4 % off rocprofv3's).  `attached`: the events ride
+// on the kernel's own dispatch packet (hipExtLaunchKernelGGL) and hold its begin and end -- what rocprofv3's kernel
+// trace reports; the three kernels of the round trip are launched that way (X3_LAUNCH_TIMED).
 struct TimerScope {
   x3_ctx* c;
   int which;
   hipStream_t st;
+  bool attached;
   std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
-  TimerScope(x3_ctx* c_, int w, hipStream_t s_ = nullptr) : c(c_), which(w), st(s_ ? s_ : c_->stream) {
+  TimerScope(x3_ctx* c_, int w, hipStream_t s_ = nullptr, bool attached_ = false)
+      : c(c_), which(w), st(s_ ? s_ : c_->stream), attached(attached_) {
     if (!c->timing) return;
     KernelTimer& t = c->timers[which];
     if (!t.pool.empty()) {
@@ -525,14 +533,20 @@ struct TimerScope {
       (void)hipEventCreate(&ev.first);
       (void)hipEventCreate(&ev.second);
     }
-    (void)hipEventRecord(ev.first, st);
+    if (!attached) (void)hipEventRecord(ev.first, st);
   }
   ~TimerScope() {
     if (!c->timing) return;
-    (void)hipEventRecord(ev.second, st);
+    if (!attached) (void)hipEventRecord(ev.second, st);
     c->timers[which].used.push_back(ev);
   }
 };
+// launch `kernel` on `stream` inside the TimerScope `ts` (constructed with attached = true)
+#define X3_LAUNCH_TIMED(ts, kernel, grid, block, smem, stream, ...)                                        \
+  do {                                                                                                     \
+    if ((ts).c->timing) hipExtLaunchKernelGGL(kernel, grid, block, smem, stream, (ts).ev.first, (ts).ev.second, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);                               \
+  } while (0)
 
 extern "C" int x3_ctx_enable_kernel_timing(x3_ctx* c, int enable) {
   if (!c) return X3_ERR_BAD_ARG;
@@ -881,8 +895,8 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
       wa.kpack = pl.dp.k[0] | (pl.dp.k[1] << 8) | (pl.dp.k[2] << 16);
       wa.drop_wgi = c->opt.wave_drop >= 0 ? (uint32_t)c->opt.wave_drop : 0xFFFFFFFFu;
       {
-        TimerScope ts(c, 0);
-        hipLaunchKernelGGL(x3_encode_wave_kernel, dim3(wa.nwg), dim3(X3W_THREADS), X3W_SMEM, c->stream, wa);
+        TimerScope ts(c, 0, nullptr, true);
+        X3_LAUNCH_TIMED(ts, x3_encode_wave_kernel, dim3(wa.nwg), dim3(X3W_THREADS), X3W_SMEM, c->stream, wa);
       }
       HIPCHK(c, hipGetLastError());
       c->last_was_wave = true;
@@ -1267,9 +1281,9 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
       HIPCHK(c, hipMemsetAsync(c->dec_cstatus.p, 0, F * sizeof(int32_t), c->stream2));
 
     } else {
-      TimerScope ts(c, 4, check_stream);
+      TimerScope ts(c, 4, check_stream, true);
       const uint64_t check_grid = std::min<uint64_t>((F + 3) / 4, (uint64_t)c->n_cus * check_wgs_per_cu);
-      hipLaunchKernelGGL(x3_frame_check_kernel, dim3((unsigned)check_grid), dim3(256), 0, check_stream,
+      X3_LAUNCH_TIMED(ts, x3_frame_check_kernel, dim3((unsigned)check_grid), dim3(256), 0, check_stream,
                          reinterpret_cast<const uint32_t*>(d_x3), x3_len, d_frame_offsets, F,
                          (const uint16_t*)c->d_xinv8, (const uint16_t*)c->d_chktab, (const uint32_t*)c->d_kx64,
                          (int32_t*)c->dec_cstatus.p, reinterpret_cast<unsigned long long*>(c->d_summary), 1u);
@@ -1300,14 +1314,14 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
 #else
     const size_t dyn_lds = 0;
 #endif
-    TimerScope ts(c, 1, dec_stream);
+    TimerScope ts(c, 1, dec_stream, split);   // (the split kernel: events on its dispatch packet; the rarer single-wave kernels below: bracketed)
     if (split) {
       // the pace word's 12-bit epoch: launches 1, 2, ... 4095, then the word starts over
       if ((c->dec_epoch & 0xFFFu) == 0u) {
         HIPCHK(c, hipMemsetAsync(c->d_pace, 0, 16, dec_stream));  // (achieved and aimed-at, one word per launch parity)
         ++c->dec_epoch;
       }
-      hipLaunchKernelGGL(x3_decode_split_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64 * X3S_WAVES),
+      X3_LAUNCH_TIMED(ts, x3_decode_split_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64 * X3S_WAVES),
                          dyn_lds, dec_stream, d_x3, x3_len,
                          d_frame_offsets, F, g, d_wav_offsets, dp, d_wav, wav_cap, d_status, (X3FrameMeta*)c->dec_meta.p,
                          c->d_pace, c->dec_epoch & 0xFFFu);
