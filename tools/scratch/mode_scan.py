@@ -8,7 +8,7 @@ F = L.x3_num_frames(n, C.byref(p)); cap = L.x3_encode_bound(n, C.byref(p))
 bufs = {"wav": ctx.alloc(2 * n), "out": ctx.alloc(cap + 16), "off": ctx.alloc(8 * (F + 1)), "back": ctx.alloc(2 * n)}
 sizes = {"wav": 2 * n, "out": cap + 16, "off": 8 * (F + 1), "back": 2 * n}
 ctx.synth_dev(2, 0x58330003, 0, n, bufs["wav"])
-def run(steps=20):
+def run(steps=int(os.environ.get("MODE_STEPS", "20"))):
     ctx.enable_kernel_timing(False)
     for _ in range(8):
         assert ctx.encode_dev(bufs["wav"], n, p, bufs["out"], cap, 0, bufs["off"]) == 0
