@@ -452,8 +452,7 @@ def main():
         hback = np.zeros(n, dtype=np.int16); hback[::2048] = 1
         hpos, hn, hok, herr = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
         hstats = np.zeros(6, dtype=np.uint64)
-        times = []
-        for _ in range(2):
+        def host_round_trip():
             t0 = time.perf_counter()
             rc = L.x3_encode(ctx._h, hwav.ctypes.data, n, 1, C.byref(p), hout.ctypes.data, hcap, 0, C.byref(hpos),
                              hstats.ctypes.data)
@@ -462,16 +461,30 @@ def main():
                                      C.byref(hok), C.byref(herr))
             t2 = time.perf_counter()
             assert rc == 0 and rc2 == 0 and hn.value == n, (rc, rc2, hn.value)
-            times.append((t1 - t0, t2 - t1))
+            return (t1 - t0, t2 - t1)
+        # first call = cold (device scratch is allocated); then four steady calls, the median one is reported (long
+        # buffers go through in chunks, uploads beside downloads, and one decode call in three is 5 ms slower than the
+        # others: DESIGN.md section 5); last, one call with the buffers in one piece (option host_chunk_frames = -1)
+        times = [host_round_trip() for _ in range(5)]
         assert np.array_equal(hback, hwav)
-        te, td = times[-1]
+        ctx.set_option("host_chunk_frames", -1)
+        host_round_trip()
+        one_piece = host_round_trip()
+        ctx.set_option("host_chunk_frames", 0)
+        assert np.array_equal(hback, hwav)
+        steady = sorted(times[1:], key=lambda t: t[0] + t[1])
+        te, td = steady[len(steady) // 2]
         host_api = {"samples": n, "encode_ms": round(te * 1e3, 2), "decode_ms": round(td * 1e3, 2),
                     "encode_msamples_s": round(n / te / 1e6, 1), "decode_msamples_s": round(n / td / 1e6, 1),
                     "msamples_s": round(n / (te + td) / 1e6, 1),
+                    "calls_ms": [[round(a * 1e3, 2), round(b * 1e3, 2)] for a, b in times[1:]],
                     "cold_call_ms": [round(times[0][0] * 1e3, 2), round(times[0][1] * 1e3, 2)],
+                    "one_piece_ms": [round(one_piece[0] * 1e3, 2), round(one_piece[1] * 1e3, 2)],
                     "pcie_gb_s": round((2 * n + hpos.value) / te / 1e9, 1),
-                    "note": "x3_encode + x3_decode_stream on caller-owned pageable host buffers: H2D, kernels, D2H "
-                            "and the host-side frame walk, second call (the first also allocates device scratch)"}
+                    "note": "x3_encode + x3_decode_stream on caller-owned pageable host buffers, taken in chunks of whole "
+                            "frames (uploads, kernels and downloads side by side on three host threads): the median of "
+                            "four steady calls (calls_ms: encode, decode); cold_call_ms: the first call (device scratch "
+                            "is allocated); one_piece_ms: the same buffers in one piece (option host_chunk_frames = -1)"}
         # ---- the reference's incremental reader (X3aReader::decode_next_frame, one frame per call) over the same
         # stream as an .x3a archive in host memory: x3_reader_* decodes a window of frames ahead per launch set and
         # hands them out one by one (the loop below is a Python loop over the C entry point: ~1 us of ctypes per call)

@@ -51,16 +51,19 @@ def check_encode(ctx, x3, wav, params=None, start_pos=0):
 def check_decode(ctx, x3, stream, params=None, wav_cap=None):
     params = params or x3.Params.default()
     r_o = O.decode_stream(stream, oparams(params), wav_cap=wav_cap)
-    # x3_decode_stream walks the frame headers on the host for short streams and on the GPU for long ones:
-    # both walks against the oracle, whatever the size
-    for host_walk in (1, 0):
+    # x3_decode_stream walks the frame headers on the host for short streams and on the GPU for long ones, and takes
+    # long streams in chunks of whole frames (downloads beside uploads): all three against the oracle, whatever the size
+    chunk = 3 if len(stream) < (4 << 20) else 800
+    for host_walk, chunk_frames in ((1, -1), (0, -1), (-1, chunk)):
         ctx.set_option("host_walk", host_walk)
+        ctx.set_option("host_chunk_frames", chunk_frames)
         try:
             r_g = ctx.decode_stream(stream, params, wav_cap=wav_cap)
         finally:
             ctx.set_option("host_walk", -1)
-        assert (r_g[0], r_g[2], r_g[3]) == (r_o[0], r_o[2], r_o[3]), (host_walk, r_g[0], r_g[2:], r_o[0], r_o[2:])
-        assert np.array_equal(r_g[1], r_o[1]), host_walk
+            ctx.set_option("host_chunk_frames", 0)
+        assert (r_g[0], r_g[2], r_g[3]) == (r_o[0], r_o[2], r_o[3]), (host_walk, chunk_frames, r_g[0], r_g[2:], r_o[0], r_o[2:])
+        assert np.array_equal(r_g[1], r_o[1]), (host_walk, chunk_frames)
     return r_o
 
 
@@ -248,6 +251,41 @@ def test_insufficient_memory_matches_oracle(ctx, x3):
     for cap in [0, 19, 20, 21, 5000, full.size - 2]:
         assert O.encode(wav, cap=cap)[0] == x3.ERR_BYTE_WRITER_INSUFFICIENT_MEMORY
         assert ctx.encode(wav, cap=cap)[0] == x3.ERR_BYTE_WRITER_INSUFFICIENT_MEMORY
+
+
+def test_encode_host_buffers_in_chunks(ctx, x3):
+    """x3_encode takes a long host buffer in chunks of whole frames, downloads beside uploads (option
+    host_chunk_frames; by default only from 64 MB of samples): same bytes, position, statistics and errors as in one
+    piece and as the oracle, for chunk sizes that do and do not divide the stream, odd start positions, short tails,
+    dense content (the wave encoder's re-run inside a chunk) and an output that ends inside a later chunk"""
+    rng = np.random.default_rng(77)
+    try:
+        for (bl, bpf), n, frames in [((20, 500), 1_234_567, 8), ((20, 500), 400_000, 16), ((20, 25), 100_003, 24),
+                                      ((7, 33), 55_555, 8), ((20, 500), 160_000, 8), ((20, 500), 170_001, 8)]:
+            p = x3.Params.make(bl, bpf, (0, 1, 3), (3, 8, 20))
+            op = O.Params.make(bl, bpf, (0, 1, 3), (3, 8, 20))
+            wav = x3.synth(2, 5, 0, n)
+            wav[n // 3: n // 3 + 30_000] = rng.integers(-32768, 32768, 30_000)  # dense frames in the middle
+            for start in (0, 7):
+                want = O.encode(wav, op, start_pos=start)
+                ctx.set_option("host_chunk_frames", -1)
+                one = ctx.encode(wav, p, start_pos=start)
+                ctx.set_option("host_chunk_frames", frames)
+                got = ctx.encode(wav, p, start_pos=start)
+                assert want[0] == 0 and one[0] == 0 and got[0] == 0
+                assert np.array_equal(got[1][start:], want[1][start:]) and np.array_equal(one[1][start:], want[1][start:])
+                assert np.array_equal(got[2], want[2]) and np.array_equal(one[2], want[2])
+            # the output ends inside the third chunk: the same status and position as in one piece
+            full = O.encode(wav, op)[1].size
+            for cap in (full - 2, full * 2 // 3, 21):
+                ctx.set_option("host_chunk_frames", -1)
+                one = ctx.encode(wav, p, cap=cap); pos_one = ctx.out_pos
+                ctx.set_option("host_chunk_frames", frames)
+                got = ctx.encode(wav, p, cap=cap)
+                assert got[0] == one[0] == O.encode(wav, op, cap=cap)[0] == x3.ERR_BYTE_WRITER_INSUFFICIENT_MEMORY
+                assert ctx.out_pos == pos_one
+    finally:
+        ctx.set_option("host_chunk_frames", 0)
 
 
 # ------------------------------------------------------------------ decode parity incl. corrupt streams
@@ -747,6 +785,7 @@ def _make_encoder_lose_its_grid(c, gen):
     the grid is not resident.  Third generation (one wave per frame): one workgroup generation never publishes its total
     (option wave_drop), which is what a workgroup that is not resident looks like to all the others."""
     c.set_option("enc_gen", gen)
+    c.set_option("host_chunk_frames", -1)   # one launch over the whole input (the host front end would take it in chunks)
     if gen == 2:
         rc, _, _ = c.encode(np.zeros(30000, dtype=np.int16), None)
         natural = c.get_option("stream_wgs_in_use")

@@ -84,7 +84,12 @@ def cmp_encode(wav, p, sp, tag, cap_cut=None):
     if cap_cut is not None:
         cap = int(cap_cut * cap)                                       # ... or one both run out of
     rc_o, out_o, st_o = O.encode(wav, oparams(p), start_pos=sp, cap=cap)
-    rc_g, out_g, st_g = ctx.encode(wav, p, start_pos=sp, cap=cap)
+    # (one input in three: the host front end takes it in chunks of eight frames, if it has sixteen)
+    ctx.set_option("host_chunk_frames", 8 if wav.size % 3 == 0 else -1)
+    try:
+        rc_g, out_g, st_g = ctx.encode(wav, p, start_pos=sp, cap=cap)
+    finally:
+        ctx.set_option("host_chunk_frames", 0)
     assert rc_g == rc_o, (tag, "status", rc_g, rc_o, ctx.last_error())
     if rc_o == 0:
         assert out_g.size == out_o.size, (tag, "size", out_g.size, out_o.size)
@@ -97,14 +102,17 @@ def cmp_encode(wav, p, sp, tag, cap_cut=None):
 
 def cmp_decode(stream, p, cap, tag):
     r_o = O.decode_stream(stream, oparams(p), wav_cap=cap)
-    for host_walk in (1, 0):
+    # the walk on the host, on the GPU, and the stream taken in chunks of 1 + (its length mod 5) frames
+    for host_walk, chunk in ((1, -1), (0, -1), (-1, 1 + len(stream) % 5)):
         ctx.set_option("host_walk", host_walk)
+        ctx.set_option("host_chunk_frames", chunk)
         try:
             r_g = ctx.decode_stream(stream, p, wav_cap=cap)
         finally:
             ctx.set_option("host_walk", -1)
-        assert (r_g[0], r_g[2], r_g[3]) == (r_o[0], r_o[2], r_o[3]), (tag, host_walk, r_g[0], r_g[2:], r_o[0], r_o[2:])
-        assert np.array_equal(r_g[1], r_o[1]), (tag, host_walk, "samples")
+            ctx.set_option("host_chunk_frames", 0)
+        assert (r_g[0], r_g[2], r_g[3]) == (r_o[0], r_o[2], r_o[3]), (tag, host_walk, chunk, r_g[0], r_g[2:], r_o[0], r_o[2:])
+        assert np.array_equal(r_g[1], r_o[1]), (tag, host_walk, chunk, "samples")
     return r_o
 
 
@@ -408,7 +416,7 @@ def run(seed=1, minutes=None, trials=None, families="egdbaf", only=-1, context=N
         if own:
             ctx.close()
         else:  # a borrowed context goes back with the options the families touch at their defaults
-            for name, value in (("reader_window_frames", 4096), ("stream_v1", 0), ("host_walk", -1),
+            for name, value in (("reader_window_frames", 4096), ("stream_v1", 0), ("host_walk", -1), ("host_chunk_frames", 0),
                                 ("file_chunk_frames", 800), ("file_workers", 4)):
                 ctx.set_option(name, value)
         ctx = None

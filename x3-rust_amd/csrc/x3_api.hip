@@ -13,7 +13,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/x3hip.h"
@@ -53,6 +56,8 @@ struct X3Opts {
                               // that is not resident looks like to the others: their bounded waits give up (-1 = none)
   int decode_single = 0;      // X3HIP_DECODE_SINGLE: single-wave decoder kernels only
   int host_walk = -1;         // X3HIP_HOST_WALK: frame walk of x3_decode_stream on the host (1) / GPU (0) / by size (-1)
+  long long host_chunk_frames = 0;  // X3HIP_HOST_CHUNK_FRAMES: x3_encode on host buffers takes a long input in chunks of this many
+                              // frames, upload / encode / download side by side (0 = 32 MiB of samples, -1 = one piece)
   int verbose = 0;            // X3HIP_VERBOSE
   long long file_chunk_frames = 800;  // X3HIP_FILE_CHUNK_FRAMES: 16 MB of samples per chunk (tools/file_bench.py)
   int file_workers = 4;       // X3HIP_FILE_WORKERS
@@ -76,6 +81,7 @@ struct x3_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipStream_t stream2 = nullptr;        // side stream: the payload-CRC pass runs beside the decoder
+  hipStream_t dl_stream = nullptr, ul_stream = nullptr;  // the down- and uploads of long host buffers taken in chunks
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::string last_error;
   // persistent small device state
@@ -102,8 +108,11 @@ struct x3_ctx {
   X3DecodeSummary* h_summary_init = nullptr;
   int32_t* dec_status_ptr = nullptr;
   uint16_t* h_crc = nullptr;
+  void* h_walk = nullptr;  // frame and sample offsets of a host walk on their way to the device
+  size_t h_walk_cap = 0;
   // growable scratch
   DevBuf in, out, frame_bytes, frame_off, dec_status, dec_cstatus, dec_meta, wav_off, seg_crc, desc;
+  DevBuf in_more[2], out_more[2];  // x3_decode_stream on a long host buffer: rings of three buffers on either side of the decoder
   DevBuf idx_cand, idx_keys, idx_vals, idx_J, idx_S, idx_L, idx_sum;  // x3_index_dev scratch
   int n_cus = 0;
   bool force_single_wave_decode = false;
@@ -187,6 +196,7 @@ static void opts_from_env(X3Opts* o) {
   o->wave_nwg = (int)std::max(0ll, std::min(256ll, geti("X3HIP_WAVE_NWG", 0)));
   o->wave_m = (int)std::max(0ll, std::min(16ll, geti("X3HIP_WAVE_M", 0)));
   if (const char* e = std::getenv("X3HIP_HOST_WALK")) o->host_walk = e[0] == '0' ? 0 : 1;
+  o->host_chunk_frames = std::max(-1ll, geti("X3HIP_HOST_CHUNK_FRAMES", o->host_chunk_frames));
   o->verbose = std::getenv("X3HIP_VERBOSE") ? 1 : 0;
   o->file_chunk_frames = std::max(1ll, geti("X3HIP_FILE_CHUNK_FRAMES", o->file_chunk_frames));
   o->file_workers = (int)std::max(1ll, std::min(16ll, geti("X3HIP_FILE_WORKERS", o->file_workers)));
@@ -404,7 +414,7 @@ extern "C" void x3_ctx_destroy(x3_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->fcache) x3_reader_close(c->fcache);
-  for (DevBuf* b : {&c->in, &c->out, &c->frame_bytes, &c->frame_off, &c->dec_status, &c->dec_cstatus, &c->dec_meta, &c->wav_off,
+  for (DevBuf* b : {&c->in, &c->out, &c->in_more[0], &c->in_more[1], &c->out_more[0], &c->out_more[1], &c->frame_bytes, &c->frame_off, &c->dec_status, &c->dec_cstatus, &c->dec_meta, &c->wav_off,
                     &c->seg_crc, &c->desc, &c->idx_cand, &c->idx_keys, &c->idx_vals, &c->idx_J, &c->idx_S,
                     &c->idx_L, &c->idx_sum})
     if (b->p) (void)hipFree(b->p);
@@ -425,10 +435,13 @@ extern "C" void x3_ctx_destroy(x3_ctx* c) {
   (void)hipFree(c->d_pace);
   (void)hipFree(c->d_crc);
   (void)hipHostFree(c->h_status);
+  if (c->h_walk) (void)hipHostFree(c->h_walk);
   (void)hipHostFree(c->h_summary);
   (void)hipHostFree(c->h_summary_init);
   (void)hipHostFree(c->h_crc);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->dl_stream) (void)hipStreamDestroy(c->dl_stream);
+  if (c->ul_stream) (void)hipStreamDestroy(c->ul_stream);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -455,6 +468,7 @@ extern "C" int x3_ctx_set_option(x3_ctx* c, const char* name, long long value) {
   else if (n == "wave_m") c->opt.wave_m = (int)std::max(0ll, std::min(16ll, value));
   else if (n == "wave_drop") c->opt.wave_drop = value;
   else if (n == "host_walk") c->opt.host_walk = value < 0 ? -1 : (value != 0);
+  else if (n == "host_chunk_frames") c->opt.host_chunk_frames = std::max(-1ll, value);
   else if (n == "verbose") c->opt.verbose = value != 0;
   else if (n == "file_chunk_frames") c->opt.file_chunk_frames = std::max(1ll, value);
   else if (n == "file_workers") c->opt.file_workers = (int)std::max(1ll, std::min(16ll, value));
@@ -476,6 +490,7 @@ extern "C" int x3_ctx_get_option(const x3_ctx* c, const char* name, long long* v
   else if (n == "enc_gen") *value = c->opt.enc_gen;
   else if (n == "encode_dense_reruns") *value = (long long)c->encode_dense_reruns;  // read-only counter
   else if (n == "host_walk") *value = c->opt.host_walk;
+  else if (n == "host_chunk_frames") *value = c->opt.host_chunk_frames;
   else if (n == "verbose") *value = c->opt.verbose;
   else if (n == "file_chunk_frames") *value = c->opt.file_chunk_frames;
   else if (n == "file_workers") *value = c->opt.file_workers;
@@ -1167,6 +1182,137 @@ static int encode_host(x3_ctx* c, const int16_t* const* wavs, uint64_t n_per_cli
   return X3_OK;
 }
 
+// A stage of the host-buffer pipelines below hands work to the next through one of these (one producer, one consumer).
+template <class T>
+struct X3Handoff {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<T> q;
+  bool closed = false;
+  void push(T v) {
+    { std::lock_guard<std::mutex> g(mu); q.push_back(std::move(v)); }
+    cv.notify_all();
+  }
+  void close() {
+    { std::lock_guard<std::mutex> g(mu); closed = true; }
+    cv.notify_all();
+  }
+  bool pop(T* v) {  // false: closed and empty
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return closed || !q.empty(); });
+    if (q.empty()) return false;
+    *v = std::move(q.front());
+    q.pop_front();
+    return true;
+  }
+};
+// a count one thread advances and another waits for
+struct X3Progress {
+  std::mutex mu;
+  std::condition_variable cv;
+  uint64_t n = 0;
+  bool stop = false;
+  void advance() {
+    { std::lock_guard<std::mutex> g(mu); ++n; }
+    cv.notify_all();
+  }
+  void halt() {
+    { std::lock_guard<std::mutex> g(mu); stop = true; }
+    cv.notify_all();
+  }
+  bool wait_for(uint64_t want) {  // false: halted first
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return stop || n >= want; });
+    return n >= want;
+  }
+};
+static int x3_pipe_streams(x3_ctx* c) {
+  if (!c->dl_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->dl_stream, hipStreamNonBlocking));
+  if (!c->ul_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->ul_stream, hipStreamNonBlocking));
+  return X3_OK;
+}
+
+// x3_encode on a LONG host buffer: the same bytes as encode_host, in chunks of whole frames.  The link to the host is
+// the whole cost of this entry point (config 3: 1.38 GB up, 0.36 GB down, 0.4 ms of kernel) and it carries both
+// directions at once (tools/ubench/pcie_duplex.hip: 24.7 ms for both against 31.0 one after the other), so three host
+// threads work side by side -- pageable copies hold their caller: one sends chunk i+2 up, this one encodes chunk i+1
+// where chunk i ended (frames do not depend on each other; x3_encode_result's position is all a chunk waits for),
+// one brings the bytes of chunk i down.
+static int encode_host_chunked(x3_ctx* c, const int16_t* wav, uint64_t n, const x3_params* p, uint64_t spf,
+                               uint64_t chunk, uint8_t* out, uint64_t out_cap, uint64_t start_pos, uint64_t* out_pos,
+                               uint64_t stats[6]) {
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = ensure(c, c->in, n * sizeof(int16_t) + 16);
+  if (rc) return rc;
+  if (start_pos > out_cap) return X3_ERR_BYTE_WRITER_INSUFFICIENT_MEMORY;
+  {
+    const uint64_t full = n / spf, tail = n % spf;
+    const uint64_t bound = full * (20 + max_payload_bytes(spf, p->block_len)) + (tail ? 20 + max_payload_bytes(tail, p->block_len) : 0);
+    if ((rc = ensure(c, c->out, std::min<uint64_t>(out_cap, start_pos + 1 + bound) + 16))) return rc;
+  }
+  if ((rc = x3_pipe_streams(c))) return rc;
+  struct Piece { uint64_t lo, hi; };
+  X3Handoff<Piece> down;
+  X3Progress up;
+  hipError_t up_err = hipSuccess, dl_err = hipSuccess;
+  int16_t* d_in = (int16_t*)c->in.p;
+  std::thread uploader([&] {
+    hipError_t e = hipSetDevice(c->device);
+    for (uint64_t s0 = 0; s0 < n && e == hipSuccess; s0 += chunk) {
+      { std::lock_guard<std::mutex> g(up.mu); if (up.stop) return; }
+      e = hipMemcpyAsync(d_in + s0, wav + s0, std::min<uint64_t>(chunk, n - s0) * sizeof(int16_t), hipMemcpyHostToDevice, c->ul_stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->ul_stream);
+      if (e == hipSuccess) up.advance();
+    }
+    if (e != hipSuccess) { up_err = e; up.halt(); }
+  });
+  std::thread downloader([&] {
+    hipError_t e = hipSetDevice(c->device);
+    Piece pc;
+    while (down.pop(&pc)) {
+      if (e != hipSuccess) continue;  // (drain)
+      e = hipMemcpyAsync(out + pc.lo, (const uint8_t*)c->out.p + pc.lo, pc.hi - pc.lo, hipMemcpyDeviceToHost, c->dl_stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->dl_stream);
+    }
+    dl_err = e;
+  });
+  x3_params pp = *p;
+  uint64_t pos = start_pos, k = 0;
+  bool halted = false;
+  for (uint64_t s0 = 0; s0 < n && rc == X3_OK; s0 += chunk, ++k) {
+    if (!up.wait_for(k + 1)) { halted = true; break; }
+    const uint64_t cnt = std::min<uint64_t>(chunk, n - s0);
+    x3_batch b{cnt, cnt, 1};
+    uint64_t st[6] = {0, 0, 0, 0, 0, 0}, end = pos;
+    {
+      std::unique_lock<std::mutex> gate;
+      if (c->enc_gate) gate = std::unique_lock<std::mutex>(*c->enc_gate);
+      rc = encode_dev_impl(c, d_in + s0, &b, &pp, spf, (uint8_t*)c->out.p, out_cap, pos, nullptr);
+      if (rc == X3_OK) rc = x3_encode_result(c, &end, st);
+    }
+    if (rc != X3_OK) break;
+    if (stats)
+      for (int i = 0; i < 6; ++i) stats[i] += st[i];
+    if (end > pos) down.push({pos, end});
+    pos = end;
+  }
+  up.halt();
+  down.close();
+  uploader.join();
+  downloader.join();
+  if (halted) HIPCHK(c, up_err);
+  if (rc == X3_ERR_BYTE_WRITER_INSUFFICIENT_MEMORY) {
+    // the position that WOULD have been reached is part of the contract (include/x3hip.h): the sizes of all frames,
+    // in one piece (an error path; nobody times it)
+    if (stats) std::memset(stats, 0, 6 * sizeof(uint64_t));
+    return encode_host(c, &wav, n, 1, p, spf, out, out_cap, start_pos, out_pos, nullptr, stats);
+  }
+  if (out_pos) *out_pos = pos;
+  if (rc) return rc;
+  HIPCHK(c, dl_err);
+  return X3_OK;
+}
+
 extern "C" int x3_encode(x3_ctx* c, const int16_t* wav, uint64_t n, uint32_t n_channels, const x3_params* p,
                          uint8_t* out, uint64_t out_cap, uint64_t start_pos, uint64_t* out_pos, uint64_t stats[6]) {
   if (!c || !p || (!wav && n) || (!out && out_cap)) return X3_ERR_BAD_ARG;
@@ -1178,6 +1324,13 @@ extern "C" int x3_encode(x3_ctx* c, const int16_t* wav, uint64_t n, uint32_t n_c
   if (rc == X3_ERR_BAD_ARG) return rc;
   const uint64_t spf = spf_of(p);
   if (spf == 0 || n == 0) return X3_OK;  // take(0) / empty iterator: nothing is written (encoder.rs:67-73)
+  if (c->opt.host_chunk_frames >= 0) {
+    // chunks of whole frames, a multiple of eight of them (16-byte aligned chunk starts on the device)
+    uint64_t frames = c->opt.host_chunk_frames ? (uint64_t)c->opt.host_chunk_frames : (16ull << 20) / spf;
+    frames = std::max<uint64_t>(8, (frames + 7) & ~7ull);
+    if (frames <= (~0ull >> 1) / spf && n / spf >= 2 * frames)
+      return encode_host_chunked(c, wav, n, p, spf, frames * spf, out, out_cap, start_pos, out_pos, stats);
+  }
   return encode_host(c, &wav, n, 1, p, spf, out, out_cap, start_pos, out_pos, nullptr, stats);
 }
 
@@ -1612,26 +1765,43 @@ static void walk_host(const uint8_t* buf, uint64_t buf_len, uint64_t real_total,
 // samples in front of the first frame that fails.  *first_bad == F: all of them decoded.
 static int decode_frames_host(x3_ctx* c, const uint8_t* x3, uint64_t len, const HostWalk& w, const x3_params* p,
                               int16_t* wav, uint64_t wav_cap, uint64_t* before, uint64_t* first_bad, int* bad_status,
-                              bool download = true) {  // !download: the samples stay in c->out (x3_mgpu_decode_stream)
+                              bool download = true,  // !download: the samples stay in c->out (x3_mgpu_decode_stream)
+                              const uint8_t* d_x3 = nullptr) {  // the frames' bytes are on the device already
   const uint64_t F = w.offs.size();
   *before = 0;
   *first_bad = 0;
   *bad_status = 0;
   if (F == 0) return X3_OK;
   int rc;
-  if ((rc = ensure(c, c->in, len + 16))) return rc;
+  if (!d_x3) {
+    if ((rc = ensure(c, c->in, len + 16))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->in.p, x3, len, hipMemcpyHostToDevice, c->stream));
+    d_x3 = (const uint8_t*)c->in.p;
+  }
   if ((rc = ensure(c, c->frame_off, (F + 1) * sizeof(uint64_t)))) return rc;
   if ((rc = ensure(c, c->wav_off, F * sizeof(uint64_t)))) return rc;
   if ((rc = ensure(c, c->out, (w.nsamp + 65536) * sizeof(int16_t)))) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->in.p, x3, len, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->frame_off.p, w.offs.data(), F * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->wav_off.p, w.woffs.data(), F * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  // (through pinned memory: a copy from pageable memory is staged by the runtime under a lock it shares with the large
+  // pageable copies the chunked front ends have in flight on other threads -- 0.2-0.4 ms per call when they collide)
+  if (c->h_walk_cap < 2 * F * sizeof(uint64_t)) {
+    if (c->h_walk) HIPCHK(c, hipHostFree(c->h_walk));
+    c->h_walk = nullptr;
+    c->h_walk_cap = 0;
+    const size_t want = (2 * F * sizeof(uint64_t) * 5 / 4 + 4095) & ~(size_t)4095;
+    HIPCHK(c, hipHostMalloc(&c->h_walk, want));
+    c->h_walk_cap = want;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // (the copy before this one has left the pinned block)
+  std::memcpy(c->h_walk, w.offs.data(), F * sizeof(uint64_t));
+  std::memcpy((uint64_t*)c->h_walk + F, w.woffs.data(), F * sizeof(uint64_t));
+  HIPCHK(c, hipMemcpyAsync(c->frame_off.p, c->h_walk, F * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->wav_off.p, (uint64_t*)c->h_walk + F, F * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
   x3_params pp = *p;
   if (pp.block_len == 0) pp.block_len = 1;  // frames that need block_len were routed to BAD_ARG by the walk
   const uint64_t dev_wav_cap = std::min<uint64_t>(wav_cap, w.nsamp + 65535);
   bool aligned = true;
   for (uint64_t v : w.woffs) aligned = aligned && (v & 7ull) == 0;
-  if ((rc = decode_dev_impl(c, (const uint8_t*)c->in.p, len, (const uint64_t*)c->frame_off.p, F, nullptr,
+  if ((rc = decode_dev_impl(c, d_x3, len, (const uint64_t*)c->frame_off.p, F, nullptr,
                             (const uint64_t*)c->wav_off.p, &pp, (int16_t*)c->out.p, dev_wav_cap, nullptr, aligned,
                             p->block_len == 0)))
     return rc;
@@ -1654,6 +1824,124 @@ static int walk_result(uint64_t F, uint64_t first_bad, int bad_status, int termi
   return terminal;
 }
 
+// x3_decode_stream on a LONG stream in host memory, in chunks of whole frames (the file pipeline's scheme in one
+// context).  The samples are 79 % of the bytes this entry point moves (config 3) and the link carries both directions at
+// once, so: one host thread walks the headers of chunk i+2 (decodefile.rs:105-121, one dependent cache miss per frame)
+// and sends its bytes up, this one decodes chunk i+1 (a launch of a few thousand frames lasts as long as one group of 64
+// does: 0.6 ms, whatever the GPU could do beside it), a third brings the samples of chunk i down.  Two device buffers
+// take turns on either side of the decoder.
+static int decode_stream_host_chunked(x3_ctx* c, const uint8_t* x3, uint64_t len, uint64_t phantom, const x3_params* p,
+                                      uint64_t chunk_samples, bool grow, int16_t* wav, uint64_t wav_cap, uint64_t* n_out,
+                                      uint64_t* frames_ok, uint64_t* frame_errors) {
+  int rc = x3_pipe_streams(c);
+  if (rc) return rc;
+  struct Chunk { HostWalk hw; uint64_t a, sample_off; const uint8_t* d_x3; };
+  struct Piece { const void* src; uint64_t sample_off, count; };
+  X3Handoff<Chunk> ready;
+  X3Handoff<Piece> down;
+  X3Progress decoded, landed;
+  hipError_t up_err = hipSuccess, dl_err = hipSuccess;
+  std::thread uploader([&] {
+    hipError_t e = hipSetDevice(c->device);
+    uint64_t a = 0, sample_off = 0;
+    for (uint64_t k = 0; e == hipSuccess; ++k) {
+      Chunk ck;
+      const uint64_t real_total = len - a;
+      // grow: a short first chunk so that the downloads start early, then longer ones (x1.5 up to x8: a chunk's walk and
+      // upload take 0.7 of the time its predecessor's samples need to come down) -- every chunk costs a launch set and a
+      // handful of runtime calls whatever its size, and those calls now and then stall for milliseconds beside the
+      // pageable copies of the other two threads
+      uint64_t budget = chunk_samples;
+      if (grow)
+        for (uint64_t g = 0; g < k && budget < 8 * chunk_samples; ++g) budget += budget >> 1;
+      walk_host(x3 + a, real_total, real_total, real_total + phantom, p, wav_cap - sample_off, budget, &ck.hw);
+      ck.a = a;
+      ck.sample_off = sample_off;
+      ck.d_x3 = nullptr;
+      const bool last = !ck.hw.need_more;
+      if (!ck.hw.offs.empty()) {
+        // this chunk's bytes go where those of chunk k-3 were: not before that chunk has been decoded
+        if (k >= 3 && !decoded.wait_for(k - 2)) break;
+        DevBuf& buf = (k % 3) ? c->in_more[k % 3 - 1] : c->in;
+        if (buf.cap < ck.hw.end_pos + 16) {
+          if (buf.p) e = hipFree(buf.p);
+          buf.p = nullptr;
+          buf.cap = 0;
+          const size_t want = (size_t)((ck.hw.end_pos * (grow ? 2 : 1) + 16 + (ck.hw.end_pos >> 3) + 255) & ~255ull);
+          if (e == hipSuccess) e = hipMalloc(&buf.p, want);
+          if (e == hipSuccess) buf.cap = want;
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(buf.p, x3 + a, ck.hw.end_pos, hipMemcpyHostToDevice, c->ul_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->ul_stream);
+        if (e != hipSuccess) break;
+        ck.d_x3 = static_cast<const uint8_t*>(buf.p);
+      }
+      a += ck.hw.end_pos;
+      sample_off += ck.hw.nsamp;
+      ready.push(std::move(ck));
+      if (last) break;
+    }
+    up_err = e;
+    ready.close();
+  });
+  std::thread downloader([&] {
+    hipError_t e = hipSetDevice(c->device);
+    Piece pc;
+    while (down.pop(&pc)) {
+      if (e == hipSuccess && pc.count) {
+        e = hipMemcpyAsync(wav + pc.sample_off, pc.src, pc.count * sizeof(int16_t), hipMemcpyDeviceToHost, c->dl_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->dl_stream);
+      }
+      landed.advance();
+    }
+    dl_err = e;
+  });
+  uint64_t total = 0, frames = 0, ferr = 0, k = 0;
+  int result = X3_OK;
+  bool ended = false;
+  Chunk ck;
+  while (!ended && ready.pop(&ck)) {
+    const uint64_t F = ck.hw.offs.size();
+    uint64_t before = 0, first_bad = 0;
+    int bad_status = 0;
+    if (F) {
+      // the buffer this chunk decodes into was the source of the download three chunks back
+      if (k >= 3) landed.wait_for(k - 2);
+      DevBuf* turn = (k % 3) ? &c->out_more[k % 3 - 1] : nullptr;
+      if (turn) std::swap(c->out, *turn);
+      if (grow && c->out.cap < (ck.hw.nsamp + 65536) * sizeof(int16_t))  // (room for the longer chunks that follow)
+        rc = ensure(c, c->out, (2 * ck.hw.nsamp + 65536) * sizeof(int16_t));
+      if (rc == X3_OK)
+        rc = decode_frames_host(c, nullptr, ck.hw.end_pos, ck.hw, p, nullptr, wav_cap - ck.sample_off, &before, &first_bad,
+                                &bad_status, false, ck.d_x3);
+      const void* src = c->out.p;
+      if (turn) std::swap(c->out, *turn);
+      if (rc) break;
+      down.push({src, ck.sample_off, before});
+      decoded.advance();
+      ++k;
+    }
+    uint64_t fe = 0;
+    result = walk_result(F, first_bad, bad_status, ck.hw.need_more ? X3_OK : ck.hw.terminal, &fe);
+    ferr += fe;
+    frames += first_bad < F ? first_bad : F;
+    total = ck.sample_off + before;
+    ended = first_bad < F || !ck.hw.need_more;
+  }
+  decoded.halt();  // (an uploader that waits for a decode that will not come)
+  while (ready.pop(&ck)) {}
+  down.close();
+  uploader.join();
+  downloader.join();
+  if (rc) return rc;
+  if (!ended) HIPCHK(c, up_err);
+  HIPCHK(c, dl_err);
+  if (n_out) *n_out = total;
+  if (frames_ok) *frames_ok = frames;
+  if (frame_errors) *frame_errors = ferr;
+  return result;
+}
+
 // `phantom`: bytes the reader BELIEVES remain beyond the real data; a read that runs past the real end is
 // X3Error::Io.
 static int decode_stream_impl(x3_ctx* c, const uint8_t* x3, uint64_t len, uint64_t phantom, const x3_params* p,
@@ -1669,6 +1957,14 @@ static int decode_stream_impl(x3_ctx* c, const uint8_t* x3, uint64_t len, uint64
   // other way round.  Option "host_walk" = 0/1 forces one or the other (tests run both).
   bool gpu_walk = len >= (4u << 20);
   if (c->opt.host_walk >= 0) gpu_walk = c->opt.host_walk == 0;
+  // long streams in chunks, downloads beside uploads (unless a test pins the walk to the GPU)
+  if (c->opt.host_walk != 0 && c->opt.host_chunk_frames >= 0 && len > 20 &&
+      (c->opt.host_chunk_frames > 0 || len >= (16u << 20))) {
+    const uint64_t spf = std::max<uint64_t>(spf_of(p), 1);
+    const uint64_t chunk = c->opt.host_chunk_frames > 0 ? (uint64_t)c->opt.host_chunk_frames * spf : 16ull << 20;
+    return decode_stream_host_chunked(c, x3, len, phantom, p, std::max<uint64_t>(chunk, 1), c->opt.host_chunk_frames == 0, wav,
+                                      wav_cap, n_out, frames_ok, frame_errors);
+  }
   if (gpu_walk && len > 0) {
     int rc = ensure(c, c->in, len + 16);
     if (rc) return rc;
