@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <system_error>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -1226,6 +1227,7 @@ struct X3Progress {
     return n >= want;
   }
 };
+#define X3_PIPE_UNAVAILABLE (-1000)  // (internal) the chunked front end could not start its threads
 static int x3_pipe_streams(x3_ctx* c) {
   if (!c->dl_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->dl_stream, hipStreamNonBlocking));
   if (!c->ul_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->ul_stream, hipStreamNonBlocking));
@@ -1256,7 +1258,9 @@ static int encode_host_chunked(x3_ctx* c, const int16_t* wav, uint64_t n, const 
   X3Progress up;
   hipError_t up_err = hipSuccess, dl_err = hipSuccess;
   int16_t* d_in = (int16_t*)c->in.p;
-  std::thread uploader([&] {
+  std::thread uploader, downloader;
+  try {
+  uploader = std::thread([&] {
     hipError_t e = hipSetDevice(c->device);
     for (uint64_t s0 = 0; s0 < n && e == hipSuccess; s0 += chunk) {
       { std::lock_guard<std::mutex> g(up.mu); if (up.stop) return; }
@@ -1266,7 +1270,7 @@ static int encode_host_chunked(x3_ctx* c, const int16_t* wav, uint64_t n, const 
     }
     if (e != hipSuccess) { up_err = e; up.halt(); }
   });
-  std::thread downloader([&] {
+  downloader = std::thread([&] {
     hipError_t e = hipSetDevice(c->device);
     Piece pc;
     while (down.pop(&pc)) {
@@ -1276,6 +1280,12 @@ static int encode_host_chunked(x3_ctx* c, const int16_t* wav, uint64_t n, const 
     }
     dl_err = e;
   });
+  } catch (const std::system_error&) {  // no thread to be had: the call goes through in one piece
+    up.halt();
+    down.close();
+    if (uploader.joinable()) uploader.join();
+    return encode_host(c, &wav, n, 1, p, spf, out, out_cap, start_pos, out_pos, nullptr, stats);
+  }
   x3_params pp = *p;
   uint64_t pos = start_pos, k = 0;
   bool halted = false;
@@ -1841,10 +1851,13 @@ static int decode_stream_host_chunked(x3_ctx* c, const uint8_t* x3, uint64_t len
   X3Handoff<Piece> down;
   X3Progress decoded, landed;
   hipError_t up_err = hipSuccess, dl_err = hipSuccess;
-  std::thread uploader([&] {
+  std::thread uploader, downloader;
+  try {
+  uploader = std::thread([&] {
     hipError_t e = hipSetDevice(c->device);
     uint64_t a = 0, sample_off = 0;
     for (uint64_t k = 0; e == hipSuccess; ++k) {
+      { std::lock_guard<std::mutex> g(decoded.mu); if (decoded.stop) break; }
       Chunk ck;
       const uint64_t real_total = len - a;
       // grow: a short first chunk so that the downloads start early, then longer ones (x1.5 up to x8: a chunk's walk and
@@ -1884,7 +1897,7 @@ static int decode_stream_host_chunked(x3_ctx* c, const uint8_t* x3, uint64_t len
     up_err = e;
     ready.close();
   });
-  std::thread downloader([&] {
+  downloader = std::thread([&] {
     hipError_t e = hipSetDevice(c->device);
     Piece pc;
     while (down.pop(&pc)) {
@@ -1896,6 +1909,11 @@ static int decode_stream_host_chunked(x3_ctx* c, const uint8_t* x3, uint64_t len
     }
     dl_err = e;
   });
+  } catch (const std::system_error&) {  // no thread to be had: the caller takes the stream in one piece
+    decoded.halt();
+    if (uploader.joinable()) uploader.join();
+    return X3_PIPE_UNAVAILABLE;
+  }
   uint64_t total = 0, frames = 0, ferr = 0, k = 0;
   int result = X3_OK;
   bool ended = false;
@@ -1962,8 +1980,9 @@ static int decode_stream_impl(x3_ctx* c, const uint8_t* x3, uint64_t len, uint64
       (c->opt.host_chunk_frames > 0 || len >= (16u << 20))) {
     const uint64_t spf = std::max<uint64_t>(spf_of(p), 1);
     const uint64_t chunk = c->opt.host_chunk_frames > 0 ? (uint64_t)c->opt.host_chunk_frames * spf : 16ull << 20;
-    return decode_stream_host_chunked(c, x3, len, phantom, p, std::max<uint64_t>(chunk, 1), c->opt.host_chunk_frames == 0, wav,
-                                      wav_cap, n_out, frames_ok, frame_errors);
+    const int rc = decode_stream_host_chunked(c, x3, len, phantom, p, std::max<uint64_t>(chunk, 1), c->opt.host_chunk_frames == 0,
+                                              wav, wav_cap, n_out, frames_ok, frame_errors);
+    if (rc != X3_PIPE_UNAVAILABLE) return rc;
   }
   if (gpu_walk && len > 0) {
     int rc = ensure(c, c->in, len + 16);
