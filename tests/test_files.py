@@ -235,6 +235,9 @@ def test_broken_archives_match_oracle(ctx, tmp_path, chunk_frames, workers):
     cases["tail_short"] = good + bytes(13)
     cases["header_only"] = good[: offs[0]]
     cases["header_cut"] = good[:100]
+    cases["empty_file"] = b""                  # (soak seed 44: the archive id's read_exact fails -- Io, not a null-pointer BAD_ARG)
+    cases["cut_in_archive_id"] = good[:5]
+    cases["cut_in_archive_header"] = good[:20]
     b = bytearray(good); b[offs[3] + 4] = 0; b[offs[3] + 5] = 0; _refresh(b, offs[3]); cases["zero_samples"] = b
     b = bytearray(good); b[40] ^= 1; cases["xml_crc"] = b  # XML payload CRC is not checked by the reader
     with _opt(ctx, file_chunk_frames=chunk_frames, file_workers=workers):

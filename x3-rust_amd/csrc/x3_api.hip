@@ -1605,20 +1605,25 @@ static int index_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t len, uint64_t
                        keys, vals, tsize - 1);
     hipLaunchKernelGGL(x3_index_succ_kernel, dim3(cg), dim3(256), 0, c->stream, (const X3Cand*)cand, n_cand,
                        (const unsigned long long*)keys, (const uint32_t*)vals, tsize - 1, J, S, L);
-    for (uint32_t r = 1; r < levels; ++r)
+    uint32_t r = 1;
+    for (; r + 4 <= levels; r += 4)  // four levels a launch
+      hipLaunchKernelGGL(x3_index_double4_kernel, dim3(cg), dim3(256), 0, c->stream, n_cand,
+                         (const uint32_t*)(J + (size_t)(r - 1) * n_cand),
+                         (const unsigned long long*)(S + (size_t)(r - 1) * n_cand),
+                         (const uint32_t*)(L + (size_t)(r - 1) * n_cand), J + (size_t)r * n_cand,
+                         S + (size_t)r * n_cand, L + (size_t)r * n_cand);
+    for (; r < levels; ++r)
       hipLaunchKernelGGL(x3_index_double_kernel, dim3(cg), dim3(256), 0, c->stream, n_cand,
                          (const uint32_t*)(J + (size_t)(r - 1) * n_cand),
                          (const unsigned long long*)(S + (size_t)(r - 1) * n_cand),
                          (const uint32_t*)(L + (size_t)(r - 1) * n_cand), J + (size_t)r * n_cand,
                          S + (size_t)r * n_cand, L + (size_t)r * n_cand);
-    hipLaunchKernelGGL(x3_index_start_kernel, dim3(1), dim3(64), 0, c->stream, (const X3Cand*)cand,
-                       (const unsigned long long*)keys, (const uint32_t*)vals, tsize - 1,
-                       (const uint32_t*)(L + (size_t)(levels - 1) * n_cand), d_sum);
     // start node and chain length stay on the device: the emit grid covers every candidate
     hipLaunchKernelGGL(x3_index_emit_kernel, dim3(cg), dim3(256), 0, c->stream, (const X3Cand*)cand, n_cand, levels,
                        (const uint32_t*)J, (const unsigned long long*)S, (unsigned long long)max_frames,
                        (unsigned long long)wav_cap, (unsigned long long*)d_frame_offsets,
-                       (unsigned long long*)d_wav_offsets, d_sum);
+                       (unsigned long long*)d_wav_offsets, d_sum, (const unsigned long long*)keys, (const uint32_t*)vals,
+                       tsize - 1, (const uint32_t*)(L + (size_t)(levels - 1) * n_cand));
     hipLaunchKernelGGL(x3_index_finalize_kernel, dim3(1), dim3(64), 0, c->stream, xw, len, len + phantom, bl0,
                        (const X3Cand*)cand, (const unsigned long long*)d_wav_offsets, d_sum);
   } else {
@@ -2248,7 +2253,7 @@ static bool parse_u32(const std::string& s, uint32_t* v) {  // Rust's str::parse
 
 extern "C" int x3_archive_header_read(const uint8_t* bytes, uint64_t len, uint32_t* sample_rate, x3_params* p,
                                       uint8_t* channels, uint64_t* header_size) {
-  if (!bytes || !p) return X3_ERR_BAD_ARG;
+  if ((!bytes && len) || !p) return X3_ERR_BAD_ARG;  // (no bytes at all -- an empty file -- is a read that fails: Io)
   if (len < 8) return X3_ERR_IO;  // read_exact fails
   if (std::memcmp(bytes, "X3ARCHIV", 8) != 0) return X3_ERR_ARCHIVE_HEADER_XML_INVALID_KEY;
   if (len < 28) return X3_ERR_IO;

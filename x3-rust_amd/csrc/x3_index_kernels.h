@@ -109,16 +109,30 @@ x3_index_candidates_kernel(const uint32_t* __restrict__ xw, uint64_t len, uint64
   // every workgroup walks ONE contiguous span of the stream (consecutive trips touch consecutive 4 KB)
   const uint64_t per_wg = ((chunks + gridDim.x - 1) / gridDim.x + blockDim.x - 1) / blockDim.x * blockDim.x;
   const uint64_t t_end = (uint64_t)(blockIdx.x + 1) * per_wg < chunks ? (uint64_t)(blockIdx.x + 1) * per_wg : chunks;
-  for (uint64_t t = (uint64_t)blockIdx.x * per_wg + threadIdx.x; t < t_end; t += blockDim.x) {
-    uint32_t w[5];
-    if (4 * t + 4 < n_dw) {  // (all but the stream's last chunk)
+  // (the chunks of the next TWO trips are requested before this trip's is looked at; with one 16-byte load in flight per
+  // lane the kernel took 118 us for config 3's 363 MB, with three it takes 115: 3.2 TB/s either way)
+  auto fetch = [&](uint64_t t, uint32_t (&w)[5]) {
+    if (t >= t_end) {
+#pragma unroll
+      for (int d = 0; d < 5; ++d) w[d] = 0u;
+    } else if (4 * t + 4 < n_dw) {  // (all but the stream's last chunk)
       const uint4 v = reinterpret_cast<const uint4*>(xw)[t];
       w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-      w[4] = xw[4 * t + 4];
+      w[4] = xw[4 * t + 4];  // (taking it from the next lane's chunk by ds_bpermute instead: 125 against 115 us)
     } else {
 #pragma unroll
       for (int d = 0; d < 5; ++d) w[d] = 4 * t + d < n_dw ? xw[4 * t + d] : 0u;
     }
+  };
+  const uint64_t t_first = (uint64_t)blockIdx.x * per_wg + threadIdx.x;
+  uint32_t wa[5], wb[5];
+  fetch(t_first, wa);
+  fetch(t_first + blockDim.x, wb);
+  for (uint64_t t = t_first; t < t_end; t += blockDim.x) {
+    uint32_t w[5];
+#pragma unroll
+    for (int d = 0; d < 5; ++d) { w[d] = wa[d]; wa[d] = wb[d]; }
+    fetch(t + 2 * (uint64_t)blockDim.x, wb);
     // filter: is the key 0x78 0x33 at ANY of the sixteen byte offsets?  Halfword-zero test (x - 0x0001..) & ~x & 0x8000..
     // on the dwords XOR the key, for the even offsets as they are and for the odd ones shifted by a byte.  One chunk
     // in 4 000 passes (random bytes), so the exact per-offset work below is rare.
@@ -231,29 +245,55 @@ x3_index_double_kernel(uint32_t n, const uint32_t* __restrict__ Jp, const unsign
   }
 }
 
-// the start node = the candidate at offset 0, if the walk can step onto it, and the length of its chain
-__global__ void x3_index_start_kernel(const X3Cand* __restrict__ cand, const unsigned long long* __restrict__ keys,
-                                      const uint32_t* __restrict__ vals, uint32_t mask,
-                                      const uint32_t* __restrict__ L_top, X3IndexSummary* __restrict__ sum) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  uint32_t s = x3i_lookup(0ull, keys, vals, mask);
-  if (s != X3I_NONE && (cand[s].plen_kind >> 16) > X3I_LAST_BAD) s = X3I_NONE;
-  sum->start = s;
-  sum->n_chain = s == X3I_NONE ? 0ull : (unsigned long long)L_top[s];
+// 3b. FOUR doubling steps in one launch: levels r .. r+3 from level r-1 alone -- the 2^(r+3)-th successor is the
+// 2^(r-1)-th successor taken sixteen times, and the levels in between fall out on the way (after 2, 4 and 8 steps).
+// Sixteen dependent gathers from L2 are cheaper than three more launches of a kernel that does one.
+__global__ void __launch_bounds__(256)
+x3_index_double4_kernel(uint32_t n, const uint32_t* __restrict__ Jp, const unsigned long long* __restrict__ Sp,
+                        const uint32_t* __restrict__ Lp, uint32_t* __restrict__ J, unsigned long long* __restrict__ S,
+                        uint32_t* __restrict__ L) {  // J/S/L: level r; the three levels behind it follow at strides of n
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t x = Jp[i], lacc = Lp[i];
+  unsigned long long sacc = Sp[i];
+  uint32_t out = 0;
+#pragma unroll
+  for (uint32_t step = 2; step <= 16; ++step) {  // x = the node `step - 1` jumps of 2^(r-1) behind i
+    if (x != X3I_NONE) {
+      sacc += Sp[x];
+      lacc += Lp[x];
+      x = Jp[x];
+    }
+    if ((step & (step - 1u)) == 0u) {  // 2, 4, 8, 16 jumps: levels r, r+1, r+2, r+3
+      J[(size_t)out * n + i] = x;
+      S[(size_t)out * n + i] = sacc;
+      L[(size_t)out * n + i] = lacc;
+      ++out;
+    }
+  }
 }
 
 // 4. frame k = the k-th successor of the start node; its sample offset = the samples of the k nodes before it.
-// levels: J/S arrays of level r start at r*n.  The start node and the chain's length come from the summary
-// (x3_index_start_kernel), so the host does not have to fetch them in between: the grid covers all n candidates.
+// levels: J/S arrays of level r start at r*n.  The start node and the chain's length are looked up here, so the
+// host does not have to fetch them in between: the grid covers all n candidates.
 // A chain longer than max_frames: sum->pad = 1 (the caller's arrays are too small), nothing behind them is written.
 __global__ void __launch_bounds__(256)
 x3_index_emit_kernel(const X3Cand* __restrict__ cand, uint32_t n, uint32_t levels, const uint32_t* __restrict__ J,
                      const unsigned long long* __restrict__ S, unsigned long long max_frames,
                      unsigned long long wav_cap, unsigned long long* __restrict__ frame_off,
-                     unsigned long long* __restrict__ wav_off, X3IndexSummary* __restrict__ sum) {
+                     unsigned long long* __restrict__ wav_off, X3IndexSummary* __restrict__ sum,
+                     const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t mask,
+                     const uint32_t* __restrict__ L_top) {
   const unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t start = sum->start;
-  const unsigned long long n_chain = sum->n_chain;
+  // the start node = the candidate at offset 0, if the walk can step onto it, and the length of its chain: every
+  // thread looks them up for itself (one launch less), thread 0 leaves them in the summary for the last kernel
+  uint32_t start = x3i_lookup(0ull, keys, vals, mask);
+  if (start != X3I_NONE && (cand[start].plen_kind >> 16) > X3I_LAST_BAD) start = X3I_NONE;
+  const unsigned long long n_chain = start == X3I_NONE ? 0ull : (unsigned long long)L_top[start];
+  if (k == 0) {
+    sum->start = start;
+    sum->n_chain = n_chain;
+  }
   if (start == X3I_NONE || k >= n_chain) return;
   if (n_chain > max_frames) {
     if (k == 0) sum->pad = 1;
