@@ -69,7 +69,7 @@ def test_reader_equals_x3a_to_wav_on_good_archives(ctx, window, tmp_path):
 
 
 @pytest.mark.parametrize("window", [2, 4096])
-def test_reader_equals_x3a_to_wav_on_broken_archives(ctx, window):
+def test_reader_equals_x3a_to_wav_on_broken_archives(ctx, window, tmp_path):
     wav = x3hip.synth(2, 77, 0, 150000)
     good = bytearray(bytes(O.x3a_encode(wav, 192000)[1]))
     offs = frame_offsets(good, 320)
@@ -85,6 +85,10 @@ def test_reader_equals_x3a_to_wav_on_broken_archives(ctx, window):
     cases["tail_garbage"] = good + bytes(range(50))
     cases["tail_short"] = good + bytes(13)
     cases["header_only"] = good[: offs[0]]
+    cases["empty"] = b""                       # (soak seed 44: no bytes at all is a read that fails, not a bad argument)
+    cases["cut_in_id"] = good[:5]
+    cases["cut_in_header"] = good[:20]
+    cases["cut_in_xml"] = good[:100]
     b = bytearray(good); b[offs[3] + 4] = 0; b[offs[3] + 5] = 0; refresh(b, offs[3]); cases["zero_samples"] = b
     b = bytearray(good); b[offs[5] + 6] = 0x70; c = O.crc16(bytes(b[offs[5]:offs[5] + 16])); b[offs[5] + 16] = c >> 8; b[offs[5] + 17] = c & 0xFF
     cases["long_payload"] = b
@@ -98,6 +102,11 @@ def test_reader_equals_x3a_to_wav_on_broken_archives(ctx, window):
             assert (rc, ferr) == (ro[0], ro[4]), (name, rc, ferr, ro[0], ro[4])
             assert np.array_equal(got, ro[1]), name
             seen.add(rc)
+            if name in ("empty", "cut_in_id", "cut_in_xml"):   # the same from a file (x3_reader_open)
+                fp = tmp_path / (name + ".x3a")
+                fp.write_bytes(bytes(b))
+                rc2, got2, ferr2, _ = read_like_x3a_to_wav(ctx, str(fp))
+                assert (rc2, ferr2, got2.size) == (rc, ferr, got.size), (name, rc2, rc)
         assert {0, 1, x3hip.ERR_FRAME_HEADER_INVALID_PAYLOAD_CRC, x3hip.ERR_FRAME_HEADER_INVALID_HEADER_CRC} <= seen
     finally:
         ctx.set_option("reader_window_frames", 4096)
