@@ -551,18 +551,26 @@ def main():
         # context first: the verification above kept the host busy for seconds and the GPU's clocks have dropped.)
         step(); step()
         assert ctx.encode_result()[0] == 0 and ctx.decode_result()[:3] == (0, F, 0)
-        c2 = x3hip.Context(local_rank)
-        def step2():
-            assert c2.encode_dev(wav.data_ptr(), n, p, out.data_ptr(), cap, 0, off.data_ptr()) == 0
-            assert c2.decode_dev(out.data_ptr(), cap, off.data_ptr(), F, p, back.data_ptr(), n, n_per_clip=n) == 0
-            c2.sync()
-        back.zero_()
-        dt, kt = timed_steps(c2, step2, 1)
-        assert c2.encode_result()[0] == 0 and c2.decode_result()[:3] == (0, F, 0) and torch.equal(back, wav)
+        # (three fresh contexts, the median one is reported: the step is dominated by the allocator, 1.5 - 4 ms by run)
+        colds = []
+        for _ in range(3):
+            c2 = x3hip.Context(local_rank)
+            def step2():
+                assert c2.encode_dev(wav.data_ptr(), n, p, out.data_ptr(), cap, 0, off.data_ptr()) == 0
+                assert c2.decode_dev(out.data_ptr(), cap, off.data_ptr(), F, p, back.data_ptr(), n, n_per_clip=n) == 0
+                c2.sync()
+            back.zero_()
+            dt, kt = timed_steps(c2, step2, 1)
+            assert c2.encode_result()[0] == 0 and c2.decode_result()[:3] == (0, F, 0) and torch.equal(back, wav)
+            colds.append((dt, kt))
+            c2.close()
+        colds.sort(key=lambda x: x[0])
+        dt, kt = colds[1]
         cold = {"ms_per_step": round(dt * 1e3, 4), "value": round(n / dt / 1e6, 2), "kernels_ms": kt,
-                "note": "first encode+decode of a fresh context (scratch allocation, no launch history) on a GPU that is awake; "
-                        "ms_per_step is host wall time incl. the allocations, kernels_ms the kernels alone"}
-        c2.close()
+                "all_ms_per_step": [round(x[0] * 1e3, 4) for x in colds],
+                "note": "first encode+decode of a fresh context (scratch allocation, no launch history) on a GPU that is awake, "
+                        "the median of three fresh contexts; ms_per_step is host wall time incl. the allocations, kernels_ms "
+                        "the kernels alone"}
         # (b) the round trip when the decoder does not get the encoder's frame index: x3_encode_dev + x3_decode_stream_dev
         def step_walk():
             assert ctx.encode_dev(wav.data_ptr(), n, p, out.data_ptr(), cap, 0, off.data_ptr()) == 0
