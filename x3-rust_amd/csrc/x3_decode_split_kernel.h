@@ -315,6 +315,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     X3_WAVE_LDS_ORDER();
   };
   // every class whose rows have completed a line: k_done = dwords of each row that are staged
+#ifndef X3S_HALF_LINES
 #define X3S_FLUSH_CLASS(c)                                                                                       \
   {                                                                                                              \
     const uint32_t ld = (ph[c] + k_done) >> 5;                                                                   \
@@ -328,6 +329,28 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     const uint32_t tail = ((ph[c] + (S0 >> 1)) & 31u) >> 2; /* pieces of the last, partial line */               \
     if (tail) flush_class(c, f_src[c][0], f_src[c][1], f_dst[c][0], f_dst[c][1], nfl[c], nfl[c] ? 0u : ph[c] >> 2, tail); \
   }
+#else
+  // EXPERIMENT (-DX3S_HALF_LINES; never shipped): the same flush in aligned 64-byte HALF lines, each as soon as it is
+  // complete -- what a group with 128-byte staging rows would do.  nfl counts half lines here.  Bit-exact
+  // (tools/scratch/half_check.py) and 0.94-1.00 ms against 0.67-0.70 on the same box: whole lines are not negotiable
+  // (DESIGN.md section 8).
+#define X3S_FLUSH_CLASS(c)                                                                                       \
+  {                                                                                                              \
+    const uint32_t hd = (ph[c] + k_done) >> 4;                                                                   \
+    if (hd > nfl[c]) {                                                                                           \
+      const uint32_t lo_ = 4u * (nfl[c] & 1u), first_ = ph[c] >> 2;                                              \
+      flush_class(c, f_src[c][0], f_src[c][1], f_dst[c][0], f_dst[c][1], nfl[c] >> 1,                            \
+                  (nfl[c] >> 1) == 0u && first_ > lo_ ? first_ : lo_, lo_ + 4u);                                 \
+      nfl[c] += 1u;                                                                                              \
+    }                                                                                                            \
+  }
+#define X3S_FLUSH_TAILS()                                                                                        \
+  _Pragma("unroll") for (uint32_t c = 0; c < 4; ++c) {                                                           \
+    const uint32_t tail = ((ph[c] + (S0 >> 1)) & 31u) >> 2; /* pieces of the last, partial line */               \
+    const uint32_t tline = (ph[c] + (S0 >> 1)) >> 5;        /* that line's number */                             \
+    if (tail) flush_class(c, f_src[c][0], f_src[c][1], f_dst[c][0], f_dst[c][1], tline, tline ? 0u : ph[c] >> 2, tail); \
+  }
+#endif
 
 
   if (flusher) {
