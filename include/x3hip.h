@@ -106,8 +106,12 @@ const char* x3_last_error(const x3_ctx* ctx);
  *   "stream_wgs" (X3HIP_STREAM_WGS)        workgroups per CU of the single-pass encoder, 0 = derived from occupancy
  *   "decode_single" (X3HIP_DECODE_SINGLE)  1: single-wave decoder kernels only
  *   "host_walk" (X3HIP_HOST_WALK)          frame walk of x3_decode_stream: 1 host, 0 GPU, -1 by stream size
- *   "host_chunk_frames" (X3HIP_HOST_CHUNK_FRAMES)  x3_encode takes a long host buffer in chunks of this many frames, downloads
- *                                           beside uploads: 0 = 32 MiB of samples (inputs from twice that), -1 = one piece
+ *   "host_chunk_frames" (X3HIP_HOST_CHUNK_FRAMES)  x3_encode and x3_decode_stream take a long host buffer in chunks of whole
+ *                                           frames, downloads beside uploads: 0 = on (x3_encode from 32 Mi samples in chunks of
+ *                                           16 Mi; x3_decode_stream from 16 MiB of stream in chunks that grow from 16 Mi to
+ *                                           128 Mi samples), N > 0 = chunks of N frames whatever the length (tests), -1 = one
+ *                                           piece.  A call that goes in chunks starts two helper threads for its duration
+ *                                           (pageable copies hold their caller); the results are the same either way.
  *   "file_chunk_frames" (X3HIP_FILE_CHUNK_FRAMES), "file_workers" (X3HIP_FILE_WORKERS)   x3_wav_to_x3a / x3_x3a_to_wav
  *   "reader_window_frames" (X3HIP_READER_WINDOW_FRAMES)   frames x3_reader decodes ahead per launch set
  *   "stream_v1" (X3HIP_STREAM_V1)          1: the first-generation single-pass encoder kernel
