@@ -440,11 +440,22 @@ int x3_shard_gather(x3_shard* shard, const uint8_t* d_sub, const uint64_t* lengt
 int x3_shard_gather_async(x3_shard* shard, const uint8_t* d_sub, const uint64_t* lengths, int root, uint8_t* d_dst,
                           uint64_t dst_cap, uint64_t* total);
 int x3_shard_gather_wait(x3_shard* shard, int on_stream);
+/* Step 2, SHARDED: no rank takes in the whole stream.  `encodefile::wav_to_x3a` writes one file through one BufWriter
+ * (src/encodefile.rs:66-74); with the frames on N GPUs the equivalent is N writers into ONE file: rank r's sub-stream
+ * goes to byte base + starts[r] (x3_shard_offsets) of `fd` -- every rank passes a descriptor of the same file, `base` =
+ * what precedes the frames (the archive header, x3_archive_header_write).  Starts behind everything enqueued on the
+ * context's stream so far, brings this rank's bytes down over its own host link in 16 MiB pieces (two pinned buffers, a
+ * piece is written while the next one is on its way) and returns when they are in the file (pwrite; no fsync).
+ * X3_ERR_IO when a write fails.  The single-root reassembly above is bound by the root's seven xGMI links whatever N is;
+ * this form scales with the ranks. */
+int x3_shard_write_at(x3_shard* shard, const uint8_t* d_sub, const uint64_t* lengths, int fd, uint64_t base,
+                      uint64_t* total);
 
 /* x3_mgpu: all GPUs from ONE process -- a context, a shard and a host thread per device.  x3_mgpu_encode /
  * x3_mgpu_decode_stream take and return the same host buffers, bytes and status as x3_encode / x3_decode_stream
  * (encoder::encode, src/encoder.rs:51-111; the walk of src/decodefile.rs:105-136): the samples are dealt out by frame
- * ranges, every GPU encodes its range, the lengths are exchanged and the sub-streams gathered on devices[0] as above;
+ * ranges, every GPU encodes its range, the lengths are exchanged and every device copies its sub-stream straight to its
+ * place in the caller's host buffer (no reassembly on one GPU first: the destination is host memory);
  * decoding walks the header chain once, deals the frames out and copies every GPU's samples straight to their place
  * (no collective).  x3_mgpu_ctx / x3_mgpu_shard hand out the per-device objects for device-resident use. */
 typedef struct x3_mgpu x3_mgpu;

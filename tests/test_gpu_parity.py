@@ -867,28 +867,87 @@ def test_wave_encoder_many_generations(x3, nwg, m):
         c.close()
 
 
-def test_wave_encoder_dense_content_reruns(x3):
-    """frames whose payload does not fit the wave encoder's LDS image (more than 9 728 bytes: loud or noisy content) flag
-    the launch; x3_encode_result encodes the call again with the second-generation kernel -- same bytes as the oracle --
-    and the context keeps to that kernel until its streams come out sparse again (twice as many sparse calls in a row
-    every time the wave encoder comes back to dense frames)"""
+def _with_loud_frames(x3, n, loud_frames, seed):
+    """hydrophone-like content of n samples in which the default frames (10 000 samples) listed in loud_frames are
+    full-scale noise: their payloads (~20 KB) do not fit the wave encoder's 9 728-byte LDS image"""
+    wav = x3.synth(x3.SYNTH_HYDROPHONE, seed, 0, n).copy()
+    rng = np.random.default_rng(seed)
+    for f in loud_frames:
+        lo, hi = 10000 * f, min(n, 10000 * (f + 1))
+        wav[lo:hi] = rng.integers(-32768, 32767, hi - lo, dtype=np.int16)
+    return wav
+
+
+@pytest.mark.parametrize("dense", ["none", "one", "three", "half", "all", "last_ragged"])
+def test_wave_encoder_dense_frames_take_the_dense_pass(x3, dense):
+    """Frames whose payload does not fit the wave encoder's LDS image (more than 9 728 bytes: loud or noisy content) are
+    ordinary content to the reference (encoder.rs:289-315).  The wave kernel sizes and places them, the dense pass behind
+    it in the same stream writes them: the stream equals the oracle's whatever the share of such frames, NO call is
+    encoded twice (round 3 re-encoded the whole call for one such frame), and the count of dense frames is exact."""
+    F = 40
+    n = 10000 * F - (3777 if dense == "last_ragged" else 0)
+    loud = {"none": [], "one": [17], "three": [0, 18, 39], "half": list(range(0, F, 2)), "all": list(range(F)),
+            "last_ragged": [5, F - 1]}[dense]
+    wav = _with_loud_frames(x3, n, loud, 7)
+    rc_o, s_o, st_o = O.encode(wav)
+    assert rc_o == 0
+    c = x3.Context(0)
+    try:
+        for start in (0, 321):   # (an odd start position: the pad byte and every frame offset move)
+            rc_o, s_o, st_o = O.encode(wav, start_pos=start)
+            rc, s, st = c.encode(wav, start_pos=start)
+            assert rc == rc_o == 0 and np.array_equal(s, s_o) and st.tolist() == st_o.tolist(), (dense, start)
+            if c.get_option("enc_gen_in_use") == 3:
+                assert c.get_option("last_dense_frames") == len(loud), (dense, c.get_option("last_dense_frames"))
+        assert c.get_option("encode_dense_reruns") == 0 and c.get_option("encode_fallbacks") == 0
+    finally:
+        c.close()
+
+
+def test_wave_encoder_dense_hint_is_only_a_hint(x3):
+    """A call in which more than a quarter of the frames were dense makes the context's NEXT call start on the
+    second-generation kernel (which holds worst-case images); that kernel counts dense frames as well, and below an
+    eighth the wave encoder is back.  Bytes and statistics equal the oracle's throughout, and one loud frame among many
+    never moves the context off the wave encoder."""
     c = x3.Context(0)
     try:
         quiet = x3.synth(x3.SYNTH_HYDROPHONE, 5, 0, 400000)
-        loud = quiet.copy()
-        loud[123456:123456 + 30000] = np.random.default_rng(7).integers(-32768, 32767, 30000, dtype=np.int16)
+        one_loud = _with_loud_frames(x3, 400000, [12], 8)
         white = x3.synth(x3.SYNTH_WHITE, 6, 0, 250000)
-        # (content, dense reruns counted so far): quiet fits; loud is encoded twice and switches the context over; white and
-        # loud keep it there without a second encode; two sparse calls in a row bring the wave encoder back
-        for wav, reruns in ((quiet, 0), (loud, 1), (white, 1), (quiet, 1), (quiet, 1), (quiet, 1), (loud, 2), (loud, 2),
-                            (quiet, 2), (quiet, 2), (quiet, 2), (loud, 3)):
+        # (content, generation expected to serve it)
+        for wav, gen in ((quiet, 3), (one_loud, 3), (one_loud, 3), (white, 3), (white, 2), (quiet, 2), (quiet, 3), (one_loud, 3)):
             rc_o, s_o, st_o = O.encode(wav)
             rc, s, st = c.encode(wav)
             assert rc == rc_o == 0 and np.array_equal(s, s_o) and st.tolist() == st_o.tolist()
-            assert c.get_option("encode_dense_reruns") == reruns, (reruns, c.get_option("encode_dense_reruns"))
-        c.set_option("enc_gen", 3)   # (setting the option starts over)
-        rc, s, st = c.encode(loud)
-        assert rc == 0 and c.get_option("encode_dense_reruns") == 4
+            assert c.get_option("enc_gen_in_use") == gen, (gen, c.get_option("enc_gen_in_use"))
+        assert c.get_option("encode_dense_reruns") == 0 and c.get_option("encode_dense_frames") == 1 + 1 + 25 + 1
+    finally:
+        c.close()
+
+
+def test_dense_frames_stream_is_complete_without_encode_result(x3):
+    """x3_encode_dev followed on the same stream by x3_decode_dev, with x3_encode_result only afterwards: the dense pass
+    is part of the encode's work in the stream, so the decoder finds every frame (with the round-3 rerun inside
+    x3_encode_result a chained consumer met CRC-bad frames)."""
+    import ctypes as C
+    c = x3.Context(0)
+    try:
+        n = 10000 * 64
+        wav = _with_loud_frames(x3, n, [3, 31, 63], 11)
+        p = x3.Params.default()
+        L = x3.lib()
+        F = L.x3_num_frames(n, C.byref(p)); cap = L.x3_encode_bound(n, C.byref(p))
+        d_wav = c.alloc(2 * n); d_out = c.alloc(cap + 16); d_off = c.alloc(8 * (F + 1)); d_back = c.alloc(2 * n)
+        c.upload(d_wav, wav)
+        assert c.encode_dev(d_wav, n, p, d_out, cap, 0, d_off) == 0
+        assert c.decode_dev(d_out, cap, d_off, F, p, d_back, n, n_per_clip=n) == 0
+        rc, pos, st = c.encode_result()
+        assert rc == 0 and c.get_option("last_dense_frames") == 3
+        r = c.decode_result()
+        assert r[:3] == (0, F, 0), r
+        back = c.download(d_back, 2 * n, np.int16)
+        assert np.array_equal(back, wav)
+        for d in (d_wav, d_out, d_off, d_back): c.free(d)
     finally:
         c.close()
 

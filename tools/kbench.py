@@ -14,6 +14,7 @@ ap.add_argument("--kind", type=int, default=2)
 ap.add_argument("--clips", type=int, default=1, help="config-5 style batch: CLIPS clips of SAMPLES/CLIPS samples")
 ap.add_argument("--pad", type=int, default=0, help="allocate PAD KiB first (shifts the addresses of everything behind it)")
 ap.add_argument("--repeat", type=int, default=1, help="re-allocate and re-measure REPEAT times in one process")
+ap.add_argument("--loud", type=float, default=0.0, help="this share of the frames is full-scale noise (frames that do not fit the wave encoder's image)")
 ap.add_argument("--opt", action="append", default=[], help="context option name=value (x3_ctx_set_option), repeatable")
 a = ap.parse_args()
 ctx = x3hip.Context(0)
@@ -29,6 +30,11 @@ F = L.x3_num_frames(npc, C.byref(p)) * a.clips; cap = L.x3_encode_bound(npc, C.b
 def run_once(tag):
     d_wav = ctx.alloc(2 * n); d_out = ctx.alloc(cap + 16); d_off = ctx.alloc(8 * (F + 1)); d_back = ctx.alloc(2 * n)
     ctx.synth_dev(a.kind, 0x58330003, 0, n, d_wav)
+    if a.loud > 0:   # every k-th frame loud
+        k = max(1, int(round(1.0 / a.loud)))
+        for f in range(k // 2, F, k):
+            lo = f * p.spf
+            ctx.synth_dev(1, 0x58330003 + f, lo, min(p.spf, n - lo), d_wav + 2 * lo)
     def step():
         assert ctx.encode_dev(d_wav, npc, p, d_out, cap, 0, d_off, n_clips=a.clips, clip_stride=npc) == 0
         assert ctx.decode_dev(d_out, cap, d_off, F, p, d_back, n, n_per_clip=npc, n_clips=a.clips, clip_stride=npc) == 0
@@ -51,8 +57,8 @@ def run_once(tag):
         ctx.decode_result(); t1 = time.perf_counter()
         print("step wall %.4f ms" % ((t1 - t0) / a.steps * 1e3), end="  ")
     assert rc == 0 and pos2 == pos and (os.environ.get("X3_NOCHECK") or r2[:3] == (0, F, 0)), (rc, pos2, r2)
-    names = ["encode", "decode", "sizes", "scan", "check"]
-    print(" ".join("%s=%.3f" % (names[i], ctx.kernel_time(i)[0] / a.steps) for i in range(5)), "ms; stream B/sample=%.4f" % (pos / n),
+    names = ["encode", "decode", "sizes", "scan", "check", "dense"]
+    print(" ".join("%s=%.3f" % (names[i], ctx.kernel_time(i)[0] / a.steps) for i in range(6)), "gen=%d dense_frames=%d" % (ctx.get_option("enc_gen_in_use"), ctx.get_option("last_dense_frames")), "ms; stream B/sample=%.4f" % (pos / n),
           "; wgs/CU=%d fallbacks=%d" % (ctx.get_option("stream_wgs_in_use"), ctx.get_option("encode_fallbacks")), a.opt, tag,
           "wav=%x out=%x back=%x" % (d_wav, d_out, d_back), flush=True)
     return d_wav, d_out, d_off, d_back

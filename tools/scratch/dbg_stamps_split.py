@@ -59,6 +59,16 @@ print("start spread (us): p50 %.1f p99 %.1f max %.1f ; end (us): p50 %.1f max %.
 key = np.concatenate([cu * 4 + simdP, cu * 4 + simdV])
 u2, c2 = np.unique(key, return_counts=True)
 print("waves per SIMD histogram:", dict(zip(*np.unique(c2, return_counts=True))))
+# parsers per SIMD: how evenly the dispatcher spreads the critical waves of a CU's groups
+u3, c3 = np.unique(cu * 4 + simdP, return_counts=True)
+print("parsers per SIMD histogram (SIMDs that hold at least one):", dict(zip(*np.unique(c3, return_counts=True))))
+for c in sorted(set(cnt)):
+    cus = [x for x in uniq if per[x] == c]
+    hh = {}
+    for x in cus:
+        k = tuple(sorted(int(((cu * 4 + simdP) == x * 4 + s_).sum()) for s_ in range(4)))
+        hh[k] = hh.get(k, 0) + 1
+    print("  CUs with %d groups: parsers on SIMD 0..3 (sorted) -> CUs:" % c, hh)
 print("kernel ms/launches decode:", ctx.kernel_time(1))
 # ---- who is slow?
 xcc = (whereP >> 32).astype(np.int64)

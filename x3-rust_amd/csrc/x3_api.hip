@@ -112,7 +112,7 @@ struct x3_ctx {
   void* h_walk = nullptr;  // frame and sample offsets of a host walk on their way to the device
   size_t h_walk_cap = 0;
   // growable scratch
-  DevBuf in, out, frame_bytes, frame_off, dec_status, dec_cstatus, dec_meta, wav_off, seg_crc, desc;
+  DevBuf in, out, frame_bytes, frame_off, dec_status, dec_cstatus, dec_meta, wav_off, seg_crc, desc, dense_list;
   DevBuf in_more[2], out_more[2];  // x3_decode_stream on a long host buffer: rings of three buffers on either side of the decoder
   DevBuf idx_cand, idx_keys, idx_vals, idx_J, idx_S, idx_L, idx_sum;  // x3_index_dev scratch
   int n_cus = 0;
@@ -126,14 +126,16 @@ struct x3_ctx {
   // are persistent grids whose workgroups wait for each other, so only one of them may be in flight on a device.  A
   // context holds the gate from its launch to the end of x3_encode_result; copies and file I/O stay outside.
   std::mutex* enc_gate = nullptr;
-  bool force_gen2 = false;    // the call is being encoded again because a frame did not fit the wave encoder's image
-  bool last_was_wave = false; // the pending encode was launched on the wave encoder
-  // Dense content (frames that do not fit the wave encoder's image): the context then keeps to the second-generation
-  // kernel until `dense_need` calls in a row have come out sparse again (stream bytes per sample, known at
-  // x3_encode_result); dense_need doubles every time the wave encoder is tried again and meets dense frames again.
-  bool dense_mode = false;
-  int dense_calm = 0, dense_need = 1;
-  unsigned long long encode_dense_reruns = 0;
+  // Dense content.  A frame that does not fit the wave encoder's LDS image (payload > X3_DENSE_PAYLOAD_BYTES) is left
+  // to the dense pass that follows the wave kernel in the same stream (x3_encode_stream2_kernel<true>): no call is ever
+  // encoded twice.  `prefer_gen2` is a speed hint only: a call in which more than a quarter of the frames were dense
+  // (white noise, full-scale music) makes the NEXT call of the context start on the second-generation kernel, which
+  // holds worst-case images and saves such content the wave kernel's analysis pass; that kernel counts dense frames too,
+  // and below an eighth the context is back on the wave encoder.  Bytes are the same either way.
+  bool prefer_gen2 = false;
+  int last_enc_gen = 0;       // which kernel generation served the pending / last encode (3 wave + dense pass, 2, 1; 0 two-pass)
+  unsigned long long encode_dense_frames = 0;   // frames handed to the dense pass so far (read-only option)
+  unsigned long long last_dense_frames = 0;     // of the last call (either generation counts them)
   struct {
     const int16_t* d_wav; x3_batch b; x3_params p; uint64_t spf; uint8_t* d_out; uint64_t out_cap, start_pos; uint64_t* d_off;
   } last_enc;
@@ -141,7 +143,7 @@ struct x3_ctx {
   uint64_t dec_frames = 0;
   // kernel timing
   bool timing = false;
-  KernelTimer timers[5];
+  KernelTimer timers[6];   // encode, decode, sizes, scan, check, dense pass
 };
 
 #define HIPCHK(ctx, call)                                                                       \
@@ -464,7 +466,7 @@ extern "C" int x3_ctx_set_option(x3_ctx* c, const char* name, long long value) {
   else if (n == "stream_wgs") { c->opt.stream_wgs = (int)std::max(0ll, value); c->stream_wg_per_cu = -1; }
   else if (n == "decode_single") c->opt.decode_single = value != 0;
   else if (n == "stream_v1") { c->opt.stream_v1 = value != 0; c->stream_wg_per_cu = -1; }
-  else if (n == "enc_gen") { c->opt.enc_gen = value == 2 ? 2 : 3; c->dense_mode = false; c->dense_calm = 0; c->dense_need = 1; }
+  else if (n == "enc_gen") { c->opt.enc_gen = value == 2 ? 2 : 3; c->prefer_gen2 = false; }
   else if (n == "wave_nwg") c->opt.wave_nwg = (int)std::max(0ll, std::min(256ll, value));
   else if (n == "wave_m") c->opt.wave_m = (int)std::max(0ll, std::min(16ll, value));
   else if (n == "wave_drop") c->opt.wave_drop = value;
@@ -489,7 +491,10 @@ extern "C" int x3_ctx_get_option(const x3_ctx* c, const char* name, long long* v
   else if (n == "decode_single") *value = c->opt.decode_single;
   else if (n == "stream_v1") *value = c->opt.stream_v1;
   else if (n == "enc_gen") *value = c->opt.enc_gen;
-  else if (n == "encode_dense_reruns") *value = (long long)c->encode_dense_reruns;  // read-only counter
+  else if (n == "encode_dense_reruns") *value = 0;  // (rounds 2-3: whole calls encoded again for a dense frame; no longer happens)
+  else if (n == "encode_dense_frames") *value = (long long)c->encode_dense_frames;  // read-only: frames the dense pass has written
+  else if (n == "last_dense_frames") *value = (long long)c->last_dense_frames;      // read-only: of the last call (after x3_encode_result)
+  else if (n == "enc_gen_in_use") *value = c->last_enc_gen;                          // read-only: 3, 2, 1, or 0 = two-pass kernels
   else if (n == "host_walk") *value = c->opt.host_walk;
   else if (n == "host_chunk_frames") *value = c->opt.host_chunk_frames;
   else if (n == "verbose") *value = c->opt.verbose;
@@ -581,7 +586,7 @@ extern "C" int x3_ctx_reset_kernel_time(x3_ctx* c) {
 }
 
 extern "C" int x3_ctx_kernel_time(x3_ctx* c, int which, double* total_ms, uint64_t* launches) {
-  if (!c || which < 0 || which > 4) return X3_ERR_BAD_ARG;
+  if (!c || which < 0 || which > 5) return X3_ERR_BAD_ARG;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   double tot = 0;
   for (auto& e : c->timers[which].used) {
@@ -863,10 +868,13 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
                            (b->n_clips == 1 || (b->clip_stride % 8) == 0) &&
                            (reinterpret_cast<uintptr_t>(d_wav) & 15u) == 0 && !c->force_two_pass && !c->opt.two_pass;
   c->last_enc = {d_wav, *b, *p, spf, d_out, out_cap, start_pos, d_frame_offsets};
-  if (stream_path && !c->opt.stream_v1 && c->opt.enc_gen == 3 && !c->force_gen2 && c->opt.stream_wgs == 0 &&
-      stream_safe_thresholds(p)) {
-    if (c->dense_mode) {
-      // the last launches met frames that do not fit the image: the second generation, until the content is sparse again
+  // part + two worst-case frame images + CRC tables + the multipliers of one chunk size (x3_encode_stream2_kernel.h)
+  const size_t smem2 = X3_ENC_SMEM_HDR + 2 * (size_t)pl.img_dwords * 4 + 2048 + X3_K2_DWORDS * 4;
+  c->last_enc_gen = 0;
+  if (stream_path && !c->opt.stream_v1 && c->opt.enc_gen == 3 && c->opt.stream_wgs == 0 &&
+      stream_safe_thresholds(p) && smem2 <= 160 * 1024) {
+    if (c->prefer_gen2) {
+      // the last call's content was mostly dense: the second generation, until it counts few dense frames again
     } else {
       // third generation (x3_encode_wave_kernel.h): one wave per frame, sixteen waves per CU, one workgroup per CU
       static_assert(X3W_SMEM <= 160 * 1024, "LDS");
@@ -897,6 +905,8 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
       wa.desc = (uint32_t*)c->desc.p + X3W_DESC_PAD;
       wa.ctl = reinterpret_cast<unsigned char*>(c->d_status);
       wa.tabs = c->d_wtab;
+      if ((rc = ensure(c, c->dense_list, F * sizeof(uint32_t)))) return rc;
+      wa.dense_list = (uint32_t*)c->dense_list.p;
       wa.out_cap = out_cap;
       wa.start_pos = start_pos;
       wa.n_per_clip = pl.g.n_per_clip;
@@ -914,8 +924,23 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
         TimerScope ts(c, 0, nullptr, true);
         X3_LAUNCH_TIMED(ts, x3_encode_wave_kernel, dim3(wa.nwg), dim3(X3W_THREADS), X3W_SMEM, c->stream, wa);
       }
+      {
+        // The dense pass, always: the frames the wave kernel listed (none, in most recordings: the workgroups read a zero
+        // count and leave, ~2 us of queue) written at the offsets it assigned.  In the stream, not in x3_encode_result:
+        // whatever the caller enqueues behind this call -- x3_decode_dev, a copy -- finds the whole stream.
+        if (smem2 > 64 * 1024)
+          HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_stream2_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
+        const uint64_t per_cu = std::max<uint64_t>(1, (160 * 1024) / (smem2 + 256));
+        const uint64_t grid = std::min<uint64_t>(F, (uint64_t)c->n_cus * std::min<uint64_t>(per_cu, 3));
+        TimerScope ts(c, 5, nullptr, true);
+        X3_LAUNCH_TIMED(ts, x3_encode_stream2_kernel<true>, dim3((unsigned)grid), dim3(X3_STREAM2_THREADS), smem2, c->stream,
+                        d_wav, pl.g, pl.dp, d_off, d_out, out_cap, start_pos, (uint32_t*)nullptr, 0u,
+                        reinterpret_cast<unsigned char*>(c->d_status), (const uint32_t*)c->d_xk2,
+                        (const uint16_t*)c->d_crctab, pl.img_dwords, (uint32_t*)nullptr, (const uint32_t*)c->dense_list.p);
+      }
       HIPCHK(c, hipGetLastError());
-      c->last_was_wave = true;
+      c->last_enc_gen = 3;
       c->encode_pending = true;
       c->enc_start_pos = start_pos;
       return X3_OK;
@@ -923,19 +948,17 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
   }
   if (stream_path && !c->opt.stream_v1 && stream_safe_thresholds(p)) {
     // second generation (x3_encode_stream2_kernel.h): eight waves, no sample tile in LDS
-    // part + two frame images + CRC tables + the multipliers of one chunk size
-    const size_t smem2 = X3_ENC_SMEM_HDR + 2 * (size_t)pl.img_dwords * 4 + 2048 + X3_K2_DWORDS * 4;
     if (c->stream_wg_per_cu < 0) {
       // Offsets wait on the other workgroups' frame sizes, so EVERY workgroup of the grid must be resident.  The
       // occupancy API can over-report by one block per CU (MI355X_MICROARCH.md, "Residency"), so it is capped
       // by the kernel's own register/LDS footprint: eight waves are two per SIMD, whatever the placement.
       if (smem2 > 64 * 1024)
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_stream2_kernel),
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_stream2_kernel<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
       int nb = 0;
-      HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, x3_encode_stream2_kernel, X3_STREAM2_THREADS, smem2));
+      HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, x3_encode_stream2_kernel<false>, X3_STREAM2_THREADS, smem2));
       hipFuncAttributes fa;
-      HIPCHK(c, hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&x3_encode_stream2_kernel)));
+      HIPCHK(c, hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&x3_encode_stream2_kernel<false>)));
       const int alloc = ((fa.numRegs + 7) / 8) * 8;
       const int wps = std::min(8, 512 / std::max(alloc, 8));
       const int by_regs = (4 * wps) / 8;
@@ -963,12 +986,13 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
       }
       {
         TimerScope ts(c, 0);
-        hipLaunchKernelGGL(x3_encode_stream2_kernel, dim3((unsigned)grid), dim3(X3_STREAM2_THREADS), smem2, c->stream,
+        hipLaunchKernelGGL(x3_encode_stream2_kernel<false>, dim3((unsigned)grid), dim3(X3_STREAM2_THREADS), smem2, c->stream,
                            d_wav, pl.g, pl.dp, d_off, d_out, out_cap, start_pos, (uint32_t*)c->desc.p + desc_pad, c->desc_epoch,
                            reinterpret_cast<unsigned char*>(c->d_status), (const uint32_t*)c->d_xk2,
-                           (const uint16_t*)c->d_crctab, pl.img_dwords, c->d_pace + 4);
+                           (const uint16_t*)c->d_crctab, pl.img_dwords, c->d_pace + 4, (const uint32_t*)nullptr);
       }
       HIPCHK(c, hipGetLastError());
+      c->last_enc_gen = 2;
       c->encode_pending = true;
       c->enc_start_pos = start_pos;
       return X3_OK;
@@ -1024,6 +1048,7 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
                            (const uint16_t*)c->d_crctab, pl.lds_in_bytes, pl.img_dwords);
       }
       HIPCHK(c, hipGetLastError());
+      c->last_enc_gen = 1;
       c->encode_pending = true;
       c->enc_start_pos = start_pos;
       return X3_OK;
@@ -1079,24 +1104,19 @@ extern "C" int x3_encode_result(x3_ctx* c, uint64_t* out_pos, uint64_t stats[6])
   HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_status, 128, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->encode_pending = false;
-  if (c->last_was_wave && c->h_status[1] == 0 && c->dense_need > 1) --c->dense_need;  // content that fits: the back-off relaxes
-  const bool was_wave = c->last_was_wave;
-  c->last_was_wave = false;
-  if (c->h_status[1] == X3D_IMAGE_OVERFLOW) {
-    // a frame of this call did not fit the wave encoder's LDS image (dense content: more than 9 728 payload bytes):
-    // the call is encoded again by the second-generation kernel, which holds worst-case images
-    ++c->encode_dense_reruns;
-    c->dense_mode = true;
-    c->dense_calm = 0;
-    c->dense_need = std::min(1 << 20, c->dense_need * 2);
-    c->force_gen2 = true;
-    auto a = c->last_enc;
-    int rc = encode_dev_impl(c, a.d_wav, &a.b, &a.p, a.spf, a.d_out, a.out_cap, a.start_pos, a.d_off);
-    c->force_gen2 = false;
-    if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_status, 128, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->encode_pending = false;
+  if (c->h_status[1] != X3D_SIZE_WAIT_TIMEOUT && (c->last_enc_gen == 3 || c->last_enc_gen == 2)) {
+    // how dense the call's content was (both single-pass generations count the frames beyond the wave encoder's image):
+    // the hint for the context's next call, nothing else
+    uint32_t dense;
+    std::memcpy(&dense, reinterpret_cast<const unsigned char*>(c->h_status) + X3_CTL_DENSE_COUNT, sizeof dense);
+    const uint64_t frames = ((c->last_enc.b.n_per_clip + c->last_enc.spf - 1) / c->last_enc.spf) * c->last_enc.b.n_clips;
+    c->last_dense_frames = dense;
+    if (c->last_enc_gen == 3) {
+      c->encode_dense_frames += dense;
+      if ((uint64_t)dense * 4u > frames) c->prefer_gen2 = true;
+    } else if (c->prefer_gen2 && (uint64_t)dense * 8u <= frames) {
+      c->prefer_gen2 = false;
+    }
   }
   if (c->h_status[1] == X3D_SIZE_WAIT_TIMEOUT) {
     if (c->opt.verbose)
@@ -1119,18 +1139,7 @@ extern "C" int x3_encode_result(x3_ctx* c, uint64_t* out_pos, uint64_t stats[6])
   if (out_pos) *out_pos = c->h_stats[6];
   if (stats)
     for (int i = 0; i < 6; ++i) stats[i] = c->h_stats[i];
-  int st = std::max(c->h_status[0], c->h_status[1]);
-  if (c->dense_mode && !was_wave && st == 0) {
-    // sparse again?  (0.6 stream bytes per sample: a default frame of 6 000 bytes, the image holds 9 728)
-    const unsigned long long samples = c->last_enc.b.n_per_clip * c->last_enc.b.n_clips;
-    const unsigned long long bytes = c->h_stats[6] - c->last_enc.start_pos;
-    if (samples && bytes * 10ull < samples * 6ull) {
-      if (++c->dense_calm >= c->dense_need) c->dense_mode = false;
-    } else {
-      c->dense_calm = 0;
-    }
-  }
-  return st;
+  return std::max(c->h_status[0], c->h_status[1]);
 }
 
 // host-buffer front end shared by x3_encode / x3_encode_frame / x3_encode_batch

@@ -53,6 +53,9 @@
 #ifndef X3S_AHEAD
 #define X3S_AHEAD 3u          // 16-byte chunks per lane requested one service ahead (of up to 6 per service)
 #endif
+#ifndef X3S_VALUER_FOLD
+#define X3S_VALUER_FOLD 0
+#endif
 #define X3S_XROWS 11u          // transfer rows per block buffer: 10 pair dwords + the header word
 #define X3S_WAVES 3u            // parser, valuer, flusher
 
@@ -76,14 +79,50 @@ __device__ __forceinline__ uint32_t x3s_half_index(uint32_t j, uint32_t lane) {
 #define X3S_PACE_BAND 6            // blocks ahead / behind that move a wave one priority level
 #define X3S_PACE_DEFAULT 2000u     // 10 ns ticks per 16 blocks when there is no launch to go by (1.25 us per block)
 #define X3S_PACE_EPOCH_SHIFT 20u   // pace word: epoch << 20 | ticks per 16 blocks
-#define X3S_PACE_STEP(b)                                                                       \
-  if (!X3S_PACE_OFF && ((b) & 7u) == 0u) {                                                                      \
+// Priorities by ROLE (round 4).  The SIMD arbitrates by priority, then age (MI355X_MICROARCH.md, "Two waves per SIMD"):
+// with all three waves of a group paced over the same four levels the critical wave -- the parser, whose dependent
+// chain sets the group's time per block -- was never preferred over the valuer or flusher of another group on its SIMD.
+// X3S_PRIO_MODE: 0 = round 3 (every role 0..3 by pace); 1 = parser {2,3}, valuer / flusher {0,1}; 2 = parser 3,
+// the others 0..2 by pace; 3 = parser {1,2,3}, others {0,1}; 4 = parser 0..3, others one level below;
+// 5 = no pacing: parser 3, valuer 1, flusher 0; 6 = parser {2,3}, valuer {1,2}, flusher {0,1}; 7 = round 3 with the
+// groups beyond 1 024 (four per CU) one level up
+#ifndef X3S_PRIO_MODE
+#define X3S_PRIO_MODE 0
+#endif
+#define X3S_ROLE_PARSER 0
+#define X3S_ROLE_VALUER 1
+#define X3S_ROLE_FLUSHER 2
+template <int ROLE>
+__device__ __forceinline__ void x3s_set_priority(int32_t d) {
+  constexpr int B2 = 2 * X3S_PACE_BAND;
+#define X3S_P4(a, b, c, e) { if (d > B2) __builtin_amdgcn_s_setprio(a); else if (d > 0) __builtin_amdgcn_s_setprio(b); else if (d > -B2) __builtin_amdgcn_s_setprio(c); else __builtin_amdgcn_s_setprio(e); }
+#define X3S_P2(a, b) { if (d > 0) __builtin_amdgcn_s_setprio(a); else __builtin_amdgcn_s_setprio(b); }
+#if X3S_PRIO_MODE == 0
+  X3S_P4(0, 1, 2, 3)
+#elif X3S_PRIO_MODE == 1
+  if (ROLE == X3S_ROLE_PARSER) X3S_P2(2, 3) else X3S_P2(0, 1)
+#elif X3S_PRIO_MODE == 2
+  if (ROLE == X3S_ROLE_PARSER) __builtin_amdgcn_s_setprio(3); else X3S_P4(0, 1, 2, 2)
+#elif X3S_PRIO_MODE == 3
+  if (ROLE == X3S_ROLE_PARSER) X3S_P4(1, 2, 2, 3) else X3S_P2(0, 1)
+#elif X3S_PRIO_MODE == 4
+  if (ROLE == X3S_ROLE_PARSER) X3S_P4(0, 1, 2, 3) else X3S_P4(0, 0, 1, 2)
+#elif X3S_PRIO_MODE == 5
+  __builtin_amdgcn_s_setprio(ROLE == X3S_ROLE_PARSER ? 3 : (ROLE == X3S_ROLE_VALUER ? 1 : 0));
+#elif X3S_PRIO_MODE == 6
+  if (ROLE == X3S_ROLE_PARSER) X3S_P2(2, 3) else if (ROLE == X3S_ROLE_VALUER) X3S_P2(1, 2) else X3S_P2(0, 1)
+#elif X3S_PRIO_MODE == 7
+  // the groups beyond four per CU (the fifth group of 56 CUs in config 3) one level up
+  if (blockIdx.x >= 1024u) X3S_P4(1, 2, 3, 3) else X3S_P4(0, 1, 2, 3)
+#endif
+#undef X3S_P4
+#undef X3S_P2
+}
+#define X3S_PACE_STEP(b, ROLE)                                                                 \
+  if (!X3S_PACE_OFF && ((b) & 7u) == 0u) {                                                     \
     const uint32_t el = (uint32_t)(wall_clock64() - pace_t0); /* 10 ns ticks */                \
     const int32_t d = (int32_t)(b) - (int32_t)(((unsigned long long)el * pace_inv) >> 16); /* (64-bit: 80 ms of ticks times the rate pass 2^32) */ \
-    if (d > 2 * X3S_PACE_BAND) __builtin_amdgcn_s_setprio(0);                                  \
-    else if (d > 0) __builtin_amdgcn_s_setprio(1);                                             \
-    else if (d > -2 * X3S_PACE_BAND) __builtin_amdgcn_s_setprio(2);                            \
-    else __builtin_amdgcn_s_setprio(3);                                                        \
+    x3s_set_priority<ROLE>(d);                                                                 \
   }
 
 // LDS barrier of the group's waves: LDS operations retired, nothing else waited for
@@ -360,7 +399,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     X3S_BARRIER();
     uint32_t rem = S0 ? S0 - 1u : 0u, have = 0;
     for (uint32_t b = 0; b < nblk_max; ++b) {
-      X3S_PACE_STEP(b)
+      X3S_PACE_STEP(b, X3S_ROLE_FLUSHER)
       X3_STAMP(0);
       X3S_BARRIER();
       X3_STAMP(4);
@@ -416,7 +455,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
 
     const uint32_t k_tab = (p.k[1] << 16) | (p.k[2] << 24);  // log2(level) by ftype
     for (uint32_t b = 0; b < nblk_max; ++b) {
-      X3S_PACE_STEP(b)
+      X3S_PACE_STEP(b, X3S_ROLE_PARSER)
       const uint32_t cnt = remaining < X3S_BL ? remaining : X3S_BL;
       remaining -= cnt;
       X3_STAMP(0);
@@ -540,7 +579,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     const uint32_t bound_tab = (p.inv_len[0] << 8) | (p.inv_len[1] << 16) | (p.inv_len[2] << 24);  // by ftype (< 256)
     uint32_t posb = pos0;  // ring byte of the block's first pair, unmasked
     for (uint32_t b = 0; b < nblk_max; ++b, posb += 2u * X3S_BL) {
-      X3S_PACE_STEP(b)
+      X3S_PACE_STEP(b, X3S_ROLE_VALUER)
       X3_STAMP(0);
       X3S_BARRIER();
       X3_STAMP(4);
@@ -572,6 +611,40 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
         uint2 XX[5];
 #pragma unroll
         for (uint32_t r = 0; r < 5u; ++r) XX[r] = b2[r * 64u];
+#if X3S_VALUER_FOLD
+        // Round 4: the Rice / BFP choice is in the CONSTANTS, not in a select behind both computations.  A Rice lane's
+        // thresh is 0 (B = X - ((X + 0xFFFF) & 0) = X: the BFP step is the identity there); a BFP lane shifts by 0 and
+        // takes no sign bit (zsh2 = 0: the zigzag step is the identity there).  One instruction per pair less than
+        // R, B and v_bfi -- and the literal select (0.1 % of config 3's blocks) only runs in blocks in which some lane
+        // of the wave HAS a literal block (6 % of them).
+        const uint32_t zsh2 = zmask & 0x00010001u;   // per half: shift and sign-bit mask of the zigzag step
+        auto pairs = [&](auto lit_tag) __attribute__((always_inline)) {
+          constexpr bool LIT = decltype(lit_tag)::value;
+#pragma unroll
+          for (uint32_t r = 0; r < 5u; ++r) {
+            uint32_t W[2];
+#pragma unroll
+            for (uint32_t e = 0; e < 2; ++e) {
+              const uint32_t X = e ? XX[r].y : XX[r].x;
+              maxii2 = x3_pk_max_u16(maxii2, X);   // (Rice: X = i, the index into the inverse table, decoder.rs:186)
+              // BFP: unsigned_to_i16 (decoder.rs:198-207): v - (v > thresh ? 2*thresh : 0), strict compare.
+              // v < 2^E and thresh = 2^(E-1), so bit E of v + thresh - 1 says v > thresh.
+              const uint32_t B = x3_pk_sub_u16(X, x3_pk_add_u16(X, tm12) & neg22);
+              // Rice: the inverse table is a zigzag (x3.rs:200-204)
+              const uint32_t D = x3_pk_lshr_b16(B, zsh2) ^ x3_pk_sub_u16(0u, B & zsh2);   // (d1, d2)
+              // (last + d1, last + d1 + d2), last = the high half of the previous pair: both halves of D plus last,
+              // then d1 once more onto the high half
+              uint32_t P = x3_pk_mad_u16_alo(D, 0x00010000u, x3_pk_add_u16_bhi(D, prevP));
+              if (LIT) P = x3_bfi(litmask, X, P);                          // literal: field = sample
+              W[e] = __builtin_amdgcn_alignbit(P, prevP, 16);                // (pending sample, la)
+              prevP = P;
+            }
+            // samples 20 b + 4 r .. + 3: eight bytes of the ring (positions are multiples of 8: no wrap inside)
+            x3_lds_write_b64(x3_and_or(posb + 8u * r, 248u, orow_b), W[0], W[1]);
+          }
+        };
+        if (__any(litmask != 0u)) pairs(std::true_type{}); else pairs(std::false_type{});
+#else
 #pragma unroll
         for (uint32_t r = 0; r < 5u; ++r) {
           uint32_t W[2];
@@ -595,6 +668,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
           // samples 20 b + 4 r .. + 3: eight bytes of the ring (positions are multiples of 8: no wrap inside)
           x3_lds_write_b64(x3_and_or(posb + 8u * r, 248u, orow_b), W[0], W[1]);
         }
+#endif
       } else {
         // short block somewhere in the group: one sample at a time, staged as halfwords
         const uint16_t* const h = reinterpret_cast<const uint16_t*>(buf);

@@ -136,6 +136,12 @@ __device__ __forceinline__ uint32_t x3_pk_max_u16(uint32_t a, uint32_t b) {
   asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+// packed 16-bit logical shift right, per-half amounts in sh2
+__device__ __forceinline__ uint32_t x3_pk_lshr_b16(uint32_t a, uint32_t sh2) {
+  uint32_t r;
+  asm("v_pk_lshrrev_b16 %0, %1, %2" : "=v"(r) : "v"(sh2), "v"(a));
+  return r;
+}
 __device__ __forceinline__ uint32_t x3_pk_lshr_b16_1(uint32_t a) {
   uint32_t r;
   asm("v_pk_lshrrev_b16 %0, 1, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a));

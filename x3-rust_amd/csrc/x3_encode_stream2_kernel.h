@@ -88,12 +88,27 @@ typedef uint32_t x3_v2u32 __attribute__((ext_vector_type(2)));
 #ifndef X3E_WAVES_PER_SIMD
 #define X3E_WAVES_PER_SIMD 6
 #endif
+// A payload of more than this many bytes does not fit the wave encoder's LDS image (x3_encode_wave_kernel.h: 38 rows of
+// 256 bytes).  The control block's word X3_CTL_DENSE_COUNT counts a call's frames beyond it: the wave encoder leaves
+// them to this kernel's LIST form, and the host reads the count as a hint for the next call (x3_api.hip).
+#define X3_DENSE_PAYLOAD_BYTES 9728u
+#define X3_CTL_DENSE_COUNT 96u   // byte offset in ctl (behind status[8], stats[6], end_pos)
+// LIST = false: the single-pass encoder of a whole call (above).
+// LIST = true (round 4): the DENSE PASS behind x3_encode_wave_kernel -- the frames that kernel could not hold in its
+// image (`dense_list`, their number in the control block) are encoded here, one workgroup per frame with worst-case
+// images, and written at the offsets the wave kernel has already assigned (frame_off[f]: every frame's size comes out
+// of the analysis, whether it is emitted or not).  No size words, no waits, no residency requirement, no pacing; the
+// statistics were counted by the wave kernel.  encoder.rs:289-315 makes no difference between a loud frame and a quiet
+// one, and neither does a call any more: one loud frame costs one workgroup a few microseconds, not a second encode of
+// the whole call (rounds 2-3).
+template <bool LIST>
 __global__ void __launch_bounds__(X3_STREAM2_THREADS, X3E_WAVES_PER_SIMD)
 x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p,
                          uint64_t* __restrict__ frame_off, uint8_t* __restrict__ out, uint64_t out_cap,
                          uint64_t start_pos, uint32_t* __restrict__ desc, uint32_t epoch,
                          unsigned char* __restrict__ ctl, const uint32_t* __restrict__ xk2,
-                         const uint16_t* __restrict__ crc_tab_g, uint32_t img_dwords, uint32_t* __restrict__ pace) {
+                         const uint16_t* __restrict__ crc_tab_g, uint32_t img_dwords, uint32_t* __restrict__ pace,
+                         const uint32_t* __restrict__ dense_list) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* part = reinterpret_cast<uint32_t*>(smem);
   uint32_t* img0 = reinterpret_cast<uint32_t*>(smem + X3_ENC_SMEM_HDR);
@@ -127,8 +142,17 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
       idx = (uint32_t)(t % g.fpc);
     }
   };
-  uint64_t clip_f = blockIdx.x / g.fpc;
-  uint32_t idx_f = (uint32_t)(blockIdx.x - clip_f * g.fpc);
+  uint32_t* const dense_count = reinterpret_cast<uint32_t*>(ctl + X3_CTL_DENSE_COUNT);
+  // LIST: this workgroup takes entries blockIdx.x, blockIdx.x + G, ... of the list
+  const uint32_t n_list = LIST ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*dense_count) : 0u;
+  if (LIST && blockIdx.x >= n_list) return;
+  auto geom_of = [&](uint64_t f_, uint64_t& clip, uint32_t& idx) __attribute__((always_inline)) {
+    clip = f_ / g.fpc;
+    idx = (uint32_t)(f_ - clip * g.fpc);
+  };
+  uint64_t clip_f;
+  uint32_t idx_f;
+  geom_of(LIST ? (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)dense_list[blockIdx.x]) : (uint64_t)blockIdx.x, clip_f, idx_f);
 #ifdef X3_DBG_STAMPS
   unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long dbg_t = clock64();
@@ -177,6 +201,8 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
   bool have_prev = false, first = true;
   uint32_t cur = 0;
   uint32_t ktab_c = 0;  // chunk size whose multipliers are in LDS (0: none yet)
+  uint32_t n_dense = 0;  // thread 0: this workgroup's frames beyond X3_DENSE_PAYLOAD_BYTES (one atomic per workgroup: 69 120
+                         // adds to one address cost a white-noise launch 2 ms)
 
   // The size words in front of frame pf: thread t holds those of frames pf-1-t and pf-513-t (the array has
   // X3_STREAM2_DESC_PAD words in front, so a window that reaches below frame 0 reads padding; range and readiness
@@ -228,6 +254,7 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
   auto resolve = [&]() __attribute__((always_inline)) -> uint64_t {
     const uint4 a = reinterpret_cast<const uint4*>(part + 8)[0], b = reinterpret_cast<const uint4*>(part + 8)[1];
     const uint32_t tot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w));
+    if (LIST) return frame_off[prev_f];  // the wave kernel put every frame's offset there
     const uint64_t off = (first ? base_pos : my_off + my_bytes) + tot;  // (1023 sizes < 2^20 each: < 2^30)
     my_off = off;
     my_bytes = prev_bytes;
@@ -299,11 +326,13 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
     // The controller of x3_decode_split_kernel.h with this kernel's numbers: at its best it achieves ~6 % more than it
     // aims at; met to within 2 % -> aim 4 % faster, to within 4 % -> 1.5 % faster; missed by more than 9 % -> back to 1/16
     // under what was achieved.  (Wider "met" bands settle faster and then overshoot every few launches: tools/pace_trace.py.)
-    const uint32_t wp = (uint32_t)__builtin_amdgcn_readfirstlane((int)pace[0]);
-    const uint32_t wt = (uint32_t)__builtin_amdgcn_readfirstlane((int)pace[2]);
+    const uint32_t wp = LIST ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)pace[0]);
+    const uint32_t wt = LIST ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)pace[2]);
     const uint32_t P = (wp >> X3_DESC_BYTES_BITS) == epoch - 1u ? (wp & X3_DESC_BYTES_MASK) : 0u;
     const uint32_t T = (wt >> X3_DESC_BYTES_BITS) == epoch - 1u ? (wt & X3_DESC_BYTES_MASK) : 0u;
-    if (P < 64u) {
+    if (LIST) {
+      // (a handful of frames per workgroup: nothing to pace)
+    } else if (P < 64u) {
       // nothing to go by (a context's first launch): 6.6 us per frame of 10 000 samples, what config 3 settles on --
       // a guess that does not fit the data pins the priorities, which is the unpaced kernel
       pace_target = (p.spf * 66u) / 1000u;
@@ -320,7 +349,9 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
       pace_inv = (16u << 16) / t;
     }
   }
-  for (uint64_t f = blockIdx.x; f < g.n_frames; f += G) {
+  for (uint64_t fi = blockIdx.x; fi < (LIST ? (uint64_t)n_list : g.n_frames); fi += G) {
+    const uint64_t f = LIST ? (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)dense_list[fi]) : fi;
+    const bool more = LIST ? fi + G < n_list : fi + G < g.n_frames;  // this workgroup has another frame behind this one
     if (pace_inv) {
       const uint32_t el = (uint32_t)(wall_clock64() - pace_t0);  // 10 ns ticks
       const int32_t d = (int32_t)(pace_k * 16u) - (int32_t)((el * pace_inv) >> 16);  // sixteenths of a frame
@@ -334,7 +365,8 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
     uint32_t n;
     geom_at(clip_f, idx_f, src, n);
     (void)src;
-    geom_advance(clip_f, idx_f);  // now the geometry of f + G
+    if (!LIST) geom_advance(clip_f, idx_f);  // now the geometry of f + G
+    else if (more) geom_of((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)dense_list[fi + G]), clip_f, idx_f);
     uint32_t* img = img0 + cur * img_dwords;
 
     // ---- B: one block per lane, in registers.  cnt = samples of this lane's block: 20, 19 in the last block of a
@@ -418,7 +450,7 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
     // the sizes in front of the PREVIOUS frame, due behind this frame's emission: asked for as late as their latency
     // allows -- the other workgroups publish theirs behind their B1, and a word that is read before it is written
     // costs a poll (asked for a whole iteration ahead, 45 % of the frames found a size missing; tools/dbg_stamps_enc2.py)
-    if (have_prev) desc_load2(prev_f, q0, q1);
+    if (!LIST && have_prev) desc_load2(prev_f, q0, q1);
     uint32_t wave_base = 0, total = 0;
     {
       const uint4 a = reinterpret_cast<const uint4*>(part)[0], c = reinterpret_cast<const uint4*>(part)[1];
@@ -444,7 +476,10 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
     }
     if (tid == 0) {
       // publish this frame's size as early as possible (the word is its own flag: cdna_hip_programming.md G16, R2)
-      __hip_atomic_store(&desc[f], ready_tag | frame_bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!LIST) {
+        __hip_atomic_store(&desc[f], ready_tag | frame_bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (L > X3_DENSE_PAYLOAD_BYTES) ++n_dense;  // (a hint for the host: how dense this call's content is; added once, at the end)
+      }
       atomicOr(&img[5], x3_bswap32(s_first << 16));  // <Audio State> (encoder.rs:189)
     }
 
@@ -490,10 +525,10 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
     }
     // statistics (encoder.rs:199): stats[type] += block.len(); one LDS atomic per lane, summed over
     // all frames of this workgroup and flushed once at the end
-    if (cnt) atomicAdd(&part[32 + type], cnt);
+    if (!LIST && cnt) atomicAdd(&part[32 + type], cnt);
     X3_STAMP(2);
     // the sizes in front of the previous frame were requested a whole iteration ago
-    if (have_prev) settle();
+    if (!LIST && have_prev) settle();
     // Nothing of this wave is in flight here but stores.  Said with the BUILTIN, so that hipcc's wait-count pass
     // clears its scoreboard: it would otherwise protect registers that "may" still be load targets (the polls of
     // settle(), the size words across the loop's back edge) with vmcnt(0) waits all over the CRC pass and the
@@ -501,7 +536,7 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
     x3_dma_wait();
     // the next frame of this workgroup: its samples fly under the CRC pass, the copy-out and the barriers (the
     // registers are free: the block has been emitted)
-    if (f + G < g.n_frames) {
+    if (more) {
       const int16_t* nsrc;
       uint32_t nn;
       geom_at(clip_f, idx_f, nsrc, nn);
@@ -606,7 +641,7 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
     X3_STAMP(0);
   }
   // ---- the workgroup's last frame
-  if (have_prev) {
+  if (!LIST && have_prev) {
     desc_load2(prev_f, q0, q1);
     settle();
   }
@@ -622,13 +657,14 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
     x3_dbg[8 * 8 * 400 + (blockIdx.x * 8 + wid) * 2 + 1] = dbg_late;
   }
 #endif
-  if (tid == 0 && pace_k >= 16u) {  // this workgroup's pace, for the next launch
+  if (!LIST && tid == 0 && pace_k >= 16u) {  // this workgroup's pace, for the next launch
     uint64_t t = (wall_clock64() - pace_t0) / pace_k;
     if (t > X3_DESC_BYTES_MASK) t = X3_DESC_BYTES_MASK;
     atomicMax(pace, (epoch << X3_DESC_BYTES_BITS) | (uint32_t)t);
     if (blockIdx.x == 0) pace[2] = (epoch << X3_DESC_BYTES_BITS) | pace_target;
   }
-  if (tid < 6) {
+  if (!LIST && tid == 0 && n_dense) atomicAdd(dense_count, n_dense);
+  if (!LIST && tid < 6) {
     const uint32_t v = part[32 + tid];  // < 2^32: at most ~270 frames x 10 000 samples per workgroup
     if (v) atomicAdd(&stats[tid], (unsigned long long)v);
   }

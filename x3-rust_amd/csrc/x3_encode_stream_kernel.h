@@ -61,12 +61,6 @@ __device__ __forceinline__ uint32_t x3_pk_sar_i16(uint32_t a, uint32_t sh) {  //
   return r;
 }
 
-// packed 16-bit logical shift right, per-half amounts in sh2
-__device__ __forceinline__ uint32_t x3_pk_lshr_b16(uint32_t a, uint32_t sh2) {
-  uint32_t r;
-  asm("v_pk_lshrrev_b16 %0, %1, %2" : "=v"(r) : "v"(sh2), "v"(a));
-  return r;
-}
 // SDWA operand selects (gfx9 encoding, available on gfx950): halves of a dword as operands of a 32-bit op
 __device__ __forceinline__ uint32_t x3_sdwa_add_w0_w1(uint32_t a) {  // a.lo16 + a.hi16
   uint32_t r;

@@ -32,8 +32,11 @@
 //    scheme, one level up).  A wave asks for those words when its emission is done and prefetches the next frame's
 //    samples behind the request.
 //
-// A frame whose payload does not fit the image (> 9 728 bytes: dense content) flags the launch; x3_encode_result then
-// runs the call again with the second-generation kernel, and the context remembers (x3_api.hip).
+// A frame whose payload does not fit the image (> 9 728 bytes: dense content) is analysed like any other -- its size goes
+// out, its statistics are counted, its offset is assigned and written to the frame index -- but it is not emitted here:
+// it appends itself to a device list, and the launch behind this one (x3_encode_stream2_kernel<true>, one workgroup per
+// listed frame, worst-case images) writes it at that offset.  Round 3 flagged the whole launch instead and the host
+// encoded the call again: one loud frame in an hour of recording cost a second encode.
 #pragma once
 #include "x3_encode_stream2_kernel.h"
 
@@ -75,7 +78,7 @@
 #define X3W_PART 5120u         // samples per part: 64 lanes x 4 blocks x 20
 #define X3W_MAX_NWG 256u      // a generation's base sums at most this many totals: four words per lane
 #define X3W_DESC_PAD 320u     // words in front of desc[0]: the windows of the first generation reach below 0
-#define X3D_IMAGE_OVERFLOW 101  // internal: a frame did not fit its LDS image (x3_encode_result re-runs the call)
+static_assert(X3W_IMG_BYTES == X3_DENSE_PAYLOAD_BYTES, "the dense pass takes what the image does not hold");
 
 struct X3WaveArgs {
   const int16_t* wav;
@@ -84,6 +87,7 @@ struct X3WaveArgs {
   uint32_t* desc;           // one word per workgroup generation, X3W_DESC_PAD words in front
   unsigned char* ctl;       // int status[8] | u64 stats[6] | u64 end_pos
   const uint32_t* tabs;     // X3W_TAB_BYTES
+  uint32_t* dense_list;     // frames that did not fit the image, in the order their offsets became known (count: ctl + X3_CTL_DENSE_COUNT)
   uint64_t out_cap, start_pos, n_per_clip, clip_stride, n_frames;
   uint32_t fpc, spf, epoch;
   uint32_t m;               // frames per workgroup generation = active waves per workgroup (1..16)
@@ -526,6 +530,8 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
         *end_pos = off + frame_bytes;
       }
       if (prev_f == 0 && (a.start_pos & 1ull) && a.start_pos < a.out_cap) a.out[a.start_pos] = 0;  // align pad byte
+      // a frame that is not in the image: to the dense pass, now that frame_off[prev_f] says where it goes
+      if (prev_ovf) a.dense_list[atomicAdd(reinterpret_cast<uint32_t*>(a.ctl + X3_CTL_DENSE_COUNT), 1u)] = (uint32_t)prev_f;
     }
     if (!prev_ovf && off + frame_bytes <= a.out_cap) {
       uint8_t* const dst = a.out + off;
@@ -872,8 +878,6 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
           const uint32_t kx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tab[2560u + (zb >> 1)]);
           crc = x3_gf_mul(crc, kx) & 0xFFFFu;
         }
-      } else if (lane == 0) {
-        atomicMax(&status[1], X3D_IMAGE_OVERFLOW);
       }
       // the next frame's second half: behind the CRC pass (whose look-ups want the registers), in front of the
       // analysis of its first half

@@ -97,7 +97,7 @@ struct WorkerCtxs {
     ctx[0]->enc_gate = nullptr;
     for (size_t k = 1; k < ctx.size(); ++k) {
       ctx[0]->encode_fallbacks += ctx[k]->encode_fallbacks;
-      ctx[0]->encode_dense_reruns += ctx[k]->encode_dense_reruns;
+      ctx[0]->encode_dense_frames += ctx[k]->encode_dense_frames;
       x3_ctx_destroy(ctx[k]);
     }
   }

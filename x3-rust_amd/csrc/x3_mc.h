@@ -80,7 +80,7 @@ extern "C" int x3_encode_mc(x3_ctx* c, const int16_t* const* wavs, uint32_t n_ch
   HIPCHK(c, hipGetLastError());
   x3_batch all{n * n_ch, n * n_ch, 1};
   c->last_enc = {d_wav, all, *p, spf, (uint8_t*)c->out.p, out_cap, start_pos, nullptr};
-  c->last_was_wave = false;
+  c->last_enc_gen = 0;
   c->encode_pending = true;
   c->enc_start_pos = start_pos;
   uint64_t pos = 0;

@@ -43,15 +43,22 @@ struct X3Rccl {
   decltype(&ncclCommAbort) CommAbort = nullptr;  // optional: teardown of a half-built group
   std::string err;
 };
-static std::string& x3_rccl_error() {
-  static std::string e;
-  return e;
+static X3Rccl& x3_rccl_state() {
+  static X3Rccl r;
+  return r;
+}
+static X3Rccl* x3_rccl();
+// why librccl could not be used (set once, inside x3_rccl's call_once; only read afterwards: no race between the
+// x3_mgpu_parallel threads -- ADVICE r3)
+static const std::string& x3_rccl_error() {
+  (void)x3_rccl();
+  return x3_rccl_state().err;
 }
 
 static X3Rccl* x3_rccl() {
-  static X3Rccl r;
+  X3Rccl& r = x3_rccl_state();
   static std::once_flag once;
-  std::call_once(once, [] {
+  std::call_once(once, [&r] {
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
       r.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
       if (r.h) break;
@@ -81,7 +88,6 @@ static X3Rccl* x3_rccl() {
       r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.h, "ncclCommAbort"));
     }
   });
-  if (!r.h) x3_rccl_error() = r.err;
   return r.h ? &r : nullptr;
 }
 
@@ -98,7 +104,11 @@ struct x3_shard {
   hipStream_t gstream = nullptr;
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;
   bool gather_pending = false;
+  // x3_shard_write_at: two pinned staging buffers (a chunk goes to the file while the next one comes down)
+  uint8_t* h_stage[2] = {nullptr, nullptr};
+  hipEvent_t ev_stage[2] = {nullptr, nullptr};
 };
+#define X3_SHARD_STAGE_BYTES (16ull << 20)
 
 #define RCCLCHK(ctx, R, call)                                                                          \
   do {                                                                                                 \
@@ -166,6 +176,10 @@ extern "C" void x3_shard_destroy(x3_shard* s) {
   if (s->gstream) (void)hipStreamDestroy(s->gstream);
   if (s->ev_ready) (void)hipEventDestroy(s->ev_ready);
   if (s->ev_done) (void)hipEventDestroy(s->ev_done);
+  for (int k = 0; k < 2; ++k) {
+    if (s->h_stage[k]) (void)hipHostFree(s->h_stage[k]);
+    if (s->ev_stage[k]) (void)hipEventDestroy(s->ev_stage[k]);
+  }
   if (s->d_mine) (void)hipFree(s->d_mine);
   if (s->d_lengths) (void)hipFree(s->d_lengths);
   if (s->h_lengths) (void)hipHostFree(s->h_lengths);
@@ -203,11 +217,24 @@ extern "C" int x3_shard_create(x3_ctx* c, const uint8_t id[X3_SHARD_ID_BYTES], i
     x3_shard_destroy(s);
     return X3_ERR_HIP;
   }
-  // (collective: every rank splits; the same members in the same order)
+  // (collective: every rank splits; the same members in the same order).  The ranks then AGREE on the outcome -- one
+  // all-gather of a flag on `comm` -- and either all use the split communicator or all fall back to `comm`: a rank that
+  // fell back alone would post its sends on another communicator than its peers' receives and hang.
   s->gcomm = s->comm;
   if (R->CommSplit && world > 1) {
     ncclComm_t g2 = nullptr;
-    if (R->CommSplit(s->comm, 0, rank, &g2, nullptr) == ncclSuccess && g2) s->gcomm = g2;
+    const bool mine = R->CommSplit(s->comm, 0, rank, &g2, nullptr) == ncclSuccess && g2;
+    bool all = false;
+    s->h_lengths[rank] = mine ? 1u : 0u;
+    if (hipMemcpyAsync(s->d_mine, &s->h_lengths[rank], sizeof(uint64_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+        R->AllGather(s->d_mine, s->d_lengths, 1, ncclUint64, s->comm, c->stream) == ncclSuccess &&
+        hipMemcpyAsync(s->h_lengths, s->d_lengths, sizeof(uint64_t) * (size_t)world, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+        hipStreamSynchronize(c->stream) == hipSuccess) {
+      all = true;
+      for (int r2 = 0; r2 < world; ++r2) all = all && s->h_lengths[r2] == 1u;
+    }
+    if (all) s->gcomm = g2;
+    else if (g2) (void)R->CommDestroy(g2);
   }
   *out = s;
   return X3_OK;
@@ -307,11 +334,18 @@ extern "C" int x3_shard_gather_async(x3_shard* s, const uint8_t* d_sub, const ui
     c->last_error = "x3_shard_gather_async: the reassembly before this one has not been waited for";
     return X3_ERR_BAD_ARG;
   }
-  HIPCHK(c, hipEventRecord(s->ev_ready, c->stream));
-  HIPCHK(c, hipStreamWaitEvent(s->gstream, s->ev_ready, 0));
-  int rc = x3_shard_gather_on(s, d_sub, lengths, root, d_dst, dst_cap, total, s->gcomm, s->gstream);
+  // (no communicator of its own -- RCCL without ncclCommSplit, or a split that did not succeed on every rank: one
+  // communicator must not be driven from two streams at once, so the reassembly then runs on the context's stream,
+  // in order with its length exchanges -- ADVICE r3)
+  const bool own = s->gcomm != s->comm;
+  hipStream_t st = own ? s->gstream : c->stream;
+  if (own) {
+    HIPCHK(c, hipEventRecord(s->ev_ready, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(s->gstream, s->ev_ready, 0));
+  }
+  int rc = x3_shard_gather_on(s, d_sub, lengths, root, d_dst, dst_cap, total, s->gcomm, st);
   if (rc) return rc;
-  HIPCHK(c, hipEventRecord(s->ev_done, s->gstream));
+  HIPCHK(c, hipEventRecord(s->ev_done, st));
   s->gather_pending = true;
   return X3_OK;
 }
@@ -327,6 +361,60 @@ extern "C" int x3_shard_gather_wait(x3_shard* s, int on_stream) {
   else HIPCHK(c, hipEventSynchronize(s->ev_done));
   s->gather_pending = false;
   return X3_OK;
+}
+
+// Step 2, SHARDED (round 4): nobody takes in the whole stream.  The reference writes one .x3a file through one BufWriter
+// (encodefile.rs:66-74); with the frames on N GPUs the equivalent is N writers into ONE file, rank r's sub-stream at byte
+// base + starts[r] (x3_shard_offsets; `base` = what precedes the frames, e.g. the archive header).  Every rank passes a
+// descriptor of the same file (one rank creates it, the others open it without O_TRUNC).  The root of x3_shard_gather
+// takes 2.5 GB per step over seven xGMI links at N = 8 -- five times the ranks' compute; here every rank's bytes leave
+// over its OWN host link, side by side.  Starts when everything enqueued on the context's stream so far has run; the
+// sub-stream comes down in 16 MiB pieces through two pinned buffers on the shard's own stream, each piece written
+// (pwrite) while the next one is on its way.  Returns when this rank's bytes are in the file (not fsync'ed).
+extern "C" int x3_shard_write_at(x3_shard* s, const uint8_t* d_sub, const uint64_t* lengths, int fd, uint64_t base,
+                                 uint64_t* total) {
+  if (!s || !lengths || fd < 0) return X3_ERR_BAD_ARG;
+  x3_ctx* c = s->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<uint64_t> starts((size_t)s->world + 1);
+  x3_shard_offsets(lengths, s->world, starts.data());
+  if (total) *total = starts[s->world];
+  const uint64_t len = lengths[s->rank];
+  if (len == 0) return X3_OK;
+  if (!d_sub) return X3_ERR_BAD_ARG;
+  for (int k = 0; k < 2; ++k) {
+    if (!s->h_stage[k]) HIPCHK(c, hipHostMalloc(&s->h_stage[k], X3_SHARD_STAGE_BYTES));
+    if (!s->ev_stage[k]) HIPCHK(c, hipEventCreateWithFlags(&s->ev_stage[k], hipEventDisableTiming));
+  }
+  HIPCHK(c, hipEventRecord(s->ev_ready, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(s->gstream, s->ev_ready, 0));
+  const uint64_t at = base + starts[s->rank];
+  const uint64_t pieces = (len + X3_SHARD_STAGE_BYTES - 1) / X3_SHARD_STAGE_BYTES;
+  auto piece_len = [&](uint64_t k) { return std::min<uint64_t>(X3_SHARD_STAGE_BYTES, len - k * X3_SHARD_STAGE_BYTES); };
+  auto fetch = [&](uint64_t k) -> int {
+    HIPCHK(c, hipMemcpyAsync(s->h_stage[k & 1], d_sub + k * X3_SHARD_STAGE_BYTES, piece_len(k), hipMemcpyDeviceToHost, s->gstream));
+    HIPCHK(c, hipEventRecord(s->ev_stage[k & 1], s->gstream));
+    return X3_OK;
+  };
+  int rc = fetch(0);
+  for (uint64_t k = 0; k < pieces && !rc; ++k) {
+    HIPCHK(c, hipEventSynchronize(s->ev_stage[k & 1]));
+    if (k + 1 < pieces) rc = fetch(k + 1);  // (into the other buffer, whose last piece has been written)
+    const uint8_t* src = s->h_stage[k & 1];
+    uint64_t left = piece_len(k), pos = at + k * X3_SHARD_STAGE_BYTES;
+    while (left) {
+      const ssize_t w = ::pwrite(fd, src, (size_t)left, (off_t)pos);
+      if (w < 0) {
+        if (errno == EINTR) continue;
+        c->last_error = std::string("x3_shard_write_at: pwrite: ") + std::strerror(errno);
+        (void)hipStreamSynchronize(s->gstream);
+        return X3_ERR_IO;
+      }
+      src += w; pos += (uint64_t)w; left -= (uint64_t)w;
+    }
+  }
+  if (rc) (void)hipStreamSynchronize(s->gstream);
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -466,18 +554,17 @@ extern "C" int x3_mgpu_encode(x3_mgpu* m, const int16_t* wav, uint64_t n, uint32
     for (int r = 0; r < G; ++r) tot += all[g][r];
     if (g == 0) total = tot;
     const bool over = base + tot > out_cap;  // the same verdict on every rank; reported below
-    // step 2: sub-streams to devices[0] over xGMI, then one copy to the caller's buffer.  (Every thread passes BOTH
-    // barriers whatever has happened, and looks at `failed` only behind the second: a thread that left between them would
-    // leave the others waiting for ever -- ADVICE r2.)
-    if (g == 0 && !failed.load() && !over && (e = ensure(c, m->whole, tot + 16))) { rcs[0] = e; failed.store(1); }
+    // step 2, sharded (round 4): the destination is HOST memory, so every device copies its own sub-stream straight to
+    // its place in the caller's buffer over its own host link -- no reassembly on devices[0] first (until round 3: all
+    // sub-streams over xGMI to one GPU, then one copy down one link).  x3_shard_gather stays for callers who want the
+    // whole stream on a GPU.  (Every thread passes BOTH barriers whatever has happened, and looks at `failed` only
+    // behind the second: a thread that left between them would leave the others waiting for ever -- ADVICE r2.)
     pthread_barrier_wait(&bar);  // B2
     if (failed.load() || over) return;
-    e = x3_shard_gather(s, (const uint8_t*)c->out.p, all[g].data(), 0, (uint8_t*)m->whole.p, tot, nullptr);
-    if (!e && hipStreamSynchronize(c->stream) != hipSuccess) e = X3_ERR_HIP;
-    if (!e && g == 0) {
-      if (start_pos & 1ull) out[start_pos] = 0;
-      if (tot && hipMemcpy(out + base, m->whole.p, tot, hipMemcpyDeviceToHost) != hipSuccess) e = X3_ERR_HIP;
-    }
+    uint64_t at = base;
+    for (int r = 0; r < g; ++r) at += all[g][r];
+    if (g == 0 && (start_pos & 1ull)) out[start_pos] = 0;
+    if (len && hipMemcpy(out + at, c->out.p, len, hipMemcpyDeviceToHost) != hipSuccess) e = X3_ERR_HIP;
     if (e) rcs[g] = e;
   });
   pthread_barrier_destroy(&bar);

@@ -48,7 +48,7 @@ SYMBOLS = [
     "x3_synth", "x3_synth_dev", "x3_dev_alloc", "x3_dev_free", "x3_dev_upload", "x3_dev_download",
     "x3_shard_unique_id", "x3_shard_create", "x3_shard_destroy", "x3_shard_rank", "x3_shard_world",
     "x3_shard_frame_range", "x3_shard_sample_range", "x3_shard_offsets", "x3_shard_exchange_lengths",
-    "x3_shard_exchange_length_value", "x3_shard_lengths", "x3_shard_gather", "x3_shard_gather_async", "x3_shard_gather_wait",
+    "x3_shard_exchange_length_value", "x3_shard_lengths", "x3_shard_gather", "x3_shard_gather_async", "x3_shard_gather_wait", "x3_shard_write_at",
     "x3_mgpu_create", "x3_mgpu_destroy", "x3_mgpu_devices", "x3_mgpu_ctx", "x3_mgpu_shard", "x3_mgpu_last_error",
     "x3_mgpu_encode", "x3_mgpu_decode_stream",
     "x3_encode_mc", "x3_decode_stream_mc",
@@ -226,6 +226,7 @@ def lib():
     L.x3_shard_gather.argtypes = [vp, vp, C.POINTER(u64), i32, vp, u64, C.POINTER(u64)]
     L.x3_shard_gather_async.argtypes = [vp, vp, C.POINTER(u64), i32, vp, u64, C.POINTER(u64)]
     L.x3_shard_gather_wait.argtypes = [vp, i32]
+    L.x3_shard_write_at.argtypes = [vp, vp, C.POINTER(u64), i32, u64, C.POINTER(u64)]
     L.x3_mgpu_create.argtypes = [C.POINTER(i32), i32, C.POINTER(vp)]
     L.x3_mgpu_destroy.restype = None
     L.x3_mgpu_destroy.argtypes = [vp]
@@ -347,6 +348,15 @@ class Shard:
         rc = fn(self._h, d_sub, src, root, d_dst, dst_cap, C.byref(tot))
         if rc:
             raise X3Error(rc, "x3_shard_gather: " + self.ctx.last_error())
+        return tot.value
+
+    def write_at(self, d_sub, lengths, fd, base=0):
+        """sharded reassembly (x3_shard_write_at): this rank's sub-stream to byte base + starts[rank] of the file `fd`"""
+        src = (C.c_uint64 * self.world)(*[int(v) for v in lengths])
+        tot = C.c_uint64(0)
+        rc = lib().x3_shard_write_at(self._h, d_sub, src, fd, base, C.byref(tot))
+        if rc:
+            raise X3Error(rc, "x3_shard_write_at: " + self.ctx.last_error())
         return tot.value
 
     def gather_wait(self, on_stream=True):
