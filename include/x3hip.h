@@ -129,10 +129,20 @@ int x3_ctx_get_option(const x3_ctx* ctx, const char* name, long long* value);
 
 /* HIP-event timing of individual kernels on the context's stream (bench.py's roofline leg).
  * which: 0 = encode kernel, 1 = decode kernel, 2 = frame-size kernel, 3 = scan kernel,
- *        4 = frame check (header + payload CRC) kernel. */
+ *        4 = frame check (header + payload CRC) kernel, 5 = the encoder's dense pass (frames the wave encoder's LDS image
+ *        does not hold: x3_encode_dev below). */
 int x3_ctx_enable_kernel_timing(x3_ctx* ctx, int enable);
 int x3_ctx_kernel_time(x3_ctx* ctx, int which, double* total_ms, uint64_t* launches); /* syncs */
 int x3_ctx_reset_kernel_time(x3_ctx* ctx);
+/* Every timed launch's own time in ms, oldest first (which as above; 5 = the encoder's dense pass): *launches = how many
+ * there are, the first min(cap, *launches) are written.  Syncs. */
+int x3_ctx_kernel_times(x3_ctx* ctx, int which, double* ms, uint64_t cap, uint64_t* launches);
+/* The launch log the kernels keep themselves: the last (up to 256) launches of the decoder (which = 1) or the wave
+ * encoder (which = 0), oldest first, four words each: the pace the launch aimed at and the pace its slowest group
+ * achieved (10 ns ticks per 16 blocks; decoder only, else 0), the shader clock in kHz that workgroup 0 measured over
+ * its life (shader ticks against the constant 100 MHz clock), and that life in 10 ns ticks.  Syncs.  For benchmarks:
+ * a reader of the line can tell a slow box (clock) from a controller that has not settled (target vs achieved). */
+int x3_ctx_launch_log(x3_ctx* ctx, int which, uint32_t* out /* 4 * cap_entries */, uint64_t cap_entries, uint64_t* n_entries);
 
 /* ------------------------------------------------------------------ x3.rs */
 

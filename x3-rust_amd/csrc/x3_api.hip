@@ -101,6 +101,7 @@ struct x3_ctx {
   struct x3_reader* fcache = nullptr;  // x3_decode_prefetch: the frame stream x3_decode_frame calls are served from
   uint32_t* d_pace = nullptr;          // x3_decode_split_kernel's pace word (see there), dec_epoch its launch count
   uint32_t dec_epoch = 1;
+  uint32_t enc_log_epoch = 0;          // launches of the wave encoder (its launch-log entries are indexed by it)
   uint16_t* d_crc = nullptr;
   // pinned mirrors
   int* h_status = nullptr;
@@ -255,8 +256,8 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
   c->d_stats = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->d_status) + 32);
   c->d_end_pos = c->d_stats + 6;
   HIPCHK(c, hipMalloc(&c->d_summary, sizeof(X3DecodeSummary)));
-  HIPCHK(c, hipMalloc(&c->d_pace, 64));
-  HIPCHK(c, hipMemset(c->d_pace, 0, 64));
+  HIPCHK(c, hipMalloc(&c->d_pace, X3_PACE_WORDS * sizeof(uint32_t)));
+  HIPCHK(c, hipMemset(c->d_pace, 0, X3_PACE_WORDS * sizeof(uint32_t)));
   HIPCHK(c, hipMalloc(&c->d_crc, 16));
   HIPCHK(c, hipHostMalloc(&c->h_status, 128));
   c->h_stats = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_status) + 32);
@@ -585,6 +586,49 @@ extern "C" int x3_ctx_reset_kernel_time(x3_ctx* c) {
   return X3_OK;
 }
 
+// every timed launch's own time, oldest first (bench.py: minimum, median, p90 of a kernel over the timed steps)
+extern "C" int x3_ctx_kernel_times(x3_ctx* c, int which, double* ms, uint64_t cap, uint64_t* launches) {
+  if (!c || which < 0 || which > 5 || (!ms && cap)) return X3_ERR_BAD_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  uint64_t k = 0;
+  for (auto& e : c->timers[which].used) {
+    float t = 0;
+    HIPCHK(c, hipEventElapsedTime(&t, e.first, e.second));
+    if (k < cap) ms[k] = t;
+    ++k;
+  }
+  if (launches) *launches = k;
+  return X3_OK;
+}
+
+// The launch log: the last X3_LOG_ENTRIES launches of the decoder (which = 1) or the wave encoder (which = 0), newest
+// last.  Per launch four values: ticks of 10 ns per 16 blocks the launch aimed at and its slowest group achieved
+// (decoder; 0 for the encoder), and the shader clock in kHz that workgroup 0 measured over its life.  Syncs.
+extern "C" int x3_ctx_launch_log(x3_ctx* c, int which, uint32_t* out, uint64_t cap_entries, uint64_t* n_entries) {
+  if (!c || (which != 0 && which != 1) || (!out && cap_entries)) return X3_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<uint32_t> w(X3_LOG_ENTRIES * X3_LOG_WORDS);
+  HIPCHK(c, hipMemcpy(w.data(), c->d_pace + (which ? X3_LOG_BASE : X3_LOG_ENC_BASE), w.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  // the newest launch: the decoder's epoch counter has been incremented behind its last launch
+  const uint32_t last = which ? (c->dec_epoch - 1u) & 0xFFFu : c->enc_log_epoch & 0xFFFu;
+  uint64_t n = 0;
+  for (uint32_t back = X3_LOG_ENTRIES; back-- > 0;) {
+    const uint32_t ep = (last - back) & 0xFFFu;
+    const uint32_t* e = &w[(size_t)(ep & (X3_LOG_ENTRIES - 1u)) * X3_LOG_WORDS];
+    if ((e[0] >> 20) != ep || e[3] == 0) continue;   // (not this epoch's entry: never written, or older)
+    if (n < cap_entries) {
+      out[4 * n + 0] = which ? e[1] & 0xFFFFFu : 0u;
+      out[4 * n + 1] = which ? e[0] & 0xFFFFFu : 0u;
+      out[4 * n + 2] = (uint32_t)((unsigned long long)e[2] * 100000ull / e[3]);   // shader ticks per 10 ns tick -> kHz
+      out[4 * n + 3] = e[3];
+    }
+    ++n;
+  }
+  if (n_entries) *n_entries = n;
+  return X3_OK;
+}
+
 extern "C" int x3_ctx_kernel_time(x3_ctx* c, int which, double* total_ms, uint64_t* launches) {
   if (!c || which < 0 || which > 5) return X3_ERR_BAD_ARG;
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -905,6 +949,8 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
       wa.desc = (uint32_t*)c->desc.p + X3W_DESC_PAD;
       wa.ctl = reinterpret_cast<unsigned char*>(c->d_status);
       wa.tabs = c->d_wtab;
+      wa.log = c->d_pace + X3_LOG_ENC_BASE;
+      wa.log_epoch = ++c->enc_log_epoch & 0xFFFu;
       if ((rc = ensure(c, c->dense_list, F * sizeof(uint32_t)))) return rc;
       wa.dense_list = (uint32_t*)c->dense_list.p;
       wa.out_cap = out_cap;
@@ -1491,6 +1537,7 @@ static int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, cons
       // the pace word's 12-bit epoch: launches 1, 2, ... 4095, then the word starts over
       if ((c->dec_epoch & 0xFFFu) == 0u) {
         HIPCHK(c, hipMemsetAsync(c->d_pace, 0, 16, dec_stream));  // (achieved and aimed-at, one word per launch parity)
+        HIPCHK(c, hipMemsetAsync(c->d_pace + X3_LOG_BASE, 0, X3_LOG_ENTRIES * X3_LOG_WORDS * sizeof(uint32_t), dec_stream));  // (its atomicMax entries carry the epoch too)
         ++c->dec_epoch;
       }
       X3_LAUNCH_TIMED(ts, x3_decode_split_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64 * X3S_WAVES),

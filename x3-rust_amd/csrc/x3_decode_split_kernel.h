@@ -56,6 +56,16 @@
 #ifndef X3S_VALUER_FOLD
 #define X3S_VALUER_FOLD 0
 #endif
+// timing experiments only (results are wrong): knock out one role's work to see what the others cost each other.
+// 1: the valuer's pair arithmetic and staging; 2: the flusher's loads and stores; 4: the parser's codeword walk;
+// 8: the flusher's global stores only (its LDS reads stay); 16: the parser's ring service (no loads, no parks);
+// 32: the service's loads only are skipped (parks of stale registers stay)
+#ifndef X3S_KO
+#define X3S_KO 0
+#endif
+// (Round 4 also swept the cache policies of the flusher's stores and the parser's requests as buffer instructions --
+// plain / nt / sc1 / sc0 sc1 / sc1 nt: nothing beats nontemporal stores and plain loads, plain or sc1 stores cost 7 %
+// and slow the ENCODER down by 8 % through what they leave in L2, nt loads cost 56 %: profiles/r4/decoder_cache_policies.txt.)
 #define X3S_XROWS 11u          // transfer rows per block buffer: 10 pair dwords + the header word
 #define X3S_WAVES 3u            // parser, valuer, flusher
 
@@ -148,6 +158,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   const bool flusher = (threadIdx.x >> 6) == 2u;
   const uint64_t f = (uint64_t)blockIdx.x * 64 + lane;
   const unsigned long long pace_t0 = wall_clock64();
+  const unsigned long long clk_t0 = clock64();   // (shader clock: the launch log's clock measurement, below)
   uint32_t pace_inv;        // blocks per tick, 16.16 fixed point
   uint32_t pace_target;     // 10 ns ticks per 16 blocks that this launch aims at
   {
@@ -305,8 +316,10 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     }
     v_next += 16u * (fit > SVC_MAX ? SVC_MAX : fit);
     v_req = v_next;
+    if (!(X3S_KO & 32)) {
 #pragma unroll
-    for (int k = 0; k < (int)SVC_AHEAD; ++k) ld[k] = request(v_req + 16u * k);
+      for (int k = 0; k < (int)SVC_AHEAD; ++k) ld[k] = request(v_req + 16u * k);
+    }
   };
 
   // the usual group: 64 frames of the same size, one behind the other in wav.  Rows r, r + 4, r + 8 ... then have
@@ -347,10 +360,11 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     const x3_u32x4 v1 = x3_lds_read_b128(c_src1 ^ flip);
     // a frame that failed is not written any further (the valuer says which)
     const bool ok0 = s_dead[4u * (lane >> 3) + c] == 0u, ok1 = s_dead[4u * ((lane >> 3) + 8u) + c] == 0u;
-    if (pc >= p_lo && pc < p_hi) {
+    if (!(X3S_KO & 8) && pc >= p_lo && pc < p_hi) {
       if (ok0) x3_store_stream16(line0 + (c_dst0 + 128u * n), v0);
       if (ok1) x3_store_stream16(line0 + (c_dst1 + 128u * n), v1);
     }
+    if (X3S_KO & 8) asm volatile("" :: "v"(v0.x), "v"(v1.x), "v"(v0.w), "v"(v1.w));
     X3_WAVE_LDS_ORDER();
   };
   // every class whose rows have completed a line: k_done = dwords of each row that are staged
@@ -403,7 +417,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       X3_STAMP(0);
       X3S_BARRIER();
       X3_STAMP(4);
-      if (regular && b) {
+      if (!(X3S_KO & 2) && regular && b) {
         const uint32_t k_done = have >> 1;
         X3S_FLUSH_CLASS(0) X3S_FLUSH_CLASS(1) X3S_FLUSH_CLASS(2) X3S_FLUSH_CLASS(3)
       }
@@ -459,7 +473,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       const uint32_t cnt = remaining < X3S_BL ? remaining : X3S_BL;
       remaining -= cnt;
       X3_STAMP(0);
-      if ((b % X3S_PERIOD) == 0) service(ring_index());
+      if (!(X3S_KO & 16) && (b % X3S_PERIOD) == 0) service(ring_index());
       X3_STAMP(1);
       // block header: 2 bits ftype; ftype 0 -> 4 more bits E-1 (decoder.rs:138-144, 209-216)
       const uint32_t hdr = __builtin_amdgcn_alignbit(w0, w1, s) >> 26;
@@ -480,7 +494,8 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       uint32_t* const buf = xfer + (b & 1u) * (X3S_XROWS * 64u);
       buf[X3S_PAIRS * 64u + lane] = hdr;
       X3_STAMP(2);
-      if (__all(cnt == X3S_BL || cnt == 0u)) {
+      if ((X3S_KO & 4)) {
+      } else if (__all(cnt == X3S_BL || cnt == 0u)) {
         // two samples per 32-bit peek and per window update (two valid codewords are <= 32 bits)
         uint2* const b2 = reinterpret_cast<uint2*>(buf) + lane;
 #pragma unroll
@@ -605,7 +620,8 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       uint32_t maxii2 = 0;
       X3_STAMP(2);
 
-      if (__all(cnt == X3S_BL || cnt == 0u)) {
+      if ((X3S_KO & 1)) {
+      } else if (__all(cnt == X3S_BL || cnt == 0u)) {
         // the whole block's indices at once (five 8-byte reads in flight), then ten pairs from registers
         const uint2* const b2 = reinterpret_cast<const uint2*>(buf) + lane;
         uint2 XX[5];
@@ -719,6 +735,18 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       if (t16 >= (1u << X3S_PACE_EPOCH_SHIFT)) t16 = (1u << X3S_PACE_EPOCH_SHIFT) - 1u;
       atomicMax(pace + (pace_epoch & 1u), ((pace_epoch & 0xFFFu) << X3S_PACE_EPOCH_SHIFT) | (uint32_t)t16);
       if (blockIdx.x == 0) pace[2u + (pace_epoch & 1u)] = ((pace_epoch & 0xFFFu) << X3S_PACE_EPOCH_SHIFT) | pace_target;
+      // The launch log (x3_ctx_launch_log; bench.py's per-step list): what this launch aimed at, what its slowest group
+      // achieved, and the shader clock it ran at -- group 0's shader ticks against the 100 MHz clock over its whole
+      // life (MI355X_MICROARCH.md, DVFS: a box that runs this kernel at 2.0 GHz instead of 2.3 shows HERE, and a line
+      // with the clock in it lets a reader tell a slow box from a controller that has not settled).  Nothing in the
+      // kernel reads these words.
+      uint32_t* const lg = pace + X3_LOG_BASE + X3_LOG_WORDS * (pace_epoch & (X3_LOG_ENTRIES - 1u));
+      atomicMax(lg, ((pace_epoch & 0xFFFu) << X3S_PACE_EPOCH_SHIFT) | (uint32_t)t16);
+      if (blockIdx.x == 0) {
+        lg[1] = ((pace_epoch & 0xFFFu) << X3S_PACE_EPOCH_SHIFT) | pace_target;
+        lg[2] = (uint32_t)(clock64() - clk_t0);
+        lg[3] = (uint32_t)(wall_clock64() - pace_t0);
+      }
     }
   }
 #ifdef X3_DBG_STAMPS

@@ -136,6 +136,15 @@ __device__ __forceinline__ uint32_t x3_pk_max_u16(uint32_t a, uint32_t b) {
   asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+// The context's pace / log words (x3_ctx::d_pace): [0..3] decoder pace by launch parity, [4..7] second-generation
+// encoder pace; from X3_LOG_BASE the decoder's launch log, X3_LOG_ENTRIES entries of X3_LOG_WORDS words indexed by the
+// launch epoch: {tag | slowest group's ticks per 16 blocks, tag | target, group 0's shader ticks, its 10 ns ticks};
+// behind it the wave encoder's: {tag | 0, 0, workgroup 0's shader ticks, its 10 ns ticks}.
+#define X3_LOG_BASE 16u
+#define X3_LOG_ENTRIES 256u
+#define X3_LOG_WORDS 4u
+#define X3_LOG_ENC_BASE (X3_LOG_BASE + X3_LOG_ENTRIES * X3_LOG_WORDS)
+#define X3_PACE_WORDS (X3_LOG_ENC_BASE + X3_LOG_ENTRIES * X3_LOG_WORDS)
 // packed 16-bit logical shift right, per-half amounts in sh2
 __device__ __forceinline__ uint32_t x3_pk_lshr_b16(uint32_t a, uint32_t sh2) {
   uint32_t r;

@@ -87,6 +87,8 @@ struct X3WaveArgs {
   uint32_t* desc;           // one word per workgroup generation, X3W_DESC_PAD words in front
   unsigned char* ctl;       // int status[8] | u64 stats[6] | u64 end_pos
   const uint32_t* tabs;     // X3W_TAB_BYTES
+  uint32_t* log;            // the context's launch log (X3_LOG_ENC_BASE words in): workgroup 0's clocks, nothing reads them
+  uint32_t log_epoch;
   uint32_t* dense_list;     // frames that did not fit the image, in the order their offsets became known (count: ctl + X3_CTL_DENSE_COUNT)
   uint64_t out_cap, start_pos, n_per_clip, clip_stride, n_frames;
   uint32_t fpc, spf, epoch;
@@ -325,6 +327,7 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
   unsigned long long* const stats = reinterpret_cast<unsigned long long*>(a.ctl + 32);
   unsigned long long* const end_pos = stats + 6;
 
+  const unsigned long long log_c0 = clock64(), log_w0 = wall_clock64();
   // ---- prologue: tables, bookkeeping, clear images
   for (uint32_t i = tid; i < X3W_TAB_BYTES / 4u; i += X3W_THREADS) reinterpret_cast<uint32_t*>(smem)[i] = a.tabs[i];
   if (tid < X3W_BOOK_BYTES / 4u) book[tid] = 0;
@@ -909,6 +912,13 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
   if (lane == 0)
     for (int k = 0; k < 4; ++k) x3_dbg[32768 + (blockIdx.x * 16 + w) * 4 + k] = dbg_cnt[k];
 #endif
+  if (blockIdx.x == 0 && w == 0 && lane == 0) {   // the launch log: the shader clock this launch ran at (x3_ctx_launch_log)
+    uint32_t* const lg = a.log + X3_LOG_WORDS * (a.log_epoch & (X3_LOG_ENTRIES - 1u));
+    lg[0] = a.log_epoch << 20;
+    lg[1] = 0;
+    lg[2] = (uint32_t)(clock64() - log_c0);
+    lg[3] = (uint32_t)(wall_clock64() - log_w0);
+  }
   // statistics: the last wave to leave adds the workgroup's sums
   if (lane == 0) {
     const uint32_t old = __hip_atomic_fetch_add(&book[136], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);

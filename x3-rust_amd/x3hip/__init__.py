@@ -31,7 +31,7 @@ ERR_BAD_ARG = 24
 SYMBOLS = [
     "x3_strerror", "x3_ctx_create", "x3_ctx_create_on_stream", "x3_ctx_destroy", "x3_ctx_sync", "x3_last_error",
     "x3_ctx_set_option", "x3_ctx_get_option",
-    "x3_ctx_enable_kernel_timing", "x3_ctx_kernel_time", "x3_ctx_reset_kernel_time",
+    "x3_ctx_enable_kernel_timing", "x3_ctx_kernel_time", "x3_ctx_kernel_times", "x3_ctx_launch_log", "x3_ctx_reset_kernel_time",
     "x3_params_default", "x3_params_validate", "x3_rice_code_get", "x3_num_frames", "x3_encode_bound",
     "x3_crc16", "x3_crc16_dev", "x3_crc16_update",
     "x3_encode", "x3_encode_frame", "x3_write_frame_header", "x3_encode_batch",
@@ -139,6 +139,8 @@ def lib():
     L.x3_ctx_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_longlong)]
     L.x3_ctx_enable_kernel_timing.argtypes = [vp, i32]
     L.x3_ctx_kernel_time.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(u64)]
+    L.x3_ctx_kernel_times.argtypes = [vp, i32, C.POINTER(C.c_double), u64, C.POINTER(u64)]
+    L.x3_ctx_launch_log.argtypes = [vp, i32, C.POINTER(C.c_uint32), u64, C.POINTER(u64)]
     L.x3_ctx_reset_kernel_time.argtypes = [vp]
     L.x3_params_default.restype = None
     L.x3_params_default.argtypes = [PP]
@@ -714,6 +716,26 @@ class Context:
         if rc:
             raise X3Error(rc, "x3_ctx_kernel_time")
         return ms.value, cnt.value
+
+    def kernel_times(self, which):
+        """every timed launch's own time in ms, oldest first"""
+        n = C.c_uint64(0)
+        lib().x3_ctx_kernel_times(self._h, which, None, 0, C.byref(n))
+        out = (C.c_double * max(1, n.value))()
+        rc = lib().x3_ctx_kernel_times(self._h, which, out, n.value, C.byref(n))
+        if rc:
+            raise X3Error(rc, "x3_ctx_kernel_times")
+        return [out[i] for i in range(n.value)]
+
+    def launch_log(self, which):
+        """the kernels' own launch log (x3_ctx_launch_log): list of dicts, oldest first"""
+        n = C.c_uint64(0)
+        out = (C.c_uint32 * (4 * 256))()
+        rc = lib().x3_ctx_launch_log(self._h, which, out, 256, C.byref(n))
+        if rc:
+            raise X3Error(rc, "x3_ctx_launch_log")
+        return [{"target_ticks16": out[4 * i], "achieved_ticks16": out[4 * i + 1], "clock_mhz": out[4 * i + 2] / 1000.0,
+                 "life_us": out[4 * i + 3] / 100.0} for i in range(min(n.value, 256))]
 
     def alloc(self, nbytes):
         p = C.c_void_p()
