@@ -55,19 +55,28 @@ def measure_traffic(n, kind, timeout=180):
         return {}, "this run is itself under a profiler"
     d = tempfile.mkdtemp(prefix="x3pmc_", dir="/tmp")
     vals = {}
+    sq_counters = ("SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", os.path.join(d, counter), "-o", "pmc",
+        # (one counter group per run, no other trace domain: MI355X_MICROARCH.md; the third pass is the SQ's view of the
+        # same launches -- busy cycles, waves, vector instructions -- and the GRBM's active cycles: VERDICT r3, item 3)
+        for tag, counters in (("FETCH_SIZE", ("FETCH_SIZE",)), ("WRITE_SIZE", ("WRITE_SIZE",)), ("SQ", sq_counters)):
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + list(counters) + ["-d", os.path.join(d, tag), "-o", "pmc",
                    "--output-format", "csv", "--", sys.executable, os.path.join(ROOT, "tools", "kbench.py"),
                    "--steps", "3", "--samples", str(n), "--kind", str(kind)]
-            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
-                           stderr=subprocess.DEVNULL, timeout=timeout, check=True)
-            acc = defaultdict(list)
-            for f in glob.glob(os.path.join(d, counter, "**", "*counter_collection.csv"), recursive=True):
-                for r in csv.DictReader(open(f)):
-                    if r["Counter_Name"] == counter:
-                        acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
-            vals[counter] = {k: sum(v) / len(v) for k, v in acc.items()}
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+            except Exception:
+                if tag == "SQ":
+                    break          # (the traffic passes are what the contract needs; the SQ pass is extra)
+                raise
+            for counter in counters:
+                acc = defaultdict(list)
+                for f in glob.glob(os.path.join(d, tag, "**", "*counter_collection.csv"), recursive=True):
+                    for r in csv.DictReader(open(f)):
+                        if r["Counter_Name"] == counter:
+                            acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+                vals[counter] = {k: sum(v) / len(v) for k, v in acc.items()}
     except Exception as e:
         return {}, "PMC pass failed: %s" % type(e).__name__
     finally:
@@ -78,6 +87,9 @@ def measure_traffic(n, kind, timeout=180):
             fb = vals["FETCH_SIZE"].get(k, 0.0) * 1024 * 2
             wb = vals["WRITE_SIZE"].get(k, 0.0) * 1024
             out[k] = {"hbm_bytes_per_launch": int(fb + wb), "fetch_bytes": int(fb), "write_bytes": int(wb)}
+            sq = {c: round(vals[c][k]) for c in sq_counters if k in vals.get(c, {})}
+            if sq:
+                out[k]["sq_per_launch"] = sq
     if not out:
         return {}, "the PMC passes returned no x3 kernels"
     return out, ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over "
@@ -95,10 +107,13 @@ def main():
     ap.add_argument("--cpu-reps", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="= --gather none")
-    ap.add_argument("--gather", choices=("in-step", "overlapped", "none"), default="in-step",
-                    help="N > 1: the reassembly of the whole stream on rank 0 -- inside every step on the context's stream (the "
-                         "contract's `value`), beside the next steps on the shard's own stream and communicator, or not at all; "
-                         "the other two modes are timed as well (gather_modes)")
+    ap.add_argument("--gather", choices=("in-step", "overlapped", "sharded", "none"), default="in-step",
+                    help="N > 1: the reassembly of the whole stream -- on rank 0 inside every step on the context's stream (the "
+                         "contract's `value`: where north_star puts it), on rank 0 beside the next steps on the shard's own stream "
+                         "and communicator, SHARDED (no rank takes in the whole stream: every rank writes its sub-stream at its "
+                         "own offset of one file, x3_shard_write_at), or not at all; the other modes are timed as well (gather_modes)")
+    ap.add_argument("--gather-file", default=None,
+                    help="--gather sharded: the file all ranks write into (default: /dev/shm/x3_bench_<MASTER_PORT>.x3a, removed at the end)")
     ap.add_argument("--mode-steps", type=int, default=10, help="timed steps for each of the gather modes that is not --gather")
     ap.add_argument("--verify-gather", action="store_true",
                     help="rank 0 compares the reassembled stream with the oracle's encoding of the whole signal (small totals)")
@@ -168,7 +183,7 @@ def main():
     if args.no_gather:
         args.gather = "none"
     gather_mode = args.gather if dist is not None else "none"
-    gather_in_step = gather_mode == "in-step"
+    gather_in_step = gather_mode in ("in-step", "sharded")
 
     # The overlapped reassembly needs the sub-stream of step k-1 to stay put while step k+1 is encoded: three output
     # buffers (and frame indexes, length vectors) in rotation; the other modes use the first one only.
@@ -179,6 +194,20 @@ def main():
     lens_pin = [torch.zeros(world, dtype=torch.int64).pin_memory() for _ in range(NB)] if dist is not None else []
     lens_ev = [torch.cuda.Event() for _ in range(NB)] if dist is not None else []
     pipe = {"k": 0, "issued": -1}   # steps enqueued so far in overlapped mode; the last step whose reassembly was issued
+
+    # --gather sharded: ONE file, every rank its own descriptor (rank 0 creates it; the others open it behind a barrier)
+    shard_file = {"fd": -1, "path": None}
+
+    def open_shard_file():
+        if shard_file["fd"] >= 0 or dist is None:
+            return
+        path = args.gather_file or "/dev/shm/x3_bench_%s.x3a" % os.environ.get("MASTER_PORT", "0")
+        if rank == 0:
+            fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o600)
+        dist.barrier()
+        if rank != 0:
+            fd = os.open(path, os.O_RDWR)
+        shard_file["fd"], shard_file["path"] = fd, path
 
     def one_step(mode, b=0):
         """encode + decode (+ the exchange of the lengths, + the reassembly as `mode` says) with output buffer b"""
@@ -196,6 +225,11 @@ def main():
             lens_h = lens_b[b].cpu().tolist()
             wb = whole_buf(sum(lens_h))
             shard_obj.gather(outs[b].data_ptr(), lens_h, 0, wb.data_ptr() if rank == 0 else None, wb.numel())
+        elif mode == "sharded":
+            # exchange step 2, sharded: nobody takes in the whole stream -- this rank's sub-stream goes down its own host link
+            # and into the file at its own offset (x3_shard_write_at; returns when the bytes are written)
+            lens_h = lens_b[b].cpu().tolist()
+            shard_obj.write_at(outs[b].data_ptr(), lens_h, shard_file["fd"], 0)
 
     def issue_gather(j):
         """overlapped mode: the reassembly of step j on the shard's own stream (its lengths are on the host by now)"""
@@ -249,6 +283,8 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    if gather_mode == "sharded":
+        open_shard_file()
     # (--settle: extra untimed launches in front of the contract's W warm-up steps, reported as config.settle_steps.
     # Round 2 needed twelve for the kernels' pace controllers; a first launch is now paced from the data: 0.)
     for _ in range(args.settle):
@@ -284,12 +320,40 @@ def main():
     assert rc == 0, (rc, ctx.last_error())
     rc, first_bad, st, before = ctx.decode_result()
     assert (rc, first_bad, st, before) == (0, F, 0, n), (rc, first_bad, st, before)
-    ktimes = {}
-    for name, which in (("encode", 0), ("decode", 1), ("frame_sizes", 2), ("scan", 3), ("frame_check", 4)):
-        ms, cnt = ctx.kernel_time(which)
-        ktimes[name] = ms / max(cnt, 1)
+    # every timed launch's own HIP-event time (the events ride on the kernels' dispatch packets): mean, minimum, median and
+    # p90 over the K timed steps, and the K values themselves
+    def kstats(ts):
+        v = sorted(ts)
+        return {"n": len(v), "mean": round(sum(v) / len(v), 4), "min": round(v[0], 4), "median": round(v[len(v) // 2], 4),
+                "p90": round(v[min(len(v) - 1, (9 * len(v)) // 10)], 4), "max": round(v[-1], 4)}
+    ktimes, ksteps = {}, {}
+    for name, which in (("encode", 0), ("decode", 1), ("frame_sizes", 2), ("scan", 3), ("frame_check", 4), ("encode_dense_pass", 5)):
+        ts = ctx.kernel_times(which)
+        ktimes[name] = sum(ts) / max(len(ts), 1)
+        if ts:
+            ksteps[name] = ts
     ctx.enable_kernel_timing(False)
-    enc_gen = int(ctx.get_option("enc_gen")) if ctx.get_option("encode_dense_reruns") == 0 else 2
+    enc_gen = int(ctx.get_option("enc_gen_in_use"))
+    # the kernels' own launch log: the shader clock each launch ran at (workgroup 0's shader ticks against the constant
+    # 100 MHz clock over its life) and, for the decoder, the pace it aimed at and the pace its slowest group achieved
+    dlog = ctx.launch_log(1)[-args.steps:]
+    elog = ctx.launch_log(0)[-args.steps:]
+    def med(v):
+        v = sorted(v)
+        return v[len(v) // 2] if v else None
+    clocks = {"device_max_mhz": torch.cuda.get_device_properties(dev).clock_rate / 1000.0 if hasattr(torch.cuda.get_device_properties(dev), "clock_rate") else None,
+              "decode_kernel_mhz": {"median": med([e["clock_mhz"] for e in dlog]), "min": min([e["clock_mhz"] for e in dlog], default=None),
+                                    "max": max([e["clock_mhz"] for e in dlog], default=None)},
+              "encode_kernel_mhz": {"median": med([e["clock_mhz"] for e in elog]), "min": min([e["clock_mhz"] for e in elog], default=None),
+                                    "max": max([e["clock_mhz"] for e in elog], default=None)},
+              "note": "shader clock DURING the kernel: workgroup 0's s_memtime ticks / s_memrealtime ticks x 100 MHz over its "
+                      "whole life, logged by the kernel itself for every launch (x3_ctx_launch_log); the pool's boxes differ "
+                      "by 9 % in the decoder's time, and this says whether a line comes from a slow box"}
+    # pace: 10 ns ticks per 16 blocks -> us per block; target = what the launch aimed at, achieved = its slowest group
+    decoder_pace = {"target_us_per_block": [round(e["target_ticks16"] / 1600.0, 4) for e in dlog],
+                    "achieved_us_per_block": [round(e["achieved_ticks16"] / 1600.0, 4) for e in dlog],
+                    "note": "per timed step: the decoder's pace controller (x3_decode_split_kernel.h); a launch that misses its "
+                            "target by more than a few per cent has all its waves at one priority = the unpaced kernel"}
 
     # ---- bit-exactness of the timed output: decode(encode(x)) == x, and the stream == the CPU oracle's
     assert torch.equal(back, wav), "decode(encode(x)) != x"
@@ -354,11 +418,23 @@ def main():
                   "gb_s": round(starts[-1] / ((g1 - g0) / greps) / 1e9, 1),
                   "pattern": "x3_shard_gather: grouped ncclSend/ncclRecv to rank 0 (one xGMI link per peer)",
                   "in_timed_region": bool(gather_in_step), "mode": gather_mode,
-                  "whole_stream_verified_vs_oracle": whole_ok}
+                  "whole_stream_verified_vs_oracle": whole_ok,
+                  "note": "What the curve over N has to look like (DESIGN.md, multi-GPU).  A rank's compute step is ~1.15 ms for "
+                          "691.2 M samples and leaves a 363 MB sub-stream.  in-step (the default, where north_star puts the "
+                          "reassembly): all of it lands on ONE GPU per step, over at most seven xGMI links at ~55 GB/s each -- "
+                          "~6.5 ms whatever N is -- so value ~ N x 691.2 M / (1.2 + 6.5 ms): 0.3 x one GPU at N = 2, 1.2 x at "
+                          "N = 8; overlapped hides the compute behind it (1.4 x at N = 8: the root's ingest is the bound).  "
+                          "sharded: nobody takes in the whole stream, every rank writes its sub-stream at its own offset of one "
+                          "file over its own host link (x3_shard_write_at; ~56 GB/s per rank: ~6.5 ms per step, but N of them "
+                          "side by side), so value ~ N x 691.2 M / 7.7 ms -- linear in N, 1.2 x one no-output GPU at N = 8.  "
+                          "none = gather_modes.none is the N x figure of the independent shards.  north_star's >= 6 x at "
+                          "8 GPUs is met by none, approached by no mode that delivers the bytes once per step."}
         # ---- the other two ways of placing the reassembly, timed like the headline (barrier + synchronize on both sides,
         # maximum over the ranks): in the step, beside the following steps, not at all
         gather_modes = {}
-        for mode in ("in-step", "overlapped", "none"):
+        for mode in ("in-step", "overlapped", "sharded", "none"):
+            if mode == "sharded":
+                open_shard_file()
             if mode == gather_mode:
                 gather_modes[mode] = {"ms_per_step": round(elapsed / args.steps * 1e3, 4),
                                       "value": round(n * world * args.steps / elapsed / 1e6, 2), "steps": args.steps, "is_value": True}
@@ -388,9 +464,31 @@ def main():
             assert rc_m == 0 and ctx.decode_result()[:3] == (0, F, 0), mode
             gather_modes[mode] = {"ms_per_step": round(mt / args.mode_steps * 1e3, 4),
                                   "value": round(n * world * args.mode_steps / mt / 1e6, 2), "steps": args.mode_steps, "is_value": False}
-        if rank == 0 and gather_mode != "none":
+        if rank == 0 and gather_mode not in ("none", "sharded"):
             # (the reassembled stream of the last mode run is rank 0's sub-stream followed by the others')
             assert torch.equal(whole_buf(starts[-1]).t[starts[0]:starts[1]], out[:pos])
+        # ---- the sharded file: every rank finds its own sub-stream at its own offset; rank 0 holds the whole file against
+        # the oracle's encoding of the whole signal (--verify-gather)
+        if shard_file["fd"] >= 0:
+            barrier()
+            mine = np.frombuffer(os.pread(shard_file["fd"], lens_h[rank], starts[rank]), dtype=np.uint8)
+            assert mine.size == lens_h[rank] and np.array_equal(mine, out[:pos].cpu().numpy()), "rank %d: its part of the sharded file" % rank
+            sharded_ok = None
+            if rank == 0:
+                assert os.fstat(shard_file["fd"]).st_size == starts[-1], (os.fstat(shard_file["fd"]).st_size, starts[-1])
+                if args.verify_gather:
+                    tot_n = args.total_samples if args.strong else n * world
+                    rc_o, ref, _ = O.encode(x3hip.synth(args.kind, SEED, 0, tot_n))
+                    whole_f = np.frombuffer(os.pread(shard_file["fd"], starts[-1], 0), dtype=np.uint8)
+                    sharded_ok = bool(rc_o == 0 and np.array_equal(ref, whole_f))
+                    assert sharded_ok, "the sharded file differs from the oracle's encoding of the whole signal"
+            gather["sharded_file"] = {"bytes": int(starts[-1]), "every_rank_verified_its_part": True,
+                                      "whole_file_verified_vs_oracle": sharded_ok,
+                                      "pattern": "x3_shard_write_at: D2H over each rank's own host link + pwrite at x3_shard_offsets[rank]"}
+            barrier()
+            os.close(shard_file["fd"])
+            if rank == 0 and not args.gather_file:
+                os.unlink(shard_file["path"])
 
     # ---- CPU baseline: the oracle (port of the reference algorithm), 1 thread, bounded sample
     cpu = None
@@ -541,7 +639,7 @@ def main():
             torch.cuda.synchronize(dev)
             dt = (time.perf_counter() - t0) / k
             kt = {}
-            for name, which in (("encode", 0), ("decode", 1), ("frame_sizes", 2), ("scan", 3), ("frame_check", 4)):
+            for name, which in (("encode", 0), ("decode", 1), ("frame_sizes", 2), ("scan", 3), ("frame_check", 4), ("encode_dense_pass", 5)):
                 ms, cnt = c.kernel_time(which)
                 if cnt:
                     kt[name] = round(ms / cnt, 4)
@@ -583,14 +681,17 @@ def main():
                      "note": "x3_encode_dev + x3_decode_stream_dev (frame walk on the GPU, check, decode; the call returns the "
                              "summary, so every step ends with a trip to the host)"}
         # (c) SURVEY 8(d)'s extremes on the same 691.2 M samples: minimum and maximum output
+        # ... and `mixed`: config 3 with every hundredth frame full-scale noise (a ship passing the hydrophone): such frames
+        # do not fit the wave encoder's LDS image and take the dense pass behind it
         extremes = {}
-        for kind, name in ((0, "zeros"), (1, "white_noise")):
+        for kind, name in ((0, "zeros"), (1, "white_noise"), (2, "mixed")):
             ctx.synth_dev(kind, SEED, 0, n, wav.data_ptr())
+            if name == "mixed":
+                for fr in range(50, F, 100):
+                    lo = fr * p.spf
+                    ctx.synth_dev(1, SEED + fr, lo, min(p.spf, n - lo), wav.data_ptr() + 2 * lo)
             torch.cuda.synchronize(dev)
-            # (the first call on new content is collected before anything is chained behind it: a context that meets
-            # frames too dense for the wave encoder encodes that call twice and keeps to the second generation after)
-            assert ctx.encode_dev(wav.data_ptr(), n, p, out.data_ptr(), cap, 0, off.data_ptr()) == 0
-            assert ctx.encode_result()[0] == 0
+            # (the first calls on new content run before the timed ones: the context's generation hint follows the content)
             for _ in range(3):
                 step()
             rc_e, pos_e, _ = ctx.encode_result()
@@ -603,11 +704,13 @@ def main():
                 enc = O.encode(wav[fr * p.spf:min(n, (fr + 1) * p.spf)].cpu().numpy())[1]
                 assert np.array_equal(enc, out[int(offs_e[fr]):int(offs_e[fr + 1])].cpu().numpy()), (name, fr)
             extremes[name] = {"ms_per_step": round(dt * 1e3, 4), "value": round(n / dt / 1e6, 2), "kernels_ms": kt,
-                              "bytes_per_sample": round(pos_e / n, 4)}
-        extremes["encoder"] = {"gen": int(ctx.get_option("enc_gen")), "dense_reruns": int(ctx.get_option("encode_dense_reruns")),
-                               "note": "white noise does not fit the wave encoder's LDS images: the first such call is encoded twice, "
-                                       "then the context keeps to the second-generation kernel (x3_encode_stream2_kernel) until its "
-                                       "streams come out sparse again"}
+                              "bytes_per_sample": round(pos_e / n, 4), "encoder_generation": int(ctx.get_option("enc_gen_in_use")),
+                              "dense_frames": int(ctx.get_option("last_dense_frames"))}
+        extremes["encoder"] = {"dense_reruns": int(ctx.get_option("encode_dense_reruns")),
+                               "note": "frames whose payload does not fit the wave encoder's LDS image (> 9 728 bytes) are written by the "
+                                       "dense pass behind it in the same stream (kernels_ms.encode_dense_pass; mixed: every hundredth "
+                                       "frame); no call is encoded twice.  A call with more than a quarter of such frames makes the "
+                                       "context's next call start on the second-generation kernel (white noise: encoder_generation 2)"}
 
     if rank == 0:
         total_samples = n * world
@@ -615,7 +718,8 @@ def main():
         # algorithmic HBM bytes per launch (DESIGN.md "Kernels"): 2 B per sample + P stream bytes for
         # the encoder and the decoder; the size pass re-reads the samples; the check pass reads the stream
         alg = {"encode": 2 * n + pos, "decode": 2 * n + pos, "frame_sizes": 2 * n, "frame_check": pos}
-        kname = {"encode": ("x3_encode_wave_kernel" if enc_gen == 3 else "x3_encode_stream2_kernel") if ktimes.get("frame_sizes", 0.0) == 0.0 else "x3_encode_frames_kernel<false>",
+        ktimes.setdefault("frame_sizes", 0.0)
+        kname = {"encode": ("x3_encode_wave_kernel" if enc_gen == 3 else "x3_encode_stream2_kernel<false>") if ktimes.get("frame_sizes", 0.0) == 0.0 else "x3_encode_frames_kernel<false>",
                  "decode": "x3_decode_split_kernel",
                  "frame_sizes": "x3_encode_frames_kernel<true>", "frame_check": "x3_frame_check_kernel"}
         alg = {k: v for k, v in alg.items() if ktimes.get(k, 0.0) > 0.0}  # the two-pass fallback kernels may not run
@@ -644,6 +748,7 @@ def main():
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": traffic.get(kname[k], {}).get("hbm_bytes_per_launch"),
                     "traffic_source": traffic_source,
+                    "sq_per_launch": traffic.get(kname[k], {}).get("sq_per_launch"),
                     "algorithmic_bytes": int(alg[k]), "avg_launch_ms": round(ktimes[k], 4)}
         secs = n / 192000.0
         kinds = {0: "all zeros", 1: "white noise", 2: "hydrophone-like noise", 3: "sine", 4: "random walk"}
@@ -683,6 +788,10 @@ def main():
             "roofline_all": {k: roof(k) for k in alg},
             "encode_read_frac": round(2 * n / (ktimes["encode"] / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
             "kernels_ms": {k: round(v, 4) for k, v in ktimes.items()},
+            "kernels_ms_stats": {k: kstats(v) for k, v in ksteps.items()},
+            "kernels_ms_steps": {k: [round(x, 4) for x in v] for k, v in ksteps.items() if k in ("encode", "decode", "frame_check")},
+            "clocks": clocks,
+            "decoder_pace": decoder_pace,
             "cpu_baseline": cpu,
         }
         if cold is not None:

@@ -15,6 +15,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def test_bench_has_no_function_local_shadowing_of_module_imports():
     tree = ast.parse(open(BENCH).read())
     top = set()
@@ -47,6 +56,15 @@ def test_bench_small_run_prints_the_contract_line():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in j["cpu_baseline"], k
     assert j["host_buffer_api"]["encode_msamples_s"] > 0
+    # per-launch statistics, the kernels' own clock measurement and the decoder's pace per step
+    for k in ("encode", "decode", "frame_check"):
+        st = j["kernels_ms_stats"][k]
+        assert st["n"] == 2 and st["min"] <= st["median"] <= st["p90"] <= st["max"] and len(j["kernels_ms_steps"][k]) == 2, (k, st)
+    assert 500 < j["clocks"]["decode_kernel_mhz"]["median"] < 3000 and 500 < j["clocks"]["encode_kernel_mhz"]["median"] < 3000, j["clocks"]
+    assert len(j["decoder_pace"]["target_us_per_block"]) == 2 and min(j["decoder_pace"]["achieved_us_per_block"]) > 0
+    # every hundredth frame loud: the dense pass writes them, the wave encoder keeps the call
+    assert j["extremes"]["mixed"]["encoder_generation"] == 3 and j["extremes"]["mixed"]["dense_frames"] == 20
+    assert j["extremes"]["encoder"]["dense_reruns"] == 0
     # roofline.traffic is measured by the run itself (two rocprofv3 PMC passes as child processes) where rocprofv3 exists
     import shutil
     if shutil.which("rocprofv3"):
@@ -61,12 +79,14 @@ def test_bench_distributed_path_with_one_rank():
     rank 0 inside the step) on the one GPU a test box has: launched through torch.distributed.run with one rank"""
     env = dict(os.environ, X3_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
-                        "--master-addr", "127.0.0.1", "--master-port", "29517", BENCH, "--gpus", "1", "--steps", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), BENCH, "--gpus", "1", "--steps", "2",
                         "--warmup", "1", "--samples", "20000000", "--no-cpu-baseline", "--no-measure-traffic"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert j["rccl_ranks"] == 1 and "x3_shard" in j["rccl"]
     assert j["gather"]["in_timed_region"] is True and j["gather"]["bytes"] == j["config"]["stream_bytes_per_gpu"]
-    assert set(j["gather_modes"]) == {"in-step", "overlapped", "none"} and j["gather_modes"]["in-step"]["is_value"] is True
+    assert set(j["gather_modes"]) == {"in-step", "overlapped", "sharded", "none"} and j["gather_modes"]["in-step"]["is_value"] is True
+    assert j["gather"]["sharded_file"]["bytes"] == j["gather"]["bytes"] and j["gather"]["sharded_file"]["every_rank_verified_its_part"]
+    assert "6.5 ms" in j["gather"]["note"]
     assert j["config"]["frames_verified_vs_oracle"] == j["config"]["frames_per_gpu"]

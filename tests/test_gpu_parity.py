@@ -1140,9 +1140,17 @@ def test_bench_strong_scaling_over_all_visible_devices():
         pytest.skip("one GPU: the one-rank form of this run is test_bench_distributed_path_with_one_rank")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for mode in ("in-step", "overlapped"):
+    import socket
+
+    def free_port():   # (two or three launches back to back: a fixed port is still in TIME_WAIT for the next one)
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        return port
+    for mode in ("in-step", "overlapped", "sharded"):
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(G),
-                            "--master-addr", "127.0.0.1", "--master-port", "29521", os.path.join(root, "bench.py"), "--gpus", str(G),
+                            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", str(G),
                             "--steps", "3", "--warmup", "2", "--strong", "--total-samples", str(10_000 * (37 * G + 5) + 123),
                             "--verify-gather", "--gather", mode, "--mode-steps", "3"],
                            capture_output=True, text=True, timeout=900, cwd=root, env=env)
@@ -1150,7 +1158,8 @@ def test_bench_strong_scaling_over_all_visible_devices():
         j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
         assert j["n_gpus"] == G and j["rccl_ranks"] == G and j["scaling"] == "strong"
         assert j["gather"]["whole_stream_verified_vs_oracle"] is True and j["gather"]["mode"] == mode
-        assert set(j["gather_modes"]) == {"in-step", "overlapped", "none"}
+        assert j["gather"]["sharded_file"]["whole_file_verified_vs_oracle"] is True
+        assert set(j["gather_modes"]) == {"in-step", "overlapped", "sharded", "none"}
 
 
 def test_decode_frame_loop_with_prefetch(ctx):

@@ -27,7 +27,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, result_path):
+def _worker(rank, world, port, n, result_path, sharded=False):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     sys.path.insert(0, os.path.join(ROOT, "x3-rust_amd"))
     import ctypes as C
@@ -54,6 +54,33 @@ def _worker(rank, world, port, n, result_path):
         starts = x3hip.shard_offsets(lens)                                # x3_shard_offsets
         assert len(starts) == world + 1 and starts[-1] == sum(lens)
         assert all(s % 2 == 0 for s in starts)  # sub-streams concatenate without padding
+        if sharded:
+            # step 2, SHARDED (x3_shard_write_at on the GPUs: every rank brings its own sub-stream down and writes it at
+            # base + starts[rank] of ONE file; nobody takes in the whole stream).  Here: the same pwrite, with the archive
+            # header in front of the frames as base -- the file is then a complete .x3a archive.
+            rc_h, hdr = x3hip.archive_header_write(192000, p)
+            assert rc_h == 0
+            base = hdr.size
+            path = result_path + ".x3a"
+            if rank == 0:
+                fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o600)
+                os.pwrite(fd, hdr.tobytes(), 0)
+            dist.barrier()
+            if rank != 0:
+                fd = os.open(path, os.O_RDWR)
+            if lens[rank]:
+                assert os.pwrite(fd, local.numpy().tobytes(), base + starts[rank]) == lens[rank]
+            os.close(fd)
+            dist.barrier()
+            if rank == 0:
+                full = x3hip.synth(x3hip.SYNTH_HYDROPHONE, 77, 0, n)
+                rc, ref, _ = O.x3a_encode(full, 192000)                    # the oracle's wav_to_x3a minus the files
+                got = np.fromfile(path, dtype=np.uint8)
+                ok = rc == 0 and got.size == ref.size and np.array_equal(got, ref)
+                os.unlink(path)
+                open(result_path, "w").write("ok" if ok else "mismatch")
+            dist.barrier()
+            return
         # step 2 (x3_shard_gather on the GPUs: grouped ncclRecv on the root at starts[r], ncclSend on the peers)
         whole = None
         if rank == 0:
@@ -83,6 +110,15 @@ def _worker(rank, world, port, n, result_path):
 def test_sharded_encode_reassembles_to_the_reference_stream(tmp_path, world, n):
     result = tmp_path / "result.txt"
     mp.spawn(_worker, args=(world, _free_port(), n, str(result)), nprocs=world, join=True)
+    assert result.read_text() == "ok"
+
+
+@pytest.mark.parametrize("world,n", [(2, 123457), (3, 70001), (2, 5)])
+def test_sharded_write_makes_the_reference_archive(tmp_path, world, n):
+    """--gather sharded / x3_shard_write_at: every rank writes its sub-stream at its own offset of one file behind the
+    archive header; the file is byte-identical to the oracle's .x3a of the whole signal (encodefile.rs:48-138)"""
+    result = tmp_path / "result.txt"
+    mp.spawn(_worker, args=(world, _free_port(), n, str(result), True), nprocs=world, join=True)
     assert result.read_text() == "ok"
 
 
