@@ -114,7 +114,6 @@ const char* x3_last_error(const x3_ctx* ctx);
  *                                           (pageable copies hold their caller); the results are the same either way.
  *   "file_chunk_frames" (X3HIP_FILE_CHUNK_FRAMES), "file_workers" (X3HIP_FILE_WORKERS)   x3_wav_to_x3a / x3_x3a_to_wav
  *   "reader_window_frames" (X3HIP_READER_WINDOW_FRAMES)   frames x3_reader decodes ahead per launch set
- *   "stream_v1" (X3HIP_STREAM_V1)          1: the first-generation single-pass encoder kernel
  *   "check_main" (X3HIP_CHECK_MAIN)        1: the check pass on the context's stream, the decoder on the side stream (experiment)
  *   "check_wgs", "check_prio", "check_first"   grid, queue priority and launch order of the check pass (experiments)
  *   "verbose" (X3HIP_VERBOSE)

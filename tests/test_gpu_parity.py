@@ -200,8 +200,9 @@ def test_encode_largest_single_pass_frames(ctx, x3, bpf):
     for sp in (0, 2):
         out = check_encode(ctx, x3, wav, p, start_pos=sp)
     check_decode(ctx, x3, out[2:], p)
-    with _opt(ctx, stream_v1=1):                 # the first-generation single-pass kernel has the same pass
+    with _opt(ctx, enc_gen=2):                   # the second-generation single-pass kernel has the same pass
         check_encode(ctx, x3, wav, p)
+    ctx.set_option("enc_gen", 3)
 
 
 @pytest.mark.parametrize("codes,thr", [((0, 1, 3), (3, 8, 20)), ((0, 1, 2), (3, 8, 18)), ((1, 2, 3), (5, 10, 25)),

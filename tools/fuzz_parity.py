@@ -124,13 +124,13 @@ def fam_e(rng, tag):
     n = max(1, spf * frames - int(rng.integers(0, spf)) + int(rng.integers(0, 3)))
     wav = content(rng, n)
     sp = int(rng.choice([0, 0, 1, 2, 3, 18]))
-    v1 = rng.random() < 0.25
-    ctx.set_option("stream_v1", 1 if v1 else 0)
+    g2 = rng.random() < 0.25   # (a quarter of the trials on the second-generation kernel: it also serves the dense pass)
+    ctx.set_option("enc_gen", 2 if g2 else 3)
     try:
         cut = float(rng.uniform(0.0, 0.3)) if rng.random() < 0.1 else None
-        rc, out = cmp_encode(wav, p, sp, (tag, "e", bpf, n, sp, v1, cut), cut)
+        rc, out = cmp_encode(wav, p, sp, (tag, "e", bpf, n, sp, g2, cut), cut)
     finally:
-        ctx.set_option("stream_v1", 0)
+        ctx.set_option("enc_gen", 3)
     if rc == 0:
         r = cmp_decode(out[(sp + 1) & ~1:], p, n, (tag, "e-dec", bpf, n))
         assert r[0] == 0 and np.array_equal(r[1], wav), (tag, "round trip")
@@ -416,7 +416,7 @@ def run(seed=1, minutes=None, trials=None, families="egdbaf", only=-1, context=N
         if own:
             ctx.close()
         else:  # a borrowed context goes back with the options the families touch at their defaults
-            for name, value in (("reader_window_frames", 4096), ("stream_v1", 0), ("host_walk", -1), ("host_chunk_frames", 0),
+            for name, value in (("reader_window_frames", 4096), ("enc_gen", 3), ("host_walk", -1), ("host_chunk_frames", 0),
                                 ("file_chunk_frames", 800), ("file_workers", 4)):
                 ctx.set_option(name, value)
         ctx = None

@@ -26,7 +26,6 @@
 #include "x3_index_kernels.h"
 #include "x3_device.h"
 #include "x3_encode_kernel.h"
-#include "x3_encode_stream_kernel.h"
 #include "x3_encode_stream2_kernel.h"
 #include "x3_encode_wave_kernel.h"
 #include "x3_synth_core.h"
@@ -49,7 +48,6 @@ struct KernelTimer {
 struct X3Opts {
   int two_pass = 0;           // X3HIP_TWO_PASS: always use the two-pass encoder kernels
   int stream_wgs = 0;         // X3HIP_STREAM_WGS: workgroups per CU of the single-pass encoder (0 = derive)
-  int stream_v1 = 0;          // X3HIP_STREAM_V1: the first-generation single-pass encoder (9 waves, LDS sample tile)
   int enc_gen = 3;            // X3HIP_ENC_GEN: 3 = one wave per frame (x3_encode_wave_kernel.h), 2 = eight waves per frame
   int wave_nwg = 0;           // X3HIP_WAVE_NWG: workgroups of the wave encoder (0 = one per CU, at most 256) -- tests: many generations on small inputs
   int wave_m = 0;             // X3HIP_WAVE_M: frames per workgroup generation (0 = derive, 1..16)
@@ -87,7 +85,6 @@ struct x3_ctx {
   std::string last_error;
   // persistent small device state
   uint16_t* d_xpow = nullptr;          // X3_XP_SIZE entries
-  uint32_t* d_xk16 = nullptr;          // [11][512][16]: x^(32*c*(511-t)) * x^b mod P (x3_encode_stream_kernel.h)
   uint32_t* d_xk2 = nullptr;           // [X3_K2_MAXC][X3_K2_DWORDS]: per-lane and per-wave multipliers (x3_encode_stream2_kernel.h)
   uint32_t* d_wtab = nullptr;          // X3W_TAB_BYTES: the LDS tables of x3_encode_wave_kernel
   uint16_t* d_crctab = nullptr;        // [6][256]: slicing-by-4 CRC tables + the two x^2048 rows
@@ -118,7 +115,7 @@ struct x3_ctx {
   DevBuf idx_cand, idx_keys, idx_vals, idx_J, idx_S, idx_L, idx_sum;  // x3_index_dev scratch
   int n_cus = 0;
   bool force_single_wave_decode = false;
-  uint32_t desc_epoch = 0;    // tag of the current launch's frame-size descriptors (x3_encode_stream_kernel)
+  uint32_t desc_epoch = 0;    // tag of the current launch's frame-size descriptors (single-pass encoders)
   int stream_wg_per_cu = -1;  // co-resident workgroups per CU of x3_encode_stream_kernel (-1 = not queried)
   // bookkeeping of the last async calls
   bool encode_pending = false, decode_pending = false;
@@ -195,7 +192,6 @@ static void opts_from_env(X3Opts* o) {
   o->two_pass = std::getenv("X3HIP_TWO_PASS") ? 1 : 0;
   o->stream_wgs = (int)std::max(0ll, geti("X3HIP_STREAM_WGS", 0));
   o->decode_single = std::getenv("X3HIP_DECODE_SINGLE") ? 1 : 0;
-  o->stream_v1 = std::getenv("X3HIP_STREAM_V1") ? 1 : 0;
   o->enc_gen = (int)geti("X3HIP_ENC_GEN", o->enc_gen) == 2 ? 2 : 3;
   o->wave_nwg = (int)std::max(0ll, std::min(256ll, geti("X3HIP_WAVE_NWG", 0)));
   o->wave_m = (int)std::max(0ll, std::min(16ll, geti("X3HIP_WAVE_M", 0)));
@@ -282,18 +278,6 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
   }
   HIPCHK(c, hipMemcpy(c->d_xpow, xp.data(), X3_XP_SIZE * sizeof(uint16_t), hipMemcpyHostToDevice));
   {
-    // (chunk sizes 1..11: 512 blocks of literals are 5 207 payload dwords, a little over ten per thread)
-    std::vector<uint32_t> xk((size_t)11 * 512 * 16);
-    for (int cd = 1; cd <= 11; ++cd)
-      for (int t = 0; t < 512; ++t) {
-        uint32_t k = gf_xpow_host(32ull * cd * (511 - t));
-        for (int b = 0; b < 16; ++b) {
-          xk[((size_t)(cd - 1) * 512 + t) * 16 + b] = k;
-          k = ((k << 1) ^ ((k & 0x8000u) ? 0x11021u : 0u)) & 0xFFFFu;
-        }
-      }
-    HIPCHK(c, hipMalloc(&c->d_xk16, xk.size() * sizeof(uint32_t)));
-    HIPCHK(c, hipMemcpy(c->d_xk16, xk.data(), xk.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     {
       // x3_encode_stream2_kernel: KN[l] = nibble tables of x^(32*c*(63-l)), KA[w] = x^(32*c*64*(7-w)) as its sixteen shifts
       std::vector<uint32_t> k2((size_t)X3_K2_MAXC * X3_K2_DWORDS, 0u);
@@ -427,7 +411,6 @@ extern "C" void x3_ctx_destroy(x3_ctx* c) {
     for (auto& e : t.pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   }
   (void)hipFree(c->d_xpow);
-  (void)hipFree(c->d_xk16);
   (void)hipFree(c->d_xk2);
   (void)hipFree(c->d_wtab);
   (void)hipFree(c->d_crctab);
@@ -466,7 +449,6 @@ extern "C" int x3_ctx_set_option(x3_ctx* c, const char* name, long long value) {
   if (n == "two_pass") c->opt.two_pass = value != 0;
   else if (n == "stream_wgs") { c->opt.stream_wgs = (int)std::max(0ll, value); c->stream_wg_per_cu = -1; }
   else if (n == "decode_single") c->opt.decode_single = value != 0;
-  else if (n == "stream_v1") { c->opt.stream_v1 = value != 0; c->stream_wg_per_cu = -1; }
   else if (n == "enc_gen") { c->opt.enc_gen = value == 2 ? 2 : 3; c->prefer_gen2 = false; }
   else if (n == "wave_nwg") c->opt.wave_nwg = (int)std::max(0ll, std::min(256ll, value));
   else if (n == "wave_m") c->opt.wave_m = (int)std::max(0ll, std::min(16ll, value));
@@ -490,7 +472,6 @@ extern "C" int x3_ctx_get_option(const x3_ctx* c, const char* name, long long* v
   if (n == "two_pass") *value = c->opt.two_pass;
   else if (n == "stream_wgs") *value = c->opt.stream_wgs;
   else if (n == "decode_single") *value = c->opt.decode_single;
-  else if (n == "stream_v1") *value = c->opt.stream_v1;
   else if (n == "enc_gen") *value = c->opt.enc_gen;
   else if (n == "encode_dense_reruns") *value = 0;  // (rounds 2-3: whole calls encoded again for a dense frame; no longer happens)
   else if (n == "encode_dense_frames") *value = (long long)c->encode_dense_frames;  // read-only: frames the dense pass has written
@@ -906,7 +887,7 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
     d_off = (uint64_t*)c->frame_off.p;
   }
   HIPCHK(c, hipMemsetAsync(c->d_status, 0, 128, c->stream));
-  // ---- single-pass path: default block length, 16-byte aligned frames (see x3_encode_stream_kernel.h)
+  // ---- single-pass path: default block length, 16-byte aligned frames (see x3_encode_stream2_kernel.h)
   const bool stream_path = p->block_len == 20 && pl.nthr == 512 && (std::min<uint64_t>(spf, b->n_per_clip) + 18) / 20 <= 512 &&
                            (spf % 8) == 0 &&
                            (b->n_clips == 1 || (b->clip_stride % 8) == 0) &&
@@ -915,7 +896,7 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
   // part + two worst-case frame images + CRC tables + the multipliers of one chunk size (x3_encode_stream2_kernel.h)
   const size_t smem2 = X3_ENC_SMEM_HDR + 2 * (size_t)pl.img_dwords * 4 + 2048 + X3_K2_DWORDS * 4;
   c->last_enc_gen = 0;
-  if (stream_path && !c->opt.stream_v1 && c->opt.enc_gen == 3 && c->opt.stream_wgs == 0 &&
+  if (stream_path && c->opt.enc_gen == 3 && c->opt.stream_wgs == 0 &&
       stream_safe_thresholds(p) && smem2 <= 160 * 1024) {
     if (c->prefer_gen2) {
       // the last call's content was mostly dense: the second generation, until it counts few dense frames again
@@ -992,7 +973,7 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
       return X3_OK;
     }
   }
-  if (stream_path && !c->opt.stream_v1 && stream_safe_thresholds(p)) {
+  if (stream_path && stream_safe_thresholds(p)) {
     // second generation (x3_encode_stream2_kernel.h): eight waves, no sample tile in LDS
     if (c->stream_wg_per_cu < 0) {
       // Offsets wait on the other workgroups' frame sizes, so EVERY workgroup of the grid must be resident.  The
@@ -1039,62 +1020,6 @@ static int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, c
       }
       HIPCHK(c, hipGetLastError());
       c->last_enc_gen = 2;
-      c->encode_pending = true;
-      c->enc_start_pos = start_pos;
-      return X3_OK;
-    }
-  }
-  if (stream_path && c->opt.stream_v1) {
-    if (c->stream_wg_per_cu < 0) {
-      // Offsets wait on the other workgroups' frame sizes, so EVERY workgroup of the grid must be resident.  The
-      // occupancy API can over-report by one block per CU (MI355X_MICROARCH.md, "Residency"), so it is
-      // capped by a conservative count from the kernel's own register/LDS footprint: 9 waves per
-      // workgroup land unevenly on the 4 SIMDs, hence the slack of 3 waves.
-      int nb = 0;
-      HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, x3_encode_stream_kernel, X3_STREAM_THREADS,
-                                                             pl.smem + (size_t)pl.img_dwords * 4 + 2048));
-      hipFuncAttributes fa;
-      HIPCHK(c, hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&x3_encode_stream_kernel)));
-      const int alloc = ((fa.numRegs + 7) / 8) * 8;
-      const int wps = std::min(8, 512 / std::max(alloc, 8));
-      // 9-wave workgroups on 4 SIMDs of wps slots each, with slack for their uneven placement.  (LDS is the
-      // binding limit: two frame images sized for an all-literal frame.)
-      const int by_regs = (4 * wps - 3) / 9;
-      const int by_lds = (int)((160 * 1024) / (pl.smem + (size_t)pl.img_dwords * 4 + 2048));
-      c->stream_wg_per_cu = std::max(0, std::min(std::min(nb, 4), std::min(by_regs, by_lds)));
-      // experiments and the fallback test: force a grid (one that is too large cannot be resident: the size
-      // waits time out and x3_encode_result re-encodes with the two-pass kernels)
-      if (c->opt.stream_wgs > 0) c->stream_wg_per_cu = c->opt.stream_wgs;
-      if (c->opt.verbose)
-        std::fprintf(stderr, "x3hip: stream encoder %d VGPRs, occupancy API %d, by_regs %d, by_lds %d -> %d workgroups/CU\n",
-                     fa.numRegs, nb, by_regs, by_lds, c->stream_wg_per_cu);
-    }
-    const size_t stream_smem = pl.smem + (size_t)pl.img_dwords * 4 + 2048;  // + second frame image + CRC tables
-    if (c->stream_wg_per_cu >= 1 && stream_smem <= 64 * 1024) {
-      // frame-size descriptors {epoch:12 | bytes:20}: the epoch makes last launch's words "not ready"
-      // without clearing the array (cleared when it is (re)allocated and when the epoch wraps)
-      // persistent grid: every workgroup must be resident (offsets wait on the other workgroups' sizes)
-      const uint64_t grid = std::min<uint64_t>(F, (uint64_t)c->n_cus * c->stream_wg_per_cu);
-      // words in front of desc[0]: the windows of the first frames reach below frame 0 -- eight windows (512)
-      // always, and (grid - 1) rounded up to whole windows when the grid is wider than that
-      const size_t desc_pad = std::max<size_t>(X3_DESC_PAD, (size_t)grid + 64);
-      const size_t desc_bytes = (F + desc_pad) * sizeof(uint32_t);
-      const bool fresh = c->desc.cap < desc_bytes;
-      if ((rc = ensure(c, c->desc, desc_bytes))) return rc;
-      if (fresh || ++c->desc_epoch > 0xFFFu) {
-        HIPCHK(c, hipMemsetAsync(c->desc.p, 0, c->desc.cap, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_pace + 4, 0, 16, c->stream));
-        c->desc_epoch = 1;
-      }
-      {
-        TimerScope ts(c, 0);
-        hipLaunchKernelGGL(x3_encode_stream_kernel, dim3((unsigned)grid), dim3(X3_STREAM_THREADS), stream_smem, c->stream,
-                           d_wav, pl.g, pl.dp, d_off, d_out, out_cap, start_pos, (uint32_t*)c->desc.p + desc_pad, c->desc_epoch,
-                           c->d_stats, c->d_status, c->d_end_pos, (const uint32_t*)c->d_xk16,
-                           (const uint16_t*)c->d_crctab, pl.lds_in_bytes, pl.img_dwords);
-      }
-      HIPCHK(c, hipGetLastError());
-      c->last_enc_gen = 1;
       c->encode_pending = true;
       c->enc_start_pos = start_pos;
       return X3_OK;

@@ -1,6 +1,6 @@
 // x3_encode_stream2_kernel.h -- single-pass frame encoder for block_len = 20, second generation.
 //
-// Same single pass as x3_encode_stream_kernel.h (persistent co-resident grid, frame f = blockIdx.x + k*G, stream
+// Same single pass as round 1's first-generation kernel (retired in round 4; persistent co-resident grid, frame f = blockIdx.x + k*G, stream
 // offsets from the frame sizes every workgroup publishes as {epoch:12 | bytes:20} words -- no prefix chain, HBM
 // traffic = 2 B/sample in + stream bytes out), restructured around what bounded the first one (profiles/r1:
 // 303 M VALU + 112 M SALU per launch at 68 % VALU-busy, two 9-wave workgroups per CU):
@@ -33,7 +33,7 @@
 #pragma once
 #include <type_traits>
 
-#include "x3_encode_stream_kernel.h"
+#include "x3_encode_common.h"
 
 #ifndef X3E_PACE_CLIMB
 #define X3E_PACE_CLIMB 1
@@ -383,7 +383,7 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
 
     uint32_t S[10];   // emission source per pair of block samples
     uint32_t type = 0, ft = 0, nb = 0, nbits = 0;
-    uint32_t amask = 0, orc = 0, qsh = 0, qmask = 0, lbase = 0;  // (code,len) recipe, see x3_encode_stream_kernel.h
+    uint32_t amask = 0, orc = 0, qsh = 0, qmask = 0, lbase = 0;  // (code,len) recipe, see x3_encode_common.h
     if (cnt) {
       uint32_t mn = 0, mx = 0;
       // (two copies of the loop behind ONE wave-uniform branch: left inside the loop, hipcc turns the test into

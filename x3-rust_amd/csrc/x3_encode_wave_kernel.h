@@ -28,7 +28,7 @@
 //    last row are undone by one multiplication with x^(-8 z): no per-size tables;
 //  * stream offsets: the sixteen frames of a workgroup's generation are CONSECUTIVE frames; their sizes meet in LDS
 //    (slot + arrival counter, the last arriver publishes the generation's total as one {epoch:12 | bytes:20} word),
-//    and a generation's base is its predecessor's base plus the <= 256 totals in between (x3_encode_stream_kernel.h's
+//    and a generation's base is its predecessor's base plus the <= 256 totals in between (the second-generation kernel's
 //    scheme, one level up).  A wave asks for those words when its emission is done and prefetches the next frame's
 //    samples behind the request.
 //
@@ -256,7 +256,7 @@ __device__ __forceinline__ void x3w_emit(const uint32_t (&W)[41], uint32_t meta,
     const uint32_t kq = lbase - rice;
     e.put(meta & 63u, rice ? 2u : 6u);
     // (code, len) of a sample v: ((v & amask) | orc, (v >> kq) * rice + lbase) -- both samples of a pair at once in
-    // packed 16-bit arithmetic, the halves combined with SDWA operand selects (x3_encode_stream_kernel.h)
+    // packed 16-bit arithmetic, the halves combined with SDWA operand selects (x3_encode_common.h)
     const uint32_t qsh2 = kq * 0x10001u, lbase2 = lbase * 0x10001u, qmul2 = rice * 0x10001u;
     const uint32_t amask2 = ((1u << kq) - 1u) * 0x10001u, orc2 = (rice << kq) * 0x10001u;
     const uint32_t last_on = cnt == 20u ? 0xFFFFFFFFu : 0x0000FFFFu;
