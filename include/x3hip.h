@@ -365,12 +365,20 @@ typedef struct x3_batch {
 /* Encode a device-resident batch into d_out[0..out_cap) starting at start_pos (even or odd; an
  * odd start is zero-padded to even as the reference does).  d_frame_offsets (may be NULL)
  * receives F+1 byte offsets: frame f occupies [d_frame_offsets[f], d_frame_offsets[f+1]).
- * Asynchronous; results via x3_encode_result().  The default-geometry encoder is a persistent grid whose
- * workgroups wait for each other's frame sizes; on a GPU that this context does not have to itself a launch
- * can find them not all resident, gives up after a bounded wait, and x3_encode_result() then re-encodes with
- * the general kernels: take the status from x3_encode_result() before the stream is trusted (launching
- * x3_decode_dev on the same context in between is fine -- same stream -- as long as its result is only used
- * after x3_encode_result() returned X3_OK). */
+ * Asynchronous; results via x3_encode_result().
+ *   Content: frames whose payload does not fit the wave encoder's LDS image (more than 9 728 bytes: loud or noisy
+ * material) are written by a dense pass that follows the encode kernel IN THE SAME STREAM, at the offsets that kernel
+ * assigned -- whatever is enqueued on the context's stream behind this call (x3_decode_dev, a copy) finds the whole
+ * stream, with or without x3_encode_result() in between; no call is encoded twice for its content (until round 3 the
+ * whole call was encoded again inside x3_encode_result).  Options "last_dense_frames", "encode_dense_frames" count such
+ * frames, "enc_gen_in_use" says which kernel generation served the last call (a call with more than a quarter of dense
+ * frames makes the context's next call start on the second-generation kernel: a speed hint, the bytes are the same).
+ *   Residency: the default-geometry encoder is a persistent grid whose workgroups wait for each other's frame
+ * sizes; on a GPU that this context does not have to itself a launch can find them not all resident, gives up after a
+ * bounded wait, and x3_encode_result() then re-encodes with the general kernels (option "encode_fallbacks" counts
+ * these).  That re-run reads d_wav again and rewrites d_out[start_pos ..): d_wav and d_out must stay untouched until
+ * x3_encode_result() has returned, and the stream is only trusted once it has returned X3_OK (launching x3_decode_dev
+ * on the same context in between is fine -- same stream -- as long as its result is only used after that). */
 int x3_encode_dev(x3_ctx* ctx, const int16_t* d_wav, const x3_batch* batch, const x3_params* p,
                   uint8_t* d_out, uint64_t out_cap, uint64_t start_pos, uint64_t* d_frame_offsets);
 /* Waits for the last x3_encode_dev; status is X3_OK, BYTE_WRITER_INSUFFICIENT_MEMORY or BAD_ARG. */

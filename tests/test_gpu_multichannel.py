@@ -38,6 +38,21 @@ def test_one_channel_is_the_mono_stream(ctx, n):
     assert (rcd, ferr) == (0, 0) and np.array_equal(back[0], wav)
 
 
+def test_one_channel_with_long_dense_frames(ctx):
+    """C = 1 with frames whose payload passes the 24 KB that only counts for several channels (blocks_per_frame 1 000 of
+    full-scale noise: ~40 KB): x3_encode's bytes, not BAD_ARG"""
+    p = x3hip.Params.default()
+    p.blocks_per_frame = 1000
+    po = O.Params.default()
+    po.blocks_per_frame = 1000
+    wav = x3hip.synth(1, 9, 0, 20000 * 3 + 777)
+    rc, mono, st = ctx.encode(wav, p)
+    rc_o, mono_o, st_o = O.encode(wav, po)
+    rcm, mc, stm = ctx.encode_mc([wav], p)
+    assert rc == rc_o == rcm == 0
+    assert np.array_equal(mono, mono_o) and np.array_equal(mc, mono) and st.tolist() == stm.tolist() == st_o.tolist()
+
+
 @pytest.mark.parametrize("n_ch", [2, 3, 4, 8])
 @pytest.mark.parametrize("n,bpf", [(30001, 500), (4000, 100), (1, 500), (20, 50), (250123, 250)])
 def test_channels_match_the_oracle(ctx, n_ch, n, bpf):

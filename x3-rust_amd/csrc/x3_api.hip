@@ -56,7 +56,8 @@ struct X3Opts {
   int decode_single = 0;      // X3HIP_DECODE_SINGLE: single-wave decoder kernels only
   int host_walk = -1;         // X3HIP_HOST_WALK: frame walk of x3_decode_stream on the host (1) / GPU (0) / by size (-1)
   long long host_chunk_frames = 0;  // X3HIP_HOST_CHUNK_FRAMES: x3_encode on host buffers takes a long input in chunks of this many
-                              // frames, upload / encode / download side by side (0 = 32 MiB of samples, -1 = one piece)
+                              // frames, upload / encode / download side by side (0 = chunks of 16 Mi samples for inputs from
+                              // 32 Mi samples on, -1 = one piece)
   int verbose = 0;            // X3HIP_VERBOSE
   long long file_chunk_frames = 800;  // X3HIP_FILE_CHUNK_FRAMES: 16 MB of samples per chunk (tools/file_bench.py)
   int file_workers = 4;       // X3HIP_FILE_WORKERS
@@ -1240,24 +1241,32 @@ static int encode_host_chunked(x3_ctx* c, const int16_t* wav, uint64_t n, const 
   int16_t* d_in = (int16_t*)c->in.p;
   std::thread uploader, downloader;
   try {
+  // (the helper threads never let an exception out -- that would be std::terminate, and x3hip.h promises that the library
+  // does not abort: whatever is thrown in them ends the pipeline with an error -- ADVICE r3)
   uploader = std::thread([&] {
-    hipError_t e = hipSetDevice(c->device);
-    for (uint64_t s0 = 0; s0 < n && e == hipSuccess; s0 += chunk) {
-      { std::lock_guard<std::mutex> g(up.mu); if (up.stop) return; }
-      e = hipMemcpyAsync(d_in + s0, wav + s0, std::min<uint64_t>(chunk, n - s0) * sizeof(int16_t), hipMemcpyHostToDevice, c->ul_stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(c->ul_stream);
-      if (e == hipSuccess) up.advance();
-    }
+    hipError_t e = hipSuccess;
+    try {
+      e = hipSetDevice(c->device);
+      for (uint64_t s0 = 0; s0 < n && e == hipSuccess; s0 += chunk) {
+        { std::lock_guard<std::mutex> g(up.mu); if (up.stop) return; }
+        e = hipMemcpyAsync(d_in + s0, wav + s0, std::min<uint64_t>(chunk, n - s0) * sizeof(int16_t), hipMemcpyHostToDevice, c->ul_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->ul_stream);
+        if (e == hipSuccess) up.advance();
+      }
+    } catch (...) { e = hipErrorOutOfMemory; }
     if (e != hipSuccess) { up_err = e; up.halt(); }
   });
   downloader = std::thread([&] {
-    hipError_t e = hipSetDevice(c->device);
-    Piece pc;
-    while (down.pop(&pc)) {
-      if (e != hipSuccess) continue;  // (drain)
-      e = hipMemcpyAsync(out + pc.lo, (const uint8_t*)c->out.p + pc.lo, pc.hi - pc.lo, hipMemcpyDeviceToHost, c->dl_stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(c->dl_stream);
-    }
+    hipError_t e = hipSuccess;
+    try {
+      e = hipSetDevice(c->device);
+      Piece pc;
+      while (down.pop(&pc)) {
+        if (e != hipSuccess) continue;  // (drain)
+        e = hipMemcpyAsync(out + pc.lo, (const uint8_t*)c->out.p + pc.lo, pc.hi - pc.lo, hipMemcpyDeviceToHost, c->dl_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->dl_stream);
+      }
+    } catch (...) { e = hipErrorOutOfMemory; }
     dl_err = e;
   });
   } catch (const std::system_error&) {  // no thread to be had: the call goes through in one piece
@@ -1269,22 +1278,29 @@ static int encode_host_chunked(x3_ctx* c, const int16_t* wav, uint64_t n, const 
   x3_params pp = *p;
   uint64_t pos = start_pos, k = 0;
   bool halted = false;
-  for (uint64_t s0 = 0; s0 < n && rc == X3_OK; s0 += chunk, ++k) {
-    if (!up.wait_for(k + 1)) { halted = true; break; }
-    const uint64_t cnt = std::min<uint64_t>(chunk, n - s0);
-    x3_batch b{cnt, cnt, 1};
-    uint64_t st[6] = {0, 0, 0, 0, 0, 0}, end = pos;
-    {
-      std::unique_lock<std::mutex> gate;
-      if (c->enc_gate) gate = std::unique_lock<std::mutex>(*c->enc_gate);
-      rc = encode_dev_impl(c, d_in + s0, &b, &pp, spf, (uint8_t*)c->out.p, out_cap, pos, nullptr);
-      if (rc == X3_OK) rc = x3_encode_result(c, &end, st);
+  // (nothing thrown between here and the joins may leave this frame: a joinable std::thread that is destroyed calls
+  // std::terminate.  The hand-off's push allocates; everything else reports through return codes.)
+  try {
+    for (uint64_t s0 = 0; s0 < n && rc == X3_OK; s0 += chunk, ++k) {
+      if (!up.wait_for(k + 1)) { halted = true; break; }
+      const uint64_t cnt = std::min<uint64_t>(chunk, n - s0);
+      x3_batch b{cnt, cnt, 1};
+      uint64_t st[6] = {0, 0, 0, 0, 0, 0}, end = pos;
+      {
+        std::unique_lock<std::mutex> gate;
+        if (c->enc_gate) gate = std::unique_lock<std::mutex>(*c->enc_gate);
+        rc = encode_dev_impl(c, d_in + s0, &b, &pp, spf, (uint8_t*)c->out.p, out_cap, pos, nullptr);
+        if (rc == X3_OK) rc = x3_encode_result(c, &end, st);
+      }
+      if (rc != X3_OK) break;
+      if (stats)
+        for (int i = 0; i < 6; ++i) stats[i] += st[i];
+      if (end > pos) down.push({pos, end});
+      pos = end;
     }
-    if (rc != X3_OK) break;
-    if (stats)
-      for (int i = 0; i < 6; ++i) stats[i] += st[i];
-    if (end > pos) down.push({pos, end});
-    pos = end;
+  } catch (...) {
+    c->last_error = "x3_encode: out of host memory in the chunked pipeline";
+    rc = X3_ERR_HIP;
   }
   up.halt();
   down.close();
@@ -1840,7 +1856,9 @@ static int decode_stream_host_chunked(x3_ctx* c, const uint8_t* x3, uint64_t len
   std::thread uploader, downloader;
   try {
   uploader = std::thread([&] {
-    hipError_t e = hipSetDevice(c->device);
+    hipError_t e = hipSuccess;
+    try {
+    e = hipSetDevice(c->device);
     uint64_t a = 0, sample_off = 0;
     for (uint64_t k = 0; e == hipSuccess; ++k) {
       { std::lock_guard<std::mutex> g(decoded.mu); if (decoded.stop) break; }
@@ -1880,19 +1898,23 @@ static int decode_stream_host_chunked(x3_ctx* c, const uint8_t* x3, uint64_t len
       ready.push(std::move(ck));
       if (last) break;
     }
+    } catch (...) { e = hipErrorOutOfMemory; }   // (walk_host's vectors, the hand-off: never std::terminate -- ADVICE r3)
     up_err = e;
     ready.close();
   });
   downloader = std::thread([&] {
-    hipError_t e = hipSetDevice(c->device);
-    Piece pc;
-    while (down.pop(&pc)) {
-      if (e == hipSuccess && pc.count) {
-        e = hipMemcpyAsync(wav + pc.sample_off, pc.src, pc.count * sizeof(int16_t), hipMemcpyDeviceToHost, c->dl_stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->dl_stream);
+    hipError_t e = hipSuccess;
+    try {
+      e = hipSetDevice(c->device);
+      Piece pc;
+      while (down.pop(&pc)) {
+        if (e == hipSuccess && pc.count) {
+          e = hipMemcpyAsync(wav + pc.sample_off, pc.src, pc.count * sizeof(int16_t), hipMemcpyDeviceToHost, c->dl_stream);
+          if (e == hipSuccess) e = hipStreamSynchronize(c->dl_stream);
+        }
+        landed.advance();
       }
-      landed.advance();
-    }
+    } catch (...) { e = hipErrorOutOfMemory; landed.halt(); }
     dl_err = e;
   });
   } catch (const std::system_error&) {  // no thread to be had: the caller takes the stream in one piece
@@ -1904,6 +1926,7 @@ static int decode_stream_host_chunked(x3_ctx* c, const uint8_t* x3, uint64_t len
   int result = X3_OK;
   bool ended = false;
   Chunk ck;
+  try {   // (as in encode_host_chunked: nothing thrown may pass the joins below)
   while (!ended && ready.pop(&ck)) {
     const uint64_t F = ck.hw.offs.size();
     uint64_t before = 0, first_bad = 0;
@@ -1932,8 +1955,12 @@ static int decode_stream_host_chunked(x3_ctx* c, const uint8_t* x3, uint64_t len
     total = ck.sample_off + before;
     ended = first_bad < F || !ck.hw.need_more;
   }
+  } catch (...) {
+    c->last_error = "x3_decode_stream: out of host memory in the chunked pipeline";
+    rc = X3_ERR_HIP;
+  }
   decoded.halt();  // (an uploader that waits for a decode that will not come)
-  while (ready.pop(&ck)) {}
+  try { while (ready.pop(&ck)) {} } catch (...) {}
   down.close();
   uploader.join();
   downloader.join();

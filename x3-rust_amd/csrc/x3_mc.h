@@ -28,6 +28,10 @@ extern "C" int x3_encode_mc(x3_ctx* c, const int16_t* const* wavs, uint32_t n_ch
   if (!c || !p || !wavs || (!out && out_cap) || n_ch == 0 || n_ch > X3_MAX_CHANNELS) return X3_ERR_BAD_ARG;
   for (uint32_t k = 0; k < n_ch; ++k)
     if (!wavs[k] && n) return X3_ERR_BAD_ARG;
+  // One channel IS the reference's stream: the mono entry point, whatever the geometry (until round 4 this path took
+  // one channel itself, with a frame image capped at the 24 KB that only counts for several channels: long dense mono
+  // frames -- blocks_per_frame 1 000 of white noise -- came back as BAD_ARG where x3_encode makes the stream: ADVICE r3).
+  if (n_ch == 1) return x3_encode(c, wavs[0], n, 1, p, out, out_cap, start_pos, out_pos, stats);
   if (stats) std::memset(stats, 0, 6 * sizeof(uint64_t));
   if (out_pos) *out_pos = start_pos;
   int rc = x3_params_validate(p);
