@@ -12,8 +12,8 @@ for _ in range(3):
     assert ctx.encode_dev(d_wav, n, p, d_out, cap, 0, d_off) == 0
     print(ctx.encode_result()[0])
 out = np.zeros(8*1024, dtype=np.uint64)
-L.x3_dbg_read.argtypes=[C.c_void_p, C.c_void_p, C.c_uint64]
-print(L.x3_dbg_read(ctx._h, out.ctypes.data, out.size))
+L.x3_dbg_read_enc.argtypes=[C.c_void_p, C.c_void_p, C.c_uint64]
+print(L.x3_dbg_read_enc(ctx._h, out.ctypes.data, out.size))
 a = out.reshape(-1, 8).astype(np.float64)
 names="analyze|geom,scan,barrier waits,zero|publish+dma,emit|hdrcrc,crc|resolve,copy-out|request,-".split(",")
 for who,sl in (("compute wave0",a[0::2]),("helper wave8",a[1::2])):

@@ -19,8 +19,8 @@ G = 256 * ctx.get_option("stream_wgs_in_use")
 fpw = F / G
 NW = 400
 out = np.zeros(8*4096, dtype=np.uint64)
-L.x3_dbg_read.argtypes=[C.c_void_p, C.c_void_p, C.c_uint64]
-L.x3_dbg_read(ctx._h, out.ctypes.data, out.size)
+L.x3_dbg_read_enc.argtypes=[C.c_void_p, C.c_void_p, C.c_uint64]
+L.x3_dbg_read_enc(ctx._h, out.ctypes.data, out.size)
 a = out[:8*8*NW].reshape(NW, 8, 8).astype(np.float64) / fpw
 sp = out[8*8*NW:8*8*NW + NW*8*2].reshape(NW, 8, 2).astype(np.float64) / fpw
 print("settle(): polls per frame and wave, mean %.2f; share of frames with a size missing at first look %.2f; by wave:" % (sp[:, :, 0].mean(), sp[:, :, 1].mean()),

@@ -13,8 +13,8 @@ for _ in range(2):
     assert ctx.encode_dev(d_wav, n, p, d_out, cap, 0, d_off) == 0
     ctx.encode_result()
 out = np.zeros(8*9*128, dtype=np.uint64)
-L.x3_dbg_read.argtypes=[C.c_void_p, C.c_void_p, C.c_uint64]
-L.x3_dbg_read(ctx._h, out.ctypes.data, out.size)
+L.x3_dbg_read_enc.argtypes=[C.c_void_p, C.c_void_p, C.c_uint64]
+L.x3_dbg_read_enc(ctx._h, out.ctypes.data, out.size)
 a = out.reshape(128, 9, 8).astype(np.float64) / 135.0   # per frame
 names = "analyze,scan,wait B1,wait B3,emit,crc,copy-out,wait B4+B4b".split(",")
 print("per frame; waves 0..7 compute, 8 helper (its slots mean other things)")

@@ -19,8 +19,8 @@ for _ in range(6):
     ctx.encode_result()
 print("kernel ms (incl. stamp overhead):", ctx.kernel_time(0)[0] / 6)
 out = np.zeros(8*8192, dtype=np.uint64)
-L.x3_dbg_read.argtypes=[C.c_void_p, C.c_void_p, C.c_uint64]
-L.x3_dbg_read(ctx._h, out.ctypes.data, out.size)
+L.x3_dbg_read_enc.argtypes=[C.c_void_p, C.c_void_p, C.c_uint64]
+L.x3_dbg_read_enc(ctx._h, out.ctypes.data, out.size)
 a = out[:256*16*8].reshape(256, 16, 8).astype(np.float64)
 fpw = F / 4096.0
 names = "wait samples,analysis,scan+size+req,emission,crc,offset waits,copy-out,clear+book".split(",")

@@ -12,8 +12,8 @@ for _ in range(6):
     assert ctx.encode_dev(d_wav, n, p, d_out, cap, 0, d_off) == 0
     ctx.encode_result()
 out = np.zeros(8*8192, dtype=np.uint64)
-L.x3_dbg_read.argtypes=[C.c_void_p, C.c_void_p, C.c_uint64]
-L.x3_dbg_read(ctx._h, out.ctypes.data, out.size)
+L.x3_dbg_read_enc.argtypes=[C.c_void_p, C.c_void_p, C.c_uint64]
+L.x3_dbg_read_enc(ctx._h, out.ctypes.data, out.size)
 t = out[49152:49152 + 5*16*20*4].reshape(5, 16, 20, 4).astype(np.float64)
 t0 = t[:, :, 0, 0][t[:, :, 0, 0] > 0].min()
 names = ["wg 0", "wg 64", "wg 128", "wg 192", "wg 255"]

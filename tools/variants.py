@@ -16,10 +16,15 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wal
 def build(arg):
     name, _, flags = arg.partition("=")
     lib = os.path.join(OUT, "libx3hip_%s.so" % name)
-    srcs = [os.path.join(PKG, "csrc", f) for f in sorted(os.listdir(os.path.join(PKG, "csrc"))) if f.endswith(".hip")]
-    cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + FLAGS + flags.split() + ["-o", lib] + srcs
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    return name, r.returncode, r.stderr[-2000:]
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("x3_build", os.path.join(PKG, "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    try:
+        b.build_lib(lib, extra=flags.split(), objdir=os.path.join(OUT, "obj_" + name), verbose=False)
+        return name, 0, ""
+    except subprocess.CalledProcessError as e:
+        return name, 1, str(e)
 
 
 if __name__ == "__main__":

@@ -11,13 +11,15 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "csrc", "x3_api.hip")
-DEPS = [os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc"))] + [
-    os.path.join(HERE, "..", "include", "x3hip.h")]
+CSRC = os.path.join(HERE, "csrc")
+# the translation units of the library (x3_internal.h says what each one holds)
+UNITS = ["x3_ctx.hip", "x3_encode.hip", "x3_decode.hip", "x3_files.hip", "x3_mgpu.hip"]
+DEPS = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "x3hip.h")]
 LIB = os.path.join(HERE, "lib", "libx3hip.so")
+OBJ = os.path.join(HERE, "lib", "obj")
 CLI = os.path.join(HERE, "bin", "x3")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-pthread"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-pthread"]
 
 
 def stale():
@@ -27,14 +29,32 @@ def stale():
     return any(os.path.getmtime(d) > t for d in DEPS + [os.path.join(HERE, "cli", "x3.cpp"), os.path.join(HERE, "host", "x3.hpp")])
 
 
-def build(force=False, verbose=True):
-    if not force and not stale():
-        return LIB
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [HIPCC] + FLAGS + ["-o", LIB, SRC]
+def build_lib(lib=LIB, extra=(), objdir=OBJ, verbose=True):
+    """hipcc -c every unit (side by side), then one link"""
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
+    os.makedirs(objdir, exist_ok=True)
+
+    def cc(u):
+        o = os.path.join(objdir, u.replace(".hip", ".o"))
+        cmd = [HIPCC] + CFLAGS + list(extra) + ["-c", "-o", o, os.path.join(CSRC, u)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return o
+    with ThreadPoolExecutor(max_workers=len(UNITS)) as ex:
+        objs = list(ex.map(cc, UNITS))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", lib] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    return lib
+
+
+def build(force=False, verbose=True):
+    if not force and not stale():
+        return LIB
+    build_lib(verbose=verbose)
     build_cli(verbose)
     return LIB
 

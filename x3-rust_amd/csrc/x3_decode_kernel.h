@@ -49,7 +49,7 @@ __device__ __forceinline__ uint32_t x3_be32_at(const uint32_t* __restrict__ xw, 
 }
 
 // x^(-8t) mod P for t = 1..3 lives behind the x^n table
-#define X3_XINV8_INDEX(t) (X3_XINV16_INDEX + 1 + (t))
+// (X3_XINV8_INDEX: x3_device.h)
 
 // decoder::read_frame_header (decoder.rs:69-118) + the walk's length checks (decodefile.rs:107-121) for
 // the frame at byte offset `off`; same check order as the reference.
@@ -103,9 +103,7 @@ __device__ __forceinline__ int32_t x3_frame_header_check(const uint32_t* __restr
 // LDS tables (uint16, twelve rows of 256): T0[k][v] = v * x^(8k + 16) (crc0 of byte k of a big-endian dword: the header
 // CRC and the final reduction), M2[k][v] = v * x^(8k + 2048) and M4[k][v] = v * x^(8k + 4096) (a dword one / two rows of 64
 // dwords further from the end): 6 KB (round 2: sixteen row tables + two, 9 KB)
-#define X3_CHECK_TAB_U16 (12u * 256u)
-#define X3_CHECK_TAB_DW (X3_CHECK_TAB_U16 / 2u)
-#define X3_CHECK_XINV_N 1024u  // x^(-8k), k < 1024: undoes the zero bytes the row grid adds behind a payload
+#include "x3_tables.h"   // X3_CHECK_TAB_U16 / _DW, X3_CHECK_XINV_N
 
 // One WAVE per frame, waves walk the frames grid-stride (the tables are loaded once per workgroup).
 // Lane t takes the payload dwords t, t + 64, t + 128, ... (every load is one contiguous 256-byte run of the
@@ -371,12 +369,7 @@ __device__ __forceinline__ uint32_t x3_wave_max_u32(uint32_t v) {
 
 // LDS traffic between lanes of ONE wave needs no s_barrier: a wave's DS instructions execute in
 // issue order.  This only stops the compiler from moving LDS accesses across the point.
-#ifdef X3_DBG_STAMPS
-__device__ unsigned long long x3_dbg[8 * 8192];
-#define X3_STAMP(k) do { unsigned long long t_ = clock64(); dbg_acc[k] += t_ - dbg_t; dbg_t = t_; } while (0)
-#else
-#define X3_STAMP(k) do { } while (0)
-#endif
+// (x3_dbg, X3_STAMP: x3_device.h)
 
 #define X3_WAVE_LDS_ORDER()                                   \
   do {                                                        \
@@ -1132,12 +1125,7 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
 }
 
 // first frame with a non-zero status, and the samples of the good frames before it
-struct X3DecodeSummary {
-  unsigned long long first_bad;
-  unsigned long long samples_before;  // valid when first_bad == n_frames (else see x3_decode_prefix_kernel)
-  int first_bad_status;
-  int pad;
-};
+// (struct X3DecodeSummary: x3_tables.h)
 
 // Merge the two concurrent passes: a frame's status is the check pass's (header, then payload CRC --
 // the reference tests those first, decodefile.rs:112-121,96-100) if that is non-zero, else the

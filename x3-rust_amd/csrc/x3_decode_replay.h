@@ -194,7 +194,7 @@ __global__ void x3_replay_one_kernel(const uint8_t* __restrict__ payload, uint32
 // then for every block index the block of channel 0 .. n_ch-1, each against its own channel's last sample.  Channel c
 // goes to wav + c * ch_stride.  status[f]: X3D_OK or the block decoder's error; frames the check kernel has refused
 // (cstatus[f] != 0) are skipped.
-#define X3_MAX_CHANNELS 8u
+// (X3_MAX_CHANNELS: x3_tables.h)
 __global__ void __launch_bounds__(64)
 x3_decode_mc_kernel(const uint8_t* __restrict__ x3, const uint64_t* __restrict__ frame_off, const uint64_t* __restrict__ wav_off,
                     uint64_t n_frames, X3DevParams p, uint32_t n_ch, int16_t* __restrict__ wav, uint64_t ch_stride,

@@ -74,7 +74,7 @@ __device__ __forceinline__ uint32_t x3_gf_mul(uint32_t a, uint32_t k) {
   return r;
 }
 
-// xpow table (built on the host, x3_api): XP[j][m] = x^(32*m*2^j) mod P, j < X3_XP_LEVELS, m <= X3_XP_M
+// xpow table (built on the host, x3_ctx.hip): XP[j][m] = x^(32*m*2^j) mod P, j < X3_XP_LEVELS, m <= X3_XP_M
 #define X3_XP_LEVELS 10
 #define X3_XP_M 128
 #define X3_XINV16_INDEX (X3_XP_LEVELS * (X3_XP_M + 1))  // x^(-16) mod P stored after the table
@@ -136,6 +136,15 @@ __device__ __forceinline__ uint32_t x3_pk_max_u16(uint32_t a, uint32_t b) {
   asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+#define X3_XINV8_INDEX(t) (X3_XINV16_INDEX + 1 + (t))   // x^(-8t), t = 1..3, behind x^(-16) in the xpow table
+// stamp builds only (-DX3_DBG_STAMPS, tools/scratch/dbg_stamps_*.py): per-phase clock sums of a wave.  One copy of the
+// array per translation unit; x3_dbg_read / x3_dbg_read_enc fetch the decoders' / the encoders'.
+#ifdef X3_DBG_STAMPS
+static __device__ unsigned long long x3_dbg[8 * 8192];
+#define X3_STAMP(k) do { unsigned long long t_ = clock64(); dbg_acc[k] += t_ - dbg_t; dbg_t = t_; } while (0)
+#else
+#define X3_STAMP(k) do { } while (0)
+#endif
 // The context's pace / log words (x3_ctx::d_pace): [0..3] decoder pace by launch parity, [4..7] second-generation
 // encoder pace; from X3_LOG_BASE the decoder's launch log, X3_LOG_ENTRIES entries of X3_LOG_WORDS words indexed by the
 // launch epoch: {tag | slowest group's ticks per 16 blocks, tag | target, group 0's shader ticks, its 10 ns ticks};

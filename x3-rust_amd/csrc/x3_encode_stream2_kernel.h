@@ -52,15 +52,9 @@
 // frame out: fewer waves pay the pass's fixed ~75 instructions (multipliers, reduction) for the same table work.  It
 // does not pay -- the pass is a chain of dependent LDS look-ups per lane, and a longer chain in fewer waves is time the
 // other waves then spend at B4: config 3 encodes in 0.78 / 0.66 / 0.63 / 0.613 / 0.615 ms with 1 / 2 / 3 / 4 / 8 waves.
-#ifndef X3E_CRC_WAVES
-#define X3E_CRC_WAVES 8u
-#endif
-#define X3E_CRC_LANES (64u * X3E_CRC_WAVES)
-// the longest payload of this path: 512 blocks of 20 literals, 20 828 bytes
-#define X3_STREAM2_MAX_PAYLOAD_DWORDS 5248u
-#define X3_K2_MAXC ((X3_STREAM2_MAX_PAYLOAD_DWORDS + X3E_CRC_LANES - 1u) / X3E_CRC_LANES)
+#include "x3_tables.h"   // X3E_CRC_WAVES / _LANES, X3_STREAM2_MAX_PAYLOAD_DWORDS, X3_K2_*
 
-// CRC multipliers (x3_api.hip builds them, one block of X3_K2_DWORDS per chunk size c = 1..X3_K2_MAXC):
+// CRC multipliers (x3_ctx.hip builds them, one block of X3_K2_DWORDS per chunk size c = 1..X3_K2_MAXC):
 //   KN[l][j][v], l < 64, j < 4, v < 16 (uint16; rows of 33 dwords, 32 used: consecutive lanes start one bank apart):
 //             (v << 4j) * x^(32*c*(63-l)) mod P -- lane l's dwords are followed by c*(63-l) dwords of its WAVE's segment,
 //             and its 16-bit partial is multiplied by that power nibble by nibble: four look-ups and ten instructions
@@ -69,9 +63,6 @@
 //             (CRC wave w of X3E_CRC_WAVES uses row 8 - X3E_CRC_WAVES + w).
 // crc0(payload) = XOR_w KA[w] * (XOR_l KN[l] * crc0(chunk of lane l of wave w)).  The block of the current chunk
 // size lives in LDS (8.75 KB; reloaded by the workgroup when c changes between frames, which it rarely does).
-#define X3_K2_ROW 33u
-#define X3_K2_KA (64u * X3_K2_ROW)
-#define X3_K2_DWORDS (X3_K2_KA + 8u * 16u)
 
 typedef uint32_t x3_v4u32 __attribute__((ext_vector_type(4)));
 typedef uint32_t x3_v2u32 __attribute__((ext_vector_type(2)));
@@ -81,7 +72,7 @@ typedef uint32_t x3_v2u32 __attribute__((ext_vector_type(2)));
 //       [41] offsets lost to a size-wait time-out
 // ctl: the context's 128-byte control block: int status[8] | u64 stats[6] | u64 end_pos
 // The host only takes this path for parameter sets whose thresholds keep every Rice block inside the reference's
-// table for its code (x3_api.hip, stream_safe_thresholds), so there is no "outside the table" test here.
+// table for its code (x3_encode.hip, stream_safe_thresholds), so there is no "outside the table" test here.
 // Waves per SIMD the register budget is cut for: 6 = 80 VGPRs (79 used) = three workgroups per CU, which is also what
 // two worst-case frame images per workgroup leave room for in LDS.  Four per CU were tried with 12 KB images (enough for
 // config 3) and a 64-VGPR build: 9 registers spill, 0.72 ms with three workgroups, 0.67 ms with four -- against 0.615.
@@ -90,7 +81,7 @@ typedef uint32_t x3_v2u32 __attribute__((ext_vector_type(2)));
 #endif
 // A payload of more than this many bytes does not fit the wave encoder's LDS image (x3_encode_wave_kernel.h: 38 rows of
 // 256 bytes).  The control block's word X3_CTL_DENSE_COUNT counts a call's frames beyond it: the wave encoder leaves
-// them to this kernel's LIST form, and the host reads the count as a hint for the next call (x3_api.hip).
+// them to this kernel's LIST form, and the host reads the count as a hint for the next call (x3_encode.hip).
 #define X3_DENSE_PAYLOAD_BYTES 9728u
 #define X3_CTL_DENSE_COUNT 96u   // byte offset in ctl (behind status[8], stats[6], end_pos)
 // LIST = false: the single-pass encoder of a whole call (above).

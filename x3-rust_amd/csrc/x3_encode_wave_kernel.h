@@ -70,7 +70,7 @@
 #endif
 #define X3W_WAVES 16u
 #define X3W_THREADS (64u * X3W_WAVES)
-#define X3W_TAB_BYTES 5376u   // M0..M3 "byte k of a 32-bit state times x^4096", T4/T5 "16-bit state times x^2048" (6 x 256 x u16), lane weights 64 x 16 x u16, x^(-16k) k < 128
+// (X3W_TAB_BYTES: x3_tables.h)
 #define X3W_BOOK_BYTES 1024u
 #define X3W_IMG_ROWS 38u
 #define X3W_IMG_BYTES (X3W_IMG_ROWS * 256u)

@@ -17,6 +17,7 @@
 // that does not validate (its error), a payload that runs past the end (quiet stop), a payload longer than
 // the reader's buffer (FrameHeaderInvalidPayloadLen), a frame the decoder cannot take (BAD_ARG, included).
 #pragma once
+#include "x3_tables.h"
 #include "x3_decode_kernel.h"
 
 #define X3I_CONT 0u     // the walk steps over this frame
@@ -34,18 +35,7 @@ struct X3Cand {
   uint32_t samples;
 };
 
-struct X3IndexSummary {
-  unsigned long long n_frames;
-  unsigned long long n_samples;
-  int terminal;
-  uint32_t last_node;   // scratch: candidate index of the last frame of the chain
-  unsigned long long first_over;  // scratch: first frame that does not fit wav_cap
-  unsigned long long n_chain;     // scratch: frames reachable from the start node
-  uint32_t start;                 // scratch: candidate at offset 0 (X3I_NONE: the walk cannot step onto it)
-  uint32_t pad;                   // 1: more frames than the caller's arrays hold
-  uint32_t unaligned;             // 1: some frame's sample offset is not a multiple of eight (picks the decoder kernel)
-  uint32_t pad2;
-};
+// (struct X3IndexSummary: x3_tables.h)
 
 // decoder::read_frame_header only (no walk checks): status, payload_len, samples
 __device__ __forceinline__ int32_t x3i_read_header(const uint32_t* __restrict__ xw, uint64_t n_dw, uint64_t off,

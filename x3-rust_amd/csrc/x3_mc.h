@@ -1,4 +1,4 @@
-// x3_mc.h -- multi-channel extension (included by x3_api.hip).
+// x3_mc.h -- multi-channel extension (included by x3_encode.hip and x3_decode.hip, one half each).
 //
 // NOT in the reference: encoder::encode returns MoreThanOneChannel for more than one channel (encoder.rs:55-57) and
 // read_frame_header refuses a frame whose <Num Channels> is above one (decoder.rs:90-94).  The library keeps that
@@ -21,8 +21,9 @@
 // order (block index, channel)), the frame check kernel (header + payload CRC, told how many channels a frame must
 // announce), and one thread per frame over the reference's own reader for the samples (x3_decode_mc_kernel).  This is
 // the generic path, not the tuned mono one: beyond parity, correctness first.
-#pragma once
+// (no include guard: x3_encode.hip takes the encoder with X3_MC_ENCODE, x3_decode.hip the decoder with X3_MC_DECODE)
 
+#ifdef X3_MC_ENCODE   // (x3_encode.hip)
 extern "C" int x3_encode_mc(x3_ctx* c, const int16_t* const* wavs, uint32_t n_ch, uint64_t n, const x3_params* p,
                             uint8_t* out, uint64_t out_cap, uint64_t start_pos, uint64_t* out_pos, uint64_t stats[6]) {
   if (!c || !p || !wavs || (!out && out_cap) || n_ch == 0 || n_ch > X3_MAX_CHANNELS) return X3_ERR_BAD_ARG;
@@ -97,6 +98,9 @@ extern "C" int x3_encode_mc(x3_ctx* c, const int16_t* const* wavs, uint32_t n_ch
   return X3_OK;
 }
 
+#endif  // X3_MC_ENCODE
+
+#ifdef X3_MC_DECODE   // (x3_decode.hip)
 // the frame walk of x3_decode_stream for frames that announce n_ch channels: wavs[k][0 .. *n_samples) per channel
 extern "C" int x3_decode_stream_mc(x3_ctx* c, const uint8_t* x3, uint64_t len, uint32_t n_ch, const x3_params* p,
                                    int16_t* const* wavs, uint64_t wav_cap, uint64_t* n_samples, uint64_t* frames_ok,
@@ -159,3 +163,4 @@ extern "C" int x3_decode_stream_mc(x3_ctx* c, const uint8_t* x3, uint64_t len, u
   if (frames_ok) *frames_ok = first_bad;
   return walk_result(F, first_bad, bad_status, w.terminal, frame_errors);
 }
+#endif  // X3_MC_DECODE

@@ -21,6 +21,8 @@
 // PyTorch's copy (same SONAME) keeps exactly one RCCL.
 #pragma once
 #include <dlfcn.h>
+#include <unistd.h>
+#include <cerrno>
 #include <pthread.h>
 #include <rccl/rccl.h>  // types and prototypes only; the entry points come from dlsym
 

@@ -267,7 +267,7 @@ extern "C" int x3_decode_prefetch(x3_ctx* c, const uint8_t* x3, uint64_t len, co
   return X3_OK;
 }
 
-static int frame_cache_serve(x3_ctx* c, const uint8_t* payload, uint64_t len, const x3_params* p, uint64_t samples, int16_t* wav) {
+int frame_cache_serve(x3_ctx* c, const uint8_t* payload, uint64_t len, const x3_params* p, uint64_t samples, int16_t* wav) {
   x3_reader* r = c->fcache;
   if (std::memcmp(p, &r->p, sizeof(x3_params)) != 0) return X3_FRAME_CACHE_MISS;
   if (payload < r->mem + 20 || payload + len > r->mem + r->real_total) return X3_FRAME_CACHE_MISS;

@@ -3,51 +3,7 @@
 #include "x3_device.h"
 #include "x3_synth_core.h"
 
-// ---------------------------------------------------------------------------------------------
-// Exclusive scan of frame sizes -> byte offset of every frame in the stream.
-//   off[0] = start_pos rounded up to even (writer.align::<2>(), encoder.rs:182);
-//   off[f+1] = off[f] + frame_bytes[f]  (every frame is 20 + even bytes, so no further padding).
-// One workgroup; each thread owns a contiguous chunk.  F <= a few 10^5, so this is microseconds.
-// Sets status[0] = BYTE_WRITER_INSUFFICIENT_MEMORY when the end exceeds out_cap.
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024)
-x3_scan_frame_offsets_kernel(const uint32_t* __restrict__ frame_bytes, uint64_t n_frames,
-                             uint64_t start_pos, uint64_t out_cap, uint64_t* __restrict__ off,
-                             unsigned long long* __restrict__ end_pos, int* __restrict__ status) {
-  __shared__ unsigned long long wave_tot[16];
-  const uint32_t tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63u, wid = tid >> 6;
-  const uint64_t per = (n_frames + nthr - 1) / nthr;
-  const uint64_t lo = (uint64_t)tid * per;
-  const uint64_t hi = lo + per < n_frames ? lo + per : n_frames;
-  unsigned long long sum = 0;
-  for (uint64_t f = lo; f < hi; ++f) sum += frame_bytes[f];
-  // wave inclusive scan of 64-bit sums
-  unsigned long long incl = sum;
-#pragma unroll
-  for (int d = 1; d < X3_WAVE; d <<= 1) {
-    unsigned long long t = __shfl_up(incl, d, X3_WAVE);
-    if ((int)lane >= d) incl += t;
-  }
-  if (lane == 63) wave_tot[wid] = incl;
-  __syncthreads();
-  unsigned long long base = (start_pos + 1ull) & ~1ull;
-  unsigned long long total = base;
-  for (uint32_t w = 0; w < (nthr >> 6); ++w) {
-    unsigned long long v = wave_tot[w];
-    if (w < wid) base += v;
-    total += v;
-  }
-  unsigned long long run = base + incl - sum;
-  for (uint64_t f = lo; f < hi; ++f) {
-    off[f] = run;
-    run += frame_bytes[f];
-  }
-  if (tid == 0) {
-    off[n_frames] = total;
-    *end_pos = total;
-    if (total > out_cap) atomicMax(&status[0], X3D_BYTE_WRITER_INSUFFICIENT_MEMORY);
-  }
-}
+// (x3_scan_frame_offsets_kernel: x3_encode_kernel.h, with the two-pass encoder it serves)
 
 // ---------------------------------------------------------------------------------------------
 // CRC-16 of an arbitrary device buffer as a segmented reduction (crc::crc16, src/crc.rs:49-58).
