@@ -314,6 +314,7 @@ extern "C" int x3_ctx_set_option(x3_ctx* c, const char* name, long long value) {
   else if (n == "check_main") c->opt.check_main = value != 0;
   else if (n == "check_first") c->opt.check_first = value != 0;
   else if (n == "check_wgs") c->opt.check_wgs = (int)std::max(1ll, value);
+  else if (n == "mc_decode_threads") c->opt.mc_decode_threads = value != 0;
   else return X3_ERR_BAD_ARG;
   return X3_OK;
 }
@@ -346,6 +347,7 @@ extern "C" int x3_ctx_get_option(const x3_ctx* c, const char* name, long long* v
   }
   else if (n == "check_first") *value = c->opt.check_first;
   else if (n == "check_wgs") *value = c->opt.check_wgs;
+  else if (n == "mc_decode_threads") *value = c->opt.mc_decode_threads;
   else if (n == "check_prio") *value = c->opt.check_prio;
   else if (n == "encode_fallbacks") *value = (long long)c->encode_fallbacks;  // read-only counter
   else if (n == "stream_wgs_in_use") *value = c->stream_wg_per_cu;            // read-only, -1 before the first launch

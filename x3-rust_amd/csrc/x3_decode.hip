@@ -4,6 +4,7 @@
 #include "x3_decode_kernel.h"
 #include "x3_decode_split_kernel.h"
 #include "x3_index_kernels.h"
+#include "x3_decode_mc_kernel.h"
 
 // ------------------------------------------------------------------------------------------------
 // decode

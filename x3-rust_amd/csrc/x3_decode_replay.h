@@ -190,7 +190,9 @@ __global__ void x3_replay_one_kernel(const uint8_t* __restrict__ payload, uint32
 }
 
 // ---- multi-channel extension (not in the reference: decoder.rs:90-94 refuses such frames; oracle/x3_oracle.c says what
-// the extension's layout is).  One thread per frame over the reference's own reader: the first sample of every channel,
+// the extension's layout is).  Since round 4 the REPLAY path of x3_decode_mc_lanes_kernel (x3_decode_mc_kernel.h), which
+// decodes a frame per lane; option "mc_decode_threads" = 1 still sends every frame here.
+// One thread per frame over the reference's own reader: the first sample of every channel,
 // then for every block index the block of channel 0 .. n_ch-1, each against its own channel's last sample.  Channel c
 // goes to wav + c * ch_stride.  status[f]: X3D_OK or the block decoder's error; frames the check kernel has refused
 // (cstatus[f] != 0) are skipped.
@@ -198,9 +200,12 @@ __global__ void x3_replay_one_kernel(const uint8_t* __restrict__ payload, uint32
 __global__ void __launch_bounds__(64)
 x3_decode_mc_kernel(const uint8_t* __restrict__ x3, const uint64_t* __restrict__ frame_off, const uint64_t* __restrict__ wav_off,
                     uint64_t n_frames, X3DevParams p, uint32_t n_ch, int16_t* __restrict__ wav, uint64_t ch_stride,
-                    uint64_t wav_cap, const int32_t* __restrict__ cstatus, int32_t* __restrict__ status) {
+                    uint64_t wav_cap, const int32_t* __restrict__ cstatus, int32_t* __restrict__ status,
+                    uint32_t replay_only) {
   const uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= n_frames) return;
+  // replay_only (round 4): the frames x3_decode_mc_lanes_kernel has flagged (x3_decode_mc_kernel.h), nothing else
+  if (replay_only && status[f] != X3D_REPLAY) return;
   if (cstatus[f] != X3D_OK) { status[f] = X3D_OK; return; }
   const uint8_t* __restrict__ h = x3 + frame_off[f];
   const uint32_t samples = ((uint32_t)h[4] << 8) | h[5], plen = ((uint32_t)h[6] << 8) | h[7];

@@ -136,9 +136,21 @@ extern "C" int x3_decode_stream_mc(x3_ctx* c, const uint8_t* x3, uint64_t len, u
                      reinterpret_cast<const uint32_t*>(c->in.p), len, (const uint64_t*)c->frame_off.p, F,
                      (const uint16_t*)c->d_xinv8, (const uint16_t*)c->d_chktab, (const uint32_t*)c->d_kx64,
                      (int32_t*)c->dec_cstatus.p, reinterpret_cast<unsigned long long*>(c->d_summary), n_ch);
-  hipLaunchKernelGGL(x3_decode_mc_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, c->stream, (const uint8_t*)c->in.p,
-                     (const uint64_t*)c->frame_off.p, (const uint64_t*)c->wav_off.p, F, dp, n_ch, (int16_t*)c->out.p, ch_stride,
-                     std::min<uint64_t>(wav_cap, w.nsamp + 65535), (const int32_t*)c->dec_cstatus.p, (int32_t*)c->dec_status.p);
+  {
+    // a frame per LANE (x3_decode_mc_kernel.h; until round 4: one thread per frame over the byte-wise reader), then the
+    // reference's reader for the frames it has flagged.  Block lengths the ring cannot keep ahead of (> 60: the
+    // reference's own limit is 60, encoder.rs:296-299) and option "mc_decode_threads" take the old path for all frames.
+    const bool lanes = !c->opt.mc_decode_threads && pp.block_len <= 60;
+    TimerScope ts(c, 1);
+    if (lanes)
+      hipLaunchKernelGGL(x3_decode_mc_lanes_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, c->stream, (const uint8_t*)c->in.p,
+                         (const uint64_t*)c->frame_off.p, (const uint64_t*)c->wav_off.p, F, dp, n_ch, (int16_t*)c->out.p, ch_stride,
+                         std::min<uint64_t>(wav_cap, w.nsamp + 65535), (const int32_t*)c->dec_cstatus.p, (int32_t*)c->dec_status.p);
+    hipLaunchKernelGGL(x3_decode_mc_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, c->stream, (const uint8_t*)c->in.p,
+                       (const uint64_t*)c->frame_off.p, (const uint64_t*)c->wav_off.p, F, dp, n_ch, (int16_t*)c->out.p, ch_stride,
+                       std::min<uint64_t>(wav_cap, w.nsamp + 65535), (const int32_t*)c->dec_cstatus.p, (int32_t*)c->dec_status.p,
+                       lanes ? 1u : 0u);
+  }
   HIPCHK(c, hipGetLastError());
   std::vector<int32_t> cst(F), dst(F);
   HIPCHK(c, hipMemcpyAsync(cst.data(), c->dec_cstatus.p, F * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
