@@ -621,9 +621,11 @@ def main():
             assert r4 == (0, n, F, 0), r4
         assert torch.equal(back, wav)
         foreign = {"ms": round(min(fs_ms[1:]), 3), "first_call_ms": round(fs_ms[0], 3),
+                   "index_fast_walks": int(ctx.get_option("index_fast_walks")), "index_general_walks": int(ctx.get_option("index_general_walks")),
                    "note": "x3_decode_stream_dev on the device-resident stream: frame walk on the GPU (every byte offset "
-                           "tested for a header, successor chain by pointer doubling) + header/payload-CRC check + decode, "
-                           "host wall time incl. the summary's trip back"}
+                           "tested for a header; a clean chain is numbered by two scans and checked in one kernel, anything "
+                           "else goes through the hash table and pointer doubling) + header/payload-CRC check + decode, "
+                           "host wall time incl. the trips back (index summary, decode result)"}
         del hwav, hout, hback
 
     # ---- what the headline does not say: a fresh context's first step, the round trip with the frame walk

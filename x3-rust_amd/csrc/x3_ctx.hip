@@ -256,7 +256,7 @@ extern "C" void x3_ctx_destroy(x3_ctx* c) {
   if (c->fcache) x3_reader_close(c->fcache);
   for (DevBuf* b : {&c->in, &c->out, &c->in_more[0], &c->in_more[1], &c->out_more[0], &c->out_more[1], &c->frame_bytes, &c->frame_off, &c->dec_status, &c->dec_cstatus, &c->dec_meta, &c->wav_off,
                     &c->seg_crc, &c->desc, &c->idx_cand, &c->idx_keys, &c->idx_vals, &c->idx_J, &c->idx_S,
-                    &c->idx_L, &c->idx_sum})
+                    &c->idx_L, &c->idx_sum, &c->idx_wg, &c->idx_sorted, &c->idx_scan, &c->dense_list})
     if (b->p) (void)hipFree(b->p);
   for (auto& t : c->timers) {
     for (auto& e : t.used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -315,6 +315,7 @@ extern "C" int x3_ctx_set_option(x3_ctx* c, const char* name, long long value) {
   else if (n == "check_first") c->opt.check_first = value != 0;
   else if (n == "check_wgs") c->opt.check_wgs = (int)std::max(1ll, value);
   else if (n == "mc_decode_threads") c->opt.mc_decode_threads = value != 0;
+  else if (n == "index_no_fast") c->opt.index_no_fast = value != 0;
   else return X3_ERR_BAD_ARG;
   return X3_OK;
 }
@@ -348,6 +349,9 @@ extern "C" int x3_ctx_get_option(const x3_ctx* c, const char* name, long long* v
   else if (n == "check_first") *value = c->opt.check_first;
   else if (n == "check_wgs") *value = c->opt.check_wgs;
   else if (n == "mc_decode_threads") *value = c->opt.mc_decode_threads;
+  else if (n == "index_no_fast") *value = c->opt.index_no_fast;
+  else if (n == "index_fast_walks") *value = (long long)c->index_fast;        // read-only counters
+  else if (n == "index_general_walks") *value = (long long)c->index_general;
   else if (n == "check_prio") *value = c->opt.check_prio;
   else if (n == "encode_fallbacks") *value = (long long)c->encode_fallbacks;  // read-only counter
   else if (n == "stream_wgs_in_use") *value = c->stream_wg_per_cu;            // read-only, -1 before the first launch

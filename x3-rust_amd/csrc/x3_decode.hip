@@ -178,9 +178,50 @@ static int index_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t len, uint64_t
   if ((rc = ensure(c, c->idx_sum, 256))) return rc;
   unsigned int* d_count = reinterpret_cast<unsigned int*>((char*)c->idx_sum.p + 128);
   X3IndexSummary* d_sum = reinterpret_cast<X3IndexSummary*>(c->idx_sum.p);
-  hipLaunchKernelGGL(x3_index_init_kernel, dim3(1), dim3(64), 0, c->stream, d_sum, d_count);
   const uint64_t chunks = (len + 15) >> 4;
   const unsigned grid = (unsigned)std::min<uint64_t>((chunks + 255) / 256, (uint64_t)c->n_cus * 16);
+  // ---- the fast path (round 4): a stream that is ONE CLEAN CHAIN -- what an encoder writes -- needs no hash table and
+  // no pointer doubling.  The scanning workgroups keep their candidates in stream order, two scans number them, and one
+  // kernel checks all at once that the first frame sits at offset 0 and that every frame ends where the next begins
+  // (x3_index_kernels.h).  Five launches and one trip to the host where the general walk below takes thirteen and two;
+  // anything else -- a false candidate inside a payload, damage, a frame the walk does not step over -- sets pad2, and
+  // the general walk takes the stream as before.
+  if (grid && !c->opt.index_no_fast) {
+    const size_t G = grid;
+    if ((rc = ensure(c, c->idx_wg, G * X3I_WG_CANDS * sizeof(X3Cand)))) return rc;
+    if ((rc = ensure(c, c->idx_sorted, G * X3I_WG_CANDS * sizeof(X3Cand)))) return rc;
+    if ((rc = ensure(c, c->idx_scan, G * 32))) return rc;   // count u32 | base u32 | samp u64 | sbase u64 per span
+    unsigned int* cnt = reinterpret_cast<unsigned int*>(c->idx_scan.p);
+    uint32_t* base = reinterpret_cast<uint32_t*>(cnt + G);
+    unsigned long long* samp = reinterpret_cast<unsigned long long*>(base + G);
+    unsigned long long* sbase = samp + G;
+    hipLaunchKernelGGL(x3_index_init_kernel, dim3(1), dim3(64), 0, c->stream, d_sum, d_count);
+    hipLaunchKernelGGL(x3_index_candidates_kernel<true>, dim3(grid), dim3(256), 0, c->stream, xw, len, len + phantom, bl0,
+                       (X3Cand*)c->idx_wg.p, 0u, cnt, samp, &d_sum->pad2);
+    hipLaunchKernelGGL(x3_index_chain_kernel, dim3(1), dim3(1024), 0, c->stream, (const unsigned int*)cnt,
+                       (const unsigned long long*)samp, (uint32_t)G, base, sbase, d_sum);
+    hipLaunchKernelGGL(x3_index_link_kernel, dim3(grid), dim3(64), 0, c->stream, (const X3Cand*)c->idx_wg.p,
+                       (const unsigned int*)cnt, (uint32_t)G, (const uint32_t*)base, (const unsigned long long*)sbase,
+                       (X3Cand*)c->idx_sorted.p, (uint32_t)std::min<uint64_t>(G * X3I_WG_CANDS, 0xFFFFFFFFull),
+                       (unsigned long long)max_frames, (unsigned long long)wav_cap, (unsigned long long*)d_frame_offsets,
+                       (unsigned long long*)d_wav_offsets, d_sum);
+    hipLaunchKernelGGL(x3_index_finalize_kernel, dim3(1), dim3(64), 0, c->stream, xw, len, len + phantom, bl0,
+                       (const X3Cand*)c->idx_sorted.p, (const unsigned long long*)d_wav_offsets, d_sum);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_summary_init, d_sum, sizeof *result, hipMemcpyDeviceToHost, c->stream));  // (pinned)
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::memcpy(result, c->h_summary_init, sizeof *result);
+    if (result->pad) {
+      c->last_error = "x3_index_dev: more frames in the stream than max_frames";
+      return X3_ERR_BAD_ARG;
+    }
+    if (!result->pad2) {
+      ++c->index_fast;
+      return X3_OK;
+    }
+  }
+  ++c->index_general;
+  hipLaunchKernelGGL(x3_index_init_kernel, dim3(1), dim3(64), 0, c->stream, d_sum, d_count);
   // ONE pass over the stream: the candidates go into a buffer sized for a frame every 256 bytes (the context keeps
   // it; typical streams hold one every few kilobytes); only a stream with more than that is scanned a second time.
   unsigned int n_cand = 0;
@@ -188,16 +229,16 @@ static int index_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t len, uint64_t
     const uint64_t guess = std::max<uint64_t>(4096, len / 256 + 1024);
     if ((rc = ensure(c, c->idx_cand, (size_t)std::min<uint64_t>(guess, 0x7FFFFFFFull) * sizeof(X3Cand)))) return rc;
     const uint32_t cap = (uint32_t)std::min<uint64_t>(c->idx_cand.cap / sizeof(X3Cand), 0x7FFFFFFFull);
-    hipLaunchKernelGGL(x3_index_candidates_kernel, dim3(grid), dim3(256), 0, c->stream, xw, len, len + phantom, bl0,
-                       (X3Cand*)c->idx_cand.p, cap, d_count);
+    hipLaunchKernelGGL(x3_index_candidates_kernel<false>, dim3(grid), dim3(256), 0, c->stream, xw, len, len + phantom, bl0,
+                       (X3Cand*)c->idx_cand.p, cap, d_count, (unsigned long long*)nullptr, (uint32_t*)nullptr);
     HIPCHK(c, hipMemcpyAsync(c->h_crc, d_count, sizeof n_cand, hipMemcpyDeviceToHost, c->stream));  // (pinned)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::memcpy(&n_cand, c->h_crc, sizeof n_cand);
     if (n_cand > cap) {  // rare: denser than one frame per 256 bytes
       if ((rc = ensure(c, c->idx_cand, (size_t)n_cand * sizeof(X3Cand)))) return rc;
       HIPCHK(c, hipMemsetAsync(d_count, 0, sizeof(unsigned int), c->stream));
-      hipLaunchKernelGGL(x3_index_candidates_kernel, dim3(grid), dim3(256), 0, c->stream, xw, len, len + phantom, bl0,
-                         (X3Cand*)c->idx_cand.p, n_cand, d_count);
+      hipLaunchKernelGGL(x3_index_candidates_kernel<false>, dim3(grid), dim3(256), 0, c->stream, xw, len, len + phantom, bl0,
+                         (X3Cand*)c->idx_cand.p, n_cand, d_count, (unsigned long long*)nullptr, (uint32_t*)nullptr);
     }
   }
   if (n_cand) {

@@ -87,9 +87,19 @@ __global__ void x3_index_init_kernel(X3IndexSummary* __restrict__ sum, unsigned 
 // 1. candidates: thread t looks at the 16 byte offsets of 16-byte chunk t.  cand == nullptr: count only.
 // (Every offset, not only the even ones an encoder produces: read_frame_header accepts any payload_len, and a
 // frame with an odd one puts its successor on an odd offset -- the host walk follows it there, so does this one.)
+//
+// ORDERED (round 4, the fast path of index_dev_impl): nothing goes through the global counter.  A workgroup scans ONE
+// contiguous span of the stream, so its candidates are a contiguous run of the stream's candidates: it sorts its (few)
+// candidates by offset and leaves them, their number and their sample sum in ITS slots of cand / count / samp
+// (cand[blockIdx * X3I_WG_CANDS ...], count[blockIdx], samp[blockIdx]); x3_index_chain_kernel scans the counts and
+// x3_index_link_kernel puts the candidates in order and checks, all at once, that each one ends where the next one
+// begins -- which is all the pointer chasing of the general path amounts to on a stream that is one clean chain.
+// A workgroup with more than X3I_WG_CANDS candidates says so in *not_simple (the general path then takes the stream).
+template <bool ORDERED>
 __global__ void __launch_bounds__(256)
 x3_index_candidates_kernel(const uint32_t* __restrict__ xw, uint64_t len, uint64_t believed, uint32_t bl0,
-                           X3Cand* __restrict__ cand, uint32_t cap, unsigned int* __restrict__ count) {
+                           X3Cand* __restrict__ cand, uint32_t cap, unsigned int* __restrict__ count,
+                           unsigned long long* __restrict__ samp, uint32_t* __restrict__ not_simple) {
   __shared__ X3Cand s_c[X3I_WG_CANDS];
   __shared__ uint32_t s_n, s_base;
   if (threadIdx.x == 0) s_n = 0;
@@ -153,7 +163,7 @@ x3_index_candidates_kernel(const uint32_t* __restrict__ xw, uint64_t len, uint64
       const uint32_t li = atomicAdd(&s_n, 1u);
       if (li < X3I_WG_CANDS) {
         s_c[li] = cd;
-      } else {  // (a span with more candidates than the workgroup's buffer holds: straight to the global counter)
+      } else if (!ORDERED) {  // (a span with more candidates than the workgroup's buffer holds: straight to the global counter)
         const unsigned int slot = atomicAdd(count, 1u);
         if (cand && slot < cap) cand[slot] = cd;
       }
@@ -161,6 +171,26 @@ x3_index_candidates_kernel(const uint32_t* __restrict__ xw, uint64_t len, uint64
   }
   __syncthreads();
   const uint32_t mine = s_n < X3I_WG_CANDS ? s_n : X3I_WG_CANDS;
+  if (ORDERED) {
+    if (threadIdx.x == 0) {
+      if (s_n > X3I_WG_CANDS) *not_simple = 1u;
+      count[blockIdx.x] = mine;
+    }
+    // rank sort by offset (a dozen candidates per workgroup on config 3; 256 at most), samples summed on the way
+    X3Cand* const dst = cand + (size_t)blockIdx.x * X3I_WG_CANDS;
+    unsigned long long tot = 0;
+    for (uint32_t i = threadIdx.x; i < mine; i += blockDim.x) {
+      const X3Cand me = s_c[i];
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < mine; ++j) rank += s_c[j].off < me.off ? 1u : 0u;
+      dst[rank] = me;
+    }
+    if (threadIdx.x == 0) {
+      for (uint32_t j = 0; j < mine; ++j) tot += s_c[j].samples;
+      samp[blockIdx.x] = tot;
+    }
+    return;
+  }
   if (threadIdx.x == 0) s_base = mine ? atomicAdd(count, mine) : 0u;
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < mine; i += blockDim.x)
@@ -346,5 +376,95 @@ __global__ void x3_index_finalize_kernel(const uint32_t* __restrict__ xw, uint64
   } else {
     sum->n_samples = wav_off[n_chain - 1] + last.samples;
     sum->terminal = ending_at(last.off + 20ull + (last.plen_kind & 0xFFFFu));
+  }
+}
+
+
+// ---- the fast path's two small kernels (see x3_index_candidates_kernel<true>)
+// F1. exclusive scans of the workgroups' candidate counts and sample sums (one workgroup; G <= 4 096 spans)
+__global__ void __launch_bounds__(1024)
+x3_index_chain_kernel(const unsigned int* __restrict__ count, const unsigned long long* __restrict__ samp, uint32_t G,
+                      uint32_t* __restrict__ base, unsigned long long* __restrict__ sbase, X3IndexSummary* __restrict__ sum) {
+  __shared__ uint32_t s_c[1024];
+  __shared__ unsigned long long s_s[1024];
+  const uint32_t t = threadIdx.x;
+  const uint32_t per = (G + 1023u) / 1024u;
+  uint32_t c = 0;
+  unsigned long long sv = 0;
+  for (uint32_t i = 0; i < per; ++i) {
+    const uint32_t b = t * per + i;
+    if (b < G) { c += count[b]; sv += samp[b]; }
+  }
+  s_c[t] = c;
+  s_s[t] = sv;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024u; d <<= 1) {   // inclusive Hillis-Steele scan
+    const uint32_t cv = t >= d ? s_c[t - d] : 0u;
+    const unsigned long long sv2 = t >= d ? s_s[t - d] : 0ull;
+    __syncthreads();
+    s_c[t] += cv;
+    s_s[t] += sv2;
+    __syncthreads();
+  }
+  uint32_t cb = s_c[t] - c;
+  unsigned long long sb = s_s[t] - sv;
+  for (uint32_t i = 0; i < per; ++i) {
+    const uint32_t b = t * per + i;
+    if (b < G) {
+      base[b] = cb;
+      sbase[b] = sb;
+      cb += count[b];
+      sb += samp[b];
+    }
+  }
+  if (t == 1023u) sum->n_chain = s_c[1023];   // candidates in all (= frames, if the chain turns out clean)
+}
+
+// F2. candidate i of span b is candidate k = base[b] + i of the stream.  It is frame k of a CLEAN chain iff the first
+// one sits at offset 0, every one is a frame the walk steps over (X3I_CONT), and each ends where the next begins;
+// anything else sets sum->pad2 (the host then runs the general path).  Writes the sorted candidates (for
+// x3_index_finalize_kernel), the frame offsets and the sample offsets.
+__global__ void __launch_bounds__(64)
+x3_index_link_kernel(const X3Cand* __restrict__ cand_wg, const unsigned int* __restrict__ count, uint32_t G,
+                     const uint32_t* __restrict__ base, const unsigned long long* __restrict__ sbase,
+                     X3Cand* __restrict__ sorted, uint32_t sorted_cap, unsigned long long max_frames,
+                     unsigned long long wav_cap, unsigned long long* __restrict__ frame_off,
+                     unsigned long long* __restrict__ wav_off, X3IndexSummary* __restrict__ sum) {
+  const uint32_t b = blockIdx.x;
+  const uint32_t n = count[b];
+  const unsigned long long total = sum->n_chain;
+  if (total == 0ull || total > max_frames || total > sorted_cap) {
+    if (b == 0 && threadIdx.x == 0) {
+      if (total == 0ull) sum->pad2 = 1;        // no candidate at all: the general path states how the walk ends
+      else if (total > max_frames) sum->pad = 1;
+      else sum->pad2 = 1;
+    }
+    return;
+  }
+  const X3Cand* const mine = cand_wg + (size_t)b * X3I_WG_CANDS;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const X3Cand cd = mine[i];
+    const unsigned long long k = (unsigned long long)base[b] + i;
+    unsigned long long acc = sbase[b];
+    for (uint32_t j = 0; j < i; ++j) acc += mine[j].samples;
+    bool ok = (cd.plen_kind >> 16) == X3I_CONT;
+    if (k == 0ull) ok = ok && cd.off == 0ull;
+    // the next candidate of the stream: the next one of this span, or the first one of the next span that has any
+    unsigned long long next_off = ~0ull;
+    if (i + 1u < n) {
+      next_off = mine[i + 1u].off;
+    } else {
+      for (uint32_t b2 = b + 1u; b2 < G; ++b2)
+        if (count[b2]) { next_off = cand_wg[(size_t)b2 * X3I_WG_CANDS].off; break; }
+    }
+    if (next_off != ~0ull) ok = ok && cd.off + 20ull + (cd.plen_kind & 0xFFFFu) == next_off;
+    else sum->last_node = (uint32_t)k;          // the stream's last candidate
+    if (!ok) sum->pad2 = 1;
+    sorted[k] = cd;
+    frame_off[k] = cd.off;
+    wav_off[k] = acc;
+    if ((acc & 7ull) && sum->unaligned == 0) sum->unaligned = 1;
+    if (acc + cd.samples > wav_cap) atomicMin(&sum->first_over, k);
+    if (k == 0ull) sum->start = 0u;
   }
 }

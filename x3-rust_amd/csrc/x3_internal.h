@@ -64,6 +64,7 @@ struct X3Opts {
   long long reader_window_frames = 4096;  // X3HIP_READER_WINDOW_FRAMES: frames x3_reader decodes ahead per launch set
   int check_prio = 1;         // X3HIP_CHECK_PRIO: queue priority of the side stream the check kernel runs on (-1 low, 0 same, 1 high)
   int check_first = 0;        // X3HIP_CHECK_FIRST: enqueue the check kernel in front of the decoder (1) or behind it (0)
+  int index_no_fast = 0;      // 1: x3_index_dev / x3_decode_stream_dev always take the general walk (hash + pointer doubling)
   int mc_decode_threads = 0;  // multi-channel decode: 1 = one thread per frame (the pre-round-4 kernel) for every frame
   int check_wgs = 4;          // X3HIP_CHECK_WGS: check-kernel workgroups per CU (8 until the kernel got leaner in round 3: gpurun_out sweep in profiles/r3)
 #ifdef X3_PROFILING
@@ -114,6 +115,8 @@ struct x3_ctx {
   DevBuf in, out, frame_bytes, frame_off, dec_status, dec_cstatus, dec_meta, wav_off, seg_crc, desc, dense_list;
   DevBuf in_more[2], out_more[2];  // x3_decode_stream on a long host buffer: rings of three buffers on either side of the decoder
   DevBuf idx_cand, idx_keys, idx_vals, idx_J, idx_S, idx_L, idx_sum;  // x3_index_dev scratch
+  DevBuf idx_wg, idx_sorted, idx_scan;  // ... of its fast path: candidates per scanning workgroup, in order, the scans
+  unsigned long long index_fast = 0, index_general = 0;  // walks that the fast path / the general path have served (options)
   int n_cus = 0;
   bool force_single_wave_decode = false;
   uint32_t desc_epoch = 0;    // tag of the current launch's frame-size descriptors (single-pass encoders)
