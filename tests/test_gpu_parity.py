@@ -721,11 +721,16 @@ def test_index_dev_matches_host_walk(ctx, x3):
     offs = frame_offsets(stream)
     # a few short frames in front: many frames per kilobyte, sample offsets that are not multiples of anything
     small = np.concatenate([O.encode(x3.synth(4, 400 + i, 0, 1 + 7 * i))[1] for i in range(40)])
-    for s in (stream, np.concatenate([small, stream]), small[:-1], stream[:offs[3] + 7], stream[:offs[3] + 21]):
+    # every stream through BOTH walks: the fast path for clean chains (round 4) with the general walk behind it, and the
+    # general walk alone (option index_no_fast)
+    for no_fast, s in [(nf_, s_) for nf_ in (0, 1) for s_ in (stream, np.concatenate([small, stream]), small[:-1],
+                                                              stream[:offs[3] + 7], stream[:offs[3] + 21])]:
+        ctx.set_option("index_no_fast", no_fast)
         d = _dev_stream(ctx, s)
         d_fo = ctx.alloc(8 * 4096)
         d_wo = ctx.alloc(8 * 4096)
         rc, nf, ns, term = ctx.index_dev(d, s.size, 4000, d_fo, d_wo)
+        ctx.set_option("index_no_fast", 0)
         assert rc == 0
         # the host walk on the same bytes
         exp_off, exp_wo, pos, nsamp = [], [], 0, 0
@@ -769,8 +774,9 @@ def test_decode_stream_dev_matches_host_api(ctx, x3):
         refresh_crcs(x3, s, offs[fi])
         cases.append(s)
     p = x3.Params.default()
-    for cap in (wav.size + 70000, 55555):
+    for cap, no_fast in ((wav.size + 70000, 0), (55555, 0), (wav.size + 70000, 1)):
         d_wav = ctx.alloc(2 * (wav.size + 70000))
+        ctx.set_option("index_no_fast", no_fast)   # (1: the general walk alone; 0: the fast path first)
         for s in cases:
             d = _dev_stream(ctx, s)
             a = ctx.decode_stream(s, p, wav_cap=cap)
@@ -778,7 +784,35 @@ def test_decode_stream_dev_matches_host_api(ctx, x3):
             assert (a[0], a[1].size, a[2], a[3]) == b, (a[0], a[1].size, a[2:], b, s.size)
             assert np.array_equal(ctx.download(d_wav, 2 * b[1], np.int16), a[1])
             ctx.free(d)
+        ctx.set_option("index_no_fast", 0)
         ctx.free(d_wav)
+
+
+def test_index_fast_path_serves_clean_chains_only(x3):
+    """the walk's fast path (ordered candidates, two scans, one check kernel) takes a stream that is one clean chain from
+    offset 0; a valid frame that no frame leads to (a false candidate, here: a frame behind six bytes of junk) or a stream
+    that does not start with a frame sends the stream through the general walk -- with the host walk's results either way"""
+    c = x3.Context(0)
+    try:
+        p = x3.Params.default()
+        wav = x3.synth(2, 77, 0, 250000)
+        stream = O.encode(wav)[1]
+        extra = O.encode(x3.synth(4, 78, 0, 5000))[1]
+        junk = np.arange(6, dtype=np.uint8) + 1
+        d_wav = c.alloc(2 * 400000)
+        for s, fast in ((stream, True), (np.concatenate([stream, extra]), True), (np.concatenate([stream, junk, extra]), False),
+                        (np.concatenate([junk, stream]), False), (stream[:stream.size - 9], False)):   # (a last frame cut short is no frame the walk steps over: general walk)
+            f0, g0 = c.get_option("index_fast_walks"), c.get_option("index_general_walks")
+            d = c.alloc(s.size + 64); c.upload(d, s)
+            a = c.decode_stream(s, p, wav_cap=400000)
+            b = c.decode_stream_dev(d, s.size, p, d_wav, 400000)
+            assert (a[0], a[1].size, a[2], a[3]) == b, (a[0], a[1].size, a[2:], b)
+            assert np.array_equal(c.download(d_wav, 2 * b[1], np.int16), a[1])
+            assert (c.get_option("index_fast_walks") - f0, c.get_option("index_general_walks") - g0) == ((1, 0) if fast else (0, 1)), (s.size, fast)
+            c.free(d)
+        c.free(d_wav)
+    finally:
+        c.close()
 
 
 def _make_encoder_lose_its_grid(c, gen):
