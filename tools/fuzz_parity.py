@@ -103,14 +103,17 @@ def cmp_encode(wav, p, sp, tag, cap_cut=None):
 def cmp_decode(stream, p, cap, tag):
     r_o = O.decode_stream(stream, oparams(p), wav_cap=cap)
     # the walk on the host, on the GPU, and the stream taken in chunks of 1 + (its length mod 5) frames
-    for host_walk, chunk in ((1, -1), (0, -1), (-1, 1 + len(stream) % 5)):
+    # (the GPU walk twice: its fast path for clean chains with the general walk behind it, and the general walk alone)
+    for host_walk, chunk, no_fast in ((1, -1, 0), (0, -1, 0), (0, -1, 1), (-1, 1 + len(stream) % 5, 0)):
         ctx.set_option("host_walk", host_walk)
         ctx.set_option("host_chunk_frames", chunk)
+        ctx.set_option("index_no_fast", no_fast)
         try:
             r_g = ctx.decode_stream(stream, p, wav_cap=cap)
         finally:
             ctx.set_option("host_walk", -1)
             ctx.set_option("host_chunk_frames", 0)
+            ctx.set_option("index_no_fast", 0)
         assert (r_g[0], r_g[2], r_g[3]) == (r_o[0], r_o[2], r_o[3]), (tag, host_walk, chunk, r_g[0], r_g[2:], r_o[0], r_o[2:])
         assert np.array_equal(r_g[1], r_o[1]), (tag, host_walk, chunk, "samples")
     return r_o
@@ -416,7 +419,7 @@ def run(seed=1, minutes=None, trials=None, families="egdbaf", only=-1, context=N
         if own:
             ctx.close()
         else:  # a borrowed context goes back with the options the families touch at their defaults
-            for name, value in (("reader_window_frames", 4096), ("enc_gen", 3), ("host_walk", -1), ("host_chunk_frames", 0),
+            for name, value in (("reader_window_frames", 4096), ("enc_gen", 3), ("host_walk", -1), ("host_chunk_frames", 0), ("index_no_fast", 0),
                                 ("file_chunk_frames", 800), ("file_workers", 4)):
                 ctx.set_option(name, value)
         ctx = None
