@@ -612,15 +612,17 @@ def main():
                              "over the whole stream from host memory into a host frame buffer; windows of %d frames are "
                              "checked and decoded ahead on the GPU" % ctx.get_option("reader_window_frames")}
         # ---- a FOREIGN stream resident in HBM (frame offsets unknown): GPU frame walk + check + decode
+        # (the host-buffer calls above decoded the stream in chunks of other sizes: the decoder's pace controller takes a few
+        # launches of THIS size to settle again -- five untimed calls, then the median of ten)
         fs_ms = []
-        for _ in range(4):
+        for _ in range(15):
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             r4 = ctx.decode_stream_dev(out.data_ptr(), pos, p, back.data_ptr(), n)
             fs_ms.append((time.perf_counter() - t0) * 1e3)
             assert r4 == (0, n, F, 0), r4
         assert torch.equal(back, wav)
-        foreign = {"ms": round(min(fs_ms[1:]), 3), "first_call_ms": round(fs_ms[0], 3),
+        foreign = {"ms": round(sorted(fs_ms[5:])[5], 3), "min_ms": round(min(fs_ms[5:]), 3), "first_call_ms": round(fs_ms[0], 3),
                    "index_fast_walks": int(ctx.get_option("index_fast_walks")), "index_general_walks": int(ctx.get_option("index_general_walks")),
                    "note": "x3_decode_stream_dev on the device-resident stream: frame walk on the GPU (every byte offset "
                            "tested for a header; a clean chain is numbered by two scans and checked in one kernel, anything "
@@ -676,7 +678,8 @@ def main():
             assert ctx.encode_dev(wav.data_ptr(), n, p, out.data_ptr(), cap, 0, off.data_ptr()) == 0
             r4 = ctx.decode_stream_dev(out.data_ptr(), pos, p, back.data_ptr(), n)
             assert r4 == (0, n, F, 0), r4
-        step_walk()
+        for _ in range(5):   # (as above: the pace controller settles on this launch size again)
+            step_walk()
         dt, kt = timed_steps(ctx, step_walk, 10)
         assert ctx.encode_result()[0] == 0 and torch.equal(back, wav)
         with_walk = {"ms_per_step": round(dt * 1e3, 4), "value": round(n / dt / 1e6, 2), "kernels_ms": kt,
