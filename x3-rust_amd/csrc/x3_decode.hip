@@ -98,6 +98,7 @@ int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint6
       // the pace word's 12-bit epoch: launches 1, 2, ... 4095, then the word starts over
       if ((c->dec_epoch & 0xFFFu) == 0u) {
         HIPCHK(c, hipMemsetAsync(c->d_pace, 0, 16, dec_stream));  // (achieved and aimed-at, one word per launch parity)
+        HIPCHK(c, hipMemsetAsync(c->d_pace + 8, 0, 8, dec_stream));   // (the launch shapes)
         HIPCHK(c, hipMemsetAsync(c->d_pace + X3_LOG_BASE, 0, X3_LOG_ENTRIES * X3_LOG_WORDS * sizeof(uint32_t), dec_stream));  // (its atomicMax entries carry the epoch too)
         ++c->dec_epoch;
       }

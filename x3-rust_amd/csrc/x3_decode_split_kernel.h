@@ -172,8 +172,15 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     // launch: tools/pace_trace.py.)
     const uint32_t mask = (1u << X3S_PACE_EPOCH_SHIFT) - 1u, prev = (pace_epoch - 1u) & 0xFFFu, q = prev & 1u;
     const uint32_t wp = __builtin_amdgcn_readfirstlane(pace[q]), wt = __builtin_amdgcn_readfirstlane(pace[2u + q]);
-    const uint32_t P = (wp >> X3S_PACE_EPOCH_SHIFT) == prev ? (wp & mask) : 0u;
-    const uint32_t T = (wt >> X3S_PACE_EPOCH_SHIFT) == prev ? (wt & mask) : 0u;
+    // ... and only a launch of the SAME SHAPE counts (round 4): pace[8 + q] holds the number of groups of the launch
+    // before.  A context that decodes a stream in chunks of growing size, or a window of 4 096 frames between two whole
+    // streams, left pace words that fitted another launch; the next launches of config 3 then took 0.75 ms instead of
+    // 0.70 until the controller had found its way back (bench.py's with_frame_walk behind the host-buffer calls).  A
+    // launch of another shape starts from the data, like a context's first.
+    const uint32_t ws = __builtin_amdgcn_readfirstlane(pace[8u + q]);
+    const bool same_shape = (ws >> X3S_PACE_EPOCH_SHIFT) == prev && (ws & mask) == (gridDim.x & mask);
+    const uint32_t P = same_shape && (wp >> X3S_PACE_EPOCH_SHIFT) == prev ? (wp & mask) : 0u;
+    const uint32_t T = same_shape && (wt >> X3S_PACE_EPOCH_SHIFT) == prev ? (wt & mask) : 0u;
     uint32_t t16;
     if (P == 0u) {
       // No launch to go by (a context's first one): from the DATA.  A group's time per block is linear in the bytes it
@@ -734,7 +741,10 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       uint64_t t16 = ((wall_clock64() - pace_t0) * 16u) / nblk_max;
       if (t16 >= (1u << X3S_PACE_EPOCH_SHIFT)) t16 = (1u << X3S_PACE_EPOCH_SHIFT) - 1u;
       atomicMax(pace + (pace_epoch & 1u), ((pace_epoch & 0xFFFu) << X3S_PACE_EPOCH_SHIFT) | (uint32_t)t16);
-      if (blockIdx.x == 0) pace[2u + (pace_epoch & 1u)] = ((pace_epoch & 0xFFFu) << X3S_PACE_EPOCH_SHIFT) | pace_target;
+      if (blockIdx.x == 0) {
+        pace[2u + (pace_epoch & 1u)] = ((pace_epoch & 0xFFFu) << X3S_PACE_EPOCH_SHIFT) | pace_target;
+        pace[8u + (pace_epoch & 1u)] = ((pace_epoch & 0xFFFu) << X3S_PACE_EPOCH_SHIFT) | (gridDim.x & ((1u << X3S_PACE_EPOCH_SHIFT) - 1u));
+      }
       // The launch log (x3_ctx_launch_log; bench.py's per-step list): what this launch aimed at, what its slowest group
       // achieved, and the shader clock it ran at -- group 0's shader ticks against the 100 MHz clock over its whole
       // life (MI355X_MICROARCH.md, DVFS: a box that runs this kernel at 2.0 GHz instead of 2.3 shows HERE, and a line

@@ -146,7 +146,7 @@ static __device__ unsigned long long x3_dbg[8 * 8192];
 #define X3_STAMP(k) do { } while (0)
 #endif
 // The context's pace / log words (x3_ctx::d_pace): [0..3] decoder pace by launch parity, [4..7] second-generation
-// encoder pace; from X3_LOG_BASE the decoder's launch log, X3_LOG_ENTRIES entries of X3_LOG_WORDS words indexed by the
+// encoder pace, [8..9] the decoder's launch shape (groups) by launch parity; from X3_LOG_BASE the decoder's launch log, X3_LOG_ENTRIES entries of X3_LOG_WORDS words indexed by the
 // launch epoch: {tag | slowest group's ticks per 16 blocks, tag | target, group 0's shader ticks, its 10 ns ticks};
 // behind it the wave encoder's: {tag | 0, 0, workgroup 0's shader ticks, its 10 ns ticks}.
 #define X3_LOG_BASE 16u
