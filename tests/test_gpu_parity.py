@@ -188,6 +188,26 @@ def test_encode_generic_geometry(ctx, x3, bl, bpf):
         check_decode(ctx, x3, out, p)
 
 
+@pytest.mark.parametrize("bpf", [2, 6, 50, 100, 256, 448, 512])
+def test_short_frames_take_the_single_pass_encoder(ctx, x3, bpf):
+    """Frames of fewer than the default 500 blocks of 20 (x3.rs:81-113 lets blocks_per_frame be anything) go through
+    the single-pass encoders too, as long as a frame is a multiple of eight samples: both generations against the
+    oracle, ragged last frame included, and the decoders on what they wrote."""
+    p = x3.Params.make(20, bpf)
+    n = 20 * bpf * 37 + 20 * bpf // 2 + 3
+    for kind in (2, 1, 4):
+        wav = x3.synth(kind, 4100 + bpf, 0, n)
+        out = check_encode(ctx, x3, wav, p)
+        # (noise in frames of 5 120 samples and more is dense content: the context moves to the second generation)
+        assert ctx.get_option("enc_gen_in_use") in ((3,) if kind == 2 else (3, 2)), ctx.get_option("enc_gen_in_use")
+        check_decode(ctx, x3, out, p)
+        with _opt(ctx, enc_gen=2):
+            check_encode(ctx, x3, wav, p)
+            assert ctx.get_option("enc_gen_in_use") == 2
+        ctx.set_option("enc_gen", 3)
+        check_encode(ctx, x3, wav, p, start_pos=2)
+
+
 @pytest.mark.parametrize("bpf", [500, 502, 504, 510])
 def test_encode_largest_single_pass_frames(ctx, x3, bpf):
     """The longest payloads the single-pass encoder sees: full-scale noise (every block a literal) in frames of up

@@ -15,13 +15,14 @@ ap.add_argument("--clips", type=int, default=1, help="config-5 style batch: CLIP
 ap.add_argument("--pad", type=int, default=0, help="allocate PAD KiB first (shifts the addresses of everything behind it)")
 ap.add_argument("--repeat", type=int, default=1, help="re-allocate and re-measure REPEAT times in one process")
 ap.add_argument("--loud", type=float, default=0.0, help="this share of the frames is full-scale noise (frames that do not fit the wave encoder's image)")
+ap.add_argument("--bpf", type=int, default=500, help="blocks per frame (of 20 samples)")
 ap.add_argument("--opt", action="append", default=[], help="context option name=value (x3_ctx_set_option), repeatable")
 a = ap.parse_args()
 ctx = x3hip.Context(0)
 for o in a.opt:
     k, v = o.split("=")
     ctx.set_option(k, int(v))
-p = x3hip.Params.default()
+p = x3hip.Params.make(20, a.bpf)
 n = a.samples
 L = x3hip.lib()
 npc = n // a.clips

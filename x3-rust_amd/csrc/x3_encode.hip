@@ -77,7 +77,7 @@ int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3
   }
   HIPCHK(c, hipMemsetAsync(c->d_status, 0, 128, c->stream));
   // ---- single-pass path: default block length, 16-byte aligned frames (see x3_encode_stream2_kernel.h)
-  const bool stream_path = p->block_len == 20 && pl.nthr == 512 && (std::min<uint64_t>(spf, b->n_per_clip) + 18) / 20 <= 512 &&
+  const bool stream_path = p->block_len == 20 && (std::min<uint64_t>(spf, b->n_per_clip) + 18) / 20 <= 512 &&
                            (spf % 8) == 0 &&
                            (b->n_clips == 1 || (b->clip_stride % 8) == 0) &&
                            (reinterpret_cast<uintptr_t>(d_wav) & 15u) == 0 && !c->force_two_pass && !c->opt.two_pass;
