@@ -327,11 +327,6 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
 #pragma unroll
       for (int k = 0; k < (int)SVC_AHEAD; ++k) ld[k] = request(v_req + 16u * k);
     }
-#ifdef X3S_LAT_PROBE
-    X3_STAMP(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    X3_STAMP(2);
-#endif
   };
 
   // the usual group: 64 frames of the same size, one behind the other in wav.  Rows r, r + 4, r + 8 ... then have
