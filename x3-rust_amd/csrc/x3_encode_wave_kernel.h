@@ -758,10 +758,12 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
       X3_STAMP(2);
 
       // ---- the frame in waiting leaves its image now (its size went out a whole iteration ago)
+#ifndef X3W_SKEW2_TIMING
       if (have_prev) {
         finish_prev();
         if (lost) break;
       }
+#endif
 
       // ---- D: emission, half 0 then half 1; the next frame's halves are requested as their registers fall free.
       // Lane 0 starts with the frame's first sample.  (The block sizes are worked out again rather than kept from the
@@ -887,6 +889,14 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
       if (have_next) load_half(X1, src_next, n_next, 1);
       X3_STAMP(4);
 
+#ifdef X3W_SKEW2_TIMING
+      // timing experiment only (the stream is NOT valid): the frame before leaves its image BEHIND this frame's emission
+      // and CRC pass, as it could if a wave had room for two images
+      if (have_prev) {
+        finish_prev();
+        if (lost) break;
+      }
+#endif
       // ---- this frame waits in its image; the wave goes on to its next one
       have_prev = true;
       prev_ovf = ovf;
