@@ -118,7 +118,7 @@ x3_index_candidates_kernel(const uint32_t* __restrict__ xw, uint64_t len, uint64
     } else if (4 * t + 4 < n_dw) {  // (all but the stream's last chunk)
       const uint4 v = reinterpret_cast<const uint4*>(xw)[t];
       w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-      w[4] = xw[4 * t + 4];  // (taking it from the next lane's chunk by ds_bpermute instead: 125 against 115 us)
+      w[4] = xw[4 * t + 4];  // (taking it from the next lane's chunk by ds_bpermute instead: 125 against 115 us; by DPP wave_shl:1, round 4: the whole call 0.89-0.91 against 0.86-0.88 ms)
     } else {
 #pragma unroll
       for (int d = 0; d < 5; ++d) w[d] = 4 * t + d < n_dw ? xw[4 * t + d] : 0u;
