@@ -208,6 +208,42 @@ def test_short_frames_take_the_single_pass_encoder(ctx, x3, bpf):
         check_encode(ctx, x3, wav, p, start_pos=2)
 
 
+@pytest.mark.parametrize("bpf", [2, 6, 50, 250, 502, 4, 100])
+def test_decode_whole_groups_of_other_frame_lengths(ctx, x3, bpf):
+    """The split decoder's whole-line flush on frames that are 8 (mod 16) samples long (an even number of blocks that is
+    not a multiple of four: eight row phases against the 128-byte lines instead of four) and, for comparison, on
+    multiples of sixteen: three full groups of 64 frames, a ragged fourth and a short last frame, decoded into a buffer
+    that starts on a 16-byte boundary but not on a line."""
+    p = x3.Params.make(20, bpf)
+    spf = 20 * bpf
+    n = spf * (3 * 64 + 17) + spf // 2 + 5
+    for kind in (2, 1):
+        wav = x3.synth(kind, 5200 + bpf, 0, n)
+        out = check_encode(ctx, x3, wav, p)
+        check_decode(ctx, x3, out, p)
+    # the device API with an output that begins 16, 48 and 80 bytes into a line
+    wav = x3.synth(2, 5300 + bpf, 0, n)
+    F = (n + spf - 1) // spf
+    lib = x3.lib()
+    cap = lib.x3_encode_bound(n, C.byref(p))
+    d_wav = ctx.alloc(2 * n); d_out = ctx.alloc(cap + 16); d_off = ctx.alloc(8 * (F + 1)); d_back = ctx.alloc(2 * n + 256)
+    try:
+        ctx.upload(d_wav, wav)
+        assert ctx.encode_dev(d_wav, n, p, d_out, cap, 0, d_off) == 0
+        assert ctx.encode_result()[0] == 0
+        for shift in (16, 48, 80):
+            ctx.upload(d_back, np.zeros(n + 128, dtype=np.int16))
+            assert ctx.decode_dev(d_out, cap, d_off, F, p, d_back + shift, n, n_per_clip=n) == 0
+            r = ctx.decode_result()
+            assert r[:3] == (0, F, 0), r
+            back = ctx.download(d_back, 2 * n + 256, np.int16)
+            assert np.array_equal(back[shift // 2: shift // 2 + n], wav), (bpf, shift)
+            assert not back[:shift // 2].any() and not back[shift // 2 + n:].any(), (bpf, shift)
+    finally:
+        for d in (d_wav, d_out, d_off, d_back):
+            ctx.free(d)
+
+
 @pytest.mark.parametrize("bpf", [500, 502, 504, 510])
 def test_encode_largest_single_pass_frames(ctx, x3, bpf):
     """The longest payloads the single-pass encoder sees: full-scale noise (every block a literal) in frames of up

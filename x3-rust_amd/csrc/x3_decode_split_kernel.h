@@ -331,25 +331,30 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
 
   // the usual group: 64 frames of the same size, one behind the other in wav.  Rows r, r + 4, r + 8 ... then have
   // the same phase against the 128-byte lines (S0 a multiple of 16 samples), and a CLASS of 16 rows (r & 3 == c)
-  // completes its next line in the same block: two store instructions of eight whole lines each.
+  // completes its next line in the same block: two store instructions of eight whole lines each.  Frames of 8 (mod 16)
+  // samples -- an even number of blocks that is not a multiple of four -- have eight phases: classes of eight rows
+  // (r & 7 == c), one store instruction each (`cls8`, round 4; such frames went row by row through the valuer before).
   const uint32_t S0 = __builtin_amdgcn_readfirstlane(samples);
   // (the builtin returns int: without the casts a low word with bit 31 set sign-extends over the high one, and every
   // group whose sample offset has that bit stops being "regular" -- half of all groups beyond 2^31 samples)
   const uint64_t wo0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(wo >> 32)) << 32) |
                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)wo);
-  bool regular = __all(active && samples == S0 && wo == wo0 + (uint64_t)lane * S0) && (S0 & 15u) == 0;
+  bool regular = __all(active && samples == S0 && wo == wo0 + (uint64_t)lane * S0) && (S0 & 7u) == 0;
+  const bool cls8 = (S0 & 15u) != 0u;
   const uint64_t B0 = (uint64_t)(uintptr_t)(wav + wo0);  // destination byte address of the group (16-byte aligned)
   uint8_t* const line0 = reinterpret_cast<uint8_t*>(B0 & ~127ull);  // its first line
   // this lane's part in the flush of class c, store i: piece `pc` of the current line of row rr[c][i]
   const uint32_t pc = lane & 7u;
   uint32_t f_src[4][2], f_dst[4][2];  // LDS byte address / byte offset from line0, for the row's FIRST line
-  uint32_t ph[4], nfl[4] = {0, 0, 0, 0};  // per class: dwords of the first line in front of the row; lines flushed
+  uint32_t ph[8], nfl[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // per class: dwords of the first line in front of the row; lines flushed
+#pragma unroll
+  for (uint32_t c = 0; c < 8; ++c) ph[c] = (uint32_t)(((B0 + (uint64_t)c * 2u * S0) & 127u) >> 2);
 #pragma unroll
   for (uint32_t c = 0; c < 4; ++c) {
-    ph[c] = (uint32_t)(((B0 + (uint64_t)c * 2u * S0) & 127u) >> 2);
 #pragma unroll
     for (uint32_t i = 0; i < 2; ++i) {
-      const uint32_t rr = 4u * ((lane >> 3) + 8u * i) + c;
+      // (eight classes: entry [c][i] is class c + 4 i)
+      const uint32_t rr = cls8 ? 8u * (lane >> 3) + (c + 4u * i) : 4u * ((lane >> 3) + 8u * i) + c;
       const uint32_t off = (uint32_t)(B0 & 127u) + rr * 2u * S0;     // bytes from line0 to the row (< 2^32: 64 frames)
       const uint32_t rrot = 16u * ((rr >> 2) & 15u);
       f_dst[c][i] = (off & ~127u) + 16u * pc;
@@ -374,6 +379,14 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     if (X3S_KO & 8) asm volatile("" :: "v"(v0.x), "v"(v1.x), "v"(v0.w), "v"(v1.w));
     X3_WAVE_LDS_ORDER();
   };
+  // the same for one of EIGHT classes: one line of each of its eight rows
+  auto flush_row = [&](uint32_t c, uint32_t c_src, uint32_t c_dst, uint32_t n, uint32_t p_lo, uint32_t p_hi) {
+    X3_WAVE_LDS_ORDER();
+    const x3_u32x4 v = x3_lds_read_b128(c_src ^ ((n & 1u) << 7));
+    const bool ok = s_dead[8u * (lane >> 3) + c] == 0u;
+    if (pc >= p_lo && pc < p_hi && ok) x3_store_stream16(line0 + (c_dst + 128u * n), v);
+    X3_WAVE_LDS_ORDER();
+  };
   // every class whose rows have completed a line: k_done = dwords of each row that are staged
 #ifndef X3S_HALF_LINES
 #define X3S_FLUSH_CLASS(c)                                                                                       \
@@ -388,6 +401,19 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   _Pragma("unroll") for (uint32_t c = 0; c < 4; ++c) {                                                           \
     const uint32_t tail = ((ph[c] + (S0 >> 1)) & 31u) >> 2; /* pieces of the last, partial line */               \
     if (tail) flush_class(c, f_src[c][0], f_src[c][1], f_dst[c][0], f_dst[c][1], nfl[c], nfl[c] ? 0u : ph[c] >> 2, tail); \
+  }
+#define X3S_FLUSH_CLASS8(c)                                                                                      \
+  {                                                                                                              \
+    const uint32_t ld = (ph[c] + k_done) >> 5;                                                                   \
+    if (ld > nfl[c]) {                                                                                           \
+      flush_row(c, f_src[(c) & 3][(c) >> 2], f_dst[(c) & 3][(c) >> 2], nfl[c], nfl[c] ? 0u : ph[c] >> 2, 8u);    \
+      nfl[c] = ld;                                                                                               \
+    }                                                                                                            \
+  }
+#define X3S_FLUSH_TAILS8()                                                                                       \
+  _Pragma("unroll") for (uint32_t c = 0; c < 8; ++c) {                                                           \
+    const uint32_t tail = ((ph[c] + (S0 >> 1)) & 31u) >> 2;                                                      \
+    if (tail) flush_row(c, f_src[c & 3][c >> 2], f_dst[c & 3][c >> 2], nfl[c], nfl[c] ? 0u : ph[c] >> 2, tail);   \
   }
 #else
   // EXPERIMENT (-DX3S_HALF_LINES; never shipped): the same flush in aligned 64-byte HALF lines, each as soon as it is
@@ -426,7 +452,15 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       X3_STAMP(4);
       if (!(X3S_KO & 2) && regular && b) {
         const uint32_t k_done = have >> 1;
-        X3S_FLUSH_CLASS(0) X3S_FLUSH_CLASS(1) X3S_FLUSH_CLASS(2) X3S_FLUSH_CLASS(3)
+#ifndef X3S_HALF_LINES
+        if (cls8) {
+          X3S_FLUSH_CLASS8(0) X3S_FLUSH_CLASS8(1) X3S_FLUSH_CLASS8(2) X3S_FLUSH_CLASS8(3)
+          X3S_FLUSH_CLASS8(4) X3S_FLUSH_CLASS8(5) X3S_FLUSH_CLASS8(6) X3S_FLUSH_CLASS8(7)
+        } else
+#endif
+        {
+          X3S_FLUSH_CLASS(0) X3S_FLUSH_CLASS(1) X3S_FLUSH_CLASS(2) X3S_FLUSH_CLASS(3)
+        }
       }
       const uint32_t cnt = rem < X3S_BL ? rem : X3S_BL;
       rem -= cnt;
@@ -436,8 +470,17 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     X3S_BARRIER();
     if (regular) {
       const uint32_t k_done = have >> 1;
-      X3S_FLUSH_CLASS(0) X3S_FLUSH_CLASS(1) X3S_FLUSH_CLASS(2) X3S_FLUSH_CLASS(3)
-      X3S_FLUSH_TAILS()
+#ifndef X3S_HALF_LINES
+      if (cls8) {
+        X3S_FLUSH_CLASS8(0) X3S_FLUSH_CLASS8(1) X3S_FLUSH_CLASS8(2) X3S_FLUSH_CLASS8(3)
+        X3S_FLUSH_CLASS8(4) X3S_FLUSH_CLASS8(5) X3S_FLUSH_CLASS8(6) X3S_FLUSH_CLASS8(7)
+        X3S_FLUSH_TAILS8()
+      } else
+#endif
+      {
+        X3S_FLUSH_CLASS(0) X3S_FLUSH_CLASS(1) X3S_FLUSH_CLASS(2) X3S_FLUSH_CLASS(3)
+        X3S_FLUSH_TAILS()
+      }
     }
   } else
   if (parser) {
