@@ -188,11 +188,11 @@ def test_encode_generic_geometry(ctx, x3, bl, bpf):
         check_decode(ctx, x3, out, p)
 
 
-@pytest.mark.parametrize("bpf", [2, 6, 50, 100, 256, 448, 512])
+@pytest.mark.parametrize("bpf", [2, 6, 50, 100, 256, 448, 512, 1, 3, 51, 255, 499, 501, 511])
 def test_short_frames_take_the_single_pass_encoder(ctx, x3, bpf):
-    """Frames of fewer than the default 500 blocks of 20 (x3.rs:81-113 lets blocks_per_frame be anything) go through
-    the single-pass encoders too, as long as a frame is a multiple of eight samples: both generations against the
-    oracle, ragged last frame included, and the decoders on what they wrote."""
+    """Frames of any number of blocks of 20 up to 512 (x3.rs:81-113 lets blocks_per_frame be anything) go through the
+    single-pass encoders -- an odd number puts every other frame on an 8-byte boundary --: both generations against
+    the oracle, ragged last frame included, and the decoders on what they wrote."""
     p = x3.Params.make(20, bpf)
     n = 20 * bpf * 37 + 20 * bpf // 2 + 3
     for kind in (2, 1, 4):
