@@ -208,6 +208,34 @@ def test_short_frames_take_the_single_pass_encoder(ctx, x3, bpf):
         check_encode(ctx, x3, wav, p, start_pos=2)
 
 
+@pytest.mark.parametrize("shift", [4, 8, 12, 2])
+def test_encode_dev_from_a_buffer_that_is_not_16_byte_aligned(ctx, x3, shift):
+    """x3_encode_dev on samples that begin 4, 8 or 12 bytes into a 16-byte unit (a slice of somebody's tensor): still the
+    single-pass encoder (its loads are dword buffer loads); 2 bytes in: the two-pass kernels.  Same stream either way."""
+    p = x3.Params.default()
+    n = 10000 * 70 + 4321
+    lib = x3.lib()
+    F = lib.x3_num_frames(n, C.byref(p)); cap = lib.x3_encode_bound(n, C.byref(p))
+    d_buf = ctx.alloc(2 * n + 64); d_out = ctx.alloc(cap + 16); d_off = ctx.alloc(8 * (F + 1))
+    try:
+        for kind in (2, 1):
+            wav = x3.synth(kind, 6100 + shift, 0, n)
+            rc_o, out_o, st_o = O.encode(wav, oparams(p))
+            assert rc_o == 0
+            ctx.upload(d_buf + shift, wav)
+            assert ctx.encode_dev(d_buf + shift, n, p, d_out, cap, 0, d_off) == 0
+            rc, pos, st = ctx.encode_result()
+            assert rc == 0 and pos == out_o.size and list(st) == st_o.tolist()
+            assert ctx.get_option("enc_gen_in_use") == (0 if shift == 2 else (3 if kind == 2 else ctx.get_option("enc_gen_in_use")))
+            assert np.array_equal(ctx.download(d_out, pos), out_o)
+            offs = ctx.download(d_off, 8 * (F + 1), np.uint64)
+            assert offs[F] == pos and offs[0] == 0
+        ctx.set_option("enc_gen", 3)
+    finally:
+        for d in (d_buf, d_out, d_off):
+            ctx.free(d)
+
+
 @pytest.mark.parametrize("bpf", [2, 6, 50, 250, 502, 4, 100])
 def test_decode_whole_groups_of_other_frame_lengths(ctx, x3, bpf):
     """The split decoder's whole-line flush on frames that are 8 (mod 16) samples long (an even number of blocks that is

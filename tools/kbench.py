@@ -15,6 +15,7 @@ ap.add_argument("--clips", type=int, default=1, help="config-5 style batch: CLIP
 ap.add_argument("--pad", type=int, default=0, help="allocate PAD KiB first (shifts the addresses of everything behind it)")
 ap.add_argument("--repeat", type=int, default=1, help="re-allocate and re-measure REPEAT times in one process")
 ap.add_argument("--loud", type=float, default=0.0, help="this share of the frames is full-scale noise (frames that do not fit the wave encoder's image)")
+ap.add_argument("--shift", type=int, default=0, help="the samples begin this many bytes into a 16-byte unit")
 ap.add_argument("--bpf", type=int, default=500, help="blocks per frame (of 20 samples)")
 ap.add_argument("--opt", action="append", default=[], help="context option name=value (x3_ctx_set_option), repeatable")
 a = ap.parse_args()
@@ -29,7 +30,7 @@ npc = n // a.clips
 n = npc * a.clips
 F = L.x3_num_frames(npc, C.byref(p)) * a.clips; cap = L.x3_encode_bound(npc, C.byref(p)) * a.clips
 def run_once(tag):
-    d_wav = ctx.alloc(2 * n); d_out = ctx.alloc(cap + 16); d_off = ctx.alloc(8 * (F + 1)); d_back = ctx.alloc(2 * n)
+    d_wav = ctx.alloc(2 * n + 64) + a.shift; d_out = ctx.alloc(cap + 16); d_off = ctx.alloc(8 * (F + 1)); d_back = ctx.alloc(2 * n)
     ctx.synth_dev(a.kind, 0x58330003, 0, n, d_wav)
     if a.loud > 0:   # every k-th frame loud
         k = max(1, int(round(1.0 / a.loud)))
@@ -69,5 +70,5 @@ if a.pad:
 for rep in range(a.repeat):
     bufs = run_once("rep %d" % rep)
     if rep + 1 < a.repeat:
-        for d in bufs: ctx.free(d)
+        for d in bufs: ctx.free(d - a.shift if d is bufs[0] else d)
         pads.append(ctx.alloc((rep + 1) * 1234 * 1024))

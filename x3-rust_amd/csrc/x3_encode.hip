@@ -12,8 +12,8 @@
 // coded with code[ft(m)], ft = [m > thr0] + [m > thr1] (encoder.rs:241-247); it is inside that code's table when
 // m <= min(offset, len - offset - 1).
 #ifndef X3_ENC_FRAME_ALIGN
-// samples between frame starts that the single-pass encoders take: 4 = frames on 8-byte boundaries.  (Their sample loads
-// are range-checked 16-byte BUFFER loads, which need dword alignment only; until round 4 this was 8 -- frames of an odd
+// samples between frame starts that the single-pass encoders take: 4 = frames on 8-byte boundaries of a buffer that is
+// itself dword aligned.  (Their sample loads are range-checked 16-byte BUFFER loads, which need dword alignment only; until round 4 this was 8 -- frames of an odd
 // number of blocks went to the two-pass kernels, 3.6 ms against 0.45 for 501 blocks a frame.)
 #define X3_ENC_FRAME_ALIGN 4u
 #endif
@@ -82,11 +82,11 @@ int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3
     d_off = (uint64_t*)c->frame_off.p;
   }
   HIPCHK(c, hipMemsetAsync(c->d_status, 0, 128, c->stream));
-  // ---- single-pass path: default block length, frames on 8-byte boundaries in a 16-byte aligned buffer
+  // ---- single-pass path: default block length, frames on dword boundaries (buffer loads)
   const bool stream_path = p->block_len == 20 && (std::min<uint64_t>(spf, b->n_per_clip) + 18) / 20 <= 512 &&
                            (spf % X3_ENC_FRAME_ALIGN) == 0 &&
                            (b->n_clips == 1 || (b->clip_stride % X3_ENC_FRAME_ALIGN) == 0) &&
-                           (reinterpret_cast<uintptr_t>(d_wav) & 15u) == 0 && !c->force_two_pass && !c->opt.two_pass;
+                           (reinterpret_cast<uintptr_t>(d_wav) & 3u) == 0 && !c->force_two_pass && !c->opt.two_pass;
   c->last_enc = {d_wav, *b, *p, spf, d_out, out_cap, start_pos, d_frame_offsets};
   // part + two worst-case frame images + CRC tables + the multipliers of one chunk size (x3_encode_stream2_kernel.h)
   const size_t smem2 = X3_ENC_SMEM_HDR + 2 * (size_t)pl.img_dwords * 4 + 2048 + X3_K2_DWORDS * 4;
