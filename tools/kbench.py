@@ -15,6 +15,7 @@ ap.add_argument("--clips", type=int, default=1, help="config-5 style batch: CLIP
 ap.add_argument("--pad", type=int, default=0, help="allocate PAD KiB first (shifts the addresses of everything behind it)")
 ap.add_argument("--repeat", type=int, default=1, help="re-allocate and re-measure REPEAT times in one process")
 ap.add_argument("--loud", type=float, default=0.0, help="this share of the frames is full-scale noise (frames that do not fit the wave encoder's image)")
+ap.add_argument("--stride", type=int, default=0, help="--clips: samples from one clip's start to the next (default: the clip length)")
 ap.add_argument("--shift", type=int, default=0, help="the samples begin this many bytes into a 16-byte unit")
 ap.add_argument("--bpf", type=int, default=500, help="blocks per frame (of 20 samples)")
 ap.add_argument("--opt", action="append", default=[], help="context option name=value (x3_ctx_set_option), repeatable")
@@ -27,25 +28,26 @@ p = x3hip.Params.make(20, a.bpf)
 n = a.samples
 L = x3hip.lib()
 npc = n // a.clips
+stride = a.stride or npc
 n = npc * a.clips
 F = L.x3_num_frames(npc, C.byref(p)) * a.clips; cap = L.x3_encode_bound(npc, C.byref(p)) * a.clips
 def run_once(tag):
-    d_wav = ctx.alloc(2 * n + 64) + a.shift; d_out = ctx.alloc(cap + 16); d_off = ctx.alloc(8 * (F + 1)); d_back = ctx.alloc(2 * n)
-    ctx.synth_dev(a.kind, 0x58330003, 0, n, d_wav)
+    d_wav = ctx.alloc(2 * stride * a.clips + 64) + a.shift; d_out = ctx.alloc(cap + 16); d_off = ctx.alloc(8 * (F + 1)); d_back = ctx.alloc(2 * stride * a.clips)
+    ctx.synth_dev(a.kind, 0x58330003, 0, stride * a.clips, d_wav)
     if a.loud > 0:   # every k-th frame loud
         k = max(1, int(round(1.0 / a.loud)))
         for f in range(k // 2, F, k):
             lo = f * p.spf
             ctx.synth_dev(1, 0x58330003 + f, lo, min(p.spf, n - lo), d_wav + 2 * lo)
     def step():
-        assert ctx.encode_dev(d_wav, npc, p, d_out, cap, 0, d_off, n_clips=a.clips, clip_stride=npc) == 0
-        assert ctx.decode_dev(d_out, cap, d_off, F, p, d_back, n, n_per_clip=npc, n_clips=a.clips, clip_stride=npc) == 0
+        assert ctx.encode_dev(d_wav, npc, p, d_out, cap, 0, d_off, n_clips=a.clips, clip_stride=stride) == 0
+        assert ctx.decode_dev(d_out, cap, d_off, F, p, d_back, stride * a.clips, n_per_clip=npc, n_clips=a.clips, clip_stride=stride) == 0
     ctx.enable_kernel_timing(False)
     # (the first call: the encoder's result first -- dense content is encoded again inside x3_encode_result, the stream is
     # not valid before it -- then the decode)
-    assert ctx.encode_dev(d_wav, npc, p, d_out, cap, 0, d_off, n_clips=a.clips, clip_stride=npc) == 0
+    assert ctx.encode_dev(d_wav, npc, p, d_out, cap, 0, d_off, n_clips=a.clips, clip_stride=stride) == 0
     rc, pos, st = ctx.encode_result(); assert rc == 0
-    assert ctx.decode_dev(d_out, cap, d_off, F, p, d_back, n, n_per_clip=npc, n_clips=a.clips, clip_stride=npc) == 0
+    assert ctx.decode_dev(d_out, cap, d_off, F, p, d_back, stride * a.clips, n_per_clip=npc, n_clips=a.clips, clip_stride=stride) == 0
     r = ctx.decode_result(); assert os.environ.get("X3_NOCHECK") or r[:3] == (0, F, 0), r
     ctx.enable_kernel_timing(not os.environ.get('X3_NOTIMING')); ctx.reset_kernel_time()
     for _ in range(a.steps): step()

@@ -17,7 +17,8 @@
 //     indexed by the DESTINATION address, and owns status and metadata.
 //   wave 2, the FLUSHER: one block behind the valuer it writes every 128-byte line of wav that has been
 //     completed in the rings -- whole, aligned lines only, eight per store instruction.  (Groups that are not
-//     64 equal frames side by side are flushed by the valuer, row by row: rare.)
+//     64 equal frames side by side -- a clip's short last frame, two clips' frames, a frame index: every row with its
+//     own phase and length -- make a list of the rows that have completed a line each block, flush_rows.)
 //
 // One s_barrier per 20-sample block: behind barrier k the parser works on block k+1, the valuer on block k,
 // the flusher on what block k-1 completed.  All waves derive the per-lane block sizes from the frame header
@@ -152,6 +153,9 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   __shared__ __attribute__((aligned(16))) uint32_t xfer[2 * X3S_XROWS * 64];
   __shared__ uint32_t s_over[64];  // parser -> valuer: the frame was read beyond its payload (x3_decode_replay.h)
   __shared__ uint32_t s_dead[64];  // valuer -> flusher: the frame failed, no more stores for it
+  // flusher, groups that are not 64 equal frames side by side: the rows that have a line to write this block, in the
+  // order of their rank among them: {line address lo, hi, row | ring byte of the line << 8 | first piece << 16 | end piece << 20}
+  __shared__ __attribute__((aligned(16))) uint32_t s_prm[64 * 4];
 
   const uint32_t lane = threadIdx.x & 63u;
   const bool parser = threadIdx.x < 64u;
@@ -445,6 +449,53 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     // (behind barrier b the valuer's block b - 1 is staged; a line is overwritten five blocks after it was completed).
     X3S_BARRIER();
     uint32_t rem = S0 ? S0 - 1u : 0u, have = 0;
+    // Any other group (a clip's short last frame, the frames of two clips, offsets from a frame index): every row has its
+    // own phase against the lines and its own length.  This lane OWNS row `lane`: it knows what the valuer has staged of
+    // it (g_have), and when that completes a line the row joins the block's list (s_prm, by rank among the rows that
+    // do); then eight lanes take one listed row each round, as in the classes' flush.  (Until round 4 the valuer moved
+    // such rows itself, sixteen bytes per lane and store: a batch of clips with ragged ends decoded at half the speed.)
+    uint32_t g_rem = samples ? samples - 1u : 0u, g_have = 0, g_nfl = 0;
+    const uint64_t g_B = (uint64_t)(uintptr_t)(wav + wo);              // the row's first byte (16-byte aligned)
+    const uint32_t g_p0 = (uint32_t)(g_B & 127u) >> 4;                 // pieces of its first line in front of it
+    const uint32_t g_end = g_p0 + (samples >> 3);                      // end of its whole pieces, counted from that line
+    const uint32_t g_rot = 16u * ((lane >> 2) & 15u);
+    auto flush_rows = [&]() {
+      X3_WAVE_LDS_ORDER();
+      const uint32_t n = g_nfl;
+      // a line that the staged dwords reach the end of -- or the row's last, partial line as soon as everything is
+      // staged: a lane whose frame has ended goes on through the group's blocks, and what its valuer lane stages from
+      // then on is not the row's (six blocks on it is over the row's last samples)
+      const bool whole = (((g_p0 << 2) + (g_have >> 1)) >> 5) > n && 8u * n + 8u <= g_end;
+      const bool rest = !whole && g_rem == 0u && 8u * n < g_end;
+      uint32_t p_hi = whole ? 8u : g_end - 8u * n;
+      if (p_hi > 8u) p_hi = 8u;
+      const uint32_t p_lo = n ? 0u : g_p0;
+      const bool ready = active && s_dead[lane] == 0u && (whole || rest) && p_hi > p_lo;
+      const unsigned long long mask = __ballot(ready);
+      if (mask == 0ull) return;
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+      const uint64_t la = (g_B & ~127ull) + 128ull * n;
+      if (ready) {
+        x3_lds_write_b128(x3_lds_addr(s_prm) + 16u * rank, (uint32_t)la, (uint32_t)(la >> 32),
+                          lane | ((((uint32_t)la + g_rot) & 255u) << 8) | (p_lo << 16) | (p_hi << 20), 0u);
+        g_nfl = n + 1u;
+      }
+      X3_WAVE_LDS_ORDER();
+      const uint32_t nready = (uint32_t)__builtin_popcountll(mask);
+      for (uint32_t i = 0; 8u * i < nready; ++i) {
+        const uint32_t idx = 8u * i + (lane >> 3);
+        if (idx < nready) {
+          const x3_u32x4 e = x3_lds_read_b128(x3_lds_addr(s_prm) + 16u * idx);
+          const uint32_t row = e.z & 63u, rb = (e.z >> 8) & 255u, lo = (e.z >> 16) & 15u, hi = (e.z >> 20) & 15u;
+          if (pc >= lo && pc < hi) {
+            const x3_u32x4 v = x3_lds_read_b128(x3_lds_addr(outs) + row * (4u * X3S_RING_DW) + ((rb + 16u * pc) & 255u));
+            uint8_t* const dst = reinterpret_cast<uint8_t*>(((uint64_t)e.y << 32) | e.x);
+            x3_store_stream16(dst + 16u * pc, v);
+          }
+        }
+      }
+      X3_WAVE_LDS_ORDER();
+    };
     for (uint32_t b = 0; b < nblk_max; ++b) {
       X3S_PACE_STEP(b, X3S_ROLE_FLUSHER)
       X3_STAMP(0);
@@ -462,12 +513,22 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
           X3S_FLUSH_CLASS(0) X3S_FLUSH_CLASS(1) X3S_FLUSH_CLASS(2) X3S_FLUSH_CLASS(3)
         }
       }
+      if (!regular && b) flush_rows();
       const uint32_t cnt = rem < X3S_BL ? rem : X3S_BL;
       rem -= cnt;
       have = 1u + X3S_BL * b + cnt - ((cnt && rem == 0u) ? 0u : 1u);  // staged once the valuer is through block b
+      {
+        const uint32_t gcnt = g_rem < X3S_BL ? g_rem : X3S_BL;
+        g_rem -= gcnt;
+        if (gcnt) g_have = 1u + X3S_BL * b + gcnt - (g_rem == 0u ? 0u : 1u);
+      }
       X3_STAMP(1);
     }
     X3S_BARRIER();
+    if (!regular) {
+      flush_rows();
+      flush_rows();
+    }
     if (regular) {
       const uint32_t k_done = have >> 1;
 #ifndef X3S_HALF_LINES
@@ -621,22 +682,6 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       prevP = first << 16;
       if (samples == 1u) o[0] = (int16_t)first;
     }
-    // any other group (ragged sizes, a frame that failed, offsets from a frame index): every lane moves the finished
-    // 16-byte pieces of its own row -- slow, and rare
-    uint32_t my_fl = 0;  // 16-byte pieces of this lane's row that are in wav
-    auto flush_own = [&](uint32_t upto_samples) {  // pieces below upto_samples / 8
-      X3_WAVE_LDS_ORDER();
-      const uint32_t done = alive ? upto_samples >> 3 : my_fl;
-#pragma unroll 1
-      while (__any(my_fl < done)) {
-        if (my_fl < done) {
-          const x3_u32x4 v = x3_lds_read_b128(orow_b + ((pos0 + 16u * my_fl) & 255u));
-          x3_store_stream16(o + 8u * my_fl, v);
-          ++my_fl;
-        }
-      }
-      X3_WAVE_LDS_ORDER();
-    };
     s_dead[lane] = 0u;
     X3_WAVE_LDS_ORDER();
     X3S_BARRIER();  // (s_dead is cleared)
@@ -765,15 +810,11 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       if (finished && alive && (samples & 1u))      // its last sample is a pending one: stage it
         x3_lds_write_u16(x3_and_or(pos0 + 2u * (samples - 1u), 254u, orow_b), prevP >> 16);
       X3_STAMP(1);
-      if (regular && !alive) s_dead[lane] = 1u;  // (visible to the flusher behind the next barrier)
-      const uint32_t have = 1u + X3S_BL * b + cnt - ((finished || samples == 0u) ? 0u : 1u);  // samples staged so far
-      if (regular) {
-      } else {
-        flush_own(samples ? (have < samples ? have : samples) : 0u);
-        if (finished && alive)  // the ragged end of the frame: fewer than eight samples
-          for (uint32_t sx = samples & ~7u; sx < samples; ++sx)
-            o[sx] = (int16_t)x3_lds_read_u16(x3_and_or(pos0 + 2u * sx, 254u, orow_b), 0u);
-      }
+      if (!alive) s_dead[lane] = 1u;  // (visible to the flusher behind the next barrier)
+      // (the flusher moves whole 16-byte pieces.)  The ragged end of a frame, fewer than eight samples:
+      if (!regular && finished && alive)
+        for (uint32_t sx = samples & ~7u; sx < samples; ++sx)
+          o[sx] = (int16_t)x3_lds_read_u16(x3_and_or(pos0 + 2u * sx, 254u, orow_b), 0u);
       X3_STAMP(5);
     }
     X3S_BARRIER();
