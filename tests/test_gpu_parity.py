@@ -236,12 +236,13 @@ def test_encode_dev_from_a_buffer_that_is_not_16_byte_aligned(ctx, x3, shift):
             ctx.free(d)
 
 
-@pytest.mark.parametrize("bpf", [2, 6, 50, 250, 502, 4, 100])
+@pytest.mark.parametrize("bpf", [2, 6, 50, 250, 502, 4, 100, 1, 3, 51, 501])
 def test_decode_whole_groups_of_other_frame_lengths(ctx, x3, bpf):
     """The split decoder's whole-line flush on frames that are 8 (mod 16) samples long (an even number of blocks that is
     not a multiple of four: eight row phases against the 128-byte lines instead of four) and, for comparison, on
     multiples of sixteen: three full groups of 64 frames, a ragged fourth and a short last frame, decoded into a buffer
-    that starts on a 16-byte boundary but not on a line."""
+    that starts on a 16-byte boundary but not on a line -- and on an 8-byte one; an odd number of blocks puts every
+    other row on an 8-byte boundary anyway (the flusher's 8-byte pieces)."""
     p = x3.Params.make(20, bpf)
     spf = 20 * bpf
     n = spf * (3 * 64 + 17) + spf // 2 + 5
@@ -249,7 +250,7 @@ def test_decode_whole_groups_of_other_frame_lengths(ctx, x3, bpf):
         wav = x3.synth(kind, 5200 + bpf, 0, n)
         out = check_encode(ctx, x3, wav, p)
         check_decode(ctx, x3, out, p)
-    # the device API with an output that begins 16, 48 and 80 bytes into a line
+    # the device API with an output that begins 16, 48, 80 and 8, 72 bytes into a line
     wav = x3.synth(2, 5300 + bpf, 0, n)
     F = (n + spf - 1) // spf
     lib = x3.lib()
@@ -259,7 +260,7 @@ def test_decode_whole_groups_of_other_frame_lengths(ctx, x3, bpf):
         ctx.upload(d_wav, wav)
         assert ctx.encode_dev(d_wav, n, p, d_out, cap, 0, d_off) == 0
         assert ctx.encode_result()[0] == 0
-        for shift in (16, 48, 80):
+        for shift in (16, 48, 80, 8, 72):
             ctx.upload(d_back, np.zeros(n + 128, dtype=np.int16))
             assert ctx.decode_dev(d_out, cap, d_off, F, p, d_back + shift, n, n_per_clip=n) == 0
             r = ctx.decode_result()

@@ -86,8 +86,10 @@ int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint6
     // follow the reference's formula literally and take every other code set.
     const bool split = fast && dp.block_len == X3S_BL && dp.k[1] == 1u && dp.k[2] == 3u &&
                        (!d_wav_offsets || wav_off_aligned) && !c->force_single_wave_decode &&
-                       !c->opt.decode_single && (reinterpret_cast<uintptr_t>(d_wav) & 15u) == 0 &&
-                       (d_wav_offsets || ((dp.spf % 8u) == 0 && (g.fpc * (uint64_t)1 >= g.n_frames || (g.clip_stride % 8u) == 0)));
+                       !c->opt.decode_single && (reinterpret_cast<uintptr_t>(d_wav) & (d_wav_offsets ? 15u : 7u)) == 0 &&
+                       (d_wav_offsets || ((dp.spf % 4u) == 0 && (g.fpc * (uint64_t)1 >= g.n_frames || (g.clip_stride % 4u) == 0)));
+    // (rows on 16-byte boundaries: whole lines in 16-byte pieces; on 8-byte boundaries -- an output pointer, a clip stride
+    // or a frame length of 4 (mod 8) samples --: the same lines in 8-byte pieces, x3_decode_split_kernel.h flush_rows)
 #ifdef X3_PROFILING
     const size_t dyn_lds = (size_t)c->opt.dyn_lds;
 #else

@@ -343,7 +343,10 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   // group whose sample offset has that bit stops being "regular" -- half of all groups beyond 2^31 samples)
   const uint64_t wo0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(wo >> 32)) << 32) |
                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)wo);
-  bool regular = __all(active && samples == S0 && wo == wo0 + (uint64_t)lane * S0) && (S0 & 7u) == 0;
+  // (rows on 8-byte boundaries only -- an output or a clip stride of 4 (mod 8) samples, frames of an odd number of
+  // blocks --: the flusher's list with 8-byte pieces, flush_rows)
+  const bool p8 = __any(active && (reinterpret_cast<uintptr_t>(wav + wo) & 15u) != 0u);
+  bool regular = __all(active && samples == S0 && wo == wo0 + (uint64_t)lane * S0) && (S0 & 7u) == 0 && !p8;
   const bool cls8 = (S0 & 15u) != 0u;
   const uint64_t B0 = (uint64_t)(uintptr_t)(wav + wo0);  // destination byte address of the group (16-byte aligned)
   uint8_t* const line0 = reinterpret_cast<uint8_t*>(B0 & ~127ull);  // its first line
@@ -455,9 +458,11 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     // do); then eight lanes take one listed row each round, as in the classes' flush.  (Until round 4 the valuer moved
     // such rows itself, sixteen bytes per lane and store: a batch of clips with ragged ends decoded at half the speed.)
     uint32_t g_rem = samples ? samples - 1u : 0u, g_have = 0, g_nfl = 0;
-    const uint64_t g_B = (uint64_t)(uintptr_t)(wav + wo);              // the row's first byte (16-byte aligned)
-    const uint32_t g_p0 = (uint32_t)(g_B & 127u) >> 4;                 // pieces of its first line in front of it
-    const uint32_t g_end = g_p0 + (samples >> 3);                      // end of its whole pieces, counted from that line
+    const uint32_t g_sh = p8 ? 3u : 4u;                                // pieces of 8 or 16 bytes (the group's rows allow)
+    const uint32_t g_pl = 128u >> g_sh;                                // pieces per line = lanes per listed row
+    const uint64_t g_B = (uint64_t)(uintptr_t)(wav + wo);              // the row's first byte
+    const uint32_t g_p0 = (uint32_t)(g_B & 127u) >> g_sh;              // pieces of its first line in front of it
+    const uint32_t g_end = g_p0 + (samples >> (g_sh - 1u));            // end of its whole pieces, counted from that line
     const uint32_t g_rot = 16u * ((lane >> 2) & 15u);
     auto flush_rows = [&]() {
       X3_WAVE_LDS_ORDER();
@@ -465,10 +470,10 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       // a line that the staged dwords reach the end of -- or the row's last, partial line as soon as everything is
       // staged: a lane whose frame has ended goes on through the group's blocks, and what its valuer lane stages from
       // then on is not the row's (six blocks on it is over the row's last samples)
-      const bool whole = (((g_p0 << 2) + (g_have >> 1)) >> 5) > n && 8u * n + 8u <= g_end;
-      const bool rest = !whole && g_rem == 0u && 8u * n < g_end;
-      uint32_t p_hi = whole ? 8u : g_end - 8u * n;
-      if (p_hi > 8u) p_hi = 8u;
+      const bool whole = ((((uint32_t)(g_B & 127u) >> 2) + (g_have >> 1)) >> 5) > n && g_pl * n + g_pl <= g_end;
+      const bool rest = !whole && g_rem == 0u && g_pl * n < g_end;
+      uint32_t p_hi = whole ? g_pl : g_end - g_pl * n;
+      if (p_hi > g_pl) p_hi = g_pl;
       const uint32_t p_lo = n ? 0u : g_p0;
       const bool ready = active && s_dead[lane] == 0u && (whole || rest) && p_hi > p_lo;
       const unsigned long long mask = __ballot(ready);
@@ -477,20 +482,23 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       const uint64_t la = (g_B & ~127ull) + 128ull * n;
       if (ready) {
         x3_lds_write_b128(x3_lds_addr(s_prm) + 16u * rank, (uint32_t)la, (uint32_t)(la >> 32),
-                          lane | ((((uint32_t)la + g_rot) & 255u) << 8) | (p_lo << 16) | (p_hi << 20), 0u);
+                          lane | ((((uint32_t)la + g_rot) & 255u) << 8) | (p_lo << 16) | (p_hi << 21), 0u);
         g_nfl = n + 1u;
       }
       X3_WAVE_LDS_ORDER();
       const uint32_t nready = (uint32_t)__builtin_popcountll(mask);
-      for (uint32_t i = 0; 8u * i < nready; ++i) {
-        const uint32_t idx = 8u * i + (lane >> 3);
+      const uint32_t per_round = 64u >> (7u - g_sh);   // listed rows a round takes: 8 (16-byte pieces) or 4
+      const uint32_t px = lane & (g_pl - 1u);          // this lane's piece of its row's line
+      for (uint32_t i = 0; per_round * i < nready; ++i) {
+        const uint32_t idx = per_round * i + (lane >> (7u - g_sh));
         if (idx < nready) {
           const x3_u32x4 e = x3_lds_read_b128(x3_lds_addr(s_prm) + 16u * idx);
-          const uint32_t row = e.z & 63u, rb = (e.z >> 8) & 255u, lo = (e.z >> 16) & 15u, hi = (e.z >> 20) & 15u;
-          if (pc >= lo && pc < hi) {
-            const x3_u32x4 v = x3_lds_read_b128(x3_lds_addr(outs) + row * (4u * X3S_RING_DW) + ((rb + 16u * pc) & 255u));
+          const uint32_t row = e.z & 63u, rb = (e.z >> 8) & 255u, lo = (e.z >> 16) & 31u, hi = (e.z >> 21) & 31u;
+          if (px >= lo && px < hi) {
             uint8_t* const dst = reinterpret_cast<uint8_t*>(((uint64_t)e.y << 32) | e.x);
-            x3_store_stream16(dst + 16u * pc, v);
+            const uint32_t src = x3_lds_addr(outs) + row * (4u * X3S_RING_DW) + ((rb + (px << g_sh)) & 255u);
+            if (p8) x3_store_stream8(dst + 8u * px, x3_lds_read_b64(src));
+            else x3_store_stream16(dst + 16u * px, x3_lds_read_b128(src));
           }
         }
       }
@@ -813,7 +821,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       if (!alive) s_dead[lane] = 1u;  // (visible to the flusher behind the next barrier)
       // (the flusher moves whole 16-byte pieces.)  The ragged end of a frame, fewer than eight samples:
       if (!regular && finished && alive)
-        for (uint32_t sx = samples & ~7u; sx < samples; ++sx)
+        for (uint32_t sx = samples & (p8 ? ~3u : ~7u); sx < samples; ++sx)
           o[sx] = (int16_t)x3_lds_read_u16(x3_and_or(pos0 + 2u * sx, 254u, orow_b), 0u);
       X3_STAMP(5);
     }

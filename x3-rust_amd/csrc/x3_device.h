@@ -253,6 +253,12 @@ __device__ __forceinline__ void x3_lds_write_u16(uint32_t addr, uint32_t v) {
 }
 // sixteen bytes to global memory as a streaming (non-temporal) store: output that is written once and not read
 // again by this kernel must not displace what the kernel is still reading from L2
+__device__ __forceinline__ x3_u32x2 x3_lds_read_b64(uint32_t addr) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) x3_u32x2*>(addr);
+}
+__device__ __forceinline__ void x3_store_stream8(void* p, x3_u32x2 v) {
+  __builtin_nontemporal_store(v, reinterpret_cast<x3_u32x2*>(p));
+}
 __device__ __forceinline__ void x3_store_stream16(void* p, x3_u32x4 v) {
   __builtin_nontemporal_store(v, reinterpret_cast<x3_u32x4*>(p));
 }
