@@ -9,8 +9,8 @@
 // ------------------------------------------------------------------------------------------------
 // decode
 // ------------------------------------------------------------------------------------------------
-// wav_off_aligned: the caller knows that every d_wav_offsets[f] is a multiple of eight samples (the two-wave decoder
-// writes 16-byte aligned rows); without that knowledge caller-supplied offsets go to the single-wave kernels
+// wav_off_aligned: the caller knows that every d_wav_offsets[f] is a multiple of FOUR samples (the three-wave decoder
+// moves rows in 8- or 16-byte pieces); without that knowledge caller-supplied offsets go to the single-wave kernels
 int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint64_t* d_frame_offsets,
                            uint64_t F, const x3_batch* batch, const uint64_t* d_wav_offsets, const x3_params* p,
                            int16_t* d_wav, uint64_t wav_cap, int32_t* d_status, bool wav_off_aligned,
@@ -86,7 +86,7 @@ int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint6
     // follow the reference's formula literally and take every other code set.
     const bool split = fast && dp.block_len == X3S_BL && dp.k[1] == 1u && dp.k[2] == 3u &&
                        (!d_wav_offsets || wav_off_aligned) && !c->force_single_wave_decode &&
-                       !c->opt.decode_single && (reinterpret_cast<uintptr_t>(d_wav) & (d_wav_offsets ? 15u : 7u)) == 0 &&
+                       !c->opt.decode_single && (reinterpret_cast<uintptr_t>(d_wav) & 7u) == 0 &&
                        (d_wav_offsets || ((dp.spf % 4u) == 0 && (g.fpc * (uint64_t)1 >= g.n_frames || (g.clip_stride % 4u) == 0)));
     // (rows on 16-byte boundaries: whole lines in 16-byte pieces; on 8-byte boundaries -- an output pointer, a clip stride
     // or a frame length of 4 (mod 8) samples --: the same lines in 8-byte pieces, x3_decode_split_kernel.h flush_rows)
@@ -457,7 +457,7 @@ int decode_frames_host(x3_ctx* c, const uint8_t* x3, uint64_t len, const HostWal
   if (pp.block_len == 0) pp.block_len = 1;  // frames that need block_len were routed to BAD_ARG by the walk
   const uint64_t dev_wav_cap = std::min<uint64_t>(wav_cap, w.nsamp + 65535);
   bool aligned = true;
-  for (uint64_t v : w.woffs) aligned = aligned && (v & 7ull) == 0;
+  for (uint64_t v : w.woffs) aligned = aligned && (v & 3ull) == 0;   // (rows on the 8-byte grid)
   if ((rc = decode_dev_impl(c, d_x3, len, (const uint64_t*)c->frame_off.p, F, nullptr,
                             (const uint64_t*)c->wav_off.p, &pp, (int16_t*)c->out.p, dev_wav_cap, nullptr, aligned,
                             p->block_len == 0)))

@@ -241,7 +241,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       st = X3D_BAD_ARG;
       active = false;
     } else {
-      if (wav_off) {  // (the caller vouches for multiples of eight samples: 16-byte aligned output rows)
+      if (wav_off) {  // (the caller vouches for multiples of four samples: output rows on 8-byte boundaries at least)
         wo = wav_off[f];
       } else {
         const uint64_t clip = f / g.fpc;

@@ -329,7 +329,7 @@ x3_index_emit_kernel(const X3Cand* __restrict__ cand, uint32_t n, uint32_t level
   }
   frame_off[k] = cand[node].off;
   wav_off[k] = acc;
-  if ((acc & 7ull) && sum->unaligned == 0) sum->unaligned = 1;  // a sample offset that is not a multiple of eight
+  if ((acc & 3ull) && sum->unaligned == 0) sum->unaligned = 1;  // a sample offset that is not a multiple of four
   // decodefile walk as the host runs it: a frame that does not fit the output is pushed and ends the walk
   if ((cand[node].plen_kind >> 16) == X3I_CONT && acc + cand[node].samples > wav_cap) atomicMin(&sum->first_over, k);
   if (k == n_chain - 1) sum->last_node = node;
@@ -463,7 +463,7 @@ x3_index_link_kernel(const X3Cand* __restrict__ cand_wg, const unsigned int* __r
     sorted[k] = cd;
     frame_off[k] = cd.off;
     wav_off[k] = acc;
-    if ((acc & 7ull) && sum->unaligned == 0) sum->unaligned = 1;
+    if ((acc & 3ull) && sum->unaligned == 0) sum->unaligned = 1;
     if (acc + cd.samples > wav_cap) atomicMin(&sum->first_over, k);
     if (k == 0ull) sum->start = 0u;
   }

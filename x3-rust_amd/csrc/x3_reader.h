@@ -100,7 +100,7 @@ static int reader_fill(x3_reader* r) {
   x3_params pp = r->p;
   if (pp.block_len == 0) pp.block_len = 1;  // (frames that need block_len are BAD_ARG frames of the walk)
   bool aligned = true;
-  for (size_t i = 0; i < F; ++i) aligned = aligned && (hw.woffs[i] & 7ull) == 0;
+  for (size_t i = 0; i < F; ++i) aligned = aligned && (hw.woffs[i] & 3ull) == 0;
   if ((rc = decode_dev_impl(c, (const uint8_t*)c->in.p, span, (const uint64_t*)c->frame_off.p, F, nullptr,
                             (const uint64_t*)c->wav_off.p, &pp, (int16_t*)c->out.p, hw.nsamp + 65535,
                             (int32_t*)c->dec_status.p, aligned, r->p.block_len == 0)))

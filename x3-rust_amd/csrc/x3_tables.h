@@ -43,6 +43,6 @@ struct X3IndexSummary {
   unsigned long long n_chain;     // scratch: frames reachable from the start node
   uint32_t start;                 // scratch: candidate at offset 0 (X3I_NONE: the walk cannot step onto it)
   uint32_t pad;                   // 1: more frames than the caller's arrays hold
-  uint32_t unaligned;             // 1: some frame's sample offset is not a multiple of eight (picks the decoder kernel)
+  uint32_t unaligned;             // 1: some frame's sample offset is not a multiple of four: rows off the 8-byte grid (picks the decoder kernel)
   uint32_t pad2;
 };
