@@ -373,6 +373,12 @@ typedef struct x3_batch {
  * whole call was encoded again inside x3_encode_result).  Options "last_dense_frames", "encode_dense_frames" count such
  * frames, "enc_gen_in_use" says which kernel generation served the last call (a call with more than a quarter of dense
  * frames makes the context's next call start on the second-generation kernel: a speed hint, the bytes are the same).
+ *   Layout: the results never depend on it, the kernels that serve a call do.  block_len 20 with up to 512 blocks a frame,
+ * d_wav on a dword boundary and (for n_clips > 1) a clip_stride that is a multiple of four samples take the single-pass
+ * encoders; x3_decode_dev takes the three-wave decoder when its output begins on an 8-byte boundary and the stride is a
+ * multiple of four samples (rows on 16-byte boundaries leave in 16-byte pieces, on 8-byte ones in 8-byte pieces, always
+ * as whole 128-byte lines).  Anything else -- other block lengths or code sets, longer frames, odd strides -- is served by
+ * the general kernels, three to eight times slower ("GPU-path limits").
  *   Residency: the default-geometry encoder is a persistent grid whose workgroups wait for each other's frame
  * sizes; on a GPU that this context does not have to itself a launch can find them not all resident, gives up after a
  * bounded wait, and x3_encode_result() then re-encodes with the general kernels (option "encode_fallbacks" counts
