@@ -110,7 +110,9 @@ x3_index_candidates_kernel(const uint32_t* __restrict__ xw, uint64_t len, uint64
   const uint64_t per_wg = ((chunks + gridDim.x - 1) / gridDim.x + blockDim.x - 1) / blockDim.x * blockDim.x;
   const uint64_t t_end = (uint64_t)(blockIdx.x + 1) * per_wg < chunks ? (uint64_t)(blockIdx.x + 1) * per_wg : chunks;
   // (the chunks of the next TWO trips are requested before this trip's is looked at; with one 16-byte load in flight per
-  // lane the kernel took 118 us for config 3's 363 MB, with three it takes 115: 3.2 TB/s either way)
+  // lane the kernel took 118 us for config 3's 363 MB, with three it takes 115: 3.2 TB/s either way.  Round 4: hipcc waits
+  // for all of them at the top of every trip -- it cannot count guarded loads --, but range-checked buffer loads in a loop
+  // unrolled by three, which it does count (vmcnt(3) at the first use), made the kernel SLOWER: 136 us.)
   auto fetch = [&](uint64_t t, uint32_t (&w)[5]) {
     if (t >= t_end) {
 #pragma unroll
