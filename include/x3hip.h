@@ -371,7 +371,9 @@ typedef struct x3_batch {
  * assigned -- whatever is enqueued on the context's stream behind this call (x3_decode_dev, a copy) finds the whole
  * stream, with or without x3_encode_result() in between; no call is encoded twice for its content (until round 3 the
  * whole call was encoded again inside x3_encode_result).  Options "last_dense_frames", "encode_dense_frames" count such
- * frames, "enc_gen_in_use" says which kernel generation served the last call (a call with more than a quarter of dense
+ * frames, "enc_gen_in_use" says which kernel served the last call -- 3 the wave encoder, 2 the second generation, 1 the
+ * general kernel in one pass (any block length: sizes by decoupled look-back), 0 the same kernel in two passes (option
+ * "two_pass", or what a launch falls back to whose waits gave up) -- (a call with more than a quarter of dense
  * frames makes the context's next call start on the second-generation kernel: a speed hint, the bytes are the same).
  *   Layout: the results never depend on it, the kernels that serve a call do.  block_len 20 with up to 512 blocks a frame,
  * d_wav on a dword boundary and (for n_clips > 1) a clip_stride that is a multiple of four samples take the single-pass

@@ -211,7 +211,7 @@ def test_short_frames_take_the_single_pass_encoder(ctx, x3, bpf):
 @pytest.mark.parametrize("shift", [4, 8, 12, 2])
 def test_encode_dev_from_a_buffer_that_is_not_16_byte_aligned(ctx, x3, shift):
     """x3_encode_dev on samples that begin 4, 8 or 12 bytes into a 16-byte unit (a slice of somebody's tensor): still the
-    single-pass encoder (its loads are dword buffer loads); 2 bytes in: the two-pass kernels.  Same stream either way."""
+    single-pass encoder (its loads are dword buffer loads); 2 bytes in: the general kernel.  Same stream either way."""
     p = x3.Params.default()
     n = 10000 * 70 + 4321
     lib = x3.lib()
@@ -226,7 +226,7 @@ def test_encode_dev_from_a_buffer_that_is_not_16_byte_aligned(ctx, x3, shift):
             assert ctx.encode_dev(d_buf + shift, n, p, d_out, cap, 0, d_off) == 0
             rc, pos, st = ctx.encode_result()
             assert rc == 0 and pos == out_o.size and list(st) == st_o.tolist()
-            assert ctx.get_option("enc_gen_in_use") == (0 if shift == 2 else (3 if kind == 2 else ctx.get_option("enc_gen_in_use")))
+            assert ctx.get_option("enc_gen_in_use") == (1 if shift == 2 else (3 if kind == 2 else ctx.get_option("enc_gen_in_use")))
             assert np.array_equal(ctx.download(d_out, pos), out_o)
             offs = ctx.download(d_off, 8 * (F + 1), np.uint64)
             assert offs[F] == pos and offs[0] == 0

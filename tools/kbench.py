@@ -17,14 +17,15 @@ ap.add_argument("--repeat", type=int, default=1, help="re-allocate and re-measur
 ap.add_argument("--loud", type=float, default=0.0, help="this share of the frames is full-scale noise (frames that do not fit the wave encoder's image)")
 ap.add_argument("--stride", type=int, default=0, help="--clips: samples from one clip's start to the next (default: the clip length)")
 ap.add_argument("--shift", type=int, default=0, help="the samples begin this many bytes into a 16-byte unit")
-ap.add_argument("--bpf", type=int, default=500, help="blocks per frame (of 20 samples)")
+ap.add_argument("--bpf", type=int, default=500, help="blocks per frame")
+ap.add_argument("--bl", type=int, default=20, help="block length (samples)")
 ap.add_argument("--opt", action="append", default=[], help="context option name=value (x3_ctx_set_option), repeatable")
 a = ap.parse_args()
 ctx = x3hip.Context(0)
 for o in a.opt:
     k, v = o.split("=")
     ctx.set_option(k, int(v))
-p = x3hip.Params.make(20, a.bpf)
+p = x3hip.Params.make(a.bl, a.bpf)
 n = a.samples
 L = x3hip.lib()
 npc = n // a.clips

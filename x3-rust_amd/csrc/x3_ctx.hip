@@ -256,7 +256,7 @@ extern "C" void x3_ctx_destroy(x3_ctx* c) {
   if (c->fcache) x3_reader_close(c->fcache);
   for (DevBuf* b : {&c->in, &c->out, &c->in_more[0], &c->in_more[1], &c->out_more[0], &c->out_more[1], &c->frame_bytes, &c->frame_off, &c->dec_status, &c->dec_cstatus, &c->dec_meta, &c->wav_off,
                     &c->seg_crc, &c->desc, &c->idx_cand, &c->idx_keys, &c->idx_vals, &c->idx_J, &c->idx_S,
-                    &c->idx_L, &c->idx_sum, &c->idx_wg, &c->idx_sorted, &c->idx_scan, &c->dense_list})
+                    &c->idx_L, &c->idx_sum, &c->idx_wg, &c->idx_sorted, &c->idx_scan, &c->dense_list, &c->lb_desc})
     if (b->p) (void)hipFree(b->p);
   for (auto& t : c->timers) {
     for (auto& e : t.used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -330,7 +330,7 @@ extern "C" int x3_ctx_get_option(const x3_ctx* c, const char* name, long long* v
   else if (n == "encode_dense_reruns") *value = 0;  // (rounds 2-3: whole calls encoded again for a dense frame; no longer happens)
   else if (n == "encode_dense_frames") *value = (long long)c->encode_dense_frames;  // read-only: frames the dense pass has written
   else if (n == "last_dense_frames") *value = (long long)c->last_dense_frames;      // read-only: of the last call (after x3_encode_result)
-  else if (n == "enc_gen_in_use") *value = c->last_enc_gen;                          // read-only: 3, 2, 1, or 0 = two-pass kernels
+  else if (n == "enc_gen_in_use") *value = c->last_enc_gen;                          // read-only: 3 = wave encoder, 2 = second generation, 1 = the general kernel in one pass (look-back), 0 = two passes
   else if (n == "host_walk") *value = c->opt.host_walk;
   else if (n == "host_chunk_frames") *value = c->opt.host_chunk_frames;
   else if (n == "verbose") *value = c->opt.verbose;

@@ -226,6 +226,31 @@ int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_frames_kernel<false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem));
   }
+  // ---- any geometry in ONE pass (round 4): sizes by decoupled look-back (x3_encode_kernel.h, LOOKBACK).  The two passes
+  // below stay as what a launch falls back to whose look-back gave up (x3_encode_result), and for option two_pass.
+  if (!c->force_two_pass && !c->opt.two_pass) {
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_frames_kernel<false, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(pl.smem, 64 * 1024)));
+    const size_t lb_bytes = F * sizeof(unsigned long long);
+    const bool fresh = c->lb_desc.cap < lb_bytes;
+    if ((rc = ensure(c, c->lb_desc, lb_bytes))) return rc;
+    if (fresh || ++c->lb_epoch > 0xFFFu) {
+      HIPCHK(c, hipMemsetAsync(c->lb_desc.p, 0, c->lb_desc.cap, c->stream));
+      c->lb_epoch = 1;
+    }
+    {
+      TimerScope ts(c, 0);
+      hipLaunchKernelGGL((x3_encode_frames_kernel<false, true>), dim3((unsigned)F), dim3(pl.nthr), pl.smem, c->stream, d_wav,
+                         pl.g, pl.dp, (const uint64_t*)d_off, (uint32_t*)c->lb_desc.p, d_out, start_pos, c->d_stats,
+                         c->d_status, (const uint16_t*)c->d_xpow, pl.lds_in_bytes, pl.img_dwords, 1u, (uint64_t)0,
+                         c->lb_epoch, out_cap, c->d_end_pos);
+    }
+    HIPCHK(c, hipGetLastError());
+    c->last_enc_gen = 1;
+    c->encode_pending = true;
+    c->enc_start_pos = start_pos;
+    return X3_OK;
+  }
   {
     TimerScope ts(c, 2);
     hipLaunchKernelGGL(x3_encode_frames_kernel<true>, dim3((unsigned)F), dim3(pl.nthr),

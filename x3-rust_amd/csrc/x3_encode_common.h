@@ -10,8 +10,6 @@
 #pragma once
 #include "x3_encode_kernel.h"
 
-#define X3_SPIN_LIMIT (1u << 16)  // polls of >= 1 memory round trip each (~0.1 s): a bounded spin, never a hang
-#define X3D_SIZE_WAIT_TIMEOUT 100  // internal: the host re-runs the two-pass encoder (x3_encode_result)
 
 typedef short x3_short2 __attribute__((ext_vector_type(2)));
 typedef unsigned short x3_ushort2 __attribute__((ext_vector_type(2)));

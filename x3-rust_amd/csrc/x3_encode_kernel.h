@@ -24,6 +24,10 @@
 #pragma once
 #include "x3_device.h"
 
+// bounded waits of the single-pass encoders (this file's LOOKBACK mode, x3_encode_stream2_kernel.h, x3_encode_wave_kernel.h)
+#define X3_SPIN_LIMIT (1u << 16)  // polls of >= 1 memory round trip each (~0.1 s): a bounded spin, never a hang
+#define X3D_SIZE_WAIT_TIMEOUT 100  // internal: the host re-runs the two-pass encoder (x3_encode_result)
+
 struct X3BitEmitter {
   uint32_t* words;  // LDS payload, word w = stream bytes 4w..4w+3 in memory order
   uint32_t w;
@@ -56,14 +60,25 @@ struct X3BitEmitter {
 
 #define X3_ENC_SMEM_HDR 256u  // bytes of bookkeeping in front of the dynamic LDS carve
 
-template <bool SIZES_ONLY>
+// LOOKBACK (round 4): ONE pass for any geometry.  The frame's size is known behind the analysis; a descriptor word per
+// frame -- {flag:2 | epoch:12 | bytes:50}, flag 1 = this frame's bytes, 2 = all bytes up to and including this frame --
+// goes out at once, and in front of the copy-out one wave looks back over the descriptors of the frames before it, 64 at a
+// time, until it meets an inclusive one (decoupled look-back; a workgroup only ever waits for workgroups with smaller
+// indices, which were dispatched before it).  frame_off is then an OUTPUT (F + 1 entries), frame_bytes holds the
+// descriptors (64-bit words), lb_epoch tags them, end_pos / status[0] are what the scan kernel of the two-pass path
+// leaves.  A wait that does not end (X3_SPIN_LIMIT) reports X3D_SIZE_WAIT_TIMEOUT and the host encodes again in two passes.
+#define X3_LB_FLAG_SHIFT 62
+#define X3_LB_EPOCH_SHIFT 50
+#define X3_LB_VALUE_MASK ((1ull << X3_LB_EPOCH_SHIFT) - 1ull)
+template <bool SIZES_ONLY, bool LOOKBACK = false>
 __global__ void __launch_bounds__(1024)
 x3_encode_frames_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p,
                         const uint64_t* __restrict__ frame_off, uint32_t* __restrict__ frame_bytes,
                         uint8_t* __restrict__ out, uint64_t start_pos,
                         unsigned long long* __restrict__ stats, int* __restrict__ status,
                         const uint16_t* __restrict__ xpow, uint32_t lds_in_bytes, uint32_t img_dwords,
-                        uint32_t n_ch, uint64_t ch_stride) {
+                        uint32_t n_ch, uint64_t ch_stride, uint32_t lb_epoch = 0, uint64_t out_cap = 0,
+                        unsigned long long* __restrict__ end_pos = nullptr) {
   // n_ch > 1: the multi-channel extension (not in the reference, which stops at MoreThanOneChannel: encoder.rs:55-57).
   // Channel c's samples are at wav + c * ch_stride; a frame holds n samples of EVERY channel: <Audio State> = the
   // first sample of each channel, then the blocks in the order (block index, channel) -- "pack the data block for each
@@ -80,7 +95,7 @@ x3_encode_frames_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
 
   // status[0] is written by the size pass / scan kernel (bad block, output overflow) and only
   // READ here, so the early exit is uniform; this kernel reports into status[1].
-  if (!SIZES_ONLY) {
+  if (!SIZES_ONLY && !LOOKBACK) {
     if (status[0] != 0) return;
   }
 
@@ -254,12 +269,24 @@ x3_encode_frames_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
   }
 
   __syncthreads();  // emission complete
-  if (part[40] || 5u + ((L + 3u) >> 2) > img_dwords) {
+  unsigned long long* const lb_desc = reinterpret_cast<unsigned long long*>(frame_bytes);
+  const unsigned long long lb_tag = (unsigned long long)(lb_epoch & 0xFFFu) << X3_LB_EPOCH_SHIFT;
+  const bool lb_bad = part[40] || 5u + ((L + 3u) >> 2) > img_dwords;
+  if (LOOKBACK) {
+    // this frame's bytes, at once (a frame that cannot be encoded still counts its bytes: nobody behind it may hang)
+    if (tid == 0) {
+      __hip_atomic_store(&lb_desc[f], (1ull << X3_LB_FLAG_SHIFT) | lb_tag | (unsigned long long)(20u + L), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      if (lb_bad) atomicMax(&status[0], X3D_BAD_ARG);   // (the reference indexes outside its Rice table here: panic)
+    }
+  } else
+  if (lb_bad) {
     if (tid == 0) atomicMax(&status[1], X3D_BAD_ARG);
     return;
   }
 
   // ---- E: payload CRC-16 (bitpacker.rs:79-82 updates it per flushed byte; here: reduction)
+  if (!(LOOKBACK && lb_bad)) {   // (uniform; a frame that cannot be encoded only takes part in the look-back)
   const uint32_t Lw = (L + 3u) >> 2;                 // payload dwords (last may hold 2 pad-to-4 zero bytes)
   const uint32_t c_dw = (Lw + nthr - 1) / nthr;      // dwords per lane, uniform
   const int32_t j0 = (int32_t)(tid * c_dw) - (int32_t)(nthr * c_dw - Lw);  // right-aligned chunks
@@ -306,9 +333,67 @@ x3_encode_frames_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
     }
   }
   __syncthreads();
+  }
 
   // ---- F: copy header + payload to the final stream position
-  const uint64_t off = frame_off[f];
+  uint64_t off;
+  if (LOOKBACK) {
+    unsigned long long* const lb_off = reinterpret_cast<unsigned long long*>(part + 48);   // (LDS: the wave's result)
+    if (wid == 0) {
+      unsigned long long excl = (start_pos + 1ull) & ~1ull;   // writer.align::<2>() (encoder.rs:182)
+      bool lost = false;
+      if (f != 0) {
+        excl = 0;
+        uint64_t top = f;   // descriptors [top - 64, top) are looked at next
+        uint32_t spins = 0;
+        for (;;) {
+          const bool in = lane < top;
+          unsigned long long d = 0;
+          if (in) d = __hip_atomic_load(&lb_desc[top - 1 - lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const bool ready = !in || ((d >> X3_LB_FLAG_SHIFT) != 0ull && ((d ^ lb_tag) & (0xFFFull << X3_LB_EPOCH_SHIFT)) == 0ull);
+          if (!__all(ready)) {
+            if (++spins > X3_SPIN_LIMIT) { lost = true; break; }
+            __builtin_amdgcn_s_sleep(4);
+            continue;
+          }
+          // the nearest inclusive word ends the walk; everything in front of it counts with its own bytes
+          const unsigned long long incl_mask = __ballot(in && (d >> X3_LB_FLAG_SHIFT) == 2ull);
+          const uint32_t stop = incl_mask ? (uint32_t)__builtin_ctzll(incl_mask) : 64u;
+          unsigned long long v = (in && lane <= stop) ? (d & X3_LB_VALUE_MASK) : 0ull;
+#pragma unroll
+          for (int sh = 1; sh < X3_WAVE; sh <<= 1) v += __shfl_xor(v, sh, X3_WAVE);
+          excl += v;
+          if (incl_mask) break;
+          if (top <= 64) { excl += (start_pos + 1ull) & ~1ull; break; }   // walked all the way to frame 0
+          top -= 64;
+        }
+      }
+      if (lane == 0) {
+        if (lost) {
+          atomicMax(&status[1], X3D_SIZE_WAIT_TIMEOUT);
+          // (whoever waits for this frame must not hang either: an inclusive word that is wrong ends their walks)
+          __hip_atomic_store(&lb_desc[f], (2ull << X3_LB_FLAG_SHIFT) | lb_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          *lb_off = ~0ull;
+        } else {
+          const unsigned long long incl = excl + 20u + L;
+          __hip_atomic_store(&lb_desc[f], (2ull << X3_LB_FLAG_SHIFT) | lb_tag | (incl & X3_LB_VALUE_MASK), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+          const_cast<uint64_t*>(frame_off)[f] = excl;
+          if (f + 1 == gridDim.x) {
+            const_cast<uint64_t*>(frame_off)[f + 1] = incl;
+            *end_pos = incl;
+          }
+          if (incl > out_cap) atomicMax(&status[0], X3D_BYTE_WRITER_INSUFFICIENT_MEMORY);
+          *lb_off = (incl > out_cap || lb_bad) ? ~0ull : excl;
+        }
+      }
+    }
+    __syncthreads();
+    off = *lb_off;
+    if (off == ~0ull) return;   // nothing of this frame is written
+  } else {
+    off = frame_off[f];
+  }
   uint8_t* dst = out + off;
   const uint32_t total_bytes = 20u + L;  // even
   const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u);

@@ -96,6 +96,8 @@ struct x3_ctx {
   int* d_status = nullptr;             // [0] size/scan pass, [1] encode pass
   unsigned long long* d_stats = nullptr;    // 6
   unsigned long long* d_end_pos = nullptr;  // 1
+  DevBuf lb_desc;                            // the general single-pass encoder's look-back descriptors (u64 per frame)
+  uint32_t lb_epoch = 0;
   X3DecodeSummary* d_summary = nullptr;
   struct x3_reader* fcache = nullptr;  // x3_decode_prefetch: the frame stream x3_decode_frame calls are served from
   uint32_t* d_pace = nullptr;          // x3_decode_split_kernel's pace word (see there), dec_epoch its launch count
