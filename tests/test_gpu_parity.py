@@ -491,6 +491,12 @@ def test_encode_batch(ctx, x3):
         assert np.array_equal(out[offs[i]:offs[i + 1]], o)
         tot += st
     assert stats.tolist() == tot.tolist()
+    # a uniform batch whose clip length is odd: side by side on the device at a padded stride, the wave encoder all the same
+    odd = [x3.synth(2, 1500 + i, 0, 57601) for i in range(70)]
+    rc, out, offs, stats = ctx.encode_batch(odd)
+    assert rc == 0 and ctx.get_option("enc_gen_in_use") == 3
+    for i, c in enumerate(odd):
+        assert np.array_equal(out[offs[i]:offs[i + 1]], O.encode(c)[1]), i
     ragged = [x3.synth(4, 2000 + i, 0, n) for i, n in enumerate([1, 10000, 25001, 3])]
     rc, out, offs, stats = ctx.encode_batch(ragged)
     assert rc == 0

@@ -336,14 +336,17 @@ int encode_host(x3_ctx* c, const int16_t* const* wavs, uint64_t n_per_clip, uint
                        const x3_params* p, uint64_t spf, uint8_t* out, uint64_t out_cap, uint64_t start_pos,
                        uint64_t* out_pos, uint64_t* clip_offsets, uint64_t stats[6]) {
   HIPCHK(c, hipSetDevice(c->device));
-  const uint64_t total = n_per_clip * n_clips;
+  // (the clips side by side on the device at a stride of a multiple of eight samples: whatever their length, the batch then
+  // takes the single-pass encoders -- x3_encode_dev's "Layout")
+  const uint64_t stride = n_clips > 1 ? (n_per_clip + 7) & ~7ull : n_per_clip;
+  const uint64_t total = stride * n_clips;
   int rc = ensure(c, c->in, total * sizeof(int16_t) + 16);
   if (rc) return rc;
   for (uint64_t k = 0; k < n_clips; ++k)
-    HIPCHK(c, hipMemcpyAsync((int16_t*)c->in.p + k * n_per_clip, wavs[k], n_per_clip * sizeof(int16_t),
+    HIPCHK(c, hipMemcpyAsync((int16_t*)c->in.p + k * stride, wavs[k], n_per_clip * sizeof(int16_t),
                              hipMemcpyHostToDevice, c->stream));
   x3_params pp = *p;
-  x3_batch b{n_per_clip, n_per_clip, n_clips};
+  x3_batch b{n_per_clip, stride, n_clips};
   uint64_t bound;
   {
     uint64_t full = n_per_clip / spf, tail = n_per_clip % spf;
