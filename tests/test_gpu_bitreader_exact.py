@@ -105,10 +105,16 @@ def run_batch(x3, ctx, params, frames, mode):
     ctx.upload(d_wav, np.full(STRIDE * F, 0x5A5A, dtype=np.int16))
     d_st = ctx.alloc(4 * F)
     spf = params.block_len * params.blocks_per_frame
-    if mode == "offsets":     # caller-supplied sample offsets: the single-wave kernels
+    if mode in ("offsets", "offsets_x4"):
+        # caller-supplied sample offsets: the single-wave kernels -- or, with the caller's promise that they are multiples
+        # of four samples (option wav_offsets_x4), the three-wave decoder and its list of rows (every row its own length)
         d_wo = ctx.alloc(8 * F)
         ctx.upload(d_wo, (np.arange(F, dtype=np.uint64) * STRIDE))
-        rc = ctx.decode_dev(d_x3, pos, d_off, F, params, d_wav, STRIDE * F, d_wav_offsets=d_wo, d_status=d_st)
+        ctx.set_option("wav_offsets_x4", 1 if mode == "offsets_x4" else 0)
+        try:
+            rc = ctx.decode_dev(d_x3, pos, d_off, F, params, d_wav, STRIDE * F, d_wav_offsets=d_wo, d_status=d_st)
+        finally:
+            ctx.set_option("wav_offsets_x4", 0)
     else:                     # a batch of F one-frame clips: the two-wave kernel for block_len 20
         d_wo = None
         rc = ctx.decode_dev(d_x3, pos, d_off, F, params, d_wav, STRIDE * F, n_per_clip=spf, n_clips=F,
@@ -141,7 +147,7 @@ def compare(x3, ctx, params, frames, mode):
     return seen
 
 
-@pytest.mark.parametrize("mode", ["batch", "offsets"])
+@pytest.mark.parametrize("mode", ["batch", "offsets", "offsets_x4"])
 def test_short_and_corrupt_payloads_default_params(x3, mode):
     rng = np.random.default_rng(20261004)
     p = x3.Params.default()

@@ -316,6 +316,7 @@ extern "C" int x3_ctx_set_option(x3_ctx* c, const char* name, long long value) {
   else if (n == "check_wgs") c->opt.check_wgs = (int)std::max(1ll, value);
   else if (n == "mc_decode_threads") c->opt.mc_decode_threads = value != 0;
   else if (n == "index_no_fast") c->opt.index_no_fast = value != 0;
+  else if (n == "wav_offsets_x4") c->opt.wav_offsets_x4 = value != 0;
   else return X3_ERR_BAD_ARG;
   return X3_OK;
 }
@@ -350,6 +351,7 @@ extern "C" int x3_ctx_get_option(const x3_ctx* c, const char* name, long long* v
   else if (n == "check_wgs") *value = c->opt.check_wgs;
   else if (n == "mc_decode_threads") *value = c->opt.mc_decode_threads;
   else if (n == "index_no_fast") *value = c->opt.index_no_fast;
+  else if (n == "wav_offsets_x4") *value = c->opt.wav_offsets_x4;
   else if (n == "index_fast_walks") *value = (long long)c->index_fast;        // read-only counters
   else if (n == "index_general_walks") *value = (long long)c->index_general;
   else if (n == "check_prio") *value = c->opt.check_prio;

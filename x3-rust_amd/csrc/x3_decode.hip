@@ -147,7 +147,10 @@ extern "C" int x3_decode_dev(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, co
                              const x3_params* p, int16_t* d_wav, uint64_t wav_cap, int32_t* d_status) {
   if (!c || !d_x3 || !d_frame_offsets || !p || !d_wav) return X3_ERR_BAD_ARG;
   HIPCHK(c, hipSetDevice(c->device));
-  return decode_dev_impl(c, d_x3, x3_len, d_frame_offsets, n_frames, batch, d_wav_offsets, p, d_wav, wav_cap, d_status);
+  // (caller-supplied sample offsets: the three-wave decoder needs rows on 8-byte boundaries, and only the caller can know
+  // that without a pass over the offsets -- option "wav_offsets_x4")
+  return decode_dev_impl(c, d_x3, x3_len, d_frame_offsets, n_frames, batch, d_wav_offsets, p, d_wav, wav_cap, d_status,
+                         d_wav_offsets != nullptr && c->opt.wav_offsets_x4 != 0);
 }
 
 extern "C" int x3_decode_result(x3_ctx* c, uint64_t* first_bad, int* first_bad_status, uint64_t* samples_before) {

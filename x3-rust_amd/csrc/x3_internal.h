@@ -65,6 +65,7 @@ struct X3Opts {
   int check_prio = 1;         // X3HIP_CHECK_PRIO: queue priority of the side stream the check kernel runs on (-1 low, 0 same, 1 high)
   int check_first = 0;        // X3HIP_CHECK_FIRST: enqueue the check kernel in front of the decoder (1) or behind it (0)
   int index_no_fast = 0;      // 1: x3_index_dev / x3_decode_stream_dev always take the general walk (hash + pointer doubling)
+  int wav_offsets_x4 = 0;     // 1: the caller promises that every d_wav_offsets[] given to x3_decode_dev is a multiple of four samples
   int mc_decode_threads = 0;  // multi-channel decode: 1 = one thread per frame (the pre-round-4 kernel) for every frame
   int check_wgs = 4;          // X3HIP_CHECK_WGS: check-kernel workgroups per CU (8 until the kernel got leaner in round 3: gpurun_out sweep in profiles/r3)
 #ifdef X3_PROFILING
