@@ -393,7 +393,16 @@ typedef struct x3_batch {
  * on the same context in between is fine -- same stream -- as long as its result is only used after that). */
 int x3_encode_dev(x3_ctx* ctx, const int16_t* d_wav, const x3_batch* batch, const x3_params* p,
                   uint8_t* d_out, uint64_t out_cap, uint64_t start_pos, uint64_t* d_frame_offsets);
-/* Waits for the last x3_encode_dev; status is X3_OK, BYTE_WRITER_INSUFFICIENT_MEMORY or BAD_ARG. */
+/* The same for frames taken from anywhere in a device buffer: frame f is the src_samples[f] samples
+ * (1 .. block_len * blocks_per_frame) at d_wav + src_offsets[f]; the stream holds them in this order.  A batch of clips of
+ * DIFFERENT lengths is such a list (each clip cut into frames as encoder::encode cuts it, encoder.rs:61-73: full frames and
+ * a last short one), one launch set for all of them instead of one per clip; d_frame_offsets[F + 1] then gives every clip's
+ * byte range.  src_offsets / src_samples are HOST arrays (checked and copied here); offsets that are all even take the
+ * single-pass encoders.  Asynchronous like x3_encode_dev; results via x3_encode_result(). */
+int x3_encode_frames_dev(x3_ctx* ctx, const int16_t* d_wav, const uint64_t* src_offsets, const uint32_t* src_samples,
+                         uint64_t n_frames, const x3_params* p, uint8_t* d_out, uint64_t out_cap, uint64_t start_pos,
+                         uint64_t* d_frame_offsets);
+/* Waits for the last x3_encode_dev / x3_encode_frames_dev; status is X3_OK, BYTE_WRITER_INSUFFICIENT_MEMORY or BAD_ARG. */
 int x3_encode_result(x3_ctx* ctx, uint64_t* out_pos, uint64_t stats[6]);
 
 /* Decode F frames of a device-resident stream.  d_frame_offsets[f] = byte offset of frame f's

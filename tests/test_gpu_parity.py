@@ -504,6 +504,71 @@ def test_encode_batch(ctx, x3):
         assert np.array_equal(out[offs[i]:offs[i + 1]], O.encode(c)[1])
 
 
+def test_encode_frames_dev_clips_of_different_lengths(ctx, x3):
+    """x3_encode_frames_dev: a batch of clips of DIFFERENT lengths as one list of frames (one launch set): each clip's
+    bytes equal the oracle's encoding of that clip; clips at even and (second round) at odd sample offsets -- the wave
+    encoder and the general kernel --, loud clips (the dense pass) among them, the frames decoded back through the frame
+    index and per-frame sample offsets."""
+    p = x3.Params.default()
+    spf = 10000
+    rng = np.random.default_rng(77)
+    lens = [1, 7, 9999, 10000, 10001, 25000, 31234, 40000, 57601, 3, 20000, 12345] + [int(v) for v in rng.integers(1, 70000, size=60)]
+    lib = x3.lib()
+    for odd in (False, True):
+        ctx.set_option("enc_gen", 3)   # (forget what earlier calls said about dense content)
+        starts, pos = [], (1 if odd else 0)
+        clips = []
+        for i, n in enumerate(lens):
+            starts.append(pos)
+            clips.append(x3.synth(1 if i % 9 == 4 else 2, 9000 + i, 0, n))
+            pos += n + (int(rng.integers(0, 5)) * 2 if not odd else int(rng.integers(0, 7)))
+            if not odd and pos % 2:
+                pos += 1
+        total = pos + 16
+        buf = np.zeros(total, dtype=np.int16)
+        so, sn, first = [], [], []
+        for s0, c in zip(starts, clips):
+            buf[s0:s0 + c.size] = c
+            first.append(len(so))
+            for k in range(0, c.size, spf):
+                so.append(s0 + k)
+                sn.append(min(spf, c.size - k))
+        F = len(so)
+        cap = sum(lib.x3_encode_bound(int(c.size), C.byref(p)) for c in clips) + 64
+        d_wav = ctx.alloc(2 * total); d_out = ctx.alloc(cap + 16); d_off = ctx.alloc(8 * (F + 1))
+        try:
+            ctx.upload(d_wav, buf)
+            assert ctx.encode_frames_dev(d_wav, so, sn, p, d_out, cap, 0, d_off) == 0
+            rc, end, st = ctx.encode_result()
+            assert rc == 0
+            assert ctx.get_option("enc_gen_in_use") == (1 if odd else 3)
+            offs = ctx.download(d_off, 8 * (F + 1), np.uint64)
+            out = ctx.download(d_out, end)
+            assert offs[F] == end
+            tot = np.zeros(6, dtype=np.uint64)
+            for i, c in enumerate(clips):
+                rc_o, o, st_o = O.encode(c)
+                lo = int(offs[first[i]]); hi = int(offs[first[i + 1]]) if i + 1 < len(clips) else int(end)
+                assert np.array_equal(out[lo:hi], o), (odd, i, c.size)
+                tot += st_o
+            assert list(st) == tot.tolist()
+            if not odd:
+                # back through the frame index, every frame to where it came from (offsets that are multiples of two
+                # only: the single-wave decoder; clips padded to multiples of four: option wav_offsets_x4, see below)
+                d_wo = ctx.alloc(8 * F); d_back = ctx.alloc(2 * total)
+                try:
+                    ctx.upload(d_wo, np.array(so, dtype=np.uint64))
+                    ctx.upload(d_back, np.zeros(total, dtype=np.int16))
+                    assert ctx.decode_dev(d_out, end, d_off, F, p, d_back, total, d_wav_offsets=d_wo) == 0
+                    assert ctx.decode_result()[:3] == (0, F, 0)
+                    assert np.array_equal(ctx.download(d_back, 2 * total, np.int16), buf)
+                finally:
+                    ctx.free(d_wo); ctx.free(d_back)
+        finally:
+            for d in (d_wav, d_out, d_off):
+                ctx.free(d)
+
+
 def test_device_batch_roundtrip(ctx, x3):
     """BASELINE config 5 in miniature: a uniform batch of clips resident in HBM (with padding between
     clips), encoded by one launch set and decoded from the encoder's frame index."""

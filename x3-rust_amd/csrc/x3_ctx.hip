@@ -256,7 +256,7 @@ extern "C" void x3_ctx_destroy(x3_ctx* c) {
   if (c->fcache) x3_reader_close(c->fcache);
   for (DevBuf* b : {&c->in, &c->out, &c->in_more[0], &c->in_more[1], &c->out_more[0], &c->out_more[1], &c->frame_bytes, &c->frame_off, &c->dec_status, &c->dec_cstatus, &c->dec_meta, &c->wav_off,
                     &c->seg_crc, &c->desc, &c->idx_cand, &c->idx_keys, &c->idx_vals, &c->idx_J, &c->idx_S,
-                    &c->idx_L, &c->idx_sum, &c->idx_wg, &c->idx_sorted, &c->idx_scan, &c->dense_list, &c->lb_desc})
+                    &c->idx_L, &c->idx_sum, &c->idx_wg, &c->idx_sorted, &c->idx_scan, &c->dense_list, &c->lb_desc, &c->src_tab})
     if (b->p) (void)hipFree(b->p);
   for (auto& t : c->timers) {
     for (auto& e : t.used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }

@@ -25,6 +25,10 @@ struct X3Geom {
   uint64_t clip_stride;  // samples between clip starts
   uint32_t fpc;          // frames per clip
   uint64_t n_frames;     // fpc * n_clips
+  // x3_encode_frames_dev: frame f is the src_n[f] samples at wav + src_off[f] (a table instead of the uniform layout above;
+  // n_frames entries; nullptr otherwise).  Encoders only: the decoders place frames by wav_off.
+  const uint64_t* src_off = nullptr;
+  const uint32_t* src_n = nullptr;
 };
 
 // status codes used on the device (values of enum x3_status in include/x3hip.h)

@@ -68,10 +68,15 @@ int plan_encode(x3_ctx* c, const x3_batch* b, const x3_params* p, uint64_t spf, 
 }
 
 int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3_params* p, uint64_t spf,
-                           uint8_t* d_out, uint64_t out_cap, uint64_t start_pos, uint64_t* d_frame_offsets) {
+                           uint8_t* d_out, uint64_t out_cap, uint64_t start_pos, uint64_t* d_frame_offsets,
+                           const X3FrameTable* tab) {
   EncPlan pl;
   int rc = plan_encode(c, b, p, spf, &pl);
   if (rc) return rc;
+  if (tab) {   // (the batch is then "n_frames clips of at most one frame each": plan_encode's geometry of the largest frame)
+    pl.g.src_off = tab->src_off;
+    pl.g.src_n = tab->src_n;
+  }
   if (reinterpret_cast<uintptr_t>(d_out) & 1u) return X3_ERR_BAD_ARG;
   if (reinterpret_cast<uintptr_t>(d_wav) & 1u) return X3_ERR_BAD_ARG;
   const uint64_t F = pl.g.n_frames;
@@ -86,8 +91,10 @@ int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3
   const bool stream_path = p->block_len == 20 && (std::min<uint64_t>(spf, b->n_per_clip) + 18) / 20 <= 512 &&
                            (spf % X3_ENC_FRAME_ALIGN) == 0 &&
                            (b->n_clips == 1 || (b->clip_stride % X3_ENC_FRAME_ALIGN) == 0) &&
-                           (reinterpret_cast<uintptr_t>(d_wav) & 3u) == 0 && !c->force_two_pass && !c->opt.two_pass;
-  c->last_enc = {d_wav, *b, *p, spf, d_out, out_cap, start_pos, d_frame_offsets};
+                           (reinterpret_cast<uintptr_t>(d_wav) & 3u) == 0 && !c->force_two_pass && !c->opt.two_pass &&
+                           (!tab || tab->even);
+  c->last_enc = {d_wav, *b, *p, spf, d_out, out_cap, start_pos, d_frame_offsets, tab ? tab->src_off : nullptr,
+                 tab ? tab->src_n : nullptr, tab ? tab->even : false};
   // part + two worst-case frame images + CRC tables + the multipliers of one chunk size (x3_encode_stream2_kernel.h)
   const size_t smem2 = X3_ENC_SMEM_HDR + 2 * (size_t)pl.img_dwords * 4 + 2048 + X3_K2_DWORDS * 4;
   c->last_enc_gen = 0;
@@ -98,7 +105,9 @@ int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3
     } else {
       // third generation (x3_encode_wave_kernel.h): one wave per frame, sixteen waves per CU, one workgroup per CU
       static_assert(X3W_SMEM <= 160 * 1024, "LDS");
-      HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_wave_kernel),
+      HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_wave_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3W_SMEM));
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_wave_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3W_SMEM));
       uint64_t nwg_max = std::min<uint64_t>((uint64_t)c->n_cus, X3W_MAX_NWG);
       if (c->opt.wave_nwg > 0) nwg_max = std::min<uint64_t>(nwg_max, (uint64_t)c->opt.wave_nwg);
@@ -134,6 +143,8 @@ int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3
       wa.n_per_clip = pl.g.n_per_clip;
       wa.clip_stride = pl.g.clip_stride;
       wa.n_frames = F;
+      wa.src_off = pl.g.src_off;
+      wa.src_n = pl.g.src_n;
       wa.fpc = pl.g.fpc;
       wa.spf = pl.dp.spf;
       wa.epoch = c->desc_epoch;
@@ -144,22 +155,29 @@ int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3
       wa.drop_wgi = c->opt.wave_drop >= 0 ? (uint32_t)c->opt.wave_drop : 0xFFFFFFFFu;
       {
         TimerScope ts(c, 0, nullptr, true);
-        X3_LAUNCH_TIMED(ts, x3_encode_wave_kernel, dim3(wa.nwg), dim3(X3W_THREADS), X3W_SMEM, c->stream, wa);
+        if (wa.src_off) X3_LAUNCH_TIMED(ts, x3_encode_wave_kernel<true>, dim3(wa.nwg), dim3(X3W_THREADS), X3W_SMEM, c->stream, wa);
+        else X3_LAUNCH_TIMED(ts, x3_encode_wave_kernel<false>, dim3(wa.nwg), dim3(X3W_THREADS), X3W_SMEM, c->stream, wa);
       }
       {
         // The dense pass, always: the frames the wave kernel listed (none, in most recordings: the workgroups read a zero
         // count and leave, ~2 us of queue) written at the offsets it assigned.  In the stream, not in x3_encode_result:
         // whatever the caller enqueues behind this call -- x3_decode_dev, a copy -- finds the whole stream.
-        if (smem2 > 64 * 1024)
-          HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_stream2_kernel<true>),
+        if (smem2 > 64 * 1024) {
+          HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_stream2_kernel<true, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
+          HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_stream2_kernel<true, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
+        }
         const uint64_t per_cu = std::max<uint64_t>(1, (160 * 1024) / (smem2 + 256));
         const uint64_t grid = std::min<uint64_t>(F, (uint64_t)c->n_cus * std::min<uint64_t>(per_cu, 3));
         TimerScope ts(c, 5, nullptr, true);
-        X3_LAUNCH_TIMED(ts, x3_encode_stream2_kernel<true>, dim3((unsigned)grid), dim3(X3_STREAM2_THREADS), smem2, c->stream,
-                        d_wav, pl.g, pl.dp, d_off, d_out, out_cap, start_pos, (uint32_t*)nullptr, 0u,
-                        reinterpret_cast<unsigned char*>(c->d_status), (const uint32_t*)c->d_xk2,
-                        (const uint16_t*)c->d_crctab, pl.img_dwords, (uint32_t*)nullptr, (const uint32_t*)c->dense_list.p);
+#define X3_DENSE_PASS(TABLE)                                                                                          \
+        X3_LAUNCH_TIMED(ts, (x3_encode_stream2_kernel<true, TABLE>), dim3((unsigned)grid), dim3(X3_STREAM2_THREADS), smem2,  \
+                        c->stream, d_wav, pl.g, pl.dp, d_off, d_out, out_cap, start_pos, (uint32_t*)nullptr, 0u,             \
+                        reinterpret_cast<unsigned char*>(c->d_status), (const uint32_t*)c->d_xk2,                           \
+                        (const uint16_t*)c->d_crctab, pl.img_dwords, (uint32_t*)nullptr, (const uint32_t*)c->dense_list.p)
+        if (pl.g.src_off) X3_DENSE_PASS(true); else X3_DENSE_PASS(false);
+#undef X3_DENSE_PASS
       }
       HIPCHK(c, hipGetLastError());
       c->last_enc_gen = 3;
@@ -174,9 +192,12 @@ int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3
       // Offsets wait on the other workgroups' frame sizes, so EVERY workgroup of the grid must be resident.  The
       // occupancy API can over-report by one block per CU (MI355X_MICROARCH.md, "Residency"), so it is capped
       // by the kernel's own register/LDS footprint: eight waves are two per SIMD, whatever the placement.
-      if (smem2 > 64 * 1024)
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_stream2_kernel<false>),
+      if (smem2 > 64 * 1024) {
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_stream2_kernel<false, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_stream2_kernel<false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
+      }
       int nb = 0;
       HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, x3_encode_stream2_kernel<false>, X3_STREAM2_THREADS, smem2));
       hipFuncAttributes fa;
@@ -208,10 +229,13 @@ int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3
       }
       {
         TimerScope ts(c, 0);
-        hipLaunchKernelGGL(x3_encode_stream2_kernel<false>, dim3((unsigned)grid), dim3(X3_STREAM2_THREADS), smem2, c->stream,
-                           d_wav, pl.g, pl.dp, d_off, d_out, out_cap, start_pos, (uint32_t*)c->desc.p + desc_pad, c->desc_epoch,
-                           reinterpret_cast<unsigned char*>(c->d_status), (const uint32_t*)c->d_xk2,
-                           (const uint16_t*)c->d_crctab, pl.img_dwords, c->d_pace + 4, (const uint32_t*)nullptr);
+#define X3_GEN2(TABLE)                                                                                                \
+        hipLaunchKernelGGL((x3_encode_stream2_kernel<false, TABLE>), dim3((unsigned)grid), dim3(X3_STREAM2_THREADS), smem2, \
+                           c->stream, d_wav, pl.g, pl.dp, d_off, d_out, out_cap, start_pos, (uint32_t*)c->desc.p + desc_pad, \
+                           c->desc_epoch, reinterpret_cast<unsigned char*>(c->d_status), (const uint32_t*)c->d_xk2,          \
+                           (const uint16_t*)c->d_crctab, pl.img_dwords, c->d_pace + 4, (const uint32_t*)nullptr)
+        if (pl.g.src_off) X3_GEN2(true); else X3_GEN2(false);
+#undef X3_GEN2
       }
       HIPCHK(c, hipGetLastError());
       c->last_enc_gen = 2;
@@ -285,6 +309,34 @@ extern "C" int x3_encode_dev(x3_ctx* c, const int16_t* d_wav, const x3_batch* ba
 }
 
 
+// Frames from anywhere: frame f is src_samples[f] samples (1 .. block_len * blocks_per_frame) at d_wav + src_offsets[f].
+// Host arrays: they are checked, and copied to the device, here.  (Clips of different lengths are runs of such frames.)
+extern "C" int x3_encode_frames_dev(x3_ctx* c, const int16_t* d_wav, const uint64_t* src_offsets, const uint32_t* src_samples,
+                                    uint64_t n_frames, const x3_params* p, uint8_t* d_out, uint64_t out_cap,
+                                    uint64_t start_pos, uint64_t* d_frame_offsets) {
+  if (!c || !d_wav || !src_offsets || !src_samples || !n_frames || !p || !d_out) return X3_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint64_t spf = spf_of(p);
+  if (spf == 0 || n_frames > 0x7FFFFFFFull) return X3_ERR_BAD_ARG;
+  uint32_t n_max = 0;
+  bool even = true;
+  for (uint64_t f = 0; f < n_frames; ++f) {
+    if (src_samples[f] == 0 || src_samples[f] > spf) return X3_ERR_BAD_ARG;
+    n_max = std::max(n_max, src_samples[f]);
+    even = even && (src_offsets[f] & 1ull) == 0;
+  }
+  int rc;
+  if ((rc = ensure(c, c->src_tab, n_frames * 12 + 16))) return rc;
+  uint64_t* d_so = (uint64_t*)c->src_tab.p;
+  uint32_t* d_sn = (uint32_t*)(d_so + n_frames);
+  // (pageable sources: the copies return when the arrays have been read)
+  HIPCHK(c, hipMemcpyAsync(d_so, src_offsets, n_frames * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_sn, src_samples, n_frames * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  const x3_batch b{n_max, 0, n_frames};   // n_frames clips of one frame each as far as the plan is concerned
+  const X3FrameTable tab{d_so, d_sn, even};
+  return encode_dev_impl(c, d_wav, &b, p, spf, d_out, out_cap, start_pos, d_frame_offsets, &tab);
+}
+
 extern "C" int x3_encode_result(x3_ctx* c, uint64_t* out_pos, uint64_t stats[6]) {
   if (!c) return X3_ERR_BAD_ARG;
   if (!c->encode_pending) return X3_ERR_BAD_ARG;
@@ -318,7 +370,8 @@ extern "C" int x3_encode_result(x3_ctx* c, uint64_t* out_pos, uint64_t stats[6])
       std::fprintf(stderr, "x3hip: stream encoder gave up waiting for frame sizes (grid not co-resident): two-pass fallback\n");
     c->force_two_pass = true;
     auto a = c->last_enc;
-    int rc = encode_dev_impl(c, a.d_wav, &a.b, &a.p, a.spf, a.d_out, a.out_cap, a.start_pos, a.d_off);
+    const X3FrameTable tab{a.src_off, a.src_n, a.src_even};
+    int rc = encode_dev_impl(c, a.d_wav, &a.b, &a.p, a.spf, a.d_out, a.out_cap, a.start_pos, a.d_off, a.src_off ? &tab : nullptr);
     c->force_two_pass = false;
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_status, 128, hipMemcpyDeviceToHost, c->stream));
@@ -539,19 +592,56 @@ extern "C" int x3_encode_batch(x3_ctx* c, const int16_t* const* wavs, const uint
     uint64_t pos = 0;
     return encode_host(c, wavs, ns[0], count, p, spf, out, out_cap, 0, &pos, clip_offsets, stats);
   }
-  // ragged batch: one launch set per clip, streams appended back to back
-  uint64_t pos = 0;
-  clip_offsets[0] = 0;
+  // ragged batch: the clips side by side on the device (each on a multiple of eight samples), every clip cut into frames as
+  // encoder::encode cuts it, ONE launch set for the list of all frames (x3_encode_frames_dev; until round 4 a launch set,
+  // a wait and two copies per clip)
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<uint64_t> so, cstart(count), first(count + 1);
+  std::vector<uint32_t> sn;
+  uint64_t total = 0, bound = 0;
   for (uint64_t k = 0; k < count; ++k) {
-    uint64_t st[6] = {0, 0, 0, 0, 0, 0};
-    if (ns[k]) {
-      rc = encode_host(c, &wavs[k], ns[k], 1, p, spf, out, out_cap, pos, &pos, nullptr, st);
-      if (rc) return rc;
+    cstart[k] = total;
+    first[k] = so.size();
+    for (uint64_t s0 = 0; s0 < ns[k]; s0 += spf) {
+      so.push_back(total + s0);
+      sn.push_back((uint32_t)std::min<uint64_t>(spf, ns[k] - s0));
     }
-    clip_offsets[k + 1] = pos;
-    if (stats)
-      for (int i = 0; i < 6; ++i) stats[i] += st[i];
+    bound += (ns[k] / spf) * (20 + max_payload_bytes(spf, p->block_len)) +
+             (ns[k] % spf ? 20 + max_payload_bytes(ns[k] % spf, p->block_len) : 0);
+    total += (ns[k] + 7) & ~7ull;
   }
+  first[count] = so.size();
+  clip_offsets[0] = 0;
+  if (so.empty()) {
+    for (uint64_t k = 0; k < count; ++k) clip_offsets[k + 1] = 0;
+    return X3_OK;
+  }
+  if ((rc = ensure(c, c->in, total * sizeof(int16_t) + 16))) return rc;
+  for (uint64_t k = 0; k < count; ++k)
+    if (ns[k])
+      HIPCHK(c, hipMemcpyAsync((int16_t*)c->in.p + cstart[k], wavs[k], ns[k] * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+  const uint64_t dev_cap = std::min<uint64_t>(out_cap, 1 + bound);
+  if ((rc = ensure(c, c->out, dev_cap + 16))) return rc;
+  const uint64_t F = so.size();
+  if ((rc = ensure(c, c->frame_off, (F + 1) * sizeof(uint64_t)))) return rc;
+  uint64_t pos = 0;
+  {
+    std::unique_lock<std::mutex> gate;
+    if (c->enc_gate) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));  // the upload is not the gate's business
+      gate = std::unique_lock<std::mutex>(*c->enc_gate);
+    }
+    if ((rc = x3_encode_frames_dev(c, (const int16_t*)c->in.p, so.data(), sn.data(), F, p, (uint8_t*)c->out.p, dev_cap, 0,
+                                   (uint64_t*)c->frame_off.p)))
+      return rc;
+    rc = x3_encode_result(c, &pos, stats);
+  }
+  if (rc) return rc;
+  if (pos) HIPCHK(c, hipMemcpyAsync(out, c->out.p, pos, hipMemcpyDeviceToHost, c->stream));
+  std::vector<uint64_t> offs(F + 1);
+  HIPCHK(c, hipMemcpyAsync(offs.data(), c->frame_off.p, offs.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (uint64_t k = 0; k <= count; ++k) clip_offsets[k] = first[k] < F ? offs[first[k]] : pos;
   return X3_OK;
 }
 

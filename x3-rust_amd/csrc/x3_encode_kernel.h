@@ -100,10 +100,10 @@ x3_encode_frames_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
   }
 
   // ---- frame geometry (encoder.rs:61-73: frames of block_len*blocks_per_frame samples)
-  const uint64_t clip = f / g.fpc;
-  const uint64_t idx = f - clip * g.fpc;
-  const uint64_t s_start = clip * g.clip_stride + idx * (uint64_t)p.spf;
-  const uint64_t left = g.n_per_clip - idx * (uint64_t)p.spf;
+  const uint64_t clip = g.src_off ? 0 : f / g.fpc;
+  const uint64_t idx = g.src_off ? 0 : f - clip * g.fpc;
+  const uint64_t s_start = g.src_off ? g.src_off[f] : clip * g.clip_stride + idx * (uint64_t)p.spf;
+  const uint64_t left = g.src_off ? (uint64_t)g.src_n[f] : g.n_per_clip - idx * (uint64_t)p.spf;
   const uint32_t n = left < p.spf ? (uint32_t)left : p.spf;  // >= 1
   const int16_t* __restrict__ src = wav + s_start;
 

@@ -92,7 +92,9 @@ typedef uint32_t x3_v2u32 __attribute__((ext_vector_type(2)));
 // statistics were counted by the wave kernel.  encoder.rs:289-315 makes no difference between a loud frame and a quiet
 // one, and neither does a call any more: one loud frame costs one workgroup a few microseconds, not a second encode of
 // the whole call (rounds 2-3).
-template <bool LIST>
+// TAB: the frames come from a table (x3_encode_frames_dev; g.src_off / g.src_n).  A template parameter: as a run-time test
+// it cost the uniform layout 17 % (white noise 0.94 ms against 0.80).
+template <bool LIST, bool TAB = false>
 __global__ void __launch_bounds__(X3_STREAM2_THREADS, X3E_WAVES_PER_SIMD)
 x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p,
                          uint64_t* __restrict__ frame_off, uint8_t* __restrict__ out, uint64_t out_cap,
@@ -118,12 +120,19 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
   const uint32_t G = gridDim.x;
   const uint32_t ready_tag = epoch << X3_DESC_BYTES_BITS;
 
+  // (a frame table, x3_encode_frames_dev: `clip` carries the frame number and idx stays 0)
   auto geom_at = [&](uint64_t clip, uint32_t idx, const int16_t*& src, uint32_t& n) __attribute__((always_inline)) {
+    if (TAB) {
+      n = g.src_n[clip];
+      src = wav + g.src_off[clip];
+      return;
+    }
     const uint64_t left = g.n_per_clip - (uint64_t)idx * (uint64_t)p.spf;
     n = left < p.spf ? (uint32_t)left : p.spf;
     src = wav + clip * g.clip_stride + (uint64_t)idx * (uint64_t)p.spf;
   };
   auto geom_advance = [&](uint64_t& clip, uint32_t& idx) __attribute__((always_inline)) {
+    if (TAB) { clip += G; return; }
     if (G < g.fpc) {
       idx += G;
       if (idx >= g.fpc) { idx -= g.fpc; ++clip; }
@@ -138,6 +147,7 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
   const uint32_t n_list = LIST ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*dense_count) : 0u;
   if (LIST && blockIdx.x >= n_list) return;
   auto geom_of = [&](uint64_t f_, uint64_t& clip, uint32_t& idx) __attribute__((always_inline)) {
+    if (TAB) { clip = f_; idx = 0; return; }
     clip = f_ / g.fpc;
     idx = (uint32_t)(f_ - clip * g.fpc);
   };

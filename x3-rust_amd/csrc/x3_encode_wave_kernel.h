@@ -96,6 +96,8 @@ struct X3WaveArgs {
   uint32_t nwg;             // workgroups (<= X3W_MAX_NWG)
   uint32_t n_wggen;         // ceil(n_frames / m)
   uint32_t step_clip, step_idx;  // (nwg * m) frames as clips + frames
+  const uint64_t* src_off;       // x3_encode_frames_dev: frame f = src_n[f] samples at wav + src_off[f] (else nullptr)
+  const uint32_t* src_n;
   uint32_t thr0, thr1, thr2, kpack;
   uint32_t drop_wgi;        // tests: the generation whose total is never published (a workgroup that is not resident); ~0: none
 };
@@ -309,6 +311,10 @@ __device__ __forceinline__ uint32_t x3w_cnt_of(int32_t rem, int q) {
   return c <= 0 ? 0u : (c < 20 ? (uint32_t)c : 20u);
 }
 
+// TAB: the frames come from a table (x3_encode_frames_dev) instead of the uniform clip layout.  A template parameter, not a
+// test of a.src_off: with the test in it the kernel of the uniform layout ran 48 % slower (0.64 ms against 0.43) -- it sits
+// at 128 VGPRs, and hipcc's schedule does not survive the extra live values.
+template <bool TAB>
 __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t* const tab = reinterpret_cast<uint16_t*>(smem);
@@ -345,8 +351,14 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
     const uint64_t f0 = (uint64_t)b * a.m + w;
     clip = f0 / a.fpc;
     idx = (uint32_t)(f0 - clip * a.fpc);
+    if (TAB) { clip = f0; idx = 0; }   // (a frame table: `clip` carries the frame number)
   }
   auto geom_at = [&](uint64_t clip_, uint32_t idx_, const int16_t*& src, uint32_t& n) __attribute__((always_inline)) {
+    if (TAB) {
+      n = a.src_n[clip_];
+      src = a.wav + a.src_off[clip_];
+      return;
+    }
     const uint64_t left = a.n_per_clip - (uint64_t)idx_ * (uint64_t)a.spf;
     n = left < a.spf ? (uint32_t)left : a.spf;
     src = a.wav + clip_ * a.clip_stride + (uint64_t)idx_ * (uint64_t)a.spf;
@@ -750,9 +762,13 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
       {
         const uint64_t wgi_n = wgi + a.nwg;
         have_next = wgi_n < a.n_wggen && wgi_n * a.m + w < a.n_frames;
-        idx += a.step_idx;
-        clip += a.step_clip;
-        if (idx >= a.fpc) { idx -= a.fpc; ++clip; }
+        if (TAB) {
+          clip += (uint64_t)a.nwg * a.m;
+        } else {
+          idx += a.step_idx;
+          clip += a.step_clip;
+          if (idx >= a.fpc) { idx -= a.fpc; ++clip; }
+        }
         if (have_next) geom_at(clip, idx, src_next, n_next);
       }
       X3_STAMP(2);

@@ -143,7 +143,9 @@ struct x3_ctx {
   unsigned long long last_dense_frames = 0;     // of the last call (either generation counts them)
   struct {
     const int16_t* d_wav; x3_batch b; x3_params p; uint64_t spf; uint8_t* d_out; uint64_t out_cap, start_pos; uint64_t* d_off;
+    const uint64_t* src_off; const uint32_t* src_n; bool src_even;   // x3_encode_frames_dev's frame table (device), or nullptr
   } last_enc;
+  DevBuf src_tab;   // that table: F offsets (u64), then F sample counts (u32)
   uint64_t enc_start_pos = 0;
   uint64_t dec_frames = 0;
   // kernel timing
@@ -282,8 +284,11 @@ X3_INTERNAL int crc_dev_async(x3_ctx* c, const uint8_t* d_data, uint64_t n);
 X3_INTERNAL extern const uint32_t X3_RICE_OFFSET[4], X3_RICE_LEN[4];
 // ---- x3_encode.hip
 X3_INTERNAL int plan_encode(x3_ctx* c, const x3_batch* b, const x3_params* p, uint64_t spf, EncPlan* pl);
+// x3_encode_frames_dev: frame f = src_n[f] samples at d_wav + src_off[f] (device pointers); even: every offset is a multiple of two
+struct X3FrameTable { const uint64_t* src_off; const uint32_t* src_n; bool even; };
 X3_INTERNAL int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3_params* p, uint64_t spf,
-                                uint8_t* d_out, uint64_t out_cap, uint64_t start_pos, uint64_t* d_frame_offsets);
+                                uint8_t* d_out, uint64_t out_cap, uint64_t start_pos, uint64_t* d_frame_offsets,
+                                const struct X3FrameTable* tab = nullptr);
 X3_INTERNAL int encode_host(x3_ctx* c, const int16_t* const* wavs, uint64_t n_per_clip, uint64_t n_clips,
                             const x3_params* p, uint64_t spf, uint8_t* out, uint64_t out_cap, uint64_t start_pos,
                             uint64_t* out_pos, uint64_t* clip_offsets, uint64_t stats[6]);

@@ -44,7 +44,7 @@ SYMBOLS = [
     "x3_bitpacker_finish", "x3_bitpacker_peek", "x3_bitpacker_take", "x3_bitpacker_free",
     "x3_reader_open", "x3_reader_open_mem", "x3_reader_spec", "x3_reader_next_frame", "x3_reader_frame_errors",
     "x3_reader_position", "x3_reader_close",
-    "x3_encode_dev", "x3_encode_result", "x3_decode_dev", "x3_decode_result", "x3_index_dev", "x3_decode_stream_dev",
+    "x3_encode_dev", "x3_encode_frames_dev", "x3_encode_result", "x3_decode_dev", "x3_decode_result", "x3_index_dev", "x3_decode_stream_dev",
     "x3_synth", "x3_synth_dev", "x3_dev_alloc", "x3_dev_free", "x3_dev_upload", "x3_dev_download",
     "x3_shard_unique_id", "x3_shard_create", "x3_shard_destroy", "x3_shard_rank", "x3_shard_world",
     "x3_shard_frame_range", "x3_shard_sample_range", "x3_shard_offsets", "x3_shard_exchange_lengths",
@@ -170,6 +170,7 @@ def lib():
     L.x3_wav_to_x3a.argtypes = [vp, C.c_char_p, C.c_char_p, vp]
     L.x3_x3a_to_wav.argtypes = [vp, C.c_char_p, C.c_char_p, C.POINTER(u64), C.POINTER(u64)]
     L.x3_encode_dev.argtypes = [vp, vp, C.POINTER(Batch), PP, vp, u64, u64, vp]
+    L.x3_encode_frames_dev.argtypes = [vp, vp, vp, vp, u64, PP, vp, u64, u64, vp]
     L.x3_encode_result.argtypes = [vp, C.POINTER(u64), vp]
     L.x3_decode_dev.argtypes = [vp, vp, u64, vp, u64, C.POINTER(Batch), vp, PP, vp, u64, vp]
     L.x3_decode_result.argtypes = [vp, C.POINTER(u64), C.POINTER(i32), C.POINTER(u64)]
@@ -665,6 +666,14 @@ class Context:
         b = Batch(n_per_clip, n_per_clip if clip_stride is None else clip_stride, n_clips)
         return lib().x3_encode_dev(self._h, d_wav, C.byref(b), C.byref(params), d_out, out_cap, start_pos,
                                    d_frame_offsets)
+
+    def encode_frames_dev(self, d_wav, src_offsets, src_samples, params, d_out, out_cap, start_pos=0, d_frame_offsets=None):
+        """x3_encode_frames_dev: frame f = src_samples[f] samples at d_wav + src_offsets[f] (host arrays)"""
+        so = np.ascontiguousarray(src_offsets, dtype=np.uint64)
+        sn = np.ascontiguousarray(src_samples, dtype=np.uint32)
+        assert so.size == sn.size
+        return lib().x3_encode_frames_dev(self._h, d_wav, so.ctypes.data, sn.ctypes.data, so.size, C.byref(params), d_out,
+                                          out_cap, start_pos, d_frame_offsets)
 
     def encode_result(self):
         pos = C.c_uint64(0)
