@@ -724,9 +724,9 @@ def main():
         # the encoder and the decoder; the size pass re-reads the samples; the check pass reads the stream
         alg = {"encode": 2 * n + pos, "decode": 2 * n + pos, "frame_sizes": 2 * n, "frame_check": pos}
         ktimes.setdefault("frame_sizes", 0.0)
-        kname = {"encode": ("x3_encode_wave_kernel<false>" if enc_gen == 3 else "x3_encode_stream2_kernel<false, false>") if ktimes.get("frame_sizes", 0.0) == 0.0 else "x3_encode_frames_kernel<false>",
+        kname = {"encode": ("x3_encode_wave_kernel<false>" if enc_gen == 3 else "x3_encode_stream2_kernel<false, false>") if ktimes.get("frame_sizes", 0.0) == 0.0 else "x3_encode_frames_kernel<false, false>",
                  "decode": "x3_decode_split_kernel",
-                 "frame_sizes": "x3_encode_frames_kernel<true>", "frame_check": "x3_frame_check_kernel"}
+                 "frame_sizes": "x3_encode_frames_kernel<true, false>", "frame_check": "x3_frame_check_kernel"}
         alg = {k: v for k, v in alg.items() if ktimes.get(k, 0.0) > 0.0}  # the two-pass fallback kernels may not run
         # the dominant kernel of the step's critical path: the frame check runs BESIDE the decoder on a second
         # stream (its co-running time is stretched by the decoder's waves), so it is reported but not a candidate

@@ -18,3 +18,13 @@ for _ in range(2):
     dt = time.perf_counter() - t0
     assert rc == 0
     print("2 000 clips, %.1f M samples: %.1f ms (%.2f Gsamples/s host to host), %d bytes" % (tot / 1e6, dt * 1e3, tot / dt / 1e9, offs[-1]))
+
+# what the ragged path did until round 4: one launch set, one wait and two copies per clip
+t0 = time.perf_counter()
+pos = 0
+for c in clips:
+    rc, o, st = ctx.encode(c)
+    assert rc == 0
+    pos += o.size
+dt = time.perf_counter() - t0
+print("the same clips one x3_encode each: %.1f ms (%.2f Gsamples/s), %d bytes" % (dt * 1e3, tot / dt / 1e9, pos))
