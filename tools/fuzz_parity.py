@@ -5,7 +5,8 @@ Not part of the test suite (it runs as long as it is told to); a failure prints 
    python tools/fuzz_parity.py --minutes 10 [--seed 1]
 Families: (e) the single-pass encoders on block_len 20 with mixed content, many frames and ragged tails;
           (g) arbitrary geometry / codes / thresholds; (d) decode of tampered streams with refreshed CRCs,
-          truncations and header damage; (b) batches of clips through the device API; (a) .x3a archives in memory and
+          truncations and header damage; (b) batches of clips through the device API, of equal and of different lengths
+          (x3_encode_frames_dev); (a) .x3a archives in memory and
           the incremental reader; (f) decode_frame frame by frame, with and without x3_decode_prefetch; (w) WAV and .x3a FILES through the
           chunked pipeline (not in the default family set: file I/O)."""
 import argparse, ctypes as C, os, sys, time
@@ -275,8 +276,74 @@ def fam_f(rng, tag):
             ctx.decode_prefetch(None)
 
 
+def fam_b_ragged(rng, tag):
+    """clips of DIFFERENT lengths: x3_encode_batch on host buffers (one launch set through x3_encode_frames_dev) and the
+    device entry itself with clips at arbitrary sample offsets, against per-clip oracle streams; decoded back by frame
+    index and per-frame sample offsets (with and without the promise that they are multiples of four)"""
+    bpf = int(rng.choice([1, 2, 7, 8, 100, 500, 501, 512]))
+    bl = 20 if rng.random() < 0.8 else int(rng.choice([7, 19, 33]))
+    p = x3hip.Params.make(bl, bpf)
+    spf = bl * bpf
+    n_clips = int(rng.integers(1, 12))
+    clips = [content(rng, int(rng.integers(1, 3 * spf + 40)) if rng.random() < 0.9 else 1) for _ in range(n_clips)]
+    exp = [O.encode(c, oparams(p)) for c in clips]
+    if any(e[0] != 0 for e in exp):
+        return
+    rc, out, offs, stats = ctx.encode_batch(clips, p)
+    assert rc == 0, (tag, "b-ragged host", rc)
+    for i, e in enumerate(exp):
+        assert np.array_equal(out[offs[i]:offs[i + 1]], e[1]), (tag, "b-ragged host", i, bl, bpf, clips[i].size)
+    assert stats.tolist() == np.sum([e[2] for e in exp], axis=0).tolist(), (tag, "b-ragged stats")
+    # the device entry: clips anywhere (even / multiple-of-four / arbitrary offsets)
+    mode = int(rng.integers(0, 3))
+    step = [1, 2, 4][mode]
+    starts, pos = [], 0
+    for c in clips:
+        pos += step * int(rng.integers(0, 9))
+        starts.append(pos)
+        pos += c.size
+        pos += (-pos) % step
+    total = pos + 16
+    buf = np.zeros(total, dtype=np.int16)
+    so, sn = [], []
+    for s0, c in zip(starts, clips):
+        buf[s0:s0 + c.size] = c
+        for k in range(0, c.size, spf):
+            so.append(s0 + k); sn.append(min(spf, c.size - k))
+    F = len(so)
+    L = x3hip.lib()
+    cap = sum(L.x3_encode_bound(int(c.size), C.byref(p)) for c in clips) + 64
+    d_wav = ctx.alloc(2 * total); d_out = ctx.alloc(cap + 16); d_off = ctx.alloc(8 * (F + 1)); d_wo = ctx.alloc(8 * F); d_back = ctx.alloc(2 * total)
+    try:
+        ctx.upload(d_wav, buf)
+        sp = int(rng.choice([0, 0, 1, 6]))
+        assert ctx.encode_frames_dev(d_wav, so, sn, p, d_out, cap, sp, d_off) == 0
+        rc, end, st = ctx.encode_result()
+        assert rc == 0, (tag, "b-ragged dev", rc)
+        body0 = (sp + 1) & ~1
+        expect = np.concatenate([e[1] for e in exp])
+        got = ctx.download(d_out, end)
+        assert end == body0 + expect.size and np.array_equal(got[body0:], expect), (tag, "b-ragged dev", bl, bpf, mode, sp)
+        # (frames of 20 x 512 samples at most: a payload beyond the walk's 24 KB buffer is the reference's FrameLength)
+        if tuple(p.codes) == (0, 1, 3) and step >= 2 and bl == 20:
+            ctx.upload(d_wo, np.array(so, dtype=np.uint64)); ctx.upload(d_back, np.zeros(total, dtype=np.int16))
+            ctx.set_option("wav_offsets_x4", 1 if (step == 4 and spf % 4 == 0) else 0)
+            try:
+                assert ctx.decode_dev(d_out, end, d_off, F, p, d_back, total, d_wav_offsets=d_wo) == 0
+                r = ctx.decode_result()
+            finally:
+                ctx.set_option("wav_offsets_x4", 0)
+            assert r[:3] == (0, F, 0), (tag, "b-ragged decode", r)
+            assert np.array_equal(ctx.download(d_back, 2 * total).view(np.int16), buf), (tag, "b-ragged round trip", bl, bpf, mode)
+    finally:
+        for d in (d_wav, d_out, d_off, d_wo, d_back):
+            ctx.free(d)
+
+
 def fam_b(rng, tag):
     """clips of equal length through the device batch API against per-clip oracle streams"""
+    if rng.random() < 0.5:
+        return fam_b_ragged(rng, tag)
     bpf = int(rng.choice([2, 8, 100, 500]))
     p = x3hip.Params.make(20, bpf)
     spf = 20 * bpf
