@@ -632,7 +632,7 @@ def main():
 
     # ---- what the headline does not say: a fresh context's first step, the round trip with the frame walk
     # in it, and the two adversarial contents of SURVEY 8(d) -- all timed here, in this run
-    cold = with_walk = extremes = None
+    cold = with_walk = extremes = layouts = None
     if rank == 0 and world == 1 and not args.no_extras:
         def timed_steps(c, fn, k):
             c.enable_kernel_timing(True); c.reset_kernel_time()
@@ -716,6 +716,37 @@ def main():
                                        "dense pass behind it in the same stream (kernels_ms.encode_dense_pass; mixed: every hundredth "
                                        "frame); no call is encoded twice.  A call with more than a quarter of such frames makes the "
                                        "context's next call start on the second-generation kernel (white noise: encoder_generation 2)"}
+
+        # (d) layouts one step away from config 3's (round 4): the same samples in frames of 501 blocks (every other frame
+        # on an 8-byte boundary) and 256 blocks, and as a batch of fifteen-second 44.1 kHz clips side by side (661 500 samples
+        # each: a short last frame per clip, groups of 64 frames that span clips, rows on 8-byte boundaries)
+        layouts = {}
+        ctx.synth_dev(args.kind, SEED, 0, n, wav.data_ptr())
+        torch.cuda.synchronize(dev)
+        for name, bpf, npc in (("blocks_501", 501, n), ("blocks_256", 256, n), ("clips_15s_44k1", 500, 661_500)):
+            pl_ = x3hip.Params.make(20, bpf)
+            n_clips = n // npc
+            n_l = npc * n_clips
+            F_l = L.x3_num_frames(npc, C.byref(pl_)) * n_clips
+            cap_l = L.x3_encode_bound(npc, C.byref(pl_)) * n_clips
+            out_l = out if cap_l <= cap else torch.empty(cap_l + 16, dtype=torch.uint8, device=dev)
+            off_l = off if F_l <= F else torch.empty(F_l + 1, dtype=torch.int64, device=dev)
+
+            def step_l():
+                assert ctx.encode_dev(wav.data_ptr(), npc, pl_, out_l.data_ptr(), cap_l, 0, off_l.data_ptr(), n_clips=n_clips,
+                                      clip_stride=npc) == 0
+                assert ctx.decode_dev(out_l.data_ptr(), cap_l, off_l.data_ptr(), F_l, pl_, back.data_ptr(), n_l, n_per_clip=npc,
+                                      n_clips=n_clips, clip_stride=npc) == 0
+            back.zero_()
+            for _ in range(3):
+                step_l()
+            assert ctx.encode_result()[0] == 0 and ctx.decode_result()[:3] == (0, F_l, 0)
+            dt, kt = timed_steps(ctx, step_l, 10)
+            assert ctx.encode_result()[0] == 0 and ctx.decode_result()[:3] == (0, F_l, 0) and torch.equal(back[:n_l], wav[:n_l]), name
+            layouts[name] = {"ms_per_step": round(dt * 1e3, 4), "value": round(n_l / dt / 1e6, 2), "kernels_ms": kt, "frames": int(F_l),
+                             "encoder_generation": int(ctx.get_option("enc_gen_in_use"))}
+        layouts["note"] = ("config 3's samples in other layouts, encode + decode per step as in `value`: frames of 501 / 256 blocks "
+                           "instead of 500; 1 044 clips of 661 500 samples (15 s at 44.1 kHz) side by side at stride = length")
 
     if rank == 0:
         total_samples = n * world
@@ -804,6 +835,7 @@ def main():
             res["value_with_frame_walk"] = with_walk["value"]
             res["with_frame_walk"] = with_walk
             res["extremes"] = extremes
+            res["layouts"] = layouts
         if host_api is not None:
             res["host_buffer_api"] = host_api
             res["per_frame_api"] = per_frame

@@ -587,6 +587,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     auto ring_index = [&]() -> uint32_t { return ~((uint32_t)((int32_t)qb >> 2)) - 2u; };  // of w0
 
     const uint32_t k_tab = (p.k[1] << 16) | (p.k[2] << 24);  // log2(level) by ftype
+    uint32_t over = 0;
     for (uint32_t b = 0; b < nblk_max; ++b) {
       X3S_PACE_STEP(b, X3S_ROLE_PARSER)
       const uint32_t cnt = remaining < X3S_BL ? remaining : X3S_BL;
@@ -658,15 +659,20 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
           h[x3s_half_index(j, lane)] = (uint16_t)((z << lsh) + v);
         }
       }
+      // A frame that was READ beyond its payload is decoded again by the reference's reader (s_over): the read position
+      // (bits from the ring's first chunk on) against the end of the payload, taken where the lane's frame ENDS.  (Until
+      // round 4 it was taken behind the group's last block -- and a lane whose frame is shorter than its neighbours'
+      // walks on through what follows its payload until then: every clip's short last frame in a batch of clips was
+      // replayed, one thread each, 2.7 ms a step for a thousand clips.)
+      if (__any(cnt != 0u && remaining == 0u)) {
+        const int32_t widx = (int32_t)ring_index();
+        if (cnt != 0u && remaining == 0u) over = (32 * widx + 32 - (int32_t)s > (int32_t)(8u * v_end)) ? 1u : 0u;
+      }
       X3_STAMP(3);
       X3S_BARRIER();
       X3_STAMP(4);
     }
-    {
-      // read position (bits from the ring's first chunk on) against the end of the payload
-      const int32_t widx = (int32_t)ring_index();
-      s_over[lane] = (32 * widx + 32 - (int32_t)s > (int32_t)(8u * v_end)) ? 1u : 0u;
-    }
+    s_over[lane] = over;
     X3S_BARRIER();
   } else {
     // ================================================================= wave 1: valuer
