@@ -552,6 +552,16 @@ def test_encode_frames_dev_clips_of_different_lengths(ctx, x3):
                 assert np.array_equal(out[lo:hi], o), (odd, i, c.size)
                 tot += st_o
             assert list(st) == tot.tolist()
+            # too little room for the stream: the reference's ByteWriterInsufficientMemory, and the position it would have needed
+            assert ctx.encode_frames_dev(d_wav, so, sn, p, d_out, int(end) - 2, 0, d_off) == 0
+            rc2, end2, _ = ctx.encode_result()
+            assert rc2 == x3.ERR_BYTE_WRITER_INSUFFICIENT_MEMORY and end2 == end, (rc2, end2, end)
+            # one frame, one sample
+            assert ctx.encode_frames_dev(d_wav, so[:1], [1], p, d_out, cap, 0, d_off) == 0
+            rc3, end3, _ = ctx.encode_result()
+            assert rc3 == 0 and np.array_equal(ctx.download(d_out, end3), O.encode(buf[so[0]:so[0] + 1])[1])
+            assert ctx.encode_frames_dev(d_wav, so[:1], [spf + 1], p, d_out, cap, 0, d_off) == x3.ERR_BAD_ARG
+            assert ctx.encode_frames_dev(d_wav, so[:1], [0], p, d_out, cap, 0, d_off) == x3.ERR_BAD_ARG
             if not odd:
                 # back through the frame index, every frame to where it came from (offsets that are multiples of two
                 # only: the single-wave decoder; clips padded to multiples of four: option wav_offsets_x4, see below)
