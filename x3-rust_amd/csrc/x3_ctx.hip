@@ -277,6 +277,8 @@ extern "C" void x3_ctx_destroy(x3_ctx* c) {
   if (c->h_walk) (void)hipHostFree(c->h_walk);
   (void)hipHostFree(c->h_summary);
   (void)hipHostFree(c->h_summary_init);
+  if (c->h_src_tab) (void)hipHostFree(c->h_src_tab);
+  if (c->ev_src_tab) (void)hipEventDestroy(c->ev_src_tab);
   (void)hipHostFree(c->h_crc);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->dl_stream) (void)hipStreamDestroy(c->dl_stream);

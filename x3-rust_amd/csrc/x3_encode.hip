@@ -329,9 +329,21 @@ extern "C" int x3_encode_frames_dev(x3_ctx* c, const int16_t* d_wav, const uint6
   if ((rc = ensure(c, c->src_tab, n_frames * 12 + 16))) return rc;
   uint64_t* d_so = (uint64_t*)c->src_tab.p;
   uint32_t* d_sn = (uint32_t*)(d_so + n_frames);
-  // (pageable sources: the copies return when the arrays have been read)
-  HIPCHK(c, hipMemcpyAsync(d_so, src_offsets, n_frames * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d_sn, src_samples, n_frames * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  // the caller's arrays are read HERE (into a pinned copy of the context's); the copy to the device is asynchronous
+  const size_t tab_bytes = n_frames * 12;
+  if (c->ev_src_tab) HIPCHK(c, hipEventSynchronize(c->ev_src_tab));   // (the last call's copy out of the pinned buffer)
+  else HIPCHK(c, hipEventCreateWithFlags(&c->ev_src_tab, hipEventDisableTiming));
+  if (c->h_src_tab_cap < tab_bytes) {
+    if (c->h_src_tab) (void)hipHostFree(c->h_src_tab);
+    c->h_src_tab = nullptr;
+    c->h_src_tab_cap = 0;
+    HIPCHK(c, hipHostMalloc(&c->h_src_tab, tab_bytes + tab_bytes / 4 + 64));
+    c->h_src_tab_cap = tab_bytes + tab_bytes / 4 + 64;
+  }
+  std::memcpy(c->h_src_tab, src_offsets, n_frames * sizeof(uint64_t));
+  std::memcpy((char*)c->h_src_tab + n_frames * sizeof(uint64_t), src_samples, n_frames * sizeof(uint32_t));
+  HIPCHK(c, hipMemcpyAsync(d_so, c->h_src_tab, tab_bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev_src_tab, c->stream));
   const x3_batch b{n_max, 0, n_frames};   // n_frames clips of one frame each as far as the plan is concerned
   const X3FrameTable tab{d_so, d_sn, even};
   return encode_dev_impl(c, d_wav, &b, p, spf, d_out, out_cap, start_pos, d_frame_offsets, &tab);

@@ -146,6 +146,9 @@ struct x3_ctx {
     const uint64_t* src_off; const uint32_t* src_n; bool src_even;   // x3_encode_frames_dev's frame table (device), or nullptr
   } last_enc;
   DevBuf src_tab;   // that table: F offsets (u64), then F sample counts (u32)
+  void* h_src_tab = nullptr;        // ... and its pinned host copy (the caller's arrays are only read inside the call)
+  size_t h_src_tab_cap = 0;
+  hipEvent_t ev_src_tab = nullptr;  // the copy out of it has been done
   uint64_t enc_start_pos = 0;
   uint64_t dec_frames = 0;
   // kernel timing
