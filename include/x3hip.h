@@ -334,7 +334,8 @@ int x3_x3a_decode(x3_ctx* ctx, const uint8_t* x3a, uint64_t len, int16_t* wav, u
  * x3_x3a_to_wav leaves, like the reference's dropped WavWriter, a valid WAV of the samples in front of the
  * frame that ended the walk, also when it returns an error.
  * Tuning (x3_ctx_set_option): "file_chunk_frames" (default 800 frames = 16 MB of samples), "file_workers"
- * (default 4; several workers encode their chunks with the two-pass kernels, see x3_encode_dev). */
+ * (default 4; the workers' contexts share the single-pass encoder through a gate -- one chunk's encode launch at a time,
+ * uploads, downloads and file I/O side by side). */
 int x3_wav_to_x3a(x3_ctx* ctx, const char* wav_path, const char* x3a_path, uint64_t stats[6]);
 int x3_x3a_to_wav(x3_ctx* ctx, const char* x3a_path, const char* wav_path, uint64_t* n_samples,
                   uint64_t* frame_errors);
