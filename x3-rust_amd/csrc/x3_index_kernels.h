@@ -112,7 +112,9 @@ x3_index_candidates_kernel(const uint32_t* __restrict__ xw, uint64_t len, uint64
   // (the chunks of the next TWO trips are requested before this trip's is looked at; with one 16-byte load in flight per
   // lane the kernel took 118 us for config 3's 363 MB, with three it takes 115: 3.2 TB/s either way.  Round 4: hipcc waits
   // for all of them at the top of every trip -- it cannot count guarded loads --, but range-checked buffer loads in a loop
-  // unrolled by three, which it does count (vmcnt(3) at the first use), made the kernel SLOWER: 136 us.)
+  // unrolled by three, which it does count (vmcnt(3) at the first use), made the kernel SLOWER: 136 us; the same loads with
+  // nothing requested ahead and half the instructions per trip: 113 us; without the fifth dword: 103.  A bare read of the
+  // same bytes, one span per workgroup, takes 58 us (tools/ubench/read_rate.hip: 6.3 TB/s): it is not the loads.)
   auto fetch = [&](uint64_t t, uint32_t (&w)[5]) {
     if (t >= t_end) {
 #pragma unroll
