@@ -27,6 +27,10 @@
 #define X3I_IO 4u       // header fine, payload inside the bytes the reader believes in but past the real end: Io
 #define X3I_NONE 0xFFFFFFFFu
 #define X3I_READ_BUFFER 24576u
+#ifndef X3I_DEFER_CHECK
+#define X3I_DEFER_CHECK 1
+#endif
+#define X3I_WG_RAW 384u     // places with the key that a workgroup of x3_index_candidates_kernel lists before it checks them
 #define X3I_WG_CANDS 256u   // candidates a workgroup of x3_index_candidates_kernel collects before it touches the global counter
 
 struct X3Cand {
@@ -101,8 +105,9 @@ x3_index_candidates_kernel(const uint32_t* __restrict__ xw, uint64_t len, uint64
                            X3Cand* __restrict__ cand, uint32_t cap, unsigned int* __restrict__ count,
                            unsigned long long* __restrict__ samp, uint32_t* __restrict__ not_simple) {
   __shared__ X3Cand s_c[X3I_WG_CANDS];
-  __shared__ uint32_t s_n, s_base;
-  if (threadIdx.x == 0) s_n = 0;
+  __shared__ uint32_t s_n, s_base, s_nraw;
+  __shared__ unsigned long long s_raw[X3I_WG_RAW];
+  if (threadIdx.x == 0) { s_n = 0; s_nraw = 0; }
   __syncthreads();
   const uint64_t n_dw = (len + 3) >> 2;
   const uint64_t chunks = (len + 15) >> 4;
@@ -114,7 +119,9 @@ x3_index_candidates_kernel(const uint32_t* __restrict__ xw, uint64_t len, uint64
   // for all of them at the top of every trip -- it cannot count guarded loads --, but range-checked buffer loads in a loop
   // unrolled by three, which it does count (vmcnt(3) at the first use), made the kernel SLOWER: 136 us; the same loads with
   // nothing requested ahead and half the instructions per trip: 113 us; without the fifth dword: 103.  A bare read of the
-  // same bytes, one span per workgroup, takes 58 us (tools/ubench/read_rate.hip: 6.3 TB/s): it is not the loads.)
+  // same bytes, one span per workgroup, takes 58 us (tools/ubench/read_rate.hip: 6.3 TB/s): it is not the loads.  It was
+  // the candidates: each header read in the loop held its wave for a memory round trip -- checked behind the loop, all at
+  // once (X3I_DEFER_CHECK): 74 us.)
   auto fetch = [&](uint64_t t, uint32_t (&w)[5]) {
     if (t >= t_end) {
 #pragma unroll
@@ -127,6 +134,23 @@ x3_index_candidates_kernel(const uint32_t* __restrict__ xw, uint64_t len, uint64
 #pragma unroll
       for (int d = 0; d < 5; ++d) w[d] = 4 * t + d < n_dw ? xw[4 * t + d] : 0u;
     }
+  };
+  auto consider = [&](uint64_t off) {
+      uint32_t plen, samples;
+      if (x3i_read_header(xw, n_dw, off, plen, samples) != X3D_OK) return;
+      // (collected per workgroup: 70 000 atomics on ONE global counter serialise in L2, ~10 ns each -- that was
+      // 0.75 of this kernel's 0.81 ms on config 3)
+      X3Cand cd;
+      cd.off = off;
+      cd.plen_kind = plen | (x3i_kind(len, believed, off, plen, samples, bl0) << 16);
+      cd.samples = samples;
+      const uint32_t li = atomicAdd(&s_n, 1u);
+      if (li < X3I_WG_CANDS) {
+        s_c[li] = cd;
+      } else if (!ORDERED) {  // (a span with more candidates than the workgroup's buffer holds: straight to the global counter)
+        const unsigned int slot = atomicAdd(count, 1u);
+        if (cand && slot < cap) cand[slot] = cd;
+      }
   };
   const uint64_t t_first = (uint64_t)blockIdx.x * per_wg + threadIdx.x;
   uint32_t wa[5], wb[5];
@@ -156,22 +180,21 @@ x3_index_candidates_kernel(const uint32_t* __restrict__ xw, uint64_t len, uint64
       if (hw != 0x3378u) continue;  // bytes 0x78 0x33
       const uint64_t off = 16 * t + b;
       if (off + 20 > len) continue;
-      uint32_t plen, samples;
-      if (x3i_read_header(xw, n_dw, off, plen, samples) != X3D_OK) continue;
-      // (collected per workgroup: 70 000 atomics on ONE global counter serialise in L2, ~10 ns each -- that was
-      // 0.75 of this kernel's 0.81 ms on config 3)
-      X3Cand cd;
-      cd.off = off;
-      cd.plen_kind = plen | (x3i_kind(len, believed, off, plen, samples, bl0) << 16);
-      cd.samples = samples;
-      const uint32_t li = atomicAdd(&s_n, 1u);
-      if (li < X3I_WG_CANDS) {
-        s_c[li] = cd;
-      } else if (!ORDERED) {  // (a span with more candidates than the workgroup's buffer holds: straight to the global counter)
-        const unsigned int slot = atomicAdd(count, 1u);
-        if (cand && slot < cap) cand[slot] = cd;
+      // the key is there: the header is read and checked BEHIND the loop, all of the workgroup's at once (X3I_DEFER_CHECK;
+      // in the loop every one of them held its wave for a memory round trip)
+      const uint32_t ri = atomicAdd(&s_nraw, 1u);
+      if (X3I_DEFER_CHECK && ri < X3I_WG_RAW) {
+        s_raw[ri] = off;
+        continue;
       }
+      consider(off);
     }
+  }
+  __syncthreads();
+  {
+    const uint32_t nraw = s_nraw < X3I_WG_RAW ? s_nraw : X3I_WG_RAW;
+    if (X3I_DEFER_CHECK)
+      for (uint32_t i = threadIdx.x; i < nraw; i += blockDim.x) consider(s_raw[i]);
   }
   __syncthreads();
   const uint32_t mine = s_n < X3I_WG_CANDS ? s_n : X3I_WG_CANDS;
