@@ -105,6 +105,10 @@ const char* x3_last_error(const x3_ctx* ctx);
  *   "two_pass" (X3HIP_TWO_PASS)            1: always encode with the two-pass kernels (no persistent grid)
  *   "stream_wgs" (X3HIP_STREAM_WGS)        workgroups per CU of the single-pass encoder, 0 = derived from occupancy
  *   "decode_single" (X3HIP_DECODE_SINGLE)  1: single-wave decoder kernels only
+ *   (environment only) X3HIP_SPIN_WAIT=1   the process's waits for the GPU spin instead of sleeping (hipDeviceScheduleSpin,
+ *                                          process-wide, effective when x3_ctx_create is the process's first use of the
+ *                                          device): calls that end with a trip to the host come back ~20 us sooner
+ *                                          (x3_decode_stream_dev on config 3: 0.82 -> 0.79 ms), a core is busy meanwhile
  *   "wav_offsets_x4"                       1: a promise -- every d_wav_offsets[] passed to x3_decode_dev is a multiple of
  *                                          four samples (rows on 8-byte boundaries): such calls then take the three-wave
  *                                          decoder like the other layouts do; an offset that breaks the promise garbles

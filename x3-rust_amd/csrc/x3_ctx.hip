@@ -74,6 +74,10 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
   }
   HIPCHK(c, hipSetDevice(device));
   c->device = device;
+  // X3HIP_SPIN_WAIT=1: the process's waits for the GPU spin instead of sleeping (hipDeviceScheduleSpin; process-wide, and
+  // only when this is the process's first use of the device): calls that end with a trip to the host -- x3_*_result,
+  // x3_decode_stream_dev -- come back a few microseconds sooner, at the price of a busy core while they wait
+  if (std::getenv("X3HIP_SPIN_WAIT")) (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
   {
     hipDeviceProp_t prop;
     HIPCHK(c, hipGetDeviceProperties(&prop, device));
