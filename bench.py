@@ -126,7 +126,31 @@ def main():
                     help="skip the cold-context, frame-walk and extreme-content measurements that ride on the line")
     ap.add_argument("--no-measure-traffic", action="store_true",
                     help="roofline.traffic from profiles/traffic.json instead of two rocprofv3 PMC passes run here")
+    ap.add_argument("--settle-ms", type=float, default=500.0,
+                    help="upper bound of the time-based settle in front of the warm-up: steps are run until the shader clock "
+                         "the kernels log has stayed within 1 %% of its running maximum for 8 launches (0: no settle)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the timing of BASELINE configs 2 and 5 (`configs` in the line)")
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the ranks as a child process (torch.distributed.run) even for --gpus 1; --gpus N > 1 without "
+                         "WORLD_SIZE in the environment does so by itself")
     args = ap.parse_args()
+
+    # `python3 bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves, as a CHILD process and before
+    # anything here has touched the GPU (a process that has initialised HIP must never be replaced by another program);
+    # the child's JSON line goes to our stdout as it is, its return code becomes ours.
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        import socket
+        import subprocess
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+        s_.close()
+        child_args = [a for a in sys.argv[1:] if a != "--spawn"]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + child_args
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.stdout.flush()
+        sys.exit(subprocess.run(cmd, env=env).returncode)
 
     import numpy as np
     import torch
@@ -136,9 +160,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-        args.gpus = world
+        args.gpus = world    # (the launcher decides; an unset WORLD_SIZE with --gpus N > 1 has started its own ranks above)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -289,6 +311,34 @@ def main():
     # Round 2 needed twelve for the kernels' pace controllers; a first launch is now paced from the data: 0.)
     for _ in range(args.settle):
         step()
+    # Time-based settle: a fresh box ramps its shader clock over the first tens of milliseconds of
+    # load, and W = 5 warm-up steps are 6 ms.  Steps are run, eight at a time, until the clock the DECODE kernel logs for
+    # itself (workgroup 0's s_memtime against s_memrealtime) has stayed within 1 % of its running maximum for eight
+    # launches, bounded by --settle-ms; the trace goes into the line (config.settle_*).  Untimed, in front of the warm-up.
+    settle = {"steps": 0, "ms": 0.0, "clock_mhz": [], "settled": None}
+    if args.settle_ms > 0:
+        t_s = time.perf_counter()
+        run_max = 0.0
+        while True:
+            for _ in range(8):
+                step()
+            if gather_mode == "overlapped":
+                drain_overlapped()
+            torch.cuda.synchronize(dev)
+            settle["steps"] += 8
+            last8 = [e["clock_mhz"] for e in ctx.launch_log(1)[-8:]]
+            settle["clock_mhz"] += [round(c) for c in last8]
+            run_max = max([run_max] + last8)
+            ok = len(last8) == 8 and min(last8) >= 0.99 * run_max and settle["steps"] >= 16
+            settle["ms"] = (time.perf_counter() - t_s) * 1e3
+            late = settle["ms"] >= args.settle_ms
+            if dist is not None:   # all ranks leave together: settled everywhere, or out of time anywhere
+                tt = torch.tensor([0 if ok else 1, 1 if late else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                ok, late = int(tt[0].item()) == 0, int(tt[1].item()) == 1
+            if ok or late:
+                settle["settled"] = bool(ok)
+                break
     for _ in range(args.warmup):
         step()
     if gather_mode == "overlapped":
@@ -748,6 +798,94 @@ def main():
         layouts["note"] = ("config 3's samples in other layouts, encode + decode per step as in `value`: frames of 501 / 256 blocks "
                            "instead of 500; 1 044 clips of 661 500 samples (15 s at 44.1 kHz) side by side at stride = length")
 
+    # ---- BASELINE configs 2 and 5, timed (they had parity tests and no number anywhere): the same entry
+    # points as the step (x3_encode_dev, x3_decode_dev from the encoder's frame index) and the foreign-stream decode
+    # (x3_decode_stream_dev), wall time per call over back-to-back calls between two synchronisations, the kernels' own
+    # HIP-event times beside it, the round trip checked for identity and sampled frames against the oracle.
+    configs = None
+    if rank == 0 and world == 1 and not args.no_extras and not args.no_configs:
+        configs = {}
+        for cname, n_per, n_clips, reps in (("config2", 26_460_000, 1, 20), ("config5", 5_760_000, 1000, 5)):
+            n_c = n_per * n_clips
+            free_b, _tot = torch.cuda.mem_get_info(dev)
+            if free_b < 5.2 * n_c + (2 << 30):
+                configs[cname] = {"skipped": "needs %.1f GB of free HBM, %.1f free" % (5.2 * n_c / 1e9, free_b / 1e9)}
+                continue
+            F_c = L.x3_num_frames(n_per, C.byref(p)) * n_clips
+            cap_c = int(n_c * 0.75) + 4096 if n_clips > 1 else L.x3_encode_bound(n_per, C.byref(p))
+            wav_c = torch.empty(n_c, dtype=torch.int16, device=dev)
+            out_c = torch.empty(cap_c + 16, dtype=torch.uint8, device=dev)
+            off_c = torch.empty(F_c + 1, dtype=torch.int64, device=dev)
+            back_c = torch.zeros(n_c, dtype=torch.int16, device=dev)
+            if n_clips == 1:
+                ctx.synth_dev(args.kind, 0x58330002, 0, n_per, wav_c.data_ptr())
+            else:
+                for c_ in range(n_clips):   # (the clips of tests/test_gpu_parity.py::test_full_size_config5_batch)
+                    ctx.synth_dev(2 if c_ % 7 else 4, 0x58330005 + c_, 0, n_per, wav_c.data_ptr() + 2 * c_ * n_per)
+            torch.cuda.synchronize(dev)
+
+            def enc_c():
+                assert ctx.encode_dev(wav_c.data_ptr(), n_per, p, out_c.data_ptr(), cap_c, 0, off_c.data_ptr(), n_clips=n_clips) == 0
+
+            def dec_c():
+                assert ctx.decode_dev(out_c.data_ptr(), cap_c, off_c.data_ptr(), F_c, p, back_c.data_ptr(), n_c, n_per_clip=n_per,
+                                      n_clips=n_clips) == 0
+            enc_c()
+            rc_c, pos_c, _ = ctx.encode_result()
+            assert rc_c == 0, (cname, rc_c, ctx.last_error())
+
+            def fs_c():
+                r4 = ctx.decode_stream_dev(out_c.data_ptr(), pos_c, p, back_c.data_ptr(), n_c)
+                assert r4 == (0, n_c, F_c, 0), (cname, r4)
+
+            def timed_calls(fn, k, kernel_ids):
+                for _ in range(3):
+                    fn()
+                ctx.enable_kernel_timing(True); ctx.reset_kernel_time()
+                torch.cuda.synchronize(dev)
+                t0_ = time.perf_counter()
+                for _ in range(k):
+                    fn()
+                torch.cuda.synchronize(dev)
+                dt_ = (time.perf_counter() - t0_) / k
+                kt_ = {}
+                for nm_, which in kernel_ids:
+                    ms_, cnt_ = ctx.kernel_time(which)
+                    if cnt_:
+                        kt_[nm_] = round(ms_ / cnt_, 4)
+                ctx.enable_kernel_timing(False)
+                return {"ms": round(dt_ * 1e3, 4), "gsamples_s": round(n_c / dt_ / 1e9, 1), "kernels_ms": kt_}
+            r_enc = timed_calls(enc_c, reps, (("encode", 0), ("encode_dense_pass", 5), ("frame_sizes", 2), ("scan", 3)))
+            assert ctx.encode_result()[0] == 0
+            r_dec = timed_calls(dec_c, reps, (("decode", 1), ("frame_check", 4)))
+            assert ctx.decode_result()[:3] == (0, F_c, 0) and torch.equal(back_c, wav_c), cname
+            back_c.zero_()
+            r_fs = timed_calls(fs_c, reps, (("decode", 1), ("frame_check", 4)))
+            assert torch.equal(back_c, wav_c), cname
+            # sampled frames against the oracle (first, last, a spread; config 5: frames of the first, a middle and the last clip)
+            offs_c = off_c.cpu().numpy()
+            assert int(offs_c[-1]) == pos_c
+            fpc_c = F_c // n_clips
+            sampled = sorted({0, 1, fpc_c - 1, F_c // 2, F_c - fpc_c, F_c - 1} | set(range(7, F_c, max(1, F_c // 24))))
+            for fr in sampled:
+                clip_, idx_ = divmod(fr, fpc_c)
+                a_ = clip_ * n_per + idx_ * p.spf
+                b_ = min(clip_ * n_per + n_per, a_ + p.spf)
+                enc = O.encode(wav_c[a_:b_].cpu().numpy())[1]
+                assert np.array_equal(enc, out_c[int(offs_c[fr]):int(offs_c[fr + 1])].cpu().numpy()), (cname, fr)
+            configs[cname] = {"samples": n_c, "clips": n_clips, "frames": int(F_c), "stream_bytes": int(pos_c),
+                              "bytes_per_sample": round(pos_c / n_c, 4),
+                              "encode": r_enc, "decode": r_dec, "decode_stream_dev": r_fs,
+                              "round_trip_ms": round(r_enc["ms"] + r_dec["ms"], 4),
+                              "round_trip_gsamples_s": round(n_c / (r_enc["ms"] + r_dec["ms"]) / 1e6, 1),
+                              "frames_verified_vs_oracle": len(sampled), "round_trip_is_identity": True}
+            del wav_c, out_c, off_c, back_c
+            torch.cuda.empty_cache()
+        configs["note"] = ("BASELINE configs 2 (10 min 44.1 kHz: 26.46 M samples, 2 646 frames) and 5 (1000 x 1 min 96 kHz clips in one "
+                           "launch set: 5.76 G samples) on the entry points of the step: ms = host wall time per call over "
+                           "back-to-back calls between two synchronisations, kernels_ms = the kernels' HIP-event times.  A stream "
+                           "of few frames cannot be faster than ONE frame's serial decode (a frame is one bit stream): 0.41 ms "
+                           "from the frame index alone (DESIGN.md section 4), unless the encoder's segment index is passed on")
     if rank == 0:
         total_samples = n * world
         value = total_samples * args.steps / elapsed / 1e6
@@ -780,12 +918,26 @@ def main():
         def roof(k):
             t = ktimes[k] / 1e3
             ach = alg[k] / t / 1e9
-            return {"bound": "hbm", "kernel": kname[k], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": traffic.get(kname[k], {}).get("hbm_bytes_per_launch"),
-                    "traffic_source": traffic_source,
-                    "sq_per_launch": traffic.get(kname[k], {}).get("sq_per_launch"),
-                    "algorithmic_bytes": int(alg[k]), "avg_launch_ms": round(ktimes[k], 4)}
+            r = {"bound": "hbm", "kernel": kname[k], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                 "traffic": traffic.get(kname[k], {}).get("hbm_bytes_per_launch"),
+                 "traffic_source": traffic_source,
+                 "sq_per_launch": traffic.get(kname[k], {}).get("sq_per_launch"),
+                 "algorithmic_bytes": int(alg[k]), "avg_launch_ms": round(ktimes[k], 4)}
+            # the wall these kernels actually stand at: vector-instruction issue.  A SIMD-32 issues a
+            # wave64 vector instruction over 2 clocks (MI355X_MICROARCH.md, cycle constants), 1 024 SIMDs; one wave alone
+            # gets one every 4 clocks, a dependent chain one every ~8.5 (tools/ubench/issue_cost.hip).
+            insts = (r["sq_per_launch"] or {}).get("SQ_INSTS_VALU")
+            mhz = (clocks.get("decode_kernel_mhz" if k in ("decode", "frame_check") else "encode_kernel_mhz") or {}).get("median")
+            if insts and mhz:
+                clk = t * mhz * 1e6 * 1024.0        # SIMD-clocks of the launch
+                r["valu_issue"] = {"insts": int(insts), "lane_insts_per_sample": round(insts * 64.0 / n, 2),
+                                   "simd_clocks_per_inst": round(clk / insts, 2), "frac": round(insts * 2.0 / clk, 4),
+                                   "peak": "one wave64 instruction per 2 clocks per SIMD-32, 1 024 SIMDs, at the kernel's logged clock",
+                                   "note": "frac = SQ_INSTS_VALU x 2 clocks / (1 024 SIMDs x launch time x shader clock).  The kernel is "
+                                           "bound by the LATENCY of its waves' dependent instruction chains (one per ~8.5 clocks for a "
+                                           "lone wave), not by HBM and not by issue bandwidth: both fractions are low by construction"}
+            return r
         secs = n / 192000.0
         kinds = {0: "all zeros", 1: "white noise", 2: "hydrophone-like noise", 3: "sine", 4: "random walk"}
         if n == N_SAMPLES:
@@ -818,7 +970,12 @@ def main():
                        "samples_per_gpu": n, "frames_per_gpu": int(F), "stream_bytes_per_gpu": int(pos),
                        "bytes_per_sample": round(pos / n, 4), "block_len": 20, "blocks_per_frame": 500,
                        "signal_kind": args.kind, "frames_verified_vs_oracle": int(verified),
-                       "settle_steps": args.settle,  # extra untimed launches in front of the warm-up
+                       "settle_steps": args.settle + settle["steps"],  # extra untimed launches in front of the warm-up
+                       "settle_ms": round(settle["ms"], 1), "settle_settled": settle["settled"],
+                       "settle_clock_mhz": settle["clock_mhz"][-64:],
+                       "settle_note": "time-based settle in front of the W warm-up steps: steps in batches of eight until the "
+                                      "shader clock the decode kernel logs has stayed within 1 % of its running maximum for "
+                                      "eight launches, bounded by --settle-ms (default 500); untimed",
                        "sharding": sharding},
             "roofline": roof(dominant),
             "roofline_all": {k: roof(k) for k in alg},
@@ -836,6 +993,8 @@ def main():
             res["with_frame_walk"] = with_walk
             res["extremes"] = extremes
             res["layouts"] = layouts
+        if configs is not None:
+            res["configs"] = configs
         if host_api is not None:
             res["host_buffer_api"] = host_api
             res["per_frame_api"] = per_frame

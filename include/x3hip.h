@@ -191,8 +191,12 @@ uint16_t x3_crc16_update(uint16_t crc, uint8_t byte);
  * zero padding to an even ABSOLUTE position.  *out_pos receives `writer.stream_position()`.
  * stats[6] (may be NULL) receives the per-sample block-type counts the reference prints
  * (Rice nsubs 0..3, BFP = 4, literal = 5; encoder.rs:96-108,199).
- * On BYTE_WRITER_INSUFFICIENT_MEMORY *out_pos = the position that would have been reached; which
- * of the frames that fit were written is unspecified (the reference leaves a partial stream too). */
+ * On BYTE_WRITER_INSUFFICIENT_MEMORY the slice holds what the reference's holds (bytewriter.rs:86-99,
+ * encoder.rs:67-73): every frame that fits, complete and in place (and the pad byte in front of
+ * the first one); *out_pos = the end of the last of them, nothing behind it is touched (the
+ * reference goes on into the frame that does not fit and leaves some of its payload bytes without
+ * a header there).  x3_ctx_get_option("encode_needed_pos") says where the whole stream would have
+ * ended. */
 int x3_encode(x3_ctx* ctx, const int16_t* wav, uint64_t n, uint32_t n_channels, const x3_params* p,
               uint8_t* out, uint64_t out_cap, uint64_t start_pos, uint64_t* out_pos, uint64_t stats[6]);
 
@@ -407,7 +411,10 @@ int x3_encode_dev(x3_ctx* ctx, const int16_t* d_wav, const x3_batch* batch, cons
 int x3_encode_frames_dev(x3_ctx* ctx, const int16_t* d_wav, const uint64_t* src_offsets, const uint32_t* src_samples,
                          uint64_t n_frames, const x3_params* p, uint8_t* d_out, uint64_t out_cap, uint64_t start_pos,
                          uint64_t* d_frame_offsets);
-/* Waits for the last x3_encode_dev / x3_encode_frames_dev; status is X3_OK, BYTE_WRITER_INSUFFICIENT_MEMORY or BAD_ARG. */
+/* Waits for the last x3_encode_dev / x3_encode_frames_dev; status is X3_OK, BYTE_WRITER_INSUFFICIENT_MEMORY or BAD_ARG.
+ * On BYTE_WRITER_INSUFFICIENT_MEMORY *out_pos = the position the whole stream would have reached, d_frame_offsets holds
+ * every frame's offset as if there had been room, and d_out holds every frame that fits (offset + size <= out_cap),
+ * complete and in place -- the prefix the reference's slice keeps; a frame that does not fit is not written at all. */
 int x3_encode_result(x3_ctx* ctx, uint64_t* out_pos, uint64_t stats[6]);
 
 /* Decode F frames of a device-resident stream.  d_frame_offsets[f] = byte offset of frame f's

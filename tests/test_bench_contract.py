@@ -65,6 +65,15 @@ def test_bench_small_run_prints_the_contract_line():
     # every hundredth frame loud: the dense pass writes them, the wave encoder keeps the call
     assert j["extremes"]["mixed"]["encoder_generation"] == 3 and j["extremes"]["mixed"]["dense_frames"] == 20
     assert j["extremes"]["encoder"]["dense_reruns"] == 0
+    # configs 2 and 5 are timed in the line
+    for cn, frames in (("config2", 2646), ("config5", 576000)):
+        c = j["configs"][cn]
+        if "skipped" in c:
+            continue
+        assert c["frames"] == frames and c["round_trip_is_identity"] and c["frames_verified_vs_oracle"] >= 20, c
+        for leg in ("encode", "decode", "decode_stream_dev"):
+            assert c[leg]["ms"] > 0 and c[leg]["gsamples_s"] > 0, (cn, leg, c[leg])
+    assert j["config"]["settle_steps"] >= 16 and j["config"]["settle_ms"] > 0
     # roofline.traffic is measured by the run itself (two rocprofv3 PMC passes as child processes) where rocprofv3 exists
     import shutil
     if shutil.which("rocprofv3"):
@@ -90,3 +99,45 @@ def test_bench_distributed_path_with_one_rank():
     assert j["gather"]["sharded_file"]["bytes"] == j["gather"]["bytes"] and j["gather"]["sharded_file"]["every_rank_verified_its_part"]
     assert "6.5 ms" in j["gather"]["note"]
     assert j["config"]["frames_verified_vs_oracle"] == j["config"]["frames_per_gpu"]
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    """`python3 bench.py --gpus N` without WORLD_SIZE starts torch.distributed.run as a child process before it touches the
+    GPU and relays the child's line and return code; --spawn forces that path for N = 1"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, BENCH, "--spawn", "--gpus", "1", "--steps", "2", "--warmup", "1", "--samples", "20000000",
+                        "--no-cpu-baseline", "--no-measure-traffic", "--no-extras"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["value"] > 0
+
+
+def test_bench_spawn_builds_the_launcher_command(monkeypatch):
+    """CPU: the self-launch happens before torch or the library is imported and hands the arguments on unchanged"""
+    import importlib.util
+    import subprocess as sp
+    spec = importlib.util.spec_from_file_location("x3_bench_mod", BENCH)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    seen = {}
+
+    class _R:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return _R()
+    monkeypatch.setattr(sp, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", [BENCH, "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        mod.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

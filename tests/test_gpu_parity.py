@@ -332,11 +332,37 @@ def test_encode_errors(ctx, x3):
 
 
 def test_insufficient_memory_matches_oracle(ctx, x3):
+    """ByteWriterInsufficientMemory keeps the reference's prefix guarantee (bytewriter.rs:86-99, encoder.rs:67-73): every
+    frame that fits is in the slice, complete and in place, *out_pos is the end of the last of them, nothing behind it is
+    touched -- in one piece and through the chunked pipeline, at even and odd start positions"""
     wav = x3.synth(2, 1, 0, 30000)
-    full = O.encode(wav)[1]
-    for cap in [0, 19, 20, 21, 5000, full.size - 2]:
-        assert O.encode(wav, cap=cap)[0] == x3.ERR_BYTE_WRITER_INSUFFICIENT_MEMORY
-        assert ctx.encode(wav, cap=cap)[0] == x3.ERR_BYTE_WRITER_INSUFFICIENT_MEMORY
+    L = x3.lib()
+    p = x3.Params.default()
+    try:
+        for start in (0, 7):
+            full = O.encode(wav, start_pos=start)[1]
+            ends = [start + (start & 1)]
+            while ends[-1] < full.size:
+                ends.append(ends[-1] + 20 + ((int(full[ends[-1] + 6]) << 8) | int(full[ends[-1] + 7])))
+            assert ends[-1] == full.size and len(ends) == 4
+            for cap in [start, start + 1, start + 19, start + 21, 5000, ends[1], ends[1] + 1, ends[2] - 1, ends[2] + 20, full.size - 2]:
+                rc_o, got_o, _ = O.encode(wav, cap=cap, start_pos=start)
+                assert rc_o == x3.ERR_BYTE_WRITER_INSUFFICIENT_MEMORY
+                want_end = max([e for e in ends if e <= cap] + [start])
+                for frames in (-1, 1):
+                    ctx.set_option("host_chunk_frames", frames)
+                    out = np.full(max(cap, 1) + 64, 0xAA, dtype=np.uint8)
+                    pos = C.c_uint64(0)
+                    rc = L.x3_encode(ctx._h, wav.ctypes.data, wav.size, 1, C.byref(p), out.ctypes.data, cap, start, C.byref(pos), None)
+                    assert rc == x3.ERR_BYTE_WRITER_INSUFFICIENT_MEMORY, (start, cap, rc)
+                    assert pos.value == want_end, (start, cap, frames, pos.value, want_end)
+                    assert np.array_equal(out[start:want_end], full[start:want_end]), (start, cap, frames)
+                    # ... which is what the reference's slice holds there (it goes on into the frame that does not fit)
+                    assert got_o.size >= want_end and np.array_equal(out[start:want_end], got_o[start:want_end])
+                    assert np.all(out[:start] == 0xAA) and np.all(out[want_end:] == 0xAA), (start, cap, frames)
+                    assert ctx.get_option("encode_needed_pos") == full.size
+    finally:
+        ctx.set_option("host_chunk_frames", 0)
 
 
 def test_encode_host_buffers_in_chunks(ctx, x3):
@@ -977,6 +1003,46 @@ def test_index_fast_path_serves_clean_chains_only(x3):
             assert (c.get_option("index_fast_walks") - f0, c.get_option("index_general_walks") - g0) == ((1, 0) if fast else (0, 1)), (s.size, fast)
             c.free(d)
         c.free(d_wav)
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
+def test_index_max_frames_equal_to_the_chain_with_a_stray_candidate(x3):
+    """a stream of N good frames plus one stray CANDIDATE (a last frame cut short, a frame behind junk) walked with
+    max_frames = N.  The fast path used to compare the number of candidates with max_frames and fail the call; it now leaves
+    such streams to the general walk, which counts the chain.  Same answers with the fast path on and off."""
+    torch = pytest.importorskip("torch")
+    c = x3.Context(0)
+    try:
+        p = x3.Params.default()
+        wav = x3.synth(2, 79, 0, 65000)
+        stream = O.encode(wav)[1]                   # 7 frames
+        hdr_offs = []
+        pos = 0
+        while pos + 20 <= stream.size:
+            hdr_offs.append(pos)
+            pos += 20 + ((int(stream[pos + 6]) << 8) | int(stream[pos + 7]))
+        assert len(hdr_offs) == 7
+        extra = O.encode(x3.synth(4, 80, 0, 5000))[1]
+        junk = np.arange(6, dtype=np.uint8) + 1
+        cases = [(stream[:hdr_offs[3] + 21], 3),                      # three frames + a header whose payload is cut short
+                 (np.concatenate([stream, junk, extra]), 7),          # seven frames, junk, a frame nothing leads to
+                 (stream, 7)]                                         # (the clean chain itself, max_frames = its length)
+        for s, nfr in cases:
+            d = c.alloc(s.size + 64); c.upload(d, s)
+            fo = torch.zeros(nfr + 8, dtype=torch.int64, device="cuda:0")
+            wo = torch.zeros(nfr + 8, dtype=torch.int64, device="cuda:0")
+            res = []
+            for no_fast in (0, 1):
+                c.set_option("index_no_fast", no_fast)
+                r = c.index_dev(d, s.size, nfr, fo.data_ptr(), wo.data_ptr())
+                res.append((r, fo[:nfr].cpu().tolist()))
+            c.set_option("index_no_fast", 0)
+            assert res[0] == res[1], (nfr, res)
+            assert res[0][0][0] == 0 and res[0][0][1] == nfr, (nfr, res[0][0])
+            assert res[0][1] == hdr_offs[:nfr]
+            c.free(d)
     finally:
         c.close()
 

@@ -362,6 +362,7 @@ extern "C" int x3_ctx_get_option(const x3_ctx* c, const char* name, long long* v
   else if (n == "index_general_walks") *value = (long long)c->index_general;
   else if (n == "check_prio") *value = c->opt.check_prio;
   else if (n == "encode_fallbacks") *value = (long long)c->encode_fallbacks;  // read-only counter
+  else if (n == "encode_needed_pos") *value = (long long)c->needed_pos;       // read-only: where the last host-buffer encode that ran out of room would have ended
   else if (n == "stream_wgs_in_use") *value = c->stream_wg_per_cu;            // read-only, -1 before the first launch
   else return X3_ERR_BAD_ARG;
   return X3_OK;

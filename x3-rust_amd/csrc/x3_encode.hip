@@ -432,6 +432,31 @@ int encode_host(x3_ctx* c, const int16_t* const* wavs, uint64_t n_per_clip, uint
       return rc;
     rc = x3_encode_result(c, &pos, stats);
   }
+  if (rc == X3_ERR_BYTE_WRITER_INSUFFICIENT_MEMORY) {
+    // The reference's slice keeps every frame that fitted (bytewriter.rs:86-99 fails the write that does not fit,
+    // encoder.rs:67-73 stops there): the caller gets those frames, complete and in place, *out_pos = the end of the last
+    // of them, and nothing behind it is touched.  Every encoder writes a frame only if all of it fits, at the offset the
+    // frame index says, so the device buffer holds exactly that prefix; the index says where it ends.  (An error path:
+    // one copy of the index, nobody times it.  c->needed_pos keeps the position the whole stream would have reached.)
+    c->needed_pos = pos;
+    const uint64_t F = ((n_per_clip + spf - 1) / spf) * n_clips;
+    std::vector<uint64_t> offs(F + 1);
+    HIPCHK(c, hipMemcpyAsync(offs.data(), c->frame_off.p, offs.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint64_t end = start_pos, first = start_pos;
+    if ((start_pos & 1ull) && start_pos < out_cap) {   // the pad byte in front of the first frame (writer.align, encoder.rs:182)
+      out[start_pos] = 0;
+      end = first = start_pos + 1;
+    }
+    for (uint64_t f = 0; f < F; ++f) {
+      if (offs[f] != end || offs[f + 1] < offs[f] + 22 || offs[f + 1] > out_cap) break;
+      end = offs[f + 1];
+    }
+    if (end > first)
+      HIPCHK(c, hipMemcpy(out + first, (uint8_t*)c->out.p + first, end - first, hipMemcpyDeviceToHost));
+    if (out_pos) *out_pos = end;
+    return rc;
+  }
   if (out_pos) *out_pos = pos;
   if (rc) return rc;
   if (pos > start_pos)

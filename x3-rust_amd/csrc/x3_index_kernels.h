@@ -461,11 +461,10 @@ x3_index_link_kernel(const X3Cand* __restrict__ cand_wg, const unsigned int* __r
   const uint32_t n = count[b];
   const unsigned long long total = sum->n_chain;
   if (total == 0ull || total > max_frames || total > sorted_cap) {
-    if (b == 0 && threadIdx.x == 0) {
-      if (total == 0ull) sum->pad2 = 1;        // no candidate at all: the general path states how the walk ends
-      else if (total > max_frames) sum->pad = 1;
-      else sum->pad2 = 1;
-    }
+    // no candidate at all: the general path states how the walk ends.  More CANDIDATES than max_frames says nothing about
+    // the chain -- a truncated last frame, a frame behind junk or a false header inside a payload is a candidate and not a
+    // frame -- so that case, too, goes to the general walk, which sets `pad` from the real chain length.
+    if (b == 0 && threadIdx.x == 0) sum->pad2 = 1;
     return;
   }
   const X3Cand* const mine = cand_wg + (size_t)b * X3I_WG_CANDS;

@@ -78,6 +78,7 @@ struct X3Opts {
 
 struct x3_ctx {
   X3Opts opt;
+  unsigned long long needed_pos = 0;        // the position a host-buffer encode that ran out of room would have reached
   unsigned long long encode_fallbacks = 0;  // launches of the single-pass encoder that timed out (two-pass re-run)
   int device = 0;
   hipStream_t stream = nullptr;
