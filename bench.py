@@ -855,6 +855,20 @@ def main():
                         kt_[nm_] = round(ms_ / cnt_, 4)
                 ctx.enable_kernel_timing(False)
                 return {"ms": round(dt_ * 1e3, 4), "gsamples_s": round(n_c / dt_ / 1e9, 1), "kernels_ms": kt_}
+            # ... and with the SEGMENT INDEX (include/x3hip.h): the encoder leaves, for every 32nd block of every frame, the bit
+            # position it begins at and the sample in front of it; the decoder then takes as many stretches of a frame side by
+            # side as fill the GPU (a hint that every stretch checks against the next one's entry; frames alone fill the GPU in
+            # config 5 and the index is not used there)
+            SEG_SB = 32
+            seg_c = torch.zeros(int(L.x3_seg_index_entries(F_c, C.byref(p), SEG_SB)) + 1, dtype=torch.int64, device=dev)
+
+            def enc_seg_c():
+                assert ctx.encode_dev_seg(wav_c.data_ptr(), n_per, p, out_c.data_ptr(), cap_c, seg_c.data_ptr(), SEG_SB, 0,
+                                          off_c.data_ptr(), n_clips=n_clips) == 0
+
+            def dec_seg_c():
+                assert ctx.decode_dev_seg(out_c.data_ptr(), cap_c, off_c.data_ptr(), F_c, p, back_c.data_ptr(), n_c, seg_c.data_ptr(),
+                                          SEG_SB, n_per_clip=n_per, n_clips=n_clips) == 0
             r_enc = timed_calls(enc_c, reps, (("encode", 0), ("encode_dense_pass", 5), ("frame_sizes", 2), ("scan", 3)))
             assert ctx.encode_result()[0] == 0
             r_dec = timed_calls(dec_c, reps, (("decode", 1), ("frame_check", 4)))
@@ -862,6 +876,12 @@ def main():
             back_c.zero_()
             r_fs = timed_calls(fs_c, reps, (("decode", 1), ("frame_check", 4)))
             assert torch.equal(back_c, wav_c), cname
+            r_enc_seg = timed_calls(enc_seg_c, reps, (("encode", 0), ("encode_dense_pass", 5)))
+            assert ctx.encode_result()[0] == 0
+            back_c.zero_()
+            r_dec_seg = timed_calls(dec_seg_c, reps, (("decode", 1), ("frame_check", 4)))
+            r_dec_seg["stretches_per_frame"] = int(ctx.get_option("last_seg_stretches"))
+            assert ctx.decode_result()[:3] == (0, F_c, 0) and torch.equal(back_c, wav_c), cname
             # sampled frames against the oracle (first, last, a spread; config 5: frames of the first, a middle and the last clip)
             offs_c = off_c.cpu().numpy()
             assert int(offs_c[-1]) == pos_c
@@ -878,14 +898,19 @@ def main():
                               "encode": r_enc, "decode": r_dec, "decode_stream_dev": r_fs,
                               "round_trip_ms": round(r_enc["ms"] + r_dec["ms"], 4),
                               "round_trip_gsamples_s": round(n_c / (r_enc["ms"] + r_dec["ms"]) / 1e6, 1),
+                              "with_segment_index": {"seg_blocks": SEG_SB, "index_bytes": int(seg_c.numel() * 8),
+                                                     "encode": r_enc_seg, "decode": r_dec_seg,
+                                                     "round_trip_ms": round(r_enc_seg["ms"] + r_dec_seg["ms"], 4),
+                                                     "round_trip_gsamples_s": round(n_c / (r_enc_seg["ms"] + r_dec_seg["ms"]) / 1e6, 1)},
                               "frames_verified_vs_oracle": len(sampled), "round_trip_is_identity": True}
-            del wav_c, out_c, off_c, back_c
+            del wav_c, out_c, off_c, back_c, seg_c
             torch.cuda.empty_cache()
         configs["note"] = ("BASELINE configs 2 (10 min 44.1 kHz: 26.46 M samples, 2 646 frames) and 5 (1000 x 1 min 96 kHz clips in one "
                            "launch set: 5.76 G samples) on the entry points of the step: ms = host wall time per call over "
                            "back-to-back calls between two synchronisations, kernels_ms = the kernels' HIP-event times.  A stream "
                            "of few frames cannot be faster than ONE frame's serial decode (a frame is one bit stream): 0.41 ms "
-                           "from the frame index alone (DESIGN.md section 4), unless the encoder's segment index is passed on")
+                           "from the frame index alone (DESIGN.md section 4); with_segment_index: x3_encode_dev_seg + "
+                           "x3_decode_dev_seg, the frames' stretches decoded side by side")
     if rank == 0:
         total_samples = n * world
         value = total_samples * args.steps / elapsed / 1e6

@@ -426,6 +426,35 @@ int x3_encode_result(x3_ctx* ctx, uint64_t* out_pos, uint64_t stats[6]);
 int x3_decode_dev(x3_ctx* ctx, const uint8_t* d_x3, uint64_t x3_len, const uint64_t* d_frame_offsets,
                   uint64_t n_frames, const x3_batch* batch, const uint64_t* d_wav_offsets,
                   const x3_params* p, int16_t* d_wav, uint64_t wav_cap, int32_t* d_status);
+/* ---- The SEGMENT INDEX: decoding a frame on more than one lane.
+ * A frame is one serial bit stream (decoder.rs:36-58), so a stream of few frames cannot be decoded faster than one
+ * frame's walk, however many lanes there are.  But a block depends only on the bit position it starts at and on the
+ * sample in front of it.  The segment index holds both for every `seg_blocks`-th block of every frame: entry
+ * [1 + f * (nseg - 1) + j - 1], j = 1 .. nseg - 1 with nseg = ceil(blocks_per_frame / seg_blocks), is the 64-bit word
+ * {bits 0..31: bit offset of block seg_blocks * j's header from the start of frame f's payload; bits 32..47: the
+ * sample in front of that block; bit 48: entry valid}.  The encoder knows it (x3_encode_dev_seg), and so does a
+ * decoder that has been through the stream once (record = 1).  With it, x3_decode_dev_seg decodes nseg stretches of
+ * every frame side by side.  The index is NOT part of the .x3a format and is never trusted: every stretch checks where
+ * it ended -- bit position and last sample -- against the next entry, which proves (by induction from the frame's
+ * first block) that the frame decoded as the serial walk decodes it; a frame with a missing, implausible or
+ * contradicted entry goes through the reference's reader, as frames with decode errors do.  A wrong or stale index
+ * costs time, never correctness.  Word 0 is a header (who fills the index says so there, and with what seg_blocks; an
+ * index without it decodes frame by frame).  The decoder takes as many stretches per frame as fill the GPU -- every
+ * entry for a stream of a few dozen frames, every second or fourth for a few hundred, none when the frames alone fill
+ * it (option "seg_stretches" overrides; "last_seg_stretches" reports).  seg_blocks: a multiple of 4;
+ * d_seg_index: x3_seg_index_entries() words of 8 bytes, 8-byte aligned; NULL = x3_decode_dev / x3_encode_dev.
+ * (Layouts the three-wave decoder does not take -- see x3_encode_dev, "Layout" -- decode frame by frame and record
+ * nothing: entries stay invalid.) */
+uint64_t x3_seg_index_entries(uint64_t n_frames, const x3_params* p, uint32_t seg_blocks);
+/* x3_encode_dev that also fills the segment index (seg_blocks: a power of two >= 4; 32 or 64 for 500-block frames).  Only
+ * the default-geometry encoder fills it; any other layout leaves an index that says "none" and decodes frame by frame. */
+int x3_encode_dev_seg(x3_ctx* ctx, const int16_t* d_wav, const x3_batch* batch, const x3_params* p,
+                      uint8_t* d_out, uint64_t out_cap, uint64_t start_pos, uint64_t* d_frame_offsets,
+                      uint64_t* d_seg_index, uint32_t seg_blocks);
+int x3_decode_dev_seg(x3_ctx* ctx, const uint8_t* d_x3, uint64_t x3_len, const uint64_t* d_frame_offsets,
+                      uint64_t n_frames, const x3_batch* batch, const uint64_t* d_wav_offsets,
+                      const x3_params* p, int16_t* d_wav, uint64_t wav_cap, int32_t* d_status,
+                      uint64_t* d_seg_index, uint32_t seg_blocks, int record);
 /* Waits for the last x3_decode_dev: index and status of the first frame whose status != 0
  * (first_bad = n_frames, status 0 if all frames are good) and the total samples of good frames
  * before it. */

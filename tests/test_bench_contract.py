@@ -73,6 +73,9 @@ def test_bench_small_run_prints_the_contract_line():
         assert c["frames"] == frames and c["round_trip_is_identity"] and c["frames_verified_vs_oracle"] >= 20, c
         for leg in ("encode", "decode", "decode_stream_dev"):
             assert c[leg]["ms"] > 0 and c[leg]["gsamples_s"] > 0, (cn, leg, c[leg])
+        ws = c["with_segment_index"]
+        assert ws["decode"]["ms"] > 0 and ws["decode"]["stretches_per_frame"] == (16 if cn == "config2" else 0), ws
+    assert j["configs"]["config2"]["with_segment_index"]["decode"]["ms"] < 0.5 * j["configs"]["config2"]["decode"]["ms"]
     assert j["config"]["settle_steps"] >= 16 and j["config"]["settle_ms"] > 0
     # roofline.traffic is measured by the run itself (two rocprofv3 PMC passes as child processes) where rocprofv3 exists
     import shutil

@@ -20,6 +20,7 @@ ap.add_argument("--shift", type=int, default=0, help="the samples begin this man
 ap.add_argument("--bpf", type=int, default=500, help="blocks per frame")
 ap.add_argument("--bl", type=int, default=20, help="block length (samples)")
 ap.add_argument("--opt", action="append", default=[], help="context option name=value (x3_ctx_set_option), repeatable")
+ap.add_argument("--seg", type=int, default=0, help="decode by a segment index of SEG blocks per stretch (recorded by the first decode)")
 a = ap.parse_args()
 ctx = x3hip.Context(0)
 for o in a.opt:
@@ -40,15 +41,26 @@ def run_once(tag):
         for f in range(k // 2, F, k):
             lo = f * p.spf
             ctx.synth_dev(1, 0x58330003 + f, lo, min(p.spf, n - lo), d_wav + 2 * lo)
+    d_seg = ctx.alloc(8 * L.x3_seg_index_entries(F, C.byref(p), a.seg) + 8) if a.seg else None
+    enc_seg = a.seg >= 4 and (a.seg & (a.seg - 1)) == 0   # (the encoder's index: a power of two; else the one the first decode records)
     def step():
-        assert ctx.encode_dev(d_wav, npc, p, d_out, cap, 0, d_off, n_clips=a.clips, clip_stride=stride) == 0
-        assert ctx.decode_dev(d_out, cap, d_off, F, p, d_back, stride * a.clips, n_per_clip=npc, n_clips=a.clips, clip_stride=stride) == 0
+        if enc_seg:
+            assert ctx.encode_dev_seg(d_wav, npc, p, d_out, cap, d_seg, a.seg, 0, d_off, n_clips=a.clips, clip_stride=stride) == 0
+        else:
+            assert ctx.encode_dev(d_wav, npc, p, d_out, cap, 0, d_off, n_clips=a.clips, clip_stride=stride) == 0
+        if a.seg:
+            assert ctx.decode_dev_seg(d_out, cap, d_off, F, p, d_back, stride * a.clips, d_seg, a.seg, n_per_clip=npc, n_clips=a.clips, clip_stride=stride) == 0
+        else:
+            assert ctx.decode_dev(d_out, cap, d_off, F, p, d_back, stride * a.clips, n_per_clip=npc, n_clips=a.clips, clip_stride=stride) == 0
     ctx.enable_kernel_timing(False)
     # (the first call: the encoder's result first -- dense content is encoded again inside x3_encode_result, the stream is
     # not valid before it -- then the decode)
     assert ctx.encode_dev(d_wav, npc, p, d_out, cap, 0, d_off, n_clips=a.clips, clip_stride=stride) == 0
     rc, pos, st = ctx.encode_result(); assert rc == 0
-    assert ctx.decode_dev(d_out, cap, d_off, F, p, d_back, stride * a.clips, n_per_clip=npc, n_clips=a.clips, clip_stride=stride) == 0
+    if a.seg:
+        assert ctx.decode_dev_seg(d_out, cap, d_off, F, p, d_back, stride * a.clips, d_seg, a.seg, record=True, n_per_clip=npc, n_clips=a.clips, clip_stride=stride) == 0
+    else:
+        assert ctx.decode_dev(d_out, cap, d_off, F, p, d_back, stride * a.clips, n_per_clip=npc, n_clips=a.clips, clip_stride=stride) == 0
     r = ctx.decode_result(); assert os.environ.get("X3_NOCHECK") or r[:3] == (0, F, 0), r
     ctx.enable_kernel_timing(not os.environ.get('X3_NOTIMING')); ctx.reset_kernel_time()
     for _ in range(a.steps): step()

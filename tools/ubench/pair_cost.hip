@@ -22,6 +22,7 @@ __global__ void __launch_bounds__(64) k(unsigned long long* out, uint32_t seed) 
   uint32_t zmask = 0xFFFFFFFFu, nwidth = 0u - 2u, fw = 1, lsh = 1, lmul = 2, c124 = 124u;
   uint32_t t = w0, u = w1, b0 = w1, b1 = wn, addr = row_base, pend = 0;
   uint32_t a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3;
+  uint32_t w2 = lds[threadIdx.x * 32 + 3], mp = 0, wna = wn, wnb = wn, pz1 = 1, pz2 = 2, pv1 = 0, pv2 = 1;
   const long long t0 = clock64();
   for (int i = 0; i < ITER; ++i) {
     if (KIND == 0) {
@@ -120,6 +121,73 @@ __global__ void __launch_bounds__(64) k(unsigned long long* out, uint32_t seed) 
         acc ^= X;
       })
     }
+    if (KIND == 5 || KIND == 6) {
+      // round 5: the same 19 vector instructions (+1: a third window word) in SOFTWARE-PIPELINED order -- every instruction
+      // of the dependent chain (peek, ffbh, mad, shift, ffbh, mad, add3, sign, bfi) is followed by one that does not depend
+      // on it: the PREVIOUS pair's packing, this pair's field extraction, the ring address and read one pair ahead (the third
+      // window word w2 is brought up to date half a pair late, so the read has a pair and a half to arrive).
+      // KIND 6: the thin form (no field extraction, no packing: 15 + read)
+#define PAIR5(WNC, WNP, CNT)                                        \
+        "v_alignbit_b32 %[tt], %[w0], %[w1], %[s]\n\t"              \
+        "v_lshl_add_u32 %[qb], %[mp], 2, %[qb]\n\t"                 \
+        "v_ffbh_u32 %[z1], %[tt]\n\t"                               \
+        "v_and_or_b32 %[ad], %[qb], %[c124], %[rowb]\n\t"           \
+        "v_mad_i32_i24 %[nn1], %[z1], %[zmask], %[nwidth]\n\t"      \
+        "ds_read_b32 %[" WNC "], %[ad]\n\t"                         \
+        "v_alignbit_b32 %[t2], %[tt], 0, %[nn1]\n\t"                \
+        "v_lshl_add_u32 %[xa], %[pz1], %[lsh], %[pv1]\n\t"          \
+        "v_ffbh_u32 %[z2], %[t2]\n\t"                               \
+        "v_lshl_add_u32 %[xb], %[pz2], %[lsh], %[pv2]\n\t"          \
+        "v_mad_i32_i24 %[nn2], %[z2], %[zmask], %[nwidth]\n\t"      \
+        "s_waitcnt lgkmcnt(" CNT ")\n\t"                            \
+        "v_bfi_b32 %[w2], %[mp], %[" WNP "], %[w2]\n\t"             \
+        "v_add3_u32 %[s2], %[s], %[nn1], %[nn2]\n\t"                \
+        "v_bfe_u32 %[pv1], %[tt], %[nn1], %[fw]\n\t"                \
+        "v_ashrrev_i32 %[mp], 31, %[s2]\n\t"                        \
+        "v_bfe_u32 %[pv2], %[t2], %[nn2], %[fw]\n\t"                \
+        "v_bfi_b32 %[w0], %[mp], %[w1], %[w0]\n\t"                  \
+        "v_mov_b32 %[pz1], %[z1]\n\t"                               \
+        "v_bfi_b32 %[w1], %[mp], %[w2], %[w1]\n\t"                  \
+        "v_perm_b32 %[xa], %[xb], %[xa], %[sel]\n\t"                \
+        "v_and_b32 %[s], 31, %[s2]\n\t"                             \
+        "v_mov_b32 %[pz2], %[z2]\n\t"
+#define PAIR6(WNC, WNP, CNT)                                        \
+        "v_alignbit_b32 %[tt], %[w0], %[w1], %[s]\n\t"              \
+        "v_lshl_add_u32 %[qb], %[mp], 2, %[qb]\n\t"                 \
+        "v_ffbh_u32 %[z1], %[tt]\n\t"                               \
+        "v_and_or_b32 %[ad], %[qb], %[c124], %[rowb]\n\t"           \
+        "v_mad_i32_i24 %[nn1], %[z1], %[zmask], %[nwidth]\n\t"      \
+        "ds_read_b32 %[" WNC "], %[ad]\n\t"                         \
+        "v_alignbit_b32 %[t2], %[tt], 0, %[nn1]\n\t"                \
+        "s_waitcnt lgkmcnt(" CNT ")\n\t"                            \
+        "v_bfi_b32 %[w2], %[mp], %[" WNP "], %[w2]\n\t"             \
+        "v_ffbh_u32 %[z2], %[t2]\n\t"                               \
+        "v_mov_b32 %[xa], %[tt]\n\t"                                \
+        "v_mad_i32_i24 %[nn2], %[z2], %[zmask], %[nwidth]\n\t"      \
+        "v_add3_u32 %[s2], %[s], %[nn1], %[nn2]\n\t"                \
+        "v_ashrrev_i32 %[mp], 31, %[s2]\n\t"                        \
+        "v_and_b32 %[s], 31, %[s2]\n\t"                             \
+        "v_bfi_b32 %[w0], %[mp], %[w1], %[w0]\n\t"                  \
+        "v_bfi_b32 %[w1], %[mp], %[w2], %[w1]\n\t"
+      REP8({
+        uint32_t tt, t2, nn1, nn2, ad, xa, xb = 0, z1, z2;
+        int32_t s2;
+        if (KIND == 5)
+          asm volatile(PAIR5("wna", "wnb", "1")
+              : [tt] "=&v"(tt), [t2] "=&v"(t2), [nn1] "=&v"(nn1), [nn2] "=&v"(nn2), [ad] "=&v"(ad), [xa] "=&v"(xa), [xb] "=&v"(xb),
+                [z1] "=&v"(z1), [z2] "=&v"(z2), [s2] "=&v"(s2), [w0] "+v"(w0), [w1] "+v"(w1), [w2] "+v"(w2), [s] "+v"(s), [qb] "+v"(qb),
+                [mp] "+v"(mp), [wna] "+v"(wna), [wnb] "+v"(wnb), [pz1] "+v"(pz1), [pz2] "+v"(pz2), [pv1] "+v"(pv1), [pv2] "+v"(pv2)
+              : [zmask] "v"(zmask), [nwidth] "v"(nwidth), [fw] "v"(fw), [lsh] "v"(lsh), [c124] "v"(c124), [rowb] "v"(row_base), [sel] "v"(0x05040100u));
+        else
+          asm volatile(PAIR6("wna", "wnb", "1")
+              : [tt] "=&v"(tt), [t2] "=&v"(t2), [nn1] "=&v"(nn1), [nn2] "=&v"(nn2), [ad] "=&v"(ad), [xa] "=&v"(xa),
+                [z1] "=&v"(z1), [z2] "=&v"(z2), [s2] "=&v"(s2), [w0] "+v"(w0), [w1] "+v"(w1), [w2] "+v"(w2), [s] "+v"(s), [qb] "+v"(qb),
+                [mp] "+v"(mp), [wna] "+v"(wna), [wnb] "+v"(wnb)
+              : [zmask] "v"(zmask), [nwidth] "v"(nwidth), [c124] "v"(c124), [rowb] "v"(row_base));
+        acc ^= xa;
+        { uint32_t tmp = wna; wna = wnb; wnb = tmp; }
+      })
+    }
     if (KIND == 3) {
       REP8(asm volatile(
           "v_add_u32 %0, %0, %4\n\tv_add_u32 %1, %1, %4\n\tv_add_u32 %2, %2, %4\n\tv_add_u32 %3, %3, %4\n\t"
@@ -141,7 +209,7 @@ __global__ void __launch_bounds__(64) k(unsigned long long* out, uint32_t seed) 
   }
   const long long t1 = clock64();
   if (threadIdx.x == 0)
-    out[blockIdx.x] = (unsigned long long)(t1 - t0) + ((unsigned long long)(acc + t + u + w0 + w1 + a0 + a1 + a2 + a3) & 1ull);
+    out[blockIdx.x] = (unsigned long long)(t1 - t0) + ((unsigned long long)(acc + t + u + w0 + w1 + w2 + wna + pz1 + pv1 + pv2 + pz2 + mp + a0 + a1 + a2 + a3) & 1ull);
 }
 
 template <int KIND>
@@ -166,6 +234,8 @@ int main() {
     run<2>("carried peek without the LDS read (20)", grid);
     run<3>("19 v_add_u32, four chains", grid);
     run<4>("19 three-operand ops, four chains", grid);
+    run<5>("software-pipelined pair (19 + 3 moves, read 1.5 pairs ahead)", grid);
+    run<6>("software-pipelined THIN pair (15 + read)", grid);
   }
   return 0;
 }

@@ -60,8 +60,8 @@ static void opts_from_env(X3Opts* o) {
 #ifdef X3_PROFILING
   o->check_serial = std::getenv("X3HIP_CHECK_SERIAL") ? 1 : 0;
   o->no_check = std::getenv("X3HIP_PROFILE_NO_CHECK") ? 1 : 0;
-  o->dyn_lds = (int)std::max(0ll, geti("X3HIP_DECODE_DYN_LDS", 0));
 #endif
+  o->dyn_lds = (int)std::max(0ll, geti("X3HIP_DECODE_DYN_LDS", 0));
 }
 
 static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
@@ -320,6 +320,7 @@ extern "C" int x3_ctx_set_option(x3_ctx* c, const char* name, long long value) {
   else if (n == "check_main") c->opt.check_main = value != 0;
   else if (n == "check_first") c->opt.check_first = value != 0;
   else if (n == "check_wgs") c->opt.check_wgs = (int)std::max(1ll, value);
+  else if (n == "seg_stretches") c->opt.seg_stretches = (int)std::max(0ll, value);
   else if (n == "mc_decode_threads") c->opt.mc_decode_threads = value != 0;
   else if (n == "index_no_fast") c->opt.index_no_fast = value != 0;
   else if (n == "wav_offsets_x4") c->opt.wav_offsets_x4 = value != 0;
@@ -355,6 +356,8 @@ extern "C" int x3_ctx_get_option(const x3_ctx* c, const char* name, long long* v
   }
   else if (n == "check_first") *value = c->opt.check_first;
   else if (n == "check_wgs") *value = c->opt.check_wgs;
+  else if (n == "seg_stretches") *value = c->opt.seg_stretches;
+  else if (n == "last_seg_stretches") *value = c->last_seg_stretches;   // read-only: how the last decode launch used its segment index
   else if (n == "mc_decode_threads") *value = c->opt.mc_decode_threads;
   else if (n == "index_no_fast") *value = c->opt.index_no_fast;
   else if (n == "wav_offsets_x4") *value = c->opt.wav_offsets_x4;

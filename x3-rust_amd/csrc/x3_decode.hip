@@ -14,7 +14,8 @@
 int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint64_t* d_frame_offsets,
                            uint64_t F, const x3_batch* batch, const uint64_t* d_wav_offsets, const x3_params* p,
                            int16_t* d_wav, uint64_t wav_cap, int32_t* d_status, bool wav_off_aligned,
-                           bool bl0) {  // bl0: the caller's block_len is 0 and p carries 1 (x3_decode_merge_kernel)
+                           bool bl0,    // bl0: the caller's block_len is 0 and p carries 1 (x3_decode_merge_kernel)
+                           const X3SegSpec* seg) {
   if (reinterpret_cast<uintptr_t>(d_x3) & 3u) return X3_ERR_BAD_ARG;
   if (reinterpret_cast<uintptr_t>(d_wav) & 1u) return X3_ERR_BAD_ARG;
   if (F == 0 || F > 0x7FFFFFFFull) return X3_ERR_BAD_ARG;
@@ -90,11 +91,8 @@ int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint6
                        (d_wav_offsets || ((dp.spf % 4u) == 0 && (g.fpc * (uint64_t)1 >= g.n_frames || (g.clip_stride % 4u) == 0)));
     // (rows on 16-byte boundaries: whole lines in 16-byte pieces; on 8-byte boundaries -- an output pointer, a clip stride
     // or a frame length of 4 (mod 8) samples --: the same lines in 8-byte pieces, x3_decode_split_kernel.h flush_rows)
-#ifdef X3_PROFILING
+    // (X3HIP_DECODE_DYN_LDS: extra LDS per decoder group = fewer groups per CU; an occupancy experiment)
     const size_t dyn_lds = (size_t)c->opt.dyn_lds;
-#else
-    const size_t dyn_lds = 0;
-#endif
     TimerScope ts(c, 1, dec_stream, split);   // (the split kernel: events on its dispatch packet; the rarer single-wave kernels below: bracketed)
     if (split) {
       // the pace word's 12-bit epoch: launches 1, 2, ... 4095, then the word starts over
@@ -104,10 +102,44 @@ int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint6
         HIPCHK(c, hipMemsetAsync(c->d_pace + X3_LOG_BASE, 0, X3_LOG_ENTRIES * X3_LOG_WORDS * sizeof(uint32_t), dec_stream));  // (its atomicMax entries carry the epoch too)
         ++c->dec_epoch;
       }
-      X3_LAUNCH_TIMED(ts, x3_decode_split_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64 * X3S_WAVES),
+      // The segment index (x3_decode_split_kernel.h, "STRETCHES"): decode by it -- a lane per stretch of `seg_blocks` blocks,
+      // nseg times the groups -- or record it while decoding frame by frame.  Frames of at most one stretch need none.
+      X3SegArgs sg{nullptr, nullptr, 0u, 1u, 0u, 1u};
+      uint64_t groups = (F + 63) / 64;
+      if (seg && seg->mode && seg->d_index && seg->seg_blocks) {
+        const uint64_t bpf = (std::min<uint64_t>(dp.spf, d_wav_offsets ? dp.spf : g.n_per_clip) + X3S_BL - 2) / X3S_BL;  // blocks of the longest frame
+        const uint64_t nidx = (bpf + seg->seg_blocks - 1) / seg->seg_blocks;   // stretches the index can tell apart
+        if (nidx >= 2) {
+          sg.pitch = (uint32_t)(nidx - 1);
+          if (seg->mode == 1) {
+            // As many stretches as fill the chip and no more: a launch whose groups fill it anyway is faster frame by frame
+            // (a stretch pays a group's start: header, ring fill, the flusher's tables; 1 080 groups: 0.70 against 0.78 ms,
+            // profiles/r5/segments_split_kernel.txt), a stream of 42 groups five times faster by stretches.
+            const uint64_t want = c->opt.seg_stretches > 0 ? (uint64_t)c->opt.seg_stretches
+                                  : (groups * 2 >= (uint64_t)c->n_cus * 5 ? 1 : ((uint64_t)c->n_cus * 4 + groups - 1) / groups);
+            const uint64_t mul = (nidx + std::min<uint64_t>(want, nidx) - 1) / std::min<uint64_t>(want, nidx);
+            const uint64_t nseg = (nidx + mul - 1) / mul;
+            if (nseg >= 2 && groups * nseg <= 0x7FFFFFFFull) {
+              sg.in = reinterpret_cast<const uint2*>(seg->d_index);
+              sg.mul = (uint32_t)mul;
+              sg.sb = (uint32_t)(seg->seg_blocks * mul);
+              sg.nseg = (uint32_t)nseg;
+              groups *= nseg;
+              HIPCHK(c, hipMemsetAsync(d_status, 0, F * sizeof(int32_t), dec_stream));  // (the stretches of a frame add to its status)
+            }
+          } else {
+            sg.out = reinterpret_cast<uint2*>(seg->d_index);
+            sg.sb = seg->seg_blocks;
+            sg.nseg = (uint32_t)nidx;
+            HIPCHK(c, hipMemsetAsync(seg->d_index, 0, (1 + F * (nidx - 1)) * sizeof(uint2), dec_stream));   // (no entry: not valid)
+          }
+        }
+      }
+      c->last_seg_stretches = sg.in ? (int)sg.nseg : (sg.out ? -1 : 0);
+      X3_LAUNCH_TIMED(ts, x3_decode_split_kernel, dim3((unsigned)groups), dim3(64 * X3S_WAVES),
                          dyn_lds, dec_stream, d_x3, x3_len,
                          d_frame_offsets, F, g, d_wav_offsets, dp, d_wav, wav_cap, d_status, (X3FrameMeta*)c->dec_meta.p,
-                         c->d_pace, c->dec_epoch & 0xFFFu);
+                         c->d_pace, c->dec_epoch & 0xFFFu, sg);
       ++c->dec_epoch;
     }
     else if (fast)
@@ -151,6 +183,27 @@ extern "C" int x3_decode_dev(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, co
   // that without a pass over the offsets -- option "wav_offsets_x4")
   return decode_dev_impl(c, d_x3, x3_len, d_frame_offsets, n_frames, batch, d_wav_offsets, p, d_wav, wav_cap, d_status,
                          d_wav_offsets != nullptr && c->opt.wav_offsets_x4 != 0);
+}
+
+// x3_decode_dev with the SEGMENT INDEX (include/x3hip.h): record = 0 decodes by it, record = 1 decodes frame by frame and
+// leaves it in d_seg_index for the next decode of the same stream
+extern "C" uint64_t x3_seg_index_entries(uint64_t n_frames, const x3_params* p, uint32_t seg_blocks) {
+  if (!p || seg_blocks == 0 || p->blocks_per_frame == 0) return 0;
+  const uint64_t nseg = ((uint64_t)p->blocks_per_frame + seg_blocks - 1) / seg_blocks;
+  return nseg >= 2 ? 1 + n_frames * (nseg - 1) : 0;   // (a header word, then nseg - 1 entries per frame)
+}
+
+extern "C" int x3_decode_dev_seg(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint64_t* d_frame_offsets,
+                                 uint64_t n_frames, const x3_batch* batch, const uint64_t* d_wav_offsets,
+                                 const x3_params* p, int16_t* d_wav, uint64_t wav_cap, int32_t* d_status,
+                                 uint64_t* d_seg_index, uint32_t seg_blocks, int record) {
+  if (!c || !d_x3 || !d_frame_offsets || !p || !d_wav) return X3_ERR_BAD_ARG;
+  if (d_seg_index && (seg_blocks == 0 || (seg_blocks & 3u) || seg_blocks > 3200u || (reinterpret_cast<uintptr_t>(d_seg_index) & 7u)))
+    return X3_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  const X3SegSpec seg{d_seg_index, seg_blocks, d_seg_index ? (record ? 2 : 1) : 0};
+  return decode_dev_impl(c, d_x3, x3_len, d_frame_offsets, n_frames, batch, d_wav_offsets, p, d_wav, wav_cap, d_status,
+                         d_wav_offsets != nullptr && c->opt.wav_offsets_x4 != 0, false, &seg);
 }
 
 extern "C" int x3_decode_result(x3_ctx* c, uint64_t* first_bad, int* first_bad_status, uint64_t* samples_before) {

@@ -57,6 +57,58 @@
 #ifndef X3S_VALUER_FOLD
 #define X3S_VALUER_FOLD 0
 #endif
+// Round 5: the THIN parser.  The parser is the group's critical wave -- its pair loop runs at the speed of a lone wave
+// (152 clocks per pair of codewords against 139 alone on a SIMD: profiles/r4/stamps_decode_split_base.txt,
+// ubench_pair_cost.txt) -- so what it does not have to do itself is taken off it: it walks the codeword LENGTHS only (peek,
+// two v_ffbh / v_mad / the shift between them, the window update: 14 vector instructions per pair instead of 19) and hands
+// over the 32-bit PEEK of every pair; the valuer, which idles 29 % of the time at the barrier and whose pairs do not depend
+// on each other, repeats the five-instruction walk on the peek and extracts the two fields from it (+10 per pair there).
+// Measured (profiles/r5/decoder_thin_parser.txt): 0.649 -> 0.684 ms.  The ten instructions a pair gains in the valuer make
+// IT the critical wave.  Kept as a build option.
+#ifndef X3S_THIN
+#define X3S_THIN 0
+#endif
+// Round 5: the parser's pair loop SOFTWARE-PIPELINED, one asm block per block of ten pairs.  A lone wave issues an
+// instruction every ~4.3 clocks when it does not depend on the one before and every ~8.5 when it does
+// (tools/ubench/issue_cost.hip), and in the loop as the compiler laid it out (peek, ffbh, mad, shift, ffbh, mad, add3,
+// sign, address, read, bfi, bfi: a dependent instruction behind nearly every one) a pair took 139 clocks for its 19 + 1
+// instructions.  Here every instruction of the dependent chain is followed by one that does not depend on it: the
+// PREVIOUS pair's index packing and its store to the block buffer, this pair's field extraction, the ring address and
+// read.  The window has a third word w2 that is brought up to date half a pair late, so that the ring read has a pair and
+// a half to arrive (tools/ubench/pair_cost.hip: 139 -> ~100 clocks per pair for one wave on its SIMD).  Nothing that the
+// asm block reads asynchronously is left pending in a register the compiler knows: the block ends with the window settled.
+#ifndef X3S_SWP
+#define X3S_SWP 1
+#endif
+#if X3S_SWP && X3S_THIN
+#error "X3S_THIN is an option of the compiler-scheduled pair loop (X3S_SWP=0)"
+#endif
+// pair i of a block: chain instruction, filler, chain instruction, filler ...; CNT = LDS operations that may still be in
+// flight when the read of pair i-1 is needed (those issued behind it); STORE = the store of pair i-1's packed indices
+#define X3S_SWP_PAIR(WNC, WNP, CNT, STORE)                           \
+  "v_alignbit_b32 %[tt], %[w0], %[w1], %[s]\n\t"                     \
+  "v_lshl_add_u32 %[xa], %[z1], %[lsh], %[pv1]\n\t"                  \
+  "v_ffbh_u32 %[z1], %[tt]\n\t"                                      \
+  "v_lshl_add_u32 %[xb], %[z2], %[lsh], %[pv2]\n\t"                  \
+  "v_mad_i32_i24 %[nn1], %[z1], %[zmask], %[nwidth]\n\t"             \
+  "v_lshl_add_u32 %[qb], %[mp], 2, %[qb]\n\t"                        \
+  "v_alignbit_b32 %[t2], %[tt], 0, %[nn1]\n\t"                       \
+  "v_and_or_b32 %[ad], %[qb], %[c124], %[rowb]\n\t"                  \
+  "v_ffbh_u32 %[z2], %[t2]\n\t"                                      \
+  "ds_read_b32 %[" WNC "], %[ad]\n\t"                                \
+  "v_mad_i32_i24 %[nn2], %[z2], %[zmask], %[nwidth]\n\t"             \
+  "v_perm_b32 %[xa], %[xb], %[xa], %[sel]\n\t"                       \
+  "s_waitcnt lgkmcnt(" CNT ")\n\t"                                   \
+  "v_bfi_b32 %[w2], %[mp], %[" WNP "], %[w2]\n\t"                    \
+  "v_add3_u32 %[s2], %[s], %[nn1], %[nn2]\n\t"                       \
+  STORE                                                              \
+  "v_bfe_u32 %[pv1], %[tt], %[nn1], %[fw]\n\t"                       \
+  "v_ashrrev_i32 %[mp], 31, %[s2]\n\t"                               \
+  "v_bfe_u32 %[pv2], %[t2], %[nn2], %[fw]\n\t"                       \
+  "v_bfi_b32 %[w0], %[mp], %[w1], %[w0]\n\t"                         \
+  "v_and_b32 %[s], 31, %[s2]\n\t"                                    \
+  "v_bfi_b32 %[w1], %[mp], %[w2], %[w1]\n\t"
+#define X3S_SWP_STORE(OFF) "ds_write_b32 %[buf], %[xa] offset:" #OFF "\n\t"
 // timing experiments only (results are wrong): knock out one role's work to see what the others cost each other.
 // 1: the valuer's pair arithmetic and staging; 2: the flusher's loads and stores; 4: the parser's codeword walk;
 // 8: the flusher's global stores only (its LDS reads stay); 16: the parser's ring service (no loads, no parks);
@@ -73,7 +125,11 @@
 // halfword index of sample j (0..19) of a block in its transfer buffer: pair j/2 is dword (j/2 & 1) of the
 // 8-byte slot of this lane in row j/4
 __device__ __forceinline__ uint32_t x3s_half_index(uint32_t j, uint32_t lane) {
+#if X3S_SWP
+  return 2u * ((j >> 1) * 64u + lane) + (j & 1u);   // (software-pipelined parser: pair j/2 is dword `lane` of row j/2)
+#else
   return 2u * (((j >> 2) * 64u + lane) * 2u + ((j >> 1) & 1u)) + (j & 1u);
+#endif
 }
 
 // Pacing.  The SQ issues oldest-first, so the groups dispatched first run ahead of the ones dispatched last (group
@@ -130,11 +186,38 @@ __device__ __forceinline__ void x3s_set_priority(int32_t d) {
 #undef X3S_P2
 }
 #define X3S_PACE_STEP(b, ROLE)                                                                 \
-  if (!X3S_PACE_OFF && ((b) & 7u) == 0u) {                                                     \
+  if (paced && ((b) & 7u) == 0u) {                                                             \
     const uint32_t el = (uint32_t)(wall_clock64() - pace_t0); /* 10 ns ticks */                \
     const int32_t d = (int32_t)(b) - (int32_t)(((unsigned long long)el * pace_inv) >> 16); /* (64-bit: 80 ms of ticks times the rate pass 2^32) */ \
     x3s_set_priority<ROLE>(d);                                                                 \
   }
+
+// ---- Round 5: STRETCHES.  A frame is one serial bit stream, so a stream of few frames cannot be decoded faster than
+// one frame's walk (0.41 ms for 500 blocks), and 1 080 groups on 256 CUs leave 56 CUs with a fifth group that ends the
+// kernel.  A block, though, depends on nothing but the bit position it starts at and the sample in front of it
+// (decoder.rs:36-58).  The encoder knows both for every block (its prefix scan of the blocks' bit lengths, its input), and
+// so does a serial decode: the SEGMENT INDEX holds, for every frame and every `sb` blocks, {bit offset of block sb*j's
+// header from the start of the payload, the sample in front of it | 0x10000}.  With it, lane = (frame, stretch j): blocks
+// [sb*j, sb*(j+1)) of the frame, decoded from the index entry into the row wav + wo + 20*sb*j.  The index is a HINT, not
+// part of the format and not trusted: a stretch that ends inside its frame compares where it ended -- bit position and
+// last sample -- with the entry of the next one; by induction from the frame's first block, the stretches of a frame
+// whose comparisons all hold decode what the serial walk decodes.  Any mismatch, any entry that is not plausible, marks
+// the frame X3D_REPLAY and the reference's reader decodes it (x3_decode_replay.h), so a wrong index costs time only.
+// Layout: word 0 is a header {X3S_SEG_MAGIC, blocks per entry}, written by whoever fills the index (an encoder that cannot --
+// the kernels for other layouts -- leaves it zero, and a decode by such an index falls back to whole frames per lane);
+// entry (f, k), k = 1 .. pitch, at word 1 + f * pitch + k - 1 is for block isb * k.  A decode may take every mul-th entry
+// (stretches of sb = isb * mul blocks): the host picks as many stretches as fill the chip and no more.
+// in: the index to decode by (grid = groups * nseg);  out: the index to RECORD while decoding serially (either may be null)
+struct X3SegArgs {
+  const uint2* in;
+  uint2* out;
+  uint32_t sb;     // blocks per stretch (a multiple of 4: stretches start on 16-sample = 32-byte boundaries of the frame)
+  uint32_t nseg;   // stretches per frame = ceil(blocks per frame / sb)
+  uint32_t pitch;  // entries per frame in the index
+  uint32_t mul;    // sb / blocks per index entry
+};
+#define X3S_SEG_VALID 0x10000u
+#define X3S_SEG_MAGIC 0x58335347u
 
 // LDS barrier of the group's waves: LDS operations retired, nothing else waited for
 #define X3S_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -143,7 +226,7 @@ __global__ void __launch_bounds__(64 * X3S_WAVES)
 x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uint64_t* __restrict__ frame_off,
                        uint64_t n_frames, X3Geom g, const uint64_t* __restrict__ wav_off, X3DevParams p,
                        int16_t* __restrict__ wav, uint64_t wav_cap, int32_t* __restrict__ status,
-                       X3FrameMeta* __restrict__ meta, uint32_t* __restrict__ pace, uint32_t pace_epoch) {
+                       X3FrameMeta* __restrict__ meta, uint32_t* __restrict__ pace, uint32_t pace_epoch, X3SegArgs sg) {
   // input ring, 32 dwords per lane in rows of exactly 128 bytes at 128-byte aligned addresses, stream word j in
   // slot ~j & 31 (descending): the address of a word is then ONE v_and_or_b32 on a byte counter that a shift of
   // the window decrements with one v_lshl_add_u32.  (Lanes are at different places in their rows, so the aligned
@@ -160,7 +243,19 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   const uint32_t lane = threadIdx.x & 63u;
   const bool parser = threadIdx.x < 64u;
   const bool flusher = (threadIdx.x >> 6) == 2u;
-  const uint64_t f = (uint64_t)blockIdx.x * 64 + lane;
+  const bool seg_grid = sg.in != nullptr;   // (uniform) the grid has nseg groups per 64 frames
+  const uint32_t seg_j = seg_grid ? blockIdx.x % sg.nseg : 0u;
+  // (an index whose header does not say what this launch expects: whole frames per lane, in the groups of stretch 0)
+  bool segd = false;
+  if (seg_grid) {
+    const uint2 h = sg.in[0];
+    segd = (uint32_t)__builtin_amdgcn_readfirstlane((int)h.x) == X3S_SEG_MAGIC &&
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)h.y) * sg.mul == sg.sb;
+    if (!segd && seg_j) return;
+  }
+  const uint64_t f = (uint64_t)(seg_grid ? blockIdx.x / sg.nseg : blockIdx.x) * 64 + lane;
+  if (sg.out && blockIdx.x == 0 && threadIdx.x == 0) sg.out[0] = make_uint2(X3S_SEG_MAGIC, sg.sb);
+  const bool paced = !X3S_PACE_OFF && !segd;   // (stretches: many short groups, dispatched as CUs fall free -- nothing to pace)
   const unsigned long long pace_t0 = wall_clock64();
   const unsigned long long clk_t0 = clock64();   // (shader clock: the launch log's clock measurement, below)
   uint32_t pace_inv;        // blocks per tick, 16.16 fixed point
@@ -254,7 +349,41 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       }
     }
   }
-  if (!active) { p0 = 0; plen = 2; wo = 0; samples = 0; }
+  // ---- the stretch of the frame that this lane decodes (all of it without an index)
+  uint32_t hb = 16u;                    // bit offset of its first block header from the start of the payload
+  uint32_t pred = 0;                    // (seg_j > 0) the sample in front of it
+  bool mid = false;                     // it ends inside the frame: its last sample is the next stretch's first
+  uint32_t exp_bits = 0, exp_pred = 0;  // (mid) the next stretch's index entry
+  if (segd && active) {
+    const uint32_t nbf = (samples - 1u + X3S_BL - 1u) / X3S_BL;   // blocks of the frame
+    const uint32_t b0 = sg.sb * seg_j;
+    const uint2* const e = sg.in + 1 + f * (uint64_t)sg.pitch;
+    if (seg_j && b0 >= nbf) {
+      active = false;                   // the frame has no such stretch (st stays OK)
+    } else {
+      if (seg_j) {
+        const uint2 h = e[seg_j * sg.mul - 1u];
+        if (!(h.y & X3S_SEG_VALID) || h.x < 16u || h.x > 8u * plen) {
+          st = X3D_REPLAY;              // not an entry to start from: the reference's reader takes the frame
+          active = false;
+        } else {
+          hb = h.x;
+          pred = h.y & 0xFFFFu;
+        }
+      }
+      if (active && b0 + sg.sb < nbf) {
+        const uint2 hn = e[(seg_j + 1u) * sg.mul - 1u];
+        mid = true;
+        exp_bits = hn.x;
+        exp_pred = hn.y;
+      }
+      if (active) {
+        wo += (uint64_t)X3S_BL * b0;
+        samples = mid ? X3S_BL * sg.sb + 1u : samples - X3S_BL * b0;
+      }
+    }
+  }
+  if (!active) { p0 = 0; plen = 2; wo = 0; samples = 0; hb = 16u; mid = false; }
   // blocks of this lane's frame and of the longest frame of the group: the loop both waves run
   const uint32_t nblk = samples ? (samples - 1u + X3S_BL - 1u) / X3S_BL : 0u;
   const uint32_t nblk_max = __builtin_amdgcn_readfirstlane(x3_wave_max_u32(nblk));
@@ -267,10 +396,12 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   const uint32_t adj = (uint32_t)(reinterpret_cast<uintptr_t>(x3) & 15u);
   // offsets are relative to this lane's first 16-byte chunk (a frame is < 64 KB): a 64-bit pointer per lane,
   // 32-bit arithmetic on everything else, streams of any length
-  const uint64_t abs_bits = (uint64_t)adj + p0 + 2u;
+  const uint64_t abs_bits = (uint64_t)adj + p0 + (hb >> 3);   // (a byte position; hb = 16 without an index: behind the first sample)
+  const uint32_t ebits = hb & 7u;                             // ... and the bits of that byte in front of the header
   const uint8_t* __restrict__ const x3b = (x3 - adj) + (abs_bits & ~15ull);
   const uint32_t v_bits = (uint32_t)(abs_bits & 15u);      // first block header
-  const uint32_t v_end = v_bits - 2u + plen;                 // end of the payload
+  const uint32_t v_end = v_bits - (hb >> 3) + plen;          // end of the payload
+  const int32_t v_rel = 8 * (int32_t)(hb >> 3) - 8 * (int32_t)v_bits;   // payload bit = ring bit + v_rel
   const uint32_t v_last = (v_end - 1u) & ~15u;               // last 16-byte chunk that holds payload
   uint32_t v_next = 0;
   uint32_t wr_abs = 0;
@@ -339,6 +470,10 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   // samples -- an even number of blocks that is not a multiple of four -- have eight phases: classes of eight rows
   // (r & 7 == c), one store instruction each (`cls8`, round 4; such frames went row by row through the valuer before).
   const uint32_t S0 = __builtin_amdgcn_readfirstlane(samples);
+  // the ROW a lane writes: its samples without the last one of a stretch that ends inside the frame (that one is the
+  // next stretch's); rows of a regular group are R0 samples long and ST samples apart (frames: R0 = ST = S0)
+  const uint32_t rowlen = samples - (mid ? 1u : 0u);
+  const uint32_t R0 = __builtin_amdgcn_readfirstlane(rowlen);
   // (the builtin returns int: without the casts a low word with bit 31 set sign-extends over the high one, and every
   // group whose sample offset has that bit stops being "regular" -- half of all groups beyond 2^31 samples)
   const uint64_t wo0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(wo >> 32)) << 32) |
@@ -346,8 +481,12 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   // (rows on 8-byte boundaries only -- an output or a clip stride of 4 (mod 8) samples, frames of an odd number of
   // blocks --: the flusher's list with 8-byte pieces, flush_rows)
   const bool p8 = __any(active && (reinterpret_cast<uintptr_t>(wav + wo) & 15u) != 0u);
-  bool regular = __all(active && samples == S0 && wo == wo0 + (uint64_t)lane * S0) && (S0 & 7u) == 0 && !p8;
-  const bool cls8 = (S0 & 15u) != 0u;
+  const uint64_t wo1 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wo >> 32), 1) << 32) |
+                       (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wo, 1);
+  const uint32_t ST = segd ? (uint32_t)(wo1 - wo0) : S0;
+  bool regular = __all(active && samples == S0 && rowlen == R0 && wo == wo0 + (uint64_t)lane * ST) && (R0 & 7u) == 0 &&
+                 (ST & 7u) == 0 && ST >= R0 && ST < 0x10000u && !p8;
+  const bool cls8 = (ST & 15u) != 0u;
   const uint64_t B0 = (uint64_t)(uintptr_t)(wav + wo0);  // destination byte address of the group (16-byte aligned)
   uint8_t* const line0 = reinterpret_cast<uint8_t*>(B0 & ~127ull);  // its first line
   // this lane's part in the flush of class c, store i: piece `pc` of the current line of row rr[c][i]
@@ -355,14 +494,14 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   uint32_t f_src[4][2], f_dst[4][2];  // LDS byte address / byte offset from line0, for the row's FIRST line
   uint32_t ph[8], nfl[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // per class: dwords of the first line in front of the row; lines flushed
 #pragma unroll
-  for (uint32_t c = 0; c < 8; ++c) ph[c] = (uint32_t)(((B0 + (uint64_t)c * 2u * S0) & 127u) >> 2);
+  for (uint32_t c = 0; c < 8; ++c) ph[c] = (uint32_t)(((B0 + (uint64_t)c * 2u * ST) & 127u) >> 2);
 #pragma unroll
   for (uint32_t c = 0; c < 4; ++c) {
 #pragma unroll
     for (uint32_t i = 0; i < 2; ++i) {
       // (eight classes: entry [c][i] is class c + 4 i)
       const uint32_t rr = cls8 ? 8u * (lane >> 3) + (c + 4u * i) : 4u * ((lane >> 3) + 8u * i) + c;
-      const uint32_t off = (uint32_t)(B0 & 127u) + rr * 2u * S0;     // bytes from line0 to the row (< 2^32: 64 frames)
+      const uint32_t off = (uint32_t)(B0 & 127u) + rr * 2u * ST;     // bytes from line0 to the row (< 2^32: 64 frames)
       const uint32_t rrot = 16u * ((rr >> 2) & 15u);
       f_dst[c][i] = (off & ~127u) + 16u * pc;
       f_src[c][i] = x3_lds_addr(outs) + rr * (4u * X3S_RING_DW) +
@@ -406,7 +545,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   }
 #define X3S_FLUSH_TAILS()                                                                                        \
   _Pragma("unroll") for (uint32_t c = 0; c < 4; ++c) {                                                           \
-    const uint32_t tail = ((ph[c] + (S0 >> 1)) & 31u) >> 2; /* pieces of the last, partial line */               \
+    const uint32_t tail = ((ph[c] + (R0 >> 1)) & 31u) >> 2; /* pieces of the last, partial line */               \
     if (tail) flush_class(c, f_src[c][0], f_src[c][1], f_dst[c][0], f_dst[c][1], nfl[c], nfl[c] ? 0u : ph[c] >> 2, tail); \
   }
 #define X3S_FLUSH_CLASS8(c)                                                                                      \
@@ -419,7 +558,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   }
 #define X3S_FLUSH_TAILS8()                                                                                       \
   _Pragma("unroll") for (uint32_t c = 0; c < 8; ++c) {                                                           \
-    const uint32_t tail = ((ph[c] + (S0 >> 1)) & 31u) >> 2;                                                      \
+    const uint32_t tail = ((ph[c] + (R0 >> 1)) & 31u) >> 2;                                                      \
     if (tail) flush_row(c, f_src[c & 3][c >> 2], f_dst[c & 3][c >> 2], nfl[c], nfl[c] ? 0u : ph[c] >> 2, tail);   \
   }
 #else
@@ -439,8 +578,8 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   }
 #define X3S_FLUSH_TAILS()                                                                                        \
   _Pragma("unroll") for (uint32_t c = 0; c < 4; ++c) {                                                           \
-    const uint32_t tail = ((ph[c] + (S0 >> 1)) & 31u) >> 2; /* pieces of the last, partial line */               \
-    const uint32_t tline = (ph[c] + (S0 >> 1)) >> 5;        /* that line's number */                             \
+    const uint32_t tail = ((ph[c] + (R0 >> 1)) & 31u) >> 2; /* pieces of the last, partial line */               \
+    const uint32_t tline = (ph[c] + (R0 >> 1)) >> 5;        /* that line's number */                             \
     if (tail) flush_class(c, f_src[c][0], f_src[c][1], f_dst[c][0], f_dst[c][1], tline, tline ? 0u : ph[c] >> 2, tail); \
   }
 #endif
@@ -462,7 +601,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     const uint32_t g_pl = 128u >> g_sh;                                // pieces per line = lanes per listed row
     const uint64_t g_B = (uint64_t)(uintptr_t)(wav + wo);              // the row's first byte
     const uint32_t g_p0 = (uint32_t)(g_B & 127u) >> g_sh;              // pieces of its first line in front of it
-    const uint32_t g_end = g_p0 + (samples >> (g_sh - 1u));            // end of its whole pieces, counted from that line
+    const uint32_t g_end = g_p0 + (rowlen >> (g_sh - 1u));             // end of its whole pieces, counted from that line
     const uint32_t g_rot = 16u * ((lane >> 2) & 15u);
     auto flush_rows = [&]() {
       X3_WAVE_LDS_ORDER();
@@ -560,20 +699,32 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     // codewords is at most 32 bits, so one peek never reaches beyond w1; wn is the word behind w1, re-read from
     // the ring after every consume (the read has a whole pair's time to arrive before the next shift needs it)
     const uint32_t skip = v_bits & 15u;
-    const uint32_t a0 = skip & 3u;
+    const uint32_t a0 = 8u * (skip & 3u) + ebits;               // bits of the first word in front of the header
     const uint32_t widx0 = (skip >> 2) - (a0 == 0 ? 1u : 0u);  // a0 == 0: start with a fully consumed w0
-    uint32_t s = (32u - 8u * a0) & 31u;
+    uint32_t s = (32u - a0) & 31u;
     uint32_t w0 = row[~widx0 & 31u], w1 = row[~(widx0 + 1u) & 31u];
+#if X3S_SWP
+    // (software-pipelined pair loop: a window of three words, wn is the word behind w2)
+    uint32_t w2 = row[~(widx0 + 2u) & 31u];
+    uint32_t wn = row[~(widx0 + 3u) & 31u];
+    uint32_t qb = 4u * ~(widx0 + 3u);
+#else
     uint32_t wn = row[~(widx0 + 2u) & 31u];
     // qb = 4 * ~(widx + 2): the byte offset of wn's slot before masking; widx itself is only needed by service()
     uint32_t qb = 4u * ~(widx0 + 2u);
+#endif
     // consume -nn (<= 32) bits, given as the NEGATIVE count (that is what the codeword walk below has at hand);
     // the word shift is v_bfi with a VGPR mask (see x3_decode_fast_kernel)
     auto consume_to = [&](int32_t s2) {  // s2 = s - bits consumed (>= -32)
       const uint32_t m = (uint32_t)(s2 >> 31);
       s = (uint32_t)s2 & 31u;
       w0 = x3_bfi(m, w1, w0);
+#if X3S_SWP
+      w1 = x3_bfi(m, w2, w1);
+      w2 = x3_bfi(m, wn, w2);
+#else
       w1 = x3_bfi(m, wn, w1);
+#endif
       uint32_t addr;
       asm("v_lshl_add_u32 %0, %2, 2, %0\n\t"                 // widx += 1 on a shift: qb -= 4
           "v_and_or_b32 %1, %0, %3, %4"
@@ -584,7 +735,11 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       __builtin_amdgcn_sched_barrier(0);
     };
     auto consume_neg = [&](uint32_t nn) { consume_to((int32_t)(s + nn)); };
+#if X3S_SWP
+    auto ring_index = [&]() -> uint32_t { return ~((uint32_t)((int32_t)qb >> 2)) - 3u; };  // of w0
+#else
     auto ring_index = [&]() -> uint32_t { return ~((uint32_t)((int32_t)qb >> 2)) - 2u; };  // of w0
+#endif
 
     const uint32_t k_tab = (p.k[1] << 16) | (p.k[2] << 24);  // log2(level) by ftype
     uint32_t over = 0;
@@ -593,6 +748,9 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       const uint32_t cnt = remaining < X3S_BL ? remaining : X3S_BL;
       remaining -= cnt;
       X3_STAMP(0);
+      // a serial decode leaves the segment index behind: where block sb * j begins (the valuer adds the sample in front)
+      if (sg.out && b && (b % sg.sb) == 0u && cnt)
+        sg.out[1 + f * (uint64_t)sg.pitch + (b / sg.sb - 1u)].x = (uint32_t)((int32_t)(32u * ring_index() + 32u - s) + v_rel);
       if (!(X3S_KO & 16) && (b % X3S_PERIOD) == 0) service(ring_index());
       X3_STAMP(1);
       // block header: 2 bits ftype; ftype 0 -> 4 more bits E-1 (decoder.rs:138-144, 209-216)
@@ -616,6 +774,44 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       X3_STAMP(2);
       if ((X3S_KO & 4)) {
       } else if (__all(cnt == X3S_BL || cnt == 0u)) {
+#if X3S_SWP
+        {
+          // ten pairs, software-pipelined (see X3S_SWP_PAIR).  Even pairs read the ring into wnb and use wn, odd pairs the
+          // other way round; pair i packs and stores the indices of pair i - 1 (row i - 1 of the block buffer: one dword per
+          // lane), the tail does so for pair 9 and settles the window: w2 up to date, the last read (into wn) arrived.
+          uint32_t tt, t2, nn1, nn2, ad, xa, xb, z1, z2, pv1, pv2, wnb, mp;
+          int32_t s2;
+          const uint32_t bufa = x3_lds_addr(buf) + 4u * lane;
+          asm volatile(
+              "v_mov_b32 %[mp], 0\n\t"
+              X3S_SWP_PAIR("wnb", "wn", "1", "")
+              X3S_SWP_PAIR("wn", "wnb", "1", X3S_SWP_STORE(0))
+              X3S_SWP_PAIR("wnb", "wn", "2", X3S_SWP_STORE(256))
+              X3S_SWP_PAIR("wn", "wnb", "2", X3S_SWP_STORE(512))
+              X3S_SWP_PAIR("wnb", "wn", "2", X3S_SWP_STORE(768))
+              X3S_SWP_PAIR("wn", "wnb", "2", X3S_SWP_STORE(1024))
+              X3S_SWP_PAIR("wnb", "wn", "2", X3S_SWP_STORE(1280))
+              X3S_SWP_PAIR("wn", "wnb", "2", X3S_SWP_STORE(1536))
+              X3S_SWP_PAIR("wnb", "wn", "2", X3S_SWP_STORE(1792))
+              X3S_SWP_PAIR("wn", "wnb", "2", X3S_SWP_STORE(2048))
+              "v_lshl_add_u32 %[xa], %[z1], %[lsh], %[pv1]\n\t"
+              "v_lshl_add_u32 %[xb], %[z2], %[lsh], %[pv2]\n\t"
+              "v_lshl_add_u32 %[qb], %[mp], 2, %[qb]\n\t"
+              "v_perm_b32 %[xa], %[xb], %[xa], %[sel]\n\t"
+              "ds_write_b32 %[buf], %[xa] offset:2304\n\t"
+              "s_waitcnt lgkmcnt(2)\n\t"
+              "v_bfi_b32 %[w2], %[mp], %[wn], %[w2]\n\t"
+              : [tt] "=&v"(tt), [t2] "=&v"(t2), [nn1] "=&v"(nn1), [nn2] "=&v"(nn2), [ad] "=&v"(ad), [xa] "=&v"(xa),
+                [xb] "=&v"(xb), [z1] "=&v"(z1), [z2] "=&v"(z2), [pv1] "=&v"(pv1), [pv2] "=&v"(pv2), [wnb] "=&v"(wnb),
+                [mp] "=&v"(mp), [s2] "=&v"(s2), [w0] "+v"(w0), [w1] "+v"(w1), [w2] "+v"(w2), [wn] "+v"(wn), [s] "+v"(s),
+                [qb] "+v"(qb)
+              : [zmask] "v"(zmask), [nwidth] "v"(nwidth), [fw] "v"(fw), [lsh] "v"(lsh), [rowb] "v"(row_base), [buf] "v"(bufa),
+                [c124] "s"(124u), [sel] "s"(0x05040100u)
+              : "memory");
+          // the word behind the settled window, as consume_to leaves it (the compiler tracks this read)
+          wn = x3_lds_read_b32(x3_and_or(qb, 124u, row_base));
+        }
+#else
         // two samples per 32-bit peek and per window update (two valid codewords are <= 32 bits)
         uint2* const b2 = reinterpret_cast<uint2*>(buf) + lane;
 #pragma unroll
@@ -630,6 +826,21 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
             // shift count (the hardware uses its low five bits): 4 instructions per codeword.  One asm block, so that the
             // compiler neither pads the dependent chain with s_nop nor reorders it.
             const uint32_t t = __builtin_amdgcn_alignbit(w0, w1, s);
+#if X3S_THIN
+            // the lengths only: the valuer takes z and the fields from the peek (x3s_fields)
+            uint32_t z1, z2, t2, nn1, nn2;
+            int32_t s2;
+            asm("v_ffbh_u32 %0, %6\n\t"
+                "v_mad_i32_i24 %2, %0, %7, %8\n\t"
+                "v_alignbit_b32 %4, %6, 0, %2\n\t"
+                "v_ffbh_u32 %1, %4\n\t"
+                "v_mad_i32_i24 %3, %1, %7, %8\n\t"
+                "v_add3_u32 %5, %9, %2, %3"
+                : "=&v"(z1), "=&v"(z2), "=&v"(nn1), "=&v"(nn2), "=&v"(t2), "=&v"(s2)
+                : "v"(t), "v"(zmask), "v"(nwidth), "v"(s));
+            consume_to(s2);
+            X[e] = t;
+#else
             uint32_t z1, z2, v1, v2, t2, nn1, nn2;
             int32_t s2;
             asm("v_ffbh_u32 %0, %8\n\t"
@@ -644,9 +855,11 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
                 : "v"(t), "v"(zmask), "v"(nwidth), "v"(s), "v"(fw));
             consume_to(s2);
             X[e] = x3_pack_lo16((z1 << lsh) + v1, (z2 << lsh) + v2);
+#endif
           }
           b2[(j >> 1) * 64u] = make_uint2(X[0], X[1]);
         }
+#endif
       } else {
         // a block that is short in some lane (the last block of a frame): one sample at a time
         uint16_t* const h = reinterpret_cast<uint16_t*>(buf);
@@ -666,7 +879,10 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       // replayed, one thread each, 2.7 ms a step for a thousand clips.)
       if (__any(cnt != 0u && remaining == 0u)) {
         const int32_t widx = (int32_t)ring_index();
-        if (cnt != 0u && remaining == 0u) over = (32 * widx + 32 - (int32_t)s > (int32_t)(8u * v_end)) ? 1u : 0u;
+        // (a stretch that ends inside the frame: it must have ended where the index says the next one begins)
+        if (cnt != 0u && remaining == 0u)
+          over = (mid ? (32 * widx + 32 - (int32_t)s + v_rel != (int32_t)exp_bits)
+                      : (32 * widx + 32 - (int32_t)s > (int32_t)(8u * v_end))) ? 1u : 0u;
       }
       X3_STAMP(3);
       X3S_BARRIER();
@@ -689,10 +905,10 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     int16_t* __restrict__ const o = wav + wo;
     const uint32_t rot = 16u * ((lane >> 2) & 15u);
     const uint32_t pos0 = ((uint32_t)(uintptr_t)o + rot) & 255u;  // ring byte of sample 0 (a multiple of 16)
-    bool alive = active;
+    bool alive = active, seg_bad = false;
     uint32_t prevP = 0;  // the previous pair; its high half is the last sample so far (pending: even index)
     if (active) {
-      const uint32_t first = ((uint32_t)x3[p0] << 8) | x3[p0 + 1];
+      const uint32_t first = seg_j ? pred : (((uint32_t)x3[p0] << 8) | x3[p0 + 1]);
       prevP = first << 16;
       if (samples == 1u) o[0] = (int16_t)first;
     }
@@ -701,6 +917,23 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     X3S_BARRIER();  // (s_dead is cleared)
 
     const uint32_t bound_tab = (p.inv_len[0] << 8) | (p.inv_len[1] << 16) | (p.inv_len[2] << 24);  // by ftype (< 256)
+#if X3S_THIN
+    const uint32_t k_tab_v = (p.k[1] << 16) | (p.k[2] << 24);  // log2(level) by ftype (the parser's k_tab)
+    // a pair's peek -> its two indices (z << k) + r / fields, packed: exactly what the parser computed until round 4
+    auto x3s_fields = [&](uint32_t t, uint32_t zmask_, uint32_t nwidth_, uint32_t fw_, uint32_t lsh_) __attribute__((always_inline)) -> uint32_t {
+      uint32_t z1, z2, v1, v2, t2, nn1, nn2;
+      asm("v_ffbh_u32 %0, %7\n\t"
+          "v_mad_i32_i24 %4, %0, %8, %9\n\t"
+          "v_alignbit_b32 %6, %7, 0, %4\n\t"
+          "v_bfe_u32 %1, %7, %4, %10\n\t"
+          "v_ffbh_u32 %2, %6\n\t"
+          "v_mad_i32_i24 %5, %2, %8, %9\n\t"
+          "v_bfe_u32 %3, %6, %5, %10"
+          : "=&v"(z1), "=&v"(v1), "=&v"(z2), "=&v"(v2), "=&v"(nn1), "=&v"(nn2), "=&v"(t2)
+          : "v"(t), "v"(zmask_), "v"(nwidth_), "v"(fw_));
+      return x3_pack_lo16((z1 << lsh_) + v1, (z2 << lsh_) + v2);
+    };
+#endif
     uint32_t posb = pos0;  // ring byte of the block's first pair, unmasked
     for (uint32_t b = 0; b < nblk_max; ++b, posb += 2u * X3S_BL) {
       X3S_PACE_STEP(b, X3S_ROLE_VALUER)
@@ -711,6 +944,8 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       remaining -= cnt;
       const uint32_t* const buf = xfer + (b & 1u) * (X3S_XROWS * 64u);
       const uint32_t hdr = buf[X3S_PAIRS * 64u + lane];
+      if (sg.out && b && (b % sg.sb) == 0u && cnt)   // (the segment index of a serial decode: the sample in front of block b)
+        sg.out[1 + f * (uint64_t)sg.pitch + (b / sg.sb - 1u)].y = (prevP >> 16) | X3S_SEG_VALID;
       // block parameters from the header bits, as arithmetic (see the parser)
       const uint32_t ftype = hdr >> 4;
       const uint32_t E = (hdr & 15u) + 1u;
@@ -724,6 +959,14 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
         st = X3D_FRAME_DECODE_INVALID_BPF;
         alive = false;
       }
+#if X3S_THIN
+      // the codeword geometry of this lane's block, as the parser derives it (thin parser: the walk is repeated here)
+      const uint32_t t_width = x3_bfi(zmask, (1u << ftype) >> 1, E);                 // Rice 1,2,4; BFP E
+      const uint32_t t_kk = (k_tab_v >> (8u * ftype)) & 0xFFu;                       // 0, 0, k1, k2
+      const uint32_t t_fw = x3_bfi(zmask, t_kk, t_width);
+      const uint32_t t_lsh = x3_bfi(zmask, t_kk, 31u);
+      const uint32_t t_nwidth = 0u - t_width;
+#endif
       const uint32_t tm12 = ((neg_thresh - 1u) & 0xFFFFu) * 0x10001u;  // thresh - 1 in each half
       const uint32_t neg22 = (neg2 & 0xFFFFu) * 0x10001u;              // 2 * thresh = 2^E (0 for a literal block)
       uint32_t maxii2 = 0;
@@ -732,10 +975,15 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       if ((X3S_KO & 1)) {
       } else if (__all(cnt == X3S_BL || cnt == 0u)) {
         // the whole block's indices at once (five 8-byte reads in flight), then ten pairs from registers
-        const uint2* const b2 = reinterpret_cast<const uint2*>(buf) + lane;
         uint2 XX[5];
+#if X3S_SWP
+#pragma unroll
+        for (uint32_t r = 0; r < 5u; ++r) XX[r] = make_uint2(buf[(2u * r) * 64u + lane], buf[(2u * r + 1u) * 64u + lane]);
+#else
+        const uint2* const b2 = reinterpret_cast<const uint2*>(buf) + lane;
 #pragma unroll
         for (uint32_t r = 0; r < 5u; ++r) XX[r] = b2[r * 64u];
+#endif
 #if X3S_VALUER_FOLD
         // Round 4: the Rice / BFP choice is in the CONSTANTS, not in a select behind both computations.  A Rice lane's
         // thresh is 0 (B = X - ((X + 0xFFFF) & 0) = X: the BFP step is the identity there); a BFP lane shifts by 0 and
@@ -750,7 +998,11 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
             uint32_t W[2];
 #pragma unroll
             for (uint32_t e = 0; e < 2; ++e) {
+#if X3S_THIN
+              const uint32_t X = x3s_fields(e ? XX[r].y : XX[r].x, zmask, t_nwidth, t_fw, t_lsh);
+#else
               const uint32_t X = e ? XX[r].y : XX[r].x;
+#endif
               maxii2 = x3_pk_max_u16(maxii2, X);   // (Rice: X = i, the index into the inverse table, decoder.rs:186)
               // BFP: unsigned_to_i16 (decoder.rs:198-207): v - (v > thresh ? 2*thresh : 0), strict compare.
               // v < 2^E and thresh = 2^(E-1), so bit E of v + thresh - 1 says v > thresh.
@@ -775,7 +1027,11 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
           uint32_t W[2];
 #pragma unroll
           for (uint32_t e = 0; e < 2; ++e) {
+#if X3S_THIN
+            const uint32_t X = x3s_fields(e ? XX[r].y : XX[r].x, zmask, t_nwidth, t_fw, t_lsh);
+#else
             const uint32_t X = e ? XX[r].y : XX[r].x;
+#endif
             // Rice: X = i, the index into the inverse table (decoder.rs:186), which is a zigzag (x3.rs:200-204)
             maxii2 = x3_pk_max_u16(maxii2, X);
             const uint32_t R = x3_pk_lshr_b16_1(X) ^ x3_pk_sub_u16(0u, X & 0x00010001u);
@@ -821,27 +1077,36 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
         alive = false;
       }
       const bool finished = cnt && remaining == 0;  // this lane's frame is complete
-      if (finished && alive && (samples & 1u))      // its last sample is a pending one: stage it
+      if (finished && alive && (samples & 1u) && !mid)      // its last sample is a pending one: stage it
         x3_lds_write_u16(x3_and_or(pos0 + 2u * (samples - 1u), 254u, orow_b), prevP >> 16);
+      // (the last sample of a stretch that ends inside the frame is the next stretch's first: not written, compared)
+      if (finished && mid && (prevP >> 16) != (exp_pred ^ X3S_SEG_VALID)) seg_bad = true;
       X3_STAMP(1);
       if (!alive) s_dead[lane] = 1u;  // (visible to the flusher behind the next barrier)
       // (the flusher moves whole 16-byte pieces.)  The ragged end of a frame, fewer than eight samples:
       if (!regular && finished && alive)
-        for (uint32_t sx = samples & (p8 ? ~3u : ~7u); sx < samples; ++sx)
+        for (uint32_t sx = rowlen & (p8 ? ~3u : ~7u); sx < rowlen; ++sx)
           o[sx] = (int16_t)x3_lds_read_u16(x3_and_or(pos0 + 2u * sx, 254u, orow_b), 0u);
       X3_STAMP(5);
     }
     X3S_BARRIER();
-    if (active && (st == X3D_OUT_OF_BOUNDS_INVERSE || st == X3D_FRAME_DECODE_INVALID_BPF || s_over[lane]))
+    if (active && (st == X3D_OUT_OF_BOUNDS_INVERSE || st == X3D_FRAME_DECODE_INVALID_BPF || s_over[lane] || seg_bad))
       st = X3D_REPLAY;  // the reference's reader decides (x3_decode_replay.h; x3_decode_merge_kernel)
-    if (f < n_frames) status[f] = st;
-    if (lane == 0 && nblk_max >= 64u) {  // this group's pace, for the next launch
+    if (f < n_frames) {
+      // (stretches: the host has cleared the array, the stretches of a frame are in different workgroups; X3D_REPLAY is the
+      // largest status, and a frame's other statuses -- its header's -- are the same in all of its stretches)
+      if (!seg_grid) status[f] = st;
+      else if (st != X3D_OK) atomicMax(&status[f], st);
+    }
+    if (lane == 0 && (nblk_max >= 64u || (segd && nblk_max))) {  // this group's pace, for the next launch
       uint64_t t16 = ((wall_clock64() - pace_t0) * 16u) / nblk_max;
       if (t16 >= (1u << X3S_PACE_EPOCH_SHIFT)) t16 = (1u << X3S_PACE_EPOCH_SHIFT) - 1u;
-      atomicMax(pace + (pace_epoch & 1u), ((pace_epoch & 0xFFFu) << X3S_PACE_EPOCH_SHIFT) | (uint32_t)t16);
-      if (blockIdx.x == 0) {
-        pace[2u + (pace_epoch & 1u)] = ((pace_epoch & 0xFFFu) << X3S_PACE_EPOCH_SHIFT) | pace_target;
-        pace[8u + (pace_epoch & 1u)] = ((pace_epoch & 0xFFFu) << X3S_PACE_EPOCH_SHIFT) | (gridDim.x & ((1u << X3S_PACE_EPOCH_SHIFT) - 1u));
+      if (!segd) {   // (launches by stretches are not paced and leave no pace behind)
+        atomicMax(pace + (pace_epoch & 1u), ((pace_epoch & 0xFFFu) << X3S_PACE_EPOCH_SHIFT) | (uint32_t)t16);
+        if (blockIdx.x == 0) {
+          pace[2u + (pace_epoch & 1u)] = ((pace_epoch & 0xFFFu) << X3S_PACE_EPOCH_SHIFT) | pace_target;
+          pace[8u + (pace_epoch & 1u)] = ((pace_epoch & 0xFFFu) << X3S_PACE_EPOCH_SHIFT) | (gridDim.x & ((1u << X3S_PACE_EPOCH_SHIFT) - 1u));
+        }
       }
       // The launch log (x3_ctx_launch_log; bench.py's per-step list): what this launch aimed at, what its slowest group
       // achieved, and the shader clock it ran at -- group 0's shader ticks against the 100 MHz clock over its whole

@@ -87,6 +87,11 @@ int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3
     d_off = (uint64_t*)c->frame_off.p;
   }
   HIPCHK(c, hipMemsetAsync(c->d_status, 0, 128, c->stream));
+  // the segment index of this call (x3_encode_dev_seg): only the wave encoder fills it; every other path leaves a header
+  // that says "no index" (the decoder then takes whole frames per lane)
+  const X3SegSpec seg = c->enc_seg;
+  c->enc_seg = X3SegSpec{nullptr, 0, 0};
+  if (seg.d_index) HIPCHK(c, hipMemsetAsync(seg.d_index, 0, sizeof(uint64_t), c->stream));
   // ---- single-pass path: default block length, frames on dword boundaries (buffer loads)
   const bool stream_path = p->block_len == 20 && (std::min<uint64_t>(spf, b->n_per_clip) + 18) / 20 <= 512 &&
                            (spf % X3_ENC_FRAME_ALIGN) == 0 &&
@@ -153,6 +158,18 @@ int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3
       wa.thr2 = pl.dp.thr[2];
       wa.kpack = pl.dp.k[0] | (pl.dp.k[1] << 8) | (pl.dp.k[2] << 16);
       wa.drop_wgi = c->opt.wave_drop >= 0 ? (uint32_t)c->opt.wave_drop : 0xFFFFFFFFu;
+      wa.seg = nullptr;
+      wa.seg_log2 = 0;
+      wa.seg_pitch = 0;
+      if (seg.d_index && seg.seg_blocks >= 4 && (seg.seg_blocks & (seg.seg_blocks - 1)) == 0) {
+        const uint64_t bpf = (std::min<uint64_t>(spf, b->n_per_clip) + 18) / 20;   // blocks of the longest frame (<= 512 here)
+        const uint64_t nidx = (bpf + seg.seg_blocks - 1) / seg.seg_blocks;
+        if (nidx >= 2 && !tab) {
+          wa.seg = reinterpret_cast<uint2*>(seg.d_index);
+          wa.seg_log2 = (uint32_t)__builtin_ctz(seg.seg_blocks);
+          wa.seg_pitch = (uint32_t)(nidx - 1);
+        }
+      }
       {
         TimerScope ts(c, 0, nullptr, true);
         if (wa.src_off) X3_LAUNCH_TIMED(ts, x3_encode_wave_kernel<true>, dim3(wa.nwg), dim3(X3W_THREADS), X3W_SMEM, c->stream, wa);
@@ -305,6 +322,21 @@ extern "C" int x3_encode_dev(x3_ctx* c, const int16_t* d_wav, const x3_batch* ba
   if (batch->n_per_clip == 0 || batch->n_clips == 0) return X3_ERR_BAD_ARG;
   if (batch->n_clips > 1 && batch->clip_stride < batch->n_per_clip) return X3_ERR_BAD_ARG;
   HIPCHK(c, hipSetDevice(c->device));
+  return encode_dev_impl(c, d_wav, batch, p, spf_of(p), d_out, out_cap, start_pos, d_frame_offsets);
+}
+
+// x3_encode_dev that also leaves the SEGMENT INDEX of the stream (include/x3hip.h): the encoder's prefix scan over the
+// blocks' bit lengths knows where every block begins, its input knows the sample in front of it
+extern "C" int x3_encode_dev_seg(x3_ctx* c, const int16_t* d_wav, const x3_batch* batch, const x3_params* p,
+                                 uint8_t* d_out, uint64_t out_cap, uint64_t start_pos, uint64_t* d_frame_offsets,
+                                 uint64_t* d_seg_index, uint32_t seg_blocks) {
+  if (!c || !d_wav || !batch || !p || !d_out) return X3_ERR_BAD_ARG;
+  if (batch->n_per_clip == 0 || batch->n_clips == 0) return X3_ERR_BAD_ARG;
+  if (batch->n_clips > 1 && batch->clip_stride < batch->n_per_clip) return X3_ERR_BAD_ARG;
+  if (d_seg_index && (seg_blocks < 4 || (seg_blocks & (seg_blocks - 1)) || seg_blocks > 2048 || (reinterpret_cast<uintptr_t>(d_seg_index) & 7u)))
+    return X3_ERR_BAD_ARG;   // (the encoder's entries fall on its lanes' block runs: a power of two >= 4)
+  HIPCHK(c, hipSetDevice(c->device));
+  c->enc_seg = X3SegSpec{d_seg_index, seg_blocks, d_seg_index ? 2 : 0};
   return encode_dev_impl(c, d_wav, batch, p, spf_of(p), d_out, out_cap, start_pos, d_frame_offsets);
 }
 

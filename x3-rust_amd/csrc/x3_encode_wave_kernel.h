@@ -103,6 +103,11 @@ struct X3WaveArgs {
   const uint32_t* src_n;
   uint32_t thr0, thr1, thr2, kpack;
   uint32_t drop_wgi;        // tests: the generation whose total is never published (a workgroup that is not resident); ~0: none
+  // the segment index (x3_decode_split_kernel.h, "STRETCHES"; include/x3hip.h): where every 2^seg_log2 -th block of a frame
+  // begins in its payload and the sample in front of it -- the prefix scan below has the one, the input is the other
+  uint2* seg;               // nullptr: none asked for
+  uint32_t seg_log2;        // blocks per entry = 1 << seg_log2 (>= 4)
+  uint32_t seg_pitch;       // entries per frame
 };
 
 __device__ __forceinline__ uint32_t x3_pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) {
@@ -342,6 +347,7 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
   if (tid < X3W_BOOK_BYTES / 4u) book[tid] = 0;
   for (uint32_t i = lane; i < X3W_IMG_BYTES / 16u; i += 64u) reinterpret_cast<uint4*>(img)[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
+  if (a.seg && blockIdx.x == 0 && tid == 0) a.seg[0] = make_uint2(0x58335347u, 1u << a.seg_log2);   // the index's header word
   if (w >= a.m) return;  // (whole waves; nothing below is a workgroup barrier)
 
   const uint32_t b = blockIdx.x;
@@ -735,6 +741,21 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
         tot1 = (uint32_t)__builtin_amdgcn_readlane((int)incl1, 63);
         excl0 = incl0 - nb0;
         excl1 = incl1 - nb1;
+      }
+      if (a.seg) {
+        // a lane's first block of half h is block 256 h + 4 lane of the frame; it begins 16 + (tot0 if h) + excl bits into the
+        // payload.  Entry k (1 .. pitch) is for block k << seg_log2; blocks the frame does not have get no entry (zero).
+        const uint32_t nbf = (n - 1u + 19u) / 20u, msk = (1u << a.seg_log2) - 1u;
+        uint2* const row = a.seg + 1 + f * (uint64_t)a.seg_pitch - 1;   // (entry k at row[k])
+#pragma unroll
+        for (uint32_t h = 0; h < 2u; ++h) {
+          const uint32_t bk = 256u * h + 4u * lane, k = bk >> a.seg_log2;
+          if (bk && (bk & msk) == 0u && k <= a.seg_pitch) {
+            uint2 e = make_uint2(0u, 0u);
+            if (bk < nbf) e = make_uint2(16u + (h ? tot0 + excl1 : excl0), (uint32_t)(uint16_t)src[20u * bk] | 0x10000u);
+            row[k] = e;
+          }
+        }
       }
       const uint32_t bits = 16u + tot0 + tot1;                 // <Audio State> + blocks (encoder.rs:189-200)
       const uint32_t L = (((bits + 7u) >> 3) + 1u) & ~1u;      // word_align (bitpacker.rs:124-132)

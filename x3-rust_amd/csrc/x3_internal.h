@@ -72,12 +72,18 @@ struct X3Opts {
   // profiling builds only (-DX3_PROFILING): never in the shipped library
   int check_serial = 0;       // X3HIP_CHECK_SERIAL: the check pass in front of the decoder, same stream
   int no_check = 0;           // X3HIP_PROFILE_NO_CHECK: time the decoder alone (payload CRCs NOT verified)
-  int dyn_lds = 0;            // X3HIP_DECODE_DYN_LDS: extra LDS per decoder group (occupancy experiments)
 #endif
+  int seg_stretches = 0;      // x3_decode_dev_seg: stretches per frame (0 = as many as fill the chip; 1 = never by stretches)
+  int dyn_lds = 0;            // X3HIP_DECODE_DYN_LDS: extra LDS per decoder group = fewer groups per CU (occupancy experiments)
 };
+
+// the segment index of a call (x3_decode_split_kernel.h, "STRETCHES"): mode 1 = decode by it, 2 = record it
+struct X3SegSpec { uint64_t* d_index; uint32_t seg_blocks; int mode; };
 
 struct x3_ctx {
   X3Opts opt;
+  X3SegSpec enc_seg{nullptr, 0, 0};         // x3_encode_dev_seg -> encode_dev_impl: the index the next launch fills
+  int last_seg_stretches = 0;               // the last decode launch: stretches per frame (0: none given, -1: recorded)
   unsigned long long needed_pos = 0;        // the position a host-buffer encode that ran out of room would have reached
   unsigned long long encode_fallbacks = 0;  // launches of the single-pass encoder that timed out (two-pass re-run)
   int device = 0;
@@ -300,7 +306,7 @@ X3_INTERNAL int encode_host(x3_ctx* c, const int16_t* const* wavs, uint64_t n_pe
 X3_INTERNAL int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint64_t* d_frame_offsets,
                                 uint64_t F, const x3_batch* batch, const uint64_t* d_wav_offsets, const x3_params* p,
                                 int16_t* d_wav, uint64_t wav_cap, int32_t* d_status, bool wav_off_aligned = false,
-                                bool bl0 = false);
+                                bool bl0 = false, const X3SegSpec* seg = nullptr);
 X3_INTERNAL int decode_stream_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t len, uint64_t phantom, const x3_params* p,
                                        int16_t* d_wav, uint64_t wav_cap, DevBuf* own_out, uint64_t* n_out,
                                        uint64_t* frames_ok, uint64_t* frame_errors);

@@ -45,6 +45,7 @@ SYMBOLS = [
     "x3_reader_open", "x3_reader_open_mem", "x3_reader_spec", "x3_reader_next_frame", "x3_reader_frame_errors",
     "x3_reader_position", "x3_reader_close",
     "x3_encode_dev", "x3_encode_frames_dev", "x3_encode_result", "x3_decode_dev", "x3_decode_result", "x3_index_dev", "x3_decode_stream_dev",
+    "x3_seg_index_entries", "x3_decode_dev_seg", "x3_encode_dev_seg",
     "x3_synth", "x3_synth_dev", "x3_dev_alloc", "x3_dev_free", "x3_dev_upload", "x3_dev_download",
     "x3_shard_unique_id", "x3_shard_create", "x3_shard_destroy", "x3_shard_rank", "x3_shard_world",
     "x3_shard_frame_range", "x3_shard_sample_range", "x3_shard_offsets", "x3_shard_exchange_lengths",
@@ -174,6 +175,10 @@ def lib():
     L.x3_encode_result.argtypes = [vp, C.POINTER(u64), vp]
     L.x3_decode_dev.argtypes = [vp, vp, u64, vp, u64, C.POINTER(Batch), vp, PP, vp, u64, vp]
     L.x3_decode_result.argtypes = [vp, C.POINTER(u64), C.POINTER(i32), C.POINTER(u64)]
+    L.x3_encode_dev_seg.argtypes = [vp, vp, C.POINTER(Batch), PP, vp, u64, u64, vp, vp, u32]
+    L.x3_seg_index_entries.argtypes = [u64, PP, u32]
+    L.x3_seg_index_entries.restype = u64
+    L.x3_decode_dev_seg.argtypes = [vp, vp, u64, vp, u64, C.POINTER(Batch), vp, PP, vp, u64, vp, vp, u32, i32]
     L.x3_index_dev.argtypes = [vp, vp, u64, u64, vp, vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(i32)]
     L.x3_decode_stream_dev.argtypes = [vp, vp, u64, PP, vp, u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.x3_synth.argtypes = [i32, u64, u64, u64, vp]
@@ -667,6 +672,13 @@ class Context:
         return lib().x3_encode_dev(self._h, d_wav, C.byref(b), C.byref(params), d_out, out_cap, start_pos,
                                    d_frame_offsets)
 
+    def encode_dev_seg(self, d_wav, n_per_clip, params, d_out, out_cap, d_seg_index, seg_blocks, start_pos=0, d_frame_offsets=None,
+                       n_clips=1, clip_stride=None):
+        """x3_encode_dev_seg: encode and leave the segment index of the stream in d_seg_index"""
+        b = Batch(n_per_clip, n_per_clip if clip_stride is None else clip_stride, n_clips)
+        return lib().x3_encode_dev_seg(self._h, d_wav, C.byref(b), C.byref(params), d_out, out_cap, start_pos,
+                                       d_frame_offsets, d_seg_index, seg_blocks)
+
     def encode_frames_dev(self, d_wav, src_offsets, src_samples, params, d_out, out_cap, start_pos=0, d_frame_offsets=None):
         """x3_encode_frames_dev: frame f = src_samples[f] samples at d_wav + src_offsets[f] (host arrays)"""
         so = np.ascontiguousarray(src_offsets, dtype=np.uint64)
@@ -688,6 +700,15 @@ class Context:
             b = C.byref(Batch(n_per_clip, n_per_clip if clip_stride is None else clip_stride, n_clips))
         return lib().x3_decode_dev(self._h, d_x3, x3_len, d_frame_offsets, n_frames, b, d_wav_offsets,
                                    C.byref(params), d_wav, wav_cap, d_status)
+
+    def decode_dev_seg(self, d_x3, x3_len, d_frame_offsets, n_frames, params, d_wav, wav_cap, d_seg_index, seg_blocks,
+                       record=False, n_per_clip=None, n_clips=1, clip_stride=None, d_wav_offsets=None, d_status=None):
+        """x3_decode_dev_seg: decode by the segment index (record=False) or decode frame by frame and record it"""
+        b = None
+        if n_per_clip is not None:
+            b = C.byref(Batch(n_per_clip, n_per_clip if clip_stride is None else clip_stride, n_clips))
+        return lib().x3_decode_dev_seg(self._h, d_x3, x3_len, d_frame_offsets, n_frames, b, d_wav_offsets,
+                                       C.byref(params), d_wav, wav_cap, d_status, d_seg_index, seg_blocks, 1 if record else 0)
 
     def decode_result(self):
         fb, st, nb = C.c_uint64(0), C.c_int(0), C.c_uint64(0)
