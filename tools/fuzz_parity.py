@@ -8,7 +8,8 @@ Families: (e) the single-pass encoders on block_len 20 with mixed content, many 
           truncations and header damage; (b) batches of clips through the device API, of equal and of different lengths
           (x3_encode_frames_dev); (a) .x3a archives in memory and
           the incremental reader; (f) decode_frame frame by frame, with and without x3_decode_prefetch; (w) WAV and .x3a FILES through the
-          chunked pipeline (not in the default family set: file I/O)."""
+          chunked pipeline (not in the default family set: file I/O); (s) the segment index: the encoder's against the one a
+          decode records, decode by it with the stream and the index intact or damaged."""
 import argparse, ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "x3-rust_amd"))
@@ -459,6 +460,99 @@ def fam_m(rng, tag):
 fams = {"w": fam_w, "e": fam_e, "g": fam_g, "d": fam_d, "b": fam_b, "a": fam_a, "f": fam_f, "m": fam_m}
 
 
+def fam_s(rng, tag):
+    """the segment index (x3_encode_dev_seg / x3_decode_dev_seg): mixed content in frames of up to 512 blocks, one clip or a
+    batch; the encoder's index = the one a frame-by-frame decode records; decoding by it -- every entry, every second one, as
+    the library picks -- gives the oracle's samples, with the stream intact or damaged (CRCs refreshed or not) and with the
+    index intact, partly overwritten or random"""
+    L = x3hip.lib()
+    bpf = int(rng.choice([8, 16, 33, 64, 100, 128, 250, 256, 500, 501, 512]))
+    p = x3hip.Params.make(20, bpf)
+    spf = 20 * bpf
+    n_clips = int(rng.choice([1, 1, 1, 2, 5]))
+    n_per = spf * int(rng.integers(1, 6)) + int(rng.choice([0, 0, 1, 19, 20, 21, spf // 2, spf - 1]))
+    if n_clips > 1:
+        n_per = (n_per + 3) & ~3
+    sb = int(rng.choice([4, 8, 16, 32, 64, 128]))
+    wavs = [content(rng, n_per) for _ in range(n_clips)]
+    wav = np.concatenate(wavs)
+    n = wav.size
+    F = L.x3_num_frames(n_per, C.byref(p)) * n_clips
+    cap = L.x3_encode_bound(n_per, C.byref(p)) * n_clips
+    ne = max(1, L.x3_seg_index_entries(F, C.byref(p), sb))
+    d = [ctx.alloc(2 * n + 64), ctx.alloc(cap + 64), ctx.alloc(8 * (F + 1)), ctx.alloc(2 * n + 64), ctx.alloc(8 * ne + 8), ctx.alloc(8 * ne + 8)]
+    d_wav, d_out, d_off, d_back, d_seg, d_seg2 = d
+    try:
+        ctx.upload(d_wav, wav)
+        ctx.upload(d_seg, rng.integers(0, 1 << 62, ne, dtype=np.uint64))
+        assert ctx.encode_dev_seg(d_wav, n_per, p, d_out, cap, d_seg, sb, 0, d_off, n_clips=n_clips) == 0
+        rc, pos, _ = ctx.encode_result()
+        assert rc == 0, (tag, rc)
+        stream = ctx.download(d_out, pos)
+        ref = np.concatenate([O.encode(w, oparams(p))[1] for w in wavs])
+        assert np.array_equal(stream, ref), (tag, "stream")
+        nseg = (bpf + sb - 1) // sb
+        have_index = nseg >= 2 and ctx.get_option("enc_gen_in_use") == 3
+        if nseg >= 2:
+            assert ctx.decode_dev_seg(d_out, pos, d_off, F, p, d_back, n, d_seg2, sb, record=True, n_per_clip=n_per, n_clips=n_clips) == 0
+            assert ctx.decode_result() == (0, F, 0, n), (tag, "record")
+            if have_index:
+                a, b = ctx.download(d_seg, 8 * ne, np.uint64), ctx.download(d_seg2, 8 * ne, np.uint64)
+                assert np.array_equal(a, b), (tag, "index", np.flatnonzero(a != b)[:8].tolist())
+        # damage: the stream, the index, both, neither
+        offs = frame_offsets(stream)
+        bad = stream
+        if rng.random() < 0.6:
+            # payload damage only (the device API places frames by the layout, the oracle's walk by the headers it reads:
+            # the two agree as long as the headers do), CRCs refreshed or not
+            bad = stream.copy()
+            for _ in range(int(rng.integers(1, 4))):
+                off = offs[int(rng.integers(0, len(offs)))]
+                plen = int(stream[off + 6]) << 8 | int(stream[off + 7])
+                if plen <= 2:
+                    continue
+                q = off + 20 + int(rng.integers(2, plen))
+                k = min(int(rng.integers(1, 10)), off + 20 + plen - q)
+                kind = int(rng.integers(0, 4))
+                if kind == 0: bad[q] ^= np.uint8(1 << int(rng.integers(0, 8)))
+                elif kind == 1: bad[q:q + k] = 0
+                elif kind == 2: bad[q:q + k] = rng.integers(0, 256, size=k, dtype=np.uint8)
+                else: bad[q:q + k] = 0xFF
+                if rng.random() < 0.7:
+                    refresh_crcs(bad, off)
+        idx = ctx.download(d_seg2 if nseg >= 2 else d_seg, 8 * ne, np.uint64)
+        r = rng.random()
+        if r < 0.25 and ne > 1:
+            k = int(rng.integers(1, ne)); idx[k] ^= np.uint64(1) << np.uint64(int(rng.integers(0, 49)))
+        elif r < 0.4 and ne > 1:
+            sel = rng.random(ne) < 0.2; sel[0] = False
+            idx[sel] = rng.integers(0, 1 << 49, int(sel.sum()), dtype=np.uint64)
+        elif r < 0.45:
+            idx[0] = 0
+        ctx.upload(d_out, bad); ctx.upload(d_seg, idx)
+        # the oracle's walk over the same frames (frame f's bytes at offs[f]; a bad frame stops it)
+        want = O.decode_stream(bad, oparams(p), wav_cap=n + 70000)
+        for want_st in (0, nseg, 2):
+            ctx.set_option("seg_stretches", want_st)
+            ctx.upload(d_back, np.zeros(n, dtype=np.int16))
+            assert ctx.decode_dev_seg(d_out, pos, d_off, F, p, d_back, n, d_seg, sb, n_per_clip=n_per, n_clips=n_clips) == 0
+            rc_d, first_bad, st, before = ctx.decode_result()
+            if n_clips == 1:
+                assert rc_d == 0 and first_bad == want[2] and before == want[1].size, (tag, want_st, first_bad, st, before, want[2], want[1].size)
+                assert np.array_equal(ctx.download(d_back, 2 * before, np.int16), want[1]), (tag, want_st, "samples")
+            else:   # (a batch: the oracle's walk knows nothing about clips; intact streams only)
+                if bad is stream:
+                    assert (rc_d, first_bad, st, before) == (0, F, 0, n), (tag, want_st)
+                    assert np.array_equal(ctx.download(d_back, 2 * n, np.int16), wav), (tag, want_st, "samples")
+    finally:
+        ctx.set_option("seg_stretches", 0)
+        for q in d:
+            ctx.free(q)
+
+
+fams["s"] = fam_s
+
+
 def run(seed=1, minutes=None, trials=None, families="egdbaf", only=-1, context=None):
     """draw and check cases until the time or the trial budget is used up -> {family: trials}"""
     global ctx
@@ -487,7 +581,7 @@ def run(seed=1, minutes=None, trials=None, families="egdbaf", only=-1, context=N
             ctx.close()
         else:  # a borrowed context goes back with the options the families touch at their defaults
             for name, value in (("reader_window_frames", 4096), ("enc_gen", 3), ("host_walk", -1), ("host_chunk_frames", 0), ("index_no_fast", 0),
-                                ("file_chunk_frames", 800), ("file_workers", 4)):
+                                ("file_chunk_frames", 800), ("file_workers", 4), ("seg_stretches", 0)):
                 ctx.set_option(name, value)
         ctx = None
     return counts

@@ -68,6 +68,15 @@
 #ifndef X3S_THIN
 #define X3S_THIN 0
 #endif
+// TIMING experiments on top of X3S_THIN (results are wrong): the valuer converts only the first X3S_THIN_K of a block's ten
+// pairs from peeks to indices (as if another wave had converted the others in place); X3S_THIN_F: the flusher executes
+// the conversion's instructions and LDS traffic for the other 10 - K on dummy data
+#ifndef X3S_THIN_K
+#define X3S_THIN_K 10
+#endif
+#ifndef X3S_THIN_F
+#define X3S_THIN_F 0
+#endif
 // Round 5: the parser's pair loop SOFTWARE-PIPELINED, one asm block per block of ten pairs.  A lone wave issues an
 // instruction every ~4.3 clocks when it does not depend on the one before and every ~8.5 when it does
 // (tools/ubench/issue_cost.hip), and in the loop as the compiler laid it out (peek, ffbh, mad, shift, ffbh, mad, add3,
@@ -78,7 +87,7 @@
 // a half to arrive (tools/ubench/pair_cost.hip: 139 -> ~100 clocks per pair for one wave on its SIMD).  Nothing that the
 // asm block reads asynchronously is left pending in a register the compiler knows: the block ends with the window settled.
 #ifndef X3S_SWP
-#define X3S_SWP 1
+#define X3S_SWP 0
 #endif
 #if X3S_SWP && X3S_THIN
 #error "X3S_THIN is an option of the compiler-scheduled pair loop (X3S_SWP=0)"
@@ -661,6 +670,22 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
         }
       }
       if (!regular && b) flush_rows();
+#if X3S_THIN && X3S_THIN_F
+      {   // TIMING ONLY: what converting 10 - K pairs of the block in place would cost this wave
+        const uint32_t* const tb = xfer + ((b + 1u) & 1u) * (X3S_XROWS * 64u);
+        uint32_t dz = lane, dn = 0u - 2u, dfw = 1u, dl = 1u, acc = 0;
+#pragma unroll
+        for (uint32_t q = X3S_THIN_K; q < 10u; ++q) {
+          const uint32_t t = tb[(q >> 1) * 128u + 2u * lane + (q & 1u)];
+          uint32_t z1, z2, v1, v2, t2, nn1, nn2;
+          asm volatile("v_ffbh_u32 %0, %7\n\tv_mad_i32_i24 %4, %0, %8, %9\n\tv_alignbit_b32 %6, %7, 0, %4\n\tv_bfe_u32 %1, %7, %4, %10\n\t"
+              "v_ffbh_u32 %2, %6\n\tv_mad_i32_i24 %5, %2, %8, %9\n\tv_bfe_u32 %3, %6, %5, %10"
+              : "=&v"(z1), "=&v"(v1), "=&v"(z2), "=&v"(v2), "=&v"(nn1), "=&v"(nn2), "=&v"(t2) : "v"(t), "v"(dz), "v"(dn), "v"(dfw));
+          acc = x3_pack_lo16((z1 << dl) + v1, (z2 << dl) + v2);
+          s_prm[(q & 3u) * 64u + lane] = acc;     // (a write of the same size, somewhere harmless)
+        }
+      }
+#endif
       const uint32_t cnt = rem < X3S_BL ? rem : X3S_BL;
       rem -= cnt;
       have = 1u + X3S_BL * b + cnt - ((cnt && rem == 0u) ? 0u : 1u);  // staged once the valuer is through block b
@@ -999,7 +1024,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
 #pragma unroll
             for (uint32_t e = 0; e < 2; ++e) {
 #if X3S_THIN
-              const uint32_t X = x3s_fields(e ? XX[r].y : XX[r].x, zmask, t_nwidth, t_fw, t_lsh);
+              const uint32_t X = (2u * r + e < X3S_THIN_K) ? x3s_fields(e ? XX[r].y : XX[r].x, zmask, t_nwidth, t_fw, t_lsh) : (e ? XX[r].y : XX[r].x);
 #else
               const uint32_t X = e ? XX[r].y : XX[r].x;
 #endif
@@ -1028,7 +1053,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
 #pragma unroll
           for (uint32_t e = 0; e < 2; ++e) {
 #if X3S_THIN
-            const uint32_t X = x3s_fields(e ? XX[r].y : XX[r].x, zmask, t_nwidth, t_fw, t_lsh);
+            const uint32_t X = (2u * r + e < X3S_THIN_K) ? x3s_fields(e ? XX[r].y : XX[r].x, zmask, t_nwidth, t_fw, t_lsh) : (e ? XX[r].y : XX[r].x);
 #else
             const uint32_t X = e ? XX[r].y : XX[r].x;
 #endif
