@@ -112,7 +112,9 @@ const char* x3_last_error(const x3_ctx* ctx);
  *   "wav_offsets_x4"                       1: a promise -- every d_wav_offsets[] passed to x3_decode_dev is a multiple of
  *                                          four samples (rows on 8-byte boundaries): such calls then take the three-wave
  *                                          decoder like the other layouts do; an offset that breaks the promise garbles
- *                                          its frame's samples (nothing outside the frame's range is written)
+ *                                          its frame's samples AND may clobber up to three samples in front of the frame's
+ *                                          range (the rows leave in whole 8-byte pieces from the piece their first sample
+ *                                          lies in): the promise is the caller's to keep
  *   "host_walk" (X3HIP_HOST_WALK)          frame walk of x3_decode_stream: 1 host, 0 GPU, -1 by stream size
  *   "host_chunk_frames" (X3HIP_HOST_CHUNK_FRAMES)  x3_encode and x3_decode_stream take a long host buffer in chunks of whole
  *                                           frames, downloads beside uploads: 0 = on (x3_encode from 32 Mi samples in chunks of

@@ -806,7 +806,9 @@ int x3o_archive_header_write(uint32_t sample_rate, const x3o_params* p, uint8_t*
   return X3O_OK;
 }
 
-static int xml_first_text(const char* xml, size_t len, const char* name, char* text, size_t cap) {
+/* -> the trimmed text of the first <NAME ...>text</NAME> element as (pointer into xml, length): the text may hold any
+ * byte, NUL included (a Rust &str does), and is as long as the payload lets it be */
+static int xml_first_text(const char* xml, size_t len, const char* name, const char** text, size_t* tlen) {
   size_t nl = strlen(name);
   for (size_t i = 0; i + nl + 1 < len; i++) {
     if (xml[i] != '<' || memcmp(xml + i + 1, name, nl) != 0) continue;
@@ -818,11 +820,10 @@ static int xml_first_text(const char* xml, size_t len, const char* name, char* t
     for (size_t c = gt + 1; c + nl + 3 <= len; c++) {
       if (xml[c] == '<' && xml[c + 1] == '/' && memcmp(xml + c + 2, name, nl) == 0 && xml[c + 2 + nl] == '>') {
         size_t a = gt + 1, b = c;
-        while (a < b && strchr(" \t\r\n", xml[a])) a++;
-        while (b > a && strchr(" \t\r\n", xml[b - 1])) b--;
-        if (b - a + 1 > cap) return 0;
-        memcpy(text, xml + a, b - a);
-        text[b - a] = 0;
+        while (a < b && (xml[a] == ' ' || xml[a] == '\t' || xml[a] == '\r' || xml[a] == '\n')) a++;
+        while (b > a && (xml[b - 1] == ' ' || xml[b - 1] == '\t' || xml[b - 1] == '\r' || xml[b - 1] == '\n')) b--;
+        *text = xml + a;
+        *tlen = b - a;
         return 1;
       }
     }
@@ -857,27 +858,28 @@ int x3o_archive_header_read(const uint8_t* bytes, uint64_t len, uint32_t* sample
   if (rc) return rc;
   if (len - 28 < h.payload_len) return X3O_IO;
   const char* xml = (const char*)bytes + 28;
-  char fs[64], bl[64], codes[128], th[128];
-  if (!xml_first_text(xml, h.payload_len, "FS", fs, sizeof fs) ||
-      !xml_first_text(xml, h.payload_len, "BLKLEN", bl, sizeof bl) ||
-      !xml_first_text(xml, h.payload_len, "CODES", codes, sizeof codes) ||
-      !xml_first_text(xml, h.payload_len, "T", th, sizeof th))
+  const char *fs, *bl, *codes, *th;
+  size_t fsl, bll, codesl, thl;
+  if (!xml_first_text(xml, h.payload_len, "FS", &fs, &fsl) ||
+      !xml_first_text(xml, h.payload_len, "BLKLEN", &bl, &bll) ||
+      !xml_first_text(xml, h.payload_len, "CODES", &codes, &codesl) ||
+      !xml_first_text(xml, h.payload_len, "T", &th, &thl))
     return X3O_BAD_ARG; /* fs[0] etc. index panic */
   uint32_t rate, block_len;
-  if (!parse_u32(fs, strlen(fs), &rate) || !parse_u32(bl, strlen(bl), &block_len)) return X3O_BAD_ARG;
+  if (!parse_u32(fs, fsl, &rate) || !parse_u32(bl, bll, &block_len)) return X3O_BAD_ARG;
   uint32_t ids[16], ths[16];
   size_t nid = 0, nth = 0;
-  for (const char* w = codes;;) {
-    const char* e = strchr(w, ',');
-    size_t wl = e ? (size_t)(e - w) : strlen(w);
+  for (const char *w = codes, *end = codes + codesl;;) {   /* str::split(','): the words between the commas, all of them */
+    const char* e = (const char*)memchr(w, ',', (size_t)(end - w));
+    size_t wl = e ? (size_t)(e - w) : (size_t)(end - w);
     if (wl == 5 && !memcmp(w, "RICE", 4) && w[4] >= '0' && w[4] <= '3') { if (nid < 16) ids[nid++] = (uint32_t)(w[4] - '0'); }
     else if (!(wl == 3 && !memcmp(w, "BFP", 3))) return X3O_ARCHIVE_HEADER_XML_RICE_CODE;
     if (!e) break;
     w = e + 1;
   }
-  for (const char* w = th;;) {
-    const char* e = strchr(w, ',');
-    size_t wl = e ? (size_t)(e - w) : strlen(w);
+  for (const char *w = th, *end = th + thl;;) {
+    const char* e = (const char*)memchr(w, ',', (size_t)(end - w));
+    size_t wl = e ? (size_t)(e - w) : (size_t)(end - w);
     uint32_t v;
     if (!parse_u32(w, wl, &v)) return X3O_BAD_ARG;
     if (nth < 16) ths[nth++] = v;

@@ -77,7 +77,14 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
   // X3HIP_SPIN_WAIT=1: the process's waits for the GPU spin instead of sleeping (hipDeviceScheduleSpin; process-wide, and
   // only when this is the process's first use of the device): calls that end with a trip to the host -- x3_*_result,
   // x3_decode_stream_dev -- come back a few microseconds sooner, at the price of a busy core while they wait
-  if (std::getenv("X3HIP_SPIN_WAIT")) (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
+  // (the value is parsed like every other X3HIP_* option: "0" and "" leave the default; a refusal -- the device is already
+  // in use with other flags -- is cleared, so that it does not surface as the error of the next kernel launch)
+  if (const char* sw = std::getenv("X3HIP_SPIN_WAIT"); sw && std::atoi(sw) != 0) {
+    if (hipSetDeviceFlags(hipDeviceScheduleSpin) != hipSuccess) {
+      (void)hipGetLastError();
+      if (c->opt.verbose) std::fprintf(stderr, "x3hip: X3HIP_SPIN_WAIT: hipSetDeviceFlags(hipDeviceScheduleSpin) refused\n");
+    }
+  }
   {
     hipDeviceProp_t prop;
     HIPCHK(c, hipGetDeviceProperties(&prop, device));

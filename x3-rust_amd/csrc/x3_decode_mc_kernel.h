@@ -131,6 +131,9 @@ x3_decode_mc_lanes_kernel(const uint8_t* __restrict__ x3, const uint64_t* __rest
     }
     slot16[((c * 64u + lane) << 3) + (i & 7u)] = (uint16_t)v;
     if ((i & 7u) == 7u) {        // the slot is complete: one 16-byte store (a wave's DS instructions execute in order)
+      // (the halfword stores above and this vector load alias through different types: keep the compiler from moving
+      // the load above the last store -- ADVICE r4)
+      X3_WAVE_LDS_ORDER();
       const uint4 q = *reinterpret_cast<const uint4*>(slot + ((c * 64u + lane) << 2));
       const x3_u32x4 vv = {q.x, q.y, q.z, q.w};
       x3_store_stream16(o + (i & ~7u), vv);

@@ -165,3 +165,15 @@ extern "C" int x3_x3a_decode(x3_ctx* c, const uint8_t* x3a, uint64_t len, int16_
 
 #include "x3_file_pipeline.h"
 #include "x3_reader.h"
+
+int x3_wav_parse_fd_for_tests(int fd, uint64_t file_len, uint32_t* sample_rate, uint16_t* channels, uint16_t* bits,
+                              uint64_t* data_off, uint64_t* data_len) {
+  WavInfo wi;
+  const int rc = wav_parse_fd(fd, file_len, &wi);
+  if (sample_rate) *sample_rate = wi.sample_rate;
+  if (channels) *channels = wi.channels;
+  if (bits) *bits = wi.bits;
+  if (data_off) *data_off = wi.data_off;
+  if (data_len) *data_len = wi.data_len;
+  return rc;
+}

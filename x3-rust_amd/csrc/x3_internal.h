@@ -321,5 +321,8 @@ X3_INTERNAL int decode_frames_host(x3_ctx* c, const uint8_t* x3, uint64_t len, c
                                    const uint8_t* d_x3 = nullptr);  // the frames' bytes are on the device already
 X3_INTERNAL int walk_result(uint64_t F, uint64_t first_bad, int bad_status, int terminal, uint64_t* frame_errors);
 // ---- x3_files.hip (x3_reader.h)
+// the RIFF/WAVE header parser of x3_wav_to_x3a on an open file, for the sanitised host tests (tests/host_cpp/fuzz_host_parsers.cpp)
+X3_INTERNAL int x3_wav_parse_fd_for_tests(int fd, uint64_t file_len, uint32_t* sample_rate, uint16_t* channels, uint16_t* bits,
+                                          uint64_t* data_off, uint64_t* data_len);
 X3_INTERNAL int frame_cache_serve(x3_ctx* c, const uint8_t* payload, uint64_t len, const x3_params* p, uint64_t samples, int16_t* wav);
 X3_INTERNAL void reader_free_internal(struct x3_reader* r);   // (x3_ctx_destroy: the frame cache of x3_decode_prefetch)

@@ -136,8 +136,13 @@ extern "C" void x3_shard_sample_range(uint64_t n_samples, const x3_params* p, in
                                       uint64_t* count) {
   const uint64_t spf = p ? spf_of(p) : 0;
   uint64_t f0 = 0, fc = 0;
-  x3_shard_frame_range(spf ? (n_samples + spf - 1) / spf : 0, rank, world, &f0, &fc);
-  const uint64_t lo = f0 * spf, hi = std::min(n_samples, (f0 + fc) * spf);
+  // (frames without the sum n + spf - 1, which wraps for sample counts near 2^64; a rank behind the last frame starts at
+  // the end of the samples, so that the ranks' ranges tile [0, n_samples) whatever the arguments -- found by
+  // tests/host_cpp/fuzz_host_parsers.cpp)
+  const uint64_t F = spf ? n_samples / spf + (n_samples % spf != 0) : 0;
+  x3_shard_frame_range(F, rank, world, &f0, &fc);
+  const uint64_t lo = f0 >= F ? n_samples : f0 * spf;
+  const uint64_t hi = f0 + fc >= F ? n_samples : (f0 + fc) * spf;
   if (first) *first = lo;
   if (count) *count = hi > lo ? hi - lo : 0;
 }
