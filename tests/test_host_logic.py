@@ -142,8 +142,10 @@ def test_shard_arithmetic():
             got = [x3hip.shard_sample_range(n, p, r, world) for r in range(world)]
             for r, (lo, cnt) in enumerate(got):
                 f_lo, f_n = x3hip.shard_frame_range(F, r, world)
-                assert lo == f_lo * 10000 and cnt == max(0, min(n, (f_lo + f_n) * 10000) - lo)
+                # (a rank behind the last frame starts at the end of the samples: the ranges tile [0, n) for any arguments)
+                assert lo == min(n, f_lo * 10000) and cnt == max(0, min(n, (f_lo + f_n) * 10000) - lo)
             assert sum(c for _, c in got) == n
+            assert got[0][0] == 0 and all(got[r][0] + got[r][1] == got[r + 1][0] for r in range(world - 1))
     assert x3hip.shard_offsets([10, 0, 22, 4]) == [0, 10, 10, 32, 36]
 
 
