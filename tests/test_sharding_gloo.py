@@ -40,7 +40,7 @@ def _worker(rank, world, port, n, result_path, sharded=False):
         p = x3hip.Params.default()
         s_lo, s_n = x3hip.shard_sample_range(n, p, rank, world)          # x3_shard_sample_range
         f_lo, f_n = x3hip.shard_frame_range((n + p.spf - 1) // p.spf, rank, world)   # x3_shard_frame_range
-        assert s_lo == f_lo * p.spf and s_n == max(0, min(n, (f_lo + f_n) * p.spf) - s_lo)
+        assert s_lo == min(n, f_lo * p.spf) and s_n == max(0, min(n, (f_lo + f_n) * p.spf) - s_lo)
         wav = x3hip.synth(x3hip.SYNTH_HYDROPHONE, 77, s_lo, s_n)
         rc, sub, stats = O.encode(wav) if s_n else (0, np.zeros(0, dtype=np.uint8), None)
         assert rc == 0
