@@ -130,7 +130,7 @@ const char* x3_last_error(const x3_ctx* ctx);
  * x3_ctx_get_option also reads "encode_fallbacks" (launches of the single-pass encoder that timed out waiting for
  * a non-resident workgroup and were redone by the two-pass kernels), "stream_wgs_in_use", and "encode_pace" /
  * "decode_pace": what the slowest workgroup of the last encoder / decoder launch achieved, in 10 ns ticks per frame /
- * per 16 blocks -- the next launch paces its waves' priorities by it (x3_encode_stream2_kernel.h,
+ * in shader clocks per 16 blocks -- the next launch paces its waves' priorities by it (x3_encode_stream2_kernel.h,
  * x3_decode_split_kernel.h); reading them synchronizes.
  * Unknown name: X3_ERR_BAD_ARG. */
 int x3_ctx_set_option(x3_ctx* ctx, const char* name, long long value);

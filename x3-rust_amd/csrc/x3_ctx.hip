@@ -353,7 +353,7 @@ extern "C" int x3_ctx_get_option(const x3_ctx* c, const char* name, long long* v
   else if (n == "file_workers") *value = c->opt.file_workers;
   else if (n == "reader_window_frames") *value = c->opt.reader_window_frames;
   else if (n == "check_main") *value = c->opt.check_main;
-  else if (n == "decode_pace" || n == "encode_pace") {  // (read-only, syncs) the pace words: 10 ns ticks per 16 blocks / per frame
+  else if (n == "decode_pace" || n == "encode_pace") {  // (read-only, syncs) the pace words: the decoder's in shader clocks per 16 blocks, the encoder's in 10 ns ticks per frame
     uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
         hipMemcpy(w, c->d_pace, sizeof w, hipMemcpyDeviceToHost) != hipSuccess)
@@ -438,8 +438,10 @@ extern "C" int x3_ctx_launch_log(x3_ctx* c, int which, uint32_t* out, uint64_t c
     const uint32_t* e = &w[(size_t)(ep & (X3_LOG_ENTRIES - 1u)) * X3_LOG_WORDS];
     if ((e[0] >> 20) != ep || e[3] == 0) continue;   // (not this epoch's entry: never written, or older)
     if (n < cap_entries) {
-      out[4 * n + 0] = which ? e[1] & 0xFFFFFu : 0u;
-      out[4 * n + 1] = which ? e[0] & 0xFFFFFu : 0u;
+      // (the decoder's pace words are in shader clocks since round 5; the log hands out 10 ns ticks as before, converted
+      // with the clock the launch itself measured: e[2] shader clocks in e[3] ticks)
+      out[4 * n + 0] = which ? (uint32_t)((unsigned long long)(e[1] & 0xFFFFFu) * e[3] / std::max<uint32_t>(e[2], 1u)) : 0u;
+      out[4 * n + 1] = which ? (uint32_t)((unsigned long long)(e[0] & 0xFFFFFu) * e[3] / std::max<uint32_t>(e[2], 1u)) : 0u;
       out[4 * n + 2] = (uint32_t)((unsigned long long)e[2] * 100000ull / e[3]);   // shader ticks per 10 ns tick -> kHz
       out[4 * n + 3] = e[3];
     }

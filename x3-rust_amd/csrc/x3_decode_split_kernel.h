@@ -145,7 +145,7 @@ __device__ __forceinline__ uint32_t x3s_half_index(uint32_t j, uint32_t lane) {
 // lifetimes 555 / 650 / 680 / 740 us by quartile of blockIdx) and the kernel ends with the stragglers, 20 % behind
 // the mean.  Every 8 blocks a wave compares its block index with where the clock says it should be and sets its own
 // priority: ahead -> lower, behind -> higher.  The groups then finish within 3 % of each other: 0.76 -> 0.65 ms.
-// The target pace comes from the launch before: every group leaves (clock ticks per 16 blocks) in `pace` by
+// The target pace comes from the launch before: every group leaves (shader clocks per 16 blocks) in `pace` by
 // atomicMax, tagged with the launch's epoch, and the next launch sets its target by that and by what the last one aimed
 // at (below).  A target that does not fit (first launch of a context, other data) pins all waves at one priority: the
 // unpaced kernel, nothing worse.
@@ -153,8 +153,11 @@ __device__ __forceinline__ uint32_t x3s_half_index(uint32_t j, uint32_t lane) {
 #define X3S_PACE_OFF 0
 #endif
 #define X3S_PACE_BAND 6            // blocks ahead / behind that move a wave one priority level
-#define X3S_PACE_DEFAULT 2000u     // 10 ns ticks per 16 blocks when there is no launch to go by (1.25 us per block)
-#define X3S_PACE_EPOCH_SHIFT 20u   // pace word: epoch << 20 | ticks per 16 blocks
+// (Round 5: the pace is counted in SHADER clocks -- s_memtime -- not in 10 ns wall ticks: a box that is still ramping its
+// clock, or a launch that runs at 2.0 GHz instead of 2.4, does the same work per clock, and a target in wall time read that
+// as "behind" -- all waves at one priority, the controller backing off for launches on end: VERDICT r4, item 2)
+#define X3S_PACE_DEFAULT 48000u    // shader clocks per 16 blocks when there is no launch to go by (1.25 us per block at 2.4 GHz)
+#define X3S_PACE_EPOCH_SHIFT 20u   // pace word: epoch << 20 | shader clocks per 16 blocks
 // Priorities by ROLE (round 4).  The SIMD arbitrates by priority, then age (MI355X_MICROARCH.md, "Two waves per SIMD"):
 // with all three waves of a group paced over the same four levels the critical wave -- the parser, whose dependent
 // chain sets the group's time per block -- was never preferred over the valuer or flusher of another group on its SIMD.
@@ -196,8 +199,8 @@ __device__ __forceinline__ void x3s_set_priority(int32_t d) {
 }
 #define X3S_PACE_STEP(b, ROLE)                                                                 \
   if (paced && ((b) & 7u) == 0u) {                                                             \
-    const uint32_t el = (uint32_t)(wall_clock64() - pace_t0); /* 10 ns ticks */                \
-    const int32_t d = (int32_t)(b) - (int32_t)(((unsigned long long)el * pace_inv) >> 16); /* (64-bit: 80 ms of ticks times the rate pass 2^32) */ \
+    const unsigned long long el = (unsigned long long)(clock64() - pace_t0); /* shader clocks */ \
+    const int32_t d = (int32_t)(b) - (int32_t)((el * pace_inv) >> 24);                           \
     x3s_set_priority<ROLE>(d);                                                                 \
   }
 
@@ -265,10 +268,11 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   const uint64_t f = (uint64_t)(seg_grid ? blockIdx.x / sg.nseg : blockIdx.x) * 64 + lane;
   if (sg.out && blockIdx.x == 0 && threadIdx.x == 0) sg.out[0] = make_uint2(X3S_SEG_MAGIC, sg.sb);
   const bool paced = !X3S_PACE_OFF && !segd;   // (stretches: many short groups, dispatched as CUs fall free -- nothing to pace)
-  const unsigned long long pace_t0 = wall_clock64();
-  const unsigned long long clk_t0 = clock64();   // (shader clock: the launch log's clock measurement, below)
-  uint32_t pace_inv;        // blocks per tick, 16.16 fixed point
-  uint32_t pace_target;     // 10 ns ticks per 16 blocks that this launch aims at
+  const unsigned long long wall_t0 = wall_clock64();
+  const unsigned long long clk_t0 = clock64();   // (shader clock: the pace's clock, and the launch log's clock measurement, below)
+  const unsigned long long pace_t0 = clk_t0;
+  uint32_t pace_inv;        // blocks per shader clock, 8.24 fixed point
+  uint32_t pace_target;     // shader clocks per 16 blocks that this launch aims at
   {
     // pace[q], pace[2 + q], q = parity of the launch before: what the slowest group of that launch achieved (P) and what it
     // aimed at (T).  This launch writes the words of ITS parity, so that a group that is dispatched late -- a grid larger
@@ -300,7 +304,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       if (n_frames >= 2u && p.spf) {
         const unsigned long long span = frame_off[n_frames - 1u] - frame_off[0];
         const unsigned long long samples = (unsigned long long)(n_frames - 1u) * p.spf;
-        const unsigned long long t = 1684ull + (612ull * span) / samples;   // 10 ns ticks per 16 blocks
+        const unsigned long long t = 40416ull + (14688ull * span) / samples;   // shader clocks per 16 blocks (the fit above at 2.4 GHz)
         t16 = t > mask ? mask : (uint32_t)t;
       }
     }
@@ -312,10 +316,10 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       const uint32_t back = P - P / 22u, cap3 = T + T / 32u;
       t16 = r < 259u ? T - T / 24u : (r < 264u ? T - T / 64u : (r <= 272u ? T : (back < cap3 ? back : cap3)));
     }
-    if (t16 < 64u) t16 = 64u;
+    if (t16 < 1536u) t16 = 1536u;
     if (t16 > mask) t16 = mask;
     pace_target = t16;
-    pace_inv = (16u << 16) / t16;
+    pace_inv = (16u << 24) / t16;
   }
 #ifdef X3_DBG_STAMPS
   unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1124,7 +1128,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       else if (st != X3D_OK) atomicMax(&status[f], st);
     }
     if (lane == 0 && (nblk_max >= 64u || (segd && nblk_max))) {  // this group's pace, for the next launch
-      uint64_t t16 = ((wall_clock64() - pace_t0) * 16u) / nblk_max;
+      uint64_t t16 = ((unsigned long long)(clock64() - pace_t0) * 16u) / nblk_max;
       if (t16 >= (1u << X3S_PACE_EPOCH_SHIFT)) t16 = (1u << X3S_PACE_EPOCH_SHIFT) - 1u;
       if (!segd) {   // (launches by stretches are not paced and leave no pace behind)
         atomicMax(pace + (pace_epoch & 1u), ((pace_epoch & 0xFFFu) << X3S_PACE_EPOCH_SHIFT) | (uint32_t)t16);
@@ -1143,7 +1147,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       if (blockIdx.x == 0) {
         lg[1] = ((pace_epoch & 0xFFFu) << X3S_PACE_EPOCH_SHIFT) | pace_target;
         lg[2] = (uint32_t)(clock64() - clk_t0);
-        lg[3] = (uint32_t)(wall_clock64() - pace_t0);
+        lg[3] = (uint32_t)(wall_clock64() - wall_t0);
       }
     }
   }
