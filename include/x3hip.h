@@ -398,7 +398,8 @@ typedef struct x3_batch {
  * the general kernels, three to eight times slower ("GPU-path limits").
  *   Residency: the default-geometry encoder is a persistent grid whose workgroups wait for each other's frame
  * sizes; on a GPU that this context does not have to itself a launch can find them not all resident, gives up after a
- * bounded wait, and x3_encode_result() then re-encodes with the general kernels (option "encode_fallbacks" counts
+ * bounded wait (15-30 ms: a stall of that length per call on a GPU shared with another process's long kernels), and
+ * x3_encode_result() then re-encodes with the general kernels (option "encode_fallbacks" counts
  * these).  That re-run reads d_wav again and rewrites d_out[start_pos ..): d_wav and d_out must stay untouched until
  * x3_encode_result() has returned, and the stream is only trusted once it has returned X3_OK (launching x3_decode_dev
  * on the same context in between is fine -- same stream -- as long as its result is only used after that). */

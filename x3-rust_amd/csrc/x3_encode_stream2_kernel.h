@@ -223,7 +223,7 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
     bool timeout = false;
     while (__any(((v0 >> X3_DESC_BYTES_BITS) != epoch) || ((v1 >> X3_DESC_BYTES_BITS) != epoch))) {
       // give up after the bounded spin -- or as soon as ANY workgroup has (then the launch is lost anyway and
-      // every further wait would only add its own 0.1 s): the host re-encodes with the two-pass kernels
+      // every further wait would only add its own 15 ms): the host re-encodes with the two-pass kernels
       if (++spins > X3_SPIN_LIMIT ||
           __hip_atomic_load(&status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == X3D_SIZE_WAIT_TIMEOUT) {
         timeout = true;

@@ -59,7 +59,7 @@
 #ifndef X3W_SLEEP_DESC
 #define X3W_SLEEP_DESC 127
 #endif
-// bounded waits of about 0.2 s with those sleeps
+// bounded waits of about 25 ms with those sleeps
 #define X3W_SPINS_LDS (X3_SPIN_LIMIT << 2)
 #define X3W_SPINS_DESC (X3_SPIN_LIMIT >> 1)
 #ifndef X3W_SKIP_EMPTY_HALF
