@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Does the register allocator wait for a ring request right behind it?  (round 5: it did, when code next to the service
+lambda changed -- part of a request's destination registers was copied directly behind the load: 0.69 -> 0.75 ms.)
+Compiles x3_decode.hip to assembly (device only) and looks, in x3_decode_split_kernel, for an `s_waitcnt vmcnt(n)` within
+four instructions behind a run of global_load_dwordx4 that leaves fewer loads in flight than the run issued.
+   python tools/check_decoder_isa.py [-DFLAG ...]        -> prints the findings, exit 1 if any"""
+import os, re, subprocess, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+def kernel_asm(flags):
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "x.s")
+        subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+                        "-Wno-unused-function", "--cuda-device-only", "-S", "-o", out] + flags +
+                       [os.path.join(ROOT, "x3-rust_amd", "csrc", "x3_decode.hip")], check=True, capture_output=True)
+        lines = open(out).read().split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith("_Z22x3_decode_split_kernel") and l.rstrip().endswith(("kernelPKhmPKmm6X3GeomS2_11X3DevParamsPsmPiP11X3FrameMetaPjj9X3SegArgs", ":")) or (l.startswith("_Z22x3_decode_split_kernel") and ":" in l))
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    return [l.strip() for l in lines[start:end] if l.strip() and not l.strip().startswith(";") and not l.strip().endswith(":")]
+def findings(flags):
+    ins = kernel_asm(flags)
+    bad = []
+    i = 0
+    while i < len(ins):
+        if ins[i].startswith("global_load_dwordx4"):
+            j = i
+            run = 0
+            while j < len(ins) and (ins[j].startswith("global_load_dwordx4") or (run and not ins[j].startswith(("s_waitcnt", "ds_", "global_", "s_cbranch", "s_branch")) and j - i < run + 6 and any(x.startswith("global_load_dwordx4") for x in ins[j:j + 3]))):
+                run += ins[j].startswith("global_load_dwordx4")
+                j += 1
+            for k in range(j, min(j + 4, len(ins))):
+                m = re.match(r"s_waitcnt.*vmcnt\((\d+)\)", ins[k])
+                if m and int(m.group(1)) < run and run >= 2:
+                    bad.append((i, run, ins[k], ins[k + 1] if k + 1 < len(ins) else ""))
+                    break
+                if ins[k].startswith(("s_cbranch", "s_branch", "ds_", "global_")):
+                    break
+            i = j
+        else:
+            i += 1
+    return bad
+if __name__ == "__main__":
+    b = findings(sys.argv[1:])
+    for at, run, w, nxt in b:
+        print("instruction %d: %d loads, then `%s` / `%s`" % (at, run, w, nxt))
+    print("%d finding(s)" % len(b))
+    sys.exit(1 if b else 0)

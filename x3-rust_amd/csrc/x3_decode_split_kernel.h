@@ -130,6 +130,23 @@
 // and slow the ENCODER down by 8 % through what they leave in L2, nt loads cost 56 %: profiles/r4/decoder_cache_policies.txt.)
 #define X3S_XROWS 11u          // transfer rows per block buffer: 10 pair dwords + the header word
 #define X3S_WAVES 3u            // parser, valuer, flusher
+// Code placement (round 5).  The kernel's time depends on where its hot loops fall against the instruction fetch windows:
+// the same instructions shifted by four bytes decode at 0.76 instead of 0.69 ms (MI355X_MICROARCH.md, "Code-placement
+// sensitivity"; profiles/r5/decoder_code_placement.txt) -- and any edit in front of a loop shifts it.  Each role's block
+// loop therefore starts at a fixed phase: aligned to 64 bytes plus X3S_PAD_x four-byte s_nops (executed once), chosen by
+// measurement.  -1: no alignment (the loop falls where the code in front of it puts it).
+#ifndef X3S_PAD_P
+#define X3S_PAD_P 0
+#endif
+#ifndef X3S_PAD_V
+#define X3S_PAD_V 0
+#endif
+#ifndef X3S_PAD_F
+#define X3S_PAD_F 0
+#endif
+#define X3S_STR2(x) #x
+#define X3S_STR(x) X3S_STR2(x)
+#define X3S_PLACE(n) do { if ((n) >= 0) asm volatile(".p2align 6\n\t.rept " X3S_STR(n) "\n\ts_nop 0\n\t.endr" ::: "memory"); } while (0)
 
 // halfword index of sample j (0..19) of a block in its transfer buffer: pair j/2 is dword (j/2 & 1) of the
 // 8-byte slot of this lane in row j/4
@@ -234,7 +251,14 @@ struct X3SegArgs {
 // LDS barrier of the group's waves: LDS operations retired, nothing else waited for
 #define X3S_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-__global__ void __launch_bounds__(64 * X3S_WAVES)
+// (amdgpu_waves_per_eu(1, 4): LDS holds five groups per CU = fifteen waves = four per SIMD at most, so the register allocator
+// may use 128 registers per lane.  Left to aim at eight waves per SIMD it squeezes the kernel into 70 and, depending on the
+// code around them, COPIES part of a ring request's destination registers right behind the request -- a wait for a load
+// that has just been issued, in every service: 0.69 -> 0.75 ms (profiles/r5/decoder_service_schedule.txt).)
+#ifndef X3S_WAVES_PER_EU
+#define X3S_WAVES_PER_EU 4
+#endif
+__global__ void __launch_bounds__(64 * X3S_WAVES) __attribute__((amdgpu_waves_per_eu(1, X3S_WAVES_PER_EU)))
 x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uint64_t* __restrict__ frame_off,
                        uint64_t n_frames, X3Geom g, const uint64_t* __restrict__ wav_off, X3DevParams p,
                        int16_t* __restrict__ wav, uint64_t wav_cap, int32_t* __restrict__ status,
@@ -435,16 +459,18 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
                       x3_bswap32(w[1]), x3_bswap32(w[0]));
     wr_abs += 4;
   };
-  uint4 ld[SVC_AHEAD];
   // Round 5 (-DX3S_DENSE_AHEAD=0: off): a group that holds a DENSE frame -- a payload beyond what the encoder's image takes,
   // literal and wide BFP blocks: a ship passing the hydrophone -- needs all SVC_MAX chunks in that lane at every service,
   // and asked for the ones beyond SVC_AHEAD only then, with the whole group waiting for memory (1 % loud frames: every
   // second group holds one, 0.82 ms against 0.68).  Such groups request all of them a service ahead.
+  // (ONE lambda, ONE array: the register allocator is touchy about the requests' destination registers -- with the two
+  // cases in lambdas of their own behind a dispatching one it copied part of a destination right behind the request and
+  // waited for it there, 0.69 -> 0.75 ms with the feature compiled out; tools/check_decoder_isa.py looks for that.)
 #ifndef X3S_DENSE_AHEAD
 #define X3S_DENSE_AHEAD 1
 #endif
   const bool dense_grp = X3S_DENSE_AHEAD && __any(active && plen > 9728u);   // (9 728: X3_DENSE_PAYLOAD_BYTES, the encoder's image)
-  uint4 lx[SVC_MAX - SVC_AHEAD];
+  uint4 ld[SVC_MAX];
   uint32_t v_req = 0;
   auto fill_ring = [&]() {  // the first 128 bytes, and the requests of the first service
     uint4 c[8];
@@ -461,7 +487,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     for (int k = 0; k < (int)SVC_AHEAD; ++k) ld[k] = request(v_next + 16u * k);
     if (dense_grp) {
 #pragma unroll
-      for (int k = 0; k < (int)(SVC_MAX - SVC_AHEAD); ++k) lx[k] = request(v_next + 16u * (SVC_AHEAD + k));
+      for (int k = (int)SVC_AHEAD; k < (int)SVC_MAX; ++k) ld[k] = request(v_next + 16u * k);
     }
     v_req = v_next;
   };
@@ -474,12 +500,13 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       if (fit > k) park(ld[k]);
     }
     if (__any(fit > SVC_AHEAD)) {  // a lane went through more than that since the last service (BFP / literal blocks)
-      uint4 more[SVC_MAX - SVC_AHEAD];
+      if (!dense_grp) {
 #pragma unroll
-      for (uint32_t k = 0; k < SVC_MAX - SVC_AHEAD; ++k) more[k] = dense_grp ? lx[k] : request(v_req + 16u * (SVC_AHEAD + k));
+        for (uint32_t k = SVC_AHEAD; k < SVC_MAX; ++k) ld[k] = request(v_req + 16u * k);
+      }
 #pragma unroll
-      for (uint32_t k = 0; k < SVC_MAX - SVC_AHEAD; ++k) {
-        if (fit > SVC_AHEAD + k) park(more[k]);
+      for (uint32_t k = SVC_AHEAD; k < SVC_MAX; ++k) {
+        if (fit > k) park(ld[k]);
       }
     }
     v_next += 16u * (fit > SVC_MAX ? SVC_MAX : fit);
@@ -489,7 +516,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       for (int k = 0; k < (int)SVC_AHEAD; ++k) ld[k] = request(v_req + 16u * k);
       if (dense_grp) {
 #pragma unroll
-        for (int k = 0; k < (int)(SVC_MAX - SVC_AHEAD); ++k) lx[k] = request(v_req + 16u * (SVC_AHEAD + k));
+        for (int k = (int)SVC_AHEAD; k < (int)SVC_MAX; ++k) ld[k] = request(v_req + 16u * k);
       }
     }
   };
@@ -673,6 +700,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       }
       X3_WAVE_LDS_ORDER();
     };
+    X3S_PLACE(X3S_PAD_F);
     for (uint32_t b = 0; b < nblk_max; ++b) {
       X3S_PACE_STEP(b, X3S_ROLE_FLUSHER)
       X3_STAMP(0);
@@ -789,6 +817,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
 
     const uint32_t k_tab = (p.k[1] << 16) | (p.k[2] << 24);  // log2(level) by ftype
     uint32_t over = 0;
+    X3S_PLACE(X3S_PAD_P);
     for (uint32_t b = 0; b < nblk_max; ++b) {
       X3S_PACE_STEP(b, X3S_ROLE_PARSER)
       const uint32_t cnt = remaining < X3S_BL ? remaining : X3S_BL;
@@ -981,6 +1010,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     };
 #endif
     uint32_t posb = pos0;  // ring byte of the block's first pair, unmasked
+    X3S_PLACE(X3S_PAD_V);
     for (uint32_t b = 0; b < nblk_max; ++b, posb += 2u * X3S_BL) {
       X3S_PACE_STEP(b, X3S_ROLE_VALUER)
       X3_STAMP(0);
