@@ -68,6 +68,9 @@
 #ifndef X3S_THIN
 #define X3S_THIN 0
 #endif
+#ifndef X3S_VALUER_ASM
+#define X3S_VALUER_ASM 0     // 1: the valuer's pair arithmetic as one asm block per pair (no s_nop padding between its instructions; measured: +-0)
+#endif
 // TIMING experiments on top of X3S_THIN (results are wrong): the valuer converts only the first X3S_THIN_K of a block's ten
 // pairs from peeks to indices (as if another wave had converted the others in place); X3S_THIN_F: the flusher executes
 // the conversion's instructions and LDS traffic for the other 10 - K on dummy data
@@ -1097,6 +1100,41 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
           }
         };
         if (__any(litmask != 0u)) pairs(std::true_type{}); else pairs(std::false_type{});
+#elif X3S_VALUER_ASM && !X3S_THIN
+        // Round 5: the thirteen instructions of a pair as ONE asm block.  As single-instruction helpers the compiler puts
+        // an `s_nop 0` behind most of them (it cannot see into an asm and assumes that one which feeds the next may have
+        // written half a register: the dst_sel forwarding hazard of gfx94x -- packed instructions write whole registers);
+        // forty issue slots per block in this wave, a quarter more than its arithmetic.  Same arithmetic, same order.
+        {
+          const uint32_t c10001 = 0x00010001u, c10000 = 0x00010000u;
+#pragma unroll
+          for (uint32_t r = 0; r < 5u; ++r) {
+            uint32_t W[2];
+#pragma unroll
+            for (uint32_t e = 0; e < 2; ++e) {
+              const uint32_t X = e ? XX[r].y : XX[r].x;
+              uint32_t t0, t1, t2, P;
+              asm("v_pk_max_u16 %[mx], %[mx], %[X]\n\t"
+                  "v_and_b32 %[t0], %[c10001], %[X]\n\t"
+                  "v_pk_lshrrev_b16 %[t1], 1, %[X] op_sel_hi:[0,1]\n\t"
+                  "v_pk_sub_u16 %[t0], 0, %[t0]\n\t"
+                  "v_pk_add_u16 %[t2], %[X], %[tm12]\n\t"
+                  "v_xor_b32 %[t1], %[t0], %[t1]\n\t"
+                  "v_and_b32 %[t2], %[t2], %[neg22]\n\t"
+                  "v_pk_sub_u16 %[t2], %[X], %[t2]\n\t"
+                  "v_bfi_b32 %[t1], %[zmask], %[t1], %[t2]\n\t"
+                  "v_pk_add_u16 %[t2], %[t1], %[prev] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                  "v_pk_mad_u16 %[t1], %[t1], %[c10000], %[t2] op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                  "v_bfi_b32 %[P], %[litmask], %[X], %[t1]\n\t"
+                  "v_alignbit_b32 %[W], %[P], %[prev], 16"
+                  : [mx] "+v"(maxii2), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [P] "=&v"(P), [W] "=&v"(W[e])
+                  : [X] "v"(X), [tm12] "v"(tm12), [neg22] "v"(neg22), [zmask] "v"(zmask), [litmask] "v"(litmask), [prev] "v"(prevP),
+                    [c10001] "s"(c10001), [c10000] "v"(c10000));
+              prevP = P;
+            }
+            x3_lds_write_b64(x3_and_or(posb + 8u * r, 248u, orow_b), W[0], W[1]);
+          }
+        }
 #else
 #pragma unroll
         for (uint32_t r = 0; r < 5u; ++r) {
