@@ -68,6 +68,9 @@
 #ifndef X3S_THIN
 #define X3S_THIN 0
 #endif
+#ifndef X3S_PAIR_ASM2
+#define X3S_PAIR_ASM2 1      // the parser's pair block also holds the shift's sign and the ring address (one s_nop per pair less)
+#endif
 #ifndef X3S_VALUER_ASM
 #define X3S_VALUER_ASM 0     // 1: the valuer's pair arithmetic as one asm block per pair (no s_nop padding between its instructions; measured: +-0)
 #endif
@@ -918,6 +921,35 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
                 : "v"(t), "v"(zmask), "v"(nwidth), "v"(s));
             consume_to(s2);
             X[e] = t;
+#elif X3S_PAIR_ASM2 && !X3S_SWP
+            // (round 5) ... and the sign of the bit counter, the ring byte counter and the address of the next ring word
+            // in the same block: a compiler-made instruction that reads what an asm block wrote gets an `s_nop 0` in
+            // front (the dst_sel forwarding hazard, assumed for any asm) -- one per pair on the parser's path
+            uint32_t z1, z2, v1, v2, t2, nn1, nn2, m, addr;
+            int32_t s2;
+            asm("v_ffbh_u32 %[z1], %[t]\n\t"
+                "v_mad_i32_i24 %[nn1], %[z1], %[zmask], %[nwidth]\n\t"
+                "v_alignbit_b32 %[t2], %[t], 0, %[nn1]\n\t"
+                "v_bfe_u32 %[v1], %[t], %[nn1], %[fw]\n\t"
+                "v_ffbh_u32 %[z2], %[t2]\n\t"
+                "v_mad_i32_i24 %[nn2], %[z2], %[zmask], %[nwidth]\n\t"
+                "v_bfe_u32 %[v2], %[t2], %[nn2], %[fw]\n\t"
+                "v_add3_u32 %[s2], %[s], %[nn1], %[nn2]\n\t"
+                "v_ashrrev_i32 %[m], 31, %[s2]\n\t"
+                "v_lshl_add_u32 %[qb], %[m], 2, %[qb]\n\t"
+                "v_and_or_b32 %[addr], %[qb], %[c124], %[rowb]"
+                : [z1] "=&v"(z1), [v1] "=&v"(v1), [z2] "=&v"(z2), [v2] "=&v"(v2), [nn1] "=&v"(nn1), [nn2] "=&v"(nn2),
+                  [t2] "=&v"(t2), [s2] "=&v"(s2), [m] "=&v"(m), [addr] "=&v"(addr), [qb] "+v"(qb)
+                : [t] "v"(t), [zmask] "v"(zmask), [nwidth] "v"(nwidth), [s] "v"(s), [fw] "v"(fw), [c124] "v"(124u), [rowb] "v"(row_base));
+            {
+              const uint32_t wn_new = x3_lds_read_b32(addr);
+              __builtin_amdgcn_sched_barrier(0);   // (the read stays here: see consume_to)
+              s = (uint32_t)s2 & 31u;
+              w0 = x3_bfi(m, w1, w0);
+              w1 = x3_bfi(m, wn, w1);
+              wn = wn_new;
+            }
+            X[e] = x3_pack_lo16((z1 << lsh) + v1, (z2 << lsh) + v2);
 #else
             uint32_t z1, z2, v1, v2, t2, nn1, nn2;
             int32_t s2;
