@@ -328,6 +328,7 @@ extern "C" int x3_ctx_set_option(x3_ctx* c, const char* name, long long value) {
   else if (n == "check_first") c->opt.check_first = value != 0;
   else if (n == "check_wgs") c->opt.check_wgs = (int)std::max(1ll, value);
   else if (n == "seg_stretches") c->opt.seg_stretches = (int)std::max(0ll, value);
+  else if (n == "two_trips") c->opt.two_trips = value != 0;
   else if (n == "mc_decode_threads") c->opt.mc_decode_threads = value != 0;
   else if (n == "index_no_fast") c->opt.index_no_fast = value != 0;
   else if (n == "wav_offsets_x4") c->opt.wav_offsets_x4 = value != 0;
@@ -364,6 +365,8 @@ extern "C" int x3_ctx_get_option(const x3_ctx* c, const char* name, long long* v
   else if (n == "check_first") *value = c->opt.check_first;
   else if (n == "check_wgs") *value = c->opt.check_wgs;
   else if (n == "seg_stretches") *value = c->opt.seg_stretches;
+  else if (n == "two_trips") *value = c->opt.two_trips;
+  else if (n == "stream_one_trip") *value = (long long)c->stream_one_trip;   // read-only counter
   else if (n == "last_seg_stretches") *value = c->last_seg_stretches;   // read-only: how the last decode launch used its segment index
   else if (n == "mc_decode_threads") *value = c->opt.mc_decode_threads;
   else if (n == "index_no_fast") *value = c->opt.index_no_fast;

@@ -15,7 +15,7 @@ int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint6
                            uint64_t F, const x3_batch* batch, const uint64_t* d_wav_offsets, const x3_params* p,
                            int16_t* d_wav, uint64_t wav_cap, int32_t* d_status, bool wav_off_aligned,
                            bool bl0,    // bl0: the caller's block_len is 0 and p carries 1 (x3_decode_merge_kernel)
-                           const X3SegSpec* seg) {
+                           const X3SegSpec* seg, const unsigned long long* d_nf) {
   if (reinterpret_cast<uintptr_t>(d_x3) & 3u) return X3_ERR_BAD_ARG;
   if (reinterpret_cast<uintptr_t>(d_wav) & 1u) return X3_ERR_BAD_ARG;
   if (F == 0 || F > 0x7FFFFFFFull) return X3_ERR_BAD_ARG;
@@ -66,7 +66,7 @@ int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint6
       X3_LAUNCH_TIMED(ts, x3_frame_check_kernel, dim3((unsigned)check_grid), dim3(256), 0, check_stream,
                          reinterpret_cast<const uint32_t*>(d_x3), x3_len, d_frame_offsets, F,
                          (const uint16_t*)c->d_xinv8, (const uint16_t*)c->d_chktab, (const uint32_t*)c->d_kx64,
-                         (int32_t*)c->dec_cstatus.p, reinterpret_cast<unsigned long long*>(c->d_summary), 1u);
+                         (int32_t*)c->dec_cstatus.p, reinterpret_cast<unsigned long long*>(c->d_summary), 1u, d_nf);
     }
     if (check_stream == c->stream2) HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
     return X3_OK;
@@ -93,6 +93,7 @@ int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint6
     // or a frame length of 4 (mod 8) samples --: the same lines in 8-byte pieces, x3_decode_split_kernel.h flush_rows)
     // (X3HIP_DECODE_DYN_LDS: extra LDS per decoder group = fewer groups per CU; an occupancy experiment)
     const size_t dyn_lds = (size_t)c->opt.dyn_lds;
+    if (d_nf && !split) return X3_ERR_BAD_ARG;   // (only the three-wave decoder takes the frame count from device memory)
     TimerScope ts(c, 1, dec_stream, split);   // (the split kernel: events on its dispatch packet; the rarer single-wave kernels below: bracketed)
     if (split) {
       // the pace word's 12-bit epoch: launches 1, 2, ... 4095, then the word starts over
@@ -139,7 +140,7 @@ int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint6
       X3_LAUNCH_TIMED(ts, x3_decode_split_kernel, dim3((unsigned)groups), dim3(64 * X3S_WAVES),
                          dyn_lds, dec_stream, d_x3, x3_len,
                          d_frame_offsets, F, g, d_wav_offsets, dp, d_wav, wav_cap, d_status, (X3FrameMeta*)c->dec_meta.p,
-                         c->d_pace, c->dec_epoch & 0xFFFu, sg);
+                         c->d_pace, c->dec_epoch & 0xFFFu, sg, d_nf);
       ++c->dec_epoch;
     }
     else if (fast)
@@ -166,7 +167,7 @@ int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint6
   }
   hipLaunchKernelGGL(x3_decode_merge_kernel, dim3((unsigned)std::min<uint64_t>((F + 255) / 256, 64)), dim3(256), 0, c->stream,
                      (const int32_t*)c->dec_cstatus.p, d_status, (const X3FrameMeta*)c->dec_meta.p, F, c->d_summary,
-                     d_x3, d_frame_offsets, g, d_wav_offsets, dp, d_wav, bl0 ? 1u : 0u);
+                     d_x3, d_frame_offsets, g, d_wav_offsets, dp, d_wav, bl0 ? 1u : 0u, d_nf);
   c->dec_status_ptr = d_status;
   HIPCHK(c, hipGetLastError());
   c->decode_pending = true;
@@ -228,10 +229,11 @@ extern "C" int x3_decode_result(x3_ctx* c, uint64_t* first_bad, int* first_bad_s
 // ------------------------------------------------------------------------------------------------
 // GPU-side frame index of a device-resident stream (x3_index_kernels.h)
 // ------------------------------------------------------------------------------------------------
-static int index_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t len, uint64_t phantom, uint32_t bl0, uint64_t wav_cap,
-                          uint64_t max_frames, uint64_t* d_frame_offsets, uint64_t* d_wav_offsets,
-                          X3IndexSummary* result) {
-  if (reinterpret_cast<uintptr_t>(d_x3) & 3u) return X3_ERR_BAD_ARG;
+// The fast path's five launches (x3_index_kernels.h), nothing waited for: the summary -- frame and sample count, how the
+// walk ends, pad2 = "not one clean chain: take the general walk" -- stays in *d_sum_out on the device.
+static int index_fast_launch(x3_ctx* c, const uint8_t* d_x3, uint64_t len, uint64_t phantom, uint32_t bl0, uint64_t wav_cap,
+                             uint64_t max_frames, uint64_t* d_frame_offsets, uint64_t* d_wav_offsets,
+                             X3IndexSummary** d_sum_out) {
   const uint32_t* xw = reinterpret_cast<const uint32_t*>(d_x3);
   int rc;
   if ((rc = ensure(c, c->idx_sum, 256))) return rc;
@@ -239,13 +241,9 @@ static int index_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t len, uint64_t
   X3IndexSummary* d_sum = reinterpret_cast<X3IndexSummary*>(c->idx_sum.p);
   const uint64_t chunks = (len + 15) >> 4;
   const unsigned grid = (unsigned)std::min<uint64_t>((chunks + 255) / 256, (uint64_t)c->n_cus * 16);
-  // ---- the fast path (round 4): a stream that is ONE CLEAN CHAIN -- what an encoder writes -- needs no hash table and
-  // no pointer doubling.  The scanning workgroups keep their candidates in stream order, two scans number them, and one
-  // kernel checks all at once that the first frame sits at offset 0 and that every frame ends where the next begins
-  // (x3_index_kernels.h).  Five launches and one trip to the host where the general walk below takes thirteen and two;
-  // anything else -- a false candidate inside a payload, damage, a frame the walk does not step over -- sets pad2, and
-  // the general walk takes the stream as before.
-  if (grid && !c->opt.index_no_fast) {
+  *d_sum_out = d_sum;
+  if (!grid) return X3_ERR_BAD_ARG;
+  {
     const size_t G = grid;
     if ((rc = ensure(c, c->idx_wg, G * X3I_WG_CANDS * sizeof(X3Cand)))) return rc;
     if ((rc = ensure(c, c->idx_sorted, G * X3I_WG_CANDS * sizeof(X3Cand)))) return rc;
@@ -267,6 +265,30 @@ static int index_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t len, uint64_t
     hipLaunchKernelGGL(x3_index_finalize_kernel, dim3(1), dim3(64), 0, c->stream, xw, len, len + phantom, bl0,
                        (const X3Cand*)c->idx_sorted.p, (const unsigned long long*)d_wav_offsets, d_sum);
     HIPCHK(c, hipGetLastError());
+  }
+  return X3_OK;
+}
+
+static int index_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t len, uint64_t phantom, uint32_t bl0, uint64_t wav_cap,
+                          uint64_t max_frames, uint64_t* d_frame_offsets, uint64_t* d_wav_offsets,
+                          X3IndexSummary* result) {
+  if (reinterpret_cast<uintptr_t>(d_x3) & 3u) return X3_ERR_BAD_ARG;
+  const uint32_t* xw = reinterpret_cast<const uint32_t*>(d_x3);
+  int rc;
+  if ((rc = ensure(c, c->idx_sum, 256))) return rc;
+  unsigned int* d_count = reinterpret_cast<unsigned int*>((char*)c->idx_sum.p + 128);
+  X3IndexSummary* d_sum = reinterpret_cast<X3IndexSummary*>(c->idx_sum.p);
+  const uint64_t chunks = (len + 15) >> 4;
+  const unsigned grid = (unsigned)std::min<uint64_t>((chunks + 255) / 256, (uint64_t)c->n_cus * 16);
+  // ---- the fast path (round 4): a stream that is ONE CLEAN CHAIN -- what an encoder writes -- needs no hash table and
+  // no pointer doubling.  The scanning workgroups keep their candidates in stream order, two scans number them, and one
+  // kernel checks all at once that the first frame sits at offset 0 and that every frame ends where the next begins
+  // (x3_index_kernels.h).  Five launches and one trip to the host where the general walk below takes thirteen and two;
+  // anything else -- a false candidate inside a payload, damage, a frame the walk does not step over -- sets pad2, and
+  // the general walk takes the stream as before.
+  if (grid && !c->opt.index_no_fast) {
+    X3IndexSummary* ds = nullptr;
+    if ((rc = index_fast_launch(c, d_x3, len, phantom, bl0, wav_cap, max_frames, d_frame_offsets, d_wav_offsets, &ds))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->h_summary_init, d_sum, sizeof *result, hipMemcpyDeviceToHost, c->stream));  // (pinned)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::memcpy(result, c->h_summary_init, sizeof *result);
@@ -395,6 +417,65 @@ int decode_stream_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t len, uint64_
   // sizes are not known before the candidate count: index_dev_impl sizes its own scratch, the two output arrays
   // are sized here from an upper bound that is refined by a first call when it is large
   uint64_t cap_frames = std::min<uint64_t>(max_frames, 1u << 20);
+  // ---- ONE trip to the host (round 5).  A stream that is one clean chain of frames -- what an encoder
+  // writes -- is walked by five launches that leave the frame count on the device; the decoder, the check pass and the merge
+  // are enqueued right behind them with a grid for an upper bound of the count (a frame per KiB of stream) and read the
+  // count from there (the groups behind it leave at once), and ONE copy brings both summaries back.  Anything the walk's
+  // summary then objects to -- not a clean chain, more frames than the bound, sample offsets off the 8-byte grid -- is done
+  // again the old way (the walk, a trip, the decode, a trip): the speculative decode wrote nothing that is not rewritten.
+  {
+    X3DevParams dq;
+    const bool try_one = !own_out && !c->opt.index_no_fast && !c->opt.two_trips && p->block_len == X3S_BL && !c->opt.decode_single &&
+                         !c->force_single_wave_decode && derive(p, spf_of(p) > 0xFFFFFFFFull ? 0 : spf_of(p), &dq) == X3_OK &&
+                         dq.k[1] == 1u && dq.k[2] == 3u && (reinterpret_cast<uintptr_t>(d_wav) & 7u) == 0 &&
+                         (reinterpret_cast<uintptr_t>(d_x3) & 3u) == 0 && len >= 22;
+    const uint64_t bound = std::min<uint64_t>(cap_frames, len / 1024 + 64);
+    if (try_one) {
+      if ((rc = ensure(c, c->frame_off, (bound + 1) * sizeof(uint64_t)))) return rc;
+      if ((rc = ensure(c, c->wav_off, bound * sizeof(uint64_t)))) return rc;
+      X3IndexSummary* ds = nullptr;
+      rc = index_fast_launch(c, d_x3, len, phantom, 0u, wav_cap, bound, (uint64_t*)c->frame_off.p, (uint64_t*)c->wav_off.p, &ds);
+      if (rc == X3_OK) {
+        x3_params pq = *p;
+        rc = decode_dev_impl(c, d_x3, len, (const uint64_t*)c->frame_off.p, bound, nullptr, (const uint64_t*)c->wav_off.p, &pq,
+                             d_wav, wav_cap, nullptr, true, false, nullptr, &ds->n_frames);
+        if (rc == X3_OK) {
+          HIPCHK(c, hipMemcpyAsync(c->h_summary_init, ds, sizeof(X3IndexSummary), hipMemcpyDeviceToHost, c->stream));  // (pinned)
+          HIPCHK(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(X3DecodeSummary), hipMemcpyDeviceToHost, c->stream));
+          HIPCHK(c, hipStreamSynchronize(c->stream));
+          std::memcpy(&r, c->h_summary_init, sizeof r);
+          c->decode_pending = false;
+          if (!r.pad && !r.pad2 && !r.unaligned && r.n_frames <= bound) {
+            ++c->index_fast;
+            ++c->stream_one_trip;
+            const uint64_t F1 = r.n_frames;
+            if (F1 == 0) return r.terminal;
+            uint64_t first_bad = c->h_summary->first_bad, before = c->h_summary->samples_before;
+            int bad_status = c->h_summary->first_bad_status;
+            if (first_bad < F1) {   // rare: a frame is bad -- its status and the samples of the good frames before it
+              c->dec_frames = F1;
+              c->decode_pending = true;
+              if ((rc = x3_decode_result(c, &first_bad, &bad_status, &before))) return rc;
+            }
+            if (n_out) *n_out = before;
+            if (frames_ok) *frames_ok = first_bad;
+            if (first_bad < F1) {
+              if (bad_status == X3_ERR_OUT_OF_BOUNDS_INVERSE || bad_status == X3_ERR_FRAME_DECODE_INVALID_BPF) {
+                if (frame_errors) *frame_errors = 1;
+                return X3_OK;
+              }
+              return bad_status;
+            }
+            return r.terminal;
+          }
+        } else if (rc != X3_ERR_BAD_ARG) {
+          return rc;
+        }
+      } else if (rc != X3_ERR_BAD_ARG) {
+        return rc;
+      }
+    }
+  }
   for (;;) {
     if ((rc = ensure(c, c->frame_off, (cap_frames + 1) * sizeof(uint64_t)))) return rc;
     if ((rc = ensure(c, c->wav_off, cap_frames * sizeof(uint64_t)))) return rc;

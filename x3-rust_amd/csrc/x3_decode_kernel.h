@@ -122,9 +122,11 @@ __device__ __forceinline__ int32_t x3_frame_header_check(const uint32_t* __restr
 
 __global__ void __launch_bounds__(256, X3_CHECK_MIN_WGS)
 x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const uint64_t* __restrict__ frame_off,
-                      uint64_t n_frames, const uint16_t* __restrict__ xinv8, const uint16_t* __restrict__ tab_g,
+                      uint64_t n_frames_arg, const uint16_t* __restrict__ xinv8, const uint16_t* __restrict__ tab_g,
                       const uint32_t* __restrict__ kx64, int32_t* __restrict__ status,
-                      unsigned long long* __restrict__ summary, uint32_t n_ch) {
+                      unsigned long long* __restrict__ summary, uint32_t n_ch,
+                      const unsigned long long* __restrict__ d_nf = nullptr) {
+  const uint64_t n_frames = d_nf ? (*d_nf < n_frames_arg ? (uint64_t)*d_nf : n_frames_arg) : n_frames_arg;   // (the count from device memory: x3_decode_split_kernel.h)
   __shared__ __attribute__((aligned(16))) uint16_t tab[X3_CHECK_TAB_U16];
   // short and latency-bound: ahead of the decoder's waves it shares the SIMDs with, so that it is out of the way
   // early instead of being stretched to the decoder's whole duration
@@ -1135,9 +1137,11 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
 // summary must be pre-set to {n_frames, 0, 0}.
 __global__ void __launch_bounds__(256)
 x3_decode_merge_kernel(const int32_t* __restrict__ cstatus, int32_t* __restrict__ status,
-                       const X3FrameMeta* __restrict__ meta, uint64_t n_frames, X3DecodeSummary* __restrict__ out,
+                       const X3FrameMeta* __restrict__ meta, uint64_t n_frames_arg, X3DecodeSummary* __restrict__ out,
                        const uint8_t* __restrict__ x3, const uint64_t* __restrict__ frame_off, X3Geom g,
-                       const uint64_t* __restrict__ wav_off, X3DevParams p, int16_t* __restrict__ wav, uint32_t bl0) {
+                       const uint64_t* __restrict__ wav_off, X3DevParams p, int16_t* __restrict__ wav, uint32_t bl0,
+                       const unsigned long long* __restrict__ d_nf = nullptr) {
+  const uint64_t n_frames = d_nf ? (*d_nf < n_frames_arg ? (uint64_t)*d_nf : n_frames_arg) : n_frames_arg;
   // grid-stride, one atomic per workgroup: a thousand waves adding to ONE address took 11 of this kernel's 16 us
   __shared__ unsigned long long s_ns[4];
   unsigned long long ns = 0;

@@ -266,9 +266,14 @@ struct X3SegArgs {
 #endif
 __global__ void __launch_bounds__(64 * X3S_WAVES) __attribute__((amdgpu_waves_per_eu(1, X3S_WAVES_PER_EU)))
 x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uint64_t* __restrict__ frame_off,
-                       uint64_t n_frames, X3Geom g, const uint64_t* __restrict__ wav_off, X3DevParams p,
+                       uint64_t n_frames_arg, X3Geom g, const uint64_t* __restrict__ wav_off, X3DevParams p,
                        int16_t* __restrict__ wav, uint64_t wav_cap, int32_t* __restrict__ status,
-                       X3FrameMeta* __restrict__ meta, uint32_t* __restrict__ pace, uint32_t pace_epoch, X3SegArgs sg) {
+                       X3FrameMeta* __restrict__ meta, uint32_t* __restrict__ pace, uint32_t pace_epoch, X3SegArgs sg,
+                       const unsigned long long* __restrict__ d_nf) {
+  // d_nf: the frame count is still on its way to the host (x3_decode_stream_dev in one trip: the frame walk's kernels are
+  // in front of this one in the stream) -- the launch covers an upper bound, the groups behind the real count leave here
+  const uint64_t n_frames = d_nf ? (*d_nf < n_frames_arg ? (uint64_t)*d_nf : n_frames_arg) : n_frames_arg;   // (never beyond the bound the arrays were sized for)
+  if (d_nf && (uint64_t)blockIdx.x * 64u >= n_frames) return;
   // input ring, 32 dwords per lane in rows of exactly 128 bytes at 128-byte aligned addresses, stream word j in
   // slot ~j & 31 (descending): the address of a word is then ONE v_and_or_b32 on a byte counter that a shift of
   // the window decrements with one v_lshl_add_u32.  (Lanes are at different places in their rows, so the aligned

@@ -73,6 +73,7 @@ struct X3Opts {
   int check_serial = 0;       // X3HIP_CHECK_SERIAL: the check pass in front of the decoder, same stream
   int no_check = 0;           // X3HIP_PROFILE_NO_CHECK: time the decoder alone (payload CRCs NOT verified)
 #endif
+  int two_trips = 0;          // 1: x3_decode_stream_dev always waits for the frame walk before it launches the decoder (the pre-round-5 path)
   int seg_stretches = 0;      // x3_decode_dev_seg: stretches per frame (0 = as many as fill the chip; 1 = never by stretches)
   int dyn_lds = 0;            // X3HIP_DECODE_DYN_LDS: extra LDS per decoder group = fewer groups per CU (occupancy experiments)
 };
@@ -83,6 +84,7 @@ struct X3SegSpec { uint64_t* d_index; uint32_t seg_blocks; int mode; };
 struct x3_ctx {
   X3Opts opt;
   X3SegSpec enc_seg{nullptr, 0, 0};         // x3_encode_dev_seg -> encode_dev_impl: the index the next launch fills
+  unsigned long long stream_one_trip = 0;   // x3_decode_stream_dev calls served with one trip to the host
   int last_seg_stretches = 0;               // the last decode launch: stretches per frame (0: none given, -1: recorded)
   unsigned long long needed_pos = 0;        // the position a host-buffer encode that ran out of room would have reached
   unsigned long long encode_fallbacks = 0;  // launches of the single-pass encoder that timed out (two-pass re-run)
@@ -306,7 +308,8 @@ X3_INTERNAL int encode_host(x3_ctx* c, const int16_t* const* wavs, uint64_t n_pe
 X3_INTERNAL int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint64_t* d_frame_offsets,
                                 uint64_t F, const x3_batch* batch, const uint64_t* d_wav_offsets, const x3_params* p,
                                 int16_t* d_wav, uint64_t wav_cap, int32_t* d_status, bool wav_off_aligned = false,
-                                bool bl0 = false, const X3SegSpec* seg = nullptr);
+                                bool bl0 = false, const X3SegSpec* seg = nullptr,
+                                const unsigned long long* d_nf = nullptr);  // d_nf: the real frame count, on the device; F is a bound
 X3_INTERNAL int decode_stream_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t len, uint64_t phantom, const x3_params* p,
                                        int16_t* d_wav, uint64_t wav_cap, DevBuf* own_out, uint64_t* n_out,
                                        uint64_t* frames_ok, uint64_t* frame_errors);
