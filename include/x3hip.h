@@ -473,7 +473,10 @@ int x3_decode_result(x3_ctx* ctx, uint64_t* first_bad, int* first_bad_status, ui
 int x3_index_dev(x3_ctx* ctx, const uint8_t* d_x3, uint64_t len, uint64_t max_frames, uint64_t* d_frame_offsets,
                  uint64_t* d_wav_offsets, uint64_t* n_frames, uint64_t* n_samples, int* terminal);
 /* x3_decode_stream for device buffers: index (above) + decode, nothing crosses PCIe but the summary.  Same
- * results and status as x3_decode_stream on the same bytes; samples go to d_wav[0..*n_out). */
+ * results and status as x3_decode_stream on the same bytes; samples go to d_wav[0..*n_out).  A stream that is one clean
+ * chain of frames (what an encoder writes) takes ONE trip to the host: the decode launches are enqueued behind the walk's
+ * and read the frame count from device memory (option "two_trips" = 1: wait for the walk first, as before round 5; a
+ * stream the walk objects to, or one with more than a frame per KiB, is done that way by itself). */
 int x3_decode_stream_dev(x3_ctx* ctx, const uint8_t* d_x3, uint64_t len, const x3_params* p, int16_t* d_wav,
                          uint64_t wav_cap, uint64_t* n_out, uint64_t* frames_ok, uint64_t* frame_errors);
 

@@ -1047,6 +1047,54 @@ def test_index_max_frames_equal_to_the_chain_with_a_stray_candidate(x3):
         c.close()
 
 
+def test_decode_stream_dev_in_one_trip_and_in_two(x3):
+    """round 5: x3_decode_stream_dev enqueues the decode behind the frame walk's fast path and reads both summaries in ONE
+    trip (the kernels take the frame count from device memory, the grid covers a frame per KiB of stream).  Same answers as
+    the two-trip path (option two_trips) and as the oracle on: a clean stream, a stream of frames shorter than the bound
+    allows for (falls back), damaged frames (decode error, CRC), a truncated tail, junk in front."""
+    c = x3.Context(0)
+    try:
+        cases = []
+        p = x3.Params.default()
+        wav = x3.synth(2, 4711, 0, 123_457)
+        stream = O.encode(wav)[1]
+        cases.append(("clean", p, stream, True))
+        ps = x3.Params.make(20, 8)                      # 160-sample frames of ~110 bytes: more frames than one per KiB
+        cases.append(("short frames", ps, O.encode(wav[:40_000], O.Params.make(20, 8))[1], False))
+        bad = stream.copy(); bad[5000] ^= 0x10
+        cases.append(("crc", p, bad, True))
+        offs = []
+        pos = 0
+        while pos + 20 <= stream.size:
+            offs.append(pos); pos += 20 + ((int(stream[pos + 6]) << 8) | int(stream[pos + 7]))
+        bad = stream.copy(); q = offs[3] + 20 + 40; bad[q:q + 12] = 0
+        pc = O.crc16(bad[offs[3] + 20:offs[4]]); bad[offs[3] + 18], bad[offs[3] + 19] = pc >> 8, pc & 0xFF
+        cases.append(("decode error", p, bad, True))
+        cases.append(("truncated", p, stream[:offs[5] + 300].copy(), False))
+        cases.append(("junk in front", p, np.concatenate([np.arange(6, dtype=np.uint8), stream]), False))
+        d_wav = c.alloc(2 * 200_000)
+        for name, pp, s, one in cases:
+            op = O.Params.make(pp.block_len, pp.blocks_per_frame)
+            want = O.decode_stream(s, op, wav_cap=200_000)
+            d = c.alloc(s.size + 64); c.upload(d, s)
+            got = []
+            for two in (0, 1):
+                c.set_option("two_trips", two)
+                n1 = c.get_option("stream_one_trip")
+                c.upload(d_wav, np.zeros(200_000, dtype=np.int16))
+                r = c.decode_stream_dev(d, s.size, pp, d_wav, 200_000)
+                got.append((r, c.download(d_wav, 2 * r[1], np.int16)))
+                assert c.get_option("stream_one_trip") - n1 == (1 if (one and not two) else 0), (name, two)
+            c.set_option("two_trips", 0)
+            for r, samples in got:
+                assert r == (want[0], want[1].size, want[2], want[3]), (name, r, want[0], want[1].size, want[2:])
+                assert np.array_equal(samples, want[1]), name
+            c.free(d)
+        c.free(d_wav)
+    finally:
+        c.close()
+
+
 def _make_encoder_lose_its_grid(c, gen):
     """-> what to undo.  Second generation (eight waves per frame): one workgroup per CU more than fit, so that part of
     the grid is not resident.  Third generation (one wave per frame): one workgroup generation never publishes its total
