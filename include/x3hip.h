@@ -458,6 +458,26 @@ int x3_decode_dev_seg(x3_ctx* ctx, const uint8_t* d_x3, uint64_t x3_len, const u
                       uint64_t n_frames, const x3_batch* batch, const uint64_t* d_wav_offsets,
                       const x3_params* p, int16_t* d_wav, uint64_t wav_cap, int32_t* d_status,
                       uint64_t* d_seg_index, uint32_t seg_blocks, int record);
+/* ---- HIP graphs: a launch-bound sequence of device calls, recorded once and replayed with one host call.
+ * A short stream's encode + decode is a dozen launches, memsets and event operations of a few microseconds each around
+ * kernels of 40-60 us: the host's share of such a step is a third.  Between x3_graph_begin and x3_graph_end the ASYNCHRONOUS
+ * device calls of this context -- x3_encode_dev[_seg], x3_encode_frames_dev, x3_decode_dev[_seg] -- are recorded (stream
+ * capture on the context's stream; the check pass's side stream joins through its events) instead of launched; nothing
+ * may allocate meanwhile, so the same calls must have been made once before, and no call that waits for the GPU
+ * (x3_*_result, x3_ctx_sync, the host-buffer entry points) may be made inside.  x3_graph_launch enqueues the whole
+ * sequence on the context's stream; x3_encode_result / x3_decode_result then report on the calls in it as if they had just
+ * been made.  The graph holds the pointers and sizes the calls were recorded with: replaying it means the same buffers
+ * with new contents.  (The decoder's paced priorities follow launch history through a per-launch tag; replays carry
+ * one tag and run as a context's first launch does: a graph is for launches too short to be paced.)
+ *   MEASURED (round 5, ROCm 7.0.2, profiles/r5/hip_graph_replay.txt): on this stack a replay is SLOWER than the same calls
+ * issued back to back on the stream -- config 2's encode + decode by stretches 0.134 against 0.128 ms a step, a 500-frame
+ * stream 0.33 against 0.095 -- the runtime executes a captured graph node by node with a barrier behind each.  The entry
+ * points are kept (bit-exact, tested) for stacks where that changes; nothing in the library or bench.py uses them. */
+typedef struct x3_graph x3_graph;
+int x3_graph_begin(x3_ctx* ctx);
+int x3_graph_end(x3_ctx* ctx, x3_graph** graph);
+int x3_graph_launch(x3_ctx* ctx, x3_graph* graph);
+void x3_graph_destroy(x3_graph* graph);
 /* Waits for the last x3_decode_dev: index and status of the first frame whose status != 0
  * (first_bad = n_frames, status 0 if all frames are good) and the total samples of good frames
  * before it. */

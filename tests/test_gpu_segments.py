@@ -225,3 +225,67 @@ def test_an_encoder_that_cannot_index_says_so(ctx, x3):
     # bad arguments
     assert ctx.encode_dev_seg(d_wav, n, p, d_out, cap, d_seg, 48, 0, d_off) == x3.ERR_BAD_ARG
     assert ctx.decode_dev_seg(d_out, pos, d_off, F, p, d_back, n, d_seg, 6, n_per_clip=n) == x3.ERR_BAD_ARG
+
+
+def test_hip_graph_replays_encode_and_decode(ctx, x3):
+    """x3_graph_*: a short stream's encode + decode by stretches recorded once and replayed on NEW contents of the same
+    buffers -- stream and samples equal the oracle's every time; recording without a first pass outside the capture (the
+    buffers would have to grow) fails cleanly; a graph of one context is refused by another"""
+    p = x3.Params.default()
+    L = x3.lib()
+    n, sb = 250_000, 32
+    F = L.x3_num_frames(n, C.byref(p)); cap = L.x3_encode_bound(n, C.byref(p))
+    ne = L.x3_seg_index_entries(F, C.byref(p), sb)
+    d_wav = ctx.alloc(2 * n + 64); d_out = ctx.alloc(cap + 16); d_off = ctx.alloc(8 * (F + 1)); d_back = ctx.alloc(2 * n)
+    d_seg = ctx.alloc(8 * ne)
+
+    def calls():
+        assert ctx.encode_dev_seg(d_wav, n, p, d_out, cap, d_seg, sb, 0, d_off) == 0
+        assert ctx.decode_dev_seg(d_out, cap, d_off, F, p, d_back, n, d_seg, sb, n_per_clip=n) == 0
+    # a fresh context has nothing allocated: recording must refuse, and leave the context usable
+    c2 = x3.Context(0)
+    try:
+        c2.graph_begin()
+        assert c2.encode_dev_seg(d_wav, n, p, d_out, cap, d_seg, sb, 0, d_off) == x3.ERR_BAD_ARG
+        assert "grow" in c2.last_error()
+        try:
+            c2.graph_destroy(c2.graph_end())    # (whatever was recorded up to there: nothing that runs a kernel)
+        except x3.X3Error:
+            pass
+        # ... and the context works as before
+        w0 = x3.synth(2, 77, 0, 30_000)
+        rc0, s0, _ = c2.encode(w0)
+        assert rc0 == 0 and np.array_equal(s0, O.encode(w0)[1])
+    finally:
+        c2.close()
+    wav = x3.synth(2, 1, 0, n)
+    ctx.upload(d_wav, wav)
+    calls()
+    assert ctx.encode_result()[0] == 0 and ctx.decode_result() == (0, F, 0, n)
+    ctx.graph_begin()
+    calls()
+    g = ctx.graph_end()
+    try:
+        for seed in (2, 3, 4, 5):
+            wav = x3.synth(2 if seed % 2 else 4, seed, 0, n)
+            if seed == 4:
+                wav[30_000:40_000] = x3.synth(1, 9, 0, 10_000)     # a loud frame: the dense pass is part of the graph
+            ctx.upload(d_wav, wav)
+            ctx.upload(d_back, np.zeros(n, dtype=np.int16))
+            ctx.graph_launch(g)
+            rc, pos, stats = ctx.encode_result()
+            assert rc == 0
+            rc_o, ref, st_o = O.encode(wav)
+            assert pos == ref.size and np.array_equal(ctx.download(d_out, pos), ref) and list(stats) == st_o.tolist(), seed
+            assert ctx.decode_result() == (0, F, 0, n)
+            assert np.array_equal(ctx.download(d_back, 2 * n, np.int16), wav), seed
+        # ordinary calls still work behind replays (the encoders' epochs go on)
+        calls()
+        assert ctx.encode_result()[0] == 0 and ctx.decode_result() == (0, F, 0, n)
+        c3 = x3.Context(0)
+        try:
+            assert L.x3_graph_launch(c3._h, g) == x3.ERR_BAD_ARG
+        finally:
+            c3.close()
+    finally:
+        ctx.graph_destroy(g)

@@ -7,6 +7,10 @@
 
 int ensure(x3_ctx* c, DevBuf& b, size_t bytes) {
   if (bytes <= b.cap) return X3_OK;
+  if (c->capturing) {   // (no allocation inside a stream capture: the same calls once outside it size everything)
+    c->last_error = "x3_graph: a device buffer would have to grow while the calls are being recorded -- make the same calls once before x3_graph_begin";
+    return X3_ERR_BAD_ARG;
+  }
   if (b.p) HIPCHK(c, hipFree(b.p));
   b.p = nullptr;
   b.cap = 0;
@@ -298,6 +302,87 @@ extern "C" void x3_ctx_destroy(x3_ctx* c) {
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// HIP graphs: a launch-bound sequence of device calls recorded once, replayed with one host call
+// ------------------------------------------------------------------------------------------------
+struct x3_graph {
+  x3_ctx* c = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  // what the result calls need to know about the recorded calls
+  bool encode_pending = false, decode_pending = false;
+  uint64_t dec_frames = 0, enc_start_pos = 0;
+  int32_t* dec_status_ptr = nullptr;
+  int last_enc_gen = 0, last_seg_stretches = 0;
+  x3_ctx::LastEnc last_enc{};
+};
+
+extern "C" int x3_graph_begin(x3_ctx* c) {
+  if (!c || c->capturing) return X3_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  c->encode_pending = c->decode_pending = false;
+  c->timing_before_capture = c->timing;
+  c->timing = false;
+  HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+  c->capturing = true;
+  return X3_OK;
+}
+
+extern "C" int x3_graph_end(x3_ctx* c, x3_graph** out) {
+  if (!c || !c->capturing || !out) return X3_ERR_BAD_ARG;
+  *out = nullptr;
+  c->capturing = false;
+  c->timing = c->timing_before_capture;
+  hipGraph_t g = nullptr;
+  HIPCHK(c, hipStreamEndCapture(c->stream, &g));
+  if (!g) { c->last_error = "x3_graph_end: the capture was invalidated"; return X3_ERR_HIP; }
+  hipGraphExec_t ex = nullptr;
+  const hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGraphDestroy(g);
+    c->last_error = std::string("hipGraphInstantiate: ") + hipGetErrorString(e);
+    return X3_ERR_HIP;
+  }
+  x3_graph* r = new (std::nothrow) x3_graph;
+  if (!r) { (void)hipGraphExecDestroy(ex); (void)hipGraphDestroy(g); return X3_ERR_HIP; }
+  r->c = c;
+  r->graph = g;
+  r->exec = ex;
+  r->encode_pending = c->encode_pending;
+  r->decode_pending = c->decode_pending;
+  r->dec_frames = c->dec_frames;
+  r->enc_start_pos = c->enc_start_pos;
+  r->dec_status_ptr = c->dec_status_ptr;
+  r->last_enc_gen = c->last_enc_gen;
+  r->last_seg_stretches = c->last_seg_stretches;
+  r->last_enc = c->last_enc;
+  c->encode_pending = c->decode_pending = false;   // (nothing has run yet: x3_graph_launch makes them pending)
+  *out = r;
+  return X3_OK;
+}
+
+extern "C" int x3_graph_launch(x3_ctx* c, x3_graph* g) {
+  if (!c || !g || g->c != c || c->capturing) return X3_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipGraphLaunch(g->exec, c->stream));
+  c->encode_pending = g->encode_pending;
+  c->decode_pending = g->decode_pending;
+  c->dec_frames = g->dec_frames;
+  c->enc_start_pos = g->enc_start_pos;
+  c->dec_status_ptr = g->dec_status_ptr;
+  c->last_enc_gen = g->last_enc_gen;
+  c->last_seg_stretches = g->last_seg_stretches;
+  c->last_enc = g->last_enc;
+  return X3_OK;
+}
+
+extern "C" void x3_graph_destroy(x3_graph* g) {
+  if (!g) return;
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  delete g;
 }
 
 extern "C" int x3_ctx_sync(x3_ctx* c) {

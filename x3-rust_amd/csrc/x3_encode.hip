@@ -128,7 +128,7 @@ int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3
       const size_t desc_bytes = (n_wggen + X3W_DESC_PAD) * sizeof(uint32_t);
       const bool fresh = c->desc.cap < desc_bytes;
       if ((rc = ensure(c, c->desc, desc_bytes))) return rc;
-      if (fresh || ++c->desc_epoch > 0xFFFu) {
+      if (fresh || c->capturing || ++c->desc_epoch > 0xFFFu) {   // (recorded into a graph: cleared by a node of it, every replay)
         HIPCHK(c, hipMemsetAsync(c->desc.p, 0, c->desc.cap, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_pace + 4, 0, 16, c->stream));
         c->desc_epoch = 1;
@@ -239,7 +239,7 @@ int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3
       const size_t desc_bytes = (F + desc_pad) * sizeof(uint32_t);
       const bool fresh = c->desc.cap < desc_bytes;
       if ((rc = ensure(c, c->desc, desc_bytes))) return rc;
-      if (fresh || ++c->desc_epoch > 0xFFFu) {
+      if (fresh || c->capturing || ++c->desc_epoch > 0xFFFu) {   // (recorded into a graph: cleared by a node of it, every replay)
         HIPCHK(c, hipMemsetAsync(c->desc.p, 0, c->desc.cap, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_pace + 4, 0, 16, c->stream));  // (the encoder's pace words carry the same epoch)
         c->desc_epoch = 1;
@@ -275,7 +275,7 @@ int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3
     const size_t lb_bytes = F * sizeof(unsigned long long);
     const bool fresh = c->lb_desc.cap < lb_bytes;
     if ((rc = ensure(c, c->lb_desc, lb_bytes))) return rc;
-    if (fresh || ++c->lb_epoch > 0xFFFu) {
+    if (fresh || c->capturing || ++c->lb_epoch > 0xFFFu) {
       HIPCHK(c, hipMemsetAsync(c->lb_desc.p, 0, c->lb_desc.cap, c->stream));
       c->lb_epoch = 1;
     }

@@ -78,6 +78,9 @@ struct X3Opts {
   int dyn_lds = 0;            // X3HIP_DECODE_DYN_LDS: extra LDS per decoder group = fewer groups per CU (occupancy experiments)
 };
 
+// a recorded sequence of device calls (x3_graph_*): the graph and what x3_encode_result / x3_decode_result need to know
+// about the calls in it
+struct x3_graph;
 // the segment index of a call (x3_decode_split_kernel.h, "STRETCHES"): mode 1 = decode by it, 2 = record it
 struct X3SegSpec { uint64_t* d_index; uint32_t seg_blocks; int mode; };
 
@@ -150,10 +153,16 @@ struct x3_ctx {
   int last_enc_gen = 0;       // which kernel generation served the pending / last encode (3 wave + dense pass, 2, 1; 0 two-pass)
   unsigned long long encode_dense_frames = 0;   // frames handed to the dense pass so far (read-only option)
   unsigned long long last_dense_frames = 0;     // of the last call (either generation counts them)
-  struct {
+  struct LastEnc {
     const int16_t* d_wav; x3_batch b; x3_params p; uint64_t spf; uint8_t* d_out; uint64_t out_cap, start_pos; uint64_t* d_off;
     const uint64_t* src_off; const uint32_t* src_n; bool src_even;   // x3_encode_frames_dev's frame table (device), or nullptr
   } last_enc;
+  // x3_graph_begin .. x3_graph_end: the device calls in between are recorded into a HIP graph instead of launched.  Nothing
+  // may allocate meanwhile (ensure() fails instead), and the encoders' descriptor words -- tagged with a per-launch epoch so
+  // that last launch's totals read as "not there yet" -- are cleared by a memset node of the graph instead (every replay of
+  // the graph carries the same epoch).
+  bool capturing = false;
+  bool timing_before_capture = false;   // (kernel timing rides on events of the dispatch packets: off while recording)
   DevBuf src_tab;   // that table: F offsets (u64), then F sample counts (u32)
   void* h_src_tab = nullptr;        // ... and its pinned host copy (the caller's arrays are only read inside the call)
   size_t h_src_tab_cap = 0;

@@ -46,6 +46,7 @@ SYMBOLS = [
     "x3_reader_position", "x3_reader_close",
     "x3_encode_dev", "x3_encode_frames_dev", "x3_encode_result", "x3_decode_dev", "x3_decode_result", "x3_index_dev", "x3_decode_stream_dev",
     "x3_seg_index_entries", "x3_decode_dev_seg", "x3_encode_dev_seg",
+    "x3_graph_begin", "x3_graph_end", "x3_graph_launch", "x3_graph_destroy",
     "x3_synth", "x3_synth_dev", "x3_dev_alloc", "x3_dev_free", "x3_dev_upload", "x3_dev_download",
     "x3_shard_unique_id", "x3_shard_create", "x3_shard_destroy", "x3_shard_rank", "x3_shard_world",
     "x3_shard_frame_range", "x3_shard_sample_range", "x3_shard_offsets", "x3_shard_exchange_lengths",
@@ -176,6 +177,11 @@ def lib():
     L.x3_decode_dev.argtypes = [vp, vp, u64, vp, u64, C.POINTER(Batch), vp, PP, vp, u64, vp]
     L.x3_decode_result.argtypes = [vp, C.POINTER(u64), C.POINTER(i32), C.POINTER(u64)]
     L.x3_encode_dev_seg.argtypes = [vp, vp, C.POINTER(Batch), PP, vp, u64, u64, vp, vp, u32]
+    L.x3_graph_begin.argtypes = [vp]
+    L.x3_graph_end.argtypes = [vp, C.POINTER(vp)]
+    L.x3_graph_launch.argtypes = [vp, vp]
+    L.x3_graph_destroy.argtypes = [vp]
+    L.x3_graph_destroy.restype = None
     L.x3_seg_index_entries.argtypes = [u64, PP, u32]
     L.x3_seg_index_entries.restype = u64
     L.x3_decode_dev_seg.argtypes = [vp, vp, u64, vp, u64, C.POINTER(Batch), vp, PP, vp, u64, vp, vp, u32, i32]
@@ -709,6 +715,27 @@ class Context:
             b = C.byref(Batch(n_per_clip, n_per_clip if clip_stride is None else clip_stride, n_clips))
         return lib().x3_decode_dev_seg(self._h, d_x3, x3_len, d_frame_offsets, n_frames, b, d_wav_offsets,
                                        C.byref(params), d_wav, wav_cap, d_status, d_seg_index, seg_blocks, 1 if record else 0)
+
+    # ---- HIP graphs (x3_graph_*): record the device calls made between graph_begin() and graph_end(), replay them
+    def graph_begin(self):
+        rc = lib().x3_graph_begin(self._h)
+        if rc:
+            raise X3Error(rc, "x3_graph_begin: " + self.last_error())
+
+    def graph_end(self):
+        g = C.c_void_p()
+        rc = lib().x3_graph_end(self._h, C.byref(g))
+        if rc:
+            raise X3Error(rc, "x3_graph_end: " + self.last_error())
+        return g
+
+    def graph_launch(self, g):
+        rc = lib().x3_graph_launch(self._h, g)
+        if rc:
+            raise X3Error(rc, "x3_graph_launch: " + self.last_error())
+
+    def graph_destroy(self, g):
+        lib().x3_graph_destroy(g)
 
     def decode_result(self):
         fb, st, nb = C.c_uint64(0), C.c_int(0), C.c_uint64(0)
