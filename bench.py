@@ -876,12 +876,22 @@ def main():
             back_c.zero_()
             r_fs = timed_calls(fs_c, reps, (("decode", 1), ("frame_check", 4)))
             assert torch.equal(back_c, wav_c), cname
+            def step_c():
+                enc_c(); dec_c()
+
+            def step_seg_c():
+                enc_seg_c(); dec_seg_c()
+            r_step = timed_calls(step_c, reps, (("encode", 0), ("decode", 1)))
+            assert ctx.encode_result()[0] == 0 and ctx.decode_result()[:3] == (0, F_c, 0)
             r_enc_seg = timed_calls(enc_seg_c, reps, (("encode", 0), ("encode_dense_pass", 5)))
             assert ctx.encode_result()[0] == 0
             back_c.zero_()
             r_dec_seg = timed_calls(dec_seg_c, reps, (("decode", 1), ("frame_check", 4)))
             r_dec_seg["stretches_per_frame"] = int(ctx.get_option("last_seg_stretches"))
             assert ctx.decode_result()[:3] == (0, F_c, 0) and torch.equal(back_c, wav_c), cname
+            back_c.zero_()
+            r_step_seg = timed_calls(step_seg_c, reps, (("encode", 0), ("decode", 1)))
+            assert ctx.encode_result()[0] == 0 and ctx.decode_result()[:3] == (0, F_c, 0) and torch.equal(back_c, wav_c), cname
             # sampled frames against the oracle (first, last, a spread; config 5: frames of the first, a middle and the last clip)
             offs_c = off_c.cpu().numpy()
             assert int(offs_c[-1]) == pos_c
@@ -898,16 +908,19 @@ def main():
                               "encode": r_enc, "decode": r_dec, "decode_stream_dev": r_fs,
                               "round_trip_ms": round(r_enc["ms"] + r_dec["ms"], 4),
                               "round_trip_gsamples_s": round(n_c / (r_enc["ms"] + r_dec["ms"]) / 1e6, 1),
+                              "step": r_step,     # encode + decode per step, steps back to back (as the headline is timed)
                               "with_segment_index": {"seg_blocks": SEG_SB, "index_bytes": int(seg_c.numel() * 8),
                                                      "encode": r_enc_seg, "decode": r_dec_seg,
                                                      "round_trip_ms": round(r_enc_seg["ms"] + r_dec_seg["ms"], 4),
-                                                     "round_trip_gsamples_s": round(n_c / (r_enc_seg["ms"] + r_dec_seg["ms"]) / 1e6, 1)},
+                                                     "round_trip_gsamples_s": round(n_c / (r_enc_seg["ms"] + r_dec_seg["ms"]) / 1e6, 1),
+                                                     "step": r_step_seg},
                               "frames_verified_vs_oracle": len(sampled), "round_trip_is_identity": True}
             del wav_c, out_c, off_c, back_c, seg_c
             torch.cuda.empty_cache()
         configs["note"] = ("BASELINE configs 2 (10 min 44.1 kHz: 26.46 M samples, 2 646 frames) and 5 (1000 x 1 min 96 kHz clips in one "
                            "launch set: 5.76 G samples) on the entry points of the step: ms = host wall time per call over "
-                           "back-to-back calls between two synchronisations, kernels_ms = the kernels' HIP-event times.  A stream "
+                           "back-to-back calls between two synchronisations, kernels_ms = the kernels' HIP-event times; step = encode + "
+                           "decode per step, steps back to back, as `value` is timed.  A stream "
                            "of few frames cannot be faster than ONE frame's serial decode (a frame is one bit stream): 0.41 ms "
                            "from the frame index alone (DESIGN.md section 4); with_segment_index: x3_encode_dev_seg + "
                            "x3_decode_dev_seg, the frames' stretches decoded side by side")
