@@ -168,6 +168,31 @@ def test_segmented_decode_of_a_batch_of_clips(ctx, x3):
     assert ctx.decode_dev_seg(d_out, pos, d_off, F, p, d_back, n, d_seg, sb, n_per_clip=n_per, n_clips=n_clips) == 0
     assert ctx.decode_result() == (0, F, 0, n)
     assert np.array_equal(ctx.download(d_back, 2 * n, np.int16), wav)
+    # clips SHORTER than a frame (6 000 samples: 300 of the parameters' 500 blocks): the index's pitch follows the parameters,
+    # so x3_seg_index_entries, the encoder and the decoder agree on the layout whatever the clips' lengths are
+    n_clips, n_per, sb = 9, 6_000, 32
+    wav = np.concatenate([x3.synth(2, 900 + c, 0, n_per) for c in range(n_clips)])
+    n = wav.size
+    L = x3.lib()
+    F = L.x3_num_frames(n_per, C.byref(p)) * n_clips
+    assert F == n_clips
+    cap = L.x3_encode_bound(n_per, C.byref(p)) * n_clips
+    ne = L.x3_seg_index_entries(F, C.byref(p), sb)
+    assert ne == 1 + F * 15
+    d_wav2 = ctx.alloc(2 * n + 64); d_out2 = ctx.alloc(cap + 16); d_off2 = ctx.alloc(8 * (F + 1)); d_back2 = ctx.alloc(2 * n)
+    d_seg2 = ctx.alloc(8 * ne); d_seg3 = ctx.alloc(8 * ne)
+    ctx.upload(d_wav2, wav)
+    assert ctx.encode_dev_seg(d_wav2, n_per, p, d_out2, cap, d_seg2, sb, 0, d_off2, n_clips=n_clips) == 0
+    rc, pos2, _ = ctx.encode_result()
+    assert rc == 0
+    assert ctx.decode_dev_seg(d_out2, pos2, d_off2, F, p, d_back2, n, d_seg3, sb, record=True, n_per_clip=n_per, n_clips=n_clips) == 0
+    assert ctx.decode_result() == (0, F, 0, n)
+    a, b = ctx.download(d_seg2, 8 * ne, np.uint64), ctx.download(d_seg3, 8 * ne, np.uint64)
+    assert np.array_equal(a, b) and int((a[1:].reshape(F, 15) != 0).sum(axis=1).max()) == 9   # (blocks 32 .. 288 of 300)
+    ctx.upload(d_back2, np.zeros(n, dtype=np.int16))
+    assert ctx.decode_dev_seg(d_out2, pos2, d_off2, F, p, d_back2, n, d_seg2, sb, n_per_clip=n_per, n_clips=n_clips) == 0
+    assert ctx.decode_result() == (0, F, 0, n) and ctx.get_option("last_seg_stretches") >= 2
+    assert np.array_equal(ctx.download(d_back2, 2 * n, np.int16), wav)
 
 
 @pytest.mark.parametrize("sb", [32, 64, 128])

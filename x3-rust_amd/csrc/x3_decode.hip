@@ -32,6 +32,7 @@ int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint6
     g.clip_stride = batch->clip_stride;
     g.fpc = (uint32_t)fpc;
   }
+  c->last_seg_stretches = 0;
   if ((rc = ensure(c, c->dec_meta, F * sizeof(X3FrameMeta)))) return rc;
   if (!d_status) {
     if ((rc = ensure(c, c->dec_status, F * sizeof(int32_t)))) return rc;
@@ -108,7 +109,9 @@ int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint6
       X3SegArgs sg{nullptr, nullptr, 0u, 1u, 0u, 1u};
       uint64_t groups = (F + 63) / 64;
       if (seg && seg->mode && seg->d_index && seg->seg_blocks) {
-        const uint64_t bpf = (std::min<uint64_t>(dp.spf, d_wav_offsets ? dp.spf : g.n_per_clip) + X3S_BL - 2) / X3S_BL;  // blocks of the longest frame
+        // (the index's pitch follows the PARAMETERS -- blocks of a full frame -- not the call: x3_seg_index_entries, the
+        // encoder and this launch must agree on it whatever the clips' lengths are)
+        const uint64_t bpf = (dp.spf + X3S_BL - 1) / X3S_BL;
         const uint64_t nidx = (bpf + seg->seg_blocks - 1) / seg->seg_blocks;   // stretches the index can tell apart
         if (nidx >= 2) {
           sg.pitch = (uint32_t)(nidx - 1);

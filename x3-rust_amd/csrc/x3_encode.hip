@@ -162,7 +162,7 @@ int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3
       wa.seg_log2 = 0;
       wa.seg_pitch = 0;
       if (seg.d_index && seg.seg_blocks >= 4 && (seg.seg_blocks & (seg.seg_blocks - 1)) == 0) {
-        const uint64_t bpf = (std::min<uint64_t>(spf, b->n_per_clip) + 18) / 20;   // blocks of the longest frame (<= 512 here)
+        const uint64_t bpf = (spf + 19) / 20;   // blocks of a full frame (<= 512 here): the pitch follows the parameters, not the call
         const uint64_t nidx = (bpf + seg.seg_blocks - 1) / seg.seg_blocks;
         if (nidx >= 2 && !tab) {
           wa.seg = reinterpret_cast<uint2*>(seg.d_index);
