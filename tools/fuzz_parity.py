@@ -16,6 +16,8 @@ sys.path.insert(0, os.path.join(ROOT, "x3-rust_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import x3hip
+if os.environ.get("X3HIP_LIB"):
+    x3hip.LIB_PATH = os.environ["X3HIP_LIB"]
 import oracle_lib as O
 
 ctx = None   # the x3hip.Context under test (set by run())
@@ -559,6 +561,31 @@ def run(seed=1, minutes=None, trials=None, families="egdbaf", only=-1, context=N
     own = context is None
     ctx = context if context is not None else x3hip.Context(0)
     t_end = time.time() + 60 * minutes if minutes is not None else None
+    trace = open(os.environ["X3_FUZZ_TRACE"], "w") if os.environ.get("X3_FUZZ_TRACE") else None
+    if os.environ.get("X3_FUZZ_TRACE_CALLS"):   # every Context call of the trial(s), appended before it is made
+        calls = open(os.environ["X3_FUZZ_TRACE_CALLS"], "a")
+
+        def brief(v):
+            if isinstance(v, np.ndarray):
+                return "ndarray(%s,%d)" % (v.dtype, v.size)
+            if isinstance(v, (list, tuple)) and len(v) > 8:
+                return "%s[%d]" % (type(v).__name__, len(v))
+            if isinstance(v, int) and v > 1 << 32:
+                return hex(v)
+            return repr(v)[:80]
+
+        def wrap(name, fn):
+            def g(*a, **k):
+                calls.write("%s(%s)\n" % (name, ", ".join([brief(v) for v in a] + ["%s=%s" % (q, brief(v)) for q, v in k.items()])))
+                calls.flush()
+                r = fn(*a, **k)
+                if name == "alloc":
+                    calls.write("  -> %s\n" % brief(r)); calls.flush()
+                return r
+            return g
+        for name in dir(ctx):
+            if not name.startswith("_") and callable(getattr(ctx, name)):
+                setattr(ctx, name, wrap(name, getattr(ctx, name)))
     trial = 0
     counts = {k: 0 for k in fams}
     try:
@@ -567,6 +594,8 @@ def run(seed=1, minutes=None, trials=None, families="egdbaf", only=-1, context=N
                 trial = only
             rng = np.random.default_rng([seed, trial])
             k = families[int(rng.integers(0, len(families)))]
+            if trace is not None:     # (a trial that kills the process -- a GPU memory fault -- leaves its number here)
+                trace.seek(0); trace.write("%d %d %s\n" % (seed, trial, k)); trace.flush()
             try:
                 fams[k](rng, (seed, trial))
             except Exception:

@@ -60,9 +60,9 @@ __global__ void x3_bitreader_op_kernel(const uint8_t* __restrict__ array, uint32
 extern "C" void x3_bitreader_free(x3_bitreader* b) {
   if (!b) return;
   if (b->c) (void)hipSetDevice(b->c->device);
-  if (b->d_array) (void)hipFree(b->d_array);
-  if (b->d_state) (void)hipFree(b->d_state);
-  if (b->d_out) (void)hipFree(b->d_out);
+  if (b->d_array) (void)x3_dfree(b->d_array);
+  if (b->d_state) (void)x3_dfree(b->d_state);
+  if (b->d_out) (void)x3_dfree(b->d_out);
   if (b->h_out) (void)hipHostFree(b->h_out);
   if (b->h_state) (void)hipHostFree(b->h_state);
   delete b;
@@ -88,8 +88,8 @@ extern "C" int x3_bitreader_new(x3_ctx* c, const uint8_t* array, uint64_t len, x
   x3_bitreader* b = new x3_bitreader();
   b->c = c;
   b->len = len;
-  if (hipMalloc(&b->d_array, len + 16) != hipSuccess || hipMalloc(&b->d_state, sizeof(X3ReaderState)) != hipSuccess ||
-      hipMalloc(&b->d_out, (2 + 64) * sizeof(uint32_t)) != hipSuccess ||
+  if (x3_dmalloc(&b->d_array, len + 16) != hipSuccess || x3_dmalloc(&b->d_state, sizeof(X3ReaderState)) != hipSuccess ||
+      x3_dmalloc(&b->d_out, (2 + 64) * sizeof(uint32_t)) != hipSuccess ||
       hipHostMalloc(&b->h_out, (2 + 64) * sizeof(uint32_t)) != hipSuccess ||
       hipHostMalloc(&b->h_state, sizeof(X3ReaderState)) != hipSuccess) {
     c->last_error = "x3_bitreader_new: out of memory";

@@ -11,12 +11,12 @@ int ensure(x3_ctx* c, DevBuf& b, size_t bytes) {
     c->last_error = "x3_graph: a device buffer would have to grow while the calls are being recorded -- make the same calls once before x3_graph_begin";
     return X3_ERR_BAD_ARG;
   }
-  if (b.p) HIPCHK(c, hipFree(b.p));
+  if (b.p) HIPCHK(c, x3_dfree(b.p));
   b.p = nullptr;
   b.cap = 0;
   size_t want = std::max(bytes, (size_t)4096);
   want = (want + 255) & ~(size_t)255;
-  HIPCHK(c, hipMalloc(&b.p, want));
+  HIPCHK(c, x3_dmalloc(&b.p, want));
   b.cap = want;
   return X3_OK;
 }
@@ -113,15 +113,15 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
   }
   HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-  HIPCHK(c, hipMalloc(&c->d_xpow, X3_XP_SIZE * sizeof(uint16_t)));
+  HIPCHK(c, x3_dmalloc(&c->d_xpow, X3_XP_SIZE * sizeof(uint16_t)));
   // status (4 ints) and stats (6 + end_pos) share one 128-byte block: one memset, one copy back
-  HIPCHK(c, hipMalloc(&c->d_status, 128));
+  HIPCHK(c, x3_dmalloc(&c->d_status, 128));
   c->d_stats = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->d_status) + 32);
   c->d_end_pos = c->d_stats + 6;
-  HIPCHK(c, hipMalloc(&c->d_summary, sizeof(X3DecodeSummary)));
-  HIPCHK(c, hipMalloc(&c->d_pace, X3_PACE_WORDS * sizeof(uint32_t)));
+  HIPCHK(c, x3_dmalloc(&c->d_summary, sizeof(X3DecodeSummary)));
+  HIPCHK(c, x3_dmalloc(&c->d_pace, X3_PACE_WORDS * sizeof(uint32_t)));
   HIPCHK(c, hipMemset(c->d_pace, 0, X3_PACE_WORDS * sizeof(uint32_t)));
-  HIPCHK(c, hipMalloc(&c->d_crc, 16));
+  HIPCHK(c, x3_dmalloc(&c->d_crc, 16));
   HIPCHK(c, hipHostMalloc(&c->h_status, 128));
   c->h_stats = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_status) + 32);
   HIPCHK(c, hipHostMalloc(&c->h_summary, sizeof(X3DecodeSummary)));
@@ -164,7 +164,7 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
           }
         }
       }
-      HIPCHK(c, hipMalloc(&c->d_xk2, k2.size() * sizeof(uint32_t)));
+      HIPCHK(c, x3_dmalloc(&c->d_xk2, k2.size() * sizeof(uint32_t)));
       HIPCHK(c, hipMemcpy(c->d_xk2, k2.data(), k2.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     // T[j][v] = crc0 of byte v followed by j zero bytes = v * x^(8j+16) mod P
@@ -188,7 +188,7 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
           k = ((k << 1) ^ ((k & 0x8000u) ? 0x11021u : 0u)) & 0xFFFFu;
         }
       }
-      HIPCHK(c, hipMalloc(&c->d_kx64, kx.size() * sizeof(uint32_t)));
+      HIPCHK(c, x3_dmalloc(&c->d_kx64, kx.size() * sizeof(uint32_t)));
       HIPCHK(c, hipMemcpy(c->d_kx64, kx.data(), kx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     {
@@ -200,12 +200,12 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
           const uint32_t sh = gf_xpow_host(8ull * k + shifts[t]);
           for (int v = 0; v < 256; ++v) ct[((size_t)t * 4 + k) * 256 + v] = (uint16_t)gf_mul_host((uint32_t)v, sh);
         }
-      HIPCHK(c, hipMalloc(&c->d_chktab, ct.size() * sizeof(uint16_t)));
+      HIPCHK(c, x3_dmalloc(&c->d_chktab, ct.size() * sizeof(uint16_t)));
       HIPCHK(c, hipMemcpy(c->d_chktab, ct.data(), ct.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
       // x^(-8k): x has order 32767 modulo P (P = (x + 1) * a primitive polynomial of degree 15)
       std::vector<uint16_t> xi(X3_CHECK_XINV_N);
       for (uint32_t k = 0; k < X3_CHECK_XINV_N; ++k) xi[k] = (uint16_t)gf_xpow_host((32767ull * 8 - 8ull * k) % 32767ull);
-      HIPCHK(c, hipMalloc(&c->d_xinv8, xi.size() * sizeof(uint16_t)));
+      HIPCHK(c, x3_dmalloc(&c->d_xinv8, xi.size() * sizeof(uint16_t)));
       HIPCHK(c, hipMemcpy(c->d_xinv8, xi.data(), xi.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
     {
@@ -227,10 +227,10 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
       }
       // x^(-16k), k < 128 (x has order 32767 modulo P): undoes the zero bytes behind a payload in its last image row
       for (uint64_t k = 0; k < 128; ++k) wt[2560 + k] = (uint16_t)gf_xpow_host((32767ull * 16 - 16ull * k) % 32767ull);
-      HIPCHK(c, hipMalloc(&c->d_wtab, X3W_TAB_BYTES));
+      HIPCHK(c, x3_dmalloc(&c->d_wtab, X3W_TAB_BYTES));
       HIPCHK(c, hipMemcpy(c->d_wtab, wt.data(), X3W_TAB_BYTES, hipMemcpyHostToDevice));
     }
-    HIPCHK(c, hipMalloc(&c->d_crctab, tab.size() * sizeof(uint16_t)));
+    HIPCHK(c, x3_dmalloc(&c->d_crctab, tab.size() * sizeof(uint16_t)));
     HIPCHK(c, hipMemcpy(c->d_crctab, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   }
   return X3_OK;
@@ -272,22 +272,22 @@ extern "C" void x3_ctx_destroy(x3_ctx* c) {
   for (DevBuf* b : {&c->in, &c->out, &c->in_more[0], &c->in_more[1], &c->out_more[0], &c->out_more[1], &c->frame_bytes, &c->frame_off, &c->dec_status, &c->dec_cstatus, &c->dec_meta, &c->wav_off,
                     &c->seg_crc, &c->desc, &c->idx_cand, &c->idx_keys, &c->idx_vals, &c->idx_J, &c->idx_S,
                     &c->idx_L, &c->idx_sum, &c->idx_wg, &c->idx_sorted, &c->idx_scan, &c->dense_list, &c->lb_desc, &c->src_tab})
-    if (b->p) (void)hipFree(b->p);
+    if (b->p) (void)x3_dfree(b->p);
   for (auto& t : c->timers) {
     for (auto& e : t.used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto& e : t.pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   }
-  (void)hipFree(c->d_xpow);
-  (void)hipFree(c->d_xk2);
-  (void)hipFree(c->d_wtab);
-  (void)hipFree(c->d_crctab);
-  (void)hipFree(c->d_kx64);
-  (void)hipFree(c->d_chktab);
-  (void)hipFree(c->d_xinv8);
-  (void)hipFree(c->d_status);
-  (void)hipFree(c->d_summary);
-  (void)hipFree(c->d_pace);
-  (void)hipFree(c->d_crc);
+  (void)x3_dfree(c->d_xpow);
+  (void)x3_dfree(c->d_xk2);
+  (void)x3_dfree(c->d_wtab);
+  (void)x3_dfree(c->d_crctab);
+  (void)x3_dfree(c->d_kx64);
+  (void)x3_dfree(c->d_chktab);
+  (void)x3_dfree(c->d_xinv8);
+  (void)x3_dfree(c->d_status);
+  (void)x3_dfree(c->d_summary);
+  (void)x3_dfree(c->d_pace);
+  (void)x3_dfree(c->d_crc);
   (void)hipHostFree(c->h_status);
   if (c->h_walk) (void)hipHostFree(c->h_walk);
   (void)hipHostFree(c->h_summary);
@@ -775,14 +775,14 @@ extern "C" int x3_synth_dev(x3_ctx* c, int kind, uint64_t seed, uint64_t start, 
 extern "C" int x3_dev_alloc(x3_ctx* c, uint64_t bytes, void** d_ptr) {
   if (!c || !d_ptr) return X3_ERR_BAD_ARG;
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipMalloc(d_ptr, bytes ? bytes : 256));
+  HIPCHK(c, x3_dmalloc(d_ptr, bytes ? bytes : 256));
   return X3_OK;
 }
 extern "C" int x3_dev_free(x3_ctx* c, void* d_ptr) {
   if (!c) return X3_ERR_BAD_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipFree(d_ptr));
+  HIPCHK(c, x3_dfree(d_ptr));
   return X3_OK;
 }
 extern "C" int x3_dev_upload(x3_ctx* c, void* d_dst, const void* src, uint64_t bytes) {

@@ -580,6 +580,7 @@ int decode_frames_host(x3_ctx* c, const uint8_t* x3, uint64_t len, const HostWal
   if ((rc = ensure(c, c->out, (w.nsamp + 65536) * sizeof(int16_t)))) return rc;
   // (through pinned memory: a copy from pageable memory is staged by the runtime under a lock it shares with the large
   // pageable copies the chunked front ends have in flight on other threads -- 0.2-0.4 ms per call when they collide)
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // (the copy before this one has left the pinned block)
   if (c->h_walk_cap < 2 * F * sizeof(uint64_t)) {
     if (c->h_walk) HIPCHK(c, hipHostFree(c->h_walk));
     c->h_walk = nullptr;
@@ -588,7 +589,6 @@ int decode_frames_host(x3_ctx* c, const uint8_t* x3, uint64_t len, const HostWal
     HIPCHK(c, hipHostMalloc(&c->h_walk, want));
     c->h_walk_cap = want;
   }
-  HIPCHK(c, hipStreamSynchronize(c->stream));  // (the copy before this one has left the pinned block)
   std::memcpy(c->h_walk, w.offs.data(), F * sizeof(uint64_t));
   std::memcpy((uint64_t*)c->h_walk + F, w.woffs.data(), F * sizeof(uint64_t));
   HIPCHK(c, hipMemcpyAsync(c->frame_off.p, c->h_walk, F * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
@@ -666,11 +666,11 @@ static int decode_stream_host_chunked(x3_ctx* c, const uint8_t* x3, uint64_t len
         if (k >= 3 && !decoded.wait_for(k - 2)) break;
         DevBuf& buf = (k % 3) ? c->in_more[k % 3 - 1] : c->in;
         if (buf.cap < ck.hw.end_pos + 16) {
-          if (buf.p) e = hipFree(buf.p);
+          if (buf.p) e = x3_dfree(buf.p);
           buf.p = nullptr;
           buf.cap = 0;
           const size_t want = (size_t)((ck.hw.end_pos * (grow ? 2 : 1) + 16 + (ck.hw.end_pos >> 3) + 255) & ~255ull);
-          if (e == hipSuccess) e = hipMalloc(&buf.p, want);
+          if (e == hipSuccess) e = x3_dmalloc(&buf.p, want);
           if (e == hipSuccess) buf.cap = want;
         }
         if (e == hipSuccess) e = hipMemcpyAsync(buf.p, x3 + a, ck.hw.end_pos, hipMemcpyHostToDevice, c->ul_stream);

@@ -785,8 +785,12 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
   // offsets are relative to this lane's first 16-byte chunk (a frame is < 64 KB): a 64-bit pointer per lane,
   // 32-bit arithmetic on everything else, streams of any length
   const uint64_t abs_bits = (uint64_t)adj + p0 + 2u;
-  const uint8_t* __restrict__ const x3b = (x3 - adj) + (abs_bits & ~15ull);
-  const uint32_t v_bits = (uint32_t)(abs_bits & 15u);    // first block header
+  // (the first chunk: the one with the first block header, or -- a payload of two bytes that ends on a 16-byte boundary --
+  // the one with the payload's last byte: the chunk behind it may be the first one behind the stream; x3_decode_split_kernel.h)
+  const uint64_t abs_last = (uint64_t)adj + p0 + plen - 1u;
+  const uint64_t abs_base = (abs_bits < abs_last ? abs_bits : abs_last) & ~15ull;
+  const uint8_t* __restrict__ const x3b = (x3 - adj) + abs_base;
+  const uint32_t v_bits = (uint32_t)(abs_bits - abs_base);   // first block header (0..16)
   const uint32_t v_end = v_bits - 2u + plen;               // end of the payload
   const uint32_t v_last = (v_end - 1u) & ~15u;             // last 16-byte chunk that holds payload
   uint32_t v_next = 0;
@@ -820,7 +824,7 @@ x3_decode_fast_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uin
     v_next += 128;
   }
   // window: w0 holds `s` unconsumed bits (its low s bits), then w1, w2; widx = ring index of w0
-  const uint32_t skip = (uint32_t)(v_bits & 15u);
+  const uint32_t skip = v_bits;                        // (0..16)
   const uint32_t a0 = skip & 3u;
   uint32_t widx = (skip >> 2) - (a0 == 0 ? 1u : 0u);   // a0 == 0: start with a fully consumed w0
   uint32_t s = (32u - 8u * a0) & 31u;

@@ -68,6 +68,25 @@
 #ifndef X3S_THIN
 #define X3S_THIN 0
 #endif
+// Round 5: the input ring TRANSPOSED -- word slot s of lane l at dword s * 64 + l instead of l * 32 + s.  With a row of 128
+// bytes per lane the 64 lanes' rows start on two banks only (lane * 32 dwords: bank 0 or 32), and lanes that are at the same
+// slot of their rows -- they read at similar rates -- pile onto one bank pair: 42 % of the decoder's LDS cycles were bank
+// conflicts (profiles/r5/pmc_instruction_mix.txt).  Transposed, lane l only ever touches bank l: the parser's read of the next
+// window word and the parks are conflict-free whatever the lanes' positions.  Same instruction count (the byte counter
+// steps by 256 instead of 4; a park is four dword rows = two ds_write2st64_b32 instead of one ds_write_b128).
+#ifndef X3S_RING_T
+#define X3S_RING_T 0
+#endif
+#if X3S_RING_T
+#define X3S_QSH 8            // log2 of the byte distance of two ring words of a lane
+#define X3S_QMASK 0x1F00u    // (slot & 31) << 8
+#else
+#define X3S_QSH 2
+#define X3S_QMASK 124u
+#endif
+#if X3S_RING_T && X3S_SWP
+#error "the software-pipelined pair loop (X3S_SWP) is written for the untransposed ring"
+#endif
 #ifndef X3S_PAIR_ASM2
 #define X3S_PAIR_ASM2 1      // the parser's pair block also holds the shift's sign and the ring address (one s_nop per pair less)
 #endif
@@ -278,7 +297,11 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   // slot ~j & 31 (descending): the address of a word is then ONE v_and_or_b32 on a byte counter that a shift of
   // the window decrements with one v_lshl_add_u32.  (Lanes are at different places in their rows, so the aligned
   // rows do not line the reads up on one bank.)
+#if X3S_RING_T
+  __shared__ __attribute__((aligned(8192))) uint32_t ring[64 * X3_DEC_RING_DW];   // [slot][lane]; 8 KB aligned: slot bits 8..12 of the address are the ring's own
+#else
   __shared__ __attribute__((aligned(128))) uint32_t ring[64 * X3_DEC_RING_DW];
+#endif
   __shared__ __attribute__((aligned(256))) uint32_t outs[64 * X3S_RING_DW];
   __shared__ __attribute__((aligned(16))) uint32_t xfer[2 * X3S_XROWS * 64];
   __shared__ uint32_t s_over[64];  // parser -> valuer: the frame was read beyond its payload (x3_decode_replay.h)
@@ -438,16 +461,28 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
   uint32_t remaining = samples ? samples - 1u : 0u;
 
   // ---- the input ring of this lane's frame (the parser fills and reads it)
+#if X3S_RING_T
+  const uint32_t row_base = x3_lds_addr(ring) + 4u * lane;   // LDS byte address of this lane's column (bits 8..12 zero)
+#define X3S_RING_WORD(j) ring[((~(j)) & 31u) * 64u + lane]
+#else
   uint32_t* const row = ring + lane * X3_DEC_RING_DW;
   const uint32_t row_base = (uint32_t)(uintptr_t)row;  // LDS byte address of the row (low 7 bits zero)
+#define X3S_RING_WORD(j) row[~(j) & 31u]
+#endif
   // words are parked BIG-ENDIAN
   const uint32_t adj = (uint32_t)(reinterpret_cast<uintptr_t>(x3) & 15u);
   // offsets are relative to this lane's first 16-byte chunk (a frame is < 64 KB): a 64-bit pointer per lane,
   // 32-bit arithmetic on everything else, streams of any length
   const uint64_t abs_bits = (uint64_t)adj + p0 + (hb >> 3);   // (a byte position; hb = 16 without an index: behind the first sample)
   const uint32_t ebits = hb & 7u;                             // ... and the bits of that byte in front of the header
-  const uint8_t* __restrict__ const x3b = (x3 - adj) + (abs_bits & ~15ull);
-  const uint32_t v_bits = (uint32_t)(abs_bits & 15u);      // first block header
+  // The first chunk is the one that holds that byte -- or the payload's LAST byte, where the bit stream starts at the very
+  // end of the payload (a frame of one sample; an index entry that points there) on a 16-byte boundary: the chunk behind
+  // the payload may be the first one behind the stream (found by the guard pages of x3_fence.h: until round 5 such a lane
+  // read its eight chunks from there, 128 bytes that nobody used and that nobody may have mapped).  hb >> 3 <= plen, plen >= 2.
+  const uint64_t abs_last = (uint64_t)adj + p0 + plen - 1u;
+  const uint64_t abs_base = (abs_bits < abs_last ? abs_bits : abs_last) & ~15ull;
+  const uint8_t* __restrict__ const x3b = (x3 - adj) + abs_base;
+  const uint32_t v_bits = (uint32_t)(abs_bits - abs_base);   // first block header (0..16)
   const uint32_t v_end = v_bits - (hb >> 3) + plen;          // end of the payload
   const int32_t v_rel = 8 * (int32_t)(hb >> 3) - 8 * (int32_t)v_bits;   // payload bit = ring bit + v_rel
   const uint32_t v_last = (v_end - 1u) & ~15u;               // last 16-byte chunk that holds payload
@@ -466,8 +501,17 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     const uint32_t w[4] = {c.x, c.y, c.z, c.w};
     // words wr_abs .. wr_abs+3 -> slots ~wr_abs & 31 downwards = the aligned 16-byte block at slot ~(wr_abs+3) & 31:
     // byte offset (-4 * wr_abs - 16) & 112 of the 128-byte aligned row
+#if X3S_RING_T
+    // ... transposed: slots g .. g + 3, g = ~(wr_abs + 3) & 31 (a multiple of four), 256 bytes apart in this lane's column
+    uint32_t* const q = ring + ((~(wr_abs + 3u)) & 31u) * 64u + lane;
+    q[0] = x3_bswap32(w[3]);
+    q[64] = x3_bswap32(w[2]);
+    q[128] = x3_bswap32(w[1]);
+    q[192] = x3_bswap32(w[0]);
+#else
     x3_lds_write_b128(x3_and_or(0u - 4u * wr_abs - 16u, 112u, row_base), x3_bswap32(w[3]), x3_bswap32(w[2]),
                       x3_bswap32(w[1]), x3_bswap32(w[0]));
+#endif
     wr_abs += 4;
   };
   // Round 5 (-DX3S_DENSE_AHEAD=0: off): a group that holds a DENSE frame -- a payload beyond what the encoder's image takes,
@@ -783,20 +827,20 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
     // window: w0 holds `s` unconsumed bits (its low s bits), then w1; widx = ring index of w0.  A pair of
     // codewords is at most 32 bits, so one peek never reaches beyond w1; wn is the word behind w1, re-read from
     // the ring after every consume (the read has a whole pair's time to arrive before the next shift needs it)
-    const uint32_t skip = v_bits & 15u;
+    const uint32_t skip = v_bits;                               // (0..16: see abs_base)
     const uint32_t a0 = 8u * (skip & 3u) + ebits;               // bits of the first word in front of the header
     const uint32_t widx0 = (skip >> 2) - (a0 == 0 ? 1u : 0u);  // a0 == 0: start with a fully consumed w0
     uint32_t s = (32u - a0) & 31u;
-    uint32_t w0 = row[~widx0 & 31u], w1 = row[~(widx0 + 1u) & 31u];
+    uint32_t w0 = X3S_RING_WORD(widx0), w1 = X3S_RING_WORD(widx0 + 1u);
 #if X3S_SWP
     // (software-pipelined pair loop: a window of three words, wn is the word behind w2)
-    uint32_t w2 = row[~(widx0 + 2u) & 31u];
-    uint32_t wn = row[~(widx0 + 3u) & 31u];
+    uint32_t w2 = X3S_RING_WORD(widx0 + 2u);
+    uint32_t wn = X3S_RING_WORD(widx0 + 3u);
     uint32_t qb = 4u * ~(widx0 + 3u);
 #else
-    uint32_t wn = row[~(widx0 + 2u) & 31u];
-    // qb = 4 * ~(widx + 2): the byte offset of wn's slot before masking; widx itself is only needed by service()
-    uint32_t qb = 4u * ~(widx0 + 2u);
+    uint32_t wn = X3S_RING_WORD(widx0 + 2u);
+    // qb = (4 or 256) * ~(widx + 2): the byte offset of wn's slot before masking; widx itself is only needed by service()
+    uint32_t qb = (1u << X3S_QSH) * ~(widx0 + 2u);
 #endif
     // consume -nn (<= 32) bits, given as the NEGATIVE count (that is what the codeword walk below has at hand);
     // the word shift is v_bfi with a VGPR mask (see x3_decode_fast_kernel)
@@ -811,9 +855,9 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       w1 = x3_bfi(m, wn, w1);
 #endif
       uint32_t addr;
-      asm("v_lshl_add_u32 %0, %2, 2, %0\n\t"                 // widx += 1 on a shift: qb -= 4
+      asm("v_lshl_add_u32 %0, %2, " X3S_STR(X3S_QSH) ", %0\n\t"   // widx += 1 on a shift: qb -= 4 (256: transposed ring)
           "v_and_or_b32 %1, %0, %3, %4"
-          : "+v"(qb), "=v"(addr) : "v"(m), "v"(124u), "v"(row_base));
+          : "+v"(qb), "=v"(addr) : "v"(m), "v"(X3S_QMASK), "v"(row_base));
       wn = x3_lds_read_b32(addr);
       // keep the read HERE: left to itself the scheduler sinks it to just in front of the next shift, where its
       // whole LDS latency is waited for
@@ -823,7 +867,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
 #if X3S_SWP
     auto ring_index = [&]() -> uint32_t { return ~((uint32_t)((int32_t)qb >> 2)) - 3u; };  // of w0
 #else
-    auto ring_index = [&]() -> uint32_t { return ~((uint32_t)((int32_t)qb >> 2)) - 2u; };  // of w0
+    auto ring_index = [&]() -> uint32_t { return ~((uint32_t)((int32_t)qb >> X3S_QSH)) - 2u; };  // of w0
 #endif
 
     const uint32_t k_tab = (p.k[1] << 16) | (p.k[2] << 24);  // log2(level) by ftype
@@ -941,11 +985,11 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
                 "v_bfe_u32 %[v2], %[t2], %[nn2], %[fw]\n\t"
                 "v_add3_u32 %[s2], %[s], %[nn1], %[nn2]\n\t"
                 "v_ashrrev_i32 %[m], 31, %[s2]\n\t"
-                "v_lshl_add_u32 %[qb], %[m], 2, %[qb]\n\t"
+                "v_lshl_add_u32 %[qb], %[m], " X3S_STR(X3S_QSH) ", %[qb]\n\t"
                 "v_and_or_b32 %[addr], %[qb], %[c124], %[rowb]"
                 : [z1] "=&v"(z1), [v1] "=&v"(v1), [z2] "=&v"(z2), [v2] "=&v"(v2), [nn1] "=&v"(nn1), [nn2] "=&v"(nn2),
                   [t2] "=&v"(t2), [s2] "=&v"(s2), [m] "=&v"(m), [addr] "=&v"(addr), [qb] "+v"(qb)
-                : [t] "v"(t), [zmask] "v"(zmask), [nwidth] "v"(nwidth), [s] "v"(s), [fw] "v"(fw), [c124] "v"(124u), [rowb] "v"(row_base));
+                : [t] "v"(t), [zmask] "v"(zmask), [nwidth] "v"(nwidth), [s] "v"(s), [fw] "v"(fw), [c124] "v"(X3S_QMASK), [rowb] "v"(row_base));
             {
               const uint32_t wn_new = x3_lds_read_b32(addr);
               __builtin_amdgcn_sched_barrier(0);   // (the read stays here: see consume_to)

@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "../../include/x3hip.h"
+#include "x3_fence.h"        // device allocations (guard pages under X3HIP_FENCE)
 #include "x3_device.h"
 #include "x3_tables.h"
 

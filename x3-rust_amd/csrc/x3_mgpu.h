@@ -187,8 +187,8 @@ extern "C" void x3_shard_destroy(x3_shard* s) {
     if (s->h_stage[k]) (void)hipHostFree(s->h_stage[k]);
     if (s->ev_stage[k]) (void)hipEventDestroy(s->ev_stage[k]);
   }
-  if (s->d_mine) (void)hipFree(s->d_mine);
-  if (s->d_lengths) (void)hipFree(s->d_lengths);
+  if (s->d_mine) (void)x3_dfree(s->d_mine);
+  if (s->d_lengths) (void)x3_dfree(s->d_lengths);
   if (s->h_lengths) (void)hipHostFree(s->h_lengths);
   delete s;
 }
@@ -215,7 +215,7 @@ extern "C" int x3_shard_create(x3_ctx* c, const uint8_t id[X3_SHARD_ID_BYTES], i
     x3_shard_destroy(s);
     return X3_ERR_HIP;
   }
-  if (hipMalloc(&s->d_mine, 16) != hipSuccess || hipMalloc(&s->d_lengths, sizeof(uint64_t) * (size_t)world) != hipSuccess ||
+  if (x3_dmalloc(&s->d_mine, 16) != hipSuccess || x3_dmalloc(&s->d_lengths, sizeof(uint64_t) * (size_t)world) != hipSuccess ||
       hipHostMalloc(&s->h_lengths, sizeof(uint64_t) * (size_t)world) != hipSuccess ||
       hipStreamCreateWithFlags(&s->gstream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming) != hipSuccess ||
@@ -447,7 +447,7 @@ extern "C" void x3_mgpu_destroy(x3_mgpu* m) {
   if (!m) return;
   if (!m->ctx.empty() && m->ctx[0] && m->whole.p) {
     (void)hipSetDevice(m->ctx[0]->device);
-    (void)hipFree(m->whole.p);
+    (void)x3_dfree(m->whole.p);
   }
   // communicators are torn down by all ranks together
   x3_mgpu_parallel((int)m->shard.size(), [&](int g) { x3_shard_destroy(m->shard[g]); });

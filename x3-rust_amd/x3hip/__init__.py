@@ -11,6 +11,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libx3hip.so")
+if os.environ.get("X3HIP_LIB"):   # (development: an experiment build of the same library, tools/variants.py)
+    LIB_PATH = os.environ["X3HIP_LIB"]
 
 OK = 0
 ERR_INVALID_ENCODING_THRESH = 4
