@@ -109,6 +109,10 @@ const char* x3_last_error(const x3_ctx* ctx);
  *                                          process-wide, effective when x3_ctx_create is the process's first use of the
  *                                          device): calls that end with a trip to the host come back ~20 us sooner
  *                                          (x3_decode_stream_dev on config 3: 0.82 -> 0.79 ms), a core is busy meanwhile
+ *   (environment only) X3HIP_FENCE=16      debugging: every device buffer of the library (its own and x3_dev_alloc's) is
+ *                                          mapped with unmapped pages on both sides and ends, rounded up to that many bytes,
+ *                                          at the end of its mapping; X3HIP_FENCE_FILL=<byte> fills it.  The kernels read
+ *                                          aligned 16-byte chunks, so 16 is the tightest fence (csrc/x3_fence.h)
  *   "wav_offsets_x4"                       1: a promise -- every d_wav_offsets[] passed to x3_decode_dev is a multiple of
  *                                          four samples (rows on 8-byte boundaries): such calls then take the three-wave
  *                                          decoder like the other layouts do; an offset that breaks the promise garbles
