@@ -97,13 +97,16 @@ __device__ __forceinline__ int32_t x3_frame_header_check(const uint32_t* __restr
 #ifndef X3_CHECK_SCHED_FENCE
 #define X3_CHECK_SCHED_FENCE 1
 #endif
+#include "x3_tables.h"   // X3_CHECK_STEP_ASM, X3_CHECK_TAB_U16 / _DW, X3_CHECK_XINV_N
 #ifndef X3_CHECK_MIN_WGS
-#define X3_CHECK_MIN_WGS 3
+// (workgroups per CU the register allocator plans for: with the step as an asm block it took 151 registers at 3 -- nothing
+// holds the allocator back below the bound -- against 92 before; 6 = 80 registers, three of its waves fit a SIMD beside the
+// decoder's as before)
+#define X3_CHECK_MIN_WGS (X3_CHECK_STEP_ASM ? 6 : 3)
 #endif
 // LDS tables (uint16, twelve rows of 256): T0[k][v] = v * x^(8k + 16) (crc0 of byte k of a big-endian dword: the header
 // CRC and the final reduction), M2[k][v] = v * x^(8k + 2048) and M4[k][v] = v * x^(8k + 4096) (a dword one / two rows of 64
 // dwords further from the end): 6 KB (round 2: sixteen row tables + two, 9 KB)
-#include "x3_tables.h"   // X3_CHECK_TAB_U16 / _DW, X3_CHECK_XINV_N
 
 // One WAVE per frame, waves walk the frames grid-stride (the tables are loaded once per workgroup).
 // Lane t takes the payload dwords t, t + 64, t + 128, ... (every load is one contiguous 256-byte run of the
@@ -166,6 +169,54 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
     return x3_lds_read_u16(tab_base + a0, 2048u + 1536u) ^ x3_lds_read_u16(tab_base + a1, 2048u + 1024u) ^
            x3_lds_read_u16(tab_base + a2, 2048u + 512u) ^ x3_lds_read_u16(tab_base + a3, 2048u);
   };
+#if X3_CHECK_STEP_ASM
+  // A two-row step in one asm block: A' = A * x^4096 ^ d0 * x^2048 ^ d1sw (d0 as loaded, d1sw byte-swapped): eight shifts
+  // that turn a byte into a table offset, eight look-ups, four three-input XORs on whole registers (the look-ups come back
+  // zero-extended) -- 12 vector instructions where the compiler's version has 14 and an s_nop or two.  (The block waits for
+  // its own reads: the compiler does not count LDS operations issued by an asm.)  `tab` is the kernel's only LDS variable, at
+  // address 0: the rows are immediate offsets.  A look-up's destination is its own address register (the address is read
+  // at issue; the compiler's code does the same).
+#define X3C_SH(dst, src, b) "v_lshlrev_b32_sdwa %[" dst "], %[one], %[" src "] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" b "\n\t"
+  auto step_first = [&](uint32_t d0, uint32_t d1sw) -> uint32_t {
+    uint32_t t0, t1, t2, t3, out;
+    asm(X3C_SH("t0", "d0", "3") X3C_SH("t1", "d0", "2") X3C_SH("t2", "d0", "1") X3C_SH("t3", "d0", "0")
+        "ds_read_u16 %[t0], %[t0] offset:2048\n\t"
+        "ds_read_u16 %[t1], %[t1] offset:2560\n\t"
+        "ds_read_u16 %[t2], %[t2] offset:3072\n\t"
+        "ds_read_u16 %[t3], %[t3] offset:3584\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_bitop3_b32 %[t0], %[t0], %[t1], %[t2] bitop3:0x96\n\t"
+        "v_bitop3_b32 %[out], %[t0], %[t3], %[d1] bitop3:0x96"
+        : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [out] "=&v"(out)
+        : [d0] "v"(d0), [d1] "v"(d1sw), [one] "s"(1u));
+    return out;
+  };
+  auto step_next = [&](uint32_t A, uint32_t d0, uint32_t d1sw) -> uint32_t {
+    uint32_t t0, t1, t2, t3, t4, t5, t6, t7;
+    asm(X3C_SH("t0", "d0", "3") X3C_SH("t1", "d0", "2") X3C_SH("t2", "d0", "1") X3C_SH("t3", "d0", "0")
+        "ds_read_u16 %[t0], %[t0] offset:2048\n\t"
+        "ds_read_u16 %[t1], %[t1] offset:2560\n\t"
+        X3C_SH("t4", "A", "0") X3C_SH("t5", "A", "1")
+        "ds_read_u16 %[t2], %[t2] offset:3072\n\t"
+        "ds_read_u16 %[t3], %[t3] offset:3584\n\t"
+        X3C_SH("t6", "A", "2") X3C_SH("t7", "A", "3")
+        "ds_read_u16 %[t4], %[t4] offset:4096\n\t"
+        "ds_read_u16 %[t5], %[t5] offset:4608\n\t"
+        "ds_read_u16 %[t6], %[t6] offset:5120\n\t"
+        "ds_read_u16 %[t7], %[t7] offset:5632\n\t"
+        "s_waitcnt lgkmcnt(4)\n\t"
+        "v_bitop3_b32 %[t0], %[t0], %[t1], %[t2] bitop3:0x96\n\t"
+        "v_bitop3_b32 %[t0], %[t0], %[t3], %[d1] bitop3:0x96\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_bitop3_b32 %[t0], %[t0], %[t4], %[t5] bitop3:0x96\n\t"
+        "v_bitop3_b32 %[A], %[t0], %[t6], %[t7] bitop3:0x96"
+        : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6),
+          [t7] "=&v"(t7), [A] "+v"(A)
+        : [d0] "v"(d0), [d1] "v"(d1sw), [one] "s"(1u));
+    return A;
+  };
+#undef X3C_SH
+#endif
   const uint64_t n_dw = (x3_len + 3) >> 2;
   const uint64_t waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
   // (the wave index through readfirstlane: the frame number is then provably uniform, and the frame offsets, spans,
@@ -302,11 +353,21 @@ x3_frame_check_kernel(const uint32_t* __restrict__ xw, uint64_t x3_len, const ui
               if (g2 == 0) {
                 if (rbase == 0) d0 = (d0 & and0) ^ xor0;
               }
+#if X3_CHECK_STEP_ASM
+              if (row + 2u >= R) {   // (whole wave, the frame's last pair of rows: a branch, not selects in every step)
+                __builtin_amdgcn_sched_barrier(0);
+                if (row + 1u >= R) d0 &= last_mask;                        // row is the last one
+                d1 &= row + 2u == R ? last_mask : 0u;                      // row + 1 is the last one, or behind it
+              }
+              if (tab_base != 0u) __builtin_trap();                        // (the asm's offsets are absolute; folded away)
+              A = row ? step_next(A, d0, x3_bswap32(d1)) : step_first(d0, x3_bswap32(d1));
+#else
               if (row + 1u >= R) d0 &= last_mask;                          // (whole wave) row is the last one
               if (row + 2u >= R) d1 &= row + 2u == R ? last_mask : 0u;     // (whole wave) row + 1 is the last one, or behind it
               uint32_t a2 = m2048_le(d0) ^ x3_bswap32(d1);
               if (row) a2 ^= m4096(A);
               A = a2;
+#endif
               rows_done = row + 2u;
             }
 #if X3_CHECK_SCHED_FENCE

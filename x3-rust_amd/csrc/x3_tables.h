@@ -21,6 +21,17 @@
 #define X3W_TAB_BYTES 5376u
 
 // ---- x3_frame_check_kernel (x3_decode_kernel.h): twelve rows of 256 uint16 (T0, M2, M4) and x^(-8k), k < 1024
+// X3_CHECK_STEP_ASM (round 5): the check kernel's two-row step as one asm block (x3_decode_kernel.h).
+// (Tried and dropped: the rows of bytes 1 and 3 loaded into the HIGH half of the register that holds the look-up of byte
+// 0 / 2, ds_read_u16_d16_hi, with those rows holding x^16 less -- four registers to XOR instead of eight.  The arithmetic is
+// right and the instruction exists, but with SRAM ECC -- gfx950 -- a d16 load does not preserve the other half: payload CRC
+// errors on every frame.)
+// Measured (profiles/r5/check_kernel_step_asm.txt): 12 instead of 18 vector instructions per step and the kernel is no
+// faster -- white noise 1.02 against 1.03 ms beside the decoder, config 3 0.666 against 0.614 (80 registers and a spill
+// instead of 92): it is not bound by what it issues.  Off.
+#ifndef X3_CHECK_STEP_ASM
+#define X3_CHECK_STEP_ASM 0
+#endif
 #define X3_CHECK_TAB_U16 (12u * 256u)
 #define X3_CHECK_TAB_DW (X3_CHECK_TAB_U16 / 2u)
 #define X3_CHECK_XINV_N 1024u  // x^(-8k), k < 1024: undoes the zero bytes the row grid adds behind a payload
