@@ -273,6 +273,47 @@ int main(int argc, char** argv) {
     }
     for (const std::string& f : {in, a, b, wa, wb}) std::remove(f.c_str());
   }
+  // x3::device: samples and stream stay in HBM; a batch of three clips with and without the segment index, a corrupted
+  // stream (the index does not hide a bad payload CRC), and a stream too short for an index
+  {
+    const size_t n_per = 41234, n_clips = 3;
+    std::vector<int16_t> clips(n_per * n_clips);
+    CHECK(x3_synth(2, 0x5834, 0, clips.size(), clips.data()) == 0);
+    std::vector<uint8_t> want;
+    for (size_t c = 0; c < n_clips; ++c) {
+      const std::vector<uint8_t> one = oracle_encode(std::vector<int16_t>(clips.begin() + c * n_per, clips.begin() + (c + 1) * n_per));
+      want.insert(want.end(), one.begin(), one.end());
+    }
+    x3::device::Buffer d_wav(ctx, clips.size() * 2), d_back(ctx, clips.size() * 2);
+    CHECK(d_wav.ok() && d_back.ok());
+    CHECK(d_wav.upload(clips.data(), clips.size() * 2) == x3::X3Error::Ok);
+    for (uint32_t sb : {0u, 32u, 64u}) {
+      x3::device::EncodedStream es;
+      CHECK(x3::device::encode(ctx, d_wav.as<int16_t>(), n_per, n_clips, params, sb, &es) == x3::X3Error::Ok);
+      CHECK(es.len == want.size() && es.n_frames == 15 && es.seg_blocks == sb);
+      std::vector<uint8_t> got(es.len);
+      CHECK(es.bytes.download(got.data(), got.size()) == x3::X3Error::Ok && got == want);
+      std::vector<int16_t> back(clips.size(), 0x5a5a);
+      CHECK(d_back.upload(back.data(), back.size() * 2) == x3::X3Error::Ok);
+      x3::decoder::StreamResult res;
+      CHECK(x3::device::decode(ctx, es, params, d_back.as<int16_t>(), clips.size(), &res) == x3::X3Error::Ok);
+      CHECK(res.samples == clips.size() && res.frames_ok == es.n_frames);
+      CHECK(d_back.download(back.data(), back.size() * 2) == x3::X3Error::Ok && back == clips);
+      // one payload bit of the second clip's third frame flipped
+      std::vector<uint64_t> offs(es.n_frames + 1);
+      CHECK(es.frame_offsets.download(offs.data(), offs.size() * 8) == x3::X3Error::Ok);
+      got[offs[7] + 20 + 100] ^= 0x10;
+      CHECK(es.bytes.upload(got.data(), got.size()) == x3::X3Error::Ok);
+      CHECK(x3::device::decode(ctx, es, params, d_back.as<int16_t>(), clips.size(), &res) == x3::X3Error::FrameHeaderInvalidPayloadCRC);
+      CHECK(res.frames_ok == 7);
+    }
+    x3::device::EncodedStream tiny;   // 100 samples: five blocks, no stretch to index
+    CHECK(x3::device::encode(ctx, d_wav.as<int16_t>(), 100, 1, params, 32, &tiny) == x3::X3Error::Ok);
+    x3::decoder::StreamResult res;
+    CHECK(x3::device::decode(ctx, tiny, params, d_back.as<int16_t>(), 100, &res) == x3::X3Error::Ok && res.samples == 100);
+    std::vector<int16_t> back(100);
+    CHECK(d_back.download(back.data(), 200) == x3::X3Error::Ok && std::equal(back.begin(), back.end(), clips.begin()));
+  }
   std::printf("x3.hpp checks ok\n");
   return 0;
 }

@@ -585,6 +585,106 @@ inline X3Error decode_stream_dev(Context& ctx, const uint8_t* d_x3, size_t len, 
 }
 }  // namespace decoder
 
+// Device-resident encode / decode (NOT in the crate, which knows no device): samples and stream stay in HBM between the two
+// (x3_encode_dev / x3_decode_dev), optionally with the SEGMENT INDEX that lets a short stream decode on as many lanes as fill
+// the GPU (x3_encode_dev_seg / x3_decode_dev_seg; the index is a hint the decoder proves entry by entry).
+namespace device {
+// device memory of a context (x3_dev_alloc): movable, freed with the object
+class Buffer {
+ public:
+  Buffer() = default;
+  Buffer(Context& ctx, size_t bytes) : ctx_(&ctx), bytes_(bytes) {
+    if (x3_dev_alloc(ctx.raw(), bytes, &p_) != X3_OK) { p_ = nullptr; bytes_ = 0; }
+  }
+  Buffer(const Buffer&) = delete;
+  Buffer& operator=(const Buffer&) = delete;
+  Buffer(Buffer&& o) noexcept : ctx_(o.ctx_), p_(o.p_), bytes_(o.bytes_) { o.p_ = nullptr; o.bytes_ = 0; }
+  Buffer& operator=(Buffer&& o) noexcept {
+    if (this != &o) { reset(); ctx_ = o.ctx_; p_ = o.p_; bytes_ = o.bytes_; o.p_ = nullptr; o.bytes_ = 0; }
+    return *this;
+  }
+  ~Buffer() { reset(); }
+  void reset() { if (p_) x3_dev_free(ctx_->raw(), p_); p_ = nullptr; bytes_ = 0; }
+  bool ok() const { return p_ != nullptr; }
+  size_t size() const { return bytes_; }
+  void* data() const { return p_; }
+  template <typename T> T* as() const { return static_cast<T*>(p_); }
+  X3Error upload(const void* src, size_t bytes) {
+    return bytes <= bytes_ ? static_cast<X3Error>(x3_dev_upload(ctx_->raw(), p_, src, bytes)) : X3Error::BadArg;
+  }
+  X3Error download(void* dst, size_t bytes) const {
+    return bytes <= bytes_ ? static_cast<X3Error>(x3_dev_download(ctx_->raw(), dst, p_, bytes)) : X3Error::BadArg;
+  }
+
+ private:
+  Context* ctx_ = nullptr;
+  void* p_ = nullptr;
+  size_t bytes_ = 0;
+};
+
+// an encoded batch in device memory: the stream, where its frames begin, and (seg_blocks != 0) the segment index
+struct EncodedStream {
+  Buffer bytes, frame_offsets, seg_index;
+  size_t len = 0;          // bytes of the stream
+  size_t n_frames = 0;
+  size_t n_per_clip = 0, n_clips = 1;
+  uint32_t seg_blocks = 0;
+  uint64_t stats[6] = {0, 0, 0, 0, 0, 0};
+};
+
+// n_clips clips of n_per_clip samples each, back to back in d_wav, each encoded like encoder::encode encodes a channel.
+// seg_blocks: 0 = no index; a power of two >= 4 (32 for the default 500-block frames) = also leave the segment index.
+inline X3Error encode(Context& ctx, const int16_t* d_wav, size_t n_per_clip, size_t n_clips, const Parameters& params,
+                      uint32_t seg_blocks, EncodedStream* out) {
+  if (!out || !d_wav || n_per_clip == 0 || n_clips == 0) return X3Error::BadArg;
+  const x3_params c = params.c_params();
+  EncodedStream e;
+  e.n_per_clip = n_per_clip;
+  e.n_clips = n_clips;
+  e.n_frames = static_cast<size_t>(x3_num_frames(n_per_clip, &c)) * n_clips;
+  const size_t cap = static_cast<size_t>(x3_encode_bound(n_per_clip, &c)) * n_clips;
+  e.bytes = Buffer(ctx, cap + 16);
+  e.frame_offsets = Buffer(ctx, 8 * (e.n_frames + 1));
+  const uint64_t n_idx = seg_blocks ? x3_seg_index_entries(e.n_frames, &c, seg_blocks) : 0;
+  if (n_idx) {
+    e.seg_index = Buffer(ctx, 8 * n_idx);
+    e.seg_blocks = seg_blocks;
+  }
+  if (!e.bytes.ok() || !e.frame_offsets.ok() || (n_idx && !e.seg_index.ok())) return X3Error::Hip;
+  const x3_batch b{n_per_clip, n_per_clip, n_clips};
+  int rc = n_idx ? x3_encode_dev_seg(ctx.raw(), d_wav, &b, &c, e.bytes.as<uint8_t>(), cap, 0, e.frame_offsets.as<uint64_t>(),
+                                     e.seg_index.as<uint64_t>(), seg_blocks)
+                 : x3_encode_dev(ctx.raw(), d_wav, &b, &c, e.bytes.as<uint8_t>(), cap, 0, e.frame_offsets.as<uint64_t>());
+  if (rc != X3_OK) return static_cast<X3Error>(rc);
+  uint64_t pos = 0;
+  rc = x3_encode_result(ctx.raw(), &pos, e.stats);
+  if (rc != X3_OK) return static_cast<X3Error>(rc);
+  e.len = static_cast<size_t>(pos);
+  *out = std::move(e);
+  return X3Error::Ok;
+}
+
+// ... and back: the samples of every clip at d_wav + clip * n_per_clip.  By the segment index when the stream has one.
+// res->frames_ok = the first frame that failed (n_frames if none), frame_errors = its status.
+inline X3Error decode(Context& ctx, const EncodedStream& s, const Parameters& params, int16_t* d_wav, size_t wav_cap,
+                      decoder::StreamResult* res) {
+  if (!d_wav || !s.bytes.ok() || !s.frame_offsets.ok()) return X3Error::BadArg;
+  const x3_params c = params.c_params();
+  const x3_batch b{s.n_per_clip, s.n_per_clip, s.n_clips};
+  int rc = s.seg_blocks ? x3_decode_dev_seg(ctx.raw(), s.bytes.as<uint8_t>(), s.len, s.frame_offsets.as<uint64_t>(), s.n_frames, &b,
+                                            nullptr, &c, d_wav, wav_cap, nullptr, s.seg_index.as<uint64_t>(), s.seg_blocks, 0)
+                        : x3_decode_dev(ctx.raw(), s.bytes.as<uint8_t>(), s.len, s.frame_offsets.as<uint64_t>(), s.n_frames, &b,
+                                        nullptr, &c, d_wav, wav_cap, nullptr);
+  if (rc != X3_OK) return static_cast<X3Error>(rc);
+  uint64_t first_bad = 0, before = 0;
+  int st = 0;
+  rc = x3_decode_result(ctx.raw(), &first_bad, &st, &before);
+  if (res) { res->samples = before; res->frames_ok = first_bad; res->frame_errors = static_cast<uint64_t>(st); }
+  if (rc != X3_OK) return static_cast<X3Error>(rc);
+  return static_cast<X3Error>(st);
+}
+}  // namespace device
+
 // Multi-channel extension (x3_mc.h; NOT in the crate, whose encode() returns MoreThanOneChannel for more than one channel
 // and whose reader refuses such frames -- as encoder::encode and decoder::decode_stream above do): the layout the frame
 // header's <Num Channels> and "pack the data block for each channel" (encoder.rs:197) foresee.  Channels of equal length.

@@ -15,6 +15,14 @@ pub mod ffi {
     //! `extern "C"` declarations of include/x3hip.h (the entry points this crate binds).
     use std::os::raw::{c_char, c_int, c_longlong, c_void};
 
+    /// `x3_batch`: `n_clips` clips of `n_per_clip` samples, `clip_stride` samples apart
+    #[repr(C)]
+    #[derive(Clone, Copy, Debug)]
+    pub struct x3_batch {
+        pub n_per_clip: u64,
+        pub clip_stride: u64,
+        pub n_clips: u64,
+    }
     #[repr(C)]
     #[derive(Clone, Copy, Debug)]
     pub struct x3_params {
@@ -93,6 +101,26 @@ pub mod ffi {
         pub fn x3_bitpacker_take(bp: *mut x3_bitpacker, dst: *mut u8, dst_cap: u64, n_new: *mut u64, len: *mut u64,
                                  crc: *mut u16) -> c_int;
         pub fn x3_bitpacker_free(bp: *mut x3_bitpacker);
+        // device-resident buffers (mod device)
+        pub fn x3_num_frames(n: u64, p: *const x3_params) -> u64;
+        pub fn x3_dev_alloc(ctx: *mut x3_ctx, bytes: u64, d_ptr: *mut *mut c_void) -> c_int;
+        pub fn x3_dev_free(ctx: *mut x3_ctx, d_ptr: *mut c_void) -> c_int;
+        pub fn x3_dev_upload(ctx: *mut x3_ctx, d_dst: *mut c_void, src: *const c_void, bytes: u64) -> c_int;
+        pub fn x3_dev_download(ctx: *mut x3_ctx, dst: *mut c_void, d_src: *const c_void, bytes: u64) -> c_int;
+        pub fn x3_seg_index_entries(n_frames: u64, p: *const x3_params, seg_blocks: u32) -> u64;
+        pub fn x3_encode_dev(ctx: *mut x3_ctx, d_wav: *const i16, batch: *const x3_batch, p: *const x3_params, d_out: *mut u8,
+                             out_cap: u64, start_pos: u64, d_frame_offsets: *mut u64) -> c_int;
+        pub fn x3_encode_dev_seg(ctx: *mut x3_ctx, d_wav: *const i16, batch: *const x3_batch, p: *const x3_params, d_out: *mut u8,
+                                 out_cap: u64, start_pos: u64, d_frame_offsets: *mut u64, d_seg_index: *mut u64,
+                                 seg_blocks: u32) -> c_int;
+        pub fn x3_encode_result(ctx: *mut x3_ctx, out_pos: *mut u64, stats: *mut u64) -> c_int;
+        pub fn x3_decode_dev(ctx: *mut x3_ctx, d_x3: *const u8, x3_len: u64, d_frame_offsets: *const u64, n_frames: u64,
+                             batch: *const x3_batch, d_wav_offsets: *const u64, p: *const x3_params, d_wav: *mut i16,
+                             wav_cap: u64, d_status: *mut i32) -> c_int;
+        pub fn x3_decode_dev_seg(ctx: *mut x3_ctx, d_x3: *const u8, x3_len: u64, d_frame_offsets: *const u64, n_frames: u64,
+                                 batch: *const x3_batch, d_wav_offsets: *const u64, p: *const x3_params, d_wav: *mut i16,
+                                 wav_cap: u64, d_status: *mut i32, d_seg_index: *mut u64, seg_blocks: u32, record: c_int) -> c_int;
+        pub fn x3_decode_result(ctx: *mut x3_ctx, first_bad: *mut u64, first_bad_status: *mut c_int, samples_before: *mut u64) -> c_int;
         pub fn x3_wav_to_x3a(ctx: *mut x3_ctx, wav_path: *const c_char, x3a_path: *const c_char, stats: *mut u64) -> c_int;
         pub fn x3_x3a_to_wav(ctx: *mut x3_ctx, x3a_path: *const c_char, wav_path: *const c_char, n_samples: *mut u64,
                              frame_errors: *mut u64) -> c_int;
@@ -979,6 +1007,123 @@ pub mod multichannel {
             })
         })?;
         Ok((n as usize, ok as usize, bad as usize))
+    }
+}
+
+pub mod device {
+    //! Not in the reference crate, which knows no device: samples and stream stay in HBM between encode and decode
+    //! (`x3_encode_dev` / `x3_decode_dev`), optionally with the SEGMENT INDEX that lets a short stream decode on as many lanes
+    //! as fill the GPU (`x3_encode_dev_seg` / `x3_decode_dev_seg`; a hint the decoder proves entry by entry).  The C++ mirror
+    //! has the same module (host/x3.hpp, `x3::device`), tested in tests/host_cpp/test_x3_hpp.cpp.
+    use crate::error::{self, X3Error};
+    use crate::ffi;
+    use crate::gpu::Gpu;
+    use crate::x3;
+    use std::os::raw::c_void;
+
+    /// device memory of a context (`x3_dev_alloc`), freed with the value
+    pub struct Buffer<'g> {
+        gpu: &'g Gpu,
+        p: *mut c_void,
+        bytes: usize,
+    }
+    impl<'g> Buffer<'g> {
+        pub fn new(gpu: &'g Gpu, bytes: usize) -> error::Result<Self> {
+            let mut p = core::ptr::null_mut();
+            error::check(unsafe { ffi::x3_dev_alloc(gpu.raw(), bytes as u64, &mut p) })?;
+            Ok(Buffer { gpu, p, bytes })
+        }
+        pub fn len(&self) -> usize {
+            self.bytes
+        }
+        pub fn is_empty(&self) -> bool {
+            self.bytes == 0
+        }
+        pub fn as_ptr<T>(&self) -> *mut T {
+            self.p as *mut T
+        }
+        pub fn upload<T: Copy>(&mut self, src: &[T]) -> error::Result<()> {
+            let n = std::mem::size_of_val(src);
+            if n > self.bytes {
+                return Err(X3Error::BadArg);
+            }
+            error::check(unsafe { ffi::x3_dev_upload(self.gpu.raw(), self.p, src.as_ptr() as *const c_void, n as u64) })
+        }
+        pub fn download<T: Copy>(&self, dst: &mut [T]) -> error::Result<()> {
+            let n = std::mem::size_of_val(dst);
+            if n > self.bytes {
+                return Err(X3Error::BadArg);
+            }
+            error::check(unsafe { ffi::x3_dev_download(self.gpu.raw(), dst.as_mut_ptr() as *mut c_void, self.p, n as u64) })
+        }
+    }
+    impl Drop for Buffer<'_> {
+        fn drop(&mut self) {
+            unsafe { ffi::x3_dev_free(self.gpu.raw(), self.p) };
+        }
+    }
+
+    /// an encoded batch in device memory: the stream, where its frames begin, and (`seg_blocks != 0`) the segment index
+    pub struct EncodedStream<'g> {
+        pub bytes: Buffer<'g>,
+        pub frame_offsets: Buffer<'g>,
+        pub seg_index: Option<Buffer<'g>>,
+        pub len: usize,
+        pub n_frames: usize,
+        pub n_per_clip: usize,
+        pub n_clips: usize,
+        pub seg_blocks: u32,
+        pub stats: [u64; 6],
+    }
+
+    /// `n_clips` clips of `n_per_clip` samples back to back in `d_wav`, each encoded as `encoder::encode` encodes a channel.
+    /// `seg_blocks`: 0 = no index; a power of two >= 4 (32 for the default frames) = also leave the segment index.
+    pub fn encode<'g>(gpu: &'g Gpu, d_wav: &Buffer<'g>, n_per_clip: usize, n_clips: usize, params: &x3::Parameters,
+                      seg_blocks: u32) -> error::Result<EncodedStream<'g>> {
+        if n_per_clip == 0 || n_clips == 0 || d_wav.len() < 2 * n_per_clip * n_clips {
+            return Err(X3Error::BadArg);
+        }
+        let p = params.c()?;
+        let n_frames = unsafe { ffi::x3_num_frames(n_per_clip as u64, &p) } as usize * n_clips;
+        let cap = unsafe { ffi::x3_encode_bound(n_per_clip as u64, &p) } as usize * n_clips;
+        let bytes = Buffer::new(gpu, cap + 16)?;
+        let frame_offsets = Buffer::new(gpu, 8 * (n_frames + 1))?;
+        let n_idx = if seg_blocks != 0 { unsafe { ffi::x3_seg_index_entries(n_frames as u64, &p, seg_blocks) } as usize } else { 0 };
+        let seg_index = if n_idx != 0 { Some(Buffer::new(gpu, 8 * n_idx)?) } else { None };
+        let b = ffi::x3_batch { n_per_clip: n_per_clip as u64, clip_stride: n_per_clip as u64, n_clips: n_clips as u64 };
+        error::check(unsafe {
+            match &seg_index {
+                Some(idx) => ffi::x3_encode_dev_seg(gpu.raw(), d_wav.as_ptr::<i16>(), &b, &p, bytes.as_ptr::<u8>(), cap as u64, 0,
+                                                    frame_offsets.as_ptr::<u64>(), idx.as_ptr::<u64>(), seg_blocks),
+                None => ffi::x3_encode_dev(gpu.raw(), d_wav.as_ptr::<i16>(), &b, &p, bytes.as_ptr::<u8>(), cap as u64, 0, frame_offsets.as_ptr::<u64>()),
+            }
+        })?;
+        let mut pos = 0u64;
+        let mut stats = [0u64; 6];
+        error::check(unsafe { ffi::x3_encode_result(gpu.raw(), &mut pos, stats.as_mut_ptr()) })?;
+        let seg_blocks = if seg_index.is_some() { seg_blocks } else { 0 };
+        Ok(EncodedStream { bytes, frame_offsets, seg_index, len: pos as usize, n_frames, n_per_clip, n_clips, seg_blocks, stats })
+    }
+
+    /// ... and back: every clip's samples at `d_wav + clip * n_per_clip`; by the segment index when the stream has one.
+    /// -> samples in front of the first frame that failed (all of them if none did); `Err` = that frame's status
+    pub fn decode<'g>(gpu: &'g Gpu, s: &EncodedStream<'g>, params: &x3::Parameters, d_wav: &mut Buffer<'g>) -> error::Result<usize> {
+        let p = params.c()?;
+        let b = ffi::x3_batch { n_per_clip: s.n_per_clip as u64, clip_stride: s.n_per_clip as u64, n_clips: s.n_clips as u64 };
+        let wav_cap = (d_wav.len() / 2) as u64;
+        error::check(unsafe {
+            match &s.seg_index {
+                Some(idx) => ffi::x3_decode_dev_seg(gpu.raw(), s.bytes.as_ptr::<u8>(), s.len as u64, s.frame_offsets.as_ptr::<u64>(), s.n_frames as u64,
+                                                    &b, core::ptr::null(), &p, d_wav.as_ptr::<i16>(), wav_cap, core::ptr::null_mut(),
+                                                    idx.as_ptr::<u64>(), s.seg_blocks, 0),
+                None => ffi::x3_decode_dev(gpu.raw(), s.bytes.as_ptr::<u8>(), s.len as u64, s.frame_offsets.as_ptr::<u64>(), s.n_frames as u64, &b,
+                                           core::ptr::null(), &p, d_wav.as_ptr::<i16>(), wav_cap, core::ptr::null_mut()),
+            }
+        })?;
+        let (mut first_bad, mut before, mut st) = (0u64, 0u64, 0);
+        error::check(unsafe { ffi::x3_decode_result(gpu.raw(), &mut first_bad, &mut st, &mut before) })?;
+        error::check(st)?;
+        Ok(before as usize)
     }
 }
 
