@@ -115,7 +115,9 @@ static int ctx_init(x3_ctx* c, int device, hipStream_t stream, bool own) {
   HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   HIPCHK(c, x3_dmalloc(&c->d_xpow, X3_XP_SIZE * sizeof(uint16_t)));
   // status (4 ints) and stats (6 + end_pos) share one 128-byte block: one memset, one copy back
-  HIPCHK(c, x3_dmalloc(&c->d_status, 128));
+  HIPCHK(c, x3_dmalloc(&c->d_ctl_base, 256));
+  HIPCHK(c, hipMemset(c->d_ctl_base, 0, 256));
+  c->d_status = c->d_ctl_base;
   c->d_stats = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->d_status) + 32);
   c->d_end_pos = c->d_stats + 6;
   HIPCHK(c, x3_dmalloc(&c->d_summary, sizeof(X3DecodeSummary)));
@@ -284,7 +286,7 @@ extern "C" void x3_ctx_destroy(x3_ctx* c) {
   (void)x3_dfree(c->d_kx64);
   (void)x3_dfree(c->d_chktab);
   (void)x3_dfree(c->d_xinv8);
-  (void)x3_dfree(c->d_status);
+  (void)x3_dfree(c->d_ctl_base);
   (void)x3_dfree(c->d_summary);
   (void)x3_dfree(c->d_pace);
   (void)x3_dfree(c->d_crc);
@@ -316,6 +318,7 @@ struct x3_graph {
   uint64_t dec_frames = 0, enc_start_pos = 0;
   int32_t* dec_status_ptr = nullptr;
   int last_enc_gen = 0, last_seg_stretches = 0;
+  int ctl_half = 0;   // the control block the recorded encode uses (x3_encode_result reads it)
   x3_ctx::LastEnc last_enc{};
 };
 
@@ -358,6 +361,7 @@ extern "C" int x3_graph_end(x3_ctx* c, x3_graph** out) {
   r->last_enc_gen = c->last_enc_gen;
   r->last_seg_stretches = c->last_seg_stretches;
   r->last_enc = c->last_enc;
+  r->ctl_half = c->ctl_half;
   c->encode_pending = c->decode_pending = false;   // (nothing has run yet: x3_graph_launch makes them pending)
   *out = r;
   return X3_OK;
@@ -367,6 +371,7 @@ extern "C" int x3_graph_launch(x3_ctx* c, x3_graph* g) {
   if (!c || !g || g->c != c || c->capturing) return X3_ERR_BAD_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipGraphLaunch(g->exec, c->stream));
+  c->ctl_clean[0] = c->ctl_clean[1] = false;   // (the recorded encoders wrote into the control blocks of their recording)
   c->encode_pending = g->encode_pending;
   c->decode_pending = g->decode_pending;
   c->dec_frames = g->dec_frames;
@@ -375,6 +380,10 @@ extern "C" int x3_graph_launch(x3_ctx* c, x3_graph* g) {
   c->last_enc_gen = g->last_enc_gen;
   c->last_seg_stretches = g->last_seg_stretches;
   c->last_enc = g->last_enc;
+  c->ctl_half = g->ctl_half;
+  c->d_status = c->d_ctl_base + 32 * c->ctl_half;
+  c->d_stats = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->d_status) + 32);
+  c->d_end_pos = c->d_stats + 6;
   return X3_OK;
 }
 

@@ -67,6 +67,17 @@ int plan_encode(x3_ctx* c, const x3_batch* b, const x3_params* p, uint64_t spf, 
   return X3_OK;
 }
 
+int ctl_begin(x3_ctx* c) {
+  c->ctl_half ^= 1;
+  c->d_status = c->d_ctl_base + 32 * c->ctl_half;   // (128 bytes each)
+  c->d_stats = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->d_status) + 32);
+  c->d_end_pos = c->d_stats + 6;
+  const bool clean = c->ctl_clean[c->ctl_half] && !c->capturing;
+  c->ctl_clean[c->ctl_half] = false;
+  if (!clean) HIPCHK(c, hipMemsetAsync(c->d_status, 0, 128, c->stream));
+  return X3_OK;
+}
+
 int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3_params* p, uint64_t spf,
                            uint8_t* d_out, uint64_t out_cap, uint64_t start_pos, uint64_t* d_frame_offsets,
                            const X3FrameTable* tab) {
@@ -86,12 +97,17 @@ int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3
     if ((rc = ensure(c, c->frame_off, (F + 1) * sizeof(uint64_t)))) return rc;
     d_off = (uint64_t*)c->frame_off.p;
   }
-  HIPCHK(c, hipMemsetAsync(c->d_status, 0, 128, c->stream));
+  if ((rc = ctl_begin(c))) return rc;
   // the segment index of this call (x3_encode_dev_seg): only the wave encoder fills it; every other path leaves a header
   // that says "no index" (the decoder then takes whole frames per lane)
   const X3SegSpec seg = c->enc_seg;
   c->enc_seg = X3SegSpec{nullptr, 0, 0};
-  if (seg.d_index) HIPCHK(c, hipMemsetAsync(seg.d_index, 0, sizeof(uint64_t), c->stream));
+  bool seg_header_open = seg.d_index != nullptr;   // (a wave-encoder call that fills the index writes the header itself)
+  auto seg_header_none = [&]() -> int {
+    if (seg_header_open) HIPCHK(c, hipMemsetAsync(seg.d_index, 0, sizeof(uint64_t), c->stream));
+    seg_header_open = false;
+    return X3_OK;
+  };
   // ---- single-pass path: default block length, frames on dword boundaries (buffer loads)
   const bool stream_path = p->block_len == 20 && (std::min<uint64_t>(spf, b->n_per_clip) + 18) / 20 <= 512 &&
                            (spf % X3_ENC_FRAME_ALIGN) == 0 &&
@@ -99,7 +115,7 @@ int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3
                            (reinterpret_cast<uintptr_t>(d_wav) & 3u) == 0 && !c->force_two_pass && !c->opt.two_pass &&
                            (!tab || tab->even);
   c->last_enc = {d_wav, *b, *p, spf, d_out, out_cap, start_pos, d_frame_offsets, tab ? tab->src_off : nullptr,
-                 tab ? tab->src_n : nullptr, tab ? tab->even : false};
+                 tab ? tab->src_n : nullptr, tab ? tab->even : false, seg};
   // part + two worst-case frame images + CRC tables + the multipliers of one chunk size (x3_encode_stream2_kernel.h)
   const size_t smem2 = X3_ENC_SMEM_HDR + 2 * (size_t)pl.img_dwords * 4 + 2048 + X3_K2_DWORDS * 4;
   c->last_enc_gen = 0;
@@ -170,6 +186,7 @@ int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3
           wa.seg_pitch = (uint32_t)(nidx - 1);
         }
       }
+      if (!wa.seg && (rc = seg_header_none())) return rc;
       {
         TimerScope ts(c, 0, nullptr, true);
         if (wa.src_off) X3_LAUNCH_TIMED(ts, x3_encode_wave_kernel<true>, dim3(wa.nwg), dim3(X3W_THREADS), X3W_SMEM, c->stream, wa);
@@ -192,17 +209,20 @@ int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3
         X3_LAUNCH_TIMED(ts, (x3_encode_stream2_kernel<true, TABLE>), dim3((unsigned)grid), dim3(X3_STREAM2_THREADS), smem2,  \
                         c->stream, d_wav, pl.g, pl.dp, d_off, d_out, out_cap, start_pos, (uint32_t*)nullptr, 0u,             \
                         reinterpret_cast<unsigned char*>(c->d_status), (const uint32_t*)c->d_xk2,                           \
-                        (const uint16_t*)c->d_crctab, pl.img_dwords, (uint32_t*)nullptr, (const uint32_t*)c->dense_list.p)
+                        (const uint16_t*)c->d_crctab, pl.img_dwords, (uint32_t*)nullptr, (const uint32_t*)c->dense_list.p,          \
+                        reinterpret_cast<uint32_t*>(c->d_ctl_base + 32 * (c->ctl_half ^ 1)))
         if (pl.g.src_off) X3_DENSE_PASS(true); else X3_DENSE_PASS(false);
 #undef X3_DENSE_PASS
       }
       HIPCHK(c, hipGetLastError());
+      c->ctl_clean[c->ctl_half ^ 1] = !c->capturing;   // (the dense pass clears the next call's control block -- when it runs)
       c->last_enc_gen = 3;
       c->encode_pending = true;
       c->enc_start_pos = start_pos;
       return X3_OK;
     }
   }
+  if ((rc = seg_header_none())) return rc;
   if (stream_path && stream_safe_thresholds(p)) {
     // second generation (x3_encode_stream2_kernel.h): eight waves, no sample tile in LDS
     if (c->stream_wg_per_cu < 0) {
@@ -414,6 +434,7 @@ extern "C" int x3_encode_result(x3_ctx* c, uint64_t* out_pos, uint64_t stats[6])
       std::fprintf(stderr, "x3hip: stream encoder gave up waiting for frame sizes (grid not co-resident): two-pass fallback\n");
     c->force_two_pass = true;
     auto a = c->last_enc;
+    c->enc_seg = a.seg;   // (the index, if the call had one: the re-run leaves a header that says "none")
     const X3FrameTable tab{a.src_off, a.src_n, a.src_even};
     int rc = encode_dev_impl(c, a.d_wav, &a.b, &a.p, a.spf, a.d_out, a.out_cap, a.start_pos, a.d_off, a.src_off ? &tab : nullptr);
     c->force_two_pass = false;

@@ -101,7 +101,10 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
                          uint64_t start_pos, uint32_t* __restrict__ desc, uint32_t epoch,
                          unsigned char* __restrict__ ctl, const uint32_t* __restrict__ xk2,
                          const uint16_t* __restrict__ crc_tab_g, uint32_t img_dwords, uint32_t* __restrict__ pace,
-                         const uint32_t* __restrict__ dense_list) {
+                         const uint32_t* __restrict__ dense_list, uint32_t* __restrict__ ctl_next = nullptr) {
+  // (round 5) the dense pass is the last kernel of a wave-encoder call: it clears the control block the context's NEXT encode
+  // call uses (the context alternates between two), which then needs no memset of its own in front of its first kernel
+  if (LIST && ctl_next && blockIdx.x == 0 && threadIdx.x < 32u) ctl_next[threadIdx.x] = 0u;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* part = reinterpret_cast<uint32_t*>(smem);
   uint32_t* img0 = reinterpret_cast<uint32_t*>(smem + X3_ENC_SMEM_HDR);

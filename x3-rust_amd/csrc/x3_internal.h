@@ -109,6 +109,13 @@ struct x3_ctx {
   uint16_t* d_xinv8 = nullptr;         // x^(-8k), k < X3_CHECK_XINV_N
   int* d_status = nullptr;             // [0] size/scan pass, [1] encode pass
   unsigned long long* d_stats = nullptr;    // 6
+  // The encoders' control block (status, statistics, end position, dense count: 128 bytes) exists twice; a call uses the one
+  // the call before did not (ctl_begin, x3_encode.hip), and d_status / d_stats / d_end_pos point into it.  A wave-encoder
+  // call's last kernel clears the other one: the next call then starts without a memset in front of its first kernel
+  // (4 us of fill + a launch gap on a stream that has nothing else to do: 1 % of config 3's step, 10 % of config 2's).
+  int32_t* d_ctl_base = nullptr;
+  int ctl_half = 0;
+  bool ctl_clean[2] = {false, false};
   unsigned long long* d_end_pos = nullptr;  // 1
   DevBuf lb_desc;                            // the general single-pass encoder's look-back descriptors (u64 per frame)
   uint32_t lb_epoch = 0;
@@ -157,6 +164,7 @@ struct x3_ctx {
   struct LastEnc {
     const int16_t* d_wav; x3_batch b; x3_params p; uint64_t spf; uint8_t* d_out; uint64_t out_cap, start_pos; uint64_t* d_off;
     const uint64_t* src_off; const uint32_t* src_n; bool src_even;   // x3_encode_frames_dev's frame table (device), or nullptr
+    X3SegSpec seg;                                                    // x3_encode_dev_seg's index (a re-run says "none" in it)
   } last_enc;
   // x3_graph_begin .. x3_graph_end: the device calls in between are recorded into a HIP graph instead of launched.  Nothing
   // may allocate meanwhile (ensure() fails instead), and the encoders' descriptor words -- tagged with a per-launch epoch so
@@ -296,6 +304,10 @@ struct EncPlan {
 
 // ---- x3_ctx.hip
 X3_INTERNAL int ensure(x3_ctx* c, DevBuf& b, size_t bytes);
+// an encode call takes the control block the call before did not use (x3_ctx::d_ctl_base), cleared -- by the last kernel of
+// the call before where that was a wave-encoder call, by a memset otherwise (and always while a graph is recorded: every
+// replay runs the same nodes); x3_encode.hip
+X3_INTERNAL int ctl_begin(x3_ctx* c);
 X3_INTERNAL int x3_pipe_streams(x3_ctx* c);
 X3_INTERNAL uint64_t spf_of(const x3_params* p);
 X3_INTERNAL uint64_t max_payload_bytes(uint64_t n, uint32_t block_len);

@@ -66,7 +66,7 @@ extern "C" int x3_encode_mc(x3_ctx* c, const int16_t* const* wavs, uint32_t n_ch
   if ((rc = ensure(c, c->frame_bytes, F * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(c, c->frame_off, (F + 1) * sizeof(uint64_t)))) return rc;
   uint64_t* d_off = (uint64_t*)c->frame_off.p;
-  HIPCHK(c, hipMemsetAsync(c->d_status, 0, 128, c->stream));
+  if (int rc_ctl = ctl_begin(c)) return rc_ctl;
   if (smem > 64 * 1024) {
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_frames_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
