@@ -77,6 +77,8 @@ def test_bench_small_run_prints_the_contract_line():
         assert ws["decode"]["ms"] > 0 and ws["decode"]["stretches_per_frame"] == (16 if cn == "config2" else 0), ws
     assert j["configs"]["config2"]["with_segment_index"]["decode"]["ms"] < 0.5 * j["configs"]["config2"]["decode"]["ms"]
     assert j["config"]["settle_steps"] >= 16 and j["config"]["settle_ms"] > 0
+    # the same K steps without the kernels' HIP events, beside `value` (which has them in the timed region, as the contract asks)
+    assert j["value_without_kernel_events"] > 0 and j["ms_per_step_without_kernel_events"] > 0
     # roofline.traffic is measured by the run itself (two rocprofv3 PMC passes as child processes) where rocprofv3 exists
     import shutil
     if shutil.which("rocprofv3"):
