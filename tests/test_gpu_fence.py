@@ -30,7 +30,7 @@ def _child(code, timeout=600):
 
 def test_last_frame_of_one_sample_ending_on_a_chunk_boundary():
     """streams of k frames + 1 sample whose length is a multiple of 16, in a buffer of exactly that length: the frame-per-lane
-    decoders (three-wave with and without a recorded index, lanes kernel through per-frame offsets) and the stream entry"""
+    decoders (three-wave with and without a recorded index, the single-wave kernel through per-frame offsets) and the stream entry"""
     out = _child("""
         import ctypes as C
         import numpy as np
@@ -78,7 +78,7 @@ def test_last_frame_of_one_sample_ending_on_a_chunk_boundary():
                         assert np.array_equal(ctx.download(d_back, 2 * n, np.int16), wav)
                     ctx.set_option("seg_stretches", 0)
                     ctx.free(d_seg)
-                # per-frame sample offsets that are not promised to be multiples of four: the lanes kernel
+                # per-frame sample offsets that are not promised to be multiples of four: the single-wave decoder (x3_decode_fast_kernel)
                 ctx.upload(d_back, np.zeros(n, dtype=np.int16))
                 assert ctx.decode_dev(d_x3, ref.size, d_off, F, p, d_back, n, d_wav_offsets=d_wo) == 0
                 assert ctx.decode_result()[:3] == (0, F, 0)
