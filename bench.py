@@ -169,6 +169,8 @@ def main():
     if world > 1 or os.environ.get("X3_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29531")   # (X3_BENCH_FORCE_DIST=1 without a launcher)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     p = x3hip.Params.default()
