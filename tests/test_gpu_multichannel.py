@@ -157,3 +157,44 @@ def test_random_multichannel_sweep(ctx):
         assert (got[0], got[2], got[3]) == (want[0], want[2], want[3]), (trial, got[0], got[2:], want[0], want[2:])
         for k in range(n_ch):
             assert np.array_equal(got[1][k], want[1][k]), (trial, k)
+
+
+def test_encode_is_one_pass_and_falls_back_to_two(ctx):
+    """x3_encode_mc runs the general encoder's one-pass kernel (sizes by decoupled look-back: enc_gen_in_use 1) since round 5;
+    the two-pass kernels give the same bytes (option two_pass), and a launch whose look-back gives up -- test hook lb_drop:
+    a frame that never publishes its size -- is encoded again in two passes by x3_encode_mc itself (several channels are
+    not the mono call x3_encode_result re-runs)."""
+    p = x3hip.Params.default()
+    p.blocks_per_frame = 100
+    po = O.Params.default()
+    po.blocks_per_frame = 100
+    wavs = _signals(2000 * 37 + 5, 3, 4242)
+    rc_o, x_o, st_o = O.encode_mc(wavs, po)
+    assert rc_o == 0
+    rc, x, st = ctx.encode_mc(wavs, p)
+    assert rc == 0 and np.array_equal(x, x_o) and st.tolist() == st_o.tolist()
+    assert ctx.get_option("enc_gen_in_use") == 1
+    ctx.set_option("two_pass", 1)
+    try:
+        rc, x, st = ctx.encode_mc(wavs, p)
+        assert rc == 0 and np.array_equal(x, x_o) and st.tolist() == st_o.tolist() and ctx.get_option("enc_gen_in_use") == 0
+    finally:
+        ctx.set_option("two_pass", 0)
+    before = ctx.get_option("encode_fallbacks")
+    ctx.set_option("lb_drop", 11)
+    try:
+        rc, x, st = ctx.encode_mc(wavs, p, start_pos=7)
+        rc_o7, x_o7, st_o7 = O.encode_mc(wavs, po, start_pos=7)
+        assert rc == 0 and np.array_equal(x[8:], x_o7[8:]) and st.tolist() == st_o7.tolist()
+        assert ctx.get_option("encode_fallbacks") == before + 1 and ctx.get_option("enc_gen_in_use") == 0
+        # the mono general path (block length 19: the one-pass kernel) falls back the same way, through x3_encode_result
+        pm = x3hip.Params.make(19, 64)
+        wav = x3hip.synth(2, 99, 0, 19 * 64 * 40 + 3)
+        rc_m, x_m, st_m = ctx.encode(wav, pm)
+        rc_om, x_om, st_om = O.encode(wav, O.Params.make(19, 64))
+        assert rc_m == rc_om == 0 and np.array_equal(x_m, x_om) and st_m.tolist() == st_om.tolist()
+        assert ctx.get_option("encode_fallbacks") == before + 2
+    finally:
+        ctx.set_option("lb_drop", -1)
+    rc, x, st = ctx.encode_mc(wavs, p)
+    assert rc == 0 and np.array_equal(x, x_o) and ctx.get_option("enc_gen_in_use") == 1

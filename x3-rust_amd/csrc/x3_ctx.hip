@@ -414,6 +414,7 @@ extern "C" int x3_ctx_set_option(x3_ctx* c, const char* name, long long value) {
   else if (n == "wave_drop") c->opt.wave_drop = value;
   else if (n == "host_walk") c->opt.host_walk = value < 0 ? -1 : (value != 0);
   else if (n == "host_chunk_frames") c->opt.host_chunk_frames = std::max(-1ll, value);
+  else if (n == "lb_drop") c->opt.lb_drop = value;
   else if (n == "verbose") c->opt.verbose = value != 0;
   else if (n == "file_chunk_frames") c->opt.file_chunk_frames = std::max(1ll, value);
   else if (n == "file_workers") c->opt.file_workers = (int)std::max(1ll, std::min(16ll, value));

@@ -304,7 +304,7 @@ int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3
       hipLaunchKernelGGL((x3_encode_frames_kernel<false, true>), dim3((unsigned)F), dim3(pl.nthr), pl.smem, c->stream, d_wav,
                          pl.g, pl.dp, (const uint64_t*)d_off, (uint32_t*)c->lb_desc.p, d_out, start_pos, c->d_stats,
                          c->d_status, (const uint16_t*)c->d_xpow, pl.lds_in_bytes, pl.img_dwords, 1u, (uint64_t)0,
-                         c->lb_epoch, out_cap, c->d_end_pos);
+                         c->lb_epoch, out_cap, c->d_end_pos, c->opt.lb_drop >= 0 ? (uint32_t)c->opt.lb_drop : 0xFFFFFFFFu);
     }
     HIPCHK(c, hipGetLastError());
     c->last_enc_gen = 1;
@@ -432,6 +432,7 @@ extern "C" int x3_encode_result(x3_ctx* c, uint64_t* out_pos, uint64_t stats[6])
     ++c->encode_fallbacks;
     if (c->opt.verbose)
       std::fprintf(stderr, "x3hip: stream encoder gave up waiting for frame sizes (grid not co-resident): two-pass fallback\n");
+    if (c->last_enc_mc) return X3_RETRY_TWO_PASS;   // (several channels: x3_encode_mc runs its own two passes)
     c->force_two_pass = true;
     auto a = c->last_enc;
     c->enc_seg = a.seg;   // (the index, if the call had one: the re-run leaves a header that says "none")

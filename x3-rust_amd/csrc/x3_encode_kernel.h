@@ -81,7 +81,7 @@ x3_encode_frames_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
                         unsigned long long* __restrict__ stats, int* __restrict__ status,
                         const uint16_t* __restrict__ xpow, uint32_t lds_in_bytes, uint32_t img_dwords,
                         uint32_t n_ch, uint64_t ch_stride, uint32_t lb_epoch = 0, uint64_t out_cap = 0,
-                        unsigned long long* __restrict__ end_pos = nullptr) {
+                        unsigned long long* __restrict__ end_pos = nullptr, uint32_t lb_drop = 0xFFFFFFFFu) {
   // n_ch > 1: the multi-channel extension (not in the reference, which stops at MoreThanOneChannel: encoder.rs:55-57).
   // Channel c's samples are at wav + c * ch_stride; a frame holds n samples of EVERY channel: <Audio State> = the
   // first sample of each channel, then the blocks in the order (block index, channel) -- "pack the data block for each
@@ -274,13 +274,19 @@ x3_encode_frames_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p
   __syncthreads();  // emission complete
   unsigned long long* const lb_desc = reinterpret_cast<unsigned long long*>(frame_bytes);
   const unsigned long long lb_tag = (unsigned long long)(lb_epoch & 0xFFFu) << X3_LB_EPOCH_SHIFT;
-  const bool lb_bad = part[40] || 5u + ((L + 3u) >> 2) > img_dwords;
+  const bool lb_long = n_ch > 1u && L > 24576u;   // (several channels: a payload no reader takes, as in the size pass above)
+  const bool lb_bad = part[40] || lb_long || 5u + ((L + 3u) >> 2) > img_dwords;
   if (LOOKBACK) {
+    // (test hook, option lb_drop: this frame's descriptor is never published -- what a workgroup that is not resident looks
+    // like to the ones behind it: their bounded waits give up and the host encodes again in two passes)
+    if (f == lb_drop) return;
     // this frame's bytes, at once (a frame that cannot be encoded still counts its bytes: nobody behind it may hang)
     if (tid == 0) {
       __hip_atomic_store(&lb_desc[f], (1ull << X3_LB_FLAG_SHIFT) | lb_tag | (unsigned long long)(20u + L), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
-      if (lb_bad) atomicMax(&status[0], X3D_BAD_ARG);   // (the reference indexes outside its Rice table here: panic)
+      // (the reference indexes outside its Rice table here: panic; several channels can make a payload that no reader
+      // takes -- the size pass's FrameLength, above)
+      if (lb_bad) atomicMax(&status[0], (!part[40] && lb_long) ? X3D_FRAME_LENGTH : X3D_BAD_ARG);
     }
   } else
   if (lb_bad) {

@@ -76,6 +76,7 @@ struct X3Opts {
 #endif
   int two_trips = 0;          // 1: x3_decode_stream_dev always waits for the frame walk before it launches the decoder (the pre-round-5 path)
   int seg_stretches = 0;      // x3_decode_dev_seg: stretches per frame (0 = as many as fill the chip; 1 = never by stretches)
+  long long lb_drop = -1;     // tests: the frame whose look-back descriptor is never published (general one-pass encoder)
   int dyn_lds = 0;            // X3HIP_DECODE_DYN_LDS: extra LDS per decoder group = fewer groups per CU (occupancy experiments)
 };
 
@@ -113,6 +114,7 @@ struct x3_ctx {
   // the call before did not (ctl_begin, x3_encode.hip), and d_status / d_stats / d_end_pos point into it.  A wave-encoder
   // call's last kernel clears the other one: the next call then starts without a memset in front of its first kernel
   // (4 us of fill + a launch gap on a stream that has nothing else to do: 1 % of config 3's step, 10 % of config 2's).
+  bool last_enc_mc = false;   // the pending encode is x3_encode_mc's (its look-back fallback is its own: x3_mc.h)
   int32_t* d_ctl_base = nullptr;
   int ctl_half = 0;
   bool ctl_clean[2] = {false, false};
@@ -308,6 +310,8 @@ X3_INTERNAL int ensure(x3_ctx* c, DevBuf& b, size_t bytes);
 // the call before where that was a wave-encoder call, by a memset otherwise (and always while a graph is recorded: every
 // replay runs the same nodes); x3_encode.hip
 X3_INTERNAL int ctl_begin(x3_ctx* c);
+// x3_encode_result to x3_encode_mc: the one-pass kernel's look-back gave up, encode again in two passes (never leaves the library)
+#define X3_RETRY_TWO_PASS (-1000)
 X3_INTERNAL int x3_pipe_streams(x3_ctx* c);
 X3_INTERNAL uint64_t spf_of(const x3_params* p);
 X3_INTERNAL uint64_t max_payload_bytes(uint64_t n, uint32_t block_len);

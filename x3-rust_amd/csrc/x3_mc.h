@@ -17,8 +17,8 @@
 // is the definition, and the tests hold the GPU path against it.  A frame whose payload would pass the 24 KB a reader
 // takes (decodefile.rs:118-121) is X3_ERR_FRAME_LENGTH.
 //
-// GPU work: the two-pass frame kernels (x3_encode_kernel.h, one workgroup per frame, one block per lane -- items in the
-// order (block index, channel)), the frame check kernel (header + payload CRC, told how many channels a frame must
+// GPU work: the general frame encoder (x3_encode_kernel.h, one workgroup per frame, one block per lane -- items in the
+// order (block index, channel); one pass with look-back since round 5, two passes as its fallback), the frame check kernel (header + payload CRC, told how many channels a frame must
 // announce), and one thread per frame over the reference's own reader for the samples (x3_decode_mc_kernel).  This is
 // the generic path, not the tuned mono one: beyond parity, correctness first.
 // (no include guard: x3_encode.hip takes the encoder with X3_MC_ENCODE, x3_decode.hip the decoder with X3_MC_DECODE)
@@ -66,30 +66,56 @@ extern "C" int x3_encode_mc(x3_ctx* c, const int16_t* const* wavs, uint32_t n_ch
   if ((rc = ensure(c, c->frame_bytes, F * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(c, c->frame_off, (F + 1) * sizeof(uint64_t)))) return rc;
   uint64_t* d_off = (uint64_t*)c->frame_off.p;
-  if (int rc_ctl = ctl_begin(c)) return rc_ctl;
-  if (smem > 64 * 1024) {
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_frames_kernel<true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_frames_kernel<false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  }
   const int16_t* d_wav = (const int16_t*)c->in.p;
-  hipLaunchKernelGGL(x3_encode_frames_kernel<true>, dim3((unsigned)F), dim3(nthr), X3_ENC_SMEM_HDR + in_bytes, c->stream,
-                     d_wav, pl.g, pl.dp, (const uint64_t*)nullptr, (uint32_t*)c->frame_bytes.p, (uint8_t*)nullptr, start_pos,
-                     c->d_stats, c->d_status, (const uint16_t*)c->d_xpow, (uint32_t)in_bytes, 0u, n_ch, ch_stride);
-  hipLaunchKernelGGL(x3_scan_frame_offsets_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)c->frame_bytes.p, F,
-                     start_pos, out_cap, d_off, c->d_end_pos, c->d_status);
-  hipLaunchKernelGGL(x3_encode_frames_kernel<false>, dim3((unsigned)F), dim3(nthr), smem, c->stream, d_wav, pl.g, pl.dp,
-                     (const uint64_t*)d_off, (uint32_t*)nullptr, (uint8_t*)c->out.p, start_pos, c->d_stats, c->d_status,
-                     (const uint16_t*)c->d_xpow, (uint32_t)in_bytes, (uint32_t)img_dw, n_ch, ch_stride);
-  HIPCHK(c, hipGetLastError());
-  x3_batch all{n * n_ch, n * n_ch, 1};
-  c->last_enc = {d_wav, all, *p, spf, (uint8_t*)c->out.p, out_cap, start_pos, nullptr};
-  c->last_enc_gen = 0;
-  c->encode_pending = true;
-  c->enc_start_pos = start_pos;
   uint64_t pos = 0;
-  rc = x3_encode_result(c, &pos, stats);
+  // One pass with decoupled look-back (x3_encode_kernel.h, LOOKBACK: the kernel of the mono general path since round 4,
+  // taking several channels since round 5); the two passes -- sizes, scan, emission -- are what a launch whose look-back
+  // gave up falls back to, and option two_pass.
+  for (int attempt = (c->opt.two_pass || c->force_two_pass) ? 1 : 0; attempt < 2; ++attempt) {
+    const bool one_pass = attempt == 0;
+    if (int rc_ctl = ctl_begin(c)) return rc_ctl;
+    if (one_pass) {
+      HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_frames_kernel<false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(smem, 64 * 1024)));
+      const size_t lb_bytes = F * sizeof(unsigned long long);
+      const bool fresh = c->lb_desc.cap < lb_bytes;
+      if ((rc = ensure(c, c->lb_desc, lb_bytes))) return rc;
+      if (fresh || c->capturing || ++c->lb_epoch > 0xFFFu) {
+        HIPCHK(c, hipMemsetAsync(c->lb_desc.p, 0, c->lb_desc.cap, c->stream));
+        c->lb_epoch = 1;
+      }
+      hipLaunchKernelGGL((x3_encode_frames_kernel<false, true>), dim3((unsigned)F), dim3(nthr), smem, c->stream, d_wav, pl.g,
+                         pl.dp, (const uint64_t*)d_off, (uint32_t*)c->lb_desc.p, (uint8_t*)c->out.p, start_pos, c->d_stats,
+                         c->d_status, (const uint16_t*)c->d_xpow, (uint32_t)in_bytes, (uint32_t)img_dw, n_ch, ch_stride,
+                         c->lb_epoch, dev_cap, c->d_end_pos, c->opt.lb_drop >= 0 ? (uint32_t)c->opt.lb_drop : 0xFFFFFFFFu);
+    } else {
+      if (smem > 64 * 1024) {
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_frames_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_frames_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      }
+      hipLaunchKernelGGL(x3_encode_frames_kernel<true>, dim3((unsigned)F), dim3(nthr), X3_ENC_SMEM_HDR + in_bytes, c->stream,
+                         d_wav, pl.g, pl.dp, (const uint64_t*)nullptr, (uint32_t*)c->frame_bytes.p, (uint8_t*)nullptr, start_pos,
+                         c->d_stats, c->d_status, (const uint16_t*)c->d_xpow, (uint32_t)in_bytes, 0u, n_ch, ch_stride);
+      hipLaunchKernelGGL(x3_scan_frame_offsets_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)c->frame_bytes.p, F,
+                         start_pos, out_cap, d_off, c->d_end_pos, c->d_status);
+      hipLaunchKernelGGL(x3_encode_frames_kernel<false>, dim3((unsigned)F), dim3(nthr), smem, c->stream, d_wav, pl.g, pl.dp,
+                         (const uint64_t*)d_off, (uint32_t*)nullptr, (uint8_t*)c->out.p, start_pos, c->d_stats, c->d_status,
+                         (const uint16_t*)c->d_xpow, (uint32_t)in_bytes, (uint32_t)img_dw, n_ch, ch_stride);
+    }
+    HIPCHK(c, hipGetLastError());
+    x3_batch all{n * n_ch, n * n_ch, 1};
+    c->last_enc = {d_wav, all, *p, spf, (uint8_t*)c->out.p, out_cap, start_pos, nullptr};
+    c->last_enc_gen = one_pass ? 1 : 0;
+    c->last_enc_mc = true;   // (x3_encode_result: a look-back that gave up is re-run HERE, not as a mono call)
+    c->encode_pending = true;
+    c->enc_start_pos = start_pos;
+    rc = x3_encode_result(c, &pos, stats);
+    c->last_enc_mc = false;
+    if (rc != X3_RETRY_TWO_PASS) break;
+    if (stats) std::memset(stats, 0, 6 * sizeof(uint64_t));
+  }
   if (out_pos) *out_pos = pos;
   if (rc) return rc;
   if (pos > start_pos)
