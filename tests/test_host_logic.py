@@ -211,3 +211,8 @@ def test_decoder_ring_requests_are_not_waited_for_right_behind_their_issue():
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     assert m.findings([]) == []
+    # ... and the budgets the decode phase's occupancy rests on: five decoder groups per CU by LDS, four waves per SIMD by
+    # registers, three check-kernel waves beside them, no scratch (a round-5 variant of the check kernel took 151 registers
+    # with nothing failing)
+    res = m.resources([])
+    assert set(res) == set(m.BUDGET) and m.over_budget([]) == [], res
