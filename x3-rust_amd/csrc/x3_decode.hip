@@ -3,6 +3,7 @@
 #include "x3_internal.h"
 #include "x3_decode_kernel.h"
 #include "x3_decode_split_kernel.h"
+#include "x3_decode_blocks_kernel.h"
 #include "x3_index_kernels.h"
 #include "x3_decode_mc_kernel.h"
 
@@ -96,7 +97,34 @@ int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint6
     const size_t dyn_lds = (size_t)c->opt.dyn_lds;
     if (d_nf && !split) return X3_ERR_BAD_ARG;   // (only the three-wave decoder takes the frame count from device memory)
     TimerScope ts(c, 1, dec_stream, split);   // (the split kernel: events on its dispatch packet; the rarer single-wave kernels below: bracketed)
-    if (split) {
+    // Round 6: a BLOCK per lane (x3_decode_blocks_kernel.h) wherever the three-wave kernel would run frame by frame; that
+    // one stays for the segment index (decoding by it, recording it) and as the kernel to compare with (option
+    // "decode_three_wave").
+    const bool by_seg = seg && seg->mode && seg->d_index && seg->seg_blocks;
+    if (split && !by_seg && !c->opt.decode_three_wave) {
+      // as many groups as give every CU the same number (five are resident per CU: the walkers of ALL groups must run
+      // side by side, a frame's walk is the kernel's critical path): config 3 is 1 280 groups of 54 frames
+      const uint64_t slots = (uint64_t)c->n_cus * 5;
+      uint64_t fpg = 1;
+      if (F >= slots) {
+        const uint64_t rounds = (F + 64 * slots - 1) / (64 * slots);
+        fpg = (F + rounds * slots - 1) / (rounds * slots);
+      }
+      const uint64_t groups = (F + fpg - 1) / fpg;
+      if ((c->dec_epoch & 0xFFFu) == 0u) {
+        HIPCHK(c, hipMemsetAsync(c->d_pace, 0, 16, dec_stream));
+        HIPCHK(c, hipMemsetAsync(c->d_pace + 8, 0, 8, dec_stream));
+        HIPCHK(c, hipMemsetAsync(c->d_pace + X3_LOG_BASE, 0, X3_LOG_ENTRIES * X3_LOG_WORDS * sizeof(uint32_t), dec_stream));
+        ++c->dec_epoch;
+      }
+      c->last_decode_kernel = 3;
+      X3_LAUNCH_TIMED(ts, x3_decode_blocks_kernel, dim3((unsigned)groups), dim3(64 * X3B_WAVES), dyn_lds, dec_stream, d_x3,
+                      x3_len, d_frame_offsets, F, (uint32_t)fpg, g, d_wav_offsets, dp, d_wav, wav_cap, d_status,
+                      (X3FrameMeta*)c->dec_meta.p, c->d_pace, c->dec_epoch & 0xFFFu, d_nf);
+      ++c->dec_epoch;
+    }
+    else if (split) {
+      c->last_decode_kernel = 2;
       // the pace word's 12-bit epoch: launches 1, 2, ... 4095, then the word starts over
       if ((c->dec_epoch & 0xFFFu) == 0u) {
         HIPCHK(c, hipMemsetAsync(c->d_pace, 0, 16, dec_stream));  // (achieved and aimed-at, one word per launch parity)
@@ -146,14 +174,17 @@ int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint6
                          c->d_pace, c->dec_epoch & 0xFFFu, sg, d_nf);
       ++c->dec_epoch;
     }
-    else if (fast)
+    else if (fast) {
+      c->last_decode_kernel = 1;
       hipLaunchKernelGGL(x3_decode_fast_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, dec_stream, d_x3, x3_len,
                          d_frame_offsets, F, g, d_wav_offsets, dp, d_wav, wav_cap, d_status,
                          (X3FrameMeta*)c->dec_meta.p);
-    else
+    } else {
+      c->last_decode_kernel = 0;
       hipLaunchKernelGGL((x3_decode_lanes_kernel<false, 64>), dim3((unsigned)((F + 63) / 64)), dim3(64), 0, dec_stream,
                          d_x3, x3_len, d_frame_offsets, F, g, d_wav_offsets, dp, d_wav, wav_cap, d_status,
                          (X3FrameMeta*)c->dec_meta.p);
+    }
   }
   if (dec_stream == c->stream2) HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
   if (!c->opt.check_first && (rc = launch_check())) return rc;

@@ -1,0 +1,537 @@
+// x3_decode_blocks_kernel.h -- the decoder of round 6: one WALKER wave finds where the blocks begin, three DECODER waves
+// decode them a BLOCK per lane.
+//
+// Why.  A frame is one serial bit stream (a block begins where the one before it ends), so the lane-per-frame decoders
+// (x3_decode_split_kernel.h and the single-wave kernels behind it) are one dependent instruction chain per frame: config
+// 3 is 1 080 waves on 1 024 SIMDs, a lone wave issues a dependent vector instruction every ~8.5 clocks, and the kernel
+// sat at 0.65 ms -- 30 % of the SIMDs' issue rate, 54 % of the wave-cycles waiting -- through five rounds of
+// rearrangements (DESIGN_HISTORY.md).  But only the block BOUNDARIES are serial.  Once a block's first bit is known it
+// depends on nothing but the sample in front of it (decoder.rs:36-58), and that dependency is an addition: a prefix sum.
+//
+// So the group (up to 64 frames) is split by what is serial and what is not:
+//
+//   wave 0, the WALKER (a frame per lane, as before): header checks, the per-lane input ring, and the codeword LENGTHS
+//     only -- per pair of codewords one peek, two v_ffbh / v_mad, the window update: no values, no hand-over of
+//     indices.  For every block it leaves the bit position the block begins at (16 bits, relative to the batch) in
+//     LDS.  It works in BATCHES of 32 blocks per frame, one s_barrier per batch (the three-wave kernel: one per block).
+//   waves 1-3, the DECODERS: a batch behind the walker, a BLOCK per lane -- 32 consecutive blocks of one frame in
+//     lanes 0-31, of another in lanes 32-63.  The frame pieces' bytes are copied into LDS (coalesced 16-byte loads:
+//     no per-lane ring, no service), each lane walks ITS 20 codewords from its block's first bit (decoder.rs:132-235)
+//     and sums its differences from zero; a 32-lane segmented scan of the blocks' totals (literal blocks reset the
+//     sum) gives every block the sample in front of it, ten packed additions put it on the block's samples.  The 64
+//     lanes' samples are consecutive in wav: they go through LDS once and leave as WHOLE 128-byte lines, 32 lanes x
+//     16 bytes per frame piece -- no staging rings, no flusher wave.
+//
+// Every lane's first batch is cut so that it ends on a line of the destination (n0 blocks, 17..32: 40 * n0 + the
+// row's phase is a multiple of 128); all later batches are 32 blocks = 1 280 bytes = ten lines.  Partial lines are
+// only written at the two ends of a frame's row.
+//
+// The group count is chosen by the host so that every CU gets the same number of groups (config 3: 1 280 groups of 54
+// frames, five per CU) -- the walker's idle lanes cost nothing, it is a latency chain; the decoders' lanes are blocks.
+// LDS (28.4 KB) admits exactly five groups per CU.
+//
+// Anything irregular -- a decode error (BFP exponent, table bound), a zero run of 32 bits, a read behind the payload,
+// a batch longer than valid codewords can make it -- marks the FRAME for the reference's own reader
+// (X3D_REPLAY, x3_decode_replay.h; x3_decode_merge_kernel), exactly as in the lane-per-frame kernels; what the
+// decoders wrote for such a frame is overwritten there.  Every read is bounded whatever the bits say.
+//
+// Geometry: block_len = 20, the default Rice codes (the hard-wired decoder.rs:180), output rows on 8-byte boundaries
+// (the host sends everything else to the older kernels).  Same results as x3_decode_split_kernel.
+#pragma once
+#include "x3_decode_kernel.h"
+
+#define X3B_BL 20u
+#define X3B_PAIRS 10u
+#define X3B_NB 32u                       // blocks per batch and frame
+#define X3B_D 3u                         // decoder waves
+#define X3B_WAVES (1u + X3B_D)
+#define X3B_SPAN_MAX (X3B_NB * 326u)     // bits 32 valid blocks can take (a literal block: 6 + 20 * 16)
+#define X3B_IN_PITCH 1392u               // input staging per frame piece: 86 chunks of 16 bytes + 16
+#define X3B_IN_CHUNKS 85u
+#define X3B_OUT_PITCH 1408u              // output staging per frame piece: up to 120 bytes of phase + 1 280 + a pending sample
+#define X3B_SCRATCH (2u * X3B_OUT_PITCH) // per decoder wave (input and output staging share it)
+#define X3B_DESC_PITCH 34u               // uint16 per frame and batch buffer: 32 + 2 (17 dwords: rows spread over the banks)
+#define X3B_PERIOD 2u                    // the walker's ring is topped up every second block
+#define X3B_AHEAD 3u
+#ifndef X3B_WALKER_PRIO
+#define X3B_WALKER_PRIO 3
+#endif
+
+#define X3B_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// one pair of codewords from the 32-bit peek t (x3_decode_split_kernel.h, the parser's pair): a codeword = z zeros +
+// `width` bits (z counts in Rice blocks only: zmask), n = z + width bits in all; nn = -n serves as shift count for
+// "drop n bits" and "the fw bits that end n bits in".  Returns nn1 + nn2.
+#define X3B_PAIR_FIELDS(t, zmask, nwidth, fw, z1, v1, z2, v2, nsum)                                         \
+  do {                                                                                                      \
+    uint32_t t2_, nn1_, nn2_;                                                                               \
+    asm("v_ffbh_u32 %[z1], %[tt]\n\t"                                                                       \
+        "v_mad_i32_i24 %[nn1], %[z1], %[zm], %[nw]\n\t"                                                     \
+        "v_alignbit_b32 %[t2], %[tt], 0, %[nn1]\n\t"                                                        \
+        "v_bfe_u32 %[v1], %[tt], %[nn1], %[fw_]\n\t"                                                        \
+        "v_ffbh_u32 %[z2], %[t2]\n\t"                                                                       \
+        "v_mad_i32_i24 %[nn2], %[z2], %[zm], %[nw]\n\t"                                                     \
+        "v_bfe_u32 %[v2], %[t2], %[nn2], %[fw_]\n\t"                                                        \
+        "v_add_u32 %[ns], %[nn1], %[nn2]"                                                                   \
+        : [z1] "=&v"(z1), [v1] "=&v"(v1), [z2] "=&v"(z2), [v2] "=&v"(v2), [nn1] "=&v"(nn1_), [nn2] "=&v"(nn2_), \
+          [t2] "=&v"(t2_), [ns] "=&v"(nsum)                                                                 \
+        : [tt] "v"(t), [zm] "v"(zmask), [nw] "v"(nwidth), [fw_] "v"(fw));                                   \
+  } while (0)
+
+// ... the lengths only (the walker)
+#define X3B_PAIR_LENGTHS(t, zmask, nwidth, nsum)                                                            \
+  do {                                                                                                      \
+    uint32_t z1_, z2_, t2_, nn1_, nn2_;                                                                     \
+    asm("v_ffbh_u32 %[z1], %[tt]\n\t"                                                                       \
+        "v_mad_i32_i24 %[nn1], %[z1], %[zm], %[nw]\n\t"                                                     \
+        "v_alignbit_b32 %[t2], %[tt], 0, %[nn1]\n\t"                                                        \
+        "v_ffbh_u32 %[z2], %[t2]\n\t"                                                                       \
+        "v_mad_i32_i24 %[nn2], %[z2], %[zm], %[nw]\n\t"                                                     \
+        "v_add_u32 %[ns], %[nn1], %[nn2]"                                                                   \
+        : [z1] "=&v"(z1_), [z2] "=&v"(z2_), [nn1] "=&v"(nn1_), [nn2] "=&v"(nn2_), [t2] "=&v"(t2_), [ns] "=&v"(nsum) \
+        : [tt] "v"(t), [zm] "v"(zmask), [nw] "v"(nwidth));                                                  \
+  } while (0)
+
+__device__ __forceinline__ void x3b_lds_write_b32(uint32_t addr, uint32_t v) {
+  *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(addr) = v;
+}
+
+// blocks of the first batch of a row that begins at byte address `row` (8-byte aligned): 17..32, and
+// (row + 40 * n0) is a multiple of 128
+__device__ __forceinline__ uint32_t x3b_first_batch(uint64_t row) {
+  const uint32_t phi8 = ((uint32_t)row & 127u) >> 3;
+  return 17u + ((3u * phi8 + 15u) & 15u);
+}
+
+__global__ void __launch_bounds__(64 * X3B_WAVES) __attribute__((amdgpu_waves_per_eu(5, 5)))
+x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uint64_t* __restrict__ frame_off,
+                        uint64_t n_frames_arg, uint32_t fpg, X3Geom g, const uint64_t* __restrict__ wav_off, X3DevParams p,
+                        int16_t* __restrict__ wav, uint64_t wav_cap, int32_t* __restrict__ status,
+                        X3FrameMeta* __restrict__ meta, uint32_t* __restrict__ pace, uint32_t pace_epoch,
+                        const unsigned long long* __restrict__ d_nf) {
+  const uint64_t n_frames = d_nf ? (*d_nf < n_frames_arg ? (uint64_t)*d_nf : n_frames_arg) : n_frames_arg;
+  const uint64_t f0 = (uint64_t)blockIdx.x * fpg;   // the group's first frame
+  if (f0 >= n_frames) return;
+  const uint32_t nfr = (uint32_t)(n_frames - f0 < fpg ? n_frames - f0 : fpg);   // its frames (uniform)
+
+  __shared__ __attribute__((aligned(128))) uint32_t ring[64 * X3_DEC_RING_DW];             // the walker's input ring
+  __shared__ __attribute__((aligned(16))) uint16_t desc[2][64 * X3B_DESC_PITCH];            // where the blocks begin
+  __shared__ uint32_t bt_base[2][64], bt_end[2][64];    // a batch's first bit and the bit behind its last block (payload bits)
+  __shared__ unsigned long long fr_in[64], fr_out[64];  // the frame's payload and its row in wav (byte addresses)
+  __shared__ uint32_t fr_samples[64];                   // 0: no such frame, or nothing to decode
+  __shared__ uint32_t fr_n0[64], fr_last[64], fr_bad[64];
+  __shared__ uint32_t s_nbatch;
+  __shared__ __attribute__((aligned(128))) uint8_t scratch[X3B_D * X3B_SCRATCH];
+
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  const unsigned long long wall_t0 = wall_clock64();
+  const unsigned long long clk_t0 = clock64();
+
+  if (wave == 0u) {
+    // ================================================================================ the walker
+    __builtin_amdgcn_s_setprio(X3B_WALKER_PRIO);
+    const uint64_t f = f0 + lane;
+    bool active = lane < nfr;
+    int32_t st = X3D_OK;
+    uint32_t samples = 0, plen = 2;
+    uint64_t p0 = 0, wo = 0;
+    if (active) {
+      uint32_t pcrc_unused;
+      st = x3_frame_header_check(reinterpret_cast<const uint32_t*>(x3 - (reinterpret_cast<uintptr_t>(x3) & 3u)),
+                                 (x3_len + (reinterpret_cast<uintptr_t>(x3) & 3u) + 3) >> 2,
+                                 x3_len + (reinterpret_cast<uintptr_t>(x3) & 3u),
+                                 frame_off[f] + (reinterpret_cast<uintptr_t>(x3) & 3u), plen, samples, pcrc_unused);
+      meta[f].payload_len = plen;
+      meta[f].samples = samples;
+      p0 = frame_off[f] + 20;
+      if (st != X3D_OK) {
+        active = false;
+      } else if (samples == 0 || plen < 2) {
+        st = X3D_BAD_ARG;
+        active = false;
+      } else {
+        if (wav_off) {
+          wo = wav_off[f];
+        } else {
+          const uint64_t clip = f / g.fpc;
+          wo = clip * g.clip_stride + (f - clip * g.fpc) * (uint64_t)p.spf;
+        }
+        if (wo + samples > wav_cap) {
+          st = X3D_BAD_ARG;
+          active = false;
+        }
+      }
+    }
+    if (!active) { p0 = 0; plen = 2; wo = 0; samples = 0; }
+    const uint32_t nblk = samples ? (samples - 1u + X3B_BL - 1u) / X3B_BL : 0u;
+    const uint64_t rowb = (uint64_t)(uintptr_t)(wav + wo);
+    const uint32_t n0 = x3b_first_batch(rowb);
+    const uint32_t nbatch = nblk == 0u ? 0u : (nblk <= n0 ? 1u : 1u + (nblk - n0 + X3B_NB - 1u) / X3B_NB);
+    const uint32_t nbatch_max = (uint32_t)__builtin_amdgcn_readfirstlane((int)x3_wave_max_u32(nbatch));
+    uint32_t first = 0;
+    if (active) {
+      first = ((uint32_t)x3[p0] << 8) | x3[p0 + 1];
+      if (samples == 1u) wav[wo] = (int16_t)first;
+    }
+    fr_in[lane] = (unsigned long long)(uintptr_t)(x3 + p0);
+    fr_out[lane] = rowb;
+    fr_samples[lane] = nblk ? samples : 0u;
+    fr_n0[lane] = n0;
+    fr_last[lane] = first;
+    fr_bad[lane] = 0u;
+    if (lane == 0u) s_nbatch = nbatch_max;
+
+    // ---- the input ring (x3_decode_split_kernel.h): 32 dwords per lane in a row of 128 bytes, stream word j in slot
+    // ~j & 31 (descending), parked big-endian
+    uint32_t* const row = ring + lane * X3_DEC_RING_DW;
+    const uint32_t row_base = x3_lds_addr(row);
+#define X3B_RING_WORD(j) row[~(j) & 31u]
+    const uint32_t adj = (uint32_t)(reinterpret_cast<uintptr_t>(x3) & 15u);
+    const uint64_t abs_bits = (uint64_t)adj + p0 + 2u;              // the byte behind the first sample
+    const uint64_t abs_last = (uint64_t)adj + p0 + plen - 1u;       // the payload's last byte
+    const uint64_t abs_base = (abs_bits < abs_last ? abs_bits : abs_last) & ~15ull;
+    const uint8_t* __restrict__ const x3b = (x3 - adj) + abs_base;
+    const uint32_t v_bits = (uint32_t)(abs_bits - abs_base);        // first block header (0..16), in bytes from the ring's first chunk
+    const uint32_t v_end = v_bits - 2u + plen;                      // end of the payload
+    const int32_t v_rel = 16 - 8 * (int32_t)v_bits;                 // payload bit = ring bit + v_rel
+    const uint32_t v_last = (v_end - 1u) & ~15u;                    // last 16-byte chunk that holds payload
+    uint32_t v_next = 0, wr_abs = 0;
+    constexpr uint32_t SVC_MAX = 3u * X3B_PERIOD;
+    constexpr uint32_t SVC_AHEAD = X3B_AHEAD;
+    auto request = [&](uint32_t v) -> uint4 {
+      const uint32_t a = v < v_last ? v : v_last;
+      return *reinterpret_cast<const uint4*>(x3b + a);
+    };
+    auto park = [&](uint4 c) {
+      x3_lds_write_b128(x3_and_or(0u - 4u * wr_abs - 16u, 112u, row_base), x3_bswap32(c.w), x3_bswap32(c.z),
+                        x3_bswap32(c.y), x3_bswap32(c.x));
+      wr_abs += 4;
+    };
+    const bool dense_grp = __any(active && plen > 9728u);
+    uint4 ld[SVC_MAX];
+    uint32_t v_req = 0;
+    {
+      uint4 c[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) c[k] = request(v_next + 16u * k);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) park(c[k]);
+      v_next += 128;
+#pragma unroll
+      for (int k = 0; k < (int)SVC_AHEAD; ++k) ld[k] = request(v_next + 16u * k);
+      if (dense_grp) {
+#pragma unroll
+        for (int k = (int)SVC_AHEAD; k < (int)SVC_MAX; ++k) ld[k] = request(v_next + 16u * k);
+      }
+      v_req = v_next;
+    }
+    auto service = [&](uint32_t widx) {
+      const uint32_t used = wr_abs - widx;
+      const uint32_t fit = used >= X3_DEC_RING_DW ? 0u : (X3_DEC_RING_DW - used) >> 2;
+#pragma unroll
+      for (uint32_t k = 0; k < SVC_AHEAD; ++k) {
+        if (fit > k) park(ld[k]);
+      }
+      if (__any(fit > SVC_AHEAD)) {
+        if (!dense_grp) {
+#pragma unroll
+          for (uint32_t k = SVC_AHEAD; k < SVC_MAX; ++k) ld[k] = request(v_req + 16u * k);
+        }
+#pragma unroll
+        for (uint32_t k = SVC_AHEAD; k < SVC_MAX; ++k) {
+          if (fit > k) park(ld[k]);
+        }
+      }
+      v_next += 16u * (fit > SVC_MAX ? SVC_MAX : fit);
+      v_req = v_next;
+#pragma unroll
+      for (int k = 0; k < (int)SVC_AHEAD; ++k) ld[k] = request(v_req + 16u * k);
+      if (dense_grp) {
+#pragma unroll
+        for (int k = (int)SVC_AHEAD; k < (int)SVC_MAX; ++k) ld[k] = request(v_req + 16u * k);
+      }
+    };
+    X3_WAVE_LDS_ORDER();
+    // window: w0 holds `s` unconsumed bits (its low s bits), then w1; wn is the word behind w1
+    const uint32_t a0 = 8u * (v_bits & 3u);
+    const uint32_t widx0 = (v_bits >> 2) - (a0 == 0 ? 1u : 0u);
+    uint32_t s = (32u - a0) & 31u;
+    uint32_t w0 = X3B_RING_WORD(widx0), w1 = X3B_RING_WORD(widx0 + 1u), wn = X3B_RING_WORD(widx0 + 2u);
+    uint32_t qb = 4u * ~(widx0 + 2u);
+    auto consume_to = [&](int32_t s2) {
+      const uint32_t m = (uint32_t)(s2 >> 31);
+      s = (uint32_t)s2 & 31u;
+      w0 = x3_bfi(m, w1, w0);
+      w1 = x3_bfi(m, wn, w1);
+      uint32_t addr;
+      asm("v_lshl_add_u32 %0, %2, 2, %0\n\t"
+          "v_and_or_b32 %1, %0, %3, %4"
+          : "+v"(qb), "=v"(addr) : "v"(m), "v"(124u), "v"(row_base));
+      wn = x3_lds_read_b32(addr);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto ring_index = [&]() -> uint32_t { return ~((uint32_t)((int32_t)qb >> 2)) - 2u; };
+    auto position = [&]() -> uint32_t { return (uint32_t)((int32_t)(32u * ring_index() + 32u - s) + v_rel); };   // payload bits
+
+    X3B_BARRIER();   // the frames' records are there (and the decoders have read nothing yet)
+
+    uint32_t remaining = samples ? samples - 1u : 0u;   // samples still to walk
+    uint32_t blocks_left = nblk;
+    bool over = false;
+    uint32_t it = 0;    // blocks walked by the wave (the service's clock)
+    for (uint32_t k = 0; k < nbatch_max; ++k) {
+      const uint32_t buf = k & 1u;
+      const uint32_t quota = k ? X3B_NB : n0;
+      const uint32_t nbk = blocks_left < quota ? blocks_left : quota;
+      blocks_left -= nbk;
+      const uint32_t maxb = (uint32_t)__builtin_amdgcn_readfirstlane((int)x3_wave_max_u32(nbk));
+      const uint32_t base = position();
+      bt_base[buf][lane] = base;
+      uint16_t* const dq = &desc[buf][lane * X3B_DESC_PITCH];
+      for (uint32_t b = 0; b < maxb; ++b, ++it) {
+        const uint32_t cnt = b < nbk ? (remaining < X3B_BL ? remaining : X3B_BL) : 0u;
+        remaining -= cnt;
+        dq[b] = (uint16_t)(position() - base);
+        if ((it % X3B_PERIOD) == 0u) service(ring_index());
+        const uint32_t hdr = __builtin_amdgcn_alignbit(w0, w1, s) >> 26;
+        const uint32_t ftype = hdr >> 4;
+        const uint32_t live = cnt ? 0xFFFFFFFFu : 0u;
+        const uint32_t zmask0 = (uint32_t)((int32_t)(15u - hdr) >> 31);      // all ones for Rice
+        consume_to((int32_t)(s + (live & ((zmask0 & 4u) - 6u))));             // 6 header bits for BFP, 2 for Rice
+        const uint32_t width = x3_bfi(zmask0, (1u << ftype) >> 1, (hdr & 15u) + 1u);   // Rice 1, 2, 4; BFP E
+        const uint32_t zmask = zmask0 & live;
+        const uint32_t nwidth = (0u - width) & live;
+        if (__all(cnt == X3B_BL || cnt == 0u)) {
+#pragma unroll
+          for (uint32_t j = 0; j < X3B_PAIRS; ++j) {
+            const uint32_t t = __builtin_amdgcn_alignbit(w0, w1, s);
+            uint32_t ns;
+            X3B_PAIR_LENGTHS(t, zmask, nwidth, ns);
+            consume_to((int32_t)(s + ns));
+          }
+        } else {
+          for (uint32_t j = 0; j < X3B_BL; ++j) {
+            const uint32_t t = __builtin_amdgcn_alignbit(w0, w1, s);
+            const uint32_t z = x3_ffbh(t) & zmask;
+            const uint32_t nn = nwidth - z;
+            consume_to((int32_t)(s + (j < cnt ? nn : 0u)));
+          }
+        }
+        // the frame ends here: was it read beyond its payload?  (x3_decode_replay.h: the reference's reader knows about
+        // the zeros there)
+        if (cnt != 0u && remaining == 0u && (int32_t)(32u * ring_index() + 32u - s) > (int32_t)(8u * v_end)) over = true;
+      }
+      bt_end[buf][lane] = position();
+      X3B_BARRIER();
+    }
+    X3B_BARRIER();   // the decoders are through the last batch
+    if (lane < nfr) {
+      if (active && (over || fr_bad[lane] != 0u)) st = X3D_REPLAY;
+      status[f] = st;
+    }
+    if (lane == 0u && blockIdx.x == 0u) {
+      // the launch log (x3_ctx_launch_log): group 0's shader ticks against the 100 MHz clock
+      uint32_t* const lg = pace + X3_LOG_BASE + X3_LOG_WORDS * (pace_epoch & (X3_LOG_ENTRIES - 1u));
+      const unsigned long long dt = clock64() - clk_t0;
+      uint64_t t16 = nblk ? (dt * 16u) / nblk : 0u;
+      if (t16 >= (1u << 20)) t16 = (1u << 20) - 1u;
+      lg[0] = ((pace_epoch & 0xFFFu) << 20) | (uint32_t)t16;
+      lg[1] = ((pace_epoch & 0xFFFu) << 20);
+      lg[2] = (uint32_t)dt;
+      lg[3] = (uint32_t)(wall_clock64() - wall_t0);
+    }
+#undef X3B_RING_WORD
+  } else {
+    // ================================================================================ the decoders
+    const uint32_t dw = wave - 1u;
+    const uint32_t h = lane >> 5, j = lane & 31u;
+    uint8_t* const my = scratch + dw * X3B_SCRATCH;
+    const uint32_t in_base = x3_lds_addr(my) + h * X3B_IN_PITCH;      // (2 * 1392 <= 2 * 1408)
+    const uint32_t in_top = in_base + X3B_IN_PITCH - 20u;             // LDS byte address of stream word 0 (words descend)
+    const uint32_t out_base = x3_lds_addr(my) + h * X3B_OUT_PITCH;
+    const uint64_t x3_lastc = ((uint64_t)(uintptr_t)x3 + x3_len - 1u) & ~15ull;   // the last 16-byte chunk that holds stream
+    const uint32_t k_tab = (p.k[1] << 16) | (p.k[2] << 24);           // log2(level) by ftype
+    const uint32_t bound_tab = (p.inv_len[0] << 8) | (p.inv_len[1] << 16) | (p.inv_len[2] << 24);
+    X3B_BARRIER();
+    const uint32_t nbatch_max = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_nbatch);
+    const uint32_t niter = (nfr + 1u) >> 1;
+    for (uint32_t k = 0; k < nbatch_max; ++k) {
+      X3B_BARRIER();   // the walker is through batch k
+      const uint32_t buf = k & 1u;
+      for (uint32_t i = dw; i < niter; i += X3B_D) {
+        const uint32_t fl = 2u * i + h;
+        const uint32_t flc = fl < 64u ? fl : 63u;
+        const uint32_t samples = fl < nfr ? fr_samples[flc] : 0u;
+        const uint32_t n0 = fr_n0[flc];
+        const uint32_t nblk = samples ? (samples - 1u + X3B_BL - 1u) / X3B_BL : 0u;
+        const uint32_t b0 = k ? n0 + X3B_NB * (k - 1u) : 0u;
+        const uint32_t quota = k ? X3B_NB : n0;
+        uint32_t nbk = nblk > b0 ? nblk - b0 : 0u;
+        if (nbk > quota) nbk = quota;
+        const uint32_t base = bt_base[buf][flc], end = bt_end[buf][flc];
+        const uint32_t span = end - base;
+        if (nbk && span > X3B_SPAN_MAX) {   // not what 32 valid blocks can take: the reference's reader decides
+          fr_bad[flc] = 1u;
+          nbk = 0u;
+        }
+        const bool has = j < nbk;
+        const uint32_t bi = b0 + j;
+        const uint32_t cnt = has ? (samples - 1u - X3B_BL * bi < X3B_BL ? samples - 1u - X3B_BL * bi : X3B_BL) : 0u;
+
+        // ---- the piece's bytes into LDS: 16-byte chunks from the aligned address in front of its first bit
+        const uint64_t gp = fr_in[flc] + (base >> 3);
+        const uint32_t off16 = (uint32_t)gp & 15u;
+        const uint64_t ga = gp - off16;
+        uint32_t nchunk = nbk ? (((span + (base & 7u) + 7u) >> 3) + off16 + 15u) / 16u + 1u : 0u;
+        if (nchunk > X3B_IN_CHUNKS) nchunk = X3B_IN_CHUNKS;
+        const uint32_t rounds = __any(nchunk > 64u) ? 3u : (__any(nchunk > 32u) ? 2u : (__any(nchunk != 0u) ? 1u : 0u));
+        X3_WAVE_LDS_ORDER();
+        for (uint32_t r = 0; r < rounds; ++r) {
+          const uint32_t c = j + 32u * r;
+          if (c < nchunk) {
+            uint64_t a = ga + 16u * c;
+            if (a > x3_lastc) a = x3_lastc;
+            const uint4 q = *reinterpret_cast<const uint4*>(a);
+            // words descend: chunk c's words 4c .. 4c+3 at in_top - 4 * (4c + i)
+            x3_lds_write_b128(in_top - 16u * c - 12u, x3_bswap32(q.w), x3_bswap32(q.z), x3_bswap32(q.y), x3_bswap32(q.x));
+          }
+        }
+        X3_WAVE_LDS_ORDER();
+
+        // ---- this lane's block: its first bit, counted from chunk 0
+        uint32_t rel = has ? desc[buf][flc * X3B_DESC_PITCH + j] : 0u;
+        if (rel > X3B_SPAN_MAX) { if (has) fr_bad[flc] = 1u; rel = 0u; }
+        const uint32_t bbit = 8u * off16 + (base & 7u) + rel;
+        const uint32_t a0 = bbit & 31u;
+        const uint32_t jdx = (bbit >> 5) - (a0 == 0u ? 1u : 0u);   // (may be -1: a word that is read and not used)
+        uint32_t s = (32u - a0) & 31u;
+        uint32_t qa = in_top - 4u * (jdx + 2u);                   // LDS address of wn
+        uint32_t w0 = x3_lds_read_b32(qa + 8u), w1 = x3_lds_read_b32(qa + 4u), wn = x3_lds_read_b32(qa);
+        auto consume_to = [&](int32_t s2) {
+          const uint32_t m = (uint32_t)(s2 >> 31);
+          s = (uint32_t)s2 & 31u;
+          w0 = x3_bfi(m, w1, w0);
+          w1 = x3_bfi(m, wn, w1);
+          asm("v_lshl_add_u32 %0, %1, 2, %0" : "+v"(qa) : "v"(m));   // a shift: the next word is four bytes down
+          wn = x3_lds_read_b32(qa);
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        // block header and parameters (decoder.rs:138-144, 209-216), as arithmetic on the six bits
+        const uint32_t hdr = __builtin_amdgcn_alignbit(w0, w1, s) >> 26;
+        const uint32_t ftype = hdr >> 4;
+        const uint32_t E = (hdr & 15u) + 1u;
+        const uint32_t zmask = (uint32_t)((int32_t)(15u - hdr) >> 31);     // all ones for Rice
+        consume_to((int32_t)(s + ((zmask & 4u) - 6u)));
+        const uint32_t width = x3_bfi(zmask, (1u << ftype) >> 1, E);
+        const uint32_t kk = (k_tab >> (8u * ftype)) & 0xFFu;
+        const uint32_t fw = x3_bfi(zmask, kk, width);
+        const uint32_t lsh = x3_bfi(zmask, kk, 31u);
+        const uint32_t nwidth = 0u - width;
+        const bool bfp = zmask == 0u;
+        const uint32_t litmask = ~zmask & (uint32_t)((int32_t)(14u - (hdr & 15u)) >> 31);  // E == 16
+        const uint32_t neg_thresh = ~zmask & (1u << (E - 1u));
+        const uint32_t neg2 = (neg_thresh << 1) & ~litmask;
+        const uint32_t bound = x3_bfi(zmask, (bound_tab >> (8u * ftype)) & 0xFFu, 0xFFFFFFFFu);
+        const uint32_t tm12 = ((neg_thresh - 1u) & 0xFFFFu) * 0x10001u;
+        const uint32_t neg22 = (neg2 & 0xFFFFu) * 0x10001u;
+        const bool full = __all(cnt == X3B_BL || cnt == 0u);
+        uint32_t maxii2 = 0, prevP = 0;
+        uint32_t W[X3B_PAIRS];
+#pragma unroll
+        for (uint32_t r = 0; r < X3B_PAIRS; ++r) {
+          const uint32_t t = __builtin_amdgcn_alignbit(w0, w1, s);
+          uint32_t z1, v1, z2, v2, ns;
+          X3B_PAIR_FIELDS(t, zmask, nwidth, fw, z1, v1, z2, v2, ns);
+          consume_to((int32_t)(s + ns));
+          uint32_t X = x3_pack_lo16((z1 << lsh) + v1, (z2 << lsh) + v2);
+          if (!full) {   // a frame's last block: the samples behind its end count for nothing
+            const uint32_t vm = (2u * r < cnt ? 0xFFFFu : 0u) | (2u * r + 1u < cnt ? 0xFFFF0000u : 0u);
+            X &= vm;
+          }
+          // Rice: X = i, the index into the inverse table (decoder.rs:186), a zigzag (x3.rs:200-204); BFP:
+          // unsigned_to_i16 (decoder.rs:198-207), strict compare; literal: the field is the sample
+          maxii2 = x3_pk_max_u16(maxii2, X);
+          const uint32_t R = x3_pk_lshr_b16_1(X) ^ x3_pk_sub_u16(0u, X & 0x00010001u);
+          const uint32_t B = x3_pk_sub_u16(X, x3_pk_add_u16(X, tm12) & neg22);
+          const uint32_t D = x3_bfi(zmask, R, B);
+          uint32_t P = x3_pk_mad_u16_alo(D, 0x00010000u, x3_pk_add_u16_bhi(D, prevP));   // (last + d1, last + d1 + d2)
+          P = x3_bfi(litmask, X, P);
+          W[r] = __builtin_amdgcn_alignbit(P, prevP, 16);   // (the sample in front, this pair's first)
+          prevP = P;
+        }
+        if (cnt && ((bfp && E <= 5u) || max(maxii2 & 0xFFFFu, maxii2 >> 16) >= bound)) fr_bad[flc] = 1u;
+
+        // ---- the sample in front of every block: a scan over the 32 blocks of the piece.  A block is the map
+        // x -> lit ? T : x + T (T = its last sample counted from zero); maps compose as (L, T) after (L', T') =
+        // (L | L', L ? T : T' + T).  Identity for lanes without a block.
+        uint32_t sT = cnt ? (prevP >> 16) : 0u;
+        uint32_t sL = cnt ? litmask : 0u;
+        // (for a short last block prevP's high half is not the last sample; nothing follows it)
+#define X3B_SCAN_STEP(ctrl, rmask)                                                                   \
+        {                                                                                            \
+          const uint32_t pT = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sT, ctrl, rmask, 0xF, false); \
+          const uint32_t pL = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sL, ctrl, rmask, 0xF, false); \
+          sT = (pT & ~sL) + sT;                                                                      \
+          sL = sL | pL;                                                                              \
+        }
+        X3B_SCAN_STEP(0x111, 0xF)   // row_shr:1
+        X3B_SCAN_STEP(0x112, 0xF)   // row_shr:2
+        X3B_SCAN_STEP(0x114, 0xF)   // row_shr:4
+        X3B_SCAN_STEP(0x118, 0xF)   // row_shr:8
+        X3B_SCAN_STEP(0x142, 0xA)   // row_bcast:15 -> rows 1, 3: the halves' second rows take their first row's total
+#undef X3B_SCAN_STEP
+        // exclusive: the lane below (nothing for the first lane of a piece)
+        uint32_t xT = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sT, 0x138, 0xF, 0xF, false);   // wave_shr:1
+        uint32_t xL = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sL, 0x138, 0xF, 0xF, false);
+        if (j == 0u) { xT = 0u; xL = 0u; }
+        const uint32_t last_in = fr_last[flc];
+        const uint32_t front = ((xL ? 0u : last_in) + xT) & 0xFFFFu;       // the sample in front of this lane's block
+        X3_WAVE_LDS_ORDER();
+        if (j == 31u && nbk) fr_last[flc] = ((sL ? 0u : last_in) + sT) & 0xFFFFu;
+        const uint32_t add2 = litmask ? 0u : front * 0x10001u;
+        W[0] = x3_pk_add_u16(W[0], litmask ? front : add2);
+#pragma unroll
+        for (uint32_t r = 1; r < X3B_PAIRS; ++r) W[r] = x3_pk_add_u16(W[r], add2);
+
+        // ---- out: the piece's samples through LDS, then whole lines.  LDS byte = destination byte modulo 128.
+        const uint64_t G0 = fr_out[flc] + 40ull * b0;
+        const uint32_t PH = (uint32_t)G0 & 127u;
+        X3_WAVE_LDS_ORDER();
+        if (has) {
+          const uint32_t oa = out_base + PH + 40u * j;
+#pragma unroll
+          for (uint32_t r = 0; r < X3B_PAIRS; r += 2) x3_lds_write_b64(oa + 4u * r, W[r], W[r + 1u]);
+          // a full last block of the frame: its last sample is nobody's "sample in front"
+          if (cnt == X3B_BL && bi + 1u == nblk)
+            x3b_lds_write_b32(oa + 40u, ((litmask ? 0u : front) + (prevP >> 16)) & 0xFFFFu);
+        }
+        X3_WAVE_LDS_ORDER();
+        // bytes [PH, EB) of the staging are the piece: all of its blocks, or what is left of the row
+        uint32_t EB = 0;
+        if (nbk) {
+          // (the batch that holds the frame's last block ends with the row: a short block, or a full one and a pending sample)
+          const uint32_t left = 2u * samples - 40u * b0;
+          EB = PH + (b0 + nbk == nblk ? left : 40u * nbk);
+        }
+        uint8_t* const GL = reinterpret_cast<uint8_t*>(G0 - PH);
+#pragma unroll
+        for (uint32_t r = 0; r < 3u; ++r) {
+          const uint32_t lo = 16u * (j + 32u * r);
+          if (lo < EB && lo + 16u > PH) {
+            if (lo >= PH && lo + 16u <= EB) {
+              x3_store_stream16(GL + lo, x3_lds_read_b128(out_base + lo));
+            } else {
+              // the two ends of a row: sample by sample
+              const uint32_t from = lo > PH ? lo : PH, to = lo + 16u < EB ? lo + 16u : EB;
+              for (uint32_t bb = from; bb < to; bb += 2u)
+                *reinterpret_cast<uint16_t*>(GL + bb) = (uint16_t)x3_lds_read_u16(out_base + bb, 0u);
+            }
+          }
+        }
+        X3_WAVE_LDS_ORDER();
+      }
+    }
+    X3B_BARRIER();   // (the walker reads fr_bad behind this one)
+  }
+}

@@ -54,6 +54,8 @@ struct X3Opts {
   long long wave_drop = -1;   // tests: the workgroup generation whose total the wave encoder never publishes -- what a workgroup
                               // that is not resident looks like to the others: their bounded waits give up (-1 = none)
   int decode_single = 0;      // X3HIP_DECODE_SINGLE: single-wave decoder kernels only
+  int decode_three_wave = 0;  // X3HIP_DECODE_THREE_WAVE: the lane-per-frame decoder of rounds 2-5 (x3_decode_split_kernel.h) where
+                              // round 6's block-per-lane decoder (x3_decode_blocks_kernel.h) would run
   int host_walk = -1;         // X3HIP_HOST_WALK: frame walk of x3_decode_stream on the host (1) / GPU (0) / by size (-1)
   long long host_chunk_frames = 0;  // X3HIP_HOST_CHUNK_FRAMES: x3_encode on host buffers takes a long input in chunks of this many
                               // frames, upload / encode / download side by side (0 = chunks of 16 Mi samples for inputs from
@@ -91,6 +93,7 @@ struct x3_ctx {
   X3SegSpec enc_seg{nullptr, 0, 0};         // x3_encode_dev_seg -> encode_dev_impl: the index the next launch fills
   unsigned long long stream_one_trip = 0;   // x3_decode_stream_dev calls served with one trip to the host
   int last_seg_stretches = 0;               // the last decode launch: stretches per frame (0: none given, -1: recorded)
+  int last_decode_kernel = 0;               // ... and which kernel served it (option "decode_kernel_in_use")
   unsigned long long needed_pos = 0;        // the position a host-buffer encode that ran out of room would have reached
   unsigned long long encode_fallbacks = 0;  // launches of the single-pass encoder that timed out (two-pass re-run)
   int device = 0;
