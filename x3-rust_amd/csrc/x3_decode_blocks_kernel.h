@@ -43,7 +43,10 @@
 #define X3B_BL 20u
 #define X3B_PAIRS 10u
 #define X3B_NB 32u                       // blocks per batch and frame
-#define X3B_D 3u                         // decoder waves
+#ifndef X3B_D
+#define X3B_D 3u
+#endif
+// (decoder waves)                         // decoder waves
 #define X3B_WAVES (1u + X3B_D)
 #define X3B_SPAN_MAX (X3B_NB * 326u)     // bits 32 valid blocks can take (a literal block: 6 + 20 * 16)
 #define X3B_IN_PITCH 1392u               // input staging per frame piece: 86 chunks of 16 bytes + 16
@@ -55,6 +58,16 @@
 #define X3B_AHEAD 3u
 #ifndef X3B_WALKER_PRIO
 #define X3B_WALKER_PRIO 3
+#endif
+
+// TIMING experiments (results are wrong; -DX3_EXPERIMENT builds only): 1 = the decoders do nothing, 2 = the walker skips its
+// codeword walk, 4 = no global stores from the decoders, 8 = no staging copy, 16 = the decoders skip their pair loops,
+// 32 = the walker skips its ring service
+#ifndef X3B_KO
+#define X3B_KO 0
+#endif
+#if X3B_KO && !defined(X3_EXPERIMENT)
+#error "X3B_KO builds give wrong results: experiment builds only (-DX3_EXPERIMENT)"
 #endif
 
 #define X3B_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -78,22 +91,69 @@
         : [tt] "v"(t), [zm] "v"(zmask), [nw] "v"(nwidth), [fw_] "v"(fw));                                   \
   } while (0)
 
-// ... the lengths only (the walker)
-#define X3B_PAIR_LENGTHS(t, zmask, nwidth, nsum)                                                            \
-  do {                                                                                                      \
-    uint32_t z1_, z2_, t2_, nn1_, nn2_;                                                                     \
-    asm("v_ffbh_u32 %[z1], %[tt]\n\t"                                                                       \
-        "v_mad_i32_i24 %[nn1], %[z1], %[zm], %[nw]\n\t"                                                     \
-        "v_alignbit_b32 %[t2], %[tt], 0, %[nn1]\n\t"                                                        \
-        "v_ffbh_u32 %[z2], %[t2]\n\t"                                                                       \
-        "v_mad_i32_i24 %[nn2], %[z2], %[zm], %[nw]\n\t"                                                     \
-        "v_add_u32 %[ns], %[nn1], %[nn2]"                                                                   \
-        : [z1] "=&v"(z1_), [z2] "=&v"(z2_), [nn1] "=&v"(nn1_), [nn2] "=&v"(nn2_), [t2] "=&v"(t2_), [ns] "=&v"(nsum) \
-        : [tt] "v"(t), [zm] "v"(zmask), [nw] "v"(nwidth));                                                  \
-  } while (0)
+// ---- the WALKER's pair: the lengths only.  14 vector instructions + 1 LDS read; the word behind the window is read into
+// WR while WU (read by the pair before) moves into the window -- a read has a whole pair's time to arrive.
+// in/out: w0 w1 s qb; temps t z n1; constants zm nw c124 rowb
+#define X3B_WPAIR(WR, WU)                                          \
+  "v_alignbit_b32 %[t], %[w0], %[w1], %[s]\n\t"                    \
+  "v_ffbh_u32 %[z], %[t]\n\t"                                      \
+  "v_mad_i32_i24 %[n1], %[z], %[zm], %[nw]\n\t"                    \
+  "v_alignbit_b32 %[t], %[t], 0, %[n1]\n\t"                        \
+  "v_ffbh_u32 %[z], %[t]\n\t"                                      \
+  "v_mad_i32_i24 %[z], %[z], %[zm], %[nw]\n\t"                     \
+  "v_add3_u32 %[s], %[s], %[n1], %[z]\n\t"                         \
+  "v_ashrrev_i32 %[n1], 31, %[s]\n\t"                              \
+  "v_lshl_add_u32 %[qb], %[n1], 2, %[qb]\n\t"                      \
+  "v_and_or_b32 %[t], %[qb], %[c124], %[rowb]\n\t"                 \
+  "ds_read_b32 %[" WR "], %[t]\n\t"                                \
+  "v_and_b32 %[s], 31, %[s]\n\t"                                   \
+  "v_bfi_b32 %[w0], %[n1], %[w1], %[w0]\n\t"                       \
+  "s_waitcnt lgkmcnt(1)\n\t"                                       \
+  "v_bfi_b32 %[w1], %[n1], %[" WU "], %[w1]\n\t"
+
+// ---- a DECODER's pair: codewords -> indices -> differences -> samples counted from zero, 29 vector instructions + 1 LDS
+// read (the parser's pair and the valuer's of x3_decode_split_kernel.h in one lane).  The Rice / BFP choice is in the
+// constants (a Rice lane's tm12 / neg22 make the BFP step the identity, a BFP lane's zsh2 = 0 the zigzag step); no
+// literal blocks here (the caller takes the general path when a lane of the wave has one).
+// PI: the pair before (its high half = the last sample so far), PO: this pair; WOUT = (the sample in front, this pair's first)
+#define X3B_DPAIR(WR, WU, PI, PO, WOUT)                                                     \
+  "v_alignbit_b32 %[t], %[w0], %[w1], %[s]\n\t"                                             \
+  "v_ffbh_u32 %[z1], %[t]\n\t"                                                              \
+  "v_mad_i32_i24 %[n1], %[z1], %[zm], %[nw]\n\t"                                            \
+  "v_alignbit_b32 %[t2], %[t], 0, %[n1]\n\t"                                                \
+  "v_bfe_u32 %[v1], %[t], %[n1], %[fw]\n\t"                                                 \
+  "v_ffbh_u32 %[z2], %[t2]\n\t"                                                             \
+  "v_mad_i32_i24 %[n2], %[z2], %[zm], %[nw]\n\t"                                            \
+  "v_bfe_u32 %[v2], %[t2], %[n2], %[fw]\n\t"                                                \
+  "v_add3_u32 %[s], %[s], %[n1], %[n2]\n\t"                                                 \
+  "v_ashrrev_i32 %[n1], 31, %[s]\n\t"                                                       \
+  "v_lshl_add_u32 %[qa], %[n1], 2, %[qa]\n\t"                                               \
+  "ds_read_b32 %[" WR "], %[qa]\n\t"                                                        \
+  "v_and_b32 %[s], 31, %[s]\n\t"                                                            \
+  "v_bfi_b32 %[w0], %[n1], %[w1], %[w0]\n\t"                                                \
+  "s_waitcnt lgkmcnt(1)\n\t"                                                                \
+  "v_bfi_b32 %[w1], %[n1], %[" WU "], %[w1]\n\t"                                            \
+  "v_lshl_add_u32 %[z1], %[z1], %[lsh], %[v1]\n\t"                                          \
+  "v_lshl_add_u32 %[z2], %[z2], %[lsh], %[v2]\n\t"                                          \
+  "v_perm_b32 %[v1], %[z2], %[z1], %[sel]\n\t"                                              \
+  "v_pk_max_u16 %[mx], %[mx], %[v1]\n\t"                                                    \
+  "v_pk_add_u16 %[v2], %[v1], %[tm12]\n\t"                                                  \
+  "v_and_b32 %[v2], %[v2], %[neg22]\n\t"                                                    \
+  "v_pk_sub_u16 %[t], %[v1], %[v2]\n\t"                                                     \
+  "v_and_b32 %[t2], %[t], %[zsh2]\n\t"                                                      \
+  "v_pk_lshrrev_b16 %[n2], %[zsh2], %[t]\n\t"                                               \
+  "v_pk_sub_u16 %[t2], 0, %[t2]\n\t"                                                        \
+  "v_xor_b32 %[n2], %[n2], %[t2]\n\t"                                                       \
+  "v_pk_add_u16 %[z1], %[n2], %[" PI "] op_sel:[0,1] op_sel_hi:[1,1]\n\t"                   \
+  "v_pk_mad_u16 %[" PO "], %[n2], %[c1], %[z1] op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"        \
+  "v_alignbit_b32 %[" WOUT "], %[" PO "], %[" PI "], 16\n\t"
 
 __device__ __forceinline__ void x3b_lds_write_b32(uint32_t addr, uint32_t v) {
   *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(addr) = v;
+}
+__device__ __forceinline__ uint4 x3b_global_load16(uint64_t addr) {
+  const x3_u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) x3_u32x4*>(addr);
+  return make_uint4(v.x, v.y, v.z, v.w);
 }
 
 // blocks of the first batch of a row that begins at byte address `row` (8-byte aligned): 17..32, and
@@ -102,6 +162,12 @@ __device__ __forceinline__ uint32_t x3b_first_batch(uint64_t row) {
   const uint32_t phi8 = ((uint32_t)row & 127u) >> 3;
   return 17u + ((3u * phi8 + 15u) & 15u);
 }
+
+// What the walker leaves for the decoders per frame and batch (LDS).  A: {first 16-byte chunk of the piece's bytes (a
+// global address), first 128-byte line of its samples}; B.x = blocks | samples of the last of them << 8 | first bit of the
+// first block in chunk 0 << 16 | chunks << 24; B.y = bytes of that line in front of the piece | end of the piece << 8 |
+// (the piece ends with a full block that is the frame's last: a pending sample) << 20
+struct X3BRecA { unsigned long long ga, gl; };
 
 __global__ void __launch_bounds__(64 * X3B_WAVES) __attribute__((amdgpu_waves_per_eu(5, 5)))
 x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uint64_t* __restrict__ frame_off,
@@ -116,10 +182,9 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
 
   __shared__ __attribute__((aligned(128))) uint32_t ring[64 * X3_DEC_RING_DW];             // the walker's input ring
   __shared__ __attribute__((aligned(16))) uint16_t desc[2][64 * X3B_DESC_PITCH];            // where the blocks begin
-  __shared__ uint32_t bt_base[2][64], bt_end[2][64];    // a batch's first bit and the bit behind its last block (payload bits)
-  __shared__ unsigned long long fr_in[64], fr_out[64];  // the frame's payload and its row in wav (byte addresses)
-  __shared__ uint32_t fr_samples[64];                   // 0: no such frame, or nothing to decode
-  __shared__ uint32_t fr_n0[64], fr_last[64], fr_bad[64];
+  __shared__ __attribute__((aligned(16))) X3BRecA recA[2][64];
+  __shared__ __attribute__((aligned(8))) uint2 recB[2][64];
+  __shared__ uint32_t fr_last[64], fr_bad[64];
   __shared__ uint32_t s_nbatch;
   __shared__ __attribute__((aligned(128))) uint8_t scratch[X3B_D * X3B_SCRATCH];
 
@@ -127,6 +192,11 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
   const uint32_t wave = threadIdx.x >> 6;
   const unsigned long long wall_t0 = wall_clock64();
   const unsigned long long clk_t0 = clock64();
+#ifdef X3_DBG_STAMPS
+  unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long dbg_t = clock64();
+  const unsigned long long dbg_start = wall_clock64();
+#endif
 
   if (wave == 0u) {
     // ================================================================================ the walker
@@ -174,13 +244,11 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
       first = ((uint32_t)x3[p0] << 8) | x3[p0 + 1];
       if (samples == 1u) wav[wo] = (int16_t)first;
     }
-    fr_in[lane] = (unsigned long long)(uintptr_t)(x3 + p0);
-    fr_out[lane] = rowb;
-    fr_samples[lane] = nblk ? samples : 0u;
-    fr_n0[lane] = n0;
     fr_last[lane] = first;
     fr_bad[lane] = 0u;
     if (lane == 0u) s_nbatch = nbatch_max;
+    const uint64_t pay = (uint64_t)(uintptr_t)(x3 + p0);                                   // the payload's first byte
+    const uint64_t x3_lastc = ((uint64_t)(uintptr_t)x3 + x3_len - 1u) & ~15ull;          // the last 16-byte chunk that holds stream
 
     // ---- the input ring (x3_decode_split_kernel.h): 32 dwords per lane in a row of 128 bytes, stream word j in slot
     // ~j & 31 (descending), parked big-endian
@@ -258,7 +326,7 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
     const uint32_t widx0 = (v_bits >> 2) - (a0 == 0 ? 1u : 0u);
     uint32_t s = (32u - a0) & 31u;
     uint32_t w0 = X3B_RING_WORD(widx0), w1 = X3B_RING_WORD(widx0 + 1u), wn = X3B_RING_WORD(widx0 + 2u);
-    uint32_t qb = 4u * ~(widx0 + 2u);
+    uint32_t qb = 4u * ~(widx0 + 2u);   // (a multiple of four: the byte counter of wn's slot before masking)
     auto consume_to = [&](int32_t s2) {
       const uint32_t m = (uint32_t)(s2 >> 31);
       s = (uint32_t)s2 & 31u;
@@ -271,14 +339,18 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
       wn = x3_lds_read_b32(addr);
       __builtin_amdgcn_sched_barrier(0);
     };
+    // ring index of w0: -qb / 4 - 3; the window's position in payload bits: 32 * index + 32 - s + v_rel
     auto ring_index = [&]() -> uint32_t { return ~((uint32_t)((int32_t)qb >> 2)) - 2u; };
-    auto position = [&]() -> uint32_t { return (uint32_t)((int32_t)(32u * ring_index() + 32u - s) + v_rel); };   // payload bits
+    const uint32_t pos_c = (uint32_t)(v_rel - 64);
+    auto position = [&]() -> uint32_t { return pos_c - ((qb << 3) + s); };
 
     X3B_BARRIER();   // the frames' records are there (and the decoders have read nothing yet)
 
     uint32_t remaining = samples ? samples - 1u : 0u;   // samples still to walk
     uint32_t blocks_left = nblk;
-    bool over = false;
+    uint32_t bytes_left = 2u * samples;                  // of the row, from the current batch's first block on
+    uint64_t G = rowb;                                   // where the current batch's samples go
+    bool bad = false;
     uint32_t it = 0;    // blocks walked by the wave (the service's clock)
     for (uint32_t k = 0; k < nbatch_max; ++k) {
       const uint32_t buf = k & 1u;
@@ -287,13 +359,17 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
       blocks_left -= nbk;
       const uint32_t maxb = (uint32_t)__builtin_amdgcn_readfirstlane((int)x3_wave_max_u32(nbk));
       const uint32_t base = position();
-      bt_base[buf][lane] = base;
+      const uint32_t rel_c = pos_c - base;
+      uint32_t lastcnt = 0;
       uint16_t* const dq = &desc[buf][lane * X3B_DESC_PITCH];
       for (uint32_t b = 0; b < maxb; ++b, ++it) {
         const uint32_t cnt = b < nbk ? (remaining < X3B_BL ? remaining : X3B_BL) : 0u;
         remaining -= cnt;
-        dq[b] = (uint16_t)(position() - base);
-        if ((it % X3B_PERIOD) == 0u) service(ring_index());
+        if (cnt) lastcnt = cnt;
+        dq[b] = (uint16_t)(rel_c - ((qb << 3) + s));
+        X3_STAMP(0);
+        if (!(X3B_KO & 32) && (it % X3B_PERIOD) == 0u) service(ring_index());
+        X3_STAMP(1);
         const uint32_t hdr = __builtin_amdgcn_alignbit(w0, w1, s) >> 26;
         const uint32_t ftype = hdr >> 4;
         const uint32_t live = cnt ? 0xFFFFFFFFu : 0u;
@@ -302,14 +378,19 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
         const uint32_t width = x3_bfi(zmask0, (1u << ftype) >> 1, (hdr & 15u) + 1u);   // Rice 1, 2, 4; BFP E
         const uint32_t zmask = zmask0 & live;
         const uint32_t nwidth = (0u - width) & live;
-        if (__all(cnt == X3B_BL || cnt == 0u)) {
-#pragma unroll
-          for (uint32_t j = 0; j < X3B_PAIRS; ++j) {
-            const uint32_t t = __builtin_amdgcn_alignbit(w0, w1, s);
-            uint32_t ns;
-            X3B_PAIR_LENGTHS(t, zmask, nwidth, ns);
-            consume_to((int32_t)(s + ns));
-          }
+        X3_STAMP(2);
+        if (X3B_KO & 2) {
+        } else if (__all(cnt == X3B_BL || cnt == 0u)) {
+          uint32_t t_, z_, n1_, wnb_;
+          asm volatile(
+              X3B_WPAIR("wnb", "wn") X3B_WPAIR("wn", "wnb") X3B_WPAIR("wnb", "wn") X3B_WPAIR("wn", "wnb")
+              X3B_WPAIR("wnb", "wn") X3B_WPAIR("wn", "wnb") X3B_WPAIR("wnb", "wn") X3B_WPAIR("wn", "wnb")
+              X3B_WPAIR("wnb", "wn") X3B_WPAIR("wn", "wnb")
+              "s_waitcnt lgkmcnt(0)"
+              : [w0] "+v"(w0), [w1] "+v"(w1), [wn] "+v"(wn), [wnb] "=&v"(wnb_), [s] "+v"(s), [qb] "+v"(qb),
+                [t] "=&v"(t_), [z] "=&v"(z_), [n1] "=&v"(n1_)
+              : [zm] "v"(zmask), [nw] "v"(nwidth), [c124] "v"(124u), [rowb] "v"(row_base)
+              : "memory");
         } else {
           for (uint32_t j = 0; j < X3B_BL; ++j) {
             const uint32_t t = __builtin_amdgcn_alignbit(w0, w1, s);
@@ -320,14 +401,49 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
         }
         // the frame ends here: was it read beyond its payload?  (x3_decode_replay.h: the reference's reader knows about
         // the zeros there)
-        if (cnt != 0u && remaining == 0u && (int32_t)(32u * ring_index() + 32u - s) > (int32_t)(8u * v_end)) over = true;
+        X3_STAMP(3);
+        if (cnt != 0u && remaining == 0u && (int32_t)position() > (int32_t)(8u * plen)) bad = true;
       }
-      bt_end[buf][lane] = position();
+      // ---- the batch's record
+      {
+        const uint32_t end = position();
+        const uint32_t span = end - base;
+        uint32_t nb_ok = nbk;
+        if (nbk && span > X3B_SPAN_MAX) {   // not what 32 valid blocks can take: the reference's reader decides
+          bad = true;
+          nb_ok = 0u;
+        }
+        const uint64_t gp = pay + (base >> 3);
+        const uint32_t off16 = (uint32_t)gp & 15u;
+        const uint64_t ga = gp - off16;
+        const uint32_t c0 = 8u * off16 + (base & 7u);
+        uint32_t nchunk = (((c0 + span + 7u) >> 3) + 15u) / 16u + 1u;
+        const uint64_t lim = ((x3_lastc - ga) >> 4) + 1u;   // chunks from ga on that hold stream (ga <= x3_lastc)
+        if ((uint64_t)nchunk > lim) nchunk = (uint32_t)lim;
+        if (nchunk > X3B_IN_CHUNKS) nchunk = X3B_IN_CHUNKS;
+        const uint32_t PH = (uint32_t)G & 127u;
+        const bool is_last = blocks_left == 0u;
+        const uint32_t bytes = is_last ? bytes_left : 40u * nbk;
+        X3BRecA ra;
+        ra.ga = ga;
+        ra.gl = G - PH;
+        uint2 rb = make_uint2(0u, 0u);
+        if (nb_ok) {
+          rb.x = nb_ok | (lastcnt << 8) | (c0 << 16) | (nchunk << 24);
+          rb.y = PH | ((PH + bytes) << 8) | ((is_last && lastcnt == X3B_BL) ? (1u << 20) : 0u);
+        }
+        recA[buf][lane] = ra;
+        recB[buf][lane] = rb;
+        G += 40ull * nbk;
+        bytes_left -= 40u * nbk < bytes_left ? 40u * nbk : bytes_left;
+      }
+      X3_STAMP(5);
       X3B_BARRIER();
+      X3_STAMP(4);
     }
     X3B_BARRIER();   // the decoders are through the last batch
     if (lane < nfr) {
-      if (active && (over || fr_bad[lane] != 0u)) st = X3D_REPLAY;
+      if (active && (bad || fr_bad[lane] != 0u)) st = X3D_REPLAY;
       status[f] = st;
     }
     if (lane == 0u && blockIdx.x == 0u) {
@@ -350,59 +466,58 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
     const uint32_t in_base = x3_lds_addr(my) + h * X3B_IN_PITCH;      // (2 * 1392 <= 2 * 1408)
     const uint32_t in_top = in_base + X3B_IN_PITCH - 20u;             // LDS byte address of stream word 0 (words descend)
     const uint32_t out_base = x3_lds_addr(my) + h * X3B_OUT_PITCH;
-    const uint64_t x3_lastc = ((uint64_t)(uintptr_t)x3 + x3_len - 1u) & ~15ull;   // the last 16-byte chunk that holds stream
     const uint32_t k_tab = (p.k[1] << 16) | (p.k[2] << 24);           // log2(level) by ftype
     const uint32_t bound_tab = (p.inv_len[0] << 8) | (p.inv_len[1] << 16) | (p.inv_len[2] << 24);
     X3B_BARRIER();
     const uint32_t nbatch_max = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_nbatch);
     const uint32_t niter = (nfr + 1u) >> 1;
     for (uint32_t k = 0; k < nbatch_max; ++k) {
+      X3_STAMP(0);
       X3B_BARRIER();   // the walker is through batch k
+      X3_STAMP(4);
       const uint32_t buf = k & 1u;
-      for (uint32_t i = dw; i < niter; i += X3B_D) {
+      // the first chunk of a piece's bytes per lane, requested an iteration ahead
+      auto fetch0 = [&](uint32_t i) -> uint4 {
         const uint32_t fl = 2u * i + h;
-        const uint32_t flc = fl < 64u ? fl : 63u;
-        const uint32_t samples = fl < nfr ? fr_samples[flc] : 0u;
-        const uint32_t n0 = fr_n0[flc];
-        const uint32_t nblk = samples ? (samples - 1u + X3B_BL - 1u) / X3B_BL : 0u;
-        const uint32_t b0 = k ? n0 + X3B_NB * (k - 1u) : 0u;
-        const uint32_t quota = k ? X3B_NB : n0;
-        uint32_t nbk = nblk > b0 ? nblk - b0 : 0u;
-        if (nbk > quota) nbk = quota;
-        const uint32_t base = bt_base[buf][flc], end = bt_end[buf][flc];
-        const uint32_t span = end - base;
-        if (nbk && span > X3B_SPAN_MAX) {   // not what 32 valid blocks can take: the reference's reader decides
-          fr_bad[flc] = 1u;
-          nbk = 0u;
-        }
+        const uint32_t nchunk = recB[buf][fl].x >> 24;
+        uint4 q = make_uint4(0u, 0u, 0u, 0u);
+        if (j < nchunk && !(X3B_KO & 8)) q = x3b_global_load16(recA[buf][fl].ga + 16u * j);
+        return q;
+      };
+      uint4 q0 = make_uint4(0u, 0u, 0u, 0u);
+      if (dw < niter && !(X3B_KO & 1)) q0 = fetch0(dw);
+      for (uint32_t i = dw; i < niter && !(X3B_KO & 1); i += X3B_D) {
+        const uint32_t fl = 2u * i + h;    // (<= 63; a frame that is not there has an empty record)
+        const X3BRecA ra = recA[buf][fl];
+        const uint2 rb = recB[buf][fl];
+        const uint32_t nbk = rb.x & 0xFFu, lastcnt = (rb.x >> 8) & 0xFFu, c0 = (rb.x >> 16) & 0xFFu, nchunk = rb.x >> 24;
+        const uint32_t PH = rb.y & 0xFFu, EB = (rb.y >> 8) & 0xFFFu;
         const bool has = j < nbk;
-        const uint32_t bi = b0 + j;
-        const uint32_t cnt = has ? (samples - 1u - X3B_BL * bi < X3B_BL ? samples - 1u - X3B_BL * bi : X3B_BL) : 0u;
+        const uint32_t cnt = has ? (j + 1u == nbk ? lastcnt : X3B_BL) : 0u;
 
-        // ---- the piece's bytes into LDS: 16-byte chunks from the aligned address in front of its first bit
-        const uint64_t gp = fr_in[flc] + (base >> 3);
-        const uint32_t off16 = (uint32_t)gp & 15u;
-        const uint64_t ga = gp - off16;
-        uint32_t nchunk = nbk ? (((span + (base & 7u) + 7u) >> 3) + off16 + 15u) / 16u + 1u : 0u;
-        if (nchunk > X3B_IN_CHUNKS) nchunk = X3B_IN_CHUNKS;
-        const uint32_t rounds = __any(nchunk > 64u) ? 3u : (__any(nchunk > 32u) ? 2u : (__any(nchunk != 0u) ? 1u : 0u));
+        // ---- the piece's bytes into LDS: 16-byte chunks from the aligned address in front of its first bit; words descend:
+        // chunk c's words 4c .. 4c+3 at in_top - 4 * (4c + i)
         X3_WAVE_LDS_ORDER();
-        for (uint32_t r = 0; r < rounds; ++r) {
-          const uint32_t c = j + 32u * r;
-          if (c < nchunk) {
-            uint64_t a = ga + 16u * c;
-            if (a > x3_lastc) a = x3_lastc;
-            const uint4 q = *reinterpret_cast<const uint4*>(a);
-            // words descend: chunk c's words 4c .. 4c+3 at in_top - 4 * (4c + i)
-            x3_lds_write_b128(in_top - 16u * c - 12u, x3_bswap32(q.w), x3_bswap32(q.z), x3_bswap32(q.y), x3_bswap32(q.x));
+        if (j < nchunk)
+          x3_lds_write_b128(in_top - 16u * j - 12u, x3_bswap32(q0.w), x3_bswap32(q0.z), x3_bswap32(q0.y), x3_bswap32(q0.x));
+        if (__any(nchunk > 32u) && !(X3B_KO & 8)) {   // long pieces (BFP / literal blocks): the rest at once
+#pragma unroll
+          for (uint32_t r = 1; r < 3u; ++r) {
+            const uint32_t c = j + 32u * r;
+            if (c < nchunk) {
+              const uint4 q = x3b_global_load16(ra.ga + 16u * c);
+              x3_lds_write_b128(in_top - 16u * c - 12u, x3_bswap32(q.w), x3_bswap32(q.z), x3_bswap32(q.y), x3_bswap32(q.x));
+            }
           }
         }
         X3_WAVE_LDS_ORDER();
+        if (i + X3B_D < niter) q0 = fetch0(i + X3B_D);
+        X3_STAMP(0);
 
         // ---- this lane's block: its first bit, counted from chunk 0
-        uint32_t rel = has ? desc[buf][flc * X3B_DESC_PITCH + j] : 0u;
-        if (rel > X3B_SPAN_MAX) { if (has) fr_bad[flc] = 1u; rel = 0u; }
-        const uint32_t bbit = 8u * off16 + (base & 7u) + rel;
+        uint32_t rel = has ? desc[buf][fl * X3B_DESC_PITCH + j] : 0u;
+        if (rel > X3B_SPAN_MAX) { if (has) fr_bad[fl] = 1u; rel = 0u; }
+        const uint32_t bbit = c0 + rel;
         const uint32_t a0 = bbit & 31u;
         const uint32_t jdx = (bbit >> 5) - (a0 == 0u ? 1u : 0u);   // (may be -1: a word that is read and not used)
         uint32_t s = (32u - a0) & 31u;
@@ -429,109 +544,169 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
         const uint32_t lsh = x3_bfi(zmask, kk, 31u);
         const uint32_t nwidth = 0u - width;
         const bool bfp = zmask == 0u;
-        const uint32_t litmask = ~zmask & (uint32_t)((int32_t)(14u - (hdr & 15u)) >> 31);  // E == 16
+        const uint32_t litmask = cnt ? (~zmask & (uint32_t)((int32_t)(14u - (hdr & 15u)) >> 31)) : 0u;  // E == 16
         const uint32_t neg_thresh = ~zmask & (1u << (E - 1u));
         const uint32_t neg2 = (neg_thresh << 1) & ~litmask;
         const uint32_t bound = x3_bfi(zmask, (bound_tab >> (8u * ftype)) & 0xFFu, 0xFFFFFFFFu);
         const uint32_t tm12 = ((neg_thresh - 1u) & 0xFFFFu) * 0x10001u;
         const uint32_t neg22 = (neg2 & 0xFFFFu) * 0x10001u;
         const bool full = __all(cnt == X3B_BL || cnt == 0u);
+        const bool any_lit = __any(litmask != 0u);
+        X3_STAMP(1);
         uint32_t maxii2 = 0, prevP = 0;
         uint32_t W[X3B_PAIRS];
+        if (X3B_KO & 16) {
 #pragma unroll
-        for (uint32_t r = 0; r < X3B_PAIRS; ++r) {
-          const uint32_t t = __builtin_amdgcn_alignbit(w0, w1, s);
-          uint32_t z1, v1, z2, v2, ns;
-          X3B_PAIR_FIELDS(t, zmask, nwidth, fw, z1, v1, z2, v2, ns);
-          consume_to((int32_t)(s + ns));
-          uint32_t X = x3_pack_lo16((z1 << lsh) + v1, (z2 << lsh) + v2);
-          if (!full) {   // a frame's last block: the samples behind its end count for nothing
-            const uint32_t vm = (2u * r < cnt ? 0xFFFFu : 0u) | (2u * r + 1u < cnt ? 0xFFFF0000u : 0u);
-            X &= vm;
+          for (uint32_t r = 0; r < X3B_PAIRS; ++r) W[r] = w0 + r;
+        } else if (full && !any_lit) {
+          const uint32_t zsh2 = zmask & 0x00010001u;
+          uint32_t wnb_, pb_, t_, t2_, z1_, z2_, n1_, n2_, v1_, v2_;
+          asm volatile(
+              X3B_DPAIR("wnb", "wn", "pa", "pb", "W0") X3B_DPAIR("wn", "wnb", "pb", "pa", "W1")
+              X3B_DPAIR("wnb", "wn", "pa", "pb", "W2") X3B_DPAIR("wn", "wnb", "pb", "pa", "W3")
+              X3B_DPAIR("wnb", "wn", "pa", "pb", "W4")
+              "s_waitcnt lgkmcnt(0)"
+              : [w0] "+v"(w0), [w1] "+v"(w1), [wn] "+v"(wn), [wnb] "=&v"(wnb_), [s] "+v"(s), [qa] "+v"(qa), [pa] "+v"(prevP),
+                [pb] "=&v"(pb_), [mx] "+v"(maxii2), [W0] "=&v"(W[0]), [W1] "=&v"(W[1]), [W2] "=&v"(W[2]), [W3] "=&v"(W[3]),
+                [W4] "=&v"(W[4]), [t] "=&v"(t_), [t2] "=&v"(t2_), [z1] "=&v"(z1_), [z2] "=&v"(z2_), [n1] "=&v"(n1_),
+                [n2] "=&v"(n2_), [v1] "=&v"(v1_), [v2] "=&v"(v2_)
+              : [zm] "v"(zmask), [nw] "v"(nwidth), [fw] "v"(fw), [lsh] "v"(lsh), [tm12] "v"(tm12), [neg22] "v"(neg22),
+                [zsh2] "v"(zsh2), [sel] "s"(0x05040100u), [c1] "s"(0x00010000u)
+              : "memory");
+          // (five pairs: the window is wnb / wn swapped an odd number of times -- the word behind it is in wnb, the last pair in pb)
+          wn = wnb_;
+          prevP = pb_;
+          asm volatile(
+              X3B_DPAIR("wnb", "wn", "pa", "pb", "W0") X3B_DPAIR("wn", "wnb", "pb", "pa", "W1")
+              X3B_DPAIR("wnb", "wn", "pa", "pb", "W2") X3B_DPAIR("wn", "wnb", "pb", "pa", "W3")
+              X3B_DPAIR("wnb", "wn", "pa", "pb", "W4")
+              "s_waitcnt lgkmcnt(0)"
+              : [w0] "+v"(w0), [w1] "+v"(w1), [wn] "+v"(wn), [wnb] "=&v"(wnb_), [s] "+v"(s), [qa] "+v"(qa), [pa] "+v"(prevP),
+                [pb] "=&v"(pb_), [mx] "+v"(maxii2), [W0] "=&v"(W[5]), [W1] "=&v"(W[6]), [W2] "=&v"(W[7]), [W3] "=&v"(W[8]),
+                [W4] "=&v"(W[9]), [t] "=&v"(t_), [t2] "=&v"(t2_), [z1] "=&v"(z1_), [z2] "=&v"(z2_), [n1] "=&v"(n1_),
+                [n2] "=&v"(n2_), [v1] "=&v"(v1_), [v2] "=&v"(v2_)
+              : [zm] "v"(zmask), [nw] "v"(nwidth), [fw] "v"(fw), [lsh] "v"(lsh), [tm12] "v"(tm12), [neg22] "v"(neg22),
+                [zsh2] "v"(zsh2), [sel] "s"(0x05040100u), [c1] "s"(0x00010000u)
+              : "memory");
+          prevP = pb_;
+        } else {
+          // a frame's last block, or a literal block in some lane: pair by pair (as x3_decode_split_kernel's valuer)
+#pragma unroll
+          for (uint32_t r = 0; r < X3B_PAIRS; ++r) {
+            const uint32_t t = __builtin_amdgcn_alignbit(w0, w1, s);
+            uint32_t z1, v1, z2, v2, ns;
+            X3B_PAIR_FIELDS(t, zmask, nwidth, fw, z1, v1, z2, v2, ns);
+            consume_to((int32_t)(s + ns));
+            uint32_t X = x3_pack_lo16((z1 << lsh) + v1, (z2 << lsh) + v2);
+            // (the samples behind a short block's end count for nothing)
+            X &= (2u * r < cnt ? 0xFFFFu : 0u) | (2u * r + 1u < cnt ? 0xFFFF0000u : 0u);
+            // Rice: X = i, the index into the inverse table (decoder.rs:186), a zigzag (x3.rs:200-204); BFP:
+            // unsigned_to_i16 (decoder.rs:198-207), strict compare; literal: the field is the sample
+            maxii2 = x3_pk_max_u16(maxii2, X);
+            const uint32_t R = x3_pk_lshr_b16_1(X) ^ x3_pk_sub_u16(0u, X & 0x00010001u);
+            const uint32_t B = x3_pk_sub_u16(X, x3_pk_add_u16(X, tm12) & neg22);
+            const uint32_t D = x3_bfi(zmask, R, B);
+            uint32_t P = x3_pk_mad_u16_alo(D, 0x00010000u, x3_pk_add_u16_bhi(D, prevP));   // (last + d1, last + d1 + d2)
+            P = x3_bfi(litmask, X, P);
+            W[r] = __builtin_amdgcn_alignbit(P, prevP, 16);   // (the sample in front, this pair's first)
+            prevP = P;
           }
-          // Rice: X = i, the index into the inverse table (decoder.rs:186), a zigzag (x3.rs:200-204); BFP:
-          // unsigned_to_i16 (decoder.rs:198-207), strict compare; literal: the field is the sample
-          maxii2 = x3_pk_max_u16(maxii2, X);
-          const uint32_t R = x3_pk_lshr_b16_1(X) ^ x3_pk_sub_u16(0u, X & 0x00010001u);
-          const uint32_t B = x3_pk_sub_u16(X, x3_pk_add_u16(X, tm12) & neg22);
-          const uint32_t D = x3_bfi(zmask, R, B);
-          uint32_t P = x3_pk_mad_u16_alo(D, 0x00010000u, x3_pk_add_u16_bhi(D, prevP));   // (last + d1, last + d1 + d2)
-          P = x3_bfi(litmask, X, P);
-          W[r] = __builtin_amdgcn_alignbit(P, prevP, 16);   // (the sample in front, this pair's first)
-          prevP = P;
         }
-        if (cnt && ((bfp && E <= 5u) || max(maxii2 & 0xFFFFu, maxii2 >> 16) >= bound)) fr_bad[flc] = 1u;
+        X3_STAMP(2);
+        if (cnt && ((bfp && E <= 5u) || max(maxii2 & 0xFFFFu, maxii2 >> 16) >= bound)) fr_bad[fl] = 1u;
 
         // ---- the sample in front of every block: a scan over the 32 blocks of the piece.  A block is the map
         // x -> lit ? T : x + T (T = its last sample counted from zero); maps compose as (L, T) after (L', T') =
         // (L | L', L ? T : T' + T).  Identity for lanes without a block.
-        uint32_t sT = cnt ? (prevP >> 16) : 0u;
-        uint32_t sL = cnt ? litmask : 0u;
-        // (for a short last block prevP's high half is not the last sample; nothing follows it)
+        uint32_t sT = cnt ? (prevP >> 16) : 0u;   // (a short last block's is not its last sample; nothing follows it)
+        const uint32_t last_in = fr_last[fl];
+        uint32_t front, last_out;
+        if (!any_lit) {
+#define X3B_ADD_STEP(ctrl, rmask) sT += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sT, ctrl, rmask, 0xF, false);
+          X3B_ADD_STEP(0x111, 0xF) X3B_ADD_STEP(0x112, 0xF) X3B_ADD_STEP(0x114, 0xF) X3B_ADD_STEP(0x118, 0xF)
+          X3B_ADD_STEP(0x142, 0xA)   // row_bcast:15 -> rows 1, 3: the halves' second rows take their first row's total
+#undef X3B_ADD_STEP
+          uint32_t xT = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sT, 0x138, 0xF, 0xF, false);   // wave_shr:1
+          if (j == 0u) xT = 0u;
+          front = (last_in + xT) & 0xFFFFu;
+          last_out = (last_in + sT) & 0xFFFFu;
+        } else {
+          uint32_t sL = litmask;
 #define X3B_SCAN_STEP(ctrl, rmask)                                                                   \
-        {                                                                                            \
-          const uint32_t pT = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sT, ctrl, rmask, 0xF, false); \
-          const uint32_t pL = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sL, ctrl, rmask, 0xF, false); \
-          sT = (pT & ~sL) + sT;                                                                      \
-          sL = sL | pL;                                                                              \
-        }
-        X3B_SCAN_STEP(0x111, 0xF)   // row_shr:1
-        X3B_SCAN_STEP(0x112, 0xF)   // row_shr:2
-        X3B_SCAN_STEP(0x114, 0xF)   // row_shr:4
-        X3B_SCAN_STEP(0x118, 0xF)   // row_shr:8
-        X3B_SCAN_STEP(0x142, 0xA)   // row_bcast:15 -> rows 1, 3: the halves' second rows take their first row's total
+          {                                                                                          \
+            const uint32_t pT = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sT, ctrl, rmask, 0xF, false); \
+            const uint32_t pL = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sL, ctrl, rmask, 0xF, false); \
+            sT = (pT & ~sL) + sT;                                                                    \
+            sL = sL | pL;                                                                            \
+          }
+          X3B_SCAN_STEP(0x111, 0xF) X3B_SCAN_STEP(0x112, 0xF) X3B_SCAN_STEP(0x114, 0xF) X3B_SCAN_STEP(0x118, 0xF)
+          X3B_SCAN_STEP(0x142, 0xA)
 #undef X3B_SCAN_STEP
-        // exclusive: the lane below (nothing for the first lane of a piece)
-        uint32_t xT = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sT, 0x138, 0xF, 0xF, false);   // wave_shr:1
-        uint32_t xL = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sL, 0x138, 0xF, 0xF, false);
-        if (j == 0u) { xT = 0u; xL = 0u; }
-        const uint32_t last_in = fr_last[flc];
-        const uint32_t front = ((xL ? 0u : last_in) + xT) & 0xFFFFu;       // the sample in front of this lane's block
+          uint32_t xT = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sT, 0x138, 0xF, 0xF, false);   // wave_shr:1
+          uint32_t xL = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sL, 0x138, 0xF, 0xF, false);
+          if (j == 0u) { xT = 0u; xL = 0u; }
+          front = ((xL ? 0u : last_in) + xT) & 0xFFFFu;       // the sample in front of this lane's block
+          last_out = ((sL ? 0u : last_in) + sT) & 0xFFFFu;
+        }
         X3_WAVE_LDS_ORDER();
-        if (j == 31u && nbk) fr_last[flc] = ((sL ? 0u : last_in) + sT) & 0xFFFFu;
+        if (j == 31u && nbk) fr_last[fl] = last_out;
         const uint32_t add2 = litmask ? 0u : front * 0x10001u;
         W[0] = x3_pk_add_u16(W[0], litmask ? front : add2);
 #pragma unroll
         for (uint32_t r = 1; r < X3B_PAIRS; ++r) W[r] = x3_pk_add_u16(W[r], add2);
 
         // ---- out: the piece's samples through LDS, then whole lines.  LDS byte = destination byte modulo 128.
-        const uint64_t G0 = fr_out[flc] + 40ull * b0;
-        const uint32_t PH = (uint32_t)G0 & 127u;
         X3_WAVE_LDS_ORDER();
         if (has) {
           const uint32_t oa = out_base + PH + 40u * j;
 #pragma unroll
           for (uint32_t r = 0; r < X3B_PAIRS; r += 2) x3_lds_write_b64(oa + 4u * r, W[r], W[r + 1u]);
           // a full last block of the frame: its last sample is nobody's "sample in front"
-          if (cnt == X3B_BL && bi + 1u == nblk)
+          if ((rb.y >> 20) && j + 1u == nbk)
             x3b_lds_write_b32(oa + 40u, ((litmask ? 0u : front) + (prevP >> 16)) & 0xFFFFu);
         }
         X3_WAVE_LDS_ORDER();
-        // bytes [PH, EB) of the staging are the piece: all of its blocks, or what is left of the row
-        uint32_t EB = 0;
-        if (nbk) {
-          // (the batch that holds the frame's last block ends with the row: a short block, or a full one and a pending sample)
-          const uint32_t left = 2u * samples - 40u * b0;
-          EB = PH + (b0 + nbk == nblk ? left : 40u * nbk);
-        }
-        uint8_t* const GL = reinterpret_cast<uint8_t*>(G0 - PH);
+        X3_STAMP(3);
+        // bytes [PH, EB) of the staging are the piece
+        uint8_t* const GL = reinterpret_cast<uint8_t*>(ra.gl);
+        if (__all((rb.y & 0xFFFFFu) == (1280u << 8))) {
+          // the usual piece: ten whole lines, in both halves
+          const x3_u32x4 v0 = x3_lds_read_b128(out_base + 16u * j);
+          const x3_u32x4 v1 = x3_lds_read_b128(out_base + 16u * j + 512u);
+          if (!(X3B_KO & 4)) {
+            x3_store_stream16(GL + 16u * j, v0);
+            x3_store_stream16(GL + 16u * j + 512u, v1);
+          }
+          if (j < 16u) {
+            const x3_u32x4 v2 = x3_lds_read_b128(out_base + 16u * j + 1024u);
+            if (!(X3B_KO & 4)) x3_store_stream16(GL + 16u * j + 1024u, v2);
+          }
+        } else {
 #pragma unroll
-        for (uint32_t r = 0; r < 3u; ++r) {
-          const uint32_t lo = 16u * (j + 32u * r);
-          if (lo < EB && lo + 16u > PH) {
-            if (lo >= PH && lo + 16u <= EB) {
-              x3_store_stream16(GL + lo, x3_lds_read_b128(out_base + lo));
-            } else {
-              // the two ends of a row: sample by sample
-              const uint32_t from = lo > PH ? lo : PH, to = lo + 16u < EB ? lo + 16u : EB;
-              for (uint32_t bb = from; bb < to; bb += 2u)
-                *reinterpret_cast<uint16_t*>(GL + bb) = (uint16_t)x3_lds_read_u16(out_base + bb, 0u);
+          for (uint32_t r = 0; r < 3u; ++r) {
+            const uint32_t lo = 16u * (j + 32u * r);
+            if (lo < EB && lo + 16u > PH) {
+              if (lo >= PH && lo + 16u <= EB) {
+                if (!(X3B_KO & 4)) x3_store_stream16(GL + lo, x3_lds_read_b128(out_base + lo));
+              } else {
+                // the two ends of a row: sample by sample
+                const uint32_t from = lo > PH ? lo : PH, to = lo + 16u < EB ? lo + 16u : EB;
+                for (uint32_t bb = from; bb < to; bb += 2u)
+                  *reinterpret_cast<uint16_t*>(GL + bb) = (uint16_t)x3_lds_read_u16(out_base + bb, 0u);
+              }
             }
           }
         }
         X3_WAVE_LDS_ORDER();
+        X3_STAMP(5);
       }
     }
     X3B_BARRIER();   // (the walker reads fr_bad behind this one)
   }
+#ifdef X3_DBG_STAMPS
+  dbg_acc[6] = dbg_start;
+  dbg_acc[7] = wall_clock64();
+  if (lane == 0 && blockIdx.x < 2048)
+    for (int q = 0; q < 8; ++q) x3_dbg[(blockIdx.x * 4 + wave) * 8 + q] = dbg_acc[q];
+#endif
 }
