@@ -16,7 +16,7 @@ for kind, n in ((2, 10_000), (2, 16_000), (2, 1), (2, 2), (2, 21), (2, 22), (2, 
     rc, stream, stats = ctx.encode(wav, p)
     assert rc == 0
     for three in (0, 1):
-        ctx.set_option("decode_three_wave", three)
+        ctx.set_option("decode_blocks", 1 - three)
         rc, back, frames_ok, frame_errors = ctx.decode_stream(stream, p, wav_cap=wav.size)
         k = ctx.get_option("decode_kernel_in_use")
         ok = rc == 0 and back.size == wav.size and np.array_equal(back, wav)
@@ -30,6 +30,6 @@ for kind, n in ((2, 10_000), (2, 16_000), (2, 1), (2, 2), (2, 21), (2, 22), (2, 
                 i = int(d[0])
                 print("   got ", back[max(0, i - 4):i + 8].tolist())
                 print("   want", wav[max(0, i - 4):i + 8].tolist())
-    ctx.set_option("decode_three_wave", 0)
+    ctx.set_option("decode_blocks", 0)
 print("BAD" if bad else "ALL OK", bad)
 sys.exit(1 if bad else 0)

@@ -97,11 +97,11 @@ int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint6
     const size_t dyn_lds = (size_t)c->opt.dyn_lds;
     if (d_nf && !split) return X3_ERR_BAD_ARG;   // (only the three-wave decoder takes the frame count from device memory)
     TimerScope ts(c, 1, dec_stream, split);   // (the split kernel: events on its dispatch packet; the rarer single-wave kernels below: bracketed)
-    // Round 6: a BLOCK per lane (x3_decode_blocks_kernel.h) wherever the three-wave kernel would run frame by frame; that
-    // one stays for the segment index (decoding by it, recording it) and as the kernel to compare with (option
-    // "decode_three_wave").
+    // Round 6: a BLOCK per lane (x3_decode_blocks_kernel.h), option "decode_blocks": wherever the three-wave kernel would run
+    // frame by frame (that one keeps the segment index -- decoding by it, recording it -- and stays the default: the
+    // block-per-lane kernel walks every frame twice and is slower on config 3, profiles/r6/decoder_blocks_kernel.txt).
     const bool by_seg = seg && seg->mode && seg->d_index && seg->seg_blocks;
-    if (split && !by_seg && !c->opt.decode_three_wave) {
+    if (split && !by_seg && c->opt.decode_blocks) {
       // as many groups as give every CU the same number (five are resident per CU: the walkers of ALL groups must run
       // side by side, a frame's walk is the kernel's critical path): config 3 is 1 280 groups of 54 frames
       const uint64_t slots = (uint64_t)c->n_cus * 5;

@@ -186,6 +186,7 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
   __shared__ __attribute__((aligned(8))) uint2 recB[2][64];
   __shared__ uint32_t fr_last[64], fr_bad[64];
   __shared__ uint32_t s_nbatch;
+  __shared__ uint32_t s_tick[2];   // the decoders' iteration tickets of a batch buffer (the walker clears them)
   __shared__ __attribute__((aligned(128))) uint8_t scratch[X3B_D * X3B_SCRATCH];
 
   const uint32_t lane = threadIdx.x & 63u;
@@ -346,7 +347,7 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
 
     X3B_BARRIER();   // the frames' records are there (and the decoders have read nothing yet)
 
-    uint32_t remaining = samples ? samples - 1u : 0u;   // samples still to walk
+    const uint32_t cnt_last = nblk ? samples - 1u - X3B_BL * (nblk - 1u) : 0u;   // samples of the frame's last block (1..20)
     uint32_t blocks_left = nblk;
     uint32_t bytes_left = 2u * samples;                  // of the row, from the current batch's first block on
     uint64_t G = rowb;                                   // where the current batch's samples go
@@ -357,15 +358,17 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
       const uint32_t quota = k ? X3B_NB : n0;
       const uint32_t nbk = blocks_left < quota ? blocks_left : quota;
       blocks_left -= nbk;
+      const bool is_last = blocks_left == 0u;           // the batch holds the frame's last block (or the frame is through)
+      const uint32_t lastcnt = is_last ? cnt_last : X3B_BL;   // samples of the batch's last block
       const uint32_t maxb = (uint32_t)__builtin_amdgcn_readfirstlane((int)x3_wave_max_u32(nbk));
+      // (only a frame's last block can be short: batches without one take the ten-pair path without looking)
+      const bool shorts = __any(nbk != 0u && lastcnt != X3B_BL);
       const uint32_t base = position();
       const uint32_t rel_c = pos_c - base;
-      uint32_t lastcnt = 0;
       uint16_t* const dq = &desc[buf][lane * X3B_DESC_PITCH];
+      if (lane == 0u) s_tick[buf] = 0u;
       for (uint32_t b = 0; b < maxb; ++b, ++it) {
-        const uint32_t cnt = b < nbk ? (remaining < X3B_BL ? remaining : X3B_BL) : 0u;
-        remaining -= cnt;
-        if (cnt) lastcnt = cnt;
+        const uint32_t cnt = b < nbk ? (b + 1u == nbk ? lastcnt : X3B_BL) : 0u;
         dq[b] = (uint16_t)(rel_c - ((qb << 3) + s));
         X3_STAMP(0);
         if (!(X3B_KO & 32) && (it % X3B_PERIOD) == 0u) service(ring_index());
@@ -380,7 +383,7 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
         const uint32_t nwidth = (0u - width) & live;
         X3_STAMP(2);
         if (X3B_KO & 2) {
-        } else if (__all(cnt == X3B_BL || cnt == 0u)) {
+        } else if (!shorts || __all(cnt == X3B_BL || cnt == 0u)) {
           uint32_t t_, z_, n1_, wnb_;
           asm volatile(
               X3B_WPAIR("wnb", "wn") X3B_WPAIR("wn", "wnb") X3B_WPAIR("wnb", "wn") X3B_WPAIR("wn", "wnb")
@@ -399,14 +402,14 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
             consume_to((int32_t)(s + (j < cnt ? nn : 0u)));
           }
         }
-        // the frame ends here: was it read beyond its payload?  (x3_decode_replay.h: the reference's reader knows about
-        // the zeros there)
         X3_STAMP(3);
-        if (cnt != 0u && remaining == 0u && (int32_t)position() > (int32_t)(8u * plen)) bad = true;
       }
       // ---- the batch's record
       {
         const uint32_t end = position();
+        // the frame ends here: was it read beyond its payload?  (x3_decode_replay.h: the reference's reader knows about
+        // the zeros there; a lane whose frame is through consumes nothing more)
+        if (nbk && is_last && (int32_t)end > (int32_t)(8u * plen)) bad = true;
         const uint32_t span = end - base;
         uint32_t nb_ok = nbk;
         if (nbk && span > X3B_SPAN_MAX) {   // not what 32 valid blocks can take: the reference's reader decides
@@ -418,11 +421,16 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
         const uint64_t ga = gp - off16;
         const uint32_t c0 = 8u * off16 + (base & 7u);
         uint32_t nchunk = (((c0 + span + 7u) >> 3) + 15u) / 16u + 1u;
-        const uint64_t lim = ((x3_lastc - ga) >> 4) + 1u;   // chunks from ga on that hold stream (ga <= x3_lastc)
+        // (a frame that was walked beyond its payload -- a header that asks for more samples than the payload holds -- can
+        // stand behind the END OF THE STREAM: the ring repeats its last chunk there, the decoders must not ask for anything)
+        if (ga > x3_lastc) {
+          if (nbk) bad = true;
+          nb_ok = 0u;
+        }
+        const uint64_t lim = ga > x3_lastc ? 1u : ((x3_lastc - ga) >> 4) + 1u;   // chunks from ga on that hold stream
         if ((uint64_t)nchunk > lim) nchunk = (uint32_t)lim;
         if (nchunk > X3B_IN_CHUNKS) nchunk = X3B_IN_CHUNKS;
         const uint32_t PH = (uint32_t)G & 127u;
-        const bool is_last = blocks_left == 0u;
         const uint32_t bytes = is_last ? bytes_left : 40u * nbk;
         X3BRecA ra;
         ra.ga = ga;
@@ -484,9 +492,19 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
         if (j < nchunk && !(X3B_KO & 8)) q = x3b_global_load16(recA[buf][fl].ga + 16u * j);
         return q;
       };
+      // iterations go to whichever decoder wave is free (the waves of a group sit on different SIMDs, whose other
+      // tenants differ: a fixed share would make the group as slow as its slowest wave)
+      auto ticket = [&]() -> uint32_t {
+        uint32_t t = 0;
+        if (lane == 0u) t = atomicAdd(&s_tick[buf], 1u);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+      };
+      uint32_t i = (X3B_KO & 1) ? niter : ticket();
       uint4 q0 = make_uint4(0u, 0u, 0u, 0u);
-      if (dw < niter && !(X3B_KO & 1)) q0 = fetch0(dw);
-      for (uint32_t i = dw; i < niter && !(X3B_KO & 1); i += X3B_D) {
+      if (i < niter) q0 = fetch0(i);
+      const uint32_t desc_lane = x3_lds_addr(&desc[buf][0]) + 2u * (h * X3B_DESC_PITCH + j);
+      while (i < niter) {
+        const uint32_t inext = ticket();
         const uint32_t fl = 2u * i + h;    // (<= 63; a frame that is not there has an empty record)
         const X3BRecA ra = recA[buf][fl];
         const uint2 rb = recB[buf][fl];
@@ -511,17 +529,16 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
           }
         }
         X3_WAVE_LDS_ORDER();
-        if (i + X3B_D < niter) q0 = fetch0(i + X3B_D);
+        if (inext < niter) q0 = fetch0(inext);
         X3_STAMP(0);
 
-        // ---- this lane's block: its first bit, counted from chunk 0
-        uint32_t rel = has ? desc[buf][fl * X3B_DESC_PITCH + j] : 0u;
-        if (rel > X3B_SPAN_MAX) { if (has) fr_bad[fl] = 1u; rel = 0u; }
+        // ---- this lane's block: its first bit, counted from chunk 0 (the walker has checked the batch's span: a block
+        // begins at most X3B_SPAN_MAX bits in)
+        const uint32_t rel = has ? x3_lds_read_u16(desc_lane + 2u * (2u * X3B_DESC_PITCH) * i, 0u) : 0u;
         const uint32_t bbit = c0 + rel;
-        const uint32_t a0 = bbit & 31u;
-        const uint32_t jdx = (bbit >> 5) - (a0 == 0u ? 1u : 0u);   // (may be -1: a word that is read and not used)
-        uint32_t s = (32u - a0) & 31u;
-        uint32_t qa = in_top - 4u * (jdx + 2u);                   // LDS address of wn
+        uint32_t s = (0u - bbit) & 31u;
+        const int32_t jdx = (int32_t)(bbit - 1u) >> 5;             // the word w0 is in (-1: a word that is read and not used)
+        uint32_t qa = in_top - 8u - 4u * (uint32_t)jdx;           // LDS address of wn, two words on
         uint32_t w0 = x3_lds_read_b32(qa + 8u), w1 = x3_lds_read_b32(qa + 4u), wn = x3_lds_read_b32(qa);
         auto consume_to = [&](int32_t s2) {
           const uint32_t m = (uint32_t)(s2 >> 31);
@@ -699,6 +716,7 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
         }
         X3_WAVE_LDS_ORDER();
         X3_STAMP(5);
+        i = inext;
       }
     }
     X3B_BARRIER();   // (the walker reads fr_bad behind this one)

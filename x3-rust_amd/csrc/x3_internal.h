@@ -54,8 +54,10 @@ struct X3Opts {
   long long wave_drop = -1;   // tests: the workgroup generation whose total the wave encoder never publishes -- what a workgroup
                               // that is not resident looks like to the others: their bounded waits give up (-1 = none)
   int decode_single = 0;      // X3HIP_DECODE_SINGLE: single-wave decoder kernels only
-  int decode_three_wave = 0;  // X3HIP_DECODE_THREE_WAVE: the lane-per-frame decoder of rounds 2-5 (x3_decode_split_kernel.h) where
-                              // round 6's block-per-lane decoder (x3_decode_blocks_kernel.h) would run
+  int decode_blocks = 0;      // X3HIP_DECODE_BLOCKS: round 6's block-per-lane decoder (x3_decode_blocks_kernel.h: a walker wave + three
+                              // decoder waves per group) where the three-wave kernel would run frame by frame.  Bit-exact and
+                              // balanced over the CUs, but it walks every frame twice: 0.82 against 0.65-0.69 ms on config 3
+                              // (profiles/r6/decoder_blocks_kernel.txt), so it is not the default
   int host_walk = -1;         // X3HIP_HOST_WALK: frame walk of x3_decode_stream on the host (1) / GPU (0) / by size (-1)
   long long host_chunk_frames = 0;  // X3HIP_HOST_CHUNK_FRAMES: x3_encode on host buffers takes a long input in chunks of this many
                               // frames, upload / encode / download side by side (0 = chunks of 16 Mi samples for inputs from
