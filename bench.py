@@ -96,6 +96,73 @@ def measure_traffic(n, kind, timeout=180):
                  "tools/kbench.py on the same workload; KiB x 1024, FETCH_SIZE x 2 (gfx950 128-byte requests)")
 
 
+COMPACT_MAX = 4000   # characters of the contract line (tests/test_bench_contract.py holds it to this)
+
+
+def compact_line(res):
+    """the contract's JSON line cut down to what the driver and the judge read (everything else: the bench_details line)"""
+    def short(s, n=150):
+        return s if len(s) <= n else s[:n - 3] + "..."
+
+    def roof(r, full):
+        keys = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "avg_launch_ms") if full else \
+               ("kernel", "frac", "avg_launch_ms", "traffic")
+        o = {k: r[k] for k in keys if k in r}
+        v = r.get("valu_issue")
+        if v:
+            o["valu"] = {"insts": v["insts"], "per_sample": v["lane_insts_per_sample"], "frac_of_issue_peak": v.get("frac_of_peak", v.get("frac"))}
+        return o
+    c = {k: res[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                             "vs_baseline", "dtype", "data")}
+    cfg = res["config"]
+    c["config"] = {k: cfg[k] for k in ("workload", "samples_per_gpu", "frames_per_gpu", "stream_bytes_per_gpu", "bytes_per_sample",
+                                       "frames_verified_vs_oracle", "settle_steps", "sharding") if k in cfg}
+    c["config"]["workload"] = short(c["config"]["workload"], 120)
+    c["config"]["sharding"] = short(c["config"]["sharding"], 120)
+    c["roofline"] = roof(res["roofline"], True)
+    c["roofline_all"] = {k: roof(v, False) for k, v in res["roofline_all"].items()}
+    c["encode_read_frac"] = res["encode_read_frac"]
+    c["kernels_ms"] = {k: v for k, v in res["kernels_ms"].items() if v}
+    st = res.get("kernels_ms_stats", {})
+    c["kernels_ms_p90_over_min"] = {k: round(v["p90"] / v["min"], 3) for k, v in st.items() if v and v.get("min")}
+    c["clocks_mhz"] = {k[:-len("_kernel_mhz")]: v.get("median") for k, v in res["clocks"].items() if k.endswith("_kernel_mhz")}
+    cb = res["cpu_baseline"]
+    c["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind") if k in cb}
+    c["cpu_baseline"]["sample"] = short(cb.get("sample", ""), 130)
+    for k in ("encode_msamples_s", "decode_msamples_s"):
+        if k in cb:
+            c["cpu_baseline"][k] = cb[k]
+    if isinstance(cb.get("all_cores"), dict):
+        c["cpu_baseline"]["all_cores"] = {k: cb["all_cores"][k] for k in ("value", "cores") if k in cb["all_cores"]}
+    c["value_without_kernel_events"] = res.get("value_without_kernel_events")
+    for k in ("decoder_kernels",):
+        if k in res:
+            c[k] = res[k]
+    if "cold" in res:
+        c["cold_ms_per_step"] = res["cold"]["ms_per_step"]
+        c["value_with_frame_walk"] = res.get("value_with_frame_walk")
+        ex = res.get("extremes", {})
+        c["extremes_ms_per_step"] = {k: v["ms_per_step"] for k, v in ex.items() if isinstance(v, dict) and "ms_per_step" in v}
+    if "configs" in res:
+        c["configs"] = {}
+        for cn in ("config2", "config5"):
+            v = res["configs"].get(cn)
+            if isinstance(v, dict):
+                c["configs"][cn] = {"skipped": short(v["skipped"], 60)} if "skipped" in v else \
+                    {"step": v.get("step"), "step_with_segment_index": (v.get("with_segment_index") or {}).get("step")}
+    if "gather" in res:
+        g = res["gather"]
+        c["gather"] = {k: g[k] for k in ("mode", "ms", "in_timed_region", "value_without_gather") if k in g}
+        c["rccl"] = res.get("rccl")
+    c["details"] = "the line before this one: {\"bench_details\": {...}} -- notes, per-step arrays, layouts, host-buffer and per-frame APIs"
+    # never longer than the tail the driver keeps: drop the least important keys first
+    for k in ("extremes_ms_per_step", "kernels_ms_p90_over_min", "configs", "decoder_kernels", "cold_ms_per_step"):
+        if len(json.dumps(c)) <= COMPACT_MAX:
+            break
+        c.pop(k, None)
+    return c
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,7 +269,9 @@ def main():
             idt.copy_(torch.frombuffer(bytearray(x3hip.shard_unique_id()), dtype=torch.uint8))
         dist.broadcast(idt, src=0)
         shard_obj = x3hip.Shard(ctx, bytes(idt.cpu().numpy().tobytes()), rank, world)
-        rccl = "librccl via x3_shard_* (ncclAllGather of %d lengths; grouped ncclSend/ncclRecv to rank 0)" % world
+        # (ranks_seen: what the communicator itself says, x3_shard_world -- so that a SCALE record answers "did RCCL see N ranks")
+        rccl = {"ranks_seen": int(x3hip.lib().x3_shard_world(shard_obj._h)),
+                "via": "librccl through x3_shard_* (ncclAllGather of %d lengths; grouped ncclSend/ncclRecv to rank 0)" % world}
 
     if args.no_gather:
         args.gather = "none"
@@ -758,6 +827,27 @@ def main():
         with_walk = {"ms_per_step": round(dt * 1e3, 4), "value": round(n / dt / 1e6, 2), "kernels_ms": kt,
                      "note": "x3_encode_dev + x3_decode_stream_dev (frame walk on the GPU, check, decode; the call returns the "
                              "summary, so every step ends with a trip to the host)"}
+        # (b2) round 6: the block-per-lane decoder (x3_decode_blocks_kernel.h, option decode_blocks) beside the default
+        # three-wave kernel, same stream, same step -- the design VERDICT r5 asked for, built, bit-exact, and slower
+        def step_plain():
+            assert ctx.encode_dev(wav.data_ptr(), n, p, out.data_ptr(), cap, 0, off.data_ptr()) == 0
+            assert ctx.decode_dev(out.data_ptr(), cap, off.data_ptr(), F, p, back.data_ptr(), n, n_per_clip=n) == 0
+        decoder_kernels = {}
+        for name, opt in (("three_wave", 0), ("block_per_lane", 1)):
+            ctx.set_option("decode_blocks", opt)
+            back.zero_()
+            for _ in range(5):
+                step_plain()
+            dt, kt = timed_steps(ctx, step_plain, 10)
+            assert ctx.encode_result()[0] == 0 and ctx.decode_result()[:3] == (0, F, 0) and torch.equal(back, wav)
+            decoder_kernels[name] = {"decode_ms": kt.get("decode"), "ms_per_step": round(dt * 1e3, 4)}
+        ctx.set_option("decode_blocks", 0)
+        for _ in range(5):
+            step_plain()
+        ctx.decode_result()
+        decoder_kernels["note"] = ("x3_decode_dev with option decode_blocks = 0 / 1; block_per_lane: a walker wave finds the block "
+                                   "boundaries, three decoder waves decode a block per lane (every frame walked twice: 363 M vector "
+                                   "instructions against 238 M, profiles/r6)")
         # (c) SURVEY 8(d)'s extremes on the same 691.2 M samples: minimum and maximum output
         # ... and `mixed`: config 3 with every hundredth frame full-scale noise (a ship passing the hydrophone): such frames
         # do not fit the wave encoder's LDS image and take the dense pass behind it
@@ -985,19 +1075,22 @@ def main():
                  "traffic_source": traffic_source,
                  "sq_per_launch": traffic.get(kname[k], {}).get("sq_per_launch"),
                  "algorithmic_bytes": int(alg[k]), "avg_launch_ms": round(ktimes[k], 4)}
-            # the wall these kernels actually stand at: vector-instruction issue.  A SIMD-32 issues a
-            # wave64 vector instruction over 2 clocks (MI355X_MICROARCH.md, cycle constants), 1 024 SIMDs; one wave alone
-            # gets one every 4 clocks, a dependent chain one every ~8.5 (tools/ubench/issue_cost.hip).
+            # the wall these kernels actually stand at: vector-instruction issue.  MEASURED (tools/ubench/valu_rate, profiles/r2/
+            # valu_rate.txt): a full SIMD retires one 64-bit-encoded vector instruction (VOP3 / VOP3P: v_alignbit, v_bfe, v_mad, v_bfi,
+            # v_perm, v_pk_*) per 1.8 ns and one 32-bit-encoded (VOP1 / VOP2) per 1.27 ns, at six waves per SIMD; one wave alone gets one
+            # per ~3.8 ns, a dependent chain one per ~8.5 clocks (tools/ubench/issue_cost).  These kernels are ~80 % 64-bit encodings.
             insts = (r["sq_per_launch"] or {}).get("SQ_INSTS_VALU")
             mhz = (clocks.get("decode_kernel_mhz" if k in ("decode", "frame_check") else "encode_kernel_mhz") or {}).get("median")
             if insts and mhz:
                 clk = t * mhz * 1e6 * 1024.0        # SIMD-clocks of the launch
                 r["valu_issue"] = {"insts": int(insts), "lane_insts_per_sample": round(insts * 64.0 / n, 2),
-                                   "simd_clocks_per_inst": round(clk / insts, 2), "frac": round(insts * 2.0 / clk, 4),
-                                   "peak": "one wave64 instruction per 2 clocks per SIMD-32, 1 024 SIMDs, at the kernel's logged clock",
-                                   "note": "frac = SQ_INSTS_VALU x 2 clocks / (1 024 SIMDs x launch time x shader clock).  The kernel is "
-                                           "bound by the LATENCY of its waves' dependent instruction chains (one per ~8.5 clocks for a "
-                                           "lone wave), not by HBM and not by issue bandwidth: both fractions are low by construction"}
+                                   "simd_clocks_per_inst": round(clk / insts, 2),
+                                   "frac_of_peak": round(insts * 1.8e-9 / (1024.0 * t), 4),
+                                   "peak": "one 64-bit-encoded vector instruction per 1.8 ns and SIMD (measured, profiles/r2/valu_rate.txt), 1 024 SIMDs",
+                                   "note": "frac_of_peak = SQ_INSTS_VALU x 1.8 ns / (1 024 SIMDs x launch time): the share of the SIMDs' "
+                                           "measured vector issue rate the kernel uses.  The decode kernels are bound by it and by the "
+                                           "LATENCY of one frame's serial walk (a lone wave: one dependent instruction per ~8.5 clocks), "
+                                           "not by HBM: round 6 measured both walls (profiles/r6/decoder_blocks_kernel.txt)"}
             return r
         secs = n / 192000.0
         kinds = {0: "all zeros", 1: "white noise", 2: "hydrophone-like noise", 3: "sine", 4: "random walk"}
@@ -1051,6 +1144,7 @@ def main():
             "cpu_baseline": cpu,
         }
         if cold is not None:
+            res["decoder_kernels"] = decoder_kernels
             res["cold"] = cold
             res["value_with_frame_walk"] = with_walk["value"]
             res["with_frame_walk"] = with_walk
@@ -1074,7 +1168,11 @@ def main():
             res["gather_modes"] = gather_modes
             res["rccl_ranks"] = world
             res["rccl"] = rccl
-        print(json.dumps(res), flush=True)
+        # Two lines: everything -- notes, per-step arrays, the wider measurements -- as {"bench_details": ...},
+        # then the CONTRACT line, compact (<= 4 KB) and last, so that the tail of the driver's record holds every number it judges
+        # by: kernels_ms, encode_read_frac, roofline_all, the clocks, the CPU baseline, configs 2 and 5.
+        print(json.dumps({"bench_details": res}), flush=True)
+        print(json.dumps(compact_line(res)), flush=True)
 
     if shard_obj is not None:
         shard_obj.close()

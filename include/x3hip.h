@@ -476,7 +476,11 @@ int x3_decode_dev_seg(x3_ctx* ctx, const uint8_t* d_x3, uint64_t x3_len, const u
  *   MEASURED (round 5, ROCm 7.0.2, profiles/r5/hip_graph_replay.txt): on this stack a replay is SLOWER than the same calls
  * issued back to back on the stream -- config 2's encode + decode by stretches 0.134 against 0.128 ms a step, a 500-frame
  * stream 0.33 against 0.095 -- the runtime executes a captured graph node by node with a barrier behind each.  The entry
- * points are kept (bit-exact, tested) for stacks where that changes; nothing in the library or bench.py uses them. */
+ * points are kept (bit-exact, tested) for stacks where that changes; nothing in the library or bench.py uses them.
+ *   EXPERIMENTAL: not part of the drop-in surface (the reference has nothing like it), and may go.
+ *   A call that fails inside a recording (X3_ERR_BAD_ARG from a buffer that would have to grow, a HIP error) leaves the
+ * capture open: end it with x3_graph_end -- it reports the failure or hands back a graph to destroy -- before the context
+ * is used again.  x3_graph_begin changes nothing of the context unless the capture has begun. */
 typedef struct x3_graph x3_graph;
 int x3_graph_begin(x3_ctx* ctx);
 int x3_graph_end(x3_ctx* ctx, x3_graph** graph);

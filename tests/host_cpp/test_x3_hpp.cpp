@@ -119,6 +119,17 @@ int main(int argc, char** argv) {
     std::vector<uint8_t> small(1000);
     x3::bytewriter::SliceByteWriter ws(small.data(), small.size());
     CHECK(x3::encoder::encode(ctx, chans, 1, ws) == x3::X3Error::ByteWriterInsufficientMemory);
+    // ... and a slice that takes some of the frames: they are there, complete and in place, and the writer stands behind
+    // the last of them (bytewriter.rs:86-99: the reference's writer has advanced over everything it took)
+    size_t third = 0, frames = 0;
+    for (size_t o = 0; o + 20 <= ref.size() && frames < 3; ++frames) { o += 20 + ((size_t)ref[o + 6] << 8 | ref[o + 7]); third = o; }
+    std::vector<uint8_t> some(third + 37, 0xEE);
+    x3::bytewriter::SliceByteWriter w3(some.data(), some.size());
+    CHECK(x3::encoder::encode(ctx, chans, 1, w3) == x3::X3Error::ByteWriterInsufficientMemory);
+    uint64_t p3 = 0;
+    w3.stream_position(&p3);
+    CHECK(p3 == third && !std::memcmp(some.data(), ref.data(), third));
+    for (size_t i = third; i < some.size(); ++i) CHECK(some[i] == 0xEE);
   }
   {
     using It = std::vector<int16_t>::const_iterator;

@@ -44,8 +44,26 @@ def test_bench_small_run_prints_the_contract_line():
                         "2000000", "--cpu-reps", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    j = json.loads(lines[0])
+    # two lines: {"bench_details": everything}, then the compact contract line, LAST and short enough for the tail the driver
+    # keeps of a run
+    assert len(lines) == 2
+    last = json.loads(lines[1])
+    assert len(lines[1]) <= 4000, len(lines[1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "kernels_ms", "encode_read_frac", "roofline_all"):
+        assert k in last, k
+    assert last["kernels_ms"]["encode"] > 0 and last["kernels_ms"]["decode"] > 0
+    assert last["roofline_all"]["encode"]["frac"] > 0 and "avg_launch_ms" in last["roofline_all"]["decode"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms"):
+        assert k in last["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in last["cpu_baseline"], k
+    assert last["clocks_mhz"]["decode"] > 500 and last["clocks_mhz"]["encode"] > 500
+    assert "step" in last["configs"]["config2"] or "skipped" in last["configs"]["config2"]
+    assert last["decoder_kernels"]["three_wave"]["decode_ms"] > 0 and last["decoder_kernels"]["block_per_lane"]["decode_ms"] > 0
+    j = json.loads(lines[0])["bench_details"]
+    for k in ("metric", "value", "ms_per_step", "config", "roofline"):
+        assert j[k] == json.loads(lines[0])["bench_details"][k] and (k in ("config", "roofline") or j[k] == last[k]), k
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in j, k
@@ -116,8 +134,26 @@ def test_bench_starts_its_own_ranks():
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    j = json.loads(lines[0])
+    # two lines: {"bench_details": everything}, then the compact contract line, LAST and short enough for the tail the driver
+    # keeps of a run
+    assert len(lines) == 2
+    last = json.loads(lines[1])
+    assert len(lines[1]) <= 4000, len(lines[1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "kernels_ms", "encode_read_frac", "roofline_all"):
+        assert k in last, k
+    assert last["kernels_ms"]["encode"] > 0 and last["kernels_ms"]["decode"] > 0
+    assert last["roofline_all"]["encode"]["frac"] > 0 and "avg_launch_ms" in last["roofline_all"]["decode"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms"):
+        assert k in last["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in last["cpu_baseline"], k
+    assert last["clocks_mhz"]["decode"] > 500 and last["clocks_mhz"]["encode"] > 500
+    assert "step" in last["configs"]["config2"] or "skipped" in last["configs"]["config2"]
+    assert last["decoder_kernels"]["three_wave"]["decode_ms"] > 0 and last["decoder_kernels"]["block_per_lane"]["decode_ms"] > 0
+    j = json.loads(lines[0])["bench_details"]
+    for k in ("metric", "value", "ms_per_step", "config", "roofline"):
+        assert j[k] == json.loads(lines[0])["bench_details"][k] and (k in ("config", "roofline") or j[k] == last[k]), k
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["value"] > 0
 
 

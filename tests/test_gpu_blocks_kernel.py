@@ -193,3 +193,36 @@ def test_whole_decoder_parity_suite_with_the_blocks_kernel_under_guard_pages():
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
     tail = "\n".join((r.stdout + r.stderr).splitlines()[-15:])
     assert r.returncode == 0, "the parity suite with the block-per-lane decoder ended with %d:\n%s" % (r.returncode, tail)
+
+
+def test_codeword_that_begins_in_the_payloads_last_bits(ctx, x3):
+    """Found by round 6's soak (seed 701, trial 120377; tools/r6/repro_overread.py): a frame whose header asks for one sample
+    more than it holds; the extra codeword's zero run begins in the payload's last bit.  Walker and decoders must parse it on
+    the SAME bytes (the stream as it comes, its last chunk repeating), see that it reads behind the payload, and leave the
+    frame to the reference's reader -- whatever stands behind the stream in the buffer."""
+    stream = np.frombuffer(bytes.fromhex(
+        "78330101003c000c0000000000000000259eac0900007ffffdfffff7ffff800078330101003d002c00000000000000005a2b611700007ffffcb0"
+        "0000000000000000000000000000000000000000000000000000000082d826984f3b7104f704"), dtype=np.uint8)
+    assert stream.size == 96
+    p = x3.Params.make(20, 3)
+    o = O.decode_stream(stream, O.Params.make(20, 3), wav_cap=200)
+    assert (o[0], o[1].size) == (0, 121) and o[1][116:121].tolist() == [-2004, -2006, -2006, -2002, -2002]
+    d_off = ctx.alloc(8 * 3); d_wo = ctx.alloc(16); d_back = ctx.alloc(2 * 256); d_x3 = ctx.alloc(256)
+    ctx.upload(d_off, np.array([0, 32, 96], dtype=np.uint64)); ctx.upload(d_wo, np.array([0, 60], dtype=np.uint64))
+    ctx.set_option("wav_offsets_x4", 1)
+    try:
+        for fill in (0x00, 0xFF, 0x80, 0x55, 0x78, 0x01, 0xA5):
+            buf = np.full(256, fill, dtype=np.uint8); buf[:96] = stream
+            ctx.upload(d_x3, buf)
+            for blocks in (1, 0):
+                ctx.set_option("decode_blocks", blocks)
+                ctx.upload(d_back, np.zeros(256, dtype=np.int16))
+                assert ctx.decode_dev(d_x3, 96, d_off, 2, p, d_back, 200, d_wav_offsets=d_wo) == 0
+                assert ctx.decode_result() == (0, 2, 0, 121)
+                assert ctx.get_option("decode_kernel_in_use") == (3 if blocks else 2)
+                assert np.array_equal(ctx.download(d_back, 2 * 121, np.int16), o[1]), (fill, blocks)
+    finally:
+        ctx.set_option("decode_blocks", 1)
+        ctx.set_option("wav_offsets_x4", 0)
+        for d in (d_off, d_wo, d_back, d_x3):
+            ctx.free(d)

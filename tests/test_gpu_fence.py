@@ -109,3 +109,49 @@ def test_fuzz_families_under_the_fence():
         print("trials", sum(c.values()))
         """, timeout=900)
     assert int(out.split("trials")[1]) == 1400
+
+
+def test_segment_index_of_frames_longer_than_the_parameters_say():
+    """a frame whose HEADER holds more blocks than the parameters' blocks_per_frame (a stream encoded with 500
+    blocks a frame, decoded with parameters that say 100) has no room in the index for its later stretches: recording must
+    not write into the next frames' rows or behind the index (guard pages: the index buffer ends at its mapping), and a
+    decode by that index must still give the stream's samples -- the last stretch decodes to the frame's end"""
+    _child("""
+        import ctypes as C
+        import numpy as np
+        import x3hip, oracle_lib as O
+        ctx = x3hip.Context(0)
+        ctx.set_option("wav_offsets_x4", 1)
+        L = x3hip.lib()
+        p_enc = x3hip.Params.make(20, 500)
+        for bpf_dec, sb in ((100, 4), (48, 8), (499, 4), (20, 4)):
+            p = x3hip.Params.make(20, bpf_dec)
+            n = 10000 * 37 + 4321
+            wav = x3hip.synth(2, 4400 + bpf_dec, 0, n)
+            rc, ref, _ = O.encode(wav, O.Params.make(20, 500))
+            assert rc == 0
+            offs, pos = [], 0
+            while pos < ref.size:
+                offs.append(pos); pos += 20 + (int(ref[pos + 6]) << 8 | int(ref[pos + 7]))
+            F = len(offs)
+            d_x3 = ctx.alloc(ref.size); d_off = ctx.alloc(8 * (F + 1)); d_back = ctx.alloc(2 * n); d_wo = ctx.alloc(8 * F)
+            ctx.upload(d_x3, ref); ctx.upload(d_off, np.array(offs + [ref.size], dtype=np.uint64))
+            ctx.upload(d_wo, np.arange(F, dtype=np.uint64) * 10000)
+            ne = L.x3_seg_index_entries(F, C.byref(p), sb)
+            assert ne > 0
+            d_seg = ctx.alloc(8 * ne)                     # exactly the entries the parameters ask for
+            ctx.upload(d_back, np.zeros(n, dtype=np.int16))
+            assert ctx.decode_dev_seg(d_x3, ref.size, d_off, F, p, d_back, n, d_seg, sb, record=True, d_wav_offsets=d_wo) == 0
+            assert ctx.decode_result() == (0, F, 0, n)
+            assert np.array_equal(ctx.download(d_back, 2 * n, np.int16), wav)
+            for want in (0, 2, 5, 25):
+                ctx.set_option("seg_stretches", want)
+                ctx.upload(d_back, np.zeros(n, dtype=np.int16))
+                assert ctx.decode_dev_seg(d_x3, ref.size, d_off, F, p, d_back, n, d_seg, sb, d_wav_offsets=d_wo) == 0
+                assert ctx.decode_result() == (0, F, 0, n), (bpf_dec, sb, want)
+                assert np.array_equal(ctx.download(d_back, 2 * n, np.int16), wav), (bpf_dec, sb, want)
+            ctx.set_option("seg_stretches", 0)
+            for d in (d_x3, d_off, d_back, d_wo, d_seg):
+                ctx.free(d)
+        print("ok")
+    """)

@@ -194,8 +194,90 @@ def test_rust_ffi_block_matches_the_header():
                 r_ptr = "*const" in ra or "*mut" in ra
                 c_ptr = "*" in ca or "[" in ca
                 assert r_ptr == c_ptr, "%s, argument %d: `%s` in lib.rs against `%s` in x3hip.h" % (name, i, ra, ca)
+                # ... and the TYPES: every C scalar / pointee type against its Rust spelling, const-ness of pointers included
+                # (a widened or narrowed argument must fail here, not on the first call of a compiled crate)
+                assert _rust_type(ra.split(":", 1)[1]) == _c_type_as_rust(ca), \
+                    "%s, argument %d: `%s` in lib.rs against `%s` in x3hip.h" % (name, i, ra, ca)
             seen += 1
+        # return types
+        for m in re.finditer(r"pub\s+fn\s+(x3_\w+)\s*\([^)]*\)\s*(->\s*([^;]+))?;", blk, flags=re.S):
+            cm = re.search(r"([\w\s\*]+?)\b%s\s*\(" % m.group(1), hdr)
+            assert cm, m.group(1)
+            c_ret = cm.group(1).strip()
+            r_ret = _rust_type(m.group(3)) if m.group(3) else "()"
+            assert r_ret == ("()" if c_ret == "void" else _c_type_as_rust(c_ret + " x")), (m.group(1), c_ret, m.group(3))
     assert seen >= 30, seen
+    # the #[repr(C)] structs: field order, names and types against the header's
+    for st in ("x3_params", "x3_frame_header", "x3_batch", "x3_rice_code"):
+        cm = re.search(r"typedef\s+struct\s+%s\s*\{(.*?)\}\s*%s\s*;" % (st, st), hdr, flags=re.S)
+        assert cm, st
+        cfields = []
+        for decl in cm.group(1).split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            base, names = re.match(r"((?:const\s+)?\w+\s*\**)\s*(.*)", decl, flags=re.S).groups()
+            for nm in names.split(","):
+                nm = nm.strip()
+                arr = re.match(r"(\w+)\[(\d+)\]", nm)
+                ctype = _c_type_as_rust(base + " x")
+                cfields.append((arr.group(1), "[%s; %s]" % (ctype, arr.group(2))) if arr else (nm.lstrip("* "), ctype))
+        rm = re.search(r"#\[repr\(C\)\][^{]*?pub\s+struct\s+%s\s*\{(.*?)\}" % st, rs, flags=re.S)
+        assert rm, "%s: no #[repr(C)] struct in lib.rs" % st
+        rfields = [(f.split(":")[0].replace("pub", "").strip(), _rust_type(f.split(":", 1)[1]))
+                   for f in re.sub(r"//[^\n]*", " ", rm.group(1)).split(",") if ":" in f]
+        assert rfields == cfields, (st, rfields, cfields)
+
+
+_C2RUST = {"uint8_t": "u8", "uint16_t": "u16", "uint32_t": "u32", "uint64_t": "u64", "int8_t": "i8", "int16_t": "i16",
+           "int32_t": "i32", "int64_t": "i64", "int": "c_int", "unsigned": "c_uint", "char": "c_char", "void": "c_void",
+           "long long": "c_longlong", "unsigned long long": "c_ulonglong", "size_t": "usize", "double": "f64", "float": "f32"}
+
+
+def _c_type_as_rust(decl):
+    """`const uint8_t* data`, `uint64_t stats[6]`, `const int16_t* const* wavs`, `x3_ctx** ctx` -> the Rust FFI spelling"""
+    import re
+    d = decl.strip()
+    is_arr = "[" in d
+    d = re.sub(r"\[[^\]]*\]", "", d)
+    parts = d.split("*")
+    last = parts[-1].split()
+    # the parameter's name: the last word of the last part, unless that part is the type itself (`int`, `long long`)
+    if len(parts) > 1:
+        parts[-1] = " ".join(t for t in last if t == "const")
+    else:
+        toks = [t for t in last if t not in ("const", "struct")]
+        if len(toks) > 1 and " ".join(toks) not in _C2RUST:
+            last = last[:-1]
+        parts[-1] = " ".join(last)
+    base_toks = parts[0].split()
+    pointee_const = ["const" in base_toks] + ["const" in p_.split() for p_ in parts[1:-1]]
+    base = " ".join(t for t in base_toks if t not in ("const", "struct"))
+    t = _C2RUST.get(base, base)
+    levels = len(parts) - 1
+    if is_arr:
+        levels += 1
+        pointee_const = pointee_const + [False] if levels > len(pointee_const) else pointee_const
+    for k in range(levels):
+        t = ("*const " if pointee_const[k] else "*mut ") + t
+    return t
+
+
+def _rust_type(t):
+    import re
+    return re.sub(r"\s+", " ", t.strip().rstrip(",")).strip()
+
+
+def test_rust_ffi_drift_test_catches_a_widened_argument():
+    """the type mapping above is not vacuous: a C `uint32_t n_channels` against a Rust `u64` differs, a `const uint8_t*` against
+    `*mut u8` too"""
+    assert _c_type_as_rust("uint32_t n_channels") == "u32" != _rust_type("u64")
+    assert _c_type_as_rust("const uint8_t* data") == "*const u8" != "*mut u8"
+    assert _c_type_as_rust("uint64_t stats[6]") == "*mut u64"
+    assert _c_type_as_rust("x3_ctx** ctx") == "*mut *mut x3_ctx"
+    assert _c_type_as_rust("const x3_params* p") == "*const x3_params"
+    assert _c_type_as_rust("long long value") == "c_longlong"
+    assert _c_type_as_rust("int") == "c_int" and _c_type_as_rust("void* hip_stream") == "*mut c_void"
 
 
 def test_decoder_ring_requests_are_not_waited_for_right_behind_their_issue():

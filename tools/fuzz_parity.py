@@ -118,6 +118,24 @@ def cmp_decode(stream, p, cap, tag):
             ctx.set_option("host_walk", -1)
             ctx.set_option("host_chunk_frames", 0)
             ctx.set_option("index_no_fast", 0)
+        ok = (r_g[0], r_g[2], r_g[3]) == (r_o[0], r_o[2], r_o[3]) and np.array_equal(r_g[1], r_o[1])
+        if not ok and os.environ.get("X3_FUZZ_DUMP"):   # what went in and what came out, for a post-mortem on the CPU
+            os.makedirs(os.environ["X3_FUZZ_DUMP"], exist_ok=True)
+            np.savez(os.path.join(os.environ["X3_FUZZ_DUMP"], "fail_%s.npz" % "_".join(str(x) for x in tag[0])), stream=stream,
+                     got=r_g[1], want=r_o[1], got_rc=np.array([r_g[0], r_g[2], r_g[3]]), want_rc=np.array([r_o[0], r_o[2], r_o[3]]),
+                     params=np.array([p.block_len, p.blocks_per_frame]), mode=np.array([host_walk, chunk, no_fast]))
+            # the same call again, twice, and on the other decoder kernels: is it the data or the moment?
+            for name, opts in (("again", {}), ("again2", {}), ("three_wave", {"decode_blocks": 0}), ("single", {"decode_blocks": 0, "decode_single": 1})):
+                old = {k: ctx.get_option(k) for k in opts}
+                for k, v in opts.items():
+                    ctx.set_option(k, v)
+                ctx.set_option("host_walk", host_walk); ctx.set_option("host_chunk_frames", chunk); ctx.set_option("index_no_fast", no_fast)
+                r2 = ctx.decode_stream(stream, p, wav_cap=cap)
+                ctx.set_option("host_walk", -1); ctx.set_option("host_chunk_frames", 0); ctx.set_option("index_no_fast", 0)
+                for k, v in old.items():
+                    ctx.set_option(k, v)
+                d = np.nonzero(r2[1][:min(r2[1].size, r_o[1].size)] != r_o[1][:min(r2[1].size, r_o[1].size)])[0]
+                print("   %-10s rc %s sizes %d/%d first diffs %s" % (name, (r2[0], r2[2], r2[3]), r2[1].size, r_o[1].size, d[:8].tolist()), flush=True)
         assert (r_g[0], r_g[2], r_g[3]) == (r_o[0], r_o[2], r_o[3]), (tag, host_walk, chunk, r_g[0], r_g[2:], r_o[0], r_o[2:])
         assert np.array_equal(r_g[1], r_o[1]), (tag, host_walk, chunk, "samples")
     return r_o
@@ -586,7 +604,7 @@ def run(seed=1, minutes=None, trials=None, families="egdbaf", only=-1, context=N
         for name in dir(ctx):
             if not name.startswith("_") and callable(getattr(ctx, name)):
                 setattr(ctx, name, wrap(name, getattr(ctx, name)))
-    trial = 0
+    trial = START_TRIAL
     counts = {k: 0 for k in fams}
     try:
         while (t_end is None or time.time() < t_end) and (trials is None or trial < trials):
@@ -622,6 +640,8 @@ if __name__ == "__main__":
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--only", type=int, default=-1)
     ap.add_argument("--families", default="egdbaf")
+    ap.add_argument("--start", type=int, default=0, help="begin the sequence of trials at this trial number (a fresh context)")
     a = ap.parse_args()
+    START_TRIAL = a.start
     c = run(a.seed, a.minutes, None, a.families, a.only)
     print("fuzz_parity: seed %d, %d trials OK in %.1f min %s" % (a.seed, sum(c.values()), a.minutes, c), flush=True)

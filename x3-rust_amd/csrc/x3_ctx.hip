@@ -326,10 +326,11 @@ struct x3_graph {
 extern "C" int x3_graph_begin(x3_ctx* c) {
   if (!c || c->capturing) return X3_ERR_BAD_ARG;
   HIPCHK(c, hipSetDevice(c->device));
+  // (nothing of the context changes unless the capture has begun: ADVICE r5)
+  HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
   c->encode_pending = c->decode_pending = false;
   c->timing_before_capture = c->timing;
   c->timing = false;
-  HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
   c->capturing = true;
   return X3_OK;
 }

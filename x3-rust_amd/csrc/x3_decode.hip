@@ -459,7 +459,10 @@ int decode_stream_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t len, uint64_
   // again the old way (the walk, a trip, the decode, a trip): the speculative decode wrote nothing that is not rewritten.
   {
     X3DevParams dq;
+    // (frames of fewer than ~1 000 samples are more than one per KiB of stream: the bound below cannot hold, and every call
+    // would pay the speculative launches and a sync before it takes the two trips anyway -- ADVICE r5)
     const bool try_one = !own_out && !c->opt.index_no_fast && !c->opt.two_trips && p->block_len == X3S_BL && !c->opt.decode_single &&
+                         spf_of(p) >= 2048 &&
                          !c->force_single_wave_decode && derive(p, spf_of(p) > 0xFFFFFFFFull ? 0 : spf_of(p), &dq) == X3_OK &&
                          dq.k[1] == 1u && dq.k[2] == 3u && (reinterpret_cast<uintptr_t>(d_wav) & 7u) == 0 &&
                          (reinterpret_cast<uintptr_t>(d_x3) & 3u) == 0 && len >= 22;

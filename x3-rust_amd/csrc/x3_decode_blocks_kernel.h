@@ -262,9 +262,19 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
     const uint64_t abs_base = (abs_bits < abs_last ? abs_bits : abs_last) & ~15ull;
     const uint8_t* __restrict__ const x3b = (x3 - adj) + abs_base;
     const uint32_t v_bits = (uint32_t)(abs_bits - abs_base);        // first block header (0..16), in bytes from the ring's first chunk
-    const uint32_t v_end = v_bits - 2u + plen;                      // end of the payload
     const int32_t v_rel = 16 - 8 * (int32_t)v_bits;                 // payload bit = ring bit + v_rel
-    const uint32_t v_last = (v_end - 1u) & ~15u;                    // last 16-byte chunk that holds payload
+    // The ring takes the STREAM as it comes -- behind the payload the next frame's bytes, up to the stream's last 16-byte
+    // chunk, which repeats from there on -- and the decoders stage the very same bytes (below): a codeword is then parsed
+    // alike by walker and decoders wherever it stands.  (Until the soak of round 6 the walker stopped at the PAYLOAD's last
+    // chunk, as the lane-per-frame kernels do; there parser and valuer share one view.  Here a codeword whose zero run
+    // began in the payload's last bits was parsed on different bits by the two sides, and the frame was not flagged:
+    // tools/r6/repro_overread.py.)  What is read behind the payload still sends the frame to the reference's reader.
+    uint32_t v_last;
+    {
+      const uint64_t lastc_abs = ((uint64_t)adj + x3_len - 1u) & ~15ull;          // (in the coordinates of abs_base)
+      const uint64_t rel = lastc_abs > abs_base ? lastc_abs - abs_base : 0u;
+      v_last = rel > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)rel;
+    }
     uint32_t v_next = 0, wr_abs = 0;
     constexpr uint32_t SVC_MAX = 3u * X3B_PERIOD;
     constexpr uint32_t SVC_AHEAD = X3B_AHEAD;
@@ -427,9 +437,10 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
           if (nbk) bad = true;
           nb_ok = 0u;
         }
-        const uint64_t lim = ga > x3_lastc ? 1u : ((x3_lastc - ga) >> 4) + 1u;   // chunks from ga on that hold stream
-        if ((uint64_t)nchunk > lim) nchunk = (uint32_t)lim;
         if (nchunk > X3B_IN_CHUNKS) nchunk = X3B_IN_CHUNKS;
+        // (chunks behind the stream's last one repeat it, as in the walker's ring: the decoders take such a piece -- the last
+        // frames of a stream -- chunk by chunk with clamped addresses)
+        const bool clamped = ga <= x3_lastc && (uint64_t)nchunk > ((x3_lastc - ga) >> 4) + 1u;
         const uint32_t PH = (uint32_t)G & 127u;
         const uint32_t bytes = is_last ? bytes_left : 40u * nbk;
         X3BRecA ra;
@@ -438,7 +449,7 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
         uint2 rb = make_uint2(0u, 0u);
         if (nb_ok) {
           rb.x = nb_ok | (lastcnt << 8) | (c0 << 16) | (nchunk << 24);
-          rb.y = PH | ((PH + bytes) << 8) | ((is_last && lastcnt == X3B_BL) ? (1u << 20) : 0u);
+          rb.y = PH | ((PH + bytes) << 8) | ((is_last && lastcnt == X3B_BL) ? (1u << 20) : 0u) | (clamped ? (1u << 21) : 0u);
         }
         recA[buf][lane] = ra;
         recB[buf][lane] = rb;
@@ -474,6 +485,7 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
     const uint32_t in_base = x3_lds_addr(my) + h * X3B_IN_PITCH;      // (2 * 1392 <= 2 * 1408)
     const uint32_t in_top = in_base + X3B_IN_PITCH - 20u;             // LDS byte address of stream word 0 (words descend)
     const uint32_t out_base = x3_lds_addr(my) + h * X3B_OUT_PITCH;
+    const uint64_t x3_lastc = ((uint64_t)(uintptr_t)x3 + x3_len - 1u) & ~15ull;   // the last 16-byte chunk that holds stream
     const uint32_t k_tab = (p.k[1] << 16) | (p.k[2] << 24);           // log2(level) by ftype
     const uint32_t bound_tab = (p.inv_len[0] << 8) | (p.inv_len[1] << 16) | (p.inv_len[2] << 24);
     X3B_BARRIER();
@@ -487,9 +499,10 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
       // the first chunk of a piece's bytes per lane, requested an iteration ahead
       auto fetch0 = [&](uint32_t i) -> uint4 {
         const uint32_t fl = 2u * i + h;
-        const uint32_t nchunk = recB[buf][fl].x >> 24;
+        const uint2 b = recB[buf][fl];
+        const uint32_t nchunk = b.x >> 24;
         uint4 q = make_uint4(0u, 0u, 0u, 0u);
-        if (j < nchunk && !(X3B_KO & 8)) q = x3b_global_load16(recA[buf][fl].ga + 16u * j);
+        if (j < nchunk && !(b.y & (1u << 21)) && !(X3B_KO & 8)) q = x3b_global_load16(recA[buf][fl].ga + 16u * j);
         return q;
       };
       // iterations go to whichever decoder wave is free (the waves of a group sit on different SIMDs, whose other
@@ -516,13 +529,26 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
         // ---- the piece's bytes into LDS: 16-byte chunks from the aligned address in front of its first bit; words descend:
         // chunk c's words 4c .. 4c+3 at in_top - 4 * (4c + i)
         X3_WAVE_LDS_ORDER();
-        if (j < nchunk)
+        const bool clamped = (rb.y & (1u << 21)) != 0u;
+        if (j < nchunk && !clamped)
           x3_lds_write_b128(in_top - 16u * j - 12u, x3_bswap32(q0.w), x3_bswap32(q0.z), x3_bswap32(q0.y), x3_bswap32(q0.x));
-        if (__any(nchunk > 32u) && !(X3B_KO & 8)) {   // long pieces (BFP / literal blocks): the rest at once
+        if (__any(clamped)) {   // a piece that reaches behind the stream's last chunk (that one repeats): chunk by chunk
+#pragma unroll
+          for (uint32_t r = 0; r < 3u; ++r) {
+            const uint32_t c = j + 32u * r;
+            if (clamped && c < nchunk) {
+              uint64_t a = ra.ga + 16u * c;
+              if (a > x3_lastc) a = x3_lastc;
+              const uint4 q = x3b_global_load16(a);
+              x3_lds_write_b128(in_top - 16u * c - 12u, x3_bswap32(q.w), x3_bswap32(q.z), x3_bswap32(q.y), x3_bswap32(q.x));
+            }
+          }
+        }
+        if (__any(nchunk > 32u && !clamped) && !(X3B_KO & 8)) {   // long pieces (BFP / literal blocks): the rest at once
 #pragma unroll
           for (uint32_t r = 1; r < 3u; ++r) {
             const uint32_t c = j + 32u * r;
-            if (c < nchunk) {
+            if (c < nchunk && !clamped) {
               const uint4 q = x3b_global_load16(ra.ga + 16u * c);
               x3_lds_write_b128(in_top - 16u * c - 12u, x3_bswap32(q.w), x3_bswap32(q.z), x3_bswap32(q.y), x3_bswap32(q.x));
             }

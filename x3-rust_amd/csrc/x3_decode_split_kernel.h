@@ -153,6 +153,11 @@
 // (Round 4 also swept the cache policies of the flusher's stores and the parser's requests as buffer instructions --
 // plain / nt / sc1 / sc0 sc1 / sc1 nt: nothing beats nontemporal stores and plain loads, plain or sc1 stores cost 7 %
 // and slow the ENCODER down by 8 % through what they leave in L2, nt loads cost 56 %: profiles/r4/decoder_cache_policies.txt.)
+//  the switches above that give WRONG RESULTS are one -D away from the shipped library: they only
+// compile in experiment builds
+#if (X3S_KO || X3S_THIN_K != 10 || X3S_THIN_F || defined(X3S_HALF_LINES_WRONG)) && !defined(X3_EXPERIMENT)
+#error "X3S_KO / X3S_THIN_K / X3S_THIN_F builds give wrong results: experiment builds only (-DX3_EXPERIMENT)"
+#endif
 #define X3S_XROWS 11u          // transfer rows per block buffer: 10 pair dwords + the header word
 #define X3S_WAVES 3u            // parser, valuer, flusher
 // Code placement (round 5).  The kernel's time depends on where its hot loops fall against the instruction fetch windows:
@@ -442,7 +447,10 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
           pred = h.y & 0xFFFFu;
         }
       }
-      if (active && b0 + sg.sb < nbf) {
+      // (the frame's LAST stretch of the launch is never `mid`: a frame with more blocks than nseg * sb -- its header asks for
+      // more than the parameters' frame holds -- is decoded to its end by that stretch, and no entry behind the frame's row
+      // of the index is ever read: ADVICE r5)
+      if (active && b0 + sg.sb < nbf && seg_j + 1u < sg.nseg) {
         const uint2 hn = e[(seg_j + 1u) * sg.mul - 1u];
         mid = true;
         exp_bits = hn.x;
@@ -879,7 +887,10 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       remaining -= cnt;
       X3_STAMP(0);
       // a serial decode leaves the segment index behind: where block sb * j begins (the valuer adds the sample in front)
-      if (sg.out && b && (b % sg.sb) == 0u && cnt)
+      // (only the entries the index has room for: a frame whose HEADER asks for more blocks than the parameters' frame --
+      // a stream encoded with a larger blocks_per_frame, a crafted sample count -- must not write into the next frames' rows
+      // or behind the index: ADVICE r5)
+      if (sg.out && b && (b % sg.sb) == 0u && cnt && b / sg.sb <= sg.pitch)
         sg.out[1 + f * (uint64_t)sg.pitch + (b / sg.sb - 1u)].x = (uint32_t)((int32_t)(32u * ring_index() + 32u - s) + v_rel);
       if (!(X3S_KO & 16) && (b % X3S_PERIOD) == 0) service(ring_index());
       X3_STAMP(1);
@@ -1104,7 +1115,7 @@ x3_decode_split_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const ui
       remaining -= cnt;
       const uint32_t* const buf = xfer + (b & 1u) * (X3S_XROWS * 64u);
       const uint32_t hdr = buf[X3S_PAIRS * 64u + lane];
-      if (sg.out && b && (b % sg.sb) == 0u && cnt)   // (the segment index of a serial decode: the sample in front of block b)
+      if (sg.out && b && (b % sg.sb) == 0u && cnt && b / sg.sb <= sg.pitch)   // (the segment index of a serial decode: the sample in front of block b)
         sg.out[1 + f * (uint64_t)sg.pitch + (b / sg.sb - 1u)].y = (prevP >> 16) | X3S_SEG_VALID;
       // block parameters from the header bits, as arithmetic (see the parser)
       const uint32_t ftype = hdr >> 4;

@@ -68,6 +68,9 @@
 #ifndef X3W_NOWAIT
 #define X3W_NOWAIT 0
 #endif
+#if X3W_NOWAIT && !defined(X3_EXPERIMENT)
+#error "X3W_NOWAIT builds give wrong results (frames land at wrong offsets): experiment builds only (-DX3_EXPERIMENT)"
+#endif
 #ifndef X3W_COPY_UNROLL
 #define X3W_COPY_UNROLL 2
 #endif

@@ -80,10 +80,17 @@ inline hipError_t x3_dmalloc_impl(void** p, size_t bytes) {
   *p = static_cast<char*>(r.mapped) + (map_size - need);
   // X3HIP_FENCE_FILL=<byte>: what a fresh buffer holds (hipMalloc promises nothing; fresh pages happen to be zero, recycled
   // ones are not -- 165 finds code that counts on zeros)
+  auto undo = [&](hipError_t err) {   // (nothing of a reservation that is not handed out stays behind: ADVICE r5)
+    (void)hipMemUnmap(r.mapped, map_size);
+    (void)hipMemRelease(r.h);
+    (void)hipMemAddressFree(r.va, r.reserved);
+    *p = nullptr;
+    return err;
+  };
   if (const char* fill = getenv("X3HIP_FENCE_FILL")) {
-    if ((e = hipMemset(r.mapped, (int)strtol(fill, nullptr, 10) & 255, map_size)) != hipSuccess) return e;
+    if ((e = hipMemset(r.mapped, (int)strtol(fill, nullptr, 10) & 255, map_size)) != hipSuccess) return undo(e);
   }
-  if (!nosync && (e = hipDeviceSynchronize()) != hipSuccess) return e;
+  if (!nosync && (e = hipDeviceSynchronize()) != hipSuccess) return undo(e);
   if (log) fprintf(stderr, "x3_fence: %p + %zu (mapped %p + %zu)\n", *p, bytes, r.mapped, map_size);
   std::lock_guard<std::mutex> lk(x3_fence_mutex());
   x3_fence_map()[*p] = r;

@@ -448,7 +448,10 @@ inline X3Error encode_samples(Context& ctx, const int16_t* wav, size_t n, size_t
     int rc = one_frame ? x3_encode_frame(ctx.raw(), wav, n, &c, sw->data(), sw->capacity(), sw->position(), &pos, stats)
                        : x3_encode(ctx.raw(), wav, n, (uint32_t)n_channels, &c, sw->data(), sw->capacity(),
                                    sw->position(), &pos, stats);
-    if (rc == 0) sw->advance_to((size_t)pos);
+    // (on ByteWriterInsufficientMemory too: the slice holds every frame that fits and *out_pos stands behind the last of
+    // them -- include/x3hip.h, x3_encode -- and so must the writer, as the reference's SliceByteWriter does after the frames
+    // it has taken: src/bytewriter.rs:86-99)
+    if (rc == 0 || rc == static_cast<int>(X3Error::ByteWriterInsufficientMemory)) sw->advance_to((size_t)pos);
     return static_cast<X3Error>(rc);
   }
   uint64_t start = 0;

@@ -864,6 +864,12 @@ pub mod encoder {
         };
         match direct {
             Some(rc) => {
+                // On ByteWriterInsufficientMemory the slice holds every frame that fits and *out_pos stands behind the last
+                // of them (include/x3hip.h, x3_encode): the writer must stand there too before the error goes up, as the
+                // reference's SliceByteWriter does after the frames it has taken (src/bytewriter.rs:86-99)
+                if rc == 22 {
+                    writer.seek(crate::bytewriter::SeekFrom::Start(pos))?;
+                }
                 error::check(rc)?;
                 writer.seek(crate::bytewriter::SeekFrom::Start(pos))?;
             }
