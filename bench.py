@@ -125,15 +125,18 @@ def compact_line(res):
     c["kernels_ms"] = {k: v for k, v in res["kernels_ms"].items() if v}
     st = res.get("kernels_ms_stats", {})
     c["kernels_ms_p90_over_min"] = {k: round(v["p90"] / v["min"], 3) for k, v in st.items() if v and v.get("min")}
-    c["clocks_mhz"] = {k[:-len("_kernel_mhz")]: v.get("median") for k, v in res["clocks"].items() if k.endswith("_kernel_mhz")}
-    cb = res["cpu_baseline"]
-    c["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind") if k in cb}
-    c["cpu_baseline"]["sample"] = short(cb.get("sample", ""), 130)
-    for k in ("encode_msamples_s", "decode_msamples_s"):
-        if k in cb:
-            c["cpu_baseline"][k] = cb[k]
-    if isinstance(cb.get("all_cores"), dict):
-        c["cpu_baseline"]["all_cores"] = {k: cb["all_cores"][k] for k in ("value", "cores") if k in cb["all_cores"]}
+    c["clocks_mhz"] = {k[:-len("_kernel_mhz")]: v.get("median") for k, v in (res.get("clocks") or {}).items() if k.endswith("_kernel_mhz")}
+    cb = res.get("cpu_baseline")
+    if isinstance(cb, dict):    # (None: --no-cpu-baseline, or a rank count above one -- the baseline is timed at N = 1 only)
+        c["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind") if k in cb}
+        c["cpu_baseline"]["sample"] = short(cb.get("sample", ""), 130)
+        for k in ("encode_msamples_s", "decode_msamples_s"):
+            if k in cb:
+                c["cpu_baseline"][k] = cb[k]
+        if isinstance(cb.get("all_cores"), dict):
+            c["cpu_baseline"]["all_cores"] = {k: cb["all_cores"][k] for k in ("value", "cores") if k in cb["all_cores"]}
+    else:
+        c["cpu_baseline"] = None
     c["value_without_kernel_events"] = res.get("value_without_kernel_events")
     for k in ("decoder_kernels",):
         if k in res:

@@ -226,3 +226,53 @@ def test_codeword_that_begins_in_the_payloads_last_bits(ctx, x3):
         ctx.set_option("wav_offsets_x4", 0)
         for d in (d_off, d_wo, d_back, d_x3):
             ctx.free(d)
+
+
+@pytest.mark.parametrize("bl,bpf", [(40, 500), (40, 250), (40, 1), (40, 3), (40, 37), (10, 500), (10, 1000), (10, 1), (10, 7), (10, 64)])
+def test_block_lengths_10_and_40_take_the_blocks_kernel(x3, bl, bpf):
+    """block lengths 10 and 40: a lane's unit is 10 or 20 samples, a block of 40 is two units -- the
+    block-per-lane kernel is the DEFAULT decoder of such streams (rows on 16-byte boundaries).  Against the oracle and the
+    single-wave kernels (option decode_blocks_off), on good and damaged streams."""
+    c = x3.Context(0)
+    try:
+        p = x3.Params.make(bl, bpf)
+        po = O.Params.make(bl, bpf)
+        spf = bl * bpf
+        rng = np.random.default_rng(1000 * bl + bpf)
+        for nfr, tail, kind in ((1, 0, 2), (2, 1, 2), (9, spf // 2 + 1, 4), (70, 0, 2), (131, 3, 1), (260, 0, 3)):
+            n = nfr * spf + tail
+            if n > 3_000_000:
+                n = 3_000_000 // spf * spf + tail
+            wav = x3.synth(kind, 6100 + bl + bpf + nfr, 0, n)
+            rc, stream, _ = O.encode(wav, po)
+            assert rc == 0
+            cases = [stream]
+            offs = frame_offsets(stream)
+            for trial in range(4):
+                s2 = stream.copy()
+                fi = int(rng.integers(0, len(offs)))
+                plen = int(s2[offs[fi] + 6]) << 8 | int(s2[offs[fi] + 7])
+                if plen > 14:
+                    pos = offs[fi] + 22 + int(rng.integers(0, plen - 12))
+                    if trial % 2:
+                        s2[pos] ^= 1 << int(rng.integers(0, 8))
+                    else:
+                        s2[pos:pos + 4] = rng.integers(0, 256, size=4, dtype=np.uint8)
+                    refresh_crcs(x3, s2, offs[fi])
+                    cases.append(s2)
+            for s2 in cases:
+                o = O.decode_stream(s2, po, wav_cap=n + 100)
+                r = c.decode_stream(s2, p, wav_cap=n + 100)
+                used = c.get_option("decode_kernel_in_use")
+                c.set_option("decode_blocks_off", 1)
+                r1 = c.decode_stream(s2, p, wav_cap=n + 100)
+                assert c.get_option("decode_kernel_in_use") != 3
+                c.set_option("decode_blocks_off", 0)
+                for a in (r, r1):
+                    assert (a[0], a[2], a[3]) == (o[0], o[2], o[3]) and np.array_equal(a[1], o[1]), (bl, bpf, nfr, tail)
+                # (rows on 16-byte boundaries -- frames of a multiple of 8 samples: always for blocks of 40, for blocks of 10
+                # when the frame has a multiple of four blocks)
+                if s2 is stream and (spf % 8) == 0:
+                    assert used == 3, (bl, bpf, used)
+    finally:
+        c.close()

@@ -21,6 +21,7 @@ if os.environ.get("X3HIP_LIB"):
 import oracle_lib as O
 
 ctx = None   # the x3hip.Context under test (set by run())
+START_TRIAL = 0   # --start: the sequence of trials begins here (a fresh context; for getting near a failing trial quickly)
 
 
 def oparams(p):

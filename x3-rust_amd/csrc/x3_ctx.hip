@@ -411,6 +411,7 @@ extern "C" int x3_ctx_set_option(x3_ctx* c, const char* name, long long value) {
   else if (n == "stream_wgs") { c->opt.stream_wgs = (int)std::max(0ll, value); c->stream_wg_per_cu = -1; }
   else if (n == "decode_single") c->opt.decode_single = value != 0;
   else if (n == "decode_blocks") c->opt.decode_blocks = value != 0;
+  else if (n == "decode_blocks_off") c->opt.decode_blocks_off = value != 0;
   else if (n == "enc_gen") { c->opt.enc_gen = value == 2 ? 2 : 3; c->prefer_gen2 = false; }
   else if (n == "wave_nwg") c->opt.wave_nwg = (int)std::max(0ll, std::min(256ll, value));
   else if (n == "wave_m") c->opt.wave_m = (int)std::max(0ll, std::min(16ll, value));
@@ -441,6 +442,7 @@ extern "C" int x3_ctx_get_option(const x3_ctx* c, const char* name, long long* v
   else if (n == "stream_wgs") *value = c->opt.stream_wgs;
   else if (n == "decode_single") *value = c->opt.decode_single;
   else if (n == "decode_blocks") *value = c->opt.decode_blocks;
+  else if (n == "decode_blocks_off") *value = c->opt.decode_blocks_off;
   else if (n == "decode_kernel_in_use") *value = c->last_decode_kernel;   // read-only: 3 = block per lane (round 6), 2 = three waves per 64 frames, 1 = single wave (fast), 0 = single wave (general)
   else if (n == "enc_gen") *value = c->opt.enc_gen;
   else if (n == "encode_dense_reruns") *value = 0;  // (rounds 2-3: whole calls encoded again for a dense frame; no longer happens)

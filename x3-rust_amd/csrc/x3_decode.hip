@@ -95,13 +95,28 @@ int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint6
     // or a frame length of 4 (mod 8) samples --: the same lines in 8-byte pieces, x3_decode_split_kernel.h flush_rows)
     // (X3HIP_DECODE_DYN_LDS: extra LDS per decoder group = fewer groups per CU; an occupancy experiment)
     const size_t dyn_lds = (size_t)c->opt.dyn_lds;
-    if (d_nf && !split) return X3_ERR_BAD_ARG;   // (only the three-wave decoder takes the frame count from device memory)
-    TimerScope ts(c, 1, dec_stream, split);   // (the split kernel: events on its dispatch packet; the rarer single-wave kernels below: bracketed)
-    // Round 6: a BLOCK per lane (x3_decode_blocks_kernel.h), option "decode_blocks": wherever the three-wave kernel would run
-    // frame by frame (that one keeps the segment index -- decoding by it, recording it -- and stays the default: the
-    // block-per-lane kernel walks every frame twice and is slower on config 3, profiles/r6/decoder_blocks_kernel.txt).
+    // Round 6: a BLOCK per lane (x3_decode_blocks_kernel.h).  Block length 20: option "decode_blocks" -- wherever the three-wave
+    // kernel would run frame by frame (that one keeps the segment index, decoding by it and recording it, and stays the default:
+    // the block-per-lane kernel walks every frame twice and is slower on config 3, profiles/r6/decoder_blocks_kernel.txt).
+    // Block lengths 10 and 40 (the default codes, rows on 16-byte boundaries): the block-per-lane kernel IS the default -- the
+    // three-wave kernel is written for blocks of 20, and the single-wave kernels such streams took until round 6 are one serial
+    // chain per frame with nothing beside it (1.8 / 1.1 ms at config 3's size).
     const bool by_seg = seg && seg->mode && seg->d_index && seg->seg_blocks;
-    if (split && !by_seg && c->opt.decode_blocks) {
+    const bool blocks_geom = fast && dp.k[1] == 1u && dp.k[2] == 3u && (!d_wav_offsets || wav_off_aligned) &&
+                             !c->force_single_wave_decode && !c->opt.decode_single;
+    // (rows: a frame's samples begin where the layout says -- multiples of spf samples, of the clip stride, or the caller's
+    // offsets -- so the row alignment follows from the pointer's and theirs)
+    auto rows_on = [&](uint64_t bytes) {
+      const uint64_t samples_unit = bytes / 2;
+      if (reinterpret_cast<uintptr_t>(d_wav) % bytes) return false;
+      if (d_wav_offsets) return bytes <= 8;            // (the caller vouches for multiples of four samples, no more)
+      return (dp.spf % samples_unit) == 0 && (g.fpc * (uint64_t)1 >= g.n_frames || (g.clip_stride % samples_unit) == 0);
+    };
+    const bool blocks40 = blocks_geom && dp.block_len == 40u && rows_on(16) && !c->opt.decode_blocks_off;
+    const bool blocks10 = blocks_geom && dp.block_len == 10u && rows_on(8) && !c->opt.decode_blocks_off;
+    if (d_nf && !split) return X3_ERR_BAD_ARG;   // (only the block_len 20 decoders take the frame count from device memory)
+    TimerScope ts(c, 1, dec_stream, split || blocks40 || blocks10);   // (events on the dispatch packet of the kernels launched with X3_LAUNCH_TIMED; the rarer single-wave kernels below: bracketed)
+    if ((split && !by_seg && c->opt.decode_blocks) || blocks40 || blocks10) {
       // as many groups as give every CU the same number (five are resident per CU: the walkers of ALL groups must run
       // side by side, a frame's walk is the kernel's critical path): config 3 is 1 280 groups of 54 frames
       const uint64_t slots = (uint64_t)c->n_cus * 5;
@@ -118,9 +133,14 @@ int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint6
         ++c->dec_epoch;
       }
       c->last_decode_kernel = 3;
-      X3_LAUNCH_TIMED(ts, x3_decode_blocks_kernel, dim3((unsigned)groups), dim3(64 * X3B_WAVES), dyn_lds, dec_stream, d_x3,
-                      x3_len, d_frame_offsets, F, (uint32_t)fpg, g, d_wav_offsets, dp, d_wav, wav_cap, d_status,
-                      (X3FrameMeta*)c->dec_meta.p, c->d_pace, c->dec_epoch & 0xFFFu, d_nf);
+#define X3B_LAUNCH(UNIT, UPB)                                                                                             \
+      X3_LAUNCH_TIMED(ts, (x3_decode_blocks_kernel<UNIT, UPB>), dim3((unsigned)groups), dim3(64 * X3B_WAVES), dyn_lds, dec_stream, \
+                      d_x3, x3_len, d_frame_offsets, F, (uint32_t)fpg, g, d_wav_offsets, dp, d_wav, wav_cap, d_status,     \
+                      (X3FrameMeta*)c->dec_meta.p, c->d_pace, c->dec_epoch & 0xFFFu, d_nf)
+      if (blocks40) X3B_LAUNCH(20u, 2u);
+      else if (blocks10) X3B_LAUNCH(10u, 1u);
+      else X3B_LAUNCH(20u, 1u);
+#undef X3B_LAUNCH
       ++c->dec_epoch;
     }
     else if (split) {

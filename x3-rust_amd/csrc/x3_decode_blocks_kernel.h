@@ -40,15 +40,17 @@
 #pragma once
 #include "x3_decode_kernel.h"
 
-#define X3B_BL 20u
-#define X3B_PAIRS 10u
-#define X3B_NB 32u                       // blocks per batch and frame
+// A lane of a decoder wave takes a UNIT: UNIT samples (20, or 10) of one block.  Blocks of 20 or 10 samples are one unit, blocks
+// of 40 are two (UPB, units per block: the second unit of a block reads the block's header where the first unit begins and
+// walks on from its own first bit) -- so that what a lane holds, what a piece is and what the staging takes do not depend on
+// the block length: instantiations <20, 1> (the default geometry), <20, 2> (block_len 40), <10, 1> (block_len 10).
+#define X3B_NB 32u                       // units per batch and frame
 #ifndef X3B_D
 #define X3B_D 3u
 #endif
 // (decoder waves)                         // decoder waves
 #define X3B_WAVES (1u + X3B_D)
-#define X3B_SPAN_MAX (X3B_NB * 326u)     // bits 32 valid blocks can take (a literal block: 6 + 20 * 16)
+#define X3B_SPAN_MAX (X3B_NB * 326u)     // bits 32 valid units can take (a literal block of 20: 6 + 20 * 16)
 #define X3B_IN_PITCH 1392u               // input staging per frame piece: 86 chunks of 16 bytes + 16
 #define X3B_IN_CHUNKS 85u
 #define X3B_OUT_PITCH 1408u              // output staging per frame piece: up to 120 bytes of phase + 1 280 + a pending sample
@@ -156,11 +158,17 @@ __device__ __forceinline__ uint4 x3b_global_load16(uint64_t addr) {
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-// blocks of the first batch of a row that begins at byte address `row` (8-byte aligned): 17..32, and
-// (row + 40 * n0) is a multiple of 128
+// units of the first batch of a row that begins at byte address `row`: (row + 2 * UNIT * n0) is a multiple of 128, and
+// whole blocks.  UNIT 20: rows on 8-byte boundaries (16-byte for two units a block: n0 is then even), n0 = 17..32;
+// UNIT 10: rows on 4-byte boundaries, n0 = 1..32
+template <uint32_t UNIT>
 __device__ __forceinline__ uint32_t x3b_first_batch(uint64_t row) {
-  const uint32_t phi8 = ((uint32_t)row & 127u) >> 3;
-  return 17u + ((3u * phi8 + 15u) & 15u);
+  if (UNIT == 20u) {
+    const uint32_t phi8 = ((uint32_t)row & 127u) >> 3;      // 40 n0 = -8 phi8 (mod 128): n0 = 3 phi8 (mod 16)
+    return 17u + ((3u * phi8 + 15u) & 15u);
+  }
+  const uint32_t phi4 = ((uint32_t)row & 127u) >> 2;        // 20 n0 = -4 phi4 (mod 128): n0 = 19 phi4 (mod 32)
+  return 1u + ((19u * phi4 + 31u) & 31u);
 }
 
 // What the walker leaves for the decoders per frame and batch (LDS).  A: {first 16-byte chunk of the piece's bytes (a
@@ -169,6 +177,7 @@ __device__ __forceinline__ uint32_t x3b_first_batch(uint64_t row) {
 // (the piece ends with a full block that is the frame's last: a pending sample) << 20
 struct X3BRecA { unsigned long long ga, gl; };
 
+template <uint32_t UNIT, uint32_t UPB>
 __global__ void __launch_bounds__(64 * X3B_WAVES) __attribute__((amdgpu_waves_per_eu(5, 5)))
 x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const uint64_t* __restrict__ frame_off,
                         uint64_t n_frames_arg, uint32_t fpg, X3Geom g, const uint64_t* __restrict__ wav_off, X3DevParams p,
@@ -235,9 +244,9 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
       }
     }
     if (!active) { p0 = 0; plen = 2; wo = 0; samples = 0; }
-    const uint32_t nblk = samples ? (samples - 1u + X3B_BL - 1u) / X3B_BL : 0u;
+    const uint32_t nblk = samples ? (samples - 1u + UNIT - 1u) / UNIT : 0u;   // UNITS of the frame
     const uint64_t rowb = (uint64_t)(uintptr_t)(wav + wo);
-    const uint32_t n0 = x3b_first_batch(rowb);
+    const uint32_t n0 = x3b_first_batch<UNIT>(rowb);
     const uint32_t nbatch = nblk == 0u ? 0u : (nblk <= n0 ? 1u : 1u + (nblk - n0 + X3B_NB - 1u) / X3B_NB);
     const uint32_t nbatch_max = (uint32_t)__builtin_amdgcn_readfirstlane((int)x3_wave_max_u32(nbatch));
     uint32_t first = 0;
@@ -357,7 +366,7 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
 
     X3B_BARRIER();   // the frames' records are there (and the decoders have read nothing yet)
 
-    const uint32_t cnt_last = nblk ? samples - 1u - X3B_BL * (nblk - 1u) : 0u;   // samples of the frame's last block (1..20)
+    const uint32_t cnt_last = nblk ? samples - 1u - UNIT * (nblk - 1u) : 0u;   // samples of the frame's last unit (1..UNIT)
     uint32_t blocks_left = nblk;
     uint32_t bytes_left = 2u * samples;                  // of the row, from the current batch's first block on
     uint64_t G = rowb;                                   // where the current batch's samples go
@@ -369,43 +378,59 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
       const uint32_t nbk = blocks_left < quota ? blocks_left : quota;
       blocks_left -= nbk;
       const bool is_last = blocks_left == 0u;           // the batch holds the frame's last block (or the frame is through)
-      const uint32_t lastcnt = is_last ? cnt_last : X3B_BL;   // samples of the batch's last block
+      const uint32_t lastcnt = is_last ? cnt_last : UNIT;     // samples of the batch's last unit
       const uint32_t maxb = (uint32_t)__builtin_amdgcn_readfirstlane((int)x3_wave_max_u32(nbk));
       // (only a frame's last block can be short: batches without one take the ten-pair path without looking)
-      const bool shorts = __any(nbk != 0u && lastcnt != X3B_BL);
+      const bool shorts = __any(nbk != 0u && lastcnt != UNIT);
       const uint32_t base = position();
       const uint32_t rel_c = pos_c - base;
       uint16_t* const dq = &desc[buf][lane * X3B_DESC_PITCH];
       if (lane == 0u) s_tick[buf] = 0u;
+      uint32_t zmask0 = 0, width = 0;   // of the block the current unit belongs to
       for (uint32_t b = 0; b < maxb; ++b, ++it) {
-        const uint32_t cnt = b < nbk ? (b + 1u == nbk ? lastcnt : X3B_BL) : 0u;
+        const uint32_t cnt = b < nbk ? (b + 1u == nbk ? lastcnt : UNIT) : 0u;
         dq[b] = (uint16_t)(rel_c - ((qb << 3) + s));
         X3_STAMP(0);
         if (!(X3B_KO & 32) && (it % X3B_PERIOD) == 0u) service(ring_index());
         X3_STAMP(1);
-        const uint32_t hdr = __builtin_amdgcn_alignbit(w0, w1, s) >> 26;
-        const uint32_t ftype = hdr >> 4;
         const uint32_t live = cnt ? 0xFFFFFFFFu : 0u;
-        const uint32_t zmask0 = (uint32_t)((int32_t)(15u - hdr) >> 31);      // all ones for Rice
-        consume_to((int32_t)(s + (live & ((zmask0 & 4u) - 6u))));             // 6 header bits for BFP, 2 for Rice
-        const uint32_t width = x3_bfi(zmask0, (1u << ftype) >> 1, (hdr & 15u) + 1u);   // Rice 1, 2, 4; BFP E
+        if (UPB == 1u || (b % UPB) == 0u) {   // (batches are whole blocks in every lane: the header's turn is the wave's)
+          const uint32_t hdr = __builtin_amdgcn_alignbit(w0, w1, s) >> 26;
+          const uint32_t ftype = hdr >> 4;
+          zmask0 = (uint32_t)((int32_t)(15u - hdr) >> 31);                      // all ones for Rice
+          consume_to((int32_t)(s + (live & ((zmask0 & 4u) - 6u))));             // 6 header bits for BFP, 2 for Rice
+          width = x3_bfi(zmask0, (1u << ftype) >> 1, (hdr & 15u) + 1u);         // Rice 1, 2, 4; BFP E
+        }
         const uint32_t zmask = zmask0 & live;
         const uint32_t nwidth = (0u - width) & live;
         X3_STAMP(2);
         if (X3B_KO & 2) {
-        } else if (!shorts || __all(cnt == X3B_BL || cnt == 0u)) {
+        } else if (!shorts || __all(cnt == UNIT || cnt == 0u)) {
           uint32_t t_, z_, n1_, wnb_;
-          asm volatile(
-              X3B_WPAIR("wnb", "wn") X3B_WPAIR("wn", "wnb") X3B_WPAIR("wnb", "wn") X3B_WPAIR("wn", "wnb")
-              X3B_WPAIR("wnb", "wn") X3B_WPAIR("wn", "wnb") X3B_WPAIR("wnb", "wn") X3B_WPAIR("wn", "wnb")
-              X3B_WPAIR("wnb", "wn") X3B_WPAIR("wn", "wnb")
-              "s_waitcnt lgkmcnt(0)"
-              : [w0] "+v"(w0), [w1] "+v"(w1), [wn] "+v"(wn), [wnb] "=&v"(wnb_), [s] "+v"(s), [qb] "+v"(qb),
-                [t] "=&v"(t_), [z] "=&v"(z_), [n1] "=&v"(n1_)
-              : [zm] "v"(zmask), [nw] "v"(nwidth), [c124] "v"(124u), [rowb] "v"(row_base)
-              : "memory");
+          if (UNIT == 20u) {
+            asm volatile(
+                X3B_WPAIR("wnb", "wn") X3B_WPAIR("wn", "wnb") X3B_WPAIR("wnb", "wn") X3B_WPAIR("wn", "wnb")
+                X3B_WPAIR("wnb", "wn") X3B_WPAIR("wn", "wnb") X3B_WPAIR("wnb", "wn") X3B_WPAIR("wn", "wnb")
+                X3B_WPAIR("wnb", "wn") X3B_WPAIR("wn", "wnb")
+                "s_waitcnt lgkmcnt(0)"
+                : [w0] "+v"(w0), [w1] "+v"(w1), [wn] "+v"(wn), [wnb] "=&v"(wnb_), [s] "+v"(s), [qb] "+v"(qb),
+                  [t] "=&v"(t_), [z] "=&v"(z_), [n1] "=&v"(n1_)
+                : [zm] "v"(zmask), [nw] "v"(nwidth), [c124] "v"(124u), [rowb] "v"(row_base)
+                : "memory");
+          } else {
+            // (five pairs: the word behind the window ends up in wnb)
+            asm volatile(
+                X3B_WPAIR("wnb", "wn") X3B_WPAIR("wn", "wnb") X3B_WPAIR("wnb", "wn") X3B_WPAIR("wn", "wnb")
+                X3B_WPAIR("wnb", "wn")
+                "s_waitcnt lgkmcnt(0)"
+                : [w0] "+v"(w0), [w1] "+v"(w1), [wn] "+v"(wn), [wnb] "=&v"(wnb_), [s] "+v"(s), [qb] "+v"(qb),
+                  [t] "=&v"(t_), [z] "=&v"(z_), [n1] "=&v"(n1_)
+                : [zm] "v"(zmask), [nw] "v"(nwidth), [c124] "v"(124u), [rowb] "v"(row_base)
+                : "memory");
+            wn = wnb_;
+          }
         } else {
-          for (uint32_t j = 0; j < X3B_BL; ++j) {
+          for (uint32_t j = 0; j < UNIT; ++j) {
             const uint32_t t = __builtin_amdgcn_alignbit(w0, w1, s);
             const uint32_t z = x3_ffbh(t) & zmask;
             const uint32_t nn = nwidth - z;
@@ -442,19 +467,19 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
         // frames of a stream -- chunk by chunk with clamped addresses)
         const bool clamped = ga <= x3_lastc && (uint64_t)nchunk > ((x3_lastc - ga) >> 4) + 1u;
         const uint32_t PH = (uint32_t)G & 127u;
-        const uint32_t bytes = is_last ? bytes_left : 40u * nbk;
+        const uint32_t bytes = is_last ? bytes_left : 2u * UNIT * nbk;
         X3BRecA ra;
         ra.ga = ga;
         ra.gl = G - PH;
         uint2 rb = make_uint2(0u, 0u);
         if (nb_ok) {
           rb.x = nb_ok | (lastcnt << 8) | (c0 << 16) | (nchunk << 24);
-          rb.y = PH | ((PH + bytes) << 8) | ((is_last && lastcnt == X3B_BL) ? (1u << 20) : 0u) | (clamped ? (1u << 21) : 0u);
+          rb.y = PH | ((PH + bytes) << 8) | ((is_last && lastcnt == UNIT) ? (1u << 20) : 0u) | (clamped ? (1u << 21) : 0u);
         }
         recA[buf][lane] = ra;
         recB[buf][lane] = rb;
-        G += 40ull * nbk;
-        bytes_left -= 40u * nbk < bytes_left ? 40u * nbk : bytes_left;
+        G += (uint64_t)(2u * UNIT) * nbk;
+        bytes_left -= 2u * UNIT * nbk < bytes_left ? 2u * UNIT * nbk : bytes_left;
       }
       X3_STAMP(5);
       X3B_BARRIER();
@@ -479,6 +504,7 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
 #undef X3B_RING_WORD
   } else {
     // ================================================================================ the decoders
+    constexpr uint32_t PAIRS = UNIT / 2u;
     const uint32_t dw = wave - 1u;
     const uint32_t h = lane >> 5, j = lane & 31u;
     uint8_t* const my = scratch + dw * X3B_SCRATCH;
@@ -524,7 +550,7 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
         const uint32_t nbk = rb.x & 0xFFu, lastcnt = (rb.x >> 8) & 0xFFu, c0 = (rb.x >> 16) & 0xFFu, nchunk = rb.x >> 24;
         const uint32_t PH = rb.y & 0xFFu, EB = (rb.y >> 8) & 0xFFFu;
         const bool has = j < nbk;
-        const uint32_t cnt = has ? (j + 1u == nbk ? lastcnt : X3B_BL) : 0u;
+        const uint32_t cnt = has ? (j + 1u == nbk ? lastcnt : UNIT) : 0u;
 
         // ---- the piece's bytes into LDS: 16-byte chunks from the aligned address in front of its first bit; words descend:
         // chunk c's words 4c .. 4c+3 at in_top - 4 * (4c + i)
@@ -558,14 +584,19 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
         if (inext < niter) q0 = fetch0(inext);
         X3_STAMP(0);
 
-        // ---- this lane's block: its first bit, counted from chunk 0 (the walker has checked the batch's span: a block
-        // begins at most X3B_SPAN_MAX bits in)
-        const uint32_t rel = has ? x3_lds_read_u16(desc_lane + 2u * (2u * X3B_DESC_PITCH) * i, 0u) : 0u;
-        const uint32_t bbit = c0 + rel;
-        uint32_t s = (0u - bbit) & 31u;
-        const int32_t jdx = (int32_t)(bbit - 1u) >> 5;             // the word w0 is in (-1: a word that is read and not used)
-        uint32_t qa = in_top - 8u - 4u * (uint32_t)jdx;           // LDS address of wn, two words on
-        uint32_t w0 = x3_lds_read_b32(qa + 8u), w1 = x3_lds_read_b32(qa + 4u), wn = x3_lds_read_b32(qa);
+        // ---- this lane's unit: its first bit, counted from chunk 0 (the walker has checked the batch's span: a unit
+        // begins at most X3B_SPAN_MAX bits in).  The unit's BLOCK begins ub units earlier, in the same piece: its header is there.
+        const uint32_t ub = UPB == 1u ? 0u : j % UPB;
+        const uint32_t rel_u = has ? x3_lds_read_u16(desc_lane + 2u * (2u * X3B_DESC_PITCH) * i, 0u) : 0u;
+        const uint32_t rel = UPB == 1u ? rel_u : (has ? x3_lds_read_u16(desc_lane + 2u * (2u * X3B_DESC_PITCH) * i - 2u * ub, 0u) : 0u);
+        uint32_t s, qa, w0, w1, wn;
+        auto window_at = [&](uint32_t bbit) {
+          s = (0u - bbit) & 31u;
+          const int32_t jdx = (int32_t)(bbit - 1u) >> 5;           // the word w0 is in (-1: a word that is read and not used)
+          qa = in_top - 8u - 4u * (uint32_t)jdx;                   // LDS address of wn, two words on
+          w0 = x3_lds_read_b32(qa + 8u); w1 = x3_lds_read_b32(qa + 4u); wn = x3_lds_read_b32(qa);
+        };
+        window_at(c0 + rel);
         auto consume_to = [&](int32_t s2) {
           const uint32_t m = (uint32_t)(s2 >> 31);
           s = (uint32_t)s2 & 31u;
@@ -580,7 +611,13 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
         const uint32_t ftype = hdr >> 4;
         const uint32_t E = (hdr & 15u) + 1u;
         const uint32_t zmask = (uint32_t)((int32_t)(15u - hdr) >> 31);     // all ones for Rice
-        consume_to((int32_t)(s + ((zmask & 4u) - 6u)));
+        if (UPB == 1u) {
+          consume_to((int32_t)(s + ((zmask & 4u) - 6u)));
+        } else {
+          // (the block's first unit goes on behind the header; a later one begins where the walker left its mark)
+          const uint32_t behind = (c0 + rel) + 6u - (zmask & 4u);
+          window_at(ub ? c0 + rel_u : behind);
+        }
         const uint32_t width = x3_bfi(zmask, (1u << ftype) >> 1, E);
         const uint32_t kk = (k_tab >> (8u * ftype)) & 0xFFu;
         const uint32_t fw = x3_bfi(zmask, kk, width);
@@ -593,14 +630,14 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
         const uint32_t bound = x3_bfi(zmask, (bound_tab >> (8u * ftype)) & 0xFFu, 0xFFFFFFFFu);
         const uint32_t tm12 = ((neg_thresh - 1u) & 0xFFFFu) * 0x10001u;
         const uint32_t neg22 = (neg2 & 0xFFFFu) * 0x10001u;
-        const bool full = __all(cnt == X3B_BL || cnt == 0u);
+        const bool full = __all(cnt == UNIT || cnt == 0u);
         const bool any_lit = __any(litmask != 0u);
         X3_STAMP(1);
         uint32_t maxii2 = 0, prevP = 0;
-        uint32_t W[X3B_PAIRS];
+        uint32_t W[PAIRS];
         if (X3B_KO & 16) {
 #pragma unroll
-          for (uint32_t r = 0; r < X3B_PAIRS; ++r) W[r] = w0 + r;
+          for (uint32_t r = 0; r < PAIRS; ++r) W[r] = w0 + r;
         } else if (full && !any_lit) {
           const uint32_t zsh2 = zmask & 0x00010001u;
           uint32_t wnb_, pb_, t_, t2_, z1_, z2_, n1_, n2_, v1_, v2_;
@@ -619,23 +656,23 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
           // (five pairs: the window is wnb / wn swapped an odd number of times -- the word behind it is in wnb, the last pair in pb)
           wn = wnb_;
           prevP = pb_;
-          asm volatile(
+          if (UNIT == 20u) asm volatile(
               X3B_DPAIR("wnb", "wn", "pa", "pb", "W0") X3B_DPAIR("wn", "wnb", "pb", "pa", "W1")
               X3B_DPAIR("wnb", "wn", "pa", "pb", "W2") X3B_DPAIR("wn", "wnb", "pb", "pa", "W3")
               X3B_DPAIR("wnb", "wn", "pa", "pb", "W4")
               "s_waitcnt lgkmcnt(0)"
               : [w0] "+v"(w0), [w1] "+v"(w1), [wn] "+v"(wn), [wnb] "=&v"(wnb_), [s] "+v"(s), [qa] "+v"(qa), [pa] "+v"(prevP),
-                [pb] "=&v"(pb_), [mx] "+v"(maxii2), [W0] "=&v"(W[5]), [W1] "=&v"(W[6]), [W2] "=&v"(W[7]), [W3] "=&v"(W[8]),
-                [W4] "=&v"(W[9]), [t] "=&v"(t_), [t2] "=&v"(t2_), [z1] "=&v"(z1_), [z2] "=&v"(z2_), [n1] "=&v"(n1_),
+                [pb] "=&v"(pb_), [mx] "+v"(maxii2), [W0] "=&v"(W[PAIRS - 5]), [W1] "=&v"(W[PAIRS - 4]), [W2] "=&v"(W[PAIRS - 3]), [W3] "=&v"(W[PAIRS - 2]),
+                [W4] "=&v"(W[PAIRS - 1]), [t] "=&v"(t_), [t2] "=&v"(t2_), [z1] "=&v"(z1_), [z2] "=&v"(z2_), [n1] "=&v"(n1_),
                 [n2] "=&v"(n2_), [v1] "=&v"(v1_), [v2] "=&v"(v2_)
               : [zm] "v"(zmask), [nw] "v"(nwidth), [fw] "v"(fw), [lsh] "v"(lsh), [tm12] "v"(tm12), [neg22] "v"(neg22),
                 [zsh2] "v"(zsh2), [sel] "s"(0x05040100u), [c1] "s"(0x00010000u)
               : "memory");
-          prevP = pb_;
+          if (UNIT == 20u) prevP = pb_;
         } else {
-          // a frame's last block, or a literal block in some lane: pair by pair (as x3_decode_split_kernel's valuer)
+          // a frame's last unit, or a literal block in some lane: pair by pair (as x3_decode_split_kernel's valuer)
 #pragma unroll
-          for (uint32_t r = 0; r < X3B_PAIRS; ++r) {
+          for (uint32_t r = 0; r < PAIRS; ++r) {
             const uint32_t t = __builtin_amdgcn_alignbit(w0, w1, s);
             uint32_t z1, v1, z2, v2, ns;
             X3B_PAIR_FIELDS(t, zmask, nwidth, fw, z1, v1, z2, v2, ns);
@@ -696,23 +733,28 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
         const uint32_t add2 = litmask ? 0u : front * 0x10001u;
         W[0] = x3_pk_add_u16(W[0], litmask ? front : add2);
 #pragma unroll
-        for (uint32_t r = 1; r < X3B_PAIRS; ++r) W[r] = x3_pk_add_u16(W[r], add2);
+        for (uint32_t r = 1; r < PAIRS; ++r) W[r] = x3_pk_add_u16(W[r], add2);
 
         // ---- out: the piece's samples through LDS, then whole lines.  LDS byte = destination byte modulo 128.
         X3_WAVE_LDS_ORDER();
         if (has) {
-          const uint32_t oa = out_base + PH + 40u * j;
+          const uint32_t oa = out_base + PH + 2u * UNIT * j;
+          if (UNIT == 20u) {   // (rows on 8-byte boundaries)
 #pragma unroll
-          for (uint32_t r = 0; r < X3B_PAIRS; r += 2) x3_lds_write_b64(oa + 4u * r, W[r], W[r + 1u]);
-          // a full last block of the frame: its last sample is nobody's "sample in front"
+            for (uint32_t r = 0; r + 1u < PAIRS; r += 2) x3_lds_write_b64(oa + 4u * r, W[r], W[r + 1u]);
+          } else {             // (rows on 4-byte boundaries)
+#pragma unroll
+            for (uint32_t r = 0; r < PAIRS; ++r) x3b_lds_write_b32(oa + 4u * r, W[r]);
+          }
+          // a full last unit of the frame: its last sample is nobody's "sample in front"
           if ((rb.y >> 20) && j + 1u == nbk)
-            x3b_lds_write_b32(oa + 40u, ((litmask ? 0u : front) + (prevP >> 16)) & 0xFFFFu);
+            x3b_lds_write_b32(oa + 2u * UNIT, ((litmask ? 0u : front) + (prevP >> 16)) & 0xFFFFu);
         }
         X3_WAVE_LDS_ORDER();
         X3_STAMP(3);
         // bytes [PH, EB) of the staging are the piece
         uint8_t* const GL = reinterpret_cast<uint8_t*>(ra.gl);
-        if (__all((rb.y & 0xFFFFFu) == (1280u << 8))) {
+        if (UNIT == 20u && __all((rb.y & 0xFFFFFu) == (1280u << 8))) {
           // the usual piece: ten whole lines, in both halves
           const x3_u32x4 v0 = x3_lds_read_b128(out_base + 16u * j);
           const x3_u32x4 v1 = x3_lds_read_b128(out_base + 16u * j + 512u);
@@ -723,6 +765,14 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
           if (j < 16u) {
             const x3_u32x4 v2 = x3_lds_read_b128(out_base + 16u * j + 1024u);
             if (!(X3B_KO & 4)) x3_store_stream16(GL + 16u * j + 1024u, v2);
+          }
+        } else if (UNIT == 10u && __all((rb.y & 0xFFFFFu) == (640u << 8))) {
+          // ... five whole lines
+          const x3_u32x4 v0 = x3_lds_read_b128(out_base + 16u * j);
+          if (!(X3B_KO & 4)) x3_store_stream16(GL + 16u * j, v0);
+          if (j < 8u) {
+            const x3_u32x4 v1 = x3_lds_read_b128(out_base + 16u * j + 512u);
+            if (!(X3B_KO & 4)) x3_store_stream16(GL + 16u * j + 512u, v1);
           }
         } else {
 #pragma unroll

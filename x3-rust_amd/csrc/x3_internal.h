@@ -54,6 +54,7 @@ struct X3Opts {
   long long wave_drop = -1;   // tests: the workgroup generation whose total the wave encoder never publishes -- what a workgroup
                               // that is not resident looks like to the others: their bounded waits give up (-1 = none)
   int decode_single = 0;      // X3HIP_DECODE_SINGLE: single-wave decoder kernels only
+  int decode_blocks_off = 0;  // 1: block lengths 10 and 40 on the single-wave kernels too (what they took until round 6)
   int decode_blocks = 0;      // X3HIP_DECODE_BLOCKS: round 6's block-per-lane decoder (x3_decode_blocks_kernel.h: a walker wave + three
                               // decoder waves per group) where the three-wave kernel would run frame by frame.  Bit-exact and
                               // balanced over the CUs, but it walks every frame twice: 0.82 against 0.65-0.69 ms on config 3
