@@ -98,7 +98,7 @@ int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint6
     // Round 6: a BLOCK per lane (x3_decode_blocks_kernel.h).  Block length 20: option "decode_blocks" -- wherever the three-wave
     // kernel would run frame by frame (that one keeps the segment index, decoding by it and recording it, and stays the default:
     // the block-per-lane kernel walks every frame twice and is slower on config 3, profiles/r6/decoder_blocks_kernel.txt).
-    // Block lengths 10 and 40 (the default codes, rows on 16-byte boundaries): the block-per-lane kernel IS the default -- the
+    // Block lengths 10 and 40 (the default codes, rows on 8-byte boundaries): the block-per-lane kernel IS the default -- the
     // three-wave kernel is written for blocks of 20, and the single-wave kernels such streams took until round 6 are one serial
     // chain per frame with nothing beside it (1.8 / 1.1 ms at config 3's size).
     const bool by_seg = seg && seg->mode && seg->d_index && seg->seg_blocks;
@@ -112,7 +112,7 @@ int decode_dev_impl(x3_ctx* c, const uint8_t* d_x3, uint64_t x3_len, const uint6
       if (d_wav_offsets) return bytes <= 8;            // (the caller vouches for multiples of four samples, no more)
       return (dp.spf % samples_unit) == 0 && (g.fpc * (uint64_t)1 >= g.n_frames || (g.clip_stride % samples_unit) == 0);
     };
-    const bool blocks40 = blocks_geom && dp.block_len == 40u && rows_on(16) && !c->opt.decode_blocks_off;
+    const bool blocks40 = blocks_geom && dp.block_len == 40u && rows_on(8) && !c->opt.decode_blocks_off;
     const bool blocks10 = blocks_geom && dp.block_len == 10u && rows_on(8) && !c->opt.decode_blocks_off;
     if (d_nf && !split) return X3_ERR_BAD_ARG;   // (only the block_len 20 decoders take the frame count from device memory)
     TimerScope ts(c, 1, dec_stream, split || blocks40 || blocks10);   // (events on the dispatch packet of the kernels launched with X3_LAUNCH_TIMED; the rarer single-wave kernels below: bracketed)

@@ -153,6 +153,14 @@
 __device__ __forceinline__ void x3b_lds_write_b32(uint32_t addr, uint32_t v) {
   *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(addr) = v;
 }
+// sixteen bytes to GLOBAL memory, non-temporal (an address that comes out of LDS as an integer is "generic" to the compiler: a
+// flat_store, which counts in lgkmcnt too and is slower than the global_store this makes of it)
+__device__ __forceinline__ void x3b_global_store16_nt(uint8_t* p, x3_u32x4 v) {
+  __builtin_nontemporal_store(v, reinterpret_cast<__attribute__((address_space(1))) x3_u32x4*>(reinterpret_cast<uintptr_t>(p)));
+}
+__device__ __forceinline__ void x3b_global_store2(uint8_t* p, uint32_t v) {
+  *reinterpret_cast<__attribute__((address_space(1))) uint16_t*>(reinterpret_cast<uintptr_t>(p)) = (uint16_t)v;
+}
 __device__ __forceinline__ uint4 x3b_global_load16(uint64_t addr) {
   const x3_u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) x3_u32x4*>(addr);
   return make_uint4(v.x, v.y, v.z, v.w);
@@ -161,11 +169,14 @@ __device__ __forceinline__ uint4 x3b_global_load16(uint64_t addr) {
 // units of the first batch of a row that begins at byte address `row`: (row + 2 * UNIT * n0) is a multiple of 128, and
 // whole blocks.  UNIT 20: rows on 8-byte boundaries (16-byte for two units a block: n0 is then even), n0 = 17..32;
 // UNIT 10: rows on 4-byte boundaries, n0 = 1..32
-template <uint32_t UNIT>
+template <uint32_t UNIT, uint32_t UPB>
 __device__ __forceinline__ uint32_t x3b_first_batch(uint64_t row) {
   if (UNIT == 20u) {
     const uint32_t phi8 = ((uint32_t)row & 127u) >> 3;      // 40 n0 = -8 phi8 (mod 128): n0 = 3 phi8 (mod 16)
-    return 17u + ((3u * phi8 + 15u) & 15u);
+    const uint32_t n0 = 17u + ((3u * phi8 + 15u) & 15u);
+    // (two units a block: whole blocks come first -- a row that begins 8 bytes into a 16-byte unit then has pieces that do
+    // not end on lines, and its lines are written in parts: slower, the same bytes)
+    return UPB == 2u ? (n0 & ~1u) : n0;
   }
   const uint32_t phi4 = ((uint32_t)row & 127u) >> 2;        // 20 n0 = -4 phi4 (mod 128): n0 = 19 phi4 (mod 32)
   return 1u + ((19u * phi4 + 31u) & 31u);
@@ -246,7 +257,7 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
     if (!active) { p0 = 0; plen = 2; wo = 0; samples = 0; }
     const uint32_t nblk = samples ? (samples - 1u + UNIT - 1u) / UNIT : 0u;   // UNITS of the frame
     const uint64_t rowb = (uint64_t)(uintptr_t)(wav + wo);
-    const uint32_t n0 = x3b_first_batch<UNIT>(rowb);
+    const uint32_t n0 = x3b_first_batch<UNIT, UPB>(rowb);
     const uint32_t nbatch = nblk == 0u ? 0u : (nblk <= n0 ? 1u : 1u + (nblk - n0 + X3B_NB - 1u) / X3B_NB);
     const uint32_t nbatch_max = (uint32_t)__builtin_amdgcn_readfirstlane((int)x3_wave_max_u32(nbatch));
     uint32_t first = 0;
@@ -759,20 +770,20 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
           const x3_u32x4 v0 = x3_lds_read_b128(out_base + 16u * j);
           const x3_u32x4 v1 = x3_lds_read_b128(out_base + 16u * j + 512u);
           if (!(X3B_KO & 4)) {
-            x3_store_stream16(GL + 16u * j, v0);
-            x3_store_stream16(GL + 16u * j + 512u, v1);
+            x3b_global_store16_nt(GL + 16u * j, v0);
+            x3b_global_store16_nt(GL + 16u * j + 512u, v1);
           }
           if (j < 16u) {
             const x3_u32x4 v2 = x3_lds_read_b128(out_base + 16u * j + 1024u);
-            if (!(X3B_KO & 4)) x3_store_stream16(GL + 16u * j + 1024u, v2);
+            if (!(X3B_KO & 4)) x3b_global_store16_nt(GL + 16u * j + 1024u, v2);
           }
         } else if (UNIT == 10u && __all((rb.y & 0xFFFFFu) == (640u << 8))) {
           // ... five whole lines
           const x3_u32x4 v0 = x3_lds_read_b128(out_base + 16u * j);
-          if (!(X3B_KO & 4)) x3_store_stream16(GL + 16u * j, v0);
+          if (!(X3B_KO & 4)) x3b_global_store16_nt(GL + 16u * j, v0);
           if (j < 8u) {
             const x3_u32x4 v1 = x3_lds_read_b128(out_base + 16u * j + 512u);
-            if (!(X3B_KO & 4)) x3_store_stream16(GL + 16u * j + 512u, v1);
+            if (!(X3B_KO & 4)) x3b_global_store16_nt(GL + 16u * j + 512u, v1);
           }
         } else {
 #pragma unroll
@@ -780,12 +791,12 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
             const uint32_t lo = 16u * (j + 32u * r);
             if (lo < EB && lo + 16u > PH) {
               if (lo >= PH && lo + 16u <= EB) {
-                if (!(X3B_KO & 4)) x3_store_stream16(GL + lo, x3_lds_read_b128(out_base + lo));
+                if (!(X3B_KO & 4)) x3b_global_store16_nt(GL + lo, x3_lds_read_b128(out_base + lo));
               } else {
                 // the two ends of a row: sample by sample
                 const uint32_t from = lo > PH ? lo : PH, to = lo + 16u < EB ? lo + 16u : EB;
                 for (uint32_t bb = from; bb < to; bb += 2u)
-                  *reinterpret_cast<uint16_t*>(GL + bb) = (uint16_t)x3_lds_read_u16(out_base + bb, 0u);
+                  x3b_global_store2(GL + bb, x3_lds_read_u16(out_base + bb, 0u));
               }
             }
           }
