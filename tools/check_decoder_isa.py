@@ -21,7 +21,12 @@ def asm_lines(flags):
 # What the decode phase's occupancy rests on: five decoder groups of 31 744 bytes of LDS per CU, four
 # waves per SIMD (<= 128 registers, arch + accumulation), and beside them three waves of the check kernel (<= 96) with its
 # 6 KB of tables; no scratch in either.  {kernel prefix: (LDS bytes max, registers max)}
-BUDGET = {"_Z22x3_decode_split_kernel": (32768, 128), "_Z21x3_frame_check_kernel": (6144, 96)}
+# Round 6's block-per-lane decoder: five groups of <= 32 768 bytes per CU and exactly five (more than a sixth of the CU's 160 KB
+# each: the host sizes the grid for five), four waves per group = five per SIMD (<= 96 registers), in all three instantiations.
+BUDGET = {"_Z22x3_decode_split_kernel": (32768, 128), "_Z21x3_frame_check_kernel": (6144, 96),
+          "_Z23x3_decode_blocks_kernelILj20ELj1E": (32768, 96), "_Z23x3_decode_blocks_kernelILj20ELj2E": (32768, 96),
+          "_Z23x3_decode_blocks_kernelILj10ELj1E": (32768, 96)}
+LDS_MIN = {"_Z23x3_decode_blocks_kernelILj20ELj1E": 27308, "_Z23x3_decode_blocks_kernelILj20ELj2E": 27308, "_Z23x3_decode_blocks_kernelILj10ELj1E": 27308}
 def resources(flags):
     """-> {kernel prefix: {"lds", "vgpr", "scratch"}} from the .amdhsa_ directives of the compiled unit"""
     lines, res, cur = asm_lines(flags), {}, None
@@ -41,7 +46,7 @@ def over_budget(flags):
     out = []
     for k, r in resources(flags).items():
         lds, vg = BUDGET[k]
-        if r.get("lds", 0) > lds or r.get("vgpr", 0) > vg or r.get("scratch", 0) != 0:
+        if r.get("lds", 0) > lds or r.get("vgpr", 0) > vg or r.get("scratch", 0) != 0 or r.get("lds", 0) < LDS_MIN.get(k, 0):
             out.append((k, r, BUDGET[k]))
     return out
 def kernel_asm(flags):
