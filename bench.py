@@ -157,7 +157,7 @@ def compact_line(res):
         g = res["gather"]
         c["gather"] = {k: g[k] for k in ("mode", "ms", "in_timed_region", "value_without_gather") if k in g}
         c["rccl"] = res.get("rccl")
-    c["details"] = "the line before this one: {\"bench_details\": {...}} -- notes, per-step arrays, layouts, host-buffer and per-frame APIs"
+    c["details"] = "bench_details.json beside this run (--details): notes, per-step arrays, layouts, host-buffer and per-frame APIs"
     # never longer than the tail the driver keeps: drop the least important keys first
     for k in ("extremes_ms_per_step", "kernels_ms_p90_over_min", "configs", "decoder_kernels", "cold_ms_per_step"):
         if len(json.dumps(c)) <= COMPACT_MAX:
@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="samples timed on the CPU baseline")
     ap.add_argument("--cpu-reps", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--details", default="bench_details.json",
+                    help="file that takes everything the one-line record leaves out ('-': stderr, '': nowhere)")
     ap.add_argument("--no-gather", action="store_true", help="= --gather none")
     ap.add_argument("--gather", choices=("in-step", "overlapped", "sharded", "none"), default="in-step",
                     help="N > 1: the reassembly of the whole stream -- on rank 0 inside every step on the context's stream (the "
@@ -1171,10 +1173,18 @@ def main():
             res["gather_modes"] = gather_modes
             res["rccl_ranks"] = world
             res["rccl"] = rccl
-        # Two lines: everything -- notes, per-step arrays, the wider measurements -- as {"bench_details": ...},
-        # then the CONTRACT line, compact (<= 4 KB) and last, so that the tail of the driver's record holds every number it judges
-        # by: kernels_ms, encode_read_frac, roofline_all, the clocks, the CPU baseline, configs 2 and 5.
-        print(json.dumps({"bench_details": res}), flush=True)
+        # ONE line on stdout, as the contract says, and short (<= 4 KB, so that the tail of the driver's
+        # record holds every number it judges by: kernels_ms, encode_read_frac, roofline_all, the clocks, the CPU baseline,
+        # configs 2 and 5); everything else -- notes, per-step arrays, the wider measurements -- goes to a FILE beside it
+        # (--details, default bench_details.json in the working directory; "-" = a second line on stderr).
+        if args.details == "-":
+            print(json.dumps({"bench_details": res}), file=sys.stderr, flush=True)
+        elif args.details:
+            try:
+                with open(args.details, "w") as fh:
+                    json.dump({"bench_details": res}, fh)
+            except OSError as e:
+                print("bench.py: cannot write %s: %s" % (args.details, e), file=sys.stderr)
         print(json.dumps(compact_line(res)), flush=True)
 
     if shard_obj is not None:

@@ -181,6 +181,26 @@ def fam_g(rng, tag):
         cmp_decode(out[(sp + 1) & ~1:], p, n, (tag, "g-dec", bl, bpf, thr, n))
 
 
+def fam_k(rng, tag):
+    """round 6's block-per-lane decoder: block lengths 10 and 40 (its units of 10 / 20 samples, two units per block of 40;
+    the default decoder there) and 20 (option decode_blocks), frames of few and many blocks, damaged streams"""
+    bl = int(rng.choice([10, 40, 20]))
+    bpf = int(rng.choice([1, 2, 3, 4, 5, 8, 16, 17, 31, 32, 33, 50, 64, 100, 250, 500])) if rng.random() < 0.8 else int(rng.integers(1, 600))
+    if bl * bpf > 20000:
+        bpf = 20000 // bl
+    p = x3hip.Params.make(bl, bpf)
+    spf = bl * bpf
+    n = spf * int(rng.integers(1, 9 if spf > 2000 else 200)) + int(rng.integers(0, spf))
+    wav = content(rng, n)
+    stream = O.encode(wav, oparams(p))[1]
+    s = damage(rng, stream, frame_offsets(stream)) if rng.random() < 0.6 else stream
+    ctx.set_option("decode_blocks", 1)
+    try:
+        cmp_decode(s, p, n + 70000, (tag, "k", bl, bpf, n))
+    finally:
+        ctx.set_option("decode_blocks", 0)
+
+
 def damage(rng, stream, offs):
     """a copy of `stream` with one to three of its frames (byte offsets `offs`) tampered with, perhaps truncated"""
     s = stream.copy()
@@ -478,7 +498,7 @@ def fam_m(rng, tag):
         assert np.array_equal(got[1][k], want[1][k]), (tag, "m samples", k)
 
 
-fams = {"w": fam_w, "e": fam_e, "g": fam_g, "d": fam_d, "b": fam_b, "a": fam_a, "f": fam_f, "m": fam_m}
+fams = {"w": fam_w, "e": fam_e, "g": fam_g, "d": fam_d, "b": fam_b, "a": fam_a, "f": fam_f, "m": fam_m, "k": fam_k}
 
 
 def fam_s(rng, tag):

@@ -9,8 +9,7 @@ out=$1
 mkdir -p $out
 export TMPDIR=/tmp
 root=$PWD
-python3 bench.py > $out/bench_default.jsonl 2> $out/bench_default.err
-tail -1 $out/bench_default.jsonl > $out/bench_default.json   # (the contract line; the details line is the one before it)
+python3 bench.py --details $out/bench_details.json > $out/bench_default.json 2> $out/bench_default.err
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $root/$out/stats -o bench --output-format csv -- python3 $root/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-measure-traffic --no-extras > $root/$out/stats.log 2>&1)
 cp $out/stats/bench_kernel_stats.csv $out/bench_kernel_stats.csv 2>/dev/null
 cp $out/stats/bench_domain_stats.csv $out/bench_domain_stats.csv 2>/dev/null
