@@ -105,6 +105,12 @@ const char* x3_last_error(const x3_ctx* ctx);
  *   "two_pass" (X3HIP_TWO_PASS)            1: always encode with the two-pass kernels (no persistent grid)
  *   "stream_wgs" (X3HIP_STREAM_WGS)        workgroups per CU of the single-pass encoder, 0 = derived from occupancy
  *   "decode_single" (X3HIP_DECODE_SINGLE)  1: single-wave decoder kernels only
+ *   "decode_blocks" (X3HIP_DECODE_BLOCKS)  1: block length 20 on round 6's block-per-lane decoder (a walker wave finds where the
+ *                                          blocks begin, three decoder waves decode a block per lane) where the three-wave
+ *                                          kernel would run; same results, 0.78-0.82 against 0.65-0.69 ms on config 3.  Block
+ *                                          lengths 10 and 40 take that decoder by default ("decode_blocks_off" = 1: not).
+ *                                          Read-only "decode_kernel_in_use": 3 = block per lane, 2 = three waves per 64
+ *                                          frames, 1 / 0 = single wave
  *   (environment only) X3HIP_SPIN_WAIT=1   the process's waits for the GPU spin instead of sleeping (hipDeviceScheduleSpin,
  *                                          process-wide, effective when x3_ctx_create is the process's first use of the
  *                                          device): calls that end with a trip to the host come back ~20 us sooner
