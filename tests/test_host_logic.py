@@ -298,3 +298,18 @@ def test_decoder_ring_requests_are_not_waited_for_right_behind_their_issue():
     # with nothing failing)
     res = m.resources([])
     assert set(res) == set(m.BUDGET) and m.over_budget([]) == [], res
+
+
+def test_encoder_instantiations_keep_their_register_budgets():
+    """Round 6 added block lengths 10 and 40 as instantiations of the two single-pass encoders: every one of them must fit the
+    registers its occupancy rests on -- 128 for the wave encoder (four waves per SIMD), 80 for the second generation (six) --
+    and use no scratch (tools/check_encoder_isa.py; compiles the encoder's translation unit to assembly, ~10 s)."""
+    import importlib.util
+    if not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not found")
+    spec = importlib.util.spec_from_file_location("check_encoder_isa", os.path.join(ROOT, "tools", "check_encoder_isa.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    res = m.resources()
+    assert set(res) == set(m.BUDGET), sorted(set(m.BUDGET) - set(res))
+    assert m.over_budget(res) == [], res

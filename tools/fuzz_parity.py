@@ -162,6 +162,37 @@ def fam_e(rng, tag):
         assert r[0] == 0 and np.array_equal(r[1], wav), (tag, "round trip")
 
 
+def fam_n(rng, tag):
+    """round 6: block lengths 10 and 40 on the single-pass encoders (wave encoder and second generation: a lane's run of 20
+    samples is two blocks of 10 or half a block of 40), whole and ragged frames, other codes and thresholds now and then"""
+    bl = int(rng.choice([10, 40]))
+    per = 20 // bl if bl < 20 else 1
+    bpf = int(rng.choice([1, 2, 3, 4, 6, 8, 16, 50, 100, 125, 250, 255, 256])) * (2 if bl == 10 else 1) if rng.random() < 0.7 else int(rng.integers(1, 257 * max(per, 1)))
+    codes, thr = (0, 1, 3), (3, 8, 20)
+    if rng.random() < 0.2:
+        offsets = [6, 11, 20, 28]
+        codes = tuple(int(c) for c in rng.integers(0, 4, size=3))
+        thr = tuple(int(rng.integers(0, offsets[c] + 1)) for c in codes)
+    p = x3hip.Params.make(bl, bpf, codes, thr)
+    if x3hip.lib().x3_params_validate(C.byref(p)) != 0:
+        return
+    spf = bl * bpf
+    frames = int(rng.choice([1, 2, 3, 5, 40, 300, 1500])) if spf <= 400 else int(rng.choice([1, 2, 3, 7, 30, 90]))
+    n = max(1, spf * frames - int(rng.integers(0, spf)) + int(rng.integers(0, 3)))
+    wav = content(rng, n)
+    sp = int(rng.choice([0, 0, 1, 2, 3, 18]))
+    g2 = rng.random() < 0.4
+    ctx.set_option("enc_gen", 2 if g2 else 3)
+    try:
+        cut = float(rng.uniform(0.0, 0.3)) if rng.random() < 0.1 else None
+        rc, out = cmp_encode(wav, p, sp, (tag, "n", bl, bpf, codes, thr, n, sp, g2, cut), cut)
+    finally:
+        ctx.set_option("enc_gen", 3)
+    if rc == 0 and codes == (0, 1, 3):
+        r = cmp_decode(out[(sp + 1) & ~1:], p, n, (tag, "n-dec", bl, bpf, n))
+        assert r[0] == 0 and np.array_equal(r[1], wav), (tag, "round trip")
+
+
 def fam_g(rng, tag):
     offsets = [6, 11, 20, 28]
     bl = int(rng.integers(1, 61))
@@ -498,7 +529,7 @@ def fam_m(rng, tag):
         assert np.array_equal(got[1][k], want[1][k]), (tag, "m samples", k)
 
 
-fams = {"w": fam_w, "e": fam_e, "g": fam_g, "d": fam_d, "b": fam_b, "a": fam_a, "f": fam_f, "m": fam_m, "k": fam_k}
+fams = {"w": fam_w, "e": fam_e, "g": fam_g, "d": fam_d, "b": fam_b, "a": fam_a, "f": fam_f, "m": fam_m, "k": fam_k, "n": fam_n}
 
 
 def fam_s(rng, tag):

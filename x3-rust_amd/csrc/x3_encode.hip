@@ -109,7 +109,10 @@ int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3
     return X3_OK;
   };
   // ---- single-pass path: default block length, frames on dword boundaries (buffer loads)
-  const bool stream_path = p->block_len == 20 && (std::min<uint64_t>(spf, b->n_per_clip) + 18) / 20 <= 512 &&
+  // (block lengths 10 and 40, round 6: the second-generation kernel's lanes hold 20 samples whatever a block is -- half a
+  // block, one, or two -- so the bound on a frame is the same 512 lanes; the wave encoder stays with the default length)
+  const bool stream_path = (p->block_len == 20 || p->block_len == 10 || p->block_len == 40) &&
+                           (std::min<uint64_t>(spf, b->n_per_clip) + 18) / 20 <= 512 &&
                            (spf % X3_ENC_FRAME_ALIGN) == 0 &&
                            (b->n_clips == 1 || (b->clip_stride % X3_ENC_FRAME_ALIGN) == 0) &&
                            (reinterpret_cast<uintptr_t>(d_wav) & 3u) == 0 && !c->force_two_pass && !c->opt.two_pass &&
@@ -126,10 +129,14 @@ int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3
     } else {
       // third generation (x3_encode_wave_kernel.h): one wave per frame, sixteen waves per CU, one workgroup per CU
       static_assert(X3W_SMEM <= 160 * 1024, "LDS");
-      HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_wave_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3W_SMEM));
-            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_wave_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3W_SMEM));
+      typedef decltype(&x3_encode_wave_kernel<false, 20u>) gen3_fn;
+      // (a block of 40 is two of a lane's runs of 20, a run is two blocks of 10: x3w_analyse40, x3w_analyse10)
+      const uint32_t bl = p->block_len;
+      const gen3_fn wave_fn = pl.g.src_off ? (bl == 40 ? &x3_encode_wave_kernel<true, 40u> : bl == 10 ? &x3_encode_wave_kernel<true, 10u>
+                                                                                                       : &x3_encode_wave_kernel<true, 20u>)
+                                           : (bl == 40 ? &x3_encode_wave_kernel<false, 40u> : bl == 10 ? &x3_encode_wave_kernel<false, 10u>
+                                                                                                       : &x3_encode_wave_kernel<false, 20u>);
+      HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(wave_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3W_SMEM));
       uint64_t nwg_max = std::min<uint64_t>((uint64_t)c->n_cus, X3W_MAX_NWG);
       if (c->opt.wave_nwg > 0) nwg_max = std::min<uint64_t>(nwg_max, (uint64_t)c->opt.wave_nwg);
       X3WaveArgs wa;
@@ -177,7 +184,7 @@ int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3
       wa.seg = nullptr;
       wa.seg_log2 = 0;
       wa.seg_pitch = 0;
-      if (seg.d_index && seg.seg_blocks >= 4 && (seg.seg_blocks & (seg.seg_blocks - 1)) == 0) {
+      if (seg.d_index && bl == 20 && seg.seg_blocks >= 4 && (seg.seg_blocks & (seg.seg_blocks - 1)) == 0) {
         const uint64_t bpf = (spf + 19) / 20;   // blocks of a full frame (<= 512 here): the pitch follows the parameters, not the call
         const uint64_t nidx = (bpf + seg.seg_blocks - 1) / seg.seg_blocks;
         if (nidx >= 2 && !tab) {
@@ -189,30 +196,28 @@ int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3
       if (!wa.seg && (rc = seg_header_none())) return rc;
       {
         TimerScope ts(c, 0, nullptr, true);
-        if (wa.src_off) X3_LAUNCH_TIMED(ts, x3_encode_wave_kernel<true>, dim3(wa.nwg), dim3(X3W_THREADS), X3W_SMEM, c->stream, wa);
-        else X3_LAUNCH_TIMED(ts, x3_encode_wave_kernel<false>, dim3(wa.nwg), dim3(X3W_THREADS), X3W_SMEM, c->stream, wa);
+        X3_LAUNCH_TIMED(ts, wave_fn, dim3(wa.nwg), dim3(X3W_THREADS), X3W_SMEM, c->stream, wa);
       }
       {
         // The dense pass, always: the frames the wave kernel listed (none, in most recordings: the workgroups read a zero
         // count and leave, ~2 us of queue) written at the offsets it assigned.  In the stream, not in x3_encode_result:
         // whatever the caller enqueues behind this call -- x3_decode_dev, a copy -- finds the whole stream.
-        if (smem2 > 64 * 1024) {
-          HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_stream2_kernel<true, false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
-          HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_stream2_kernel<true, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
-        }
+        typedef decltype(&x3_encode_stream2_kernel<true, false, 20u>) dense_fn_t;
+        const dense_fn_t dense_fn =
+            pl.g.src_off ? (bl == 40 ? &x3_encode_stream2_kernel<true, true, 40u> : bl == 10 ? &x3_encode_stream2_kernel<true, true, 10u>
+                                                                                             : &x3_encode_stream2_kernel<true, true, 20u>)
+                         : (bl == 40 ? &x3_encode_stream2_kernel<true, false, 40u> : bl == 10 ? &x3_encode_stream2_kernel<true, false, 10u>
+                                                                                              : &x3_encode_stream2_kernel<true, false, 20u>);
+        if (smem2 > 64 * 1024)
+          HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
         const uint64_t per_cu = std::max<uint64_t>(1, (160 * 1024) / (smem2 + 256));
         const uint64_t grid = std::min<uint64_t>(F, (uint64_t)c->n_cus * std::min<uint64_t>(per_cu, 3));
         TimerScope ts(c, 5, nullptr, true);
-#define X3_DENSE_PASS(TABLE)                                                                                          \
-        X3_LAUNCH_TIMED(ts, (x3_encode_stream2_kernel<true, TABLE>), dim3((unsigned)grid), dim3(X3_STREAM2_THREADS), smem2,  \
-                        c->stream, d_wav, pl.g, pl.dp, d_off, d_out, out_cap, start_pos, (uint32_t*)nullptr, 0u,             \
-                        reinterpret_cast<unsigned char*>(c->d_status), (const uint32_t*)c->d_xk2,                           \
-                        (const uint16_t*)c->d_crctab, pl.img_dwords, (uint32_t*)nullptr, (const uint32_t*)c->dense_list.p,          \
-                        reinterpret_cast<uint32_t*>(c->d_ctl_base + 32 * (c->ctl_half ^ 1)))
-        if (pl.g.src_off) X3_DENSE_PASS(true); else X3_DENSE_PASS(false);
-#undef X3_DENSE_PASS
+        X3_LAUNCH_TIMED(ts, dense_fn, dim3((unsigned)grid), dim3(X3_STREAM2_THREADS), smem2,
+                        c->stream, d_wav, pl.g, pl.dp, d_off, d_out, out_cap, start_pos, (uint32_t*)nullptr, 0u,
+                        reinterpret_cast<unsigned char*>(c->d_status), (const uint32_t*)c->d_xk2,
+                        (const uint16_t*)c->d_crctab, pl.img_dwords, (uint32_t*)nullptr, (const uint32_t*)c->dense_list.p,
+                        reinterpret_cast<uint32_t*>(c->d_ctl_base + 32 * (c->ctl_half ^ 1)));
       }
       HIPCHK(c, hipGetLastError());
       c->ctl_clean[c->ctl_half ^ 1] = !c->capturing;   // (the dense pass clears the next call's control block -- when it runs)
@@ -225,20 +230,27 @@ int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3
   if ((rc = seg_header_none())) return rc;
   if (stream_path && stream_safe_thresholds(p)) {
     // second generation (x3_encode_stream2_kernel.h): eight waves, no sample tile in LDS
-    if (c->stream_wg_per_cu < 0) {
+    // the instantiation of this call: block length x (frames from a table?)
+    typedef decltype(&x3_encode_stream2_kernel<false, false, 20u>) gen2_fn;
+    const gen2_fn fn_plain = p->block_len == 10 ? &x3_encode_stream2_kernel<false, false, 10u>
+                           : p->block_len == 40 ? &x3_encode_stream2_kernel<false, false, 40u>
+                                                : &x3_encode_stream2_kernel<false, false, 20u>;
+    const gen2_fn fn_tab = p->block_len == 10 ? &x3_encode_stream2_kernel<false, true, 10u>
+                         : p->block_len == 40 ? &x3_encode_stream2_kernel<false, true, 40u>
+                                              : &x3_encode_stream2_kernel<false, true, 20u>;
+    const gen2_fn fn = pl.g.src_off ? fn_tab : fn_plain;
+    const uint64_t wg_key = (uint64_t)smem2 | ((uint64_t)p->block_len << 32) | (pl.g.src_off ? 1ull << 40 : 0ull);
+    if (c->stream_wg_per_cu < 0 || c->stream_wg_key != wg_key) {
+      c->stream_wg_key = wg_key;
       // Offsets wait on the other workgroups' frame sizes, so EVERY workgroup of the grid must be resident.  The
       // occupancy API can over-report by one block per CU (MI355X_MICROARCH.md, "Residency"), so it is capped
       // by the kernel's own register/LDS footprint: eight waves are two per SIMD, whatever the placement.
-      if (smem2 > 64 * 1024) {
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_stream2_kernel<false, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_encode_stream2_kernel<false, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
-      }
+      if (smem2 > 64 * 1024)
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
       int nb = 0;
-      HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, x3_encode_stream2_kernel<false>, X3_STREAM2_THREADS, smem2));
+      HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(fn), X3_STREAM2_THREADS, smem2));
       hipFuncAttributes fa;
-      HIPCHK(c, hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&x3_encode_stream2_kernel<false>)));
+      HIPCHK(c, hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(fn)));
       const int alloc = ((fa.numRegs + 7) / 8) * 8;
       const int wps = std::min(8, 512 / std::max(alloc, 8));
       const int by_regs = (4 * wps) / 8;
@@ -248,8 +260,8 @@ int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3
       // waits time out and x3_encode_result re-encodes with the two-pass kernels)
       if (c->opt.stream_wgs > 0) c->stream_wg_per_cu = c->opt.stream_wgs;
       if (c->opt.verbose)
-        std::fprintf(stderr, "x3hip: stream encoder v2 %d VGPRs, %zu B LDS, occupancy API %d, by_regs %d, by_lds %d -> %d workgroups/CU\n",
-                     fa.numRegs, smem2, nb, by_regs, by_lds, c->stream_wg_per_cu);
+        std::fprintf(stderr, "x3hip: stream encoder v2 (block length %u) %d VGPRs, %zu B LDS, occupancy API %d, by_regs %d, by_lds %d -> %d workgroups/CU\n",
+                     p->block_len, fa.numRegs, smem2, nb, by_regs, by_lds, c->stream_wg_per_cu);
     }
     if (c->stream_wg_per_cu >= 1 && smem2 <= 160 * 1024) {
       // frame-size descriptors {epoch:12 | bytes:20}: the epoch makes last launch's words "not ready"
@@ -266,13 +278,11 @@ int encode_dev_impl(x3_ctx* c, const int16_t* d_wav, const x3_batch* b, const x3
       }
       {
         TimerScope ts(c, 0);
-#define X3_GEN2(TABLE)                                                                                                \
-        hipLaunchKernelGGL((x3_encode_stream2_kernel<false, TABLE>), dim3((unsigned)grid), dim3(X3_STREAM2_THREADS), smem2, \
-                           c->stream, d_wav, pl.g, pl.dp, d_off, d_out, out_cap, start_pos, (uint32_t*)c->desc.p + desc_pad, \
-                           c->desc_epoch, reinterpret_cast<unsigned char*>(c->d_status), (const uint32_t*)c->d_xk2,          \
-                           (const uint16_t*)c->d_crctab, pl.img_dwords, c->d_pace + 4, (const uint32_t*)nullptr)
-        if (pl.g.src_off) X3_GEN2(true); else X3_GEN2(false);
-#undef X3_GEN2
+        hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(X3_STREAM2_THREADS), smem2,
+                           c->stream, d_wav, pl.g, pl.dp, d_off, d_out, out_cap, start_pos, (uint32_t*)c->desc.p + desc_pad,
+                           c->desc_epoch, reinterpret_cast<unsigned char*>(c->d_status), (const uint32_t*)c->d_xk2,
+                           (const uint16_t*)c->d_crctab, pl.img_dwords, c->d_pace + 4, (const uint32_t*)nullptr,
+                           (uint32_t*)nullptr);
       }
       HIPCHK(c, hipGetLastError());
       c->last_enc_gen = 2;

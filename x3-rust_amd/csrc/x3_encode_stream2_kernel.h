@@ -94,7 +94,13 @@ typedef uint32_t x3_v2u32 __attribute__((ext_vector_type(2)));
 // the whole call (rounds 2-3).
 // TAB: the frames come from a table (x3_encode_frames_dev; g.src_off / g.src_n).  A template parameter: as a run-time test
 // it cost the uniform layout 17 % (white noise 0.94 ms against 0.80).
-template <bool LIST, bool TAB = false>
+// BL (round 6): the block length.  A lane always holds 20 samples -- loads, pair masks, the scan of bit lengths, the CRC pass
+// and the copy-out do not know about blocks at all.  What a block decides is the filter (its largest |difference|), its
+// header and the statistics: with BL = 10 a lane holds TWO blocks (two maxima, two headers, one run of bits), with BL = 40
+// a block is TWO neighbouring lanes (one quad-permute DPP shares the maximum, the even lane writes the header).  The
+// BL = 20 instantiation is the code of rounds 2-5, untouched (`if constexpr`; its instruction stream compared equal when this
+// was added); tools/check_encoder_isa.py keeps every instantiation inside its register budget.
+template <bool LIST, bool TAB = false, uint32_t BL = 20u>
 __global__ void __launch_bounds__(X3_STREAM2_THREADS, X3E_WAVES_PER_SIMD)
 x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams p,
                          uint64_t* __restrict__ frame_off, uint8_t* __restrict__ out, uint64_t out_cap,
@@ -388,10 +394,77 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
     uint32_t S[10];   // emission source per pair of block samples
     uint32_t type = 0, ft = 0, nb = 0, nbits = 0;
     uint32_t amask = 0, orc = 0, qsh = 0, qmask = 0, lbase = 0;  // (code,len) recipe, see x3_encode_common.h
-    if (cnt) {
-      uint32_t mn = 0, mx = 0;
-      // (two copies of the loop behind ONE wave-uniform branch: left inside the loop, hipcc turns the test into
-      // per-pair selects and every pair of every block pays for the masks)
+    // (general block lengths) blocks of a lane / lanes of a block / pairs of a lane's (part of a) block
+    constexpr uint32_t BU = BL < 20u ? 20u / BL : 1u, BV = BL > 20u ? BL / 20u : 1u, BP = 10u / BU;
+    static_assert(BL == 10u || BL == 20u || BL == 40u, "block lengths 10, 20 and 40");
+    uint32_t hd[BU];   // per block of the lane: type | header value << 8
+    const bool lead = BV == 1u || (lane & (BV - 1u)) == 0u;   // this lane holds the block's first samples: it writes the header
+    // samples of block u of this lane
+    auto cnt_of = [&](uint32_t u) __attribute__((always_inline)) -> uint32_t {
+      if (BU == 1u) return cnt;
+      return cnt > u * BL ? (cnt - u * BL < BL ? cnt - u * BL : BL) : 0u;
+    };
+    if constexpr (BL == 20u) {
+      if (cnt) {
+        uint32_t mn = 0, mx = 0;
+        // (two copies of the loop behind ONE wave-uniform branch: left inside the loop, hipcc turns the test into
+        // per-pair selects and every pair of every block pays for the masks)
+        auto diffs = [&](auto plain_tag) __attribute__((always_inline)) {
+          constexpr bool PLAIN = decltype(plain_tag)::value;
+  #pragma unroll
+          for (int j = 0; j < 10; ++j) {
+            const uint32_t Xj = __builtin_amdgcn_alignbit(W[j + 1], W[j], 16);  // (s[2j+1], s[2j+2])
+            S[j] = x3_pk_sub_sat(Xj, W[j]);                                      // (d[2j+1], d[2j+2]), saturated
+            if (PLAIN) {
+              if (j == 9) S[9] &= cnt == 20u ? 0xFFFFFFFFu : 0x0000FFFFu;        // a 19-sample block has no sample 20
+            } else {
+              S[j] &= pair_mask(j);
+            }
+            mn = x3_pk_min_i16(mn, S[j]);
+            mx = x3_pk_max_i16(mx, S[j]);
+          }
+        };
+        if (plain) diffs(std::true_type{}); else diffs(std::false_type{});
+        const int32_t dmin = min((int32_t)(int16_t)(mn & 0xFFFFu), (int32_t)mn >> 16);
+        const int32_t dmax = max((int32_t)(int16_t)(mx & 0xFFFFu), (int32_t)mx >> 16);
+        const int32_t maxabs = (-dmin) > dmax ? (-dmin) : dmax;
+        if (maxabs <= (int32_t)p.thr[2]) {
+          ft = (maxabs > (int32_t)p.thr[0] ? 1u : 0u) + (maxabs > (int32_t)p.thr[1] ? 1u : 0u);
+          const uint32_t k = (kpack >> (8u * ft)) & 0xFFu;
+          type = k;
+          uint32_t sum = 0;
+  #pragma unroll
+          for (int j = 0; j < 10; ++j) {
+            S[j] = x3_pk_shl_b16(S[j], 1) ^ x3_pk_sar_i16(S[j], 15);  // zigzag, per half (0 stays 0)
+            sum = x3_pk_add_u16(sum, x3_pk_shr_u16(S[j], k));
+          }
+          nbits = 2u + cnt * (k + 1u) + (sum & 0xFFFFu) + (sum >> 16);
+          amask = (1u << k) - 1u;
+          orc = 1u << k;
+          qsh = k;
+          qmask = 0xFFFFFFFFu;
+          lbase = k + 1u;
+        } else {
+          nb = 32u - (uint32_t)__clz(maxabs);
+          if (nb >= 15) {
+            type = 5;
+            nbits = 6 + 16 * cnt;
+  #pragma unroll
+            for (int j = 0; j < 10; ++j) S[j] = __builtin_amdgcn_alignbit(W[j + 1], W[j], 16);  // raw samples
+            amask = 0xFFFFu;
+            lbase = 16;
+          } else {
+            type = 4;
+            nbits = 6 + cnt * (nb + 1);
+            amask = (1u << (nb + 1)) - 1u;  // S already holds the exact diffs
+            lbase = nb + 1;
+          }
+        }
+      }
+    } else {
+      uint32_t mn[BU], mx[BU];
+#pragma unroll
+      for (uint32_t u = 0; u < BU; ++u) mn[u] = mx[u] = 0;
       auto diffs = [&](auto plain_tag) __attribute__((always_inline)) {
         constexpr bool PLAIN = decltype(plain_tag)::value;
 #pragma unroll
@@ -399,49 +472,56 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
           const uint32_t Xj = __builtin_amdgcn_alignbit(W[j + 1], W[j], 16);  // (s[2j+1], s[2j+2])
           S[j] = x3_pk_sub_sat(Xj, W[j]);                                      // (d[2j+1], d[2j+2]), saturated
           if (PLAIN) {
-            if (j == 9) S[9] &= cnt == 20u ? 0xFFFFFFFFu : 0x0000FFFFu;        // a 19-sample block has no sample 20
+            if (j == 9) S[9] &= cnt == 20u ? 0xFFFFFFFFu : 0x0000FFFFu;
           } else {
             S[j] &= pair_mask(j);
           }
-          mn = x3_pk_min_i16(mn, S[j]);
-          mx = x3_pk_max_i16(mx, S[j]);
+          mn[j / BP] = x3_pk_min_i16(mn[j / BP], S[j]);
+          mx[j / BP] = x3_pk_max_i16(mx[j / BP], S[j]);
         }
       };
       if (plain) diffs(std::true_type{}); else diffs(std::false_type{});
-      const int32_t dmin = min((int32_t)(int16_t)(mn & 0xFFFFu), (int32_t)mn >> 16);
-      const int32_t dmax = max((int32_t)(int16_t)(mx & 0xFFFFu), (int32_t)mx >> 16);
-      const int32_t maxabs = (-dmin) > dmax ? (-dmin) : dmax;
-      if (maxabs <= (int32_t)p.thr[2]) {
-        ft = (maxabs > (int32_t)p.thr[0] ? 1u : 0u) + (maxabs > (int32_t)p.thr[1] ? 1u : 0u);
-        const uint32_t k = (kpack >> (8u * ft)) & 0xFFu;
-        type = k;
-        uint32_t sum = 0;
+      // (a plain wave's lanes behind the frame hold whatever their loads returned: they count as silence)
+      const uint32_t on = cnt ? 0xFFFFFFFFu : 0u;
 #pragma unroll
-        for (int j = 0; j < 10; ++j) {
-          S[j] = x3_pk_shl_b16(S[j], 1) ^ x3_pk_sar_i16(S[j], 15);  // zigzag, per half (0 stays 0)
-          sum = x3_pk_add_u16(sum, x3_pk_shr_u16(S[j], k));
-        }
-        nbits = 2u + cnt * (k + 1u) + (sum & 0xFFFFu) + (sum >> 16);
-        amask = (1u << k) - 1u;
-        orc = 1u << k;
-        qsh = k;
-        qmask = 0xFFFFFFFFu;
-        lbase = k + 1u;
-      } else {
-        nb = 32u - (uint32_t)__clz(maxabs);
-        if (nb >= 15) {
-          type = 5;
-          nbits = 6 + 16 * cnt;
+      for (uint32_t u = 0; u < BU; ++u) {
+        const int32_t dmin = min((int32_t)(int16_t)(mn[u] & 0xFFFFu), (int32_t)mn[u] >> 16);
+        const int32_t dmax = max((int32_t)(int16_t)(mx[u] & 0xFFFFu), (int32_t)mx[u] >> 16);
+        uint32_t maxabs = (uint32_t)((-dmin) > dmax ? (-dmin) : dmax) & on;
+        // the block's other lane (quad_perm [1,0,3,2]; every lane of the wave is here)
+        if (BV == 2u) maxabs = max(maxabs, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)maxabs, 0xB1, 0xF, 0xF, false));
+        const uint32_t cu = cnt_of(u);
+        uint32_t ty = 0, hv = 0, nbu = 0;
+        if (cu) {
+          if (maxabs <= p.thr[2]) {
+            const uint32_t f_ = (maxabs > p.thr[0] ? 1u : 0u) + (maxabs > p.thr[1] ? 1u : 0u);
+            const uint32_t k = (kpack >> (8u * f_)) & 0xFFu;
+            ty = k;
+            hv = f_ + 1u;
+            uint32_t sum = 0;
 #pragma unroll
-          for (int j = 0; j < 10; ++j) S[j] = __builtin_amdgcn_alignbit(W[j + 1], W[j], 16);  // raw samples
-          amask = 0xFFFFu;
-          lbase = 16;
-        } else {
-          type = 4;
-          nbits = 6 + cnt * (nb + 1);
-          amask = (1u << (nb + 1)) - 1u;  // S already holds the exact diffs
-          lbase = nb + 1;
+            for (uint32_t j = u * BP; j < (u + 1u) * BP; ++j) {
+              S[j] = x3_pk_shl_b16(S[j], 1) ^ x3_pk_sar_i16(S[j], 15);  // zigzag, per half (0 stays 0)
+              sum = x3_pk_add_u16(sum, x3_pk_shr_u16(S[j], k));
+            }
+            nbu = (lead ? 2u : 0u) + cu * (k + 1u) + (sum & 0xFFFFu) + (sum >> 16);
+          } else {
+            const uint32_t nbw = 32u - (uint32_t)__clz(maxabs);
+            if (nbw >= 15) {
+              ty = 5;
+              hv = 15;
+              nbu = (lead ? 6u : 0u) + 16u * cu;
+#pragma unroll
+              for (uint32_t j = u * BP; j < (u + 1u) * BP; ++j) S[j] = __builtin_amdgcn_alignbit(W[j + 1], W[j], 16);  // raw samples
+            } else {
+              ty = 4;
+              hv = nbw;
+              nbu = (lead ? 6u : 0u) + cu * (nbw + 1u);
+            }
+          }
         }
+        hd[u] = ty | (hv << 8);
+        nbits += nbu;
       }
     }
 
@@ -488,48 +568,107 @@ x3_encode_stream2_kernel(const int16_t* __restrict__ wav, X3Geom g, X3DevParams 
     }
 
     // ---- D: emission
-    if (nbits) {
+    if constexpr (BL == 20u) {
+      if (nbits) {
+        X3BitEmitter e;
+        e.init(img + 5, pos);
+        e.put(type <= 3 ? ft + 1u : (type == 4 ? nb : 15u), type <= 3 ? 2u : 6u);
+        // (code, len) for BOTH samples of a pair in packed 16-bit arithmetic, the halves combined with
+        // SDWA operand selects: 11 VALU per pair in front of the flush test
+        const uint32_t qsh2 = qsh * 0x10001u, lbase2 = lbase * 0x10001u;
+        const uint32_t amask2 = amask * 0x10001u, orc2 = orc * 0x10001u;
+        const uint32_t last_on = cnt == 20 ? 0xFFFFFFFFu : 0x0000FFFFu;  // a 19-sample block has no sample 20
+        uint32_t waddr = x3_lds_addr(e.words + e.w);  // byte address of the word the accumulator flushes to
+        uint64_t acc = e.acc;
+        uint32_t pend = e.cnt;
+        auto pairs = [&](auto plain_tag) __attribute__((always_inline)) {
+          constexpr bool PLAIN = decltype(plain_tag)::value;
+  #pragma unroll
+          for (int j = 0; j < 10; ++j) {
+            uint32_t Lp = x3_pk_add_u16(x3_pk_lshr_b16(S[j], qsh2) & qmask, lbase2);  // (la, lc)
+            uint32_t Cp = (S[j] & amask2) | orc2;                                        // (ca, cc)
+            if (PLAIN) {
+              if (j == 9) { Lp &= last_on; Cp &= last_on; }
+            } else {
+              const uint32_t m = pair_mask(j);
+              Lp &= m;
+              Cp &= m;
+            }
+            const uint32_t tot = x3_sdwa_add_w0_w1(Lp);                                  // la + lc <= 32
+            const uint32_t pair = x3_sdwa_or_w1(x3_sdwa_shl_w0_by_w1(Cp, Lp), Cp);       // (ca << lc) | cc
+            acc = (acc << tot) | (unsigned long long)pair;
+            pend += tot;
+            if (pend >= 32u) {
+              pend -= 32u;
+              x3_lds_or_b32(waddr, x3_bswap32((uint32_t)(acc >> pend)));
+              waddr += 4u;
+            }
+          }
+        };
+        if (plain) pairs(std::true_type{}); else pairs(std::false_type{});
+        if (pend) x3_lds_or_b32(waddr, x3_bswap32((uint32_t)(acc << (32u - pend))));
+      }
+    } else if (nbits) {
       X3BitEmitter e;
       e.init(img + 5, pos);
-      e.put(type <= 3 ? ft + 1u : (type == 4 ? nb : 15u), type <= 3 ? 2u : 6u);
-      // (code, len) for BOTH samples of a pair in packed 16-bit arithmetic, the halves combined with
-      // SDWA operand selects: 11 VALU per pair in front of the flush test
-      const uint32_t qsh2 = qsh * 0x10001u, lbase2 = lbase * 0x10001u;
-      const uint32_t amask2 = amask * 0x10001u, orc2 = orc * 0x10001u;
-      const uint32_t last_on = cnt == 20 ? 0xFFFFFFFFu : 0x0000FFFFu;  // a 19-sample block has no sample 20
       uint32_t waddr = x3_lds_addr(e.words + e.w);  // byte address of the word the accumulator flushes to
-      uint64_t acc = e.acc;
+      uint64_t acc = 0;
       uint32_t pend = e.cnt;
-      auto pairs = [&](auto plain_tag) __attribute__((always_inline)) {
-        constexpr bool PLAIN = decltype(plain_tag)::value;
+      const uint32_t last_on = cnt == 20 ? 0xFFFFFFFFu : 0x0000FFFFu;  // a 19-sample lane has no sample 20
 #pragma unroll
-        for (int j = 0; j < 10; ++j) {
-          uint32_t Lp = x3_pk_add_u16(x3_pk_lshr_b16(S[j], qsh2) & qmask, lbase2);  // (la, lc)
-          uint32_t Cp = (S[j] & amask2) | orc2;                                        // (ca, cc)
-          if (PLAIN) {
-            if (j == 9) { Lp &= last_on; Cp &= last_on; }
-          } else {
-            const uint32_t m = pair_mask(j);
-            Lp &= m;
-            Cp &= m;
+      for (uint32_t u = 0; u < BU; ++u) {
+        const uint32_t cu = cnt_of(u);
+        if (cu) {
+          const uint32_t ty = hd[u] & 0xFFu, hv = hd[u] >> 8;
+          if (lead) {
+            const uint32_t hl = ty <= 3u ? 2u : 6u;
+            acc = (acc << hl) | (unsigned long long)hv;
+            pend += hl;
+            if (pend >= 32u) {
+              pend -= 32u;
+              x3_lds_or_b32(waddr, x3_bswap32((uint32_t)(acc >> pend)));
+              waddr += 4u;
+            }
           }
-          const uint32_t tot = x3_sdwa_add_w0_w1(Lp);                                  // la + lc <= 32
-          const uint32_t pair = x3_sdwa_or_w1(x3_sdwa_shl_w0_by_w1(Cp, Lp), Cp);       // (ca << lc) | cc
-          acc = (acc << tot) | (unsigned long long)pair;
-          pend += tot;
-          if (pend >= 32u) {
-            pend -= 32u;
-            x3_lds_or_b32(waddr, x3_bswap32((uint32_t)(acc >> pend)));
-            waddr += 4u;
-          }
+          // the (code, len) recipe of this block (x3_encode_common.h)
+          const bool rice = ty <= 3u;
+          const uint32_t wdt = ty == 4u ? hv + 1u : 16u;   // BFP: nb + 1 bits; literal: 16
+          const uint32_t qsh2 = (rice ? ty : 0u) * 0x10001u, lbase2 = (rice ? ty + 1u : wdt) * 0x10001u;
+          const uint32_t amask2 = ((1u << (rice ? ty : wdt)) - 1u) * 0x10001u, orc2 = (rice ? 1u << ty : 0u) * 0x10001u;
+          const uint32_t qmask = rice ? 0xFFFFFFFFu : 0u;
+          auto pairs = [&](auto plain_tag) __attribute__((always_inline)) {
+            constexpr bool PLAIN = decltype(plain_tag)::value;
+#pragma unroll
+            for (uint32_t j = u * BP; j < (u + 1u) * BP; ++j) {
+              uint32_t Lp = x3_pk_add_u16(x3_pk_lshr_b16(S[j], qsh2) & qmask, lbase2);  // (la, lc)
+              uint32_t Cp = (S[j] & amask2) | orc2;                                        // (ca, cc)
+              if (PLAIN) {
+                if (j == 9) { Lp &= last_on; Cp &= last_on; }
+              } else {
+                const uint32_t m = pair_mask(j);
+                Lp &= m;
+                Cp &= m;
+              }
+              const uint32_t tot = x3_sdwa_add_w0_w1(Lp);                                  // la + lc <= 32
+              const uint32_t pair = x3_sdwa_or_w1(x3_sdwa_shl_w0_by_w1(Cp, Lp), Cp);       // (ca << lc) | cc
+              acc = (acc << tot) | (unsigned long long)pair;
+              pend += tot;
+              if (pend >= 32u) {
+                pend -= 32u;
+                x3_lds_or_b32(waddr, x3_bswap32((uint32_t)(acc >> pend)));
+                waddr += 4u;
+              }
+            }
+          };
+          if (plain) pairs(std::true_type{}); else pairs(std::false_type{});
+          if (!LIST) atomicAdd(&part[32 + ty], cu);   // statistics (encoder.rs:199): stats[type] += block.len()
         }
-      };
-      if (plain) pairs(std::true_type{}); else pairs(std::false_type{});
+      }
       if (pend) x3_lds_or_b32(waddr, x3_bswap32((uint32_t)(acc << (32u - pend))));
     }
     // statistics (encoder.rs:199): stats[type] += block.len(); one LDS atomic per lane, summed over
     // all frames of this workgroup and flushed once at the end
-    if (!LIST && cnt) atomicAdd(&part[32 + type], cnt);
+    if (BL == 20u && !LIST && cnt) atomicAdd(&part[32 + type], cnt);
     X3_STAMP(2);
     // the sizes in front of the previous frame were requested a whole iteration ago
     if (!LIST && have_prev) settle();

@@ -190,20 +190,157 @@ __device__ __forceinline__ void x3w_analyse(uint32_t (&X)[41], uint32_t cnt, uin
   meta = cnt ? mt : 0u;
 }
 
+// ---- block length 40 (round 6): a block is TWO of the lane's four runs of ten dwords -- one filter over both (their largest
+// |difference| together), one header, the second run a continuation that x3w_emit<Q, true> writes without a header.  cntA, cntB:
+// samples of the two runs, (20, 20), (20, 19), (20, 0), (19, 0) or (0, 0): everything else takes the generic path.  The
+// arithmetic is x3w_analyse's; what is new are the masks of the second run (a block that ends in its first run must not
+// see what the loads returned behind it).
+template <int QQ>
+__device__ __forceinline__ void x3w_analyse40(uint32_t (&X)[41], uint32_t cntA, uint32_t cntB, uint32_t thr0, uint32_t thr1,
+                                              uint32_t thr2, uint32_t kpack, __amdgpu_buffer_rsrc_t rs, uint32_t vo, uint32_t so,
+                                              uint32_t& nbits, uint32_t& metaA, uint32_t& metaB) {
+  constexpr int B = 20 * QQ;
+  uint32_t mx = 0x80008000u, mn = 0x7FFF7FFFu;
+  const uint32_t onB = cntB ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+  for (int j = 0; j < 20; ++j) {
+    const uint32_t Xj = __builtin_amdgcn_alignbit(X[B + j + 1], X[B + j], 16);
+    uint32_t d = x3_pk_sub_sat(Xj, X[B + j]);
+    if (j == 9) d &= cntA == 20u ? 0xFFFFFFFFu : 0x0000FFFFu;
+    if (j >= 10 && j < 19) d &= onB;
+    if (j == 19) d &= cntB == 20u ? 0xFFFFFFFFu : (cntB ? 0x0000FFFFu : 0u);
+    X[B + j] = d;
+    mx = x3_pk_max_i16(mx, d);
+    mn = x3_pk_min_i16(mn, d);
+  }
+  const uint32_t ab = x3_pk_max_i16(mx, x3_pk_sub_sat(0u, mn));
+  const int32_t maxabs = (int32_t)max(ab & 0xFFFFu, ab >> 16);
+  const uint32_t cnt = cntA + cntB;
+  uint32_t nb_ = 0, mt = 0;
+  if (maxabs <= (int32_t)thr2) {
+    const uint32_t ft = (maxabs > (int32_t)thr0 ? 1u : 0u) + (maxabs > (int32_t)thr1 ? 1u : 0u);
+    const uint32_t k = (kpack >> (8u * ft)) & 0xFFu;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < 20; ++j) {
+      const uint32_t d = X[B + j];
+      const uint32_t z = x3_pk_shl_b16_1(d) ^ x3_pk_ashr_i16_15(d);
+      X[B + j] = z;
+      sum = x3_pk_add_u16(sum, x3_pk_shr_u16(z, k));
+    }
+    nb_ = 2u + cnt * (k + 1u) + (sum & 0xFFFFu) + (sum >> 16);
+    mt = (ft + 1u) | ((k + 1u) << 6) | (1u << 11) | (k << 12);
+  } else {
+    const uint32_t nb = 32u - (uint32_t)__clz(maxabs);
+    if (nb >= 15u) {
+      nb_ = 6u + 16u * cnt;
+      uint32_t prev = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(vo + 4u * B), (int)so, 0);
+#pragma unroll
+      for (int j = 0; j < 20; ++j) {
+        const uint32_t nxt = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(vo + 4u * (B + j + 1)), (int)so, 0);
+        X[B + j] = __builtin_amdgcn_alignbit(nxt, prev, 16);
+        prev = nxt;
+      }
+      mt = 15u | (16u << 6) | (5u << 12);
+    } else {
+      nb_ = 6u + cnt * (nb + 1u);
+      mt = nb | ((nb + 1u) << 6) | (4u << 12);
+    }
+  }
+  nbits = cntA ? nb_ : 0u;
+  metaA = cntA ? mt : 0u;
+  metaB = cntB ? mt : 0u;
+}
+
+// ---- block length 10 (round 6): a lane's run of ten dwords is TWO blocks, each with its own filter and header.  The lane
+// has eight blocks per half and four 16-bit meta slots: a block's meta shrinks to 8 bits -- header value [0..3] | Rice [4] |
+// present [5] -- and x3w_meta_of() makes the 15-bit form of x3w_analyse out of it again where a block is emitted or counted
+// (field width, Rice parameter and statistics index all follow from the header value and the parameter set).
+__device__ __forceinline__ uint32_t x3w_meta8(uint32_t meta) {   // 15-bit form -> 8-bit form
+  return meta ? (meta & 15u) | (((meta >> 11) & 1u) << 4) | 32u : 0u;
+}
+__device__ __forceinline__ uint32_t x3w_meta_of(uint32_t m8, uint32_t kpack) {
+  const uint32_t hv = m8 & 15u, rice = (m8 >> 4) & 1u;
+  const uint32_t k = (kpack >> (8u * ((hv - 1u) & 3u))) & 0xFFu;
+  const uint32_t lbase = rice ? k + 1u : (hv == 15u ? 16u : hv + 1u);
+  const uint32_t sidx = rice ? k : (hv == 15u ? 5u : 4u);
+  return (m8 & 32u) ? hv | (lbase << 6) | (rice << 11) | (sidx << 12) : 0u;
+}
+// cnt: samples of the RUN, 20, 19 or 0 (as x3w_analyse); meta: the two blocks' 8-bit forms, first block low
+template <int Q>
+__device__ __forceinline__ void x3w_analyse10(uint32_t (&X)[41], uint32_t cnt, uint32_t thr0, uint32_t thr1, uint32_t thr2,
+                                              uint32_t kpack, __amdgpu_buffer_rsrc_t rs, uint32_t vo, uint32_t so,
+                                              uint32_t& nbits, uint32_t& meta) {
+  constexpr int B = 10 * Q;
+  uint32_t mx[2] = {0x80008000u, 0x80008000u}, mn[2] = {0x7FFF7FFFu, 0x7FFF7FFFu};
+#pragma unroll
+  for (int j = 0; j < 10; ++j) {
+    const uint32_t Xj = __builtin_amdgcn_alignbit(X[B + j + 1], X[B + j], 16);
+    uint32_t d = x3_pk_sub_sat(Xj, X[B + j]);
+    if (j == 9) d &= cnt == 20u ? 0xFFFFFFFFu : 0x0000FFFFu;
+    X[B + j] = d;
+    mx[j / 5] = x3_pk_max_i16(mx[j / 5], d);
+    mn[j / 5] = x3_pk_min_i16(mn[j / 5], d);
+  }
+  uint32_t nbt = 0, mt2 = 0;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const uint32_t cu = u ? cnt - 10u : 10u;   // (used when cnt != 0: 20 or 19)
+    const uint32_t ab = x3_pk_max_i16(mx[u], x3_pk_sub_sat(0u, mn[u]));
+    const int32_t maxabs = (int32_t)max(ab & 0xFFFFu, ab >> 16);
+    uint32_t nb_ = 0, m8 = 0;
+    if (maxabs <= (int32_t)thr2) {
+      const uint32_t ft = (maxabs > (int32_t)thr0 ? 1u : 0u) + (maxabs > (int32_t)thr1 ? 1u : 0u);
+      const uint32_t k = (kpack >> (8u * ft)) & 0xFFu;
+      uint32_t sum = 0;
+#pragma unroll
+      for (int j = 5 * u; j < 5 * u + 5; ++j) {
+        const uint32_t d = X[B + j];
+        const uint32_t z = x3_pk_shl_b16_1(d) ^ x3_pk_ashr_i16_15(d);
+        X[B + j] = z;
+        sum = x3_pk_add_u16(sum, x3_pk_shr_u16(z, k));
+      }
+      nb_ = 2u + cu * (k + 1u) + (sum & 0xFFFFu) + (sum >> 16);
+      m8 = (ft + 1u) | 16u | 32u;
+    } else {
+      const uint32_t nb = 32u - (uint32_t)__clz(maxabs);
+      if (nb >= 15u) {
+        nb_ = 6u + 16u * cu;
+        uint32_t prev = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(vo + 4u * (B + 5 * u)), (int)so, 0);
+#pragma unroll
+        for (int j = 5 * u; j < 5 * u + 5; ++j) {
+          const uint32_t nxt = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(vo + 4u * (B + j + 1)), (int)so, 0);
+          X[B + j] = __builtin_amdgcn_alignbit(nxt, prev, 16);
+          prev = nxt;
+        }
+        m8 = 15u | 32u;
+      } else {
+        nb_ = 6u + cu * (nb + 1u);
+        m8 = nb | 32u;
+      }
+    }
+    nbt += nb_;
+    mt2 |= m8 << (8 * u);
+  }
+  nbits = cnt ? nbt : 0u;
+  meta = cnt ? mt2 : 0u;
+}
+
 // ---- the generic path: frames whose last block has 1..18 samples (the ragged tail frame of a clip).  Sample by
 // sample from memory as the reference does it (x3_encode_block, encoder.rs:289-315), in 32-bit arithmetic; it shares
 // nothing with the register arrays of the fast path.  bi: block index in the frame, cnt: its samples (1..20).
 __device__ __forceinline__ int32_t x3w_sample(__amdgpu_buffer_rsrc_t rs, uint32_t i) {
   return (int32_t)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)(2u * i), 0, 0);
 }
+template <uint32_t BL = 20u>
 __device__ __forceinline__ void x3w_slow_analyse(__amdgpu_buffer_rsrc_t rs, uint32_t bi, uint32_t cnt, uint32_t thr0,
                                                  uint32_t thr1, uint32_t thr2, uint32_t kpack, uint32_t& nbits, uint32_t& meta) {
   nbits = 0;
   meta = 0;
   if (cnt == 0) return;
-  int32_t prev = x3w_sample(rs, 20u * bi), maxabs = 0;
+  int32_t prev = x3w_sample(rs, BL * bi), maxabs = 0;
   for (uint32_t i = 1; i <= cnt; ++i) {
-    const int32_t sv = x3w_sample(rs, 20u * bi + i), d = sv - prev;
+    const int32_t sv = x3w_sample(rs, BL * bi + i), d = sv - prev;
     prev = sv;
     maxabs = max(maxabs, d < 0 ? -d : d);
   }
@@ -211,9 +348,9 @@ __device__ __forceinline__ void x3w_slow_analyse(__amdgpu_buffer_rsrc_t rs, uint
     const uint32_t ft = (maxabs > (int32_t)thr0 ? 1u : 0u) + (maxabs > (int32_t)thr1 ? 1u : 0u);
     const uint32_t k = (kpack >> (8u * ft)) & 0xFFu;
     uint32_t sum = 0;
-    prev = x3w_sample(rs, 20u * bi);
+    prev = x3w_sample(rs, BL * bi);
     for (uint32_t i = 1; i <= cnt; ++i) {
-      const int32_t sv = x3w_sample(rs, 20u * bi + i), d = sv - prev;
+      const int32_t sv = x3w_sample(rs, BL * bi + i), d = sv - prev;
       prev = sv;
       const uint32_t u = d >= 0 ? 2u * (uint32_t)d : 2u * (uint32_t)(-d) - 1u;
       sum += u >> k;
@@ -232,7 +369,6 @@ __device__ __forceinline__ void x3w_slow_analyse(__amdgpu_buffer_rsrc_t rs, uint
   }
 }
 struct X3WEmit;
-__device__ __forceinline__ void x3w_slow_emit(__amdgpu_buffer_rsrc_t rs, uint32_t bi, uint32_t cnt, uint32_t meta, X3WEmit& e);
 
 struct X3WEmit {
   uint64_t acc;    // low (q + 32) bits are waiting for their word
@@ -261,13 +397,15 @@ struct X3WEmit {
 
 // ---- emission of block Q (encode_rice_block / encode_bfp_block / encode_literal, encoder.rs:233-285): the image
 // holds the stream's bytes as big-endian dword VALUES (bit 31 of a word = the first bit of the stream in it).
-template <int Q>
+// CONT (block length 40): this run continues the block of the run in front of it -- no header
+// J0, J1 (block length 10): the pairs of the run that belong to this block
+template <int Q, bool CONT = false, int J0 = 0, int J1 = 10>
 __device__ __forceinline__ void x3w_emit(const uint32_t (&W)[41], uint32_t meta, uint32_t cnt, X3WEmit& e) {
   constexpr int B = 10 * Q;
   if (meta) {
     const uint32_t lbase = (meta >> 6) & 31u, rice = (meta >> 11) & 1u;
     const uint32_t kq = lbase - rice;
-    e.put(meta & 63u, rice ? 2u : 6u);
+    if (!CONT) e.put(meta & 63u, rice ? 2u : 6u);
     // (code, len) of a sample v: ((v & amask) | orc, (v >> kq) * rice + lbase) -- both samples of a pair at once in
     // packed 16-bit arithmetic, the halves combined with SDWA operand selects (x3_encode_common.h)
     const uint32_t qsh2 = kq * 0x10001u, lbase2 = lbase * 0x10001u, qmul2 = rice * 0x10001u;
@@ -276,7 +414,7 @@ __device__ __forceinline__ void x3w_emit(const uint32_t (&W)[41], uint32_t meta,
     uint64_t acc = e.acc;
     uint32_t q = e.q, waddr = e.waddr;
 #pragma unroll
-    for (int j = 0; j < 10; ++j) {
+    for (int j = J0; j < J1; ++j) {
       uint32_t Lp = x3_pk_mad_u16(x3_pk_lshr_b16(W[B + j], qsh2), qmul2, lbase2);  // (la, lc)
       uint32_t Cp = x3_and_or(W[B + j], amask2, orc2);                              // (ca, cc)
       if (j == 9) { Lp &= last_on; Cp &= last_on; }
@@ -297,13 +435,14 @@ __device__ __forceinline__ void x3w_emit(const uint32_t (&W)[41], uint32_t meta,
   }
 }
 
+template <uint32_t BL = 20u>
 __device__ __forceinline__ void x3w_slow_emit(__amdgpu_buffer_rsrc_t rs, uint32_t bi, uint32_t cnt, uint32_t meta, X3WEmit& e) {
   if (meta == 0) return;
   const uint32_t lbase = (meta >> 6) & 31u, rice = (meta >> 11) & 1u;
   e.put(meta & 63u, rice ? 2u : 6u);
-  int32_t prev = x3w_sample(rs, 20u * bi);
+  int32_t prev = x3w_sample(rs, BL * bi);
   for (uint32_t i = 1; i <= cnt; ++i) {
-    const int32_t sv = x3w_sample(rs, 20u * bi + i), d = sv - prev;
+    const int32_t sv = x3w_sample(rs, BL * bi + i), d = sv - prev;
     prev = sv;
     if (rice) {
       const uint32_t k = lbase - 1u;
@@ -325,8 +464,11 @@ __device__ __forceinline__ uint32_t x3w_cnt_of(int32_t rem, int q) {
 // TAB: the frames come from a table (x3_encode_frames_dev) instead of the uniform clip layout.  A template parameter, not a
 // test of a.src_off: with the test in it the kernel of the uniform layout ran 48 % slower (0.64 ms against 0.43) -- it sits
 // at 128 VGPRs, and hipcc's schedule does not survive the extra live values.
-template <bool TAB>
+// BL (round 6): 20, or 40 -- a block is then two of a lane's four runs per half (x3w_analyse40); the BL = 20 instantiation
+// is the code of rounds 3-5 (`if constexpr`).
+template <bool TAB, uint32_t BL = 20u>
 __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs a) {
+  static_assert(BL == 10u || BL == 20u || BL == 40u, "block lengths 10, 20 and 40");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t* const tab = reinterpret_cast<uint16_t*>(smem);
   uint32_t* const book = reinterpret_cast<uint32_t*>(smem + X3W_TAB_BYTES);
@@ -694,18 +836,62 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
           // the LDS -- 4 % of the kernel's time with one copy)
           if (mt) atomicAdd(&book[192u + 8u * (lane & 7u) + ((mt >> 12) & 7u)], cnt);
         };
-        if (plain) {
-          x3w_analyse<0>(X0, x3w_cnt_of(rem0, 0), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 0u, t, m0); nb0 += t;
-          x3w_analyse<1>(X0, x3w_cnt_of(rem0, 1), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 0u, t, m1); nb0 += t;
-          x3w_analyse<2>(X0, x3w_cnt_of(rem0, 2), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 0u, t, m2); nb0 += t;
-          x3w_analyse<3>(X0, x3w_cnt_of(rem0, 3), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 0u, t, m3); nb0 += t;
+        // (blocks of 10, generic path: eight blocks of a lane's half one by one, their metas in the 8-bit form)
+        auto slow10 = [&](uint32_t bi0, int32_t rem, uint32_t& nbh, uint32_t& ma, uint32_t& mb, uint32_t& mc, uint32_t& md)
+                          __attribute__((always_inline)) {
+          uint32_t mm[4] = {0, 0, 0, 0};
+          for (uint32_t i = 0; i < 8u; ++i) {
+            const int32_t c = rem - 10 * (int32_t)i;
+            const uint32_t cu = c <= 0 ? 0u : (c < 10 ? (uint32_t)c : 10u);
+            uint32_t tt, m15;
+            x3w_slow_analyse<10u>(rs_cur, bi0 + i, cu, a.thr0, a.thr1, a.thr2, a.kpack, tt, m15);
+            nbh += tt;
+            stat(m15, cu);
+            mm[i >> 1] |= x3w_meta8(m15) << (8u * (i & 1u));
+          }
+          ma = mm[0]; mb = mm[1]; mc = mm[2]; md = mm[3];
+        };
+        auto stat10 = [&](uint32_t m, uint32_t cnt) __attribute__((always_inline)) {   // a run's two blocks
+          stat(x3w_meta_of(m & 0xFFu, a.kpack), 10u);
+          stat(x3w_meta_of(m >> 8, a.kpack), cnt - 10u);
+        };
+        if constexpr (BL == 10u) {
+          if (plain) {
+            x3w_analyse10<0>(X0, x3w_cnt_of(rem0, 0), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 0u, t, m0); nb0 += t;
+            x3w_analyse10<1>(X0, x3w_cnt_of(rem0, 1), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 0u, t, m1); nb0 += t;
+            x3w_analyse10<2>(X0, x3w_cnt_of(rem0, 2), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 0u, t, m2); nb0 += t;
+            x3w_analyse10<3>(X0, x3w_cnt_of(rem0, 3), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 0u, t, m3); nb0 += t;
+            stat10(m0, x3w_cnt_of(rem0, 0)); stat10(m1, x3w_cnt_of(rem0, 1)); stat10(m2, x3w_cnt_of(rem0, 2)); stat10(m3, x3w_cnt_of(rem0, 3));
+          } else {
+            slow10(8u * lane, rem0, nb0, m0, m1, m2, m3);
+          }
+        } else if constexpr (BL == 40u) {
+          // (blocks of 40: runs 0+1 and 2+3; the generic path takes a whole block at the first run's meta)
+          const uint32_t c0 = x3w_cnt_of(rem0, 0), c1 = x3w_cnt_of(rem0, 1), c2 = x3w_cnt_of(rem0, 2), c3 = x3w_cnt_of(rem0, 3);
+          if (plain) {
+            x3w_analyse40<0>(X0, c0, c1, a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 0u, t, m0, m1); nb0 += t;
+            x3w_analyse40<1>(X0, c2, c3, a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 0u, t, m2, m3); nb0 += t;
+            stat(m0, c0 + c1); stat(m2, c2 + c3);
+          } else {
+            x3w_slow_analyse<40u>(rs_cur, 2u * lane + 0u, c0 + c1, a.thr0, a.thr1, a.thr2, a.kpack, t, m0); nb0 += t;
+            x3w_slow_analyse<40u>(rs_cur, 2u * lane + 1u, c2 + c3, a.thr0, a.thr1, a.thr2, a.kpack, t, m2); nb0 += t;
+            m1 = m3 = 0;
+            stat(m0, c0 + c1); stat(m2, c2 + c3);
+          }
         } else {
-          x3w_slow_analyse(rs_cur, 4u * lane + 0u, x3w_cnt_of(rem0, 0), a.thr0, a.thr1, a.thr2, a.kpack, t, m0); nb0 += t;
-          x3w_slow_analyse(rs_cur, 4u * lane + 1u, x3w_cnt_of(rem0, 1), a.thr0, a.thr1, a.thr2, a.kpack, t, m1); nb0 += t;
-          x3w_slow_analyse(rs_cur, 4u * lane + 2u, x3w_cnt_of(rem0, 2), a.thr0, a.thr1, a.thr2, a.kpack, t, m2); nb0 += t;
-          x3w_slow_analyse(rs_cur, 4u * lane + 3u, x3w_cnt_of(rem0, 3), a.thr0, a.thr1, a.thr2, a.kpack, t, m3); nb0 += t;
+          if (plain) {
+            x3w_analyse<0>(X0, x3w_cnt_of(rem0, 0), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 0u, t, m0); nb0 += t;
+            x3w_analyse<1>(X0, x3w_cnt_of(rem0, 1), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 0u, t, m1); nb0 += t;
+            x3w_analyse<2>(X0, x3w_cnt_of(rem0, 2), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 0u, t, m2); nb0 += t;
+            x3w_analyse<3>(X0, x3w_cnt_of(rem0, 3), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 0u, t, m3); nb0 += t;
+          } else {
+            x3w_slow_analyse(rs_cur, 4u * lane + 0u, x3w_cnt_of(rem0, 0), a.thr0, a.thr1, a.thr2, a.kpack, t, m0); nb0 += t;
+            x3w_slow_analyse(rs_cur, 4u * lane + 1u, x3w_cnt_of(rem0, 1), a.thr0, a.thr1, a.thr2, a.kpack, t, m1); nb0 += t;
+            x3w_slow_analyse(rs_cur, 4u * lane + 2u, x3w_cnt_of(rem0, 2), a.thr0, a.thr1, a.thr2, a.kpack, t, m2); nb0 += t;
+            x3w_slow_analyse(rs_cur, 4u * lane + 3u, x3w_cnt_of(rem0, 3), a.thr0, a.thr1, a.thr2, a.kpack, t, m3); nb0 += t;
+          }
+          stat(m0, x3w_cnt_of(rem0, 0)); stat(m1, x3w_cnt_of(rem0, 1)); stat(m2, x3w_cnt_of(rem0, 2)); stat(m3, x3w_cnt_of(rem0, 3));
         }
-        stat(m0, x3w_cnt_of(rem0, 0)); stat(m1, x3w_cnt_of(rem0, 1)); stat(m2, x3w_cnt_of(rem0, 2)); stat(m3, x3w_cnt_of(rem0, 3));
         mA = m0 | (m1 << 16);
         mB = m2 | (m3 << 16);
         mC = 0;
@@ -714,18 +900,41 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
           // (a frame of at most 5 121 samples has nothing in its second half: no analysis, no emission, no loads for it --
           // 256 blocks a frame 0.58 -> 0.48 ms, 100 blocks 1.34 -> 1.06; config 3 the same)
         } else {
-        if (plain) {
-          x3w_analyse<0>(X1, x3w_cnt_of(rem1, 0), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 2u * X3W_PART, t, m0); nb1 += t;
-          x3w_analyse<1>(X1, x3w_cnt_of(rem1, 1), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 2u * X3W_PART, t, m1); nb1 += t;
-          x3w_analyse<2>(X1, x3w_cnt_of(rem1, 2), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 2u * X3W_PART, t, m2); nb1 += t;
-          x3w_analyse<3>(X1, x3w_cnt_of(rem1, 3), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 2u * X3W_PART, t, m3); nb1 += t;
+        if constexpr (BL == 10u) {
+          if (plain) {
+            x3w_analyse10<0>(X1, x3w_cnt_of(rem1, 0), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 2u * X3W_PART, t, m0); nb1 += t;
+            x3w_analyse10<1>(X1, x3w_cnt_of(rem1, 1), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 2u * X3W_PART, t, m1); nb1 += t;
+            x3w_analyse10<2>(X1, x3w_cnt_of(rem1, 2), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 2u * X3W_PART, t, m2); nb1 += t;
+            x3w_analyse10<3>(X1, x3w_cnt_of(rem1, 3), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 2u * X3W_PART, t, m3); nb1 += t;
+            stat10(m0, x3w_cnt_of(rem1, 0)); stat10(m1, x3w_cnt_of(rem1, 1)); stat10(m2, x3w_cnt_of(rem1, 2)); stat10(m3, x3w_cnt_of(rem1, 3));
+          } else {
+            slow10(512u + 8u * lane, rem1, nb1, m0, m1, m2, m3);
+          }
+        } else if constexpr (BL == 40u) {
+          const uint32_t c0 = x3w_cnt_of(rem1, 0), c1 = x3w_cnt_of(rem1, 1), c2 = x3w_cnt_of(rem1, 2), c3 = x3w_cnt_of(rem1, 3);
+          if (plain) {
+            x3w_analyse40<0>(X1, c0, c1, a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 2u * X3W_PART, t, m0, m1); nb1 += t;
+            x3w_analyse40<1>(X1, c2, c3, a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 2u * X3W_PART, t, m2, m3); nb1 += t;
+          } else {
+            x3w_slow_analyse<40u>(rs_cur, 128u + 2u * lane + 0u, c0 + c1, a.thr0, a.thr1, a.thr2, a.kpack, t, m0); nb1 += t;
+            x3w_slow_analyse<40u>(rs_cur, 128u + 2u * lane + 1u, c2 + c3, a.thr0, a.thr1, a.thr2, a.kpack, t, m2); nb1 += t;
+            m1 = m3 = 0;
+          }
+          stat(m0, c0 + c1); stat(m2, c2 + c3);
         } else {
-          x3w_slow_analyse(rs_cur, 256u + 4u * lane + 0u, x3w_cnt_of(rem1, 0), a.thr0, a.thr1, a.thr2, a.kpack, t, m0); nb1 += t;
-          x3w_slow_analyse(rs_cur, 256u + 4u * lane + 1u, x3w_cnt_of(rem1, 1), a.thr0, a.thr1, a.thr2, a.kpack, t, m1); nb1 += t;
-          x3w_slow_analyse(rs_cur, 256u + 4u * lane + 2u, x3w_cnt_of(rem1, 2), a.thr0, a.thr1, a.thr2, a.kpack, t, m2); nb1 += t;
-          x3w_slow_analyse(rs_cur, 256u + 4u * lane + 3u, x3w_cnt_of(rem1, 3), a.thr0, a.thr1, a.thr2, a.kpack, t, m3); nb1 += t;
+          if (plain) {
+            x3w_analyse<0>(X1, x3w_cnt_of(rem1, 0), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 2u * X3W_PART, t, m0); nb1 += t;
+            x3w_analyse<1>(X1, x3w_cnt_of(rem1, 1), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 2u * X3W_PART, t, m1); nb1 += t;
+            x3w_analyse<2>(X1, x3w_cnt_of(rem1, 2), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 2u * X3W_PART, t, m2); nb1 += t;
+            x3w_analyse<3>(X1, x3w_cnt_of(rem1, 3), a.thr0, a.thr1, a.thr2, a.kpack, rs_cur, vo_cur, 2u * X3W_PART, t, m3); nb1 += t;
+          } else {
+            x3w_slow_analyse(rs_cur, 256u + 4u * lane + 0u, x3w_cnt_of(rem1, 0), a.thr0, a.thr1, a.thr2, a.kpack, t, m0); nb1 += t;
+            x3w_slow_analyse(rs_cur, 256u + 4u * lane + 1u, x3w_cnt_of(rem1, 1), a.thr0, a.thr1, a.thr2, a.kpack, t, m1); nb1 += t;
+            x3w_slow_analyse(rs_cur, 256u + 4u * lane + 2u, x3w_cnt_of(rem1, 2), a.thr0, a.thr1, a.thr2, a.kpack, t, m2); nb1 += t;
+            x3w_slow_analyse(rs_cur, 256u + 4u * lane + 3u, x3w_cnt_of(rem1, 3), a.thr0, a.thr1, a.thr2, a.kpack, t, m3); nb1 += t;
+          }
+          stat(m0, x3w_cnt_of(rem1, 0)); stat(m1, x3w_cnt_of(rem1, 1)); stat(m2, x3w_cnt_of(rem1, 2)); stat(m3, x3w_cnt_of(rem1, 3));
         }
-        stat(m0, x3w_cnt_of(rem1, 0)); stat(m1, x3w_cnt_of(rem1, 1)); stat(m2, x3w_cnt_of(rem1, 2)); stat(m3, x3w_cnt_of(rem1, 3));
         mC = m0 | (m1 << 16);
         mD = m2 | (m3 << 16);
         }
@@ -825,20 +1034,60 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
         rem0e = (int32_t)n - 1 - 80 * (int32_t)lane_e;
         rem1e = rem0e - (int32_t)X3W_PART;
       }
+      // (blocks of 10: a run's two blocks from its two 8-bit metas)
+      auto emit10 = [&](const uint32_t (&X)[41], uint32_t mlo, uint32_t mhi, int32_t rem, X3WEmit& e) __attribute__((always_inline)) {
+        x3w_emit<0, false, 0, 5>(X, x3w_meta_of(mlo & 0xFFu, a.kpack), x3w_cnt_of(rem, 0), e);
+        x3w_emit<0, false, 5, 10>(X, x3w_meta_of((mlo >> 8) & 0xFFu, a.kpack), x3w_cnt_of(rem, 0), e);
+        x3w_emit<1, false, 0, 5>(X, x3w_meta_of((mlo >> 16) & 0xFFu, a.kpack), x3w_cnt_of(rem, 1), e);
+        x3w_emit<1, false, 5, 10>(X, x3w_meta_of(mlo >> 24, a.kpack), x3w_cnt_of(rem, 1), e);
+        x3w_emit<2, false, 0, 5>(X, x3w_meta_of(mhi & 0xFFu, a.kpack), x3w_cnt_of(rem, 2), e);
+        x3w_emit<2, false, 5, 10>(X, x3w_meta_of((mhi >> 8) & 0xFFu, a.kpack), x3w_cnt_of(rem, 2), e);
+        x3w_emit<3, false, 0, 5>(X, x3w_meta_of((mhi >> 16) & 0xFFu, a.kpack), x3w_cnt_of(rem, 3), e);
+        x3w_emit<3, false, 5, 10>(X, x3w_meta_of(mhi >> 24, a.kpack), x3w_cnt_of(rem, 3), e);
+      };
+      auto emit10_slow = [&](__amdgpu_buffer_rsrc_t rs_, uint32_t bi0, uint32_t mlo, uint32_t mhi, int32_t rem, X3WEmit& e)
+                             __attribute__((always_inline)) {
+        for (uint32_t i = 0; i < 8u; ++i) {
+          const int32_t c = rem - 10 * (int32_t)i;
+          const uint32_t cu = c <= 0 ? 0u : (c < 10 ? (uint32_t)c : 10u);
+          const uint32_t m8 = ((i < 4u ? mlo : mhi) >> (8u * (i & 3u))) & 0xFFu;
+          x3w_slow_emit<10u>(rs_, bi0 + i, cu, x3w_meta_of(m8, a.kpack), e);
+        }
+      };
       if (!ovf) {
         X3WEmit e;
         e.start(lane ? 16u + excl0 : 0u, img_addr);
         if (lane == 0) e.put(*reinterpret_cast<const uint32_t*>(src) & 0xFFFFu, 16u);  // the frame's first sample (frames are 16-byte aligned)
-        if (plain) {
-          x3w_emit<0>(X0, mA & 0xFFFFu, x3w_cnt_of(rem0e, 0), e); x3w_emit<1>(X0, mA >> 16, x3w_cnt_of(rem0e, 1), e);
-          x3w_emit<2>(X0, mB & 0xFFFFu, x3w_cnt_of(rem0e, 2), e); x3w_emit<3>(X0, mB >> 16, x3w_cnt_of(rem0e, 3), e);
+        if constexpr (BL == 10u) {
+          if (plain) {
+            emit10(X0, mA, mB, rem0e, e);
+          } else {
+            const __amdgpu_buffer_rsrc_t rs_cur =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(src), 0, (int)((2u * n + 3u) & ~3u), 0x00020000);
+            emit10_slow(rs_cur, 8u * lane, mA, mB, rem0e, e);
+          }
+        } else if constexpr (BL == 40u) {
+          if (plain) {
+            x3w_emit<0>(X0, mA & 0xFFFFu, x3w_cnt_of(rem0e, 0), e); x3w_emit<1, true>(X0, mA >> 16, x3w_cnt_of(rem0e, 1), e);
+            x3w_emit<2>(X0, mB & 0xFFFFu, x3w_cnt_of(rem0e, 2), e); x3w_emit<3, true>(X0, mB >> 16, x3w_cnt_of(rem0e, 3), e);
+          } else {
+            const __amdgpu_buffer_rsrc_t rs_cur =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(src), 0, (int)((2u * n + 3u) & ~3u), 0x00020000);
+            x3w_slow_emit<40u>(rs_cur, 2u * lane + 0u, x3w_cnt_of(rem0e, 0) + x3w_cnt_of(rem0e, 1), mA & 0xFFFFu, e);
+            x3w_slow_emit<40u>(rs_cur, 2u * lane + 1u, x3w_cnt_of(rem0e, 2) + x3w_cnt_of(rem0e, 3), mB & 0xFFFFu, e);
+          }
         } else {
-          const __amdgpu_buffer_rsrc_t rs_cur =
-              __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(src), 0, (int)((2u * n + 3u) & ~3u), 0x00020000);
-          x3w_slow_emit(rs_cur, 4u * lane + 0u, x3w_cnt_of(rem0e, 0), mA & 0xFFFFu, e);
-          x3w_slow_emit(rs_cur, 4u * lane + 1u, x3w_cnt_of(rem0e, 1), mA >> 16, e);
-          x3w_slow_emit(rs_cur, 4u * lane + 2u, x3w_cnt_of(rem0e, 2), mB & 0xFFFFu, e);
-          x3w_slow_emit(rs_cur, 4u * lane + 3u, x3w_cnt_of(rem0e, 3), mB >> 16, e);
+          if (plain) {
+            x3w_emit<0>(X0, mA & 0xFFFFu, x3w_cnt_of(rem0e, 0), e); x3w_emit<1>(X0, mA >> 16, x3w_cnt_of(rem0e, 1), e);
+            x3w_emit<2>(X0, mB & 0xFFFFu, x3w_cnt_of(rem0e, 2), e); x3w_emit<3>(X0, mB >> 16, x3w_cnt_of(rem0e, 3), e);
+          } else {
+            const __amdgpu_buffer_rsrc_t rs_cur =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(src), 0, (int)((2u * n + 3u) & ~3u), 0x00020000);
+            x3w_slow_emit(rs_cur, 4u * lane + 0u, x3w_cnt_of(rem0e, 0), mA & 0xFFFFu, e);
+            x3w_slow_emit(rs_cur, 4u * lane + 1u, x3w_cnt_of(rem0e, 1), mA >> 16, e);
+            x3w_slow_emit(rs_cur, 4u * lane + 2u, x3w_cnt_of(rem0e, 2), mB & 0xFFFFu, e);
+            x3w_slow_emit(rs_cur, 4u * lane + 3u, x3w_cnt_of(rem0e, 3), mB >> 16, e);
+          }
         }
         if ((mA | mB) || lane == 0) e.finish();
       }
@@ -846,16 +1095,36 @@ __global__ void __launch_bounds__(X3W_THREADS) x3_encode_wave_kernel(X3WaveArgs 
       if (!ovf && !(X3W_SKIP_EMPTY_HALF && n <= X3W_PART + 1u)) {
         X3WEmit e;
         e.start(16u + tot0 + excl1, img_addr);
-        if (plain) {
-          x3w_emit<0>(X1, mC & 0xFFFFu, x3w_cnt_of(rem1e, 0), e); x3w_emit<1>(X1, mC >> 16, x3w_cnt_of(rem1e, 1), e);
-          x3w_emit<2>(X1, mD & 0xFFFFu, x3w_cnt_of(rem1e, 2), e); x3w_emit<3>(X1, mD >> 16, x3w_cnt_of(rem1e, 3), e);
+        if constexpr (BL == 10u) {
+          if (plain) {
+            emit10(X1, mC, mD, rem1e, e);
+          } else {
+            const __amdgpu_buffer_rsrc_t rs_cur =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(src), 0, (int)((2u * n + 3u) & ~3u), 0x00020000);
+            emit10_slow(rs_cur, 512u + 8u * lane, mC, mD, rem1e, e);
+          }
+        } else if constexpr (BL == 40u) {
+          if (plain) {
+            x3w_emit<0>(X1, mC & 0xFFFFu, x3w_cnt_of(rem1e, 0), e); x3w_emit<1, true>(X1, mC >> 16, x3w_cnt_of(rem1e, 1), e);
+            x3w_emit<2>(X1, mD & 0xFFFFu, x3w_cnt_of(rem1e, 2), e); x3w_emit<3, true>(X1, mD >> 16, x3w_cnt_of(rem1e, 3), e);
+          } else {
+            const __amdgpu_buffer_rsrc_t rs_cur =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(src), 0, (int)((2u * n + 3u) & ~3u), 0x00020000);
+            x3w_slow_emit<40u>(rs_cur, 128u + 2u * lane + 0u, x3w_cnt_of(rem1e, 0) + x3w_cnt_of(rem1e, 1), mC & 0xFFFFu, e);
+            x3w_slow_emit<40u>(rs_cur, 128u + 2u * lane + 1u, x3w_cnt_of(rem1e, 2) + x3w_cnt_of(rem1e, 3), mD & 0xFFFFu, e);
+          }
         } else {
-          const __amdgpu_buffer_rsrc_t rs_cur =
-              __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(src), 0, (int)((2u * n + 3u) & ~3u), 0x00020000);
-          x3w_slow_emit(rs_cur, 256u + 4u * lane + 0u, x3w_cnt_of(rem1e, 0), mC & 0xFFFFu, e);
-          x3w_slow_emit(rs_cur, 256u + 4u * lane + 1u, x3w_cnt_of(rem1e, 1), mC >> 16, e);
-          x3w_slow_emit(rs_cur, 256u + 4u * lane + 2u, x3w_cnt_of(rem1e, 2), mD & 0xFFFFu, e);
-          x3w_slow_emit(rs_cur, 256u + 4u * lane + 3u, x3w_cnt_of(rem1e, 3), mD >> 16, e);
+          if (plain) {
+            x3w_emit<0>(X1, mC & 0xFFFFu, x3w_cnt_of(rem1e, 0), e); x3w_emit<1>(X1, mC >> 16, x3w_cnt_of(rem1e, 1), e);
+            x3w_emit<2>(X1, mD & 0xFFFFu, x3w_cnt_of(rem1e, 2), e); x3w_emit<3>(X1, mD >> 16, x3w_cnt_of(rem1e, 3), e);
+          } else {
+            const __amdgpu_buffer_rsrc_t rs_cur =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(src), 0, (int)((2u * n + 3u) & ~3u), 0x00020000);
+            x3w_slow_emit(rs_cur, 256u + 4u * lane + 0u, x3w_cnt_of(rem1e, 0), mC & 0xFFFFu, e);
+            x3w_slow_emit(rs_cur, 256u + 4u * lane + 1u, x3w_cnt_of(rem1e, 1), mC >> 16, e);
+            x3w_slow_emit(rs_cur, 256u + 4u * lane + 2u, x3w_cnt_of(rem1e, 2), mD & 0xFFFFu, e);
+            x3w_slow_emit(rs_cur, 256u + 4u * lane + 3u, x3w_cnt_of(rem1e, 3), mD >> 16, e);
+          }
         }
         if (mC | mD) e.finish();
       }

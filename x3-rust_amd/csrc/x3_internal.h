@@ -151,7 +151,8 @@ struct x3_ctx {
   int n_cus = 0;
   bool force_single_wave_decode = false;
   uint32_t desc_epoch = 0;    // tag of the current launch's frame-size descriptors (single-pass encoders)
-  int stream_wg_per_cu = -1;  // co-resident workgroups per CU of x3_encode_stream_kernel (-1 = not queried)
+  int stream_wg_per_cu = -1;  // co-resident workgroups per CU of x3_encode_stream2_kernel (-1 = not queried)
+  uint64_t stream_wg_key = 0; // ... of which instantiation with how much LDS (block length, table form, bytes)
   // bookkeeping of the last async calls
   bool encode_pending = false, decode_pending = false;
   bool force_two_pass = false;
