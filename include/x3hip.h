@@ -400,8 +400,8 @@ typedef struct x3_batch {
  * general kernel in one pass (any block length: sizes by decoupled look-back), 0 the same kernel in two passes (option
  * "two_pass", or what a launch falls back to whose waits gave up) -- (a call with more than a quarter of dense
  * frames makes the context's next call start on the second-generation kernel: a speed hint, the bytes are the same).
- *   Layout: the results never depend on it, the kernels that serve a call do.  block_len 20 with up to 512 blocks a frame,
- * d_wav on a dword boundary and (for n_clips > 1) a clip_stride that is a multiple of four samples take the single-pass
+ *   Layout: the results never depend on it, the kernels that serve a call do.  block_len 20, 10 or 40 with frames of at most
+ * 10 240 samples (512 blocks of 20), d_wav on a dword boundary and (for n_clips > 1) a clip_stride that is a multiple of four samples take the single-pass
  * encoders; x3_decode_dev takes the three-wave decoder when its output begins on an 8-byte boundary and the stride is a
  * multiple of four samples (rows on 16-byte boundaries leave in 16-byte pieces, on 8-byte ones in 8-byte pieces, always
  * as whole 128-byte lines).  Anything else -- other block lengths or code sets, longer frames, odd strides -- is served by
