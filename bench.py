@@ -157,6 +157,9 @@ def compact_line(res):
         g = res["gather"]
         c["gather"] = {k: g[k] for k in ("mode", "ms", "in_timed_region", "value_without_gather") if k in g}
         c["rccl"] = res.get("rccl")
+    if res.get("placement"):
+        pl = res["placement"]
+        c["placement"] = {"candidates_per_buffer": pl["candidates_per_buffer"], "step_ms": pl["step_ms"]}
     c["details"] = "bench_details.json beside this run (--details): notes, per-step arrays, layouts, host-buffer and per-frame APIs"
     # never longer than the tail the driver keeps: drop the least important keys first
     for k in ("extremes_ms_per_step", "kernels_ms_p90_over_min", "configs", "decoder_kernels", "cold_ms_per_step"):
@@ -201,6 +204,9 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=500.0,
                     help="upper bound of the time-based settle in front of the warm-up: steps are run until the shader clock "
                          "the kernels log has stayed within 2.5 %% of its running maximum for 8 launches (0: no settle)")
+    ap.add_argument("--place", type=int, default=6,
+                    help="candidates per buffer for the placement probe (x3hip.place_buffers: the pair of stream / sample buffers "
+                         "the round trip runs best on is kept; 1 = take the first allocation as it comes)")
     ap.add_argument("--no-configs", action="store_true", help="skip the timing of BASELINE configs 2 and 5 (`configs` in the line)")
     ap.add_argument("--spawn", action="store_true",
                     help="start the ranks as a child process (torch.distributed.run) even for --gpus 1; --gpus N > 1 without "
@@ -263,6 +269,30 @@ def main():
     back = torch.empty(n, dtype=torch.int16, device=dev)
     ctx.synth_dev(args.kind, SEED, first_sample, n, wav.data_ptr())
     torch.cuda.synchronize(dev)
+
+    # ---- placement (round 6): where the stream and the decoded samples lie in HBM decides the decode
+    # phase's pace by up to 10 % -- per pair of buffers, reproducibly within a process (profiles/r6/decoder_modes.txt).  As a
+    # pipeline that keeps its buffers would: a few candidates, a short probe of every pair, the best pair stays.
+    placement = None
+    if args.place > 1:
+        cand_out, cand_back, pads = [out], [back], []
+        for k in range(args.place - 1):
+            # (odd-sized allocations between the candidates: so that they do not all lie alike)
+            pads.append(torch.empty((k + 1) * 1237 * 1024, dtype=torch.uint8, device=dev))
+            cand_out.append(torch.empty(cap + 16, dtype=torch.uint8, device=dev))
+            cand_back.append(torch.empty(n, dtype=torch.int16, device=dev))
+        ms = x3hip.place_buffers(ctx, p, wav.data_ptr(), n, [t.data_ptr() for t in cand_out], cap, off.data_ptr(),
+                                 [t.data_ptr() for t in cand_back])
+        flat = [(ms[i][j], i, j) for i in range(args.place) for j in range(args.place)]
+        best = min(flat)
+        placement = {"candidates_per_buffer": args.place, "probe": "4 untimed + 8 timed round trips per pair, host wall time",
+                     "step_ms": {"first_allocation": round(ms[0][0], 4), "best": round(best[0], 4), "worst": round(max(flat)[0], 4)},
+                     "kept": {"stream": best[1], "samples": best[2]},
+                     "ms_per_step": [[round(v, 4) for v in row] for row in ms],
+                     "stream_buffers": ["%x" % t.data_ptr() for t in cand_out], "sample_buffers": ["%x" % t.data_ptr() for t in cand_back]}
+        out, back = cand_out[best[1]], cand_back[best[2]]
+        del cand_out, cand_back, pads
+        torch.cuda.empty_cache()
 
     # ---- the group of ranks: librccl through the library's own C ABI (x3_shard_*)
     rccl = None
@@ -1173,6 +1203,8 @@ def main():
             res["gather_modes"] = gather_modes
             res["rccl_ranks"] = world
             res["rccl"] = rccl
+        if placement is not None:
+            res["placement"] = placement
         # ONE line on stdout, as the contract says, and short (<= 4 KB, so that the tail of the driver's
         # record holds every number it judges by: kernels_ms, encode_read_frac, roofline_all, the clocks, the CPU baseline,
         # configs 2 and 5); everything else -- notes, per-step arrays, the wider measurements -- goes to a FILE beside it

@@ -20,6 +20,10 @@ ap.add_argument("--shift", type=int, default=0, help="the samples begin this man
 ap.add_argument("--bpf", type=int, default=500, help="blocks per frame")
 ap.add_argument("--bl", type=int, default=20, help="block length (samples)")
 ap.add_argument("--opt", action="append", default=[], help="context option name=value (x3_ctx_set_option), repeatable")
+ap.add_argument("--order", default="wofb", help="the order the buffers are allocated in: w(av) o(ut) f(rame offsets) b(ack)")
+ap.add_argument("--out-shift", type=int, default=0, help="the stream begins this many bytes into its allocation")
+ap.add_argument("--back-shift", type=int, default=0, help="the decoded samples begin this many bytes into their allocation")
+ap.add_argument("--decode-only", action="store_true", help="the timed steps decode only (the stream of the first encode)")
 ap.add_argument("--seg", type=int, default=0, help="decode by a segment index of SEG blocks per stretch (recorded by the first decode)")
 a = ap.parse_args()
 ctx = x3hip.Context(0)
@@ -34,7 +38,11 @@ stride = a.stride or npc
 n = npc * a.clips
 F = L.x3_num_frames(npc, C.byref(p)) * a.clips; cap = L.x3_encode_bound(npc, C.byref(p)) * a.clips
 def run_once(tag):
-    d_wav = ctx.alloc(2 * stride * a.clips + 64) + a.shift; d_out = ctx.alloc(cap + 16); d_off = ctx.alloc(8 * (F + 1)); d_back = ctx.alloc(2 * stride * a.clips)
+    bufs = {}
+    for ch in a.order:
+        bufs[ch] = {"w": lambda: ctx.alloc(2 * stride * a.clips + 64) + a.shift, "o": lambda: ctx.alloc(cap + 16 + a.out_shift) + a.out_shift,
+                    "f": lambda: ctx.alloc(8 * (F + 1)), "b": lambda: ctx.alloc(2 * stride * a.clips + a.back_shift) + a.back_shift}[ch]()
+    d_wav, d_out, d_off, d_back = bufs["w"], bufs["o"], bufs["f"], bufs["b"]
     ctx.synth_dev(a.kind, 0x58330003, 0, stride * a.clips, d_wav)
     if a.loud > 0:   # every k-th frame loud
         k = max(1, int(round(1.0 / a.loud)))
@@ -44,7 +52,9 @@ def run_once(tag):
     d_seg = ctx.alloc(8 * L.x3_seg_index_entries(F, C.byref(p), a.seg) + 8) if a.seg else None
     enc_seg = a.seg >= 4 and (a.seg & (a.seg - 1)) == 0   # (the encoder's index: a power of two; else the one the first decode records)
     def step():
-        if enc_seg:
+        if a.decode_only:
+            pass
+        elif enc_seg:
             assert ctx.encode_dev_seg(d_wav, npc, p, d_out, cap, d_seg, a.seg, 0, d_off, n_clips=a.clips, clip_stride=stride) == 0
         else:
             assert ctx.encode_dev(d_wav, npc, p, d_out, cap, 0, d_off, n_clips=a.clips, clip_stride=stride) == 0
@@ -64,7 +74,7 @@ def run_once(tag):
     r = ctx.decode_result(); assert os.environ.get("X3_NOCHECK") or r[:3] == (0, F, 0), r
     ctx.enable_kernel_timing(not os.environ.get('X3_NOTIMING')); ctx.reset_kernel_time()
     for _ in range(a.steps): step()
-    rc, pos2, st2 = ctx.encode_result(); r2 = ctx.decode_result()
+    rc, pos2, st2 = (0, pos, st) if a.decode_only else ctx.encode_result(); r2 = ctx.decode_result()
     if os.environ.get("X3_WALL"):   # the whole step, without the timers' events in the queues
         import time
         ctx.enable_kernel_timing(False)

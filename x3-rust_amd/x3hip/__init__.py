@@ -423,6 +423,47 @@ class MultiGpu:
         return rc, wav[: n.value].copy(), fok.value, ferr.value
 
 
+def place_buffers(ctx, params, d_wav, n, d_streams, cap, d_frame_offsets, d_backs, warm=4, steps=8):
+    """Where in HBM the stream and the decoded samples lie decides the decode phase's pace by up to 10 % -- per PAIR of
+    buffers, reproducibly within a process, and not by anything an address shows (profiles/r6/decoder_modes.txt).  A pipeline
+    that keeps its buffers allocates a few candidates once and keeps the pair that runs best: this times `steps` round trips
+    (x3_encode_dev + x3_decode_dev of the `n` samples at d_wav, after `warm` untimed ones: the decoder's pace controller
+    settles) for every (stream buffer, sample buffer) pair and returns ms_per_step[i][j] -- host wall time, synchronised.
+    The caller frees what it does not keep."""
+    import time
+    F = lib().x3_num_frames(n, C.byref(params))
+    ms = []
+    # (the clocks and the caches of a process that has just started: the first pair would pay for them)
+    for _ in range(6 * warm):
+        if ctx.encode_dev(d_wav, n, params, d_streams[0], cap, 0, d_frame_offsets) or \
+           ctx.decode_dev(d_streams[0], cap, d_frame_offsets, F, params, d_backs[0], n, n_per_clip=n):
+            raise X3Error(X3_ERR_HIP if "X3_ERR_HIP" in globals() else 23, "place_buffers: " + ctx.last_error())
+    ctx.decode_result()
+    for d_out in d_streams:
+        row = []
+        for d_back in d_backs:
+            def once():
+                rc = ctx.encode_dev(d_wav, n, params, d_out, cap, 0, d_frame_offsets)
+                if rc == 0:
+                    rc = ctx.decode_dev(d_out, cap, d_frame_offsets, F, params, d_back, n, n_per_clip=n)
+                if rc:
+                    raise X3Error(rc, "place_buffers: " + ctx.last_error())
+            for _ in range(warm):
+                once()
+            ctx.decode_result()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                once()
+            r = ctx.decode_result()
+            t1 = time.perf_counter()
+            if r[0] != 0 or r[2] != 0:
+                raise X3Error(r[0] or 1, "place_buffers: the probe stream did not decode")
+            row.append((t1 - t0) / steps * 1e3)
+        ms.append(row)
+    ctx.encode_result()
+    return ms
+
+
 def strerror(rc):
     return lib().x3_strerror(rc).decode()
 
