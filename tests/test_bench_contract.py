@@ -62,9 +62,13 @@ def test_bench_small_run_prints_the_contract_line():
     assert last["clocks_mhz"]["decode"] > 500 and last["clocks_mhz"]["encode"] > 500
     assert "step" in last["configs"]["config2"] or "skipped" in last["configs"]["config2"]
     assert last["decoder_kernels"]["three_wave"]["decode_ms"] > 0 and last["decoder_kernels"]["block_per_lane"]["decode_ms"] > 0
+    # the placement probe (round 6): what it saw is in the line, the whole matrix in the details
+    sm = last["placement"]["step_ms"]
+    assert last["placement"]["candidates_per_buffer"] == 6 and 0 < sm["best"] <= sm["first_allocation"] <= sm["worst"]
     j = json.load(open(details))["bench_details"]
     for k in ("metric", "value", "ms_per_step"):
         assert j[k] == last[k], k
+    assert len(j["placement"]["ms_per_step"]) == 6 and all(len(r) == 6 for r in j["placement"]["ms_per_step"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in j, k
@@ -137,12 +141,13 @@ def test_bench_starts_its_own_ranks():
     GPU and relays the child's line and return code; --spawn forces that path for N = 1"""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, BENCH, "--spawn", "--gpus", "1", "--steps", "2", "--warmup", "1", "--samples", "20000000",
-                        "--no-cpu-baseline", "--no-measure-traffic", "--no-extras"],
+                        "--no-cpu-baseline", "--no-measure-traffic", "--no-extras", "--place", "1"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and len(lines[0]) <= 4000     # (the contract line, relayed from the child)
     last = json.loads(lines[0])
+    assert "placement" not in last      # (--place 1: the first allocation as it comes)
     assert last["kernels_ms"]["encode"] > 0 and last["kernels_ms"]["decode"] > 0
     j = last
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["value"] > 0
