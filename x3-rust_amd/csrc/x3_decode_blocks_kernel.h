@@ -402,7 +402,8 @@ x3_decode_blocks_kernel(const uint8_t* __restrict__ x3, uint64_t x3_len, const u
         const uint32_t cnt = b < nbk ? (b + 1u == nbk ? lastcnt : UNIT) : 0u;
         dq[b] = (uint16_t)(rel_c - ((qb << 3) + s));
         X3_STAMP(0);
-        if (!(X3B_KO & 32) && (it % X3B_PERIOD) == 0u) service(ring_index());
+        // (every 40 samples walked, whatever a unit is: units of 10 are served every fourth)
+        if (!(X3B_KO & 32) && (it % (X3B_PERIOD * (20u / UNIT))) == 0u) service(ring_index());
         X3_STAMP(1);
         const uint32_t live = cnt ? 0xFFFFFFFFu : 0u;
         if (UPB == 1u || (b % UPB) == 0u) {   // (batches are whole blocks in every lane: the header's turn is the wave's)
