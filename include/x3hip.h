@@ -468,6 +468,18 @@ int x3_decode_dev_seg(x3_ctx* ctx, const uint8_t* d_x3, uint64_t x3_len, const u
                       uint64_t n_frames, const x3_batch* batch, const uint64_t* d_wav_offsets,
                       const x3_params* p, int16_t* d_wav, uint64_t wav_cap, int32_t* d_status,
                       uint64_t* d_seg_index, uint32_t seg_blocks, int record);
+/* ---- Placement (round 6).  Where the x3 stream and where the decoded samples lie in HBM decides the decode phase's pace by
+ * up to 10 % -- per PAIR of buffers, reproducibly within a process, and by nothing their addresses show
+ * (profiles/r6/decoder_modes.txt).  A pipeline that keeps its buffers allocates a few candidates once and keeps the pair that
+ * runs best; this is the measuring loop: for every pair (d_streams[i], d_backs[j]) `warm` untimed and `steps` timed round
+ * trips -- x3_encode_dev of the n samples at d_wav into d_streams[i] (capacity cap each; d_frame_offsets: x3_num_frames + 1
+ * words), x3_decode_dev of that stream into d_backs[j] (n samples each) -- and ms_per_step[i * n_backs + j] = host wall time
+ * per round trip, synchronised.  The samples at d_wav should be of the kind the pipeline will see (the pace follows the
+ * stream's density).  X3_ERR_* if a round trip fails or its stream does not decode; the caller frees what it does not keep.
+ * (No counterpart in the reference: a property of the device.) */
+int x3_place_buffers(x3_ctx* ctx, const int16_t* d_wav, uint64_t n, const x3_params* p, uint8_t* const* d_streams,
+                     uint32_t n_streams, uint64_t cap, uint64_t* d_frame_offsets, int16_t* const* d_backs, uint32_t n_backs,
+                     uint32_t warm, uint32_t steps, double* ms_per_step);
 /* ---- HIP graphs: a launch-bound sequence of device calls, recorded once and replayed with one host call.
  * A short stream's encode + decode is a dozen launches, memsets and event operations of a few microseconds each around
  * kernels of 40-60 us: the host's share of such a step is a third.  Between x3_graph_begin and x3_graph_end the ASYNCHRONOUS

@@ -1,5 +1,6 @@
 // x3_decode.hip -- decoder, frame-check and index kernels and the x3_decode* / x3_index_dev entry points, the stream walks,
 // the BitReader / BitPacker handles (C ABI: include/x3hip.h; units: x3_internal.h).
+#include <chrono>
 #include "x3_internal.h"
 #include "x3_decode_kernel.h"
 #include "x3_decode_split_kernel.h"
@@ -966,3 +967,39 @@ extern "C" int x3_dbg_read(x3_ctx* c, unsigned long long* out, uint64_t n) {
 #include "x3_bits.h"
 #define X3_MC_DECODE
 #include "x3_mc.h"
+
+// ---- x3_place_buffers (include/x3hip.h, "Placement"): the round trip timed on every pair of candidate buffers
+extern "C" int x3_place_buffers(x3_ctx* c, const int16_t* d_wav, uint64_t n, const x3_params* p, uint8_t* const* d_streams,
+                                uint32_t n_streams, uint64_t cap, uint64_t* d_frame_offsets, int16_t* const* d_backs,
+                                uint32_t n_backs, uint32_t warm, uint32_t steps, double* ms_per_step) {
+  if (!c || !d_wav || !n || !p || !d_streams || !n_streams || !d_frame_offsets || !d_backs || !n_backs || !steps || !ms_per_step)
+    return X3_ERR_BAD_ARG;
+  for (uint32_t i = 0; i < n_streams; ++i) if (!d_streams[i]) return X3_ERR_BAD_ARG;
+  for (uint32_t j = 0; j < n_backs; ++j) if (!d_backs[j]) return X3_ERR_BAD_ARG;
+  const uint64_t F = x3_num_frames(n, p);
+  const x3_batch b{n, n, 1};
+  int rc = X3_OK;
+  auto trips = [&](uint8_t* d_out, int16_t* d_back, uint32_t k) -> int {
+    for (uint32_t t = 0; t < k; ++t) {
+      if ((rc = x3_encode_dev(c, d_wav, &b, p, d_out, cap, 0, d_frame_offsets))) return rc;
+      if ((rc = x3_decode_dev(c, d_out, cap, d_frame_offsets, F, &b, nullptr, p, d_back, n, nullptr))) return rc;
+    }
+    uint64_t pos = 0, first_bad = 0, before = 0;
+    int bad_status = 0;
+    if ((rc = x3_encode_result(c, &pos, nullptr))) return rc;       // (ByteWriterInsufficientMemory: cap does not hold the stream)
+    if ((rc = x3_decode_result(c, &first_bad, &bad_status, &before))) return rc;
+    return bad_status ? bad_status : X3_OK;
+  };
+  // (the clocks and the caches of a process that has just started: the first pair would pay for them)
+  if ((rc = trips(d_streams[0], d_backs[0], 6 * warm + 1))) return rc;
+  for (uint32_t i = 0; i < n_streams; ++i) {
+    for (uint32_t j = 0; j < n_backs; ++j) {
+      if (warm && (rc = trips(d_streams[i], d_backs[j], warm))) return rc;   // (the decoder's pace controller settles)
+      const auto t0 = std::chrono::steady_clock::now();
+      if ((rc = trips(d_streams[i], d_backs[j], steps))) return rc;
+      const auto t1 = std::chrono::steady_clock::now();
+      ms_per_step[(size_t)i * n_backs + j] = std::chrono::duration<double, std::milli>(t1 - t0).count() / steps;
+    }
+  }
+  return X3_OK;
+}

@@ -121,6 +121,9 @@ pub mod ffi {
                                  batch: *const x3_batch, d_wav_offsets: *const u64, p: *const x3_params, d_wav: *mut i16,
                                  wav_cap: u64, d_status: *mut i32, d_seg_index: *mut u64, seg_blocks: u32, record: c_int) -> c_int;
         pub fn x3_decode_result(ctx: *mut x3_ctx, first_bad: *mut u64, first_bad_status: *mut c_int, samples_before: *mut u64) -> c_int;
+        pub fn x3_place_buffers(ctx: *mut x3_ctx, d_wav: *const i16, n: u64, p: *const x3_params, d_streams: *const *mut u8,
+                                n_streams: u32, cap: u64, d_frame_offsets: *mut u64, d_backs: *const *mut i16, n_backs: u32,
+                                warm: u32, steps: u32, ms_per_step: *mut f64) -> c_int;
         pub fn x3_wav_to_x3a(ctx: *mut x3_ctx, wav_path: *const c_char, x3a_path: *const c_char, stats: *mut u64) -> c_int;
         pub fn x3_x3a_to_wav(ctx: *mut x3_ctx, x3a_path: *const c_char, wav_path: *const c_char, n_samples: *mut u64,
                              frame_errors: *mut u64) -> c_int;

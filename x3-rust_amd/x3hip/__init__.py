@@ -47,7 +47,7 @@ SYMBOLS = [
     "x3_reader_open", "x3_reader_open_mem", "x3_reader_spec", "x3_reader_next_frame", "x3_reader_frame_errors",
     "x3_reader_position", "x3_reader_close",
     "x3_encode_dev", "x3_encode_frames_dev", "x3_encode_result", "x3_decode_dev", "x3_decode_result", "x3_index_dev", "x3_decode_stream_dev",
-    "x3_seg_index_entries", "x3_decode_dev_seg", "x3_encode_dev_seg",
+    "x3_seg_index_entries", "x3_decode_dev_seg", "x3_encode_dev_seg", "x3_place_buffers",
     "x3_graph_begin", "x3_graph_end", "x3_graph_launch", "x3_graph_destroy",
     "x3_synth", "x3_synth_dev", "x3_dev_alloc", "x3_dev_free", "x3_dev_upload", "x3_dev_download",
     "x3_shard_unique_id", "x3_shard_create", "x3_shard_destroy", "x3_shard_rank", "x3_shard_world",
@@ -424,44 +424,22 @@ class MultiGpu:
 
 
 def place_buffers(ctx, params, d_wav, n, d_streams, cap, d_frame_offsets, d_backs, warm=4, steps=8):
-    """Where in HBM the stream and the decoded samples lie decides the decode phase's pace by up to 10 % -- per PAIR of
-    buffers, reproducibly within a process, and not by anything an address shows (profiles/r6/decoder_modes.txt).  A pipeline
-    that keeps its buffers allocates a few candidates once and keeps the pair that runs best: this times `steps` round trips
-    (x3_encode_dev + x3_decode_dev of the `n` samples at d_wav, after `warm` untimed ones: the decoder's pace controller
-    settles) for every (stream buffer, sample buffer) pair and returns ms_per_step[i][j] -- host wall time, synchronised.
-    The caller frees what it does not keep."""
-    import time
-    F = lib().x3_num_frames(n, C.byref(params))
-    ms = []
-    # (the clocks and the caches of a process that has just started: the first pair would pay for them)
-    for _ in range(6 * warm):
-        if ctx.encode_dev(d_wav, n, params, d_streams[0], cap, 0, d_frame_offsets) or \
-           ctx.decode_dev(d_streams[0], cap, d_frame_offsets, F, params, d_backs[0], n, n_per_clip=n):
-            raise X3Error(X3_ERR_HIP if "X3_ERR_HIP" in globals() else 23, "place_buffers: " + ctx.last_error())
-    ctx.decode_result()
-    for d_out in d_streams:
-        row = []
-        for d_back in d_backs:
-            def once():
-                rc = ctx.encode_dev(d_wav, n, params, d_out, cap, 0, d_frame_offsets)
-                if rc == 0:
-                    rc = ctx.decode_dev(d_out, cap, d_frame_offsets, F, params, d_back, n, n_per_clip=n)
-                if rc:
-                    raise X3Error(rc, "place_buffers: " + ctx.last_error())
-            for _ in range(warm):
-                once()
-            ctx.decode_result()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                once()
-            r = ctx.decode_result()
-            t1 = time.perf_counter()
-            if r[0] != 0 or r[2] != 0:
-                raise X3Error(r[0] or 1, "place_buffers: the probe stream did not decode")
-            row.append((t1 - t0) / steps * 1e3)
-        ms.append(row)
-    ctx.encode_result()
-    return ms
+    """x3_place_buffers (include/x3hip.h, "Placement"): where in HBM the stream and the decoded samples lie decides the decode
+    phase's pace by up to 10 % -- per PAIR of buffers, reproducibly within a process, and not by anything an address shows
+    (profiles/r6/decoder_modes.txt).  Times `steps` round trips (after `warm` untimed ones) on every (stream buffer, sample
+    buffer) pair and returns ms_per_step[i][j]; the caller keeps the best pair and frees the rest."""
+    ns, nb = len(d_streams), len(d_backs)
+    streams = (C.c_void_p * ns)(*d_streams)
+    backs = (C.c_void_p * nb)(*d_backs)
+    ms = (C.c_double * (ns * nb))()
+    L = lib()
+    L.x3_place_buffers.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_uint64,
+                                   C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.x3_place_buffers.restype = C.c_int
+    rc = L.x3_place_buffers(ctx._h, d_wav, n, C.byref(params), streams, ns, cap, d_frame_offsets, backs, nb, warm, steps, ms)
+    if rc:
+        raise X3Error(rc, "x3_place_buffers: " + ctx.last_error())
+    return [[ms[i * nb + j] for j in range(nb)] for i in range(ns)]
 
 
 def strerror(rc):
