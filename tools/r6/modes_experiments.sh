@@ -1,6 +1,8 @@
 #!/bin/bash
 # What selects the decode phase's pace?  Every line a fresh process; S = the default allocation (slow on every box so far),
-# F = the stream 4 096 bytes into its allocation (fast).  tools/scratch/exp/: -DX3_PROFILING and -DX3S_PACE_OFF=1 builds.
+# F = the stream 4 096 bytes into its allocation (fast).  tools/scratch/exp/: -DX3_PROFILING and -DX3S_PACE_OFF=1 builds --
+#   JOBS=3 python3 tools/variants.py prof="-DX3_PROFILING" nopace="-DX3S_PACE_OFF=1"; mkdir -p tools/scratch/exp;
+#   cp x3-rust_amd/lib/variants/libx3hip_{prof,nopace}.so tools/scratch/exp/   (lib/variants/ itself does not travel with gpurun)
 out=${1:-gpurun_out/r6/modes_experiments.txt}
 run() { echo -n "$LABEL $*: "; python3 tools/kbench.py --steps 20 "$@" 2>&1 | tail -1 | sed -e 's/sizes=.*check=/check=/' -e 's/dense=.*rep 0//'; }
 {
