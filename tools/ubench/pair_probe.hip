@@ -1,0 +1,125 @@
+// pair_probe.hip -- does a bare kernel with the decoder's memory pattern see the PAIR of buffers it runs on?
+//   hipcc --offload-arch=gfx950 -O3 -o pair_probe pair_probe.hip && ./pair_probe [n_candidates]
+// profiles/r6/decoder_modes.txt: the decode phase's pace follows the pair (stream buffer, sample buffer) by up to 10 %.
+// Here, without any decoding: 1 080 waves, a frame per lane -- every lane reads its frame's 5 264 bytes of A in 16-byte
+// chunks and the wave writes its 64 rows of B (20 000 bytes apart) as whole 128-byte lines, eight rows per store
+// instruction (x3_decode_split_kernel.h's flusher), 2.1 chunks read per line written; beside it, optionally, a reader of
+// all of A (a wave per frame: the check kernel's pattern) on a second stream.  Variants: lines of 256 / 512 bytes per row
+// and store, plain instead of non-temporal stores, reads only, writes only.  Prints ms per (A, B) pair.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <cstdlib>
+#include <vector>
+#define FRAMES 69120u
+#define FB 5264u      // stream bytes per frame (16-byte multiple near config 3's 5 257)
+#define ROW 20000u    // sample bytes per frame
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1); } } while (0)
+
+// LINE: bytes a row gets per store (128: the decoder's); NT: non-temporal stores; RD / WR: do the reads / the writes
+template <int LINE, bool NT, bool RD, bool WR>
+__global__ void __launch_bounds__(64) decoder_like(const uint8_t* __restrict__ A, uint8_t* __restrict__ B, uint32_t delay) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t f0 = blockIdx.x * 64u;
+  const u32x4* src = reinterpret_cast<const u32x4*>(A + (size_t)(f0 + lane) * FB);
+  uint8_t* dst0 = B + (size_t)f0 * ROW;
+  constexpr uint32_t LPS = LINE / 16u;           // lanes per row and store
+  constexpr uint32_t RPS = 64u / LPS;            // rows per store instruction
+  const uint32_t nsteps = (ROW - LINE) / LINE;   // steps of LINE bytes per row
+  u32x4 acc = {lane, 1u, 2u, 3u};
+  uint32_t c = 0;                                 // chunks read, as 16.16: FB / ROW chunks of 16 B per 16 B written
+  const uint32_t cstep = (uint32_t)(((unsigned long long)FB << 16) / ROW) * (LINE / 16u);
+  for (uint32_t k = 0; k < nsteps; ++k) {
+    if (RD) {
+      const uint32_t c1 = c + cstep;
+      for (uint32_t i = c >> 16; i < (c1 >> 16); ++i) {
+        const u32x4 v = src[i];
+        acc ^= v;
+      }
+      c = c1;
+    }
+    // (a dependent chain between the steps, as the parser's: the kernel is not bandwidth-bound)
+    for (uint32_t d = 0; d < delay * (LINE / 128u); ++d) acc.x = acc.x * 1664525u + 1013904223u;
+    if (WR) {
+#pragma unroll
+      for (uint32_t r0 = 0; r0 < 64u; r0 += RPS) {
+        const uint32_t r = r0 + lane / LPS, p = lane % LPS;
+        // (whole 128-byte lines, as the flusher writes them: a row's pieces are cut at the destination's line boundaries)
+        u32x4* d = reinterpret_cast<u32x4*>(B + ((((size_t)(f0 + r) * ROW) & ~(size_t)127) + (size_t)k * LINE + 16u * p));
+        if (NT) __builtin_nontemporal_store(acc, d); else *d = acc;
+      }
+    }
+  }
+  if (!WR && acc.x == 0x12345u) B[0] = 1;
+}
+// a wave per frame reads the whole frame (256 threads = 4 frames a workgroup), grid-stride over the frames
+__global__ void __launch_bounds__(256) reader_like(const uint8_t* __restrict__ A, uint32_t* __restrict__ sink) {
+  const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  u32x4 acc = {0, 0, 0, 0};
+  for (uint32_t f = blockIdx.x * 4u + w; f < FRAMES; f += gridDim.x * 4u) {
+    const u32x4* src = reinterpret_cast<const u32x4*>(A + (size_t)f * FB);
+    for (uint32_t i = lane; i < FB / 16u; i += 64u) acc ^= src[i];
+  }
+  if (acc.x == 0x12345u) sink[0] = 1;
+}
+
+template <int LINE, bool NT, bool RD, bool WR>
+static float run(const uint8_t* A, uint8_t* B, uint32_t delay, bool with_reader, uint32_t* sink, hipStream_t s0, hipStream_t s1) {
+  hipEvent_t a, b, fork, join;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); CK(hipEventCreate(&fork)); CK(hipEventCreate(&join));
+  float tot = 0;
+  const int reps = 6;
+  for (int rep = -2; rep < reps; ++rep) {
+    CK(hipEventRecord(fork, s0));
+    CK(hipStreamWaitEvent(s1, fork, 0));
+    CK(hipEventRecord(a, s0));
+    hipLaunchKernelGGL((decoder_like<LINE, NT, RD, WR>), dim3(FRAMES / 64u), dim3(64), 0, s0, A, B, delay);
+    if (with_reader) hipLaunchKernelGGL(reader_like, dim3(1024), dim3(256), 0, s1, A, sink);
+    CK(hipEventRecord(join, s1));
+    CK(hipStreamWaitEvent(s0, join, 0));
+    CK(hipEventRecord(b, s0));
+    CK(hipStreamSynchronize(s0));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    if (rep >= 0) tot += ms;
+  }
+  return tot / reps;
+}
+
+int main(int argc, char** argv) {
+  const int n = argc > 1 ? std::atoi(argv[1]) : 3;
+  const uint32_t delay = argc > 2 ? (uint32_t)std::atoi(argv[2]) : 600u;   // ~4 us a step: the decoder's 0.65 ms for its 156 lines a row
+  const size_t a_bytes = (size_t)FRAMES * FB + 4096, b_bytes = (size_t)FRAMES * ROW + 4096;
+  std::vector<uint8_t*> As, Bs;
+  for (int i = 0; i < n; ++i) {
+    uint8_t *a, *b, *pad;
+    CK(hipMalloc(&a, a_bytes)); CK(hipMalloc(&b, b_bytes)); CK(hipMalloc(&pad, (size_t)(i + 1) * 1237 * 1024));
+    CK(hipMemset(a, 0x5A, a_bytes)); CK(hipMemset(b, 0, b_bytes));
+    As.push_back(a); Bs.push_back(b);
+  }
+  uint32_t* sink;
+  CK(hipMalloc(&sink, 64));
+  hipStream_t s0, s1;
+  CK(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+  struct V { const char* name; float (*fn)(const uint8_t*, uint8_t*, uint32_t, bool, uint32_t*, hipStream_t, hipStream_t); bool reader; };
+  const V vs[] = {
+      {"lines of 128 B, nt, + reader of A (the decode phase)", run<128, true, true, true>, true},
+      {"lines of 128 B, nt, alone", run<128, true, true, true>, false},
+      {"lines of 128 B, plain stores, + reader", run<128, false, true, true>, true},
+      {"lines of 256 B, nt, + reader", run<256, true, true, true>, true},
+      {"lines of 512 B, nt, + reader", run<512, true, true, true>, true},
+      {"writes only (128 B, nt)", run<128, true, false, true>, false},
+      {"reads only, + reader", run<128, true, true, false>, true},
+  };
+  for (const V& v : vs) {
+    std::printf("%s   (delay %u)\n", v.name, delay);
+    for (int i = 0; i < n; ++i) {
+      std::printf("  A[%d]:", i);
+      for (int j = 0; j < n; ++j) std::printf("  B[%d] %.3f", j, v.fn(As[i], Bs[j], delay, v.reader, sink, s0, s1));
+      std::printf("\n");
+      std::fflush(stdout);
+    }
+  }
+  return 0;
+}
