@@ -324,6 +324,22 @@ int main(int argc, char** argv) {
     CHECK(x3::device::decode(ctx, tiny, params, d_back.as<int16_t>(), 100, &res) == x3::X3Error::Ok && res.samples == 100);
     std::vector<int16_t> back(100);
     CHECK(d_back.download(back.data(), 200) == x3::X3Error::Ok && std::equal(back.begin(), back.end(), clips.begin()));
+    // x3::device::place_buffers: every pair of two stream buffers and two sample buffers timed; the last pair holds the
+    // last round trip; a stream buffer too small for the stream is the writer's error
+    {
+      const x3_params cp = params.c_params();
+      const size_t n = clips.size(), cap = x3_encode_bound(n, &cp), nf = x3_num_frames(n, &cp);
+      x3::device::Buffer s0(ctx, cap + 16), s1(ctx, cap + 16), b0(ctx, 2 * n), b1(ctx, 2 * n), fo(ctx, 8 * (nf + 1));
+      CHECK(s0.ok() && s1.ok() && b0.ok() && b1.ok() && fo.ok());
+      std::vector<double> ms;
+      CHECK(x3::device::place_buffers(ctx, d_wav.as<int16_t>(), n, params, {s0.as<uint8_t>(), s1.as<uint8_t>()}, cap, fo.as<uint64_t>(),
+                                      {b0.as<int16_t>(), b1.as<int16_t>()}, &ms, 1, 2) == x3::X3Error::Ok);
+      CHECK(ms.size() == 4 && ms[0] > 0 && ms[1] > 0 && ms[2] > 0 && ms[3] > 0);
+      std::vector<int16_t> rt(n);
+      CHECK(b1.download(rt.data(), 2 * n) == x3::X3Error::Ok && rt == clips);
+      CHECK(x3::device::place_buffers(ctx, d_wav.as<int16_t>(), n, params, {s0.as<uint8_t>()}, 64, fo.as<uint64_t>(), {b0.as<int16_t>()}, &ms,
+                                      1, 1) == x3::X3Error::ByteWriterInsufficientMemory);
+    }
   }
   std::printf("x3.hpp checks ok\n");
   return 0;

@@ -686,6 +686,20 @@ inline X3Error decode(Context& ctx, const EncodedStream& s, const Parameters& pa
   if (rc != X3_OK) return static_cast<X3Error>(rc);
   return static_cast<X3Error>(st);
 }
+
+// Placement (x3_place_buffers; profiles/r6/decoder_modes.txt): the round trip timed on every pair of candidate buffers --
+// ms[i * backs.size() + j] for (streams[i], backs[j]).  A pipeline that keeps its buffers calls this once and keeps the
+// pair that runs best; what it does not keep it frees.
+inline X3Error place_buffers(Context& ctx, const int16_t* d_wav, size_t n, const Parameters& params,
+                             const std::vector<uint8_t*>& streams, size_t cap, uint64_t* d_frame_offsets,
+                             const std::vector<int16_t*>& backs, std::vector<double>* ms, uint32_t warm = 4, uint32_t steps = 8) {
+  if (!ms || streams.empty() || backs.empty()) return X3Error::BadArg;
+  const x3_params c = params.c_params();
+  ms->assign(streams.size() * backs.size(), 0.0);
+  return static_cast<X3Error>(x3_place_buffers(ctx.raw(), d_wav, n, &c, streams.data(), static_cast<uint32_t>(streams.size()), cap,
+                                               d_frame_offsets, backs.data(), static_cast<uint32_t>(backs.size()), warm, steps,
+                                               ms->data()));
+}
 }  // namespace device
 
 // Multi-channel extension (x3_mc.h; NOT in the crate, whose encode() returns MoreThanOneChannel for more than one channel

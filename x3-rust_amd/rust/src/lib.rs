@@ -1134,6 +1134,22 @@ pub mod device {
         error::check(st)?;
         Ok(before as usize)
     }
+
+    /// Placement (`x3_place_buffers`; profiles/r6/decoder_modes.txt): the round trip timed on every pair of candidate buffers --
+    /// `ms[i * backs.len() + j]` for `(streams[i], backs[j])`, `cap` bytes of room in every stream buffer.  A pipeline that keeps its
+    /// buffers calls this once and keeps the pair that runs best.
+    pub fn place_buffers<'g>(gpu: &'g Gpu, d_wav: &Buffer<'g>, n: usize, params: &x3::Parameters, streams: &[&Buffer<'g>], cap: usize,
+                             frame_offsets: &mut Buffer<'g>, backs: &[&Buffer<'g>], warm: u32, steps: u32) -> error::Result<Vec<f64>> {
+        let p = params.c()?;
+        let s: Vec<*mut u8> = streams.iter().map(|b| b.as_ptr::<u8>()).collect();
+        let k: Vec<*mut i16> = backs.iter().map(|b| b.as_ptr::<i16>()).collect();
+        let mut ms = vec![0f64; s.len() * k.len()];
+        error::check(unsafe {
+            ffi::x3_place_buffers(gpu.raw(), d_wav.as_ptr::<i16>(), n as u64, &p, s.as_ptr(), s.len() as u32, cap as u64,
+                                  frame_offsets.as_ptr::<u64>(), k.as_ptr(), k.len() as u32, warm, steps, ms.as_mut_ptr())
+        })?;
+        Ok(ms)
+    }
 }
 
 pub mod encodefile {
