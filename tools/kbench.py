@@ -23,6 +23,7 @@ ap.add_argument("--opt", action="append", default=[], help="context option name=
 ap.add_argument("--order", default="wofb", help="the order the buffers are allocated in: w(av) o(ut) f(rame offsets) b(ack)")
 ap.add_argument("--out-shift", type=int, default=0, help="the stream begins this many bytes into its allocation")
 ap.add_argument("--back-shift", type=int, default=0, help="the decoded samples begin this many bytes into their allocation")
+ap.add_argument("--place", type=int, default=1, help="candidates per buffer for x3hip.place_buffers (the best pair of stream / sample buffers is used; 1 = the first allocation)")
 ap.add_argument("--decode-only", action="store_true", help="the timed steps decode only (the stream of the first encode)")
 ap.add_argument("--seg", type=int, default=0, help="decode by a segment index of SEG blocks per stretch (recorded by the first decode)")
 a = ap.parse_args()
@@ -43,6 +44,15 @@ def run_once(tag):
         bufs[ch] = {"w": lambda: ctx.alloc(2 * stride * a.clips + 64) + a.shift, "o": lambda: ctx.alloc(cap + 16 + a.out_shift) + a.out_shift,
                     "f": lambda: ctx.alloc(8 * (F + 1)), "b": lambda: ctx.alloc(2 * stride * a.clips + a.back_shift) + a.back_shift}[ch]()
     d_wav, d_out, d_off, d_back = bufs["w"], bufs["o"], bufs["f"], bufs["b"]
+    if a.place > 1 and a.clips == 1:
+        ctx.synth_dev(a.kind, 0x58330003, 0, stride * a.clips, d_wav)
+        co, cb = [d_out], [d_back]
+        for k in range(a.place - 1):
+            ctx.alloc((k + 1) * 1237 * 1024); co.append(ctx.alloc(cap + 16)); cb.append(ctx.alloc(2 * stride * a.clips))
+        ms = x3hip.place_buffers(ctx, p, d_wav, npc, co, cap, d_off, cb)
+        best = min((ms[i][j], i, j) for i in range(a.place) for j in range(a.place))
+        d_out, d_back = co[best[1]], cb[best[2]]
+        print("placement: first %.4f best %.4f worst %.4f ms per step" % (ms[0][0], best[0], max(max(r) for r in ms)), end="; ")
     ctx.synth_dev(a.kind, 0x58330003, 0, stride * a.clips, d_wav)
     if a.loud > 0:   # every k-th frame loud
         k = max(1, int(round(1.0 / a.loud)))

@@ -39,7 +39,9 @@
 //   * The flush costs the valuer ~15 % of its time if it does it itself; a wave of its own does it for free.
 //   * Tried and dropped: a fourth wave that keeps the parser's ring filled (its requests, one block ahead, wait ~2 400
 //     clocks for HBM beside the write stream, and two blocks ahead needs a 256-byte ring per lane that LDS has no room
-//     for: +3 % at best, -5 % with the flusher beside it); touching the stream a line ahead (-3 %); s_setprio by
+//     for: +3 % at best, -5 % with the flusher beside it); touching the stream a line ahead (-3 %; round 6, the same touch from the
+//     FLUSHER, which has no loads of its own to wait behind it, at the position the frame's density predicts 16 / 32 / 64
+//     blocks on: 0.661 / 0.655 / 0.645 against 0.643 ms, placed buffers, profiles/r6/decoder_modes.txt); s_setprio by
 //     dispatch order (the SQ issues oldest-first and the last groups run 20 % longer than the first, but handing
 //     the priority to them only moves the tail to the first groups).
 #pragma once
