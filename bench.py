@@ -204,7 +204,7 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=500.0,
                     help="upper bound of the time-based settle in front of the warm-up: steps are run until the shader clock "
                          "the kernels log has stayed within 2.5 %% of its running maximum for 8 launches (0: no settle)")
-    ap.add_argument("--place", type=int, default=6,
+    ap.add_argument("--place", type=int, default=8,
                     help="candidates per buffer for the placement probe (x3hip.place_buffers: the pair of stream / sample buffers "
                          "the round trip runs best on is kept; 1 = take the first allocation as it comes)")
     ap.add_argument("--no-configs", action="store_true", help="skip the timing of BASELINE configs 2 and 5 (`configs` in the line)")

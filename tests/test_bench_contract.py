@@ -64,11 +64,11 @@ def test_bench_small_run_prints_the_contract_line():
     assert last["decoder_kernels"]["three_wave"]["decode_ms"] > 0 and last["decoder_kernels"]["block_per_lane"]["decode_ms"] > 0
     # the placement probe (round 6): what it saw is in the line, the whole matrix in the details
     sm = last["placement"]["step_ms"]
-    assert last["placement"]["candidates_per_buffer"] == 6 and 0 < sm["best"] <= sm["first_allocation"] <= sm["worst"]
+    assert last["placement"]["candidates_per_buffer"] == 8 and 0 < sm["best"] <= sm["first_allocation"] <= sm["worst"]
     j = json.load(open(details))["bench_details"]
     for k in ("metric", "value", "ms_per_step"):
         assert j[k] == last[k], k
-    assert len(j["placement"]["ms_per_step"]) == 6 and all(len(r) == 6 for r in j["placement"]["ms_per_step"])
+    assert len(j["placement"]["ms_per_step"]) == 8 and all(len(r) == 8 for r in j["placement"]["ms_per_step"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in j, k

@@ -53,6 +53,8 @@ def run_once(tag):
         best = min((ms[i][j], i, j) for i in range(a.place) for j in range(a.place))
         d_out, d_back = co[best[1]], cb[best[2]]
         print("placement: first %.4f best %.4f worst %.4f ms per step" % (ms[0][0], best[0], max(max(r) for r in ms)), end="; ")
+        if os.environ.get("X3_PLACE_MATRIX"):
+            print("\n" + "\n".join("  stream[%d]: " % i + " ".join("%.3f" % v for v in r) for i, r in enumerate(ms)))
     ctx.synth_dev(a.kind, 0x58330003, 0, stride * a.clips, d_wav)
     if a.loud > 0:   # every k-th frame loud
         k = max(1, int(round(1.0 / a.loud)))
