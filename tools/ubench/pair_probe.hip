@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <vector>
+#include <string>
 #define FRAMES 69120u
 #define FB 5264u      // stream bytes per frame (16-byte multiple near config 3's 5 257)
 #define ROW 20000u    // sample bytes per frame
@@ -87,7 +88,33 @@ static float run(const uint8_t* A, uint8_t* B, uint32_t delay, bool with_reader,
   return tot / reps;
 }
 
+// `shift` mode: ONE sample buffer with room behind it; the write-only kernel at growing offsets into it -- is a buffer's
+// kind (profiles/r6/decoder_modes.txt, 4c) a matter of where in the allocation it begins?
+static int shift_mode() {
+  const size_t b_bytes = (size_t)FRAMES * ROW + 4096, room = (size_t)6 << 30;
+  hipStream_t s0, s1;
+  CK(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+  uint32_t* sink;
+  CK(hipMalloc(&sink, 64));
+  for (int rep = 0; rep < 3; ++rep) {
+    uint8_t *a, *b, *pad;
+    CK(hipMalloc(&pad, (size_t)(rep + 1) * 1237 * 1024));
+    CK(hipMalloc(&a, (size_t)FRAMES * FB + 4096));
+    CK(hipMalloc(&b, b_bytes + room));
+    CK(hipMemset(b, 0, b_bytes + room));
+    std::printf("allocation %d (%p): writes only, 128-byte lines, by the offset the buffer begins at\n ", rep, (void*)b);
+    const size_t offs[] = {0, (size_t)1 << 21, (size_t)1 << 24, (size_t)1 << 25, (size_t)1 << 26, (size_t)1 << 27, (size_t)1 << 28, (size_t)3 << 27,
+                           (size_t)1 << 29, (size_t)3 << 28, (size_t)1 << 30, (size_t)3 << 29, (size_t)1 << 31, (size_t)5 << 29, (size_t)3 << 30,
+                           (size_t)1 << 32, (size_t)5 << 30, ((size_t)1 << 30) + ((size_t)1 << 21) * 77};
+    for (size_t o : offs) std::printf(" %zuM:%.3f", o >> 20, run<128, true, false, true>(a, b + o, 0, false, sink, s0, s1));
+    std::printf("\n");
+    std::fflush(stdout);
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1 && std::string(argv[1]) == "shift") return shift_mode();
   const int n = argc > 1 ? std::atoi(argv[1]) : 3;
   const uint32_t delay = argc > 2 ? (uint32_t)std::atoi(argv[2]) : 600u;   // ~4 us a step: the decoder's 0.65 ms for its 156 lines a row
   const size_t a_bytes = (size_t)FRAMES * FB + 4096, b_bytes = (size_t)FRAMES * ROW + 4096;
