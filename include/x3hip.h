@@ -149,7 +149,8 @@ int x3_ctx_get_option(const x3_ctx* ctx, const char* name, long long* value);
 /* HIP-event timing of individual kernels on the context's stream (bench.py's roofline leg).
  * which: 0 = encode kernel, 1 = decode kernel, 2 = frame-size kernel, 3 = scan kernel,
  *        4 = frame check (header + payload CRC) kernel, 5 = the encoder's dense pass (frames the wave encoder's LDS image
- *        does not hold: x3_encode_dev below). */
+ *        does not hold: x3_encode_dev below).  Every timed kernel costs a marker behind its dispatch packet (~5 us each,
+ *        five a round trip); option "kernel_timing_mask" (bit k = kernel id k, default all) chooses which ones carry them. */
 int x3_ctx_enable_kernel_timing(x3_ctx* ctx, int enable);
 int x3_ctx_kernel_time(x3_ctx* ctx, int which, double* total_ms, uint64_t* launches); /* syncs */
 int x3_ctx_reset_kernel_time(x3_ctx* ctx);

@@ -102,6 +102,8 @@ def test_bench_small_run_prints_the_contract_line():
     assert j["config"]["settle_steps"] >= 16 and j["config"]["settle_ms"] > 0
     # the same K steps without the kernels' HIP events, beside `value` (which has them in the timed region, as the contract asks)
     assert j["value_without_kernel_events"] > 0 and j["ms_per_step_without_kernel_events"] > 0
+    # (the timed region carries the events of the decode phase's two kernels; the pass behind it all five kernels': what `value` was until round 5)
+    assert j["value_with_all_kernel_events"] > 0 and last["value_with_all_kernel_events"] == j["value_with_all_kernel_events"]
     # roofline.traffic is measured by the run itself (two rocprofv3 PMC passes as child processes) where rocprofv3 exists
     import shutil
     if shutil.which("rocprofv3"):

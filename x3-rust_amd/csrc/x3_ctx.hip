@@ -423,6 +423,7 @@ extern "C" int x3_ctx_set_option(x3_ctx* c, const char* name, long long value) {
   else if (n == "file_chunk_frames") c->opt.file_chunk_frames = std::max(1ll, value);
   else if (n == "file_workers") c->opt.file_workers = (int)std::max(1ll, std::min(16ll, value));
   else if (n == "reader_window_frames") c->opt.reader_window_frames = std::max(1ll, value);
+  else if (n == "kernel_timing_mask") c->timing_mask = (uint32_t)value;   // bit k: kernel id k carries events while timing is enabled (default: all)
   else if (n == "check_main") c->opt.check_main = value != 0;
   else if (n == "check_first") c->opt.check_first = value != 0;
   else if (n == "check_wgs") c->opt.check_wgs = (int)std::max(1ll, value);

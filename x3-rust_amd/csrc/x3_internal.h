@@ -189,6 +189,7 @@ struct x3_ctx {
   uint64_t dec_frames = 0;
   // kernel timing
   bool timing = false;
+  uint32_t timing_mask = 0xFFFFFFFFu;   // option "kernel_timing_mask": which kernels (bit = the id x3_ctx_kernel_time takes) carry events
   KernelTimer timers[6];   // encode, decode, sizes, scan, check, dense pass
 };
 
@@ -213,10 +214,11 @@ struct TimerScope {
   int which;
   hipStream_t st;
   bool attached;
+  bool on;
   std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
   TimerScope(x3_ctx* c_, int w, hipStream_t s_ = nullptr, bool attached_ = false)
-      : c(c_), which(w), st(s_ ? s_ : c_->stream), attached(attached_) {
-    if (!c->timing) return;
+      : c(c_), which(w), st(s_ ? s_ : c_->stream), attached(attached_), on(c_->timing && ((c_->timing_mask >> w) & 1u)) {
+    if (!on) return;
     KernelTimer& t = c->timers[which];
     if (!t.pool.empty()) {
       ev = t.pool.back();
@@ -228,7 +230,7 @@ struct TimerScope {
     if (!attached) (void)hipEventRecord(ev.first, st);
   }
   ~TimerScope() {
-    if (!c->timing) return;
+    if (!on) return;
     if (!attached) (void)hipEventRecord(ev.second, st);
     c->timers[which].used.push_back(ev);
   }
@@ -236,7 +238,7 @@ struct TimerScope {
 // launch `kernel` on `stream` inside the TimerScope `ts` (constructed with attached = true)
 #define X3_LAUNCH_TIMED(ts, kernel, grid, block, smem, stream, ...)                                        \
   do {                                                                                                     \
-    if ((ts).c->timing) hipExtLaunchKernelGGL(kernel, grid, block, smem, stream, (ts).ev.first, (ts).ev.second, 0, __VA_ARGS__); \
+    if ((ts).on) hipExtLaunchKernelGGL(kernel, grid, block, smem, stream, (ts).ev.first, (ts).ev.second, 0, __VA_ARGS__); \
     else hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);                               \
   } while (0)
 
