@@ -14,8 +14,8 @@ python3 bench.py --details $out/bench_details.json > $out/bench_default.json 2> 
 cp $out/stats/bench_kernel_stats.csv $out/bench_kernel_stats.csv 2>/dev/null
 cp $out/stats/bench_domain_stats.csv $out/bench_domain_stats.csv 2>/dev/null
 # (--stats averages every launch of the process, the placement probe's 64 x 13 round trips on other buffers among them: the
-# timed steps' own averages, from the same run's kernel trace, beside what its JSON line said)
-python3 tools/timed_steps_stats.py $out/stats 100 $out/stats.log > $out/bench_kernel_stats_timed_steps.txt 2>&1
+# timed passes (three of 100 steps each) on their own, from the same run.s kernel trace, beside what its JSON line said)
+python3 tools/timed_steps_stats.py $out/stats 300 $out/stats.log > $out/bench_kernel_stats_timed_steps.txt 2>&1
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"; do
   i=$((i+1))
