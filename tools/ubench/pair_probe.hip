@@ -88,6 +88,56 @@ static float run(const uint8_t* A, uint8_t* B, uint32_t delay, bool with_reader,
   return tot / reps;
 }
 
+// `chunks` mode: which PIECES of memory are of which kind?  N allocations of S megabytes, the write-only pattern folded into
+// each (the same 1 080 waves and 64-row stores, addresses modulo the piece), in allocation order.
+__global__ void __launch_bounds__(64) write_folded(uint8_t* __restrict__ B, uint32_t piece_lines) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t f0 = blockIdx.x * 64u;
+  const uint32_t nsteps = (ROW - 128u) / 128u;
+  u32x4 acc = {lane, 1u, 2u, 3u};
+  for (uint32_t k = 0; k < nsteps; ++k) {
+#pragma unroll
+    for (uint32_t r0 = 0; r0 < 64u; r0 += 8u) {
+      const uint32_t r = r0 + lane / 8u, p = lane % 8u;
+      const size_t line = ((((size_t)(f0 + r) * ROW) >> 7) + k) % piece_lines;
+      __builtin_nontemporal_store(acc, reinterpret_cast<u32x4*>(B + line * 128u + 16u * p));
+    }
+  }
+}
+static int chunks_mode(int n, size_t mb) {
+  const size_t bytes = mb << 20;
+  std::vector<uint8_t*> c;
+  for (int i = 0; i < n; ++i) {
+    uint8_t* p;
+    CK(hipMalloc(&p, bytes));
+    CK(hipMemset(p, 0, bytes));
+    c.push_back(p);
+  }
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  std::printf("%d pieces of %zu MB in allocation order: ms of the folded write-only pattern (1.38 GB written into each)\n", n, mb);
+  for (int rep = 0; rep < 2; ++rep) {
+    for (int i = 0; i < n; ++i) {
+      float tot = 0;
+      for (int r = -1; r < 3; ++r) {
+        CK(hipEventRecord(a, 0));
+        hipLaunchKernelGGL(write_folded, dim3(FRAMES / 64u), dim3(64), 0, 0, c[i], (uint32_t)(bytes >> 7));
+        CK(hipEventRecord(b, 0));
+        CK(hipEventSynchronize(b));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, a, b));
+        if (r >= 0) tot += ms;
+      }
+      std::printf(" %.3f", tot / 3);
+      if (i % 16 == 15) std::printf("\n");
+    }
+    std::printf("\n");
+  }
+  for (int i = 0; i < n; ++i) std::printf(" %p", (void*)c[i]);
+  std::printf("\n");
+  return 0;
+}
+
 // `shift` mode: ONE sample buffer with room behind it; the write-only kernel at growing offsets into it -- is a buffer's
 // kind (profiles/r6/decoder_modes.txt, 4c) a matter of where in the allocation it begins?
 static int shift_mode() {
@@ -115,6 +165,7 @@ static int shift_mode() {
 
 int main(int argc, char** argv) {
   if (argc > 1 && std::string(argv[1]) == "shift") return shift_mode();
+  if (argc > 1 && std::string(argv[1]) == "chunks") return chunks_mode(argc > 2 ? std::atoi(argv[2]) : 48, argc > 3 ? (size_t)std::atoi(argv[3]) : 512);
   const int n = argc > 1 ? std::atoi(argv[1]) : 3;
   const uint32_t delay = argc > 2 ? (uint32_t)std::atoi(argv[2]) : 600u;   // ~4 us a step: the decoder's 0.65 ms for its 156 lines a row
   const size_t a_bytes = (size_t)FRAMES * FB + 4096, b_bytes = (size_t)FRAMES * ROW + 4096;
