@@ -138,6 +138,34 @@ static int chunks_mode(int n, size_t mb) {
   return 0;
 }
 
+// `sizes` mode: does the SIZE an allocation is made with decide its kind?  Eight allocations of each size (the 1.38 GB are
+// written at their start), the write-only pattern on each.
+static int sizes_mode() {
+  hipStream_t s0, s1;
+  CK(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+  uint32_t* sink;
+  uint8_t* a;
+  CK(hipMalloc(&sink, 64));
+  CK(hipMalloc(&a, (size_t)FRAMES * FB + 4096));
+  const size_t need = (size_t)FRAMES * ROW + 4096;
+  const size_t sizes[] = {need, (size_t)1536 << 20, (size_t)2048 << 20, (size_t)3072 << 20, (size_t)4096 << 20, need};
+  for (size_t sz : sizes) {
+    std::printf("allocations of %zu MB:", sz >> 20);
+    std::vector<uint8_t*> keep;
+    for (int i = 0; i < 8; ++i) {
+      uint8_t* b;
+      CK(hipMalloc(&b, sz));
+      CK(hipMemset(b, 0, need));
+      keep.push_back(b);
+      std::printf(" %.3f", run<128, true, false, true>(a, b, 0, false, sink, s0, s1));
+      std::fflush(stdout);
+    }
+    std::printf("\n");
+    for (uint8_t* b : keep) CK(hipFree(b));
+  }
+  return 0;
+}
+
 // `shift` mode: ONE sample buffer with room behind it; the write-only kernel at growing offsets into it -- is a buffer's
 // kind (profiles/r6/decoder_modes.txt, 4c) a matter of where in the allocation it begins?
 static int shift_mode() {
@@ -165,6 +193,7 @@ static int shift_mode() {
 
 int main(int argc, char** argv) {
   if (argc > 1 && std::string(argv[1]) == "shift") return shift_mode();
+  if (argc > 1 && std::string(argv[1]) == "sizes") return sizes_mode();
   if (argc > 1 && std::string(argv[1]) == "chunks") return chunks_mode(argc > 2 ? std::atoi(argv[2]) : 48, argc > 3 ? (size_t)std::atoi(argv[3]) : 512);
   const int n = argc > 1 ? std::atoi(argv[1]) : 3;
   const uint32_t delay = argc > 2 ? (uint32_t)std::atoi(argv[2]) : 600u;   // ~4 us a step: the decoder's 0.65 ms for its 156 lines a row
