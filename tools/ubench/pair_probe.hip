@@ -166,6 +166,58 @@ static int sizes_mode() {
   return 0;
 }
 
+// `vmm` mode: a sample buffer PIECED TOGETHER on purpose -- one range of virtual addresses, `parts` separate physical
+// allocations (hipMemCreate) mapped into it one behind the other.  Is such a buffer of the fast kind by construction?
+static int vmm_mode() {
+  hipStream_t s0, s1;
+  CK(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+  uint32_t* sink;
+  uint8_t* a;
+  CK(hipMalloc(&sink, 64));
+  CK(hipMalloc(&a, (size_t)FRAMES * FB + 4096));
+  int dev = 0;
+  CK(hipGetDevice(&dev));
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = dev;
+  size_t gran = 0;
+  CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+  const size_t need = (size_t)FRAMES * ROW + 4096;
+  std::printf("granularity %zu bytes\n", gran);
+  for (int parts : {1, 2, 3, 4, 6, 11, 2, 1}) {
+    std::printf("%2d parts:", parts);
+    for (int trial = 0; trial < 8; ++trial) {
+      const size_t part = ((need + parts - 1) / parts + gran - 1) / gran * gran, total = part * parts;
+      hipDeviceptr_t va = nullptr;
+      CK(hipMemAddressReserve(&va, total, 0, nullptr, 0));
+      std::vector<hipMemGenericAllocationHandle_t> hs(parts);
+      // (something odd-sized between the parts, so that they are not neighbours)
+      std::vector<void*> pads;
+      for (int k = 0; k < parts; ++k) {
+        CK(hipMemCreate(&hs[k], part, &prop, 0));
+        void* pd;
+        CK(hipMalloc(&pd, (size_t)(37 + 11 * k + trial) << 20));
+        pads.push_back(pd);
+        CK(hipMemMap((hipDeviceptr_t)((uint8_t*)va + k * part), part, 0, hs[k], 0));
+      }
+      hipMemAccessDesc acc = {};
+      acc.location = prop.location;
+      acc.flags = hipMemAccessFlagsProtReadWrite;
+      CK(hipMemSetAccess(va, total, &acc, 1));
+      CK(hipMemset(va, 0, need));
+      std::printf(" %.3f", run<128, true, false, true>(a, (uint8_t*)va, 0, false, sink, s0, s1));
+      std::fflush(stdout);
+      CK(hipMemUnmap(va, total));
+      for (auto h : hs) CK(hipMemRelease(h));
+      CK(hipMemAddressFree(va, total));
+      for (void* pd : pads) CK(hipFree(pd));
+    }
+    std::printf("\n");
+  }
+  return 0;
+}
+
 // `shift` mode: ONE sample buffer with room behind it; the write-only kernel at growing offsets into it -- is a buffer's
 // kind (profiles/r6/decoder_modes.txt, 4c) a matter of where in the allocation it begins?
 static int shift_mode() {
@@ -194,6 +246,7 @@ static int shift_mode() {
 int main(int argc, char** argv) {
   if (argc > 1 && std::string(argv[1]) == "shift") return shift_mode();
   if (argc > 1 && std::string(argv[1]) == "sizes") return sizes_mode();
+  if (argc > 1 && std::string(argv[1]) == "vmm") return vmm_mode();
   if (argc > 1 && std::string(argv[1]) == "chunks") return chunks_mode(argc > 2 ? std::atoi(argv[2]) : 48, argc > 3 ? (size_t)std::atoi(argv[3]) : 512);
   const int n = argc > 1 ? std::atoi(argv[1]) : 3;
   const uint32_t delay = argc > 2 ? (uint32_t)std::atoi(argv[2]) : 600u;   // ~4 us a step: the decoder's 0.65 ms for its 156 lines a row
