@@ -357,7 +357,7 @@ def fam_b_ragged(rng, tag):
     device entry itself with clips at arbitrary sample offsets, against per-clip oracle streams; decoded back by frame
     index and per-frame sample offsets (with and without the promise that they are multiples of four)"""
     bpf = int(rng.choice([1, 2, 7, 8, 100, 500, 501, 512]))
-    bl = 20 if rng.random() < 0.8 else int(rng.choice([7, 19, 33]))
+    bl = 20 if rng.random() < 0.6 else int(rng.choice([7, 19, 33, 10, 40, 10, 40]))   # (10 and 40: the single-pass encoders' table forms since round 6)
     p = x3hip.Params.make(bl, bpf)
     spf = bl * bpf
     n_clips = int(rng.integers(1, 12))
