@@ -1,4 +1,5 @@
-// x3_encode_stream2_kernel.h -- single-pass frame encoder for block_len = 20, second generation.
+// x3_encode_stream2_kernel.h -- single-pass frame encoder for block_len = 20 (and, round 6, 10 and 40: template parameter BL),
+// second generation.
 //
 // Same single pass as round 1's first-generation kernel (retired in round 4; persistent co-resident grid, frame f = blockIdx.x + k*G, stream
 // offsets from the frame sizes every workgroup publishes as {epoch:12 | bytes:20} words -- no prefix chain, HBM

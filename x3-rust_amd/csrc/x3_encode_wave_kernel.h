@@ -1,4 +1,5 @@
-// x3_encode_wave_kernel.h -- single-pass frame encoder for block_len = 20, third generation: ONE WAVE PER FRAME.
+// x3_encode_wave_kernel.h -- single-pass frame encoder for block_len = 20 (and, round 6, 10 and 40: template parameter BL),
+// third generation: ONE WAVE PER FRAME.
 //
 // Replaces encoder::encode / encode_frame / x3_encode_block / encode_rice_block / encode_bfp_block / encode_literal
 // (src/encoder.rs:51-315), BitPacker (src/bitpacker.rs:46-177) and the running crc16 (src/crc.rs:44-58).
