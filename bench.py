@@ -279,14 +279,19 @@ def main():
         cand_out, cand_back, pads = [out], [back], []
         for k in range(args.place - 1):
             # (odd-sized allocations between the candidates: so that they do not all lie alike)
-            pads.append(torch.empty((k + 1) * 1237 * 1024, dtype=torch.uint8, device=dev))
-            cand_out.append(torch.empty(cap + 16, dtype=torch.uint8, device=dev))
-            cand_back.append(torch.empty(n, dtype=torch.int16, device=dev))
+            try:
+                pads.append(torch.empty((k + 1) * 1237 * 1024, dtype=torch.uint8, device=dev))
+                o_k = torch.empty(cap + 16, dtype=torch.uint8, device=dev)
+                b_k = torch.empty(n, dtype=torch.int16, device=dev)
+            except RuntimeError:   # (a GPU that has no room for more candidates: the probe makes do with what it has)
+                break
+            cand_out.append(o_k)
+            cand_back.append(b_k)
         ms = x3hip.place_buffers(ctx, p, wav.data_ptr(), n, [t.data_ptr() for t in cand_out], cap, off.data_ptr(),
                                  [t.data_ptr() for t in cand_back])
-        flat = [(ms[i][j], i, j) for i in range(args.place) for j in range(args.place)]
+        flat = [(ms[i][j], i, j) for i in range(len(cand_out)) for j in range(len(cand_back))]
         best = min(flat)
-        placement = {"candidates_per_buffer": args.place, "probe": "4 untimed + 8 timed round trips per pair, host wall time",
+        placement = {"candidates_per_buffer": len(cand_out), "probe": "4 untimed + 8 timed round trips per pair, host wall time",
                      "step_ms": {"first_allocation": round(ms[0][0], 4), "best": round(best[0], 4), "worst": round(max(flat)[0], 4)},
                      "kept": {"stream": best[1], "samples": best[2]},
                      "ms_per_step": [[round(v, 4) for v in row] for row in ms],
